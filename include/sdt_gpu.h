@@ -1,0 +1,136 @@
+/*
+ * sdt_gpu.h -- C ABI of libsdt_gpu.so: the MI355X (gfx950) implementation of SOAPdenovo-Trans's
+ * `pregraph` hashing path (read chopping -> canonical k-mer -> hash insert/count -> -d filter ->
+ * linear marking + k-mer frequency histogram -> node export).
+ *
+ * The reference has no FFI layer: the path sits behind the C functions that call_pregraph() calls
+ * (inc/extfunc.h:82,156-163) with state in globals.  Each entry point below names the reference
+ * function / call site it replaces (paths relative to /root/reference/src).  A host written in C
+ * (soapdenovo-trans_amd/csrc/host/pregraph_main.c), Python/ctypes (soapdenovo-trans_amd/__init__.py)
+ * or the reference's own prlHashReads.c binds exactly these symbols.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative SDT_E* code and
+ * leaves a message retrievable by sdt_gpu_last_error(); no exceptions cross the boundary; one host
+ * thread per context; a context owns one GPU.  There is NO CPU fallback: without a usable gfx950
+ * device sdt_gpu_init fails with SDT_ENODEV.
+ *
+ * Packed reads ("2-bit stream"): all reads of a batch concatenated, 2 bits per base with the
+ * reference's coding A=0 C=1 T=2 G=3 (inc/def.h:39-42), 16 bases per little-endian uint32 word, FIRST
+ * base in the MOST significant bit pair (so a k-mer is a funnel shift of consecutive words and equals
+ * the reference's Kmer value, inc/def.h:45-59).  read i occupies bases [offsets[i], offsets[i+1]).
+ * The word array must be readable for 4 words past the last base (pad with zeros).
+ */
+#ifndef SDT_GPU_H
+#define SDT_GPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDT_ABI_VERSION 1
+
+enum {
+	SDT_OK       = 0,
+	SDT_EINVAL   = -1,   /* bad argument */
+	SDT_ENODEV   = -2,   /* no gfx950 device / HIP runtime error at init */
+	SDT_ENOMEM   = -3,   /* device or host allocation failed */
+	SDT_EHIP     = -4,   /* HIP runtime error (message in sdt_gpu_last_error) */
+	SDT_EFULL    = -5,   /* node table cannot grow any further */
+	SDT_ESTATE   = -6    /* call out of order (e.g. export before finish) */
+};
+
+typedef struct sdt_ctx sdt_ctx;
+
+/* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
+ * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
+ * prev/next the neighbour base codes 0..3 or SDT_REC_NB_NONE (prlHashReads.c:215-230,275-308). */
+#define SDT_REC_NB_NONE 4
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* Replaces the allocation half of prlRead2HashTable (prlHashReads.c:355,402-423: createFilter +
+ * init_kmerset x thrd_num).  K = overlaplen after call_pregraph's clamp (pregraph.c:38-59): odd, 13..127.
+ * est_distinct sizes the device node table (it grows by rebuild when needed, the analogue of
+ * encap_kmerset, newhash.c:293-409); 0 = default.  device = HIP device ordinal. */
+int sdt_gpu_init(sdt_ctx **ctx, int device, int K, uint64_t est_distinct, uint32_t flags);
+int sdt_gpu_destroy(sdt_ctx *ctx);                 /* free_Sets (pregraph.c:107) */
+const char *sdt_gpu_last_error(void);
+int sdt_gpu_abi_version(void);
+
+/* forget all nodes, keep allocations (a fresh prlRead2HashTable run on the same context) */
+int sdt_gpu_reset(sdt_ctx *ctx);
+
+/* ---- pass 1: chop + insert/count ------------------------------------------------------------- */
+
+/* Replaces one `sendWorkSignal(2); sendWorkSignal(1);` pair (prlHashReads.c:523-526,600-606,615-620):
+ * chopKmer4read over every read of the batch (:164-310) and put_kmerset of every record
+ * (newhash.c:411-462).  Host buffers; the call stages them to the device asynchronously (double
+ * buffered) and returns once the buffers may be reused.  Reads shorter than K+1 are skipped (:592). */
+int sdt_gpu_push_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords,
+                       const uint64_t *offsets, uint64_t nreads);
+
+/* Same, for a batch that is already resident in device memory (device pointers; the bench and the
+ * multi-GPU driver use this).  Asynchronous on the context's stream.  max_read_len bounds the longest
+ * read of the batch (the reference's maxReadLen, prlHashReads.c:358-366); it sizes the LDS tile. */
+int sdt_gpu_count_reads_device(sdt_ctx *ctx, const void *d_packed_words, uint64_t nwords,
+                               const void *d_offsets, uint64_t nreads, uint64_t max_read_len);
+
+/* Drain: all pushed batches are in the table on return (end of the read loop, prlHashReads.c:615-623).
+ * Outputs (may be NULL): k-mer occurrences processed ("kmer in reads", :662) and distinct nodes
+ * ("nodes allocated" = sum of count_kmerset, :655-662). */
+int sdt_gpu_finish_count(sdt_ctx *ctx, uint64_t *kmers_processed, uint64_t *nodes);
+
+/* ---- multi-GPU: owner-computes sharding -------------------------------------------------------
+ * The reference partitions records over threads by hash_kmer % thrd_num (prlHashReads.c:81).  Across
+ * GPUs the owner of a canonical k-mer is sdt_owner_of(key) % nranks (a mixed hash: canonical prefixes
+ * are skewed).  extract_route chops the batch and writes 16-byte records grouped by owner rank into
+ * d_records (capacity max_records, split in nranks equal slices), with counts[r] / displs[r] (device
+ * uint64[nranks], in records) describing each rank's slice: the send buffer of an all-to-all(v).
+ * A slice overflow is reported by the next sdt_gpu_finish_count as SDT_EFULL.
+ * insert_records consumes received records. */
+int sdt_gpu_extract_route(sdt_ctx *ctx, const void *d_packed_words, uint64_t nwords,
+                          const void *d_offsets, uint64_t nreads, uint64_t max_read_len, int nranks,
+                          void *d_records, uint64_t max_records,
+                          void *d_counts, void *d_displs);
+int sdt_gpu_insert_records(sdt_ctx *ctx, const void *d_records, uint64_t nrecords);
+/* bytes per routed record for this context's key width */
+int sdt_gpu_record_bytes(const sdt_ctx *ctx);
+
+/* ---- table scans ------------------------------------------------------------------------------ */
+
+/* deLowCov / thread_delow (prlHashReads.c:844-909), `-d d`: zero links with 0 < v <= d, mark nodes
+ * left without links deleted.  *removed = "%lld kmer removed". */
+int sdt_gpu_delow(sdt_ctx *ctx, int d, uint64_t *removed);
+
+/* Mark1in1outNode / thread_mark (prlHashReads.c:911-992): set `linear`, fill the 257-bin histogram
+ * that freqStat (:994-1023) prints bins 1..255 of.  *linear = "%lld linear nodes". */
+int sdt_gpu_mark_and_hist(sdt_ctx *ctx, int64_t hist[257], uint64_t *linear);
+
+/* ---- hand the node table back to host graph phases (cutTipPreGraph.c, node2edge.c) ------------
+ * Copies every node to caller-owned host arrays of capacity max_nodes (order unspecified):
+ *   keys     : key_words() uint64 per node, MOST significant word first (the reference Kmer struct order)
+ *   l_links  : kmer_t.l_links (4 x 6-bit, inc/newhash.h:38-43)
+ *   r_flags  : the second 32-bit word of kmer_t (inc/newhash.h:69-75): r_links:24 | linear<<24 |
+ *              deleted<<25 | checked<<26 | single<<27 | twin<<28 | inEdge<<30
+ *   count    : kmer_t.count
+ * Any array may be NULL.  *n receives the node count. */
+int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags,
+                         uint32_t *count, uint64_t max_nodes, uint64_t *n);
+
+/* ---- introspection / measurement --------------------------------------------------------------- */
+int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */
+uint64_t sdt_gpu_table_slots(const sdt_ctx *ctx);
+void *sdt_gpu_stream(const sdt_ctx *ctx);          /* hipStream_t the kernels are launched on */
+/* HIP-event timing of the dominant (chop+insert) kernel accumulated since the last call with reset!=0:
+ * total milliseconds, number of launches, k-mer occurrences those launches processed. */
+int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches, uint64_t *kmers);
+/* the hash used for sharding (host-callable, identical to the device function):
+ * owner rank = ((sdt_owner_hash(key) >> 32) * nranks) >> 32 */
+uint64_t sdt_owner_hash(const uint64_t *key_words_msw_first, int nwords);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""soapdenovo-trans_amd -- MI355X-native `pregraph` hashing path of SOAPdenovo-Trans.
+
+The product is ``csrc/libsdt_gpu.so`` (hand-written HIP for gfx950 behind the C ABI declared in
+``include/sdt_gpu.h``) plus the C host ``csrc/host`` that keeps the reference's
+``pregraph -s cfg -K k -o out`` command line.  This Python package is the thin host-side mirror used by
+tests and bench.py: it loads the shared library with ctypes and exposes one class whose methods have
+the names and argument meaning of the C ABI.  There is no CPU fallback here: if the library is missing
+or no gfx950 device is present the calls raise.
+
+The directory name contains a hyphen, so import it through ``__graft_entry__.load_package()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
+REPO_ROOT = os.path.dirname(PKG_DIR)
+
+SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
+_c = ctypes
+_ABI = [
+    ("sdt_gpu_init", _c.c_int, [_c.POINTER(_c.c_void_p), _c.c_int, _c.c_int, _c.c_uint64, _c.c_uint32]),
+    ("sdt_gpu_destroy", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_last_error", _c.c_char_p, []),
+    ("sdt_gpu_abi_version", _c.c_int, []),
+    ("sdt_gpu_reset", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_push_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_count_reads_device", _c.c_int,
+     [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_extract_route", _c.c_int,
+     [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_void_p,
+      _c.c_uint64, _c.c_void_p, _c.c_void_p]),
+    ("sdt_gpu_insert_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_record_bytes", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_mark_and_hist", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_export_nodes", _c.c_int,
+     [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
+    ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),
+    ("sdt_gpu_kernel_time", _c.c_int,
+     [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_owner_hash", _c.c_uint64, [_c.c_void_p, _c.c_int]),
+]
+ABI_SYMBOLS = [n for n, _, _ in _ABI]
+
+_lib = None
+
+
+class SdtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsdt_gpu error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU). Returns the library path."""
+    cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen libsdt_gpu.so and bind every ABI symbol. Fails loudly when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the pregraph hashing path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in _ABI:
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """host numpy array or torch tensor (host or device) or int -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return ctypes.c_void_p(a.ctypes.data)
+    return ctypes.c_void_p(a.data_ptr())  # torch tensor
+
+
+def key_words_for(K: int) -> int:
+    return 1 if K <= 31 else (2 if K <= 63 else 4)
+
+
+def clamp_K(K: int, max_k: int = 127) -> int:
+    """call_pregraph's K handling (pregraph.c:38-59): even -> +1, < 13 -> 13, > max -> max."""
+    if K % 2 == 0:
+        K += 1
+    if K < 13:
+        K = 13
+    elif K > max_k:
+        K = max_k
+    return K
+
+
+class PregraphGPU:
+    """One device context: mirrors sdt_gpu_* one to one (see include/sdt_gpu.h for the reference
+    call sites each method replaces)."""
+
+    def __init__(self, K: int, est_distinct: int = 0, device: int = 0):
+        self.lib = load_library()
+        self.K = K
+        self._ctx = ctypes.c_void_p()
+        rc = self.lib.sdt_gpu_init(ctypes.byref(self._ctx), device, K, est_distinct, 0)
+        self._check(rc)
+        self.nw = self.lib.sdt_gpu_key_words(self._ctx)
+
+    def _check(self, rc):
+        if rc != SDT_OK:
+            raise SdtError(rc, self.lib.sdt_gpu_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.sdt_gpu_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- pass 1
+    def reset(self):
+        self._check(self.lib.sdt_gpu_reset(self._ctx))
+
+    def push_reads(self, packed_words: np.ndarray, offsets: np.ndarray):
+        packed_words = np.ascontiguousarray(packed_words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_push_reads(self._ctx, _ptr(packed_words), packed_words.size,
+                                                _ptr(offsets), offsets.size - 1))
+
+    def count_reads_device(self, d_words, nwords: int, d_offsets, nreads: int, max_read_len: int):
+        self._check(self.lib.sdt_gpu_count_reads_device(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets),
+                                                        nreads, max_read_len))
+
+    def finish_count(self):
+        k, n = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_finish_count(self._ctx, ctypes.byref(k), ctypes.byref(n)))
+        return k.value, n.value
+
+    # -- sharding
+    def record_bytes(self) -> int:
+        return self.lib.sdt_gpu_record_bytes(self._ctx)
+
+    def extract_route(self, d_words, nwords, d_offsets, nreads, max_read_len, nranks, d_records, max_records,
+                      d_counts, d_displs):
+        self._check(self.lib.sdt_gpu_extract_route(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets), nreads,
+                                                   max_read_len, nranks, _ptr(d_records), max_records,
+                                                   _ptr(d_counts), _ptr(d_displs)))
+
+    def insert_records(self, d_records, nrecords: int):
+        self._check(self.lib.sdt_gpu_insert_records(self._ctx, _ptr(d_records), nrecords))
+
+    # -- scans
+    def delow(self, d: int) -> int:
+        r = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_delow(self._ctx, d, ctypes.byref(r)))
+        return r.value
+
+    def mark_and_hist(self):
+        hist = np.zeros(257, dtype=np.int64)
+        lin = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_mark_and_hist(self._ctx, _ptr(hist), ctypes.byref(lin)))
+        return hist, lin.value
+
+    def export_nodes(self):
+        n = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_export_nodes(self._ctx, None, None, None, None, 0, ctypes.byref(n)))
+        m = max(n.value, 1)
+        keys = np.zeros((m, self.nw), dtype=np.uint64)
+        l_links = np.zeros(m, dtype=np.uint32)
+        r_flags = np.zeros(m, dtype=np.uint32)
+        count = np.zeros(m, dtype=np.uint32)
+        self._check(self.lib.sdt_gpu_export_nodes(self._ctx, _ptr(keys), _ptr(l_links), _ptr(r_flags),
+                                                  _ptr(count), m, ctypes.byref(n)))
+        k = n.value
+        return keys[:k], l_links[:k], r_flags[:k], count[:k]
+
+    # -- introspection
+    def table_slots(self) -> int:
+        return self.lib.sdt_gpu_table_slots(self._ctx)
+
+    def stream(self) -> int:
+        return self.lib.sdt_gpu_stream(self._ctx) or 0
+
+    def kernel_time(self, reset: bool = True):
+        ms, launches, kmers = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_kernel_time(self._ctx, int(reset), ctypes.byref(ms), ctypes.byref(launches),
+                                                 ctypes.byref(kmers)))
+        return ms.value, launches.value, kmers.value
+
+
+def write_kmerfreq(path: str, hist) -> None:
+    """freqStat (prlHashReads.c:994-1023): bins 1..255, one "%lld\\n" per line."""
+    with open(path, "w") as fo:
+        for i in range(1, 256):
+            fo.write(f"{int(hist[i])}\n")
+
+
+def kmerfreq_text(hist) -> str:
+    return "".join(f"{int(hist[i])}\n" for i in range(1, 256))

@@ -1,0 +1,1030 @@
+// sdt_gpu.hip -- kernels + C ABI (include/sdt_gpu.h) of the MI355X-native pregraph hashing path.
+//
+// gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
+//
+// Kernels (all integer / HBM-bound, no MFMA):
+//   k_count_reads<NW>     chopKmer4read (prlHashReads.c:164-310) fused with put_kmerset
+//                         (newhash.c:411-462): a workgroup stages a tile of packed reads in LDS with
+//                         coalesced loads, every lane cuts its k-mers out of LDS by funnel shift and
+//                         updates the node table with one 64-bit atomic per occurrence.
+//   k_extract_route<NW>   same chop, but records go to per-owner-rank slices (send side of the
+//                         all-to-all that replaces `hash_kmer % thrd_num`, prlHashReads.c:81)
+//   k_insert_records<NW>  put_kmerset for received records
+//   k_delow<NW>           thread_delow   (prlHashReads.c:844-887)
+//   k_mark_hist<NW>       thread_mark    (prlHashReads.c:911-967) + per-thread kmerFreq bins
+//   k_export<NW>          compaction of the table into kmer_t-shaped arrays (inc/newhash.h:65-77)
+//   k_rehash<NW>          table growth (the analogue of encap_kmerset, newhash.c:293-409)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+#include <new>
+
+#include "../../include/sdt_gpu.h"
+#include "sdt_kmer.cuh"
+#include "sdt_table.cuh"
+
+using namespace sdt;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+	do {                                                                                              \
+		hipError_t e_ = (expr);                                                                       \
+		if (e_ != hipSuccess)                                                                         \
+			return fail(e_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)",   \
+			            #expr, hipGetErrorString(e_), __FILE__, __LINE__);                            \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int TPB = 256;           // 4 waves
+constexpr int TILE_READS = 64;     // reads staged per workgroup tile
+constexpr int TAIL_PAD = 4;        // readable words past the last base of a tile
+
+// Stage reads [r0, r1) of the batch in LDS.  Returns the tile's k-mer count; fills
+//   s_words : LDS_LEAD lead words, then the packed words that hold bases [off[r0], off[r1])
+//   s_rb[i] : stream base index of read r0+i relative to the first staged word (i = 0..nr)
+//   s_pre[i]: exclusive prefix sum of k-mers per read (i = 0..nr)
+struct TileView {
+	const uint32_t *words;  // points at the first staged word (after the lead)
+	const uint32_t *rb;
+	const uint32_t *pre;
+	int nr;
+	uint32_t nk;
+};
+
+__device__ inline TileView stage_tile(uint32_t *smem, int max_tile_words, const uint32_t *__restrict__ packed,
+                                      const uint64_t *__restrict__ offs, uint64_t r0, uint64_t nreads, int K)
+{
+	uint32_t *s_rb = smem;                           // TILE_READS + 1
+	uint32_t *s_pre = smem + (TILE_READS + 1);       // TILE_READS + 1
+	uint32_t *s_words = smem + 2 * (TILE_READS + 1) + 2;   // keep 16-byte alignment irrelevant: b32 reads
+	const int tid = threadIdx.x;
+	const int nr = (int)((nreads - r0) < (uint64_t)TILE_READS ? (nreads - r0) : (uint64_t)TILE_READS);
+	const uint64_t base0 = offs[r0];
+	const uint64_t word0 = base0 >> 4;
+	const uint64_t base_end = offs[r0 + nr];
+	const uint64_t word_end = (base_end + 15) >> 4;
+	int nwords = (int)(word_end - word0) + TAIL_PAD;
+	if (nwords > max_tile_words)
+		nwords = max_tile_words;                     // cannot happen when max_read_len was honoured
+	// per-read geometry
+	if (tid <= nr) {
+		const uint64_t o = offs[r0 + tid];
+		s_rb[tid] = (uint32_t)(o - (word0 << 4));
+		uint32_t nk = 0;
+		if (tid < nr) {
+			const uint64_t len = offs[r0 + tid + 1] - o;
+			nk = len >= (uint64_t)(K + 1) ? (uint32_t)(len - K + 1) : 0u;    // prlHashReads.c:592
+		}
+		s_pre[tid] = nk;
+	}
+	// coalesced copy of the packed words (zero lead: its content is masked off anyway)
+	if (tid < LDS_LEAD)
+		s_words[tid] = 0;
+	for (int i = tid; i < nwords; i += TPB)
+		s_words[LDS_LEAD + i] = packed[word0 + i];
+	__syncthreads();
+	// exclusive scan of <= 65 values by one wave (two values per lane)
+	if (tid < 64) {
+		uint32_t a = tid < nr ? s_pre[tid] : 0u;
+		uint32_t x = a;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t y = __shfl_up(x, d);
+			if (tid >= d)
+				x += y;
+		}
+		s_pre[tid] = x - a;
+		if (tid == 63)
+			s_pre[64] = x;
+	}
+	__syncthreads();
+	TileView tv;
+	tv.words = s_words + LDS_LEAD;
+	tv.rb = s_rb;
+	tv.pre = s_pre;
+	tv.nr = nr;
+	tv.nk = s_pre[64];
+	return tv;
+}
+
+// find the read that owns k-mer q of the tile: largest i with pre[i] <= q (reads with 0 k-mers are skipped
+// automatically because their interval is empty)
+__device__ inline int tile_find_read(const uint32_t *pre, uint32_t q)
+{
+	int lo = 0, hi = TILE_READS;                     // pre[64] = total > q
+#pragma unroll
+	for (int s = 0; s < 6; s++) {
+		const int mid = (lo + hi) >> 1;
+		if (pre[mid] <= q) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+static_assert(TILE_READS == 64, "the scan and the binary search assume 64 reads per tile");
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict__ packed,
+                                                     const uint64_t *__restrict__ offs, uint64_t nreads, int K,
+                                                     int max_tile_words, Table<NW> tbl, Stats *stats)
+{
+	extern __shared__ uint32_t smem[];
+	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	uint32_t claimed = 0, failed = 0, done = 0;
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
+		for (uint32_t q = threadIdx.x; q < tv.nk; q += TPB) {
+			const int r = tile_find_read(tv.pre, q);
+			const int j = (int)(q - tv.pre[r]);
+			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
+			uint32_t prev, next;
+			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
+			if (!table_put<NW>(tbl, key, prev, next, claimed))
+				failed++;
+			done++;
+		}
+		__syncthreads();                             // tile buffer is reused
+	}
+	// per-wave reduction of the counters, one atomic per wave
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		claimed += __shfl_down(claimed, d);
+		failed += __shfl_down(failed, d);
+		done += __shfl_down(done, d);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (done) atomicAdd(&stats->kmers, (unsigned long long)done);
+		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+	}
+}
+
+// routed record: NW key words (most significant first) + one meta word (prev | next << 3)
+template <int NW> struct Record {
+	uint64_t key[NW];
+	uint64_t meta;
+};
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_extract_route(const uint32_t *__restrict__ packed,
+                                                       const uint64_t *__restrict__ offs, uint64_t nreads, int K,
+                                                       int max_tile_words, int nranks, Record<NW> *__restrict__ out,
+                                                       const unsigned long long *__restrict__ displs,
+                                                       unsigned long long *__restrict__ cursors,
+                                                       unsigned long long cap_per_rank, Stats *stats)
+{
+	extern __shared__ uint32_t smem[];
+	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	uint32_t failed = 0;
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
+		const uint32_t rounds = (tv.nk + TPB - 1) / TPB;
+		for (uint32_t it = 0; it < rounds; it++) {
+			const uint32_t q = it * TPB + threadIdx.x;
+			const bool live = q < tv.nk;
+			Key<NW> key;
+			uint32_t prev = 4, next = 4;
+			int owner = -1;
+			if (live) {
+				const int r = tile_find_read(tv.pre, q);
+				const int j = (int)(q - tv.pre[r]);
+				const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
+				key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
+				owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
+			}
+			// wave-aggregated slot reservation: one atomic per (wave, owner) instead of one per record
+			const int lane = threadIdx.x & 63;
+			for (int rk = 0; rk < nranks; rk++) {
+				const unsigned long long m = __ballot(owner == rk);
+				if (m == 0)
+					continue;
+				const int leader = __ffsll((long long)m) - 1;
+				unsigned long long base = 0;
+				if (lane == leader)
+					base = atomicAdd(&cursors[rk], (unsigned long long)__popcll(m));
+				base = __shfl(base, leader);
+				if (owner == rk) {
+					const unsigned long long pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
+					if (pos < cap_per_rank) {
+						Record<NW> rec;
+#pragma unroll
+						for (int i = 0; i < NW; i++)
+							rec.key[i] = key.w[i];
+						rec.meta = (uint64_t)prev | ((uint64_t)next << 3);
+						out[displs[rk] + pos] = rec;
+					} else {
+						failed++;
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_insert_records(const Record<NW> *__restrict__ recs, uint64_t n,
+                                                        Table<NW> tbl, Stats *stats)
+{
+	uint32_t claimed = 0, failed = 0, done = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		const Record<NW> rec = recs[i];
+		Key<NW> key;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			key.w[w] = rec.key[w];
+		if (!table_put<NW>(tbl, key, (uint32_t)(rec.meta & 7u), (uint32_t)((rec.meta >> 3) & 7u), claimed))
+			failed++;
+		done++;
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		claimed += __shfl_down(claimed, d);
+		failed += __shfl_down(failed, d);
+		done += __shfl_down(done, d);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (done) atomicAdd(&stats->kmers, (unsigned long long)done);
+		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+	}
+}
+
+template <int NW> __global__ __launch_bounds__(TPB) void k_clear(Table<NW> tbl)
+{
+	const uint64_t slots = tbl.mask + 1;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		Entry<NW> e;
+#pragma unroll
+		for (int i = 0; i < NW; i++)
+			e.key[i] = KEY_EMPTY;
+		e.val = 0;
+		tbl.ent[s] = e;
+		tbl.aux[s] = 0;
+	}
+}
+
+// thread_delow (prlHashReads.c:844-887)
+template <int NW> __global__ __launch_bounds__(TPB) void k_delow(Table<NW> tbl, uint32_t d, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	uint32_t removed = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY)
+			continue;
+		uint64_t v = tbl.ent[s].val;
+		uint64_t nv = v;
+#pragma unroll
+		for (int f = 0; f < 8; f++) {
+			const uint32_t c = (uint32_t)(v >> (6 * f)) & 63u;
+			if (c > 0 && c <= d)
+				nv &= ~(63ULL << (6 * f));
+		}
+		if (nv != v)
+			tbl.ent[s].val = nv;
+		if ((nv & 0xFFFFFFFFFFFFULL) == 0) {         // l_links == 0 && r_links == 0
+			tbl.aux[s] |= AUX_DELETED;
+			removed++;
+		}
+	}
+#pragma unroll
+	for (int dd = 32; dd > 0; dd >>= 1)
+		removed += __shfl_down(removed, dd);
+	if ((threadIdx.x & 63) == 0 && removed)
+		atomicAdd(&stats->scratch, (unsigned long long)removed);
+}
+
+// thread_mark (prlHashReads.c:911-967): bins in LDS per workgroup, flushed once
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_mark_hist(Table<NW> tbl, unsigned long long *__restrict__ hist, Stats *stats)
+{
+	__shared__ uint32_t s_hist[257];
+	for (int i = threadIdx.x; i < 257; i += TPB)
+		s_hist[i] = 0;
+	__syncthreads();
+	const uint64_t slots = tbl.mask + 1;
+	uint32_t linear = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY)
+			continue;
+		const uint64_t v = tbl.ent[s].val;
+		const uint32_t aux = tbl.aux[s];
+		uint32_t in_num = 0, out_num = 0, l_cvg = 0, r_cvg = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const uint32_t l = (uint32_t)(v >> (6 * b)) & 63u, r = (uint32_t)(v >> (24 + 6 * b)) & 63u;
+			in_num += l > 0; l_cvg += l;
+			out_num += r > 0; r_cvg += r;
+		}
+		const uint32_t count = ((aux & 0xFFFFu) << 16) | (uint32_t)(v >> 48);
+		const uint32_t bin = count == 1 ? 1u : (l_cvg > r_cvg ? l_cvg : r_cvg);   // single <=> count == 1
+		atomicAdd(&s_hist[bin], 1u);
+		if (in_num == 1 && out_num == 1) {
+			tbl.aux[s] = aux | AUX_LINEAR;
+			linear++;
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < 257; i += TPB)
+		if (s_hist[i])
+			atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
+#pragma unroll
+	for (int dd = 32; dd > 0; dd >>= 1)
+		linear += __shfl_down(linear, dd);
+	if ((threadIdx.x & 63) == 0 && linear)
+		atomicAdd(&stats->scratch, (unsigned long long)linear);
+}
+
+// compaction into kmer_t-shaped arrays (inc/newhash.h:65-77); order = arrival order of the cursor
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_export(Table<NW> tbl, uint64_t *__restrict__ keys, uint32_t *__restrict__ l_links,
+                                                uint32_t *__restrict__ r_flags, uint32_t *__restrict__ count,
+                                                unsigned long long max_nodes, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY)
+			continue;
+		const unsigned long long pos = atomicAdd(&stats->scratch, 1ULL);   // hipcc aggregates this per wave
+		if (pos >= max_nodes)
+			continue;
+		const uint32_t aux = tbl.aux[s];
+		const uint32_t cnt = ((aux & 0xFFFFu) << 16) | (uint32_t)(e.val >> 48);
+		if (keys) {
+#pragma unroll
+			for (int i = 0; i < NW; i++)
+				keys[pos * NW + i] = e.key[i];
+		}
+		if (l_links) l_links[pos] = (uint32_t)(e.val & 0xFFFFFFu);
+		if (r_flags)
+			r_flags[pos] = (uint32_t)((e.val >> 24) & 0xFFFFFFu) | ((aux & AUX_LINEAR) ? 1u << 24 : 0u) |
+			               ((aux & AUX_DELETED) ? 1u << 25 : 0u) | (cnt == 1 ? 1u << 27 : 0u);
+		if (count) count[pos] = cnt;
+	}
+}
+
+// growth: move every node of `src` into the (empty, larger) table `dst`; keys are unique so a claim is
+// a plain CAS on the first word and the payload is copied, not re-counted
+template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src, Table<NW> dst, Stats *stats)
+{
+	const uint64_t slots = src.mask + 1;
+	uint32_t failed = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = src.ent[s];
+		if (e.key[0] == KEY_EMPTY)
+			continue;
+		Key<NW> key;
+#pragma unroll
+		for (int i = 0; i < NW; i++)
+			key.w[i] = e.key[i];
+		uint64_t slot = key_hash<NW>(key) & dst.mask;
+		bool placed = false;
+		for (uint64_t probe = 0; probe <= dst.mask; probe++) {
+			const uint64_t old = atomicCAS((unsigned long long *)&dst.ent[slot].key[0], (unsigned long long)KEY_EMPTY,
+			                               (unsigned long long)e.key[0]);
+			if (old == KEY_EMPTY) {
+#pragma unroll
+				for (int i = 1; i < NW; i++)
+					dst.ent[slot].key[i] = e.key[i];
+				dst.ent[slot].val = e.val;
+				dst.aux[slot] = src.aux[s];
+				placed = true;
+				break;
+			}
+			slot = (slot + 1) & dst.mask;
+		}
+		if (!placed)
+			failed++;
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct EventPair {
+	hipEvent_t a, b;
+	uint64_t kmers;
+};
+
+struct sdt_ctx {
+	int device = 0;
+	int K = 0;
+	int nw = 1;
+	uint64_t slots = 0;
+	void *d_ent = nullptr;
+	uint32_t *d_aux = nullptr;
+	Stats *d_stats = nullptr;
+	Stats *h_stats = nullptr;          // pinned
+	unsigned long long *d_hist = nullptr;
+	hipStream_t stream = nullptr, copy_stream = nullptr;
+	// host-batch staging (double buffered)
+	uint32_t *d_words[2] = {nullptr, nullptr};
+	uint64_t *d_offs[2] = {nullptr, nullptr};
+	uint64_t cap_words[2] = {0, 0}, cap_offs[2] = {0, 0};
+	hipEvent_t buf_free[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+	int next_buf = 0;
+	// bookkeeping for growth: upper bound of distinct nodes without syncing
+	uint64_t distinct_known = 0;       // as of the last sync
+	uint64_t kmers_since_sync = 0;     // launched since then
+	uint64_t kmers_total_host = 0;
+	// route scratch
+	unsigned long long *d_cursors = nullptr;
+	// timing
+	std::vector<EventPair> ev;
+	size_t ev_used = 0;
+	int cu_count = 256;
+};
+
+static const double MAX_LOAD = 0.70;
+
+template <int NW> static Table<NW> table_of(const sdt_ctx *c)
+{
+	Table<NW> t;
+	t.ent = (Entry<NW> *)c->d_ent;
+	t.aux = c->d_aux;
+	t.mask = c->slots - 1;
+	return t;
+}
+
+static size_t entry_bytes(int nw) { return nw == 1 ? sizeof(Entry<1>) : nw == 2 ? sizeof(Entry<2>) : sizeof(Entry<4>); }
+
+static int scan_grid(const sdt_ctx *c, uint64_t items)
+{
+	uint64_t blocks = (items + TPB - 1) / TPB;
+	const uint64_t cap = (uint64_t)c->cu_count * 8;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+static int launch_clear(sdt_ctx *c, void *ent, uint32_t *aux, uint64_t slots)
+{
+	const int g = scan_grid(c, slots);
+	if (c->nw == 1) { Table<1> t{(Entry<1> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<1>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else if (c->nw == 2) { Table<2> t{(Entry<2> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<2>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else { Table<4> t{(Entry<4> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<4>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux)
+{
+	hipError_t e = hipMalloc(ent, slots * entry_bytes(c->nw));
+	if (e != hipSuccess)
+		return fail(SDT_ENOMEM, "node table: hipMalloc(%llu slots x %zu B) failed: %s", (unsigned long long)slots,
+		            entry_bytes(c->nw), hipGetErrorString(e));
+	e = hipMalloc((void **)aux, slots * sizeof(uint32_t));
+	if (e != hipSuccess) {
+		(void)hipFree(*ent);
+		*ent = nullptr;
+		return fail(SDT_ENOMEM, "node table aux: hipMalloc failed: %s", hipGetErrorString(e));
+	}
+	return SDT_OK;
+}
+
+static int sync_stats(sdt_ctx *c)
+{
+	HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->h_stats->probe_fail)
+		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full or route bucket overflow)",
+		            (unsigned long long)c->h_stats->probe_fail);
+	c->distinct_known = c->h_stats->distinct;
+	c->kmers_since_sync = 0;
+	return SDT_OK;
+}
+
+static int grow_table(sdt_ctx *c, uint64_t need_nodes)
+{
+	uint64_t slots = c->slots;
+	while ((double)slots * MAX_LOAD < (double)need_nodes)
+		slots <<= 1;
+	void *ent = nullptr;
+	uint32_t *aux = nullptr;
+	int rc = alloc_table(c, slots, &ent, &aux);
+	if (rc != SDT_OK)
+		return fail(SDT_EFULL, "cannot grow node table to %llu slots: %s", (unsigned long long)slots, g_err);
+	rc = launch_clear(c, ent, aux, slots);
+	if (rc != SDT_OK)
+		return rc;
+	const int g = scan_grid(c, c->slots);
+	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d, c->d_stats); }
+	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d, c->d_stats); }
+	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d, c->d_stats); }
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipFree(c->d_ent));
+	HIPCHK(hipFree(c->d_aux));
+	c->d_ent = ent;
+	c->d_aux = aux;
+	c->slots = slots;
+	return SDT_OK;
+}
+
+// make sure `incoming` more occurrences cannot push the table past MAX_LOAD (every occurrence might
+// be a new node); syncs only when the cheap upper bound says it could
+static int ensure_room(sdt_ctx *c, uint64_t incoming)
+{
+	const double room = (double)c->slots * MAX_LOAD;
+	if ((double)(c->distinct_known + c->kmers_since_sync + incoming) <= room)
+		return SDT_OK;
+	int rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return rc;
+	if ((double)(c->distinct_known + incoming) <= room)
+		return SDT_OK;
+	return grow_table(c, c->distinct_known + incoming);
+}
+
+static EventPair *next_event(sdt_ctx *c)
+{
+	if (c->ev_used == c->ev.size()) {
+		EventPair p;
+		if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)
+			return nullptr;
+		p.kmers = 0;
+		c->ev.push_back(p);
+	}
+	return &c->ev[c->ev_used++];
+}
+
+static size_t tile_smem_bytes(int max_tile_words)
+{
+	return (size_t)(2 * (TILE_READS + 1) + 2 + LDS_LEAD + max_tile_words) * sizeof(uint32_t);
+}
+
+// the largest tile a batch can produce: TILE_READS consecutive reads; computed on the host side from the
+// maximum read length the caller promised (offsets are device resident for the device entry point)
+static int tile_words_for(uint64_t max_read_len)
+{
+	const uint64_t bases = (uint64_t)TILE_READS * max_read_len + 16;
+	return (int)((bases + 15) / 16) + TAIL_PAD + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *sdt_gpu_last_error(void) { return g_err; }
+int sdt_gpu_abi_version(void) { return SDT_ABI_VERSION; }
+
+uint64_t sdt_owner_hash(const uint64_t *key_words_msw_first, int nwords)
+{
+	if (nwords == 1) { Key<1> k{{key_words_msw_first[0]}}; return key_hash<1>(k); }
+	if (nwords == 2) { Key<2> k{{key_words_msw_first[0], key_words_msw_first[1]}}; return key_hash<2>(k); }
+	Key<4> k{{key_words_msw_first[0], key_words_msw_first[1], key_words_msw_first[2], key_words_msw_first[3]}};
+	return key_hash<4>(k);
+}
+
+int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32_t flags)
+{
+	(void)flags;
+	if (!out)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	*out = nullptr;
+	if (K < 13 || K > 127 || (K & 1) == 0)
+		return fail(SDT_EINVAL, "K must be odd and in 13..127 (got %d); apply call_pregraph's clamp first", K);
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(SDT_ENODEV, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+	if (device < 0 || device >= ndev)
+		return fail(SDT_EINVAL, "device %d out of range (have %d)", device, ndev);
+	e = hipSetDevice(device);
+	if (e != hipSuccess)
+		return fail(SDT_ENODEV, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess)
+		return fail(SDT_ENODEV, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(SDT_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+	sdt_ctx *c = new (std::nothrow) sdt_ctx();
+	if (!c)
+		return fail(SDT_ENOMEM, "out of host memory");
+	c->device = device;
+	c->K = K;
+	c->nw = K <= 31 ? 1 : (K <= 63 ? 2 : 4);
+	c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (est_distinct == 0)
+		est_distinct = 1ULL << 22;
+	uint64_t slots = 1ULL << 16;
+	while ((double)slots * 0.5 < (double)est_distinct)
+		slots <<= 1;
+	c->slots = slots;
+#define INIT_CHK(expr)                                                                    \
+	do {                                                                                  \
+		hipError_t e2_ = (expr);                                                          \
+		if (e2_ != hipSuccess) {                                                          \
+			int rc_ = fail(e2_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e2_)); \
+			sdt_gpu_destroy(c);                                                           \
+			return rc_;                                                                   \
+		}                                                                                 \
+	} while (0)
+	INIT_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	INIT_CHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) {
+		INIT_CHK(hipEventCreateWithFlags(&c->buf_free[i], hipEventDisableTiming));
+		INIT_CHK(hipEventCreateWithFlags(&c->copied[i], hipEventDisableTiming));
+	}
+	INIT_CHK(hipMalloc((void **)&c->d_stats, sizeof(Stats)));
+	INIT_CHK(hipHostMalloc((void **)&c->h_stats, sizeof(Stats), hipHostMallocDefault));
+	INIT_CHK(hipMalloc((void **)&c->d_hist, 257 * sizeof(unsigned long long)));
+	INIT_CHK(hipMalloc((void **)&c->d_cursors, 64 * sizeof(unsigned long long)));
+	int rc = alloc_table(c, c->slots, &c->d_ent, &c->d_aux);
+	if (rc != SDT_OK) {
+		sdt_gpu_destroy(c);
+		return rc;
+	}
+	rc = sdt_gpu_reset(c);
+	if (rc != SDT_OK) {
+		sdt_gpu_destroy(c);
+		return rc;
+	}
+	*out = c;
+	return SDT_OK;
+}
+
+int sdt_gpu_destroy(sdt_ctx *c)
+{
+	if (!c)
+		return SDT_OK;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+	for (auto &p : c->ev) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+	for (int i = 0; i < 2; i++) {
+		if (c->d_words[i]) (void)hipFree(c->d_words[i]);
+		if (c->d_offs[i]) (void)hipFree(c->d_offs[i]);
+		if (c->buf_free[i]) (void)hipEventDestroy(c->buf_free[i]);
+		if (c->copied[i]) (void)hipEventDestroy(c->copied[i]);
+	}
+	if (c->d_ent) (void)hipFree(c->d_ent);
+	if (c->d_aux) (void)hipFree(c->d_aux);
+	if (c->d_stats) (void)hipFree(c->d_stats);
+	if (c->h_stats) (void)hipHostFree(c->h_stats);
+	if (c->d_hist) (void)hipFree(c->d_hist);
+	if (c->d_cursors) (void)hipFree(c->d_cursors);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+	delete c;
+	return SDT_OK;
+}
+
+int sdt_gpu_reset(sdt_ctx *c)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = launch_clear(c, c->d_ent, c->d_aux, c->slots);
+	if (rc != SDT_OK)
+		return rc;
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
+	c->distinct_known = 0;
+	c->kmers_since_sync = 0;
+	c->kmers_total_host = 0;
+	return SDT_OK;
+}
+
+int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
+uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
+void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int sdt_gpu_record_bytes(const sdt_ctx *c) { return c ? (c->nw + 1) * 8 : 0; }
+
+// launch the fused chop+insert kernel on a device-resident batch, in chunks of reads small enough that
+// "every occurrence is a new node" cannot overflow the table between two looks at the node counter.
+static const uint64_t CHUNK_KMERS = 1ULL << 27;
+
+static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads,
+                        uint64_t max_read_len)
+{
+	if (nreads == 0)
+		return SDT_OK;
+	if (max_read_len < (uint64_t)c->K + 1)
+		return SDT_OK;                               // no read can hold a k-mer (prlHashReads.c:592)
+	const int mtw = tile_words_for(max_read_len);
+	const size_t smem = tile_smem_bytes(mtw);
+	if (smem > 64 * 1024)
+		return fail(SDT_EINVAL, "max read length %llu needs %zu B of LDS per tile (limit 64 KiB)",
+		            (unsigned long long)max_read_len, smem);
+	const uint64_t per_read = max_read_len - c->K + 1;
+	uint64_t chunk_reads = CHUNK_KMERS / per_read;
+	chunk_reads = chunk_reads / TILE_READS * TILE_READS;
+	if (chunk_reads < TILE_READS)
+		chunk_reads = TILE_READS;
+	for (uint64_t r0 = 0; r0 < nreads; r0 += chunk_reads) {
+		const uint64_t nr = nreads - r0 < chunk_reads ? nreads - r0 : chunk_reads;
+		const uint64_t upper = nr * per_read;
+		int rc = ensure_room(c, upper);
+		if (rc != SDT_OK)
+			return rc;
+		const uint64_t ntiles = (nr + TILE_READS - 1) / TILE_READS;
+		uint64_t grid = ntiles;
+		const uint64_t cap = (uint64_t)c->cu_count * 8;
+		if (grid > cap) grid = cap;
+		EventPair *ev = next_event(c);
+		if (!ev)
+			return fail(SDT_EHIP, "hipEventCreate failed");
+		ev->kmers = upper;
+		HIPCHK(hipEventRecord(ev->a, c->stream));
+		// offsets are absolute base indices into d_words, so a sub-range of reads is just a shifted pointer
+		if (c->nw == 1)
+			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats);
+		else if (c->nw == 2)
+			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats);
+		else
+			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(ev->b, c->stream));
+		c->kmers_since_sync += upper;
+	}
+	return SDT_OK;
+}
+
+int sdt_gpu_push_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
+                       uint64_t nreads)
+{
+	if (!c || (!packed_words && nwords) || !offsets)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (nreads == 0)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(c->device));
+	// batch geometry from the host copy of the offsets
+	uint64_t kmers = 0, maxlen = 0;
+	for (uint64_t i = 0; i < nreads; i++) {
+		if (offsets[i + 1] < offsets[i])
+			return fail(SDT_EINVAL, "offsets not monotonic at read %llu", (unsigned long long)i);
+		const uint64_t len = offsets[i + 1] - offsets[i];
+		if (len > maxlen) maxlen = len;
+		if (len >= (uint64_t)c->K + 1) kmers += len - c->K + 1;
+	}
+	if (((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
+		return fail(SDT_EINVAL, "packed_words too short: need %llu words incl. %d pad words, got %llu",
+		            (unsigned long long)(((offsets[nreads] + 15) >> 4) + TAIL_PAD), TAIL_PAD, (unsigned long long)nwords);
+	const int b = c->next_buf;
+	c->next_buf ^= 1;
+	// the kernel that last read this staging buffer must be done before we overwrite it
+	HIPCHK(hipEventSynchronize(c->buf_free[b]));
+	if (c->cap_words[b] < nwords) {
+		if (c->d_words[b]) HIPCHK(hipFree(c->d_words[b]));
+		c->d_words[b] = nullptr;
+		c->cap_words[b] = 0;
+		HIPCHK(hipMalloc((void **)&c->d_words[b], nwords * sizeof(uint32_t)));
+		c->cap_words[b] = nwords;
+	}
+	if (c->cap_offs[b] < nreads + 1) {
+		if (c->d_offs[b]) HIPCHK(hipFree(c->d_offs[b]));
+		c->d_offs[b] = nullptr;
+		c->cap_offs[b] = 0;
+		HIPCHK(hipMalloc((void **)&c->d_offs[b], (nreads + 1) * sizeof(uint64_t)));
+		c->cap_offs[b] = nreads + 1;
+	}
+	HIPCHK(hipMemcpyAsync(c->d_words[b], packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+	HIPCHK(hipMemcpyAsync(c->d_offs[b], offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+	HIPCHK(hipEventRecord(c->copied[b], c->copy_stream));
+	HIPCHK(hipStreamWaitEvent(c->stream, c->copied[b], 0));
+	int rc = launch_count(c, c->d_words[b], c->d_offs[b], nreads, maxlen);
+	if (rc != SDT_OK)
+		return rc;
+	HIPCHK(hipEventRecord(c->buf_free[b], c->stream));
+	c->kmers_total_host += kmers;
+	// the caller may reuse its buffers once the H2D copies have left them
+	HIPCHK(hipStreamSynchronize(c->copy_stream));
+	return SDT_OK;
+}
+
+int sdt_gpu_count_reads_device(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets,
+                               uint64_t nreads, uint64_t max_read_len)
+{
+	(void)nwords;
+	if (!c || !d_packed_words || !d_offsets)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (max_read_len == 0)
+		return fail(SDT_EINVAL, "max_read_len must be > 0");
+	HIPCHK(hipSetDevice(c->device));
+	return launch_count(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, max_read_len);
+}
+
+int sdt_gpu_finish_count(sdt_ctx *c, uint64_t *kmers_processed, uint64_t *nodes)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return rc;
+	if (kmers_processed) *kmers_processed = c->h_stats->kmers;
+	if (nodes) *nodes = c->h_stats->distinct;
+	return SDT_OK;
+}
+
+int sdt_gpu_extract_route(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets,
+                          uint64_t nreads, uint64_t max_read_len, int nranks, void *d_records, uint64_t max_records,
+                          void *d_counts, void *d_displs)
+{
+	(void)nwords;
+	if (!c || !d_packed_words || !d_offsets || !d_records || !d_counts || !d_displs)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (nranks < 1 || nranks > 64)
+		return fail(SDT_EINVAL, "nranks must be 1..64");
+	HIPCHK(hipSetDevice(c->device));
+	// fixed-capacity slices: rank r owns [r * cap, (r+1) * cap)
+	const unsigned long long cap = max_records / (uint64_t)nranks;
+	std::vector<unsigned long long> displs(nranks);
+	for (int r = 0; r < nranks; r++)
+		displs[r] = cap * (unsigned long long)r;
+	HIPCHK(hipMemcpyAsync(d_displs, displs.data(), nranks * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(d_counts, 0, nranks * sizeof(unsigned long long), c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));   // displs lives on our stack
+	if (nreads == 0)
+		return SDT_OK;
+	if (max_read_len == 0)
+		return fail(SDT_EINVAL, "max_read_len must be > 0");
+	const int mtw = tile_words_for(max_read_len);
+	const size_t smem = tile_smem_bytes(mtw);
+	if (smem > 64 * 1024)
+		return fail(SDT_EINVAL, "max read length %llu needs %zu B of LDS per tile (limit 64 KiB)",
+		            (unsigned long long)max_read_len, smem);
+	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	uint64_t grid = ntiles;
+	const uint64_t gcap = (uint64_t)c->cu_count * 4;
+	if (grid > gcap) grid = gcap;
+	if (c->nw == 1)
+		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+	else if (c->nw == 2)
+		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+	else
+		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+int sdt_gpu_insert_records(sdt_ctx *c, const void *d_records, uint64_t nrecords)
+{
+	if (!c || (!d_records && nrecords))
+		return fail(SDT_EINVAL, "NULL argument");
+	if (nrecords == 0)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(c->device));
+	int rc = ensure_room(c, nrecords);
+	if (rc != SDT_OK)
+		return rc;
+	const int g = scan_grid(c, nrecords);
+	EventPair *ev = next_event(c);
+	if (!ev)
+		return fail(SDT_EHIP, "hipEventCreate failed");
+	ev->kmers = nrecords;
+	HIPCHK(hipEventRecord(ev->a, c->stream));
+	if (c->nw == 1)
+		hipLaunchKernelGGL(k_insert_records<1>, dim3(g), dim3(TPB), 0, c->stream, (const Record<1> *)d_records, nrecords, table_of<1>(c), c->d_stats);
+	else if (c->nw == 2)
+		hipLaunchKernelGGL(k_insert_records<2>, dim3(g), dim3(TPB), 0, c->stream, (const Record<2> *)d_records, nrecords, table_of<2>(c), c->d_stats);
+	else
+		hipLaunchKernelGGL(k_insert_records<4>, dim3(g), dim3(TPB), 0, c->stream, (const Record<4> *)d_records, nrecords, table_of<4>(c), c->d_stats);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(ev->b, c->stream));
+	c->kmers_since_sync += nrecords;
+	return SDT_OK;
+}
+
+int sdt_gpu_delow(sdt_ctx *c, int d, uint64_t *removed)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	if (d < 0)
+		d = 0;       // pregraph.c:159: negative -d becomes 0
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
+	const int g = scan_grid(c, c->slots);
+	if (c->nw == 1) hipLaunchKernelGGL(k_delow<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), (uint32_t)d, c->d_stats);
+	else if (c->nw == 2) hipLaunchKernelGGL(k_delow<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), (uint32_t)d, c->d_stats);
+	else hipLaunchKernelGGL(k_delow<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), (uint32_t)d, c->d_stats);
+	HIPCHK(hipGetLastError());
+	int rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return rc;
+	if (removed) *removed = c->h_stats->scratch;
+	return SDT_OK;
+}
+
+int sdt_gpu_mark_and_hist(sdt_ctx *c, int64_t hist[257], uint64_t *linear)
+{
+	if (!c || !hist)
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
+	HIPCHK(hipMemsetAsync(c->d_hist, 0, 257 * sizeof(unsigned long long), c->stream));
+	const int g = scan_grid(c, c->slots);
+	if (c->nw == 1) hipLaunchKernelGGL(k_mark_hist<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_hist, c->d_stats);
+	else if (c->nw == 2) hipLaunchKernelGGL(k_mark_hist<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_hist, c->d_stats);
+	else hipLaunchKernelGGL(k_mark_hist<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_hist, c->d_stats);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(hist, c->d_hist, 257 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return rc;
+	if (linear) *linear = c->h_stats->scratch;
+	return SDT_OK;
+}
+
+int sdt_gpu_export_nodes(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count,
+                         uint64_t max_nodes, uint64_t *n)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return rc;
+	const uint64_t nodes = c->h_stats->distinct;
+	if (n) *n = nodes;
+	if (!keys && !l_links && !r_flags && !count)
+		return SDT_OK;
+	if (max_nodes < nodes)
+		return fail(SDT_EINVAL, "export arrays hold %llu nodes, table has %llu", (unsigned long long)max_nodes,
+		            (unsigned long long)nodes);
+	uint64_t *d_keys = nullptr;
+	uint32_t *d_l = nullptr, *d_r = nullptr, *d_c = nullptr;
+	const uint64_t m = nodes ? nodes : 1;
+	int ret = SDT_OK;
+#define EXP_CHK(expr)                                                                                  \
+	do {                                                                                               \
+		hipError_t e3_ = (expr);                                                                       \
+		if (e3_ != hipSuccess) {                                                                       \
+			ret = fail(e3_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e3_)); \
+			goto done;                                                                                 \
+		}                                                                                              \
+	} while (0)
+	if (keys) EXP_CHK(hipMalloc((void **)&d_keys, m * c->nw * sizeof(uint64_t)));
+	if (l_links) EXP_CHK(hipMalloc((void **)&d_l, m * sizeof(uint32_t)));
+	if (r_flags) EXP_CHK(hipMalloc((void **)&d_r, m * sizeof(uint32_t)));
+	if (count) EXP_CHK(hipMalloc((void **)&d_c, m * sizeof(uint32_t)));
+	EXP_CHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
+	{
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_export<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_export<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
+		else hipLaunchKernelGGL(k_export<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
+	}
+	EXP_CHK(hipGetLastError());
+	if (keys) EXP_CHK(hipMemcpyAsync(keys, d_keys, nodes * c->nw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	if (l_links) EXP_CHK(hipMemcpyAsync(l_links, d_l, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if (r_flags) EXP_CHK(hipMemcpyAsync(r_flags, d_r, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if (count) EXP_CHK(hipMemcpyAsync(count, d_c, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	EXP_CHK(hipStreamSynchronize(c->stream));
+done:
+	if (d_keys) (void)hipFree(d_keys);
+	if (d_l) (void)hipFree(d_l);
+	if (d_r) (void)hipFree(d_r);
+	if (d_c) (void)hipFree(d_c);
+	return ret;
+}
+
+int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	double total = 0;
+	uint64_t km = 0;
+	for (size_t i = 0; i < c->ev_used; i++) {
+		float t = 0;
+		HIPCHK(hipEventElapsedTime(&t, c->ev[i].a, c->ev[i].b));
+		total += t;
+		km += c->ev[i].kmers;
+	}
+	if (ms) *ms = total;
+	if (launches) *launches = c->ev_used;
+	if (kmers) *kmers = km;
+	if (reset)
+		c->ev_used = 0;
+	return SDT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,150 @@
+// sdt_table.cuh -- device-resident node table for gfx950.
+//
+// Replaces the reference's KmerSet (inc/newhash.h:65-88, newhash.c) for the counting pass.  What must
+// be preserved is the node STATE after all occurrences (survey 9.1):
+//     count      = number of occurrences (u32, unsaturated)              newhash.c:75
+//     left[b]    = min(63, #occurrences with prev == b)   b = 0..3       newhash.c:77-94, newhash.h:30
+//     right[b]   = min(63, #occurrences with next == b)
+//     single     = (count == 1)                                          newhash.c:32-40,445
+// not the layout (prime-sized table, in-place rehash).  MI355X-first layout:
+//
+//   Entry<NW> (AoS, 8-byte aligned, 16 / 24 / 40 bytes for 1 / 2 / 4 key words)
+//     key[NW]  w[0] most significant.  key[0] doubles as the claim word:
+//                 KEY_EMPTY  = ~0      (never a legal high word: at least 2 top bits are unused)
+//                 KEY_LOCKED = ~0 - 1  (multi-word keys only: claimed, low words not yet published)
+//     val      [63:48] count bits 15..0   [47:24] r_links (4 x 6 bit)   [23:0] l_links (4 x 6 bit)
+//   aux[slot]  u32: [15:0] count bits 31..16,  bit 16 linear, bit 17 deleted   (written by scans)
+//
+// Every occurrence costs ONE 64-bit device-scope atomic on `val`:
+//   * both neighbour counters already saturated (or absent)  -> atomicAdd(val, 1<<48); the 16-bit
+//     count field sits at the top of the word so its carry falls off the end, and the returned old
+//     value tells the one thread that wrapped it to bump aux (count bits 31..16);
+//   * otherwise a CAS loop that does the saturating 6-bit increments and the count increment together.
+// Counters are monotonic, so a stale observation can only send a thread down the (always correct) CAS
+// path; device-scope atomics are resolved at the memory side on gfx950 (per-XCD L2s are not coherent),
+// so the atomics, not the plain loads, are authoritative.
+#pragma once
+#include "sdt_kmer.cuh"
+
+namespace sdt {
+
+constexpr uint64_t KEY_EMPTY = ~0ULL;
+constexpr uint64_t KEY_LOCKED = ~0ULL - 1ULL;
+constexpr uint32_t AUX_LINEAR = 1u << 16;
+constexpr uint32_t AUX_DELETED = 1u << 17;
+constexpr uint64_t VAL_COUNT_ONE = 1ULL << 48;
+
+template <int NW> struct Entry {
+	uint64_t key[NW];
+	uint64_t val;
+};
+template <> struct alignas(16) Entry<1> {   // one global_load_dwordx4 fetches key + val
+	uint64_t key[1];
+	uint64_t val;
+};
+
+template <int NW> struct Table {
+	Entry<NW> *ent;
+	uint32_t *aux;
+	uint64_t mask;        // slots - 1 (slots is a power of two)
+};
+
+struct Stats {             // device counters, one cache line each would be nicer; they are cold
+	unsigned long long kmers;      // occurrences inserted
+	unsigned long long distinct;   // slots claimed
+	unsigned long long probe_fail; // inserts that ran out of probes (table too full): fatal
+	unsigned long long scratch;    // scan kernels: removed / linear / export cursor
+};
+
+__device__ inline uint64_t ld_relaxed(const uint64_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one occurrence into an existing node
+__device__ inline void node_update(uint64_t *val, uint32_t *aux, uint64_t seen, uint32_t prev, uint32_t next)
+{
+	const int ls = 6 * (int)prev, rs = 24 + 6 * (int)next;
+	for (;;) {
+		const bool l_done = prev >= 4u || ((seen >> ls) & 63u) >= 63u;
+		const bool r_done = next >= 4u || ((seen >> rs) & 63u) >= 63u;
+		if (l_done && r_done) {
+			const uint64_t old = atomicAdd((unsigned long long *)val, (unsigned long long)VAL_COUNT_ONE);
+			if ((old >> 48) == 0xFFFFu)
+				atomicAdd(aux, 1u);
+			return;
+		}
+		uint64_t nv = seen + VAL_COUNT_ONE;     // 16-bit count wraps off the top
+		if (!l_done) nv += 1ULL << ls;
+		if (!r_done) nv += 1ULL << rs;
+		const uint64_t got = atomicCAS((unsigned long long *)val, (unsigned long long)seen, (unsigned long long)nv);
+		if (got == seen) {
+			if ((seen >> 48) == 0xFFFFu)
+				atomicAdd(aux, 1u);
+			return;
+		}
+		seen = got;
+	}
+}
+
+// put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
+template <int NW>
+__device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_t prev, uint32_t next,
+                                 uint32_t &claimed)
+{
+	uint64_t slot = key_hash<NW>(key) & t.mask;
+	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
+	for (uint64_t probe = 0; probe < max_probe;) {
+		Entry<NW> *e = t.ent + slot;
+		uint64_t k0, seen = 0;
+		if (NW == 1) {
+			// one 16-byte load: key + val (val may be stale: see node_update)
+			const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(e);
+			k0 = kv.x;
+			seen = kv.y;
+		} else {
+			k0 = ld_relaxed(&e->key[0]);
+		}
+		if (k0 == KEY_EMPTY) {
+			const uint64_t want = NW == 1 ? key.w[0] : KEY_LOCKED;
+			const uint64_t old = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY,
+			                               (unsigned long long)want);
+			if (old == KEY_EMPTY) {
+				claimed++;
+				if (NW > 1) {
+#pragma unroll
+					for (int i = 1; i < NW; i++)
+						__hip_atomic_store(&e->key[i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				node_update(&e->val, t.aux + slot, 0, prev, next);
+				return true;
+			}
+			k0 = old;        // somebody else got it first: fall through and look at what they put
+			seen = 0;
+		}
+		if (NW > 1 && k0 == KEY_LOCKED)
+			continue;        // owner is publishing the low words: look again (no inner spin: SIMT-safe)
+		bool same = k0 == key.w[0];
+		if (NW > 1 && same) {
+			// key[0] was published (release) after the low words, and every load of them below is an
+			// agent-scope (sc1, L1-bypassing) load issued after the load of key[0]: no cache
+			// invalidate is needed, only that the compiler keeps the order
+			__atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+			for (int i = 1; i < NW; i++)
+				same = same && (ld_relaxed(&e->key[i]) == key.w[i]);
+			if (same)
+				seen = ld_relaxed(&e->val);
+		}
+		if (same) {
+			node_update(&e->val, t.aux + slot, seen, prev, next);
+			return true;
+		}
+		slot = (slot + 1) & t.mask;
+		probe++;
+	}
+	return false;
+}
+
+} // namespace sdt

@@ -1,0 +1,176 @@
+"""ctypes view of oracle/libsdt_oracle.so (the CPU restatement) -- test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libsdt_oracle.so")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+
+
+class Kmer(C.Structure):
+    _fields_ = [("w", C.c_uint64 * 4)]
+
+    @staticmethod
+    def of(words4):
+        k = Kmer()
+        for i in range(4):
+            k.w[i] = int(words4[i])
+        return k
+
+    def tup(self):
+        return tuple(int(self.w[i]) for i in range(4))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ORACLE_DIR, "sdt_oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
+    L = C.CDLL(LIB)
+    L.sdto_base2int.restype = C.c_int
+    L.sdto_base2int.argtypes = [C.c_int]
+    L.sdto_encode_line.restype = C.c_int
+    L.sdto_encode_line.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    for name in ("sdto_create_filter",):
+        getattr(L, name).restype = Kmer
+        getattr(L, name).argtypes = [C.c_int]
+    L.sdto_next_kmer.restype = Kmer
+    L.sdto_next_kmer.argtypes = [Kmer, C.c_int, C.c_int]
+    L.sdto_prev_kmer.restype = Kmer
+    L.sdto_prev_kmer.argtypes = [Kmer, C.c_int, C.c_int]
+    L.sdto_reverse_complement.restype = Kmer
+    L.sdto_reverse_complement.argtypes = [Kmer, C.c_int]
+    L.sdto_kmer_smaller.restype = C.c_int
+    L.sdto_kmer_smaller.argtypes = [Kmer, Kmer]
+    L.sdto_first_char.restype = C.c_int
+    L.sdto_first_char.argtypes = [Kmer, C.c_int]
+    L.sdto_last_char.restype = C.c_int
+    L.sdto_last_char.argtypes = [Kmer]
+    L.sdto_hash_kmer.restype = C.c_uint64
+    L.sdto_hash_kmer.argtypes = [Kmer, C.c_int]
+    L.sdto_chop_read.restype = C.c_int
+    L.sdto_chop_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sdto_next_prime.restype = C.c_uint64
+    L.sdto_next_prime.argtypes = [C.c_uint64]
+    L.sdto_set_new.restype = C.c_void_p
+    L.sdto_set_new.argtypes = [C.c_uint64, C.c_float]
+    L.sdto_set_free.argtypes = [C.c_void_p]
+    L.sdto_set_put.restype = C.c_int
+    L.sdto_set_put.argtypes = [C.c_void_p, Kmer, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.sdto_set_search.restype = C.c_int
+    L.sdto_set_search.argtypes = [C.c_void_p, Kmer, C.c_int, C.POINTER(C.c_uint64)]
+    L.sdto_set_first_probe.restype = C.c_uint64
+    L.sdto_set_first_probe.argtypes = [C.c_void_p, Kmer, C.c_int]
+    L.sdto_sets_new.restype = C.c_void_p
+    L.sdto_sets_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sdto_sets_free.argtypes = [C.c_void_p]
+    L.sdto_sets_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.sdto_sets_node_count.restype = C.c_uint64
+    L.sdto_sets_node_count.argtypes = [C.c_void_p]
+    L.sdto_sets_delow.restype = C.c_uint64
+    L.sdto_sets_delow.argtypes = [C.c_void_p, C.c_int]
+    L.sdto_sets_mark.restype = C.c_uint64
+    L.sdto_sets_mark.argtypes = [C.c_void_p, C.c_void_p]
+    L.sdto_write_kmerfreq.restype = C.c_int
+    L.sdto_write_kmerfreq.argtypes = [C.c_char_p, C.c_void_p]
+    L.sdto_sets_export.restype = C.c_uint64
+    L.sdto_sets_export.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    _lib = L
+    return L
+
+
+class SetStruct(C.Structure):      # sdto_set
+    _fields_ = [("array", C.c_void_p), ("flags", C.c_void_p), ("size", C.c_uint64), ("count", C.c_uint64),
+                ("max", C.c_uint64), ("load_factor", C.c_double)]
+
+
+class SetsStruct(C.Structure):     # sdto_sets
+    _fields_ = [("nsets", C.c_int), ("nw", C.c_int), ("K", C.c_int), ("sets", C.c_void_p),
+                ("kmers_in_reads", C.c_uint64)]
+
+
+def key_words_for(K):
+    return 1 if K <= 31 else (2 if K <= 63 else 4)
+
+
+class Oracle:
+    """prlRead2HashTable restated: nsets = thrd_num, nw = key words of the reference variant."""
+
+    def __init__(self, K, nsets=8, nw=None):
+        self.L = lib()
+        self.K = K
+        self.nw = nw or key_words_for(K)
+        self.h = self.L.sdto_sets_new(nsets, self.nw, K)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.sdto_sets_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def add_reads(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.L.sdto_sets_add_reads(self.h, codes.ctypes.data, offsets.ctypes.data, offsets.size - 1)
+
+    def kmers_in_reads(self):
+        return C.cast(self.h, C.POINTER(SetsStruct)).contents.kmers_in_reads
+
+    def node_count(self):
+        return self.L.sdto_sets_node_count(self.h)
+
+    def delow(self, d):
+        return self.L.sdto_sets_delow(self.h, d)
+
+    def mark(self):
+        hist = np.zeros(257, dtype=np.int64)
+        lin = self.L.sdto_sets_mark(self.h, hist.ctypes.data)
+        return hist, lin
+
+    def export(self):
+        n = self.node_count()
+        keys = np.zeros((max(n, 1), 4), dtype=np.uint64)
+        l = np.zeros(max(n, 1), dtype=np.uint32)
+        r = np.zeros(max(n, 1), dtype=np.uint32)
+        c = np.zeros(max(n, 1), dtype=np.uint32)
+        f = np.zeros(max(n, 1), dtype=np.uint8)
+        m = self.L.sdto_sets_export(self.h, keys.ctypes.data, l.ctypes.data, r.ctypes.data, c.ctypes.data, f.ctypes.data)
+        assert m == n
+        return keys[:n], l[:n], r[:n], c[:n], f[:n]
+
+
+def kmerfreq_text(hist):
+    return "".join(f"{int(hist[i])}\n" for i in range(1, 256))
+
+
+def chop_read(codes, K, nw=None):
+    """sdto_chop_read -> (keys uint64[n,4], prev uint8[n], next uint8[n], hash uint64[n])"""
+    L = lib()
+    nw = nw or key_words_for(K)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n = max(len(codes) - K + 1, 0)
+    keys = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    p = np.zeros(max(n, 1), dtype=np.uint8)
+    q = np.zeros(max(n, 1), dtype=np.uint8)
+    h = np.zeros(max(n, 1), dtype=np.uint64)
+    m = L.sdto_chop_read(codes.ctypes.data, len(codes), K, nw, keys.ctypes.data, p.ctypes.data, q.ctypes.data, h.ctypes.data)
+    return keys[:m], p[:m], q[:m], h[:m]
+
+
+def ref_binary(variant):
+    """oracle/_ref/SOAPdenovo-Trans-<variant>mer if it was built (container with /root/reference)"""
+    p = os.path.join(REF_DIR, f"SOAPdenovo-Trans-{variant}mer")
+    return p if os.path.exists(p) else None

@@ -1,0 +1,157 @@
+"""CPU: pin the oracle (oracle/sdt_oracle.c) against fixtures produced by the reference itself.
+
+unit_<variant>.txt come from oracle/_ref/probe<variant> (the reference's kmer.o/hashFunction.o/newhash.o);
+cases/* hold what the reference binary wrote.  See tests/golden/make_golden.py."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import golden_util as gu
+
+K4 = ob.Kmer.of
+
+
+def parse_unit(variant):
+    recs = []
+    with open(os.path.join(gu.GOLD, f"unit_{variant}.txt")) as fi:
+        for line in fi:
+            recs.append(line.split())
+    return recs
+
+
+def hx(tok4):
+    return tuple(int(t, 16) for t in tok4)
+
+
+@pytest.mark.parametrize("variant", [31, 63, 127])
+def test_unit_vectors(variant):
+    L = ob.lib()
+    nw = gu.VARIANT_WORDS[variant]
+    recs = parse_unit(variant)
+    sizes = [r for r in recs if r[0] == "sizeof"][0]
+    assert int(sizes[1]) == 8 * nw                      # sizeof(Kmer)
+    assert int(sizes[2]) == {1: 24, 2: 32, 4: 48}[nw]   # sizeof(kmer_t): the node record E of SURVEY 8(d)
+    nk = 0
+    for r in recs:
+        if r[0] == "filter":
+            assert L.sdto_create_filter(int(r[1])).tup() == hx(r[2:6])
+        elif r[0] == "kmer":
+            K = int(r[1])
+            k = K4(hx(r[2:6]))
+            assert r[6] == "rc"
+            rc = hx(r[7:11])
+            assert L.sdto_reverse_complement(k, K).tup() == rc
+            assert r[11] == "hash" and L.sdto_hash_kmer(k, nw) == int(r[12], 16)
+            assert r[13] == "smaller" and L.sdto_kmer_smaller(k, K4(rc)) == int(r[14])
+            assert r[15] == "first" and L.sdto_first_char(k, K) == int(r[16])
+            assert r[17] == "last" and L.sdto_last_char(k) == int(r[18])
+            assert r[19] == "next" and L.sdto_next_kmer(k, int(r[20]), K).tup() == hx(r[21:25])
+            assert r[25] == "prev" and L.sdto_prev_kmer(k, int(r[26]), K).tup() == hx(r[27:31])
+            nk += 1
+        elif r[0] == "prime":
+            n = int(r[1])
+            want = int(r[2])
+            got = 3 if n < 3 else L.sdto_next_prime(n)
+            assert got == want, (n, got, want)
+    assert nk >= 100
+
+
+def _rng_stream():
+    """splitmix64 stream of oracle/ref_probe.c (state continues across the whole probe run, so the table
+    part is replayed from the fixture's slot lines instead of the RNG)"""
+
+
+@pytest.mark.parametrize("variant", [31, 63, 127])
+def test_table_layout_replay(variant):
+    """put_kmerset / encap_kmerset: rebuild the probe's final table from its own slot dump by inserting
+    the distinct keys, then compare sizes, growth sequence and every slot.  Layout is a function of the
+    set of keys and their first-occurrence order only; the fixture's slot order is not the
+    insertion order, so this checks the weaker, order-free facts; the strict check is in the case tests
+    (vertex order) once the graph phases land.  Here: size/max sequence + search finds every key."""
+    L = ob.lib()
+    nw = gu.VARIANT_WORDS[variant]
+    recs = parse_unit(variant)
+    init = [r for r in recs if r[0] == "init"][0]
+    s = L.sdto_set_new(1024, 0.77)
+    st = ob.C.cast(s, ob.C.POINTER(ob.SetStruct)).contents
+    assert (st.size, st.max) == (int(init[1]), int(init[2]))
+    grows = [(int(r[1]), int(r[2]), int(r[3])) for r in recs if r[0] == "grow"]
+    slots = [r for r in recs if r[0] == "slot"]
+    final = [r for r in recs if r[0] == "final"][0]
+    seen_grow = []
+    last = st.size
+    for r in slots:
+        L.sdto_set_put(s, K4(hx(r[2:6])), 4, 4, nw, None)
+        if st.size != last:
+            seen_grow.append((st.count, st.size, st.max))
+            last = st.size
+    # same count -> same (size, max) sequence as the reference run (growth happens at count+1 > max)
+    assert [(g[1], g[2]) for g in seen_grow] == [(g[1], g[2]) for g in grows]
+    assert (st.size, st.count) == (int(final[2]), int(final[3]))
+    slot = ob.C.c_uint64()
+    for r in slots:
+        assert L.sdto_set_search(s, K4(hx(r[2:6])), nw, ob.C.byref(slot)) == 1
+    L.sdto_set_free(s)
+
+
+def test_base_coding():
+    L = ob.lib()
+    assert [L.sdto_base2int(ord(c)) for c in "ACTGN"] == [0, 1, 2, 3, 3]     # inc/def.h:39, survey q1
+    buf = np.zeros(64, dtype=np.uint8)
+    n = L.sdto_encode_line(b"acgtN.x-9R", 10, 100, buf.ctypes.data)
+    # lowercase folded; '.' -> A; 'x' is a letter: ('X'&6)>>1 = 0; '-' and '9' dropped; R -> 1
+    assert list(buf[:n]) == [0, 1, 3, 2, 3, 0, 0, 1]
+    n = L.sdto_encode_line(b"ACGTACGT", 8, 5, buf.ctypes.data)                # truncation to max_rd_len
+    assert n == 5
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_case_kmerfreq(name):
+    """oracle == reference binary on *.kmerFreq (byte-identical) and on the counters it prints"""
+    info = gu.load_case(name)
+    variant = info["variant"]
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    pkg = ge.load_package()
+    K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
+    codes, offs = gu.case_reads(info)
+    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant])
+    o.add_reads(codes, offs)
+    assert o.kmers_in_reads() == info["kmer_in_reads"]
+    assert o.node_count() == info["nodes_allocated"]
+    if info["d"]:
+        assert o.delow(info["d"]) == info["kmer_removed"]
+    hist, linear = o.mark()
+    assert linear == info["linear_nodes"]
+    assert ob.kmerfreq_text(hist) == gu.golden_text(info, "kmerFreq")
+    assert f" K {K}\n" in gu.golden_text(info, "preGraphBasic")
+
+
+def test_chop_matches_definition():
+    """chopKmer4read restatement vs. the closed form of SURVEY 9.1 (independent of the rolling update)"""
+    rng = np.random.default_rng(3)
+    L = ob.lib()
+    for K in (13, 23, 31, 33, 63, 65, 127):
+        nw = ob.key_words_for(K)
+        codes = rng.integers(0, 4, size=K + 40, dtype=np.uint8)
+        keys, p, q, h = ob.chop_read(codes, K)
+        assert len(keys) == len(codes) - K + 1
+        for j in range(len(keys)):
+            w = 0
+            for b in codes[j:j + K]:
+                w = (w << 2) | int(b)
+            r = 0
+            for b in codes[j:j + K][::-1]:
+                r = (r << 2) | (int(b) ^ 2)
+            has_l, has_r = j > 0, j < len(codes) - K
+            if w < r:
+                key, pv, nx = w, (codes[j - 1] if has_l else 4), (codes[j + K] if has_r else 4)
+            else:
+                key, pv, nx = r, ((codes[j + K] ^ 2) if has_r else 4), ((codes[j - 1] ^ 2) if has_l else 4)
+            got = 0
+            for x in keys[j]:
+                got = (got << 64) | int(x)
+            assert got == key and p[j] == pv and q[j] == nx
+            assert h[j] == L.sdto_hash_kmer(ob.Kmer.of(keys[j]), nw)
