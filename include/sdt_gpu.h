@@ -123,6 +123,9 @@ int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32
 int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */
 uint64_t sdt_gpu_table_slots(const sdt_ctx *ctx);
 void *sdt_gpu_stream(const sdt_ctx *ctx);          /* hipStream_t the kernels are launched on */
+/* launch on a caller-owned hipStream_t instead (NULL = back to a private stream); used by the multi-GPU
+ * driver so that RCCL collectives and our kernels are ordered by one stream */
+int sdt_gpu_set_stream(sdt_ctx *ctx, void *hip_stream);
 /* HIP-event timing of the dominant (chop+insert) kernel accumulated since the last call with reset!=0:
  * total milliseconds, number of launches, k-mer occurrences those launches processed. */
 int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches, uint64_t *kmers);

@@ -48,6 +48,7 @@ _ABI = [
     ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
     ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),
+    ("sdt_gpu_set_stream", _c.c_int, [_c.c_void_p, _c.c_void_p]),
     ("sdt_gpu_kernel_time", _c.c_int,
      [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_owner_hash", _c.c_uint64, [_c.c_void_p, _c.c_int]),
@@ -210,6 +211,9 @@ class PregraphGPU:
 
     def stream(self) -> int:
         return self.lib.sdt_gpu_stream(self._ctx) or 0
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.lib.sdt_gpu_set_stream(self._ctx, ctypes.c_void_p(hip_stream)))
 
     def kernel_time(self, reset: bool = True):
         ms, launches, kmers = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()

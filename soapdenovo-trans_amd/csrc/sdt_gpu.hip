@@ -440,6 +440,7 @@ struct sdt_ctx {
 	Stats *h_stats = nullptr;          // pinned
 	unsigned long long *d_hist = nullptr;
 	hipStream_t stream = nullptr, copy_stream = nullptr;
+	bool own_stream = true;
 	// host-batch staging (double buffered)
 	uint32_t *d_words[2] = {nullptr, nullptr};
 	uint64_t *d_offs[2] = {nullptr, nullptr};
@@ -690,7 +691,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
 	if (c->d_cursors) (void)hipFree(c->d_cursors);
-	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	delete c;
 	return SDT_OK;
@@ -715,6 +716,26 @@ int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
 uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int sdt_gpu_record_bytes(const sdt_ctx *c) { return c ? (c->nw + 1) * 8 : 0; }
+
+// run the kernels on a stream the caller owns (e.g. the stream a collective library orders against)
+int sdt_gpu_set_stream(sdt_ctx *c, void *hip_stream)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->own_stream) {
+		HIPCHK(hipStreamDestroy(c->stream));
+		c->own_stream = false;
+	}
+	if (hip_stream) {
+		c->stream = (hipStream_t)hip_stream;
+	} else {
+		HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->own_stream = true;
+	}
+	return SDT_OK;
+}
 
 // launch the fused chop+insert kernel on a device-resident batch, in chunks of reads small enough that
 // "every occurrence is a new node" cannot overflow the table between two looks at the node counter.

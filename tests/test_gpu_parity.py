@@ -1,0 +1,207 @@
+"""GPU (-m gpu): the HIP path through the C ABI vs. the oracle and vs. the reference's golden files.
+Bit-exact: integer work only."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def keys_to_int(keys):
+    out = []
+    for row in keys:
+        v = 0
+        for x in row:
+            v = (v << 64) | int(x)
+        out.append(v)
+    return out
+
+
+def node_dict_gpu(g):
+    keys, l, rf, cnt = g.export_nodes()
+    ki = keys_to_int(keys)
+    return {k: (int(a), int(b) & 0xFFFFFF, int(b) >> 24, int(c)) for k, a, b, c in zip(ki, l, rf, cnt)}
+
+
+def node_dict_oracle(o):
+    keys, l, r, cnt, fl = o.export()
+    ki = keys_to_int(keys)
+    # oracle flags: bit0 linear, bit1 deleted, bit2 single -> kmer_t bitfield order linear, deleted, checked, single
+    def f(x):
+        x = int(x)
+        return (x & 1) | ((x >> 1 & 1) << 1) | ((x >> 2 & 1) << 3)
+    return {k: (int(a), int(b), f(c), int(d)) for k, a, b, c, d in zip(ki, l, r, fl, cnt)}
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_golden_case_kmerfreq_bit_identical(pkg, name):
+    """reference binary's *.kmerFreq reproduced byte for byte by the GPU path"""
+    info = gu.load_case(name)
+    K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[info["variant"]])
+    codes, offs = gu.case_reads(info)
+    from soapdenovo_trans_amd import synth
+    words = synth.pack_2bit(codes)
+    with pkg.PregraphGPU(K, est_distinct=1 << 17) as g:
+        g.push_reads(words, offs)
+        kmers, nodes = g.finish_count()
+        assert kmers == info["kmer_in_reads"]
+        assert nodes == info["nodes_allocated"]
+        if info["d"]:
+            assert g.delow(info["d"]) == info["kmer_removed"]
+        hist, linear = g.mark_and_hist()
+        assert linear == info["linear_nodes"]
+        assert pkg.kmerfreq_text(hist) == gu.golden_text(info, "kmerFreq")
+
+
+@pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (31, 150, True), (33, 150, True),
+                                        (63, 250, False), (65, 200, True), (127, 250, True)])
+def test_node_table_equals_oracle(pkg, synth, K, L, ragged):
+    """every node: key, 8 saturating link counters, count, single/linear/deleted flags"""
+    tx = synth.make_transcriptome(25, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=6000, read_len=L, seed=K + 1, err=0.003, ragged=ragged)
+    words = synth.pack_2bit(codes)
+    o = ob.Oracle(K, nsets=5)
+    o.add_reads(codes, offs)
+    with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:        # small table: forces growth by rebuild
+        half = len(offs) // 2
+        # two pushes with different batch geometry (second batch starts mid-stream)
+        w1 = synth.pack_2bit(codes[: int(offs[half])])
+        g.push_reads(w1, offs[: half + 1])
+        rest = codes[int(offs[half]):]
+        g.push_reads(synth.pack_2bit(rest), offs[half:] - offs[half])
+        kmers, nodes = g.finish_count()
+        assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+        for d in (0, 2):
+            if d:
+                assert g.delow(d) == o.delow(d)
+            hist, linear = g.mark_and_hist()
+            ohist, olinear = o.mark()
+            assert linear == olinear
+            assert (hist == ohist).all()
+            assert node_dict_gpu(g) == node_dict_oracle(o)
+
+
+def test_saturation_and_hot_keys(pkg, synth):
+    """poly-A and tandem repeats: one key hit tens of thousands of times from every lane of a wave --
+    6-bit counters must stop at 63, count must not (and must carry past 16 bits into aux)"""
+    K = 21
+    n, L = 1500, 100
+    codes = np.zeros(n * L, dtype=np.uint8)                     # all A: one canonical k-mer, count = n*(L-K+1) = 120000
+    codes[L * 1000:] = np.tile(np.array([0, 1, 2, 3, 3, 1], dtype=np.uint8), (n - 1000) * L // 6 + 1)[: (n - 1000) * L]
+    offs = (np.arange(n + 1) * L).astype(np.uint64)
+    o = ob.Oracle(K, nsets=3)
+    o.add_reads(codes, offs)
+    with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        kmers, nodes = g.finish_count()
+        assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+        hist, linear = g.mark_and_hist()
+        ohist, olinear = o.mark()
+        assert (hist == ohist).all() and linear == olinear
+        gd = node_dict_gpu(g)
+        assert gd == node_dict_oracle(o)
+        assert max(v[3] for v in gd.values()) > 65536
+
+
+def test_edge_cases(pkg, synth):
+    """empty batch, reads shorter than K+1 (skipped, prlHashReads.c:592), a read of exactly K+1, reset"""
+    K = 25
+    with pkg.PregraphGPU(K) as g:
+        g.push_reads(np.zeros(4, dtype=np.uint32), np.zeros(1, dtype=np.uint64))       # zero reads
+        assert g.finish_count() == (0, 0)
+        rng = np.random.default_rng(1)
+        lens = np.array([0, 1, K - 1, K, K + 1, 3, K + 1, 200, K, K + 2], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        codes = rng.integers(0, 4, size=int(offs[-1]), dtype=np.uint8)
+        o = ob.Oracle(K, nsets=2)
+        o.add_reads(codes, offs)
+        g.push_reads(synth.pack_2bit(codes), offs)
+        assert g.finish_count() == (o.kmers_in_reads(), o.node_count())
+        assert o.kmers_in_reads() == 2 + 2 + (200 - K + 1) + 3
+        hist, _ = g.mark_and_hist()
+        assert (hist == o.mark()[0]).all()
+        g.reset()
+        assert g.finish_count() == (0, 0)
+        hist, lin = g.mark_and_hist()
+        assert hist.sum() == 0 and lin == 0
+
+
+def test_device_resident_batch_and_properties(pkg, synth):
+    """device entry point on a torch-generated workload: size-independent properties + oracle on a slice"""
+    import torch
+    dev = torch.device("cuda:0")
+    K, L, n = 31, 150, 200_000
+    words, offsets, nwords = synth.torch_workload(n, L, T=300, device=dev, seed=11)
+    torch.cuda.synchronize()
+    with pkg.PregraphGPU(K, est_distinct=1 << 22) as g:
+        g.count_reads_device(words, nwords, offsets, n, L)
+        kmers, nodes = g.finish_count()
+        assert kmers == n * (L - K + 1)
+        hist, linear = g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        assert len(keys) == nodes
+        assert hist.sum() == nodes                                   # every node lands in exactly one bin
+        assert int(cnt.astype(np.uint64).sum()) == kmers             # counts add up to the occurrences
+        assert len(set(keys[:, 0].tolist())) == nodes                # keys are distinct
+        # each occurrence has exactly one left and one right neighbour slot or none: link sums <= count
+        ls = sum(((l >> (6 * b)) & 63).astype(np.int64) for b in range(4))
+        assert (ls <= cnt).all()
+        # idempotence of the scan: marking twice gives the same histogram
+        hist2, linear2 = g.mark_and_hist()
+        assert (hist2 == hist).all() and linear2 == linear
+        # oracle on the first 3000 reads, through the same device buffers
+        sub = 3000
+        hw = words.cpu().numpy().view(np.uint32)
+        codes = np.zeros(sub * L, dtype=np.uint8)
+        idx = np.arange(sub * L)
+        codes[:] = (hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3
+        g.reset()
+        g.count_reads_device(words, nwords, offsets, sub, L)
+        k2, n2 = g.finish_count()
+        o = ob.Oracle(K, nsets=8)
+        o.add_reads(codes, (np.arange(sub + 1) * L).astype(np.uint64))
+        assert (k2, n2) == (o.kmers_in_reads(), o.node_count())
+        assert (g.mark_and_hist()[0] == o.mark()[0]).all()
+
+
+def test_route_then_insert_equals_direct(pkg, synth):
+    """owner-computes sharding on one GPU: extract_route into N virtual ranks, insert every slice into
+    one table == counting directly; and slices are disjoint by owner hash"""
+    import torch
+    dev = torch.device("cuda:0")
+    K, L, n, nranks = 31, 100, 20000, 4
+    tx = synth.make_transcriptome(40, seed=5)
+    codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=L, seed=6)
+    words = torch.from_numpy(synth.pack_2bit(codes).view(np.int32)).to(dev)
+    offsets = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    o = ob.Oracle(K, nsets=4)
+    o.add_reads(codes, offs)
+    ohist, _ = o.mark()
+    with pkg.PregraphGPU(K, est_distinct=1 << 20) as g:
+        rb = g.record_bytes()
+        assert rb == 16
+        total = n * (L - K + 1)
+        cap = int(total / nranks * 1.5) * nranks
+        recs = torch.zeros(cap * rb // 8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(nranks, dtype=torch.int64, device=dev)
+        displs = torch.zeros(nranks, dtype=torch.int64, device=dev)
+        g.extract_route(words, words.numel(), offsets, n, L, nranks, recs, cap, counts, displs)
+        g.finish_count()
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy()
+        d = displs.cpu().numpy()
+        assert c.sum() == total
+        lib = pkg.load_library()
+        r2 = recs.view(-1, 2)
+        for r in range(nranks):
+            sl = r2[d[r]: d[r] + c[r]]
+            kk = sl[:200, 0].cpu().numpy().view(np.uint64)
+            for k in kk:                                            # owner function agrees host/device
+                a = np.array([k], dtype=np.uint64)
+                assert ((lib.sdt_owner_hash(a.ctypes.data, 1) >> 32) * nranks) >> 32 == r
+            g.insert_records(sl.contiguous(), int(c[r]))
+        kmers, nodes = g.finish_count()
+        assert (kmers, nodes) == (total, o.node_count())
+        assert (g.mark_and_hist()[0] == ohist).all()
