@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- pregraph k-mers hashed per second on MI355X (BASELINE.json metric).
+
+A step = one full pass of the hot path over the workload: reset the node table, chop + insert/count every
+read (sdt_gpu_count_reads_device; N>1: extract_route -> RCCL all-to-all -> insert_records), drain,
+then the linear-mark + kmerFreq scan.  Inputs (packed 2-bit reads) are resident in HBM before the timed
+region.  value = k-mer occurrences of the WHOLE job / wall time of the step (max over ranks).
+
+Workload: BASELINE.json metric "200M x 150bp, K=31" (configs[2]) when --reads is not given, as STRONG
+scaling: the same 200 M reads are split over the N ranks.  --reads/--read-len/--K/--T select other configs
+(configs[1] = --reads 50000000).
+
+One JSON line on rank 0.  roofline.achieved uses SURVEY.md 8(d)'s algorithmic bytes per k-mer occurrence,
+B = 0.25*L/(L-K+1) + 2*E (E = 24/32/48 B reference node), times the k-mers of the chop+insert launches,
+divided by their HIP-event time on the library's stream (sdt_gpu_kernel_time).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_kmer(L, K):
+    E = 24 if K <= 31 else (32 if K <= 63 else 48)
+    return 0.25 * L / (L - K + 1) + 2 * E
+
+
+def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
+    """Rank 0, N=1 only.  Time the reference binary (oracle/_ref, kind 'reference') on the first
+    `sample_reads` reads of the same workload, from process start until <prefix>.kmerFreq is complete
+    (= parse + chop + hash + mark, the part of pregraph this repo replaces); fall back to the oracle port."""
+    import oracle_binding as ob
+
+    n = min(sample_reads, n_reads_total)
+    nw = (n * L + 15) // 16
+    hw = words_dev[:nw].cpu().numpy().view(np.uint32)
+    idx = np.arange(n * L, dtype=np.int64)
+    codes = ((hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
+    del idx
+    kmers = n * (L - K + 1)
+    cores = os.cpu_count() or 1
+    exe = ob.ref_binary(31 if K <= 31 else 127)
+    if exe and os.access(exe, os.X_OK):
+        from soapdenovo_trans_amd import synth
+        tmp = tempfile.mkdtemp(prefix="sdt_cpu_")
+        try:
+            fq = os.path.join(tmp, "reads.fq")
+            letters = synth.BASES[codes].reshape(n, L)
+            with open(fq, "wb") as fo:
+                qual = b"I" * L
+                parts = []
+                for i in range(n):
+                    parts.append(b"@r%d\n%s\n+\n%s\n" % (i, letters[i].tobytes(), qual))
+                    if len(parts) == 65536:
+                        fo.write(b"".join(parts))
+                        parts = []
+                fo.write(b"".join(parts))
+            if os.path.getsize(fq) % 32768 == 0:       # reference hangs on exact multiples (survey q9)
+                with open(fq, "ab") as fo:
+                    fo.write(b"\n")
+            synth.write_config(os.path.join(tmp, "lib.cfg"), L, fastq=[fq])
+            p_threads = min(cores, 64)
+            out = os.path.join(tmp, "out")
+            t0 = time.time()
+            proc = subprocess.Popen([exe, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(K), "-p",
+                                     str(p_threads), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            kf = out + ".kmerFreq"
+            t1 = None
+            while proc.poll() is None and time.time() - t0 < 600:
+                if os.path.exists(kf) and os.path.getsize(kf) > 0:
+                    with open(kf, "rb") as fi:
+                        if fi.read().count(b"\n") >= 255:
+                            t1 = time.time()
+                            break
+                time.sleep(0.02)
+            if proc.poll() is None:
+                proc.kill()           # exact child we started; the later phases are out of scope here
+            proc.wait()
+            if t1 is not None:
+                return {"value": kmers / (t1 - t0), "unit": "kmers/s", "cores": p_threads, "kind": "reference",
+                        "sample": f"first {n} reads ({kmers} k-mers) of the workload as FASTQ; reference "
+                                  f"SOAPdenovo-Trans pregraph -K {K} -p {p_threads}, process start until "
+                                  f"*.kmerFreq written ({t1 - t0:.2f} s)"}
+            log("reference binary did not produce kmerFreq; falling back to the oracle port")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    o = ob.Oracle(K, nsets=8)
+    offs = (np.arange(n + 1, dtype=np.uint64) * L)
+    t0 = time.time()
+    o.add_reads(codes, offs)
+    o.mark()
+    dt = time.time() - t0
+    return {"value": kmers / dt, "unit": "kmers/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} reads ({kmers} k-mers), oracle/sdt_oracle.c single thread ({dt:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=200_000_000, help="reads of the whole job")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--K", type=int, default=31)
+    ap.add_argument("--T", type=int, default=20000, help="synthetic transcripts")
+    ap.add_argument("--err", type=float, default=0.002)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
+    ap.add_argument("--est-distinct", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from soapdenovo_trans_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    def log(*a):
+        if rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    K, L = pkg.clamp_K(args.K), args.read_len
+    n_total = args.reads
+    n_local = n_total // world + (1 if rank < n_total % world else 0)
+    kmers_total = n_total * (L - K + 1)
+    t0 = time.time()
+    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, seed=42 + 1000 * rank, err=args.err)
+    torch.cuda.synchronize()
+    log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
+
+    # distinct k-mers ~ true k-mers + errors * K; table sized so that MAX_LOAD is not hit
+    est = args.est_distinct or int(args.T * 2250 + n_total * L * args.err * K * 1.1) // world + (1 << 20)
+    g = pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0)
+    stream = torch.cuda.Stream(device=dev)
+    g.set_stream(stream.cuda_stream)
+    log(f"node table: {g.table_slots()} slots")
+
+    rb = g.record_bytes()
+    if world > 1:
+        per_round = min(args.route_batch, n_local)
+        cap_per_rank = int(per_round * (L - K + 1) / world * 1.25) + 4096
+        send = torch.empty(cap_per_rank * world * rb // 8, dtype=torch.int64, device=dev)
+        recv = torch.empty(cap_per_rank * world * rb // 8, dtype=torch.int64, device=dev)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        displs = torch.zeros(world, dtype=torch.int64, device=dev)
+        rcounts = torch.zeros(world, dtype=torch.int64, device=dev)
+
+    def one_step():
+        g.reset()
+        if world == 1:
+            g.count_reads_device(words, nwords, offsets, n_local, L)
+        else:
+            w8 = rb // 8
+            with torch.cuda.stream(stream):
+                for r0 in range(0, n_local, per_round):
+                    nr = min(per_round, n_local - r0)
+                    g.extract_route(words, nwords, offsets[r0:], nr, L, world, send, cap_per_rank * world, counts, displs)
+                    dist.all_to_all_single(rcounts, counts)
+                    c = counts.cpu().tolist()
+                    rc = rcounts.cpu().tolist()
+                    ins = [send[(i * cap_per_rank) * w8:(i * cap_per_rank + c[i]) * w8] for i in range(world)]
+                    roff = np.concatenate([[0], np.cumsum(rc)])
+                    outs = [recv[int(roff[i]) * w8:int(roff[i + 1]) * w8] for i in range(world)]
+                    dist.all_to_all(outs, ins)
+                    g.insert_records(recv, int(roff[-1]))
+        kmers, nodes = g.finish_count()
+        hist, linear = g.mark_and_hist()
+        if world > 1:
+            h = torch.from_numpy(hist).to(dev)
+            agg = torch.tensor([kmers, nodes, linear], dtype=torch.int64, device=dev)
+            dist.all_reduce(h)
+            dist.all_reduce(agg)
+            hist = h.cpu().numpy()
+            kmers, nodes, linear = (int(x) for x in agg.cpu().tolist())
+        return kmers, nodes, linear, hist
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = one_step()
+    g.kernel_time(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kmers, nodes, linear, hist = res
+    assert kmers == kmers_total, f"processed {kmers} k-mers, expected {kmers_total}"
+    assert int(hist.sum()) == nodes, "kmerFreq bins do not add up to the node count"
+    kms, launches, _ = g.kernel_time(reset=True)
+    ms_per_step = dt / args.steps * 1e3
+    value = kmers_total * args.steps / dt
+    B = algorithmic_bytes_per_kmer(L, K)
+    # kernel-level: this rank's k-mers over this rank's kernel time (N=1: whole job)
+    local_kmers = n_local * (L - K + 1) if world == 1 else None
+    roof = None
+    if world == 1 and kms > 0:
+        ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_count_reads",
+                "bytes_per_kmer": round(B, 3), "launches": int(launches),
+                "avg_launch_ms": round(kms / max(launches, 1), 4), "kernel_ms_per_step": round(kms / args.steps, 3)}
+    out = {
+        "metric": "pregraph k-mers hashed/sec", "value": value, "unit": "kmers/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{n_total} x {L} bp synthetic transcriptome reads (T={args.T}, err={args.err}), "
+                               f"K={K}, pass-1 chop+hash+count+kmerFreq", "reads": n_total, "read_len": L, "K": K,
+                   "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
+                   "parallelism": f"owner-sharded x{world}" if world > 1 else "single-GPU table"},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log)
+        except Exception as e:     # the baseline is reported, never required
+            log("cpu baseline failed:", repr(e))
+            out["cpu_baseline"] = None
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

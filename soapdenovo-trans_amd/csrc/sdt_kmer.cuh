@@ -124,9 +124,16 @@ template <int NW> __device__ inline Key<NW> stream_kmer(const uint32_t *lds, int
 		const uint64_t hi = (a << 32) | b;
 		k.w[i] = sh ? ((hi << sh) | (c >> (32 - sh))) : hi;
 	}
-	// createFilter: keep the low 2K bits (2K > 64*(NW-1) always holds for the NW chosen from K)
-	const int topbits = 2 * K - 64 * (NW - 1);      // 2..62 significant bits in w[0]
-	k.w[0] &= (topbits >= 64) ? ~0ULL : ((1ULL << topbits) - 1ULL);
+	// createFilter (kmer.c:313-355): keep the low 2K bits.  With 4-word keys K may be as small as 65, so
+	// more than one leading word can be (partly) outside the k-mer.
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);     // significant bits in word i
+		if (bits <= 0)
+			k.w[i] = 0;
+		else if (bits < 64)
+			k.w[i] &= (1ULL << bits) - 1ULL;
+	}
 	return k;
 }
 
