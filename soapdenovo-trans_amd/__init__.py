@@ -80,6 +80,13 @@ def load_library():
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the pregraph hashing path)")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (soname libamdhip64.so.7, file name
+    # libamdhip64.so).  Loaded first, the dynamic linker resolves our NEEDED libamdhip64.so.7 to it; loaded
+    # second, torch would map a second runtime next to /opt/rocm's and fail with hipErrorNoDevice.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in _ABI:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
