@@ -163,43 +163,22 @@ def main():
     g.set_stream(stream.cuda_stream)
     log(f"node table: {g.table_slots()} slots")
 
-    rb = g.record_bytes()
+    sharded = None
     if world > 1:
-        per_round = min(args.route_batch, n_local)
-        cap_per_rank = int(per_round * (L - K + 1) / world * 1.25) + 4096
-        send = torch.empty(cap_per_rank * world * rb // 8, dtype=torch.int64, device=dev)
-        recv = torch.empty(cap_per_rank * world * rb // 8, dtype=torch.int64, device=dev)
-        counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        displs = torch.zeros(world, dtype=torch.int64, device=dev)
-        rcounts = torch.zeros(world, dtype=torch.int64, device=dev)
+        from soapdenovo_trans_amd.sharding import ShardedCounter, allreduce_stats
+        sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
 
     def one_step():
         g.reset()
         if world == 1:
             g.count_reads_device(words, nwords, offsets, n_local, L)
         else:
-            w8 = rb // 8
             with torch.cuda.stream(stream):
-                for r0 in range(0, n_local, per_round):
-                    nr = min(per_round, n_local - r0)
-                    g.extract_route(words, nwords, offsets[r0:], nr, L, world, send, cap_per_rank * world, counts, displs)
-                    dist.all_to_all_single(rcounts, counts)
-                    c = counts.cpu().tolist()
-                    rc = rcounts.cpu().tolist()
-                    ins = [send[(i * cap_per_rank) * w8:(i * cap_per_rank + c[i]) * w8] for i in range(world)]
-                    roff = np.concatenate([[0], np.cumsum(rc)])
-                    outs = [recv[int(roff[i]) * w8:int(roff[i + 1]) * w8] for i in range(world)]
-                    dist.all_to_all(outs, ins)
-                    g.insert_records(recv, int(roff[-1]))
+                sharded.count_reads(words, nwords, offsets, n_local)
         kmers, nodes = g.finish_count()
         hist, linear = g.mark_and_hist()
         if world > 1:
-            h = torch.from_numpy(hist).to(dev)
-            agg = torch.tensor([kmers, nodes, linear], dtype=torch.int64, device=dev)
-            dist.all_reduce(h)
-            dist.all_reduce(agg)
-            hist = h.cpu().numpy()
-            kmers, nodes, linear = (int(x) for x in agg.cpu().tolist())
+            hist, kmers, nodes, linear = allreduce_stats(hist, kmers, nodes, linear, dev)
         return kmers, nodes, linear, hist
 
     def barrier():

@@ -137,8 +137,9 @@ def write_config(path: str, max_rd_len: int, fastq=None, fastq_pairs=None, avg_i
 # ------------------------------------------------------------------------------------------------ torch (device) generator
 
 def torch_workload(n_reads: int, read_len: int, T: int, device, seed: int = 42, err: float = 0.002,
-                   sigma: float = 2.0, chunk: int = 1 << 20):
-    """Generate the bench workload directly in device memory.
+                   sigma: float = 2.0, chunk: int = 1 << 20, tx_seed: int = 42):
+    """Generate the bench workload directly in device memory (tx_seed fixes the transcriptome, seed the
+    read sampling: ranks share the former and differ in the latter).
 
     Returns (words int32[nwords] (bit pattern of the uint32 packed stream, 4 pad words),
              offsets int64[n_reads+1], nwords).  Reads are fixed length (Illumina-like), so read i starts
@@ -147,7 +148,7 @@ def torch_workload(n_reads: int, read_len: int, T: int, device, seed: int = 42, 
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    codes_np, starts_np, w_np = make_transcriptome(T, seed=seed, sigma=sigma)
+    codes_np, starts_np, w_np = make_transcriptome(T, seed=tx_seed, sigma=sigma)
     tx = torch.from_numpy(codes_np).to(device)
     starts = torch.from_numpy(starts_np).to(device)
     lens_t = starts[1:] - starts[:-1]
