@@ -39,6 +39,21 @@ def algorithmic_bytes_per_kmer(L, K):
     return 0.25 * L / (L - K + 1) + 2 * E
 
 
+def pmc_traffic_per_kmer(kernel="k_count_reads"):
+    """HBM bytes per k-mer of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE are collected in separate rocprofv3 --pmc runs, tools/pmc_summary.py; they cannot be read live).
+    Returns (bytes per k-mer, source file) or (None, None)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_{kernel}*.json"))):
+        try:
+            j = json.load(open(f))
+            best = (j["hbm_bytes"]["per_kmer"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best or (None, None)
+
+
 def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
     """Rank 0, N=1 only.  Time the reference binary (oracle/_ref, kind 'reference') on the first
     `sample_reads` reads of the same workload, from process start until <prefix>.kmerFreq is complete
@@ -213,8 +228,13 @@ def main():
     roof = None
     if world == 1 and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
+        tpk, tsrc = pmc_traffic_per_kmer()
+        per_launch_kmers = local_kmers * args.steps / max(launches, 1)
         roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_count_reads",
+                "frac": round(ach / HBM_PEAK_GBS, 5),
+                "traffic": None if tpk is None else round(tpk * per_launch_kmers),
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE PMC passes)", "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(B * per_launch_kmers), "kernel": "k_count_reads",
                 "bytes_per_kmer": round(B, 3), "launches": int(launches),
                 "avg_launch_ms": round(kms / max(launches, 1), 4), "kernel_ms_per_step": round(kms / args.steps, 3)}
     out = {
