@@ -1,0 +1,154 @@
+/* sdt_pregraph.c -- `sdt-pregraph -s configFile -o outputGraph [-K kmer -p n_cpu -d kmerFreqCutoff]`
+ *
+ * The reference's `pregraph` command line (pregraph.c:118-204) over the MI355X hashing path
+ * (include/sdt_gpu.h).  Same options, same K clamp (pregraph.c:38-59), same stdout phrases for the
+ * counters, and <prefix>.kmerFreq byte-identical to the reference (freqStat, prlHashReads.c:994-1023).
+ * -p is the number of host parser threads here (the reference's worker pool is the GPU now).
+ * There is no CPU fallback: without a gfx950 device the program exits non-zero.
+ */
+#define _GNU_SOURCE
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../../include/sdt_gpu.h"
+#include "libcfg.h"
+#include "seqio.h"
+
+#ifndef SDT_MAX_K
+#define SDT_MAX_K 127        /* one binary covers the 31/63/127mer variants; --max-k emulates a smaller one */
+#endif
+
+static void usage(int max_k)
+{
+	printf("\npregraph -s configFile -o outputGraph [-K kmer -p n_cpu -d kmerFreqCutoff]\n");
+	printf("  -s\t<string>\tconfigFile: the config file of reads\n");
+	printf("  -o\t<string>\toutputGraph: prefix of output graph file name\n");
+	printf("  -K\t<int>\t\tkmer(min 13, max %d): kmer size, [23]\n", max_k);
+	printf("  -p\t<int>\t\tn_cpu: number of cpu for use, [8]\n");
+	printf("  -d\t<int>\t\tkmerFreqCutoff: kmers with frequency no larger than KmerFreqCutoff will be deleted, [0]\n");
+}
+
+typedef struct {
+	sdt_ctx *gpu;
+	unsigned long long reads;
+} push_state;
+
+static int push_batch(void *user, const sdt_batch *b)
+{
+	push_state *st = (push_state *)user;
+	unsigned long long before = st->reads / 1000000ULL;
+	st->reads += b->nreads;
+	if (st->reads / 1000000ULL != before)
+		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);    /* prlHashReads.c:587-588 */
+	if (sdt_gpu_push_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_push_reads: %s\n", sdt_gpu_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	char cfgfile[4096] = "", prefix[4096] = "";
+	int K = 23, threads = 8, d = 0, max_k = SDT_MAX_K, device = 0;
+	int have_s = 0, have_o = 0, c;
+	unsigned long long est = 0;
+	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
+	                                   {"est-distinct", required_argument, 0, 1002}, {0, 0, 0, 0}};
+	/* accept an optional leading "pregraph" sub-command like the reference's dispatcher (main.c:49-106) */
+	if (argc > 1 && strcmp(argv[1], "pregraph") == 0) { argv++; argc--; }
+	while ((c = getopt_long(argc, argv, "a:s:o:K:p:d:Di:n", longopts, NULL)) != -1) {
+		switch (c) {
+		case 's': have_s = 1; snprintf(cfgfile, sizeof cfgfile, "%s", optarg); break;
+		case 'o': have_o = 1; snprintf(prefix, sizeof prefix, "%s", optarg); break;
+		case 'K': K = atoi(optarg); break;
+		case 'p': threads = atoi(optarg); break;
+		case 'd': d = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;          /* pregraph.c:159 */
+		case 'a': case 'i': case 'D': break;                                 /* accepted; no effect on this path */
+		case 'n':
+			fprintf(stderr, "-n (N-aware k-mers) is not supported: the reference path is broken (survey 9.3-q11)\n");
+			return 1;
+		case 1000: max_k = atoi(optarg); break;
+		case 1001: device = atoi(optarg); break;
+		case 1002: est = strtoull(optarg, NULL, 10); break;
+		default:
+			if (!have_s || !have_o) { usage(max_k); return 255; }
+		}
+	}
+	if (!have_s || !have_o) { usage(max_k); return 255; }
+	if (d > 127) d = (signed char)d;                                        /* deLowKmer is a char (survey q12) */
+	/* pregraph.c:38-59 */
+	if (K % 2 == 0) { K++; printf("K should be an odd number\n"); }
+	if (K < 13) { K = 13; printf("K should not be less than 13\n"); }
+	else if (K > max_k) K = max_k;
+
+	time_t t_start = time(NULL);
+	sdt_cfg cfg;
+	if (sdt_cfg_load(cfgfile, &cfg) != 0) return 255;
+	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;                /* prlHashReads.c:361-364 */
+	printf("In %s, %d libs, max seq len %d, max name len %d\n\n", cfgfile, cfg.nlibs, max_read_len, 256);
+
+	sdt_ctx *gpu = NULL;
+	if (sdt_gpu_init(&gpu, device, K, est, 0) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+	push_state st = {gpu, 0};
+	const size_t chunk = 32u << 20;
+	int rc = 0;
+	for (int i = 0; i < cfg.nlibs && rc == 0; i++) {
+		sdt_lib *l = &cfg.libs[i];
+		if (l->asm_flag != 1 && l->asm_flag != 3)                           /* readseq1by1.c:563 */
+			continue;
+		int mrl = max_read_len;                                              /* prlHashReads.c:820-823 */
+		if (l->rd_len_cutoff > 0 && l->rd_len_cutoff < mrl) mrl = l->rd_len_cutoff;
+		if (l->nb) {
+			fprintf(stderr, "b= (BAM) input is not supported by this build\n");
+			rc = -1;
+			break;
+		}
+		/* file-type order of nextValidIndex (readseq1by1.c:579-632): f1/f2, q1/q2, p, [b], f, q */
+		struct { char **names; int n; int fmt; int type; } groups[] = {
+			{l->f1, l->nf1, 'a', 1}, {l->f2, l->nf2, 'a', 1}, {l->q1, l->nq1, 'q', 2}, {l->q2, l->nq2, 'q', 2},
+			{l->p, l->np, 'a', 3}, {l->f, l->nf, 'a', 5}, {l->q, l->nq, 'q', 6}};
+		for (unsigned g = 0; g < sizeof groups / sizeof groups[0] && rc == 0; g++)
+			for (int f = 0; f < groups[g].n && rc == 0; f++) {
+				printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].names[f]);
+				rc = sdt_read_file(groups[g].names[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, NULL);
+			}
+	}
+	if (rc != 0) { sdt_gpu_destroy(gpu); return 1; }
+	uint64_t kmers = 0, nodes = 0, removed = 0, linear = 0;
+	if (sdt_gpu_finish_count(gpu, &kmers, &nodes) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_finish_count: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+	printf("time spent on hash reads: %ds, %llu reads processed\n", (int)(time(NULL) - t_start), st.reads);
+	printf("%llu nodes allocated, %llu kmer in reads, %llu kmer processed\n", (unsigned long long)nodes,
+	       (unsigned long long)kmers, (unsigned long long)kmers);
+	if (d) {
+		if (sdt_gpu_delow(gpu, d, &removed) != SDT_OK) { fprintf(stderr, "sdt_gpu_delow: %s\n", sdt_gpu_last_error()); return 1; }
+		printf("%llu kmer removed\n", (unsigned long long)removed);
+	}
+	int64_t hist[257];
+	if (sdt_gpu_mark_and_hist(gpu, hist, &linear) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_mark_and_hist: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+	printf("%llu linear nodes\n", (unsigned long long)linear);
+	char name[4200];
+	snprintf(name, sizeof name, "%s.kmerFreq", prefix);
+	FILE *fo = fopen(name, "w");
+	if (!fo) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
+	for (int i = 1; i < 256; i++)
+		fprintf(fo, "%lld\n", (long long)hist[i]);
+	fclose(fo);
+	printf("time spent on pre-graph construction: %ds\n\n", (int)(time(NULL) - t_start));
+	printf("deLowKmer %d, deLowEdge %d\n", d, 0);
+	sdt_gpu_destroy(gpu);
+	sdt_cfg_free(&cfg);
+	return 0;
+}

@@ -1,0 +1,245 @@
+/* seqio.c -- see seqio.h */
+#define _GNU_SOURCE
+#include "seqio.h"
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+typedef struct {
+	const char *beg, *end;      /* [beg, end) holds whole records */
+	sdt_batch out;
+	int done;
+} chunk_t;
+
+typedef struct {
+	chunk_t *chunks;
+	int nchunks, next;
+	int fmt, max_read_len, reverse;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+} job_t;
+
+/* ---- 2-bit stream writer ---- */
+typedef struct {
+	uint32_t *w;
+	uint64_t cap, nbases;
+} packer_t;
+
+static void pk_reserve(packer_t *p, uint64_t more_bases)
+{
+	uint64_t need = ((p->nbases + more_bases + 15) >> 4) + 8;
+	if (need > p->cap) {
+		uint64_t ncap = p->cap ? p->cap * 2 : 1 << 16;
+		while (ncap < need) ncap *= 2;
+		p->w = (uint32_t *)realloc(p->w, ncap * sizeof(uint32_t));
+		memset(p->w + p->cap, 0, (ncap - p->cap) * sizeof(uint32_t));
+		p->cap = ncap;
+	}
+}
+
+static inline void pk_put(packer_t *p, unsigned code)
+{
+	p->w[p->nbases >> 4] |= (uint32_t)code << (30 - 2 * (p->nbases & 15));
+	p->nbases++;
+}
+
+/* one sequence line -> stream; returns coded length */
+static int encode_line(packer_t *pk, const char *s, int n, int max_read_len, int reverse)
+{
+	unsigned char tmp[8192];
+	unsigned char *codes = tmp;
+	if (n > max_read_len) n = max_read_len;
+	if (n > (int)sizeof tmp) codes = (unsigned char *)malloc((size_t)n);
+	int m = 0;
+	for (int i = 0; i < n; i++) {
+		unsigned char c = (unsigned char)s[i];
+		if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 'a' + 'A');
+		if (c >= 'A' && c <= 'Z') codes[m++] = (unsigned char)((c & 6) >> 1);
+		else if (c == '.') codes[m++] = 0;
+	}
+	pk_reserve(pk, (uint64_t)m);
+	if (!reverse)
+		for (int i = 0; i < m; i++) pk_put(pk, codes[i]);
+	else
+		for (int i = m - 1; i >= 0; i--) pk_put(pk, codes[i] ^ 2u);
+	if (codes != tmp) free(codes);
+	return m;
+}
+
+static inline const char *line_end(const char *p, const char *end)
+{
+	const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+	return q ? q : end;
+}
+
+static void parse_chunk(job_t *J, chunk_t *c)
+{
+	packer_t pk = {0};
+	uint64_t cap_off = 1024, n = 0;
+	uint64_t *offs = (uint64_t *)malloc(cap_off * sizeof(uint64_t));
+	offs[0] = 0;
+	const char *p = c->beg, *end = c->end;
+	pk_reserve(&pk, 0);
+	while (p < end) {
+		const char *e = line_end(p, end);             /* header line */
+		if (e == p) { p = e + 1; continue; }          /* blank line between records */
+		const char *seq = e < end ? e + 1 : end;
+		int len = 0;
+		if (J->fmt == 'q') {
+			const char *se = line_end(seq, end);
+			int sl = (int)(se - seq);
+			if (sl > 0 && seq[sl - 1] == '\r') sl--;
+			len = encode_line(&pk, seq, sl, J->max_read_len, J->reverse);
+			const char *plus = se < end ? se + 1 : end;
+			const char *pe = line_end(plus, end);
+			const char *qual = pe < end ? pe + 1 : end;
+			const char *qe = line_end(qual, end);
+			p = qe < end ? qe + 1 : end;
+		} else {
+			/* FASTA: sequence lines up to the next '>' at a line start are one read (the reference only
+			 * handles the one-line form correctly; multi-line records are concatenated here) */
+			char stackbuf[16384];
+			char *buf = stackbuf;
+			size_t bl = 0, bcap = sizeof stackbuf;
+			const char *q = seq;
+			while (q < end && *q != '>') {
+				const char *se = line_end(q, end);
+				size_t sl = (size_t)(se - q);
+				if (sl > 0 && q[sl - 1] == '\r') sl--;
+				if (bl + sl > bcap) {
+					bcap = (bl + sl) * 2;
+					char *nb = (char *)malloc(bcap);
+					memcpy(nb, buf, bl);
+					if (buf != stackbuf) free(buf);
+					buf = nb;
+				}
+				memcpy(buf + bl, q, sl);
+				bl += sl;
+				q = se < end ? se + 1 : end;
+			}
+			len = encode_line(&pk, buf, (int)bl, J->max_read_len, J->reverse);
+			if (buf != stackbuf) free(buf);
+			p = q;
+		}
+		if (n + 2 > cap_off) {
+			cap_off *= 2;
+			offs = (uint64_t *)realloc(offs, cap_off * sizeof(uint64_t));
+		}
+		offs[n + 1] = offs[n] + (uint64_t)len;
+		n++;
+	}
+	c->out.words = pk.w;
+	c->out.nwords = ((pk.nbases + 15) >> 4) + 4;          /* pk_reserve keeps >= 8 zero words of slack */
+	c->out.offsets = offs;
+	c->out.nreads = n;
+}
+
+static void *worker(void *arg)
+{
+	job_t *J = (job_t *)arg;
+	for (;;) {
+		pthread_mutex_lock(&J->mu);
+		int i = J->next < J->nchunks ? J->next++ : -1;
+		pthread_mutex_unlock(&J->mu);
+		if (i < 0) break;
+		parse_chunk(J, &J->chunks[i]);
+		pthread_mutex_lock(&J->mu);
+		J->chunks[i].done = 1;
+		pthread_cond_broadcast(&J->cv);
+		pthread_mutex_unlock(&J->mu);
+	}
+	return NULL;
+}
+
+/* first record start at or after p: FASTQ = a line starting with '@' whose line+2 starts with '+';
+ * FASTA = a line starting with '>' */
+static const char *record_start(const char *base, const char *p, const char *end, int fmt)
+{
+	if (p <= base) return base;
+	/* move to the start of the next line */
+	const char *q = line_end(p - 1, end);
+	p = q < end ? q + 1 : end;
+	while (p < end) {
+		if (fmt == 'a') {
+			if (*p == '>') return p;
+		} else if (*p == '@') {
+			const char *l1 = line_end(p, end);
+			const char *l2 = l1 < end ? line_end(l1 + 1, end) : end;
+			if (l2 < end && l2 + 1 < end && l2[1] == '+') return p;
+		}
+		const char *e = line_end(p, end);
+		p = e < end ? e + 1 : end;
+	}
+	return end;
+}
+
+int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int threads, size_t chunk_bytes,
+                  sdt_batch_fn fn, void *user, uint64_t *nreads_out)
+{
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) {
+		printf("Cannot open %s. Now exit to system...\n", path);
+		return -1;
+	}
+	struct stat st;
+	fstat(fd, &st);
+	size_t size = (size_t)st.st_size;
+	if (nreads_out) *nreads_out = 0;
+	if (size == 0) { close(fd); return 0; }
+	const char *base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+	if (base == MAP_FAILED) {
+		printf("mmap of %s failed\n", path);
+		close(fd);
+		return -1;
+	}
+	madvise((void *)base, size, MADV_SEQUENTIAL);
+	const char *end = base + size;
+	int nchunks = (int)((size + chunk_bytes - 1) / chunk_bytes);
+	job_t J;
+	memset(&J, 0, sizeof J);
+	J.chunks = (chunk_t *)calloc((size_t)nchunks, sizeof(chunk_t));
+	J.fmt = fmt; J.max_read_len = max_read_len; J.reverse = reverse;
+	const char *prev = record_start(base, base, end, fmt);
+	int nc = 0;
+	for (int i = 1; i <= nchunks; i++) {
+		const char *cut = i == nchunks ? end : record_start(base, base + (size_t)i * chunk_bytes, end, fmt);
+		if (cut > prev) {
+			J.chunks[nc].beg = prev;
+			J.chunks[nc].end = cut;
+			nc++;
+			prev = cut;
+		}
+	}
+	J.nchunks = nc;
+	pthread_mutex_init(&J.mu, NULL);
+	pthread_cond_init(&J.cv, NULL);
+	if (threads < 1) threads = 1;
+	if (threads > nc) threads = nc > 0 ? nc : 1;
+	pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+	for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, worker, &J);
+	int rc = 0;
+	uint64_t total = 0;
+	for (int i = 0; i < nc; i++) {
+		pthread_mutex_lock(&J.mu);
+		while (!J.chunks[i].done) pthread_cond_wait(&J.cv, &J.mu);
+		pthread_mutex_unlock(&J.mu);
+		if (rc == 0 && fn(user, &J.chunks[i].out) != 0) rc = -1;
+		total += J.chunks[i].out.nreads;
+		free(J.chunks[i].out.words);
+		free(J.chunks[i].out.offsets);
+	}
+	for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+	free(th);
+	free(J.chunks);
+	pthread_mutex_destroy(&J.mu);
+	pthread_cond_destroy(&J.cv);
+	munmap((void *)base, size);
+	close(fd);
+	if (nreads_out) *nreads_out = total;
+	return rc;
+}

@@ -1,0 +1,28 @@
+/* seqio.h -- read ingest for the MI355X pregraph host: mmap + parallel parse of FASTQ / FASTA straight
+ * into the packed 2-bit stream of include/sdt_gpu.h.
+ *
+ * Reference semantics kept (readseq1by1.c:122-178 readseqInBuf, :281-340 readseqfq): the sequence line is
+ * cut to max_read_len characters first; then lowercase is folded, letters are coded (c & 6) >> 1 (A0 C1 T2
+ * G3, N and every other letter by their bits), '.' is A, anything else is dropped; reverse_seq libraries
+ * reverse-complement every read (reverse2k :749-764).  NOT kept: the 32 KiB POSIX-AIO chunker
+ * (prlHashReads.c:718-806) and its hang on files that are a multiple of 32768 bytes. */
+#ifndef SDT_SEQIO_H
+#define SDT_SEQIO_H
+#include <stdint.h>
+#include <stddef.h>
+
+typedef struct {
+	uint32_t *words;        /* packed stream, 4 zero pad words at the end */
+	uint64_t nwords;
+	uint64_t *offsets;      /* nreads + 1, in bases */
+	uint64_t nreads;        /* every record of the chunk, also reads shorter than K+1 (the device skips them) */
+} sdt_batch;
+
+typedef int (*sdt_batch_fn)(void *user, const sdt_batch *b);
+
+/* Parse one file with `threads` workers; call `fn` on the calling thread for each batch in file order.
+ * fmt: 'q' FASTQ, 'a' FASTA.  Returns 0, or -1 after printing a message. */
+int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int threads, size_t chunk_bytes,
+                  sdt_batch_fn fn, void *user, uint64_t *nreads_out);
+
+#endif
