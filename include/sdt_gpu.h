@@ -43,6 +43,10 @@ enum {
 
 typedef struct sdt_ctx sdt_ctx;
 
+/* sdt_gpu_init flags: pick the pass-1 kernel family (default: DIRECT).  Both give identical tables. */
+#define SDT_FLAG_DIRECT    1u   /* always one device atomic per k-mer occurrence (k_count_reads) */
+#define SDT_FLAG_PARTITION 2u   /* always partition -> count in LDS -> one merge per distinct key (K <= 31) */
+
 /* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
  * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
  * prev/next the neighbour base codes 0..3 or SDT_REC_NB_NONE (prlHashReads.c:215-230,275-308). */

@@ -22,6 +22,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
+SDT_FLAG_DIRECT, SDT_FLAG_PARTITION = 1, 2
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
@@ -126,11 +127,11 @@ class PregraphGPU:
     """One device context: mirrors sdt_gpu_* one to one (see include/sdt_gpu.h for the reference
     call sites each method replaces)."""
 
-    def __init__(self, K: int, est_distinct: int = 0, device: int = 0):
+    def __init__(self, K: int, est_distinct: int = 0, device: int = 0, flags: int = 0):
         self.lib = load_library()
         self.K = K
         self._ctx = ctypes.c_void_p()
-        rc = self.lib.sdt_gpu_init(ctypes.byref(self._ctx), device, K, est_distinct, 0)
+        rc = self.lib.sdt_gpu_init(ctypes.byref(self._ctx), device, K, est_distinct, flags)
         self._check(rc)
         self.nw = self.lib.sdt_gpu_key_words(self._ctx)
 

@@ -26,6 +26,7 @@
 #include "../../include/sdt_gpu.h"
 #include "sdt_kmer.cuh"
 #include "sdt_table.cuh"
+#include "sdt_partition.cuh"
 
 using namespace sdt;
 
@@ -421,6 +422,8 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+#include "sdt_partition_kernels.cuh"
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -453,6 +456,11 @@ struct sdt_ctx {
 	uint64_t kmers_total_host = 0;
 	// route scratch
 	unsigned long long *d_cursors = nullptr;
+	// locality pipeline (1-word keys)
+	uint32_t flags = 0;
+	PartBufs pb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	uint64_t part_cap = 0;             // records A and B can hold
+	unsigned long long *h_off2 = nullptr;   // pinned copy of off2 (NBF + 1)
 	// timing
 	std::vector<EventPair> ev;
 	size_t ev_used = 0;
@@ -603,7 +611,6 @@ uint64_t sdt_owner_hash(const uint64_t *key_words_msw_first, int nwords)
 
 int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32_t flags)
 {
-	(void)flags;
 	if (!out)
 		return fail(SDT_EINVAL, "ctx is NULL");
 	*out = nullptr;
@@ -631,6 +638,7 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	c->device = device;
 	c->K = K;
 	c->nw = K <= 31 ? 1 : (K <= 63 ? 2 : 4);
+	c->flags = flags;
 	c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (est_distinct == 0)
 		est_distinct = 1ULL << 22;
@@ -691,6 +699,14 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
 	if (c->d_cursors) (void)hipFree(c->d_cursors);
+	if (c->pb.hist) (void)hipFree(c->pb.hist);
+	if (c->pb.off2) (void)hipFree(c->pb.off2);
+	if (c->pb.cursor1) (void)hipFree(c->pb.cursor1);
+	if (c->pb.cursor2) (void)hipFree(c->pb.cursor2);
+	if (c->pb.tile1) (void)hipFree(c->pb.tile1);
+	if (c->pb.A) (void)hipFree(c->pb.A);
+	if (c->pb.B) (void)hipFree(c->pb.B);
+	if (c->h_off2) (void)hipHostFree(c->h_off2);
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	delete c;
@@ -741,6 +757,108 @@ int sdt_gpu_set_stream(sdt_ctx *c, void *hip_stream)
 // "every occurrence is a new node" cannot overflow the table between two looks at the node counter.
 static const uint64_t CHUNK_KMERS = 1ULL << 27;
 
+
+
+// ------------------------------------------------------------------------------------------------
+// locality pipeline (sdt_partition.cuh): partition -> LDS count -> one merge per distinct key
+// ------------------------------------------------------------------------------------------------
+static const uint64_t PART_BATCH_RECORDS = 1ULL << 31;      // records per batch (A and B: 16 GiB each at most)
+
+static int part_alloc(sdt_ctx *c, uint64_t records)
+{
+	if (!c->pb.hist) {
+		HIPCHK(hipMalloc((void **)&c->pb.hist, NBF * sizeof(unsigned int)));
+		HIPCHK(hipMalloc((void **)&c->pb.off2, (NBF + 1) * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void **)&c->pb.cursor1, NB1 * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void **)&c->pb.cursor2, NBF * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void **)&c->pb.tile1, (NB1 + 1) * sizeof(unsigned int)));
+		HIPCHK(hipHostMalloc((void **)&c->h_off2, (NBF + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	if (c->part_cap < records) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (c->pb.A) HIPCHK(hipFree(c->pb.A));
+		if (c->pb.B) HIPCHK(hipFree(c->pb.B));
+		c->pb.A = c->pb.B = nullptr;
+		c->part_cap = 0;
+		hipError_t e = hipMalloc((void **)&c->pb.A, records * sizeof(uint64_t));
+		if (e == hipSuccess)
+			e = hipMalloc((void **)&c->pb.B, records * sizeof(uint64_t));
+		if (e != hipSuccess)
+			return fail(SDT_ENOMEM, "partition buffers (2 x %llu records): %s", (unsigned long long)records, hipGetErrorString(e));
+		c->part_cap = records;
+	}
+	return SDT_OK;
+}
+
+static int launch_count_partitioned(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads,
+                                    uint64_t max_read_len)
+{
+	const int mtw = tile_words_for(max_read_len);
+	const size_t tile_bytes = tile_smem_bytes(mtw);
+	const int tile_words = (int)((tile_bytes / sizeof(uint32_t) + 1) & ~(size_t)1);      // even: 8-byte alignment behind it
+	const size_t smem_hist = (size_t)tile_words * 4 + NBF * sizeof(uint32_t);
+	const size_t smem_l1 = (size_t)tile_words * 4 + 2 * NB1 * sizeof(uint32_t) + NB1 * sizeof(unsigned long long);
+	if (smem_hist > 160 * 1024)
+		return fail(SDT_EINVAL, "max read length %llu does not fit the LDS tile of the partition path", (unsigned long long)max_read_len);
+	static bool attr_set = false;
+	if (!attr_set) {
+		HIPCHK(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		attr_set = true;
+	}
+	const PartGeom geo{2 * c->K, 2 * c->K - L1BITS - L2BITS};
+	const uint64_t per_read = max_read_len - c->K + 1;
+	uint64_t batch_reads = PART_BATCH_RECORDS / per_read;
+	batch_reads = batch_reads / TILE_READS * TILE_READS;
+	if (batch_reads > nreads)
+		batch_reads = (nreads + TILE_READS - 1) / TILE_READS * TILE_READS;
+	int rc = part_alloc(c, batch_reads * per_read);
+	if (rc != SDT_OK)
+		return rc;
+	for (uint64_t r0 = 0; r0 < nreads; r0 += batch_reads) {
+		const uint64_t nr = nreads - r0 < batch_reads ? nreads - r0 : batch_reads;
+		const uint64_t ntiles = (nr + TILE_READS - 1) / TILE_READS;
+		unsigned grid = (unsigned)(ntiles < (uint64_t)c->cu_count * 2 ? ntiles : (uint64_t)c->cu_count * 2);
+		EventPair *ev = next_event(c);
+		if (!ev)
+			return fail(SDT_EHIP, "hipEventCreate failed");
+		ev->kmers = nr * per_read;
+		HIPCHK(hipEventRecord(ev->a, c->stream));
+		HIPCHK(hipMemsetAsync(c->pb.hist, 0, NBF * sizeof(unsigned int), c->stream));
+		hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(PT_TPB), smem_hist, c->stream, d_words, d_offs + r0, nr, c->K, mtw,
+		                   tile_words, geo, c->pb.hist);
+		HIPCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, c->stream, c->pb);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(c->h_off2, c->pb.off2, (NBF + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+		unsigned grid1 = (unsigned)(ntiles < (uint64_t)c->cu_count * 8 ? ntiles : (uint64_t)c->cu_count * 8);
+		hipLaunchKernelGGL(k_part_l1, dim3(grid1), dim3(PT_TPB), smem_l1, c->stream, d_words, d_offs + r0, nr, c->K, mtw, tile_words,
+		                   geo, c->pb);
+		HIPCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_part_l2, dim3((unsigned)c->cu_count * 8), dim3(PT_TPB), 0, c->stream, geo, c->pb);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(c->stream));          // h_off2 is valid; A/B are complete
+		// final stage in slices of buckets small enough for the "every record is a new node" growth bound
+		unsigned f0 = 0;
+		while (f0 < (unsigned)NBF) {
+			unsigned f1 = f0;
+			while (f1 < (unsigned)NBF && (f1 == f0 || c->h_off2[f1 + 1] - c->h_off2[f0] <= CHUNK_KMERS))
+				f1++;
+			const uint64_t recs = c->h_off2[f1] - c->h_off2[f0];
+			if (recs) {
+				rc = ensure_room(c, recs);
+				if (rc != SDT_OK)
+					return rc;
+				hipLaunchKernelGGL(k_part_final, dim3(f1 - f0), dim3(FIN_TPB), 0, c->stream, geo, c->pb, f0, table_of<1>(c), c->d_stats);
+				HIPCHK(hipGetLastError());
+				c->kmers_since_sync += recs;
+			}
+			f0 = f1;
+		}
+		HIPCHK(hipEventRecord(ev->b, c->stream));
+	}
+	return SDT_OK;
+}
+
 static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads,
                         uint64_t max_read_len)
 {
@@ -754,6 +872,10 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 		return fail(SDT_EINVAL, "max read length %llu needs %zu B of LDS per tile (limit 64 KiB)",
 		            (unsigned long long)max_read_len, smem);
 	const uint64_t per_read = max_read_len - c->K + 1;
+	// The locality pipeline is opt-in in round 1: on MI355X it measures 11 G k-mers/s against the direct
+	// kernel's 19.5 G (profiles/r1/partition_pipeline_50M.md has the per-stage rates and what has to change).
+	if (c->nw == 1 && (c->flags & SDT_FLAG_PARTITION) && !(c->flags & SDT_FLAG_DIRECT))
+		return launch_count_partitioned(c, d_words, d_offs, nreads, max_read_len);
 	uint64_t chunk_reads = CHUNK_KMERS / per_read;
 	chunk_reads = chunk_reads / TILE_READS * TILE_READS;
 	if (chunk_reads < TILE_READS)

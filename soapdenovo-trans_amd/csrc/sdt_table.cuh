@@ -87,6 +87,61 @@ __device__ inline void node_update(uint64_t *val, uint32_t *aux, uint64_t seen, 
 	}
 }
 
+// many occurrences of one key at once: `add` has the layout of `val` (count low 16 | r_links | l_links) with every
+// 6-bit field already clamped to 63.  min(63, a + b) per field is exactly what replaying the occurrences one
+// by one through update_kmer (newhash.c:71-96) would leave.
+__device__ inline void node_merge(uint64_t *val, uint32_t *aux, uint64_t seen, uint64_t add)
+{
+	for (;;) {
+		uint64_t nv = 0;
+#pragma unroll
+		for (int f = 0; f < 8; f++) {
+			const uint32_t a = (uint32_t)(seen >> (6 * f)) & 63u, b = (uint32_t)(add >> (6 * f)) & 63u;
+			const uint32_t s = a + b > 63u ? 63u : a + b;
+			nv |= (uint64_t)s << (6 * f);
+		}
+		const uint32_t c = (uint32_t)(seen >> 48) + (uint32_t)(add >> 48);
+		nv |= (uint64_t)(c & 0xFFFFu) << 48;
+		const uint64_t got = atomicCAS((unsigned long long *)val, (unsigned long long)seen, (unsigned long long)nv);
+		if (got == seen) {
+			if (c >> 16)
+				atomicAdd(aux, c >> 16);
+			return;
+		}
+		seen = got;
+	}
+}
+
+// put_kmerset for an aggregated record (1-word keys)
+__device__ inline bool table_merge(const Table<1> &t, uint64_t key, uint64_t add, uint32_t &claimed)
+{
+	Key<1> k{{key}};
+	uint64_t slot = key_hash<1>(k) & t.mask;
+	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
+	for (uint64_t probe = 0; probe < max_probe; probe++) {
+		Entry<1> *e = t.ent + slot;
+		const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(e);
+		uint64_t k0 = kv.x, seen = kv.y;
+		if (k0 == KEY_EMPTY) {
+			const uint64_t old = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY,
+			                               (unsigned long long)key);
+			if (old == KEY_EMPTY) {
+				claimed++;
+				k0 = key;
+			} else {
+				k0 = old;
+			}
+			seen = 0;
+		}
+		if (k0 == key) {
+			node_merge(&e->val, t.aux + slot, seen, add);
+			return true;
+		}
+		slot = (slot + 1) & t.mask;
+	}
+	return false;
+}
+
 // put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
 template <int NW>
 __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_t prev, uint32_t next,

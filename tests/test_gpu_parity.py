@@ -35,15 +35,19 @@ def node_dict_oracle(o):
     return {k: (int(a), int(b), f(c), int(d)) for k, a, b, c, d in zip(ki, l, r, fl, cnt)}
 
 
+MODES = [1, 2]     # SDT_FLAG_DIRECT, SDT_FLAG_PARTITION (the latter only changes the K <= 31 path)
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", gu.case_names())
-def test_golden_case_kmerfreq_bit_identical(pkg, name):
+def test_golden_case_kmerfreq_bit_identical(pkg, name, mode):
     """reference binary's *.kmerFreq reproduced byte for byte by the GPU path"""
     info = gu.load_case(name)
     K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[info["variant"]])
     codes, offs = gu.case_reads(info)
     from soapdenovo_trans_amd import synth
     words = synth.pack_2bit(codes)
-    with pkg.PregraphGPU(K, est_distinct=1 << 17) as g:
+    with pkg.PregraphGPU(K, est_distinct=1 << 17, flags=mode) as g:
         g.push_reads(words, offs)
         kmers, nodes = g.finish_count()
         assert kmers == info["kmer_in_reads"]
@@ -55,16 +59,19 @@ def test_golden_case_kmerfreq_bit_identical(pkg, name):
         assert pkg.kmerfreq_text(hist) == gu.golden_text(info, "kmerFreq")
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (31, 150, True), (33, 150, True),
                                         (63, 250, False), (65, 200, True), (127, 250, True)])
-def test_node_table_equals_oracle(pkg, synth, K, L, ragged):
+def test_node_table_equals_oracle(pkg, synth, K, L, ragged, mode):
+    if mode == 2 and K > 31:
+        pytest.skip("the partition path is the 1-word-key path")
     """every node: key, 8 saturating link counters, count, single/linear/deleted flags"""
     tx = synth.make_transcriptome(25, seed=K)
     codes, offs = synth.sample_reads(*tx, n_reads=6000, read_len=L, seed=K + 1, err=0.003, ragged=ragged)
     words = synth.pack_2bit(codes)
     o = ob.Oracle(K, nsets=5)
     o.add_reads(codes, offs)
-    with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:        # small table: forces growth by rebuild
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=mode) as g:        # small table: forces growth by rebuild
         half = len(offs) // 2
         # two pushes with different batch geometry (second batch starts mid-stream)
         w1 = synth.pack_2bit(codes[: int(offs[half])])
@@ -83,7 +90,8 @@ def test_node_table_equals_oracle(pkg, synth, K, L, ragged):
             assert node_dict_gpu(g) == node_dict_oracle(o)
 
 
-def test_saturation_and_hot_keys(pkg, synth):
+@pytest.mark.parametrize("mode", MODES)
+def test_saturation_and_hot_keys(pkg, synth, mode):
     """poly-A and tandem repeats: one key hit tens of thousands of times from every lane of a wave --
     6-bit counters must stop at 63, count must not (and must carry past 16 bits into aux)"""
     K = 21
@@ -93,7 +101,7 @@ def test_saturation_and_hot_keys(pkg, synth):
     offs = (np.arange(n + 1) * L).astype(np.uint64)
     o = ob.Oracle(K, nsets=3)
     o.add_reads(codes, offs)
-    with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=mode) as g:
         g.push_reads(synth.pack_2bit(codes), offs)
         kmers, nodes = g.finish_count()
         assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
@@ -105,10 +113,11 @@ def test_saturation_and_hot_keys(pkg, synth):
         assert max(v[3] for v in gd.values()) > 65536
 
 
-def test_edge_cases(pkg, synth):
+@pytest.mark.parametrize("mode", MODES)
+def test_edge_cases(pkg, synth, mode):
     """empty batch, reads shorter than K+1 (skipped, prlHashReads.c:592), a read of exactly K+1, reset"""
     K = 25
-    with pkg.PregraphGPU(K) as g:
+    with pkg.PregraphGPU(K, flags=mode) as g:
         g.push_reads(np.zeros(4, dtype=np.uint32), np.zeros(1, dtype=np.uint64))       # zero reads
         assert g.finish_count() == (0, 0)
         rng = np.random.default_rng(1)
@@ -128,14 +137,15 @@ def test_edge_cases(pkg, synth):
         assert hist.sum() == 0 and lin == 0
 
 
-def test_device_resident_batch_and_properties(pkg, synth):
+@pytest.mark.parametrize("mode", MODES)
+def test_device_resident_batch_and_properties(pkg, synth, mode):
     """device entry point on a torch-generated workload: size-independent properties + oracle on a slice"""
     import torch
     dev = torch.device("cuda:0")
     K, L, n = 31, 150, 200_000
     words, offsets, nwords = synth.torch_workload(n, L, T=300, device=dev, seed=11)
     torch.cuda.synchronize()
-    with pkg.PregraphGPU(K, est_distinct=1 << 22) as g:
+    with pkg.PregraphGPU(K, est_distinct=1 << 22, flags=mode) as g:
         g.count_reads_device(words, nwords, offsets, n, L)
         kmers, nodes = g.finish_count()
         assert kmers == n * (L - K + 1)
