@@ -1,0 +1,291 @@
+/*
+ * sdt_oracle_graph.c -- CPU restatement of the k-mer-graph cleaning passes of `pregraph`
+ * (cutTipPreGraph.c: removeMinorOut / clipKmerFromNode, removeSingleTips / removeMinorTips / clipTipFromNode,
+ * Mark1in1outNode) and of output_vertex.  TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).
+ *
+ * These passes are ORDER DEPENDENT (survey 7.3-1): they visit set 0..p-1, slot 0..size-1 of the reference's
+ * table layout and mutate neighbours as they go.  The oracle's sets have that exact layout (sdto_set_put is a
+ * bit-exact put_kmerset), so running the passes here reproduces the reference's result for the same -p.
+ * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files.
+ */
+#include "sdt_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FL_NULL(f, i) (((f)[(i) >> 4] >> (((i) & 0x0f) << 1)) & 0x01)
+
+static inline uint32_t lcov(const sdto_node *n, int b) { return (n->l_links >> (6 * b)) & 0x3f; }
+static inline uint32_t rcov(const sdto_node *n, int b) { return (n->r_links >> (6 * b)) & 0x3f; }
+static inline void lzero(sdto_node *n, int b) { n->l_links &= ~(0x3fu << (6 * b)); }
+static inline void rzero(sdto_node *n, int b) { n->r_links &= ~(0x3fu << (6 * b)); }
+
+/* newhash.c:510-538 */
+static int branch2prev(const sdto_node *n) { int c = 0; for (int b = 0; b < 4; b++) c += lcov(n, b) > 0; return c; }
+static int branch2next(const sdto_node *n) { int c = 0; for (int b = 0; b < 4; b++) c += rcov(n, b) > 0; return c; }
+
+/* newhash.c:540-562: orientation-aware removal of one link */
+static void dislink2prev(sdto_node *n, int ch, int smaller) { if (smaller) lzero(n, ch); else rzero(n, ch ^ 2); }
+static void dislink2next(sdto_node *n, int ch, int smaller) { if (smaller) rzero(n, ch); else lzero(n, ch ^ 2); }
+
+/* the lookup every pass uses: canonicalise (KmerLarger(word, bal) -> take bal, smaller = 0), pick the set by
+ * hash_kmer % thrd_num, search_kmerset; a miss is fatal in the reference (exit(1), cutTipPreGraph.c:124-140) */
+static sdto_node *find_oriented(sdto_sets *S, sdto_kmer word, int *smaller, sdto_kmer *canon_out)
+{
+	sdto_kmer bal = sdto_reverse_complement(word, S->K);
+	sdto_kmer canon = word;
+	*smaller = 1;
+	if (sdto_kmer_smaller(bal, word)) {          /* KmerLarger(word, bal_word) */
+		canon = bal;
+		*smaller = 0;
+	}
+	if (canon_out) *canon_out = canon;
+	sdto_set *set = S->sets[sdto_hash_kmer(canon, S->nw) % (uint64_t)S->nsets];
+	uint64_t slot;
+	if (!sdto_set_search(set, canon, S->nw, &slot)) {
+		fprintf(stderr, "oracle: kmer %llx %llx %llx %llx not found\n", (unsigned long long)canon.w[0],
+		        (unsigned long long)canon.w[1], (unsigned long long)canon.w[2], (unsigned long long)canon.w[3]);
+		abort();
+	}
+	return set->array + slot;
+}
+
+/* cutTipPreGraph.c:1121-1229 thread_mark + Mark1in1outNode: only ever SETS linear, skips deleted / already linear */
+static uint64_t mark_more_linear(sdto_sets *S)
+{
+	uint64_t n = 0;
+	for (int t = 0; t < S->nsets; t++) {
+		sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++) {
+			if (FL_NULL(s->flags, i)) continue;
+			sdto_node *rs = s->array + i;
+			if (rs->deleted || rs->linear) continue;
+			if (branch2prev(rs) == 1 && branch2next(rs) == 1) {
+				rs->linear = 1;
+				n++;
+			}
+		}
+	}
+	return n;
+}
+
+/* ---- clipKmerFromNode (cutTipPreGraph.c:591-1010) ---- */
+
+/* after q was judged a minor branch: q.deleted = 1 and every neighbour of q forgets its link to q
+ * (:685-820 and the mirrored :886-1005).  q's own links stay. */
+static void cut_out_node(sdto_sets *S, sdto_node *q)
+{
+	const sdto_kmer qseq = q->seq;
+	int K = S->K, smaller;
+	q->deleted = 1;
+	for (int ch = 0; ch < 4; ch++) {
+		if (!lcov(q, ch)) continue;
+		sdto_node *x = find_oriented(S, sdto_prev_kmer(qseq, ch, K), &smaller, NULL);
+		dislink2next(x, sdto_last_char(qseq), smaller);
+		x->linear = (branch2prev(x) == 1 && branch2next(x) == 1);
+	}
+	for (int ch = 0; ch < 4; ch++) {
+		if (!rcov(q, ch)) continue;
+		sdto_node *y = find_oriented(S, sdto_next_kmer(qseq, ch, K), &smaller, NULL);
+		dislink2prev(y, sdto_first_char(qseq, K), smaller);
+		y->linear = (branch2prev(y) == 1 && branch2next(y) == 1);
+	}
+}
+
+static void clip_kmer_from_node(sdto_sets *S, sdto_node *n1, double threshold, uint64_t *kmers_c)
+{
+	int K = S->K, smaller;
+	if (n1->linear || n1->deleted) return;
+	int in_num = branch2prev(n1), out_num = branch2next(n1);
+	if (in_num <= 1 && out_num <= 1) return;
+	if (in_num > 1) {
+		/* getmaxofprev (:439-513): max unsaturated count over the linked predecessors */
+		int maxIn = 0;
+		for (int c = 0; c < 4; c++)
+			if (lcov(n1, c)) {
+				sdto_node *p = find_oriented(S, sdto_prev_kmer(n1->seq, c, K), &smaller, NULL);
+				if ((int)p->count > maxIn) maxIn = (int)p->count;
+			}
+		if (maxIn) {
+			for (int c = 0; c < 4; c++) {
+				if (!lcov(n1, c)) continue;        /* read live: earlier cuts may have removed it (:626) */
+				sdto_node *p = find_oriented(S, sdto_prev_kmer(n1->seq, c, K), &smaller, NULL);
+				int temp = (int)p->count;
+				if (temp && (double)temp / maxIn < threshold) {
+					(*kmers_c)++;
+					cut_out_node(S, p);
+				}
+			}
+		}
+	}
+	if (out_num > 1) {                             /* out_num was sampled before the in-side cuts (:617,826) */
+		int maxOut = 0;
+		for (int c = 0; c < 4; c++)
+			if (rcov(n1, c)) {
+				sdto_node *p = find_oriented(S, sdto_next_kmer(n1->seq, c, K), &smaller, NULL);
+				if ((int)p->count > maxOut) maxOut = (int)p->count;
+			}
+		if (maxOut) {
+			for (int c = 0; c < 4; c++) {
+				if (!rcov(n1, c)) continue;
+				sdto_node *p = find_oriented(S, sdto_next_kmer(n1->seq, c, K), &smaller, NULL);
+				int temp = (int)p->count;
+				if (temp && (double)temp / maxOut < threshold) {
+					(*kmers_c)++;
+					cut_out_node(S, p);
+				}
+			}
+		}
+	}
+}
+
+uint64_t sdto_remove_minor_out(sdto_sets *S, int dd, uint64_t *more_linear)
+{
+	double threshold = (double)dd / 100;          /* :1014 */
+	uint64_t kmers_c = 0;
+	for (int t = 0; t < S->nsets; t++) {
+		sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++)
+			if (!FL_NULL(s->flags, i))
+				clip_kmer_from_node(S, s->array + i, threshold, &kmers_c);
+	}
+	uint64_t ml = mark_more_linear(S);
+	if (more_linear) *more_linear = ml;
+	return kmers_c;
+}
+
+/* ---- clipTipFromNode (cutTipPreGraph.c:43-337) ---- */
+static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin, uint64_t *tip_c)
+{
+	int K = S->K, smaller, ch1, ch;
+	sdto_kmer pre_word, word;
+	if (n1->linear || n1->deleted) return 0;
+	if (thin && !n1->single) return 0;
+	int in_num = branch2prev(n1), out_num = branch2next(n1);
+	if (in_num == 0 && out_num == 1) {
+		pre_word = n1->seq;
+		for (ch1 = 0; ch1 < 4; ch1++) if (rcov(n1, ch1)) break;
+		word = sdto_next_kmer(pre_word, ch1, K);
+	} else if (in_num == 1 && out_num == 0) {
+		pre_word = sdto_reverse_complement(n1->seq, K);
+		for (ch1 = 0; ch1 < 4; ch1++) if (lcov(n1, ch1)) break;
+		word = sdto_next_kmer(pre_word, ch1 ^ 2, K);
+	} else {
+		return 0;
+	}
+	int count = 1;
+	sdto_kmer canon;
+	sdto_node *o = find_oriented(S, word, &smaller, &canon);
+	/* from here `word` is the canonical form and `bal` its reverse complement, as in the reference */
+	while (o->linear) {
+		count++;
+		if (thin && !o->single) break;
+		if (count > cut_len) return 0;
+		if (smaller) {
+			pre_word = canon;                                         /* oriented = canonical */
+			for (ch = 0; ch < 4; ch++) if (rcov(o, ch)) break;
+			word = sdto_next_kmer(pre_word, ch, K);
+		} else {
+			pre_word = sdto_reverse_complement(canon, K);             /* oriented = the larger strand */
+			for (ch = 0; ch < 4; ch++) if (lcov(o, ch)) break;
+			word = sdto_next_kmer(pre_word, ch ^ 2, K);
+		}
+		o = find_oriented(S, word, &smaller, &canon);
+	}
+	if (branch2next(o) + branch2prev(o) == 1) {                        /* :282-288 isolated path */
+		(*tip_c)++;
+		n1->deleted = 1;
+		o->deleted = 1;
+		return 1;
+	}
+	ch = sdto_first_char(pre_word, K);
+	if (thin) {                                                        /* :293-300 */
+		(*tip_c)++;
+		n1->deleted = 1;
+		dislink2prev(o, ch, smaller);
+		o->linear = 0;
+		return 1;
+	}
+	uint32_t max_links = 0;                                            /* :303-322 */
+	for (int c = 0; c < 4; c++) {
+		uint32_t v = smaller ? lcov(o, c) : rcov(o, c);
+		if (v > max_links) max_links = v;
+	}
+	uint32_t mine = smaller ? lcov(o, ch) : rcov(o, ch ^ 2);
+	if (mine < max_links) {                                            /* :324-349 strict < */
+		(*tip_c)++;
+		n1->deleted = 1;
+		dislink2prev(o, ch, smaller);
+		if (branch2prev(o) == 1 && branch2next(o) == 1)
+			o->linear = 1;
+		return 1;
+	}
+	return 0;
+}
+
+uint64_t sdto_remove_single_tips(sdto_sets *S, uint64_t *more_linear)
+{
+	uint64_t tip_c = 0;
+	int cut_len = 2 * S->K;
+	for (int t = 0; t < S->nsets; t++) {
+		sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++)
+			if (!FL_NULL(s->flags, i))
+				clip_tip_from_node(S, s->array + i, cut_len, 1, &tip_c);
+	}
+	uint64_t ml = mark_more_linear(S);
+	if (more_linear) *more_linear = ml;
+	return tip_c;
+}
+
+uint64_t sdto_remove_minor_tips(sdto_sets *S, uint64_t *more_linear)
+{
+	uint64_t tip_c = 0;
+	int cut_len = 2 * S->K;
+	for (int t = 0; t < S->nsets; t++) {
+		sdto_set *s = S->sets[t];
+		int flag = 1;
+		while (flag) {                         /* fixed point PER SET before the next set (:385-408) */
+			flag = 0;
+			for (uint64_t i = 0; i < s->size; i++)
+				if (!FL_NULL(s->flags, i))
+					flag += clip_tip_from_node(S, s->array + i, cut_len, 0, &tip_c);
+		}
+	}
+	uint64_t ml = mark_more_linear(S);
+	if (more_linear) *more_linear = ml;
+	return tip_c;
+}
+
+/* output_vertex (output_pregraph.c:29-81): every !linear && !deleted node in table order, 8 per line,
+ * print_kmer format of the variant (kmer.c:499-516): MER31 "%llx" with 0 printed as "0x0"; MER63 two words;
+ * MER127 four words */
+uint64_t sdto_write_vertex(const sdto_sets *S, const char *path)
+{
+	FILE *fp = fopen(path, "w");
+	if (!fp) return 0;
+	uint64_t n = 0;
+	for (int t = 0; t < S->nsets; t++) {
+		const sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++) {
+			if (FL_NULL(s->flags, i)) continue;
+			const sdto_node *rs = s->array + i;
+			if (rs->linear || rs->deleted) continue;
+			n++;
+			const uint64_t *w = rs->seq.w;
+			if (S->nw == 4)
+				fprintf(fp, "%llx %llx %llx %llx", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
+			else if (S->nw == 2)
+				fprintf(fp, "%llx %llx", (unsigned long long)w[2], (unsigned long long)w[3]);
+			else if (w[3])
+				fprintf(fp, "%llx", (unsigned long long)w[3]);
+			else
+				fprintf(fp, "0x0");
+			fputc(' ', fp);
+			if (n % 8 == 0) fputc('\n', fp);
+		}
+	}
+	fputc('\n', fp);
+	fclose(fp);
+	return n;
+}

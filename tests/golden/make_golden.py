@@ -126,6 +126,13 @@ def make_case(c):
     m = re.search(r"(\d+) kmer removed", log)
     info["kmer_removed"] = int(m.group(1)) if m else None
     info["max_rd_len"] = max_rd_len
+    # graph-cleaning counters (cutTipPreGraph.c:367,434,1074; Mark1in1outNode :1227 prints after each pass)
+    info["kmers_off"] = int(re.search(r"(\d+) kmers off", log).group(1))
+    info["tips_off"] = [int(x) for x in re.findall(r"(\d+) tips off", log)]
+    info["linear_after"] = [int(x) for x in re.findall(r"(\d+) linear nodes", log)]
+    info["vertex_outputed"] = int(re.search(r"(\d+) vertex outputed", log).group(1))
+    with open(os.path.join(cdir, "stdout.log"), "w") as fo:
+        fo.write("".join(l + "\n" for l in log.splitlines() if "time spent" not in l and tmp not in l and "overall time" not in l))
     # fixtures
     for f in files:
         with open(f, "rb") as fi, gzip.GzipFile(os.path.join(cdir, os.path.basename(f) + ".gz"), "wb", mtime=0) as fo:

@@ -34,8 +34,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    src = os.path.join(ORACLE_DIR, "sdt_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sdt_oracle.c", "sdt_oracle_graph.c", "sdt_oracle.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
     L = C.CDLL(LIB)
     L.sdto_base2int.restype = C.c_int
@@ -86,6 +86,13 @@ def lib():
     L.sdto_write_kmerfreq.argtypes = [C.c_char_p, C.c_void_p]
     L.sdto_sets_export.restype = C.c_uint64
     L.sdto_sets_export.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    for name in ("sdto_remove_single_tips", "sdto_remove_minor_tips"):
+        getattr(L, name).restype = C.c_uint64
+        getattr(L, name).argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.sdto_remove_minor_out.restype = C.c_uint64
+    L.sdto_remove_minor_out.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.sdto_write_vertex.restype = C.c_uint64
+    L.sdto_write_vertex.argtypes = [C.c_void_p, C.c_char_p]
     _lib = L
     return L
 
@@ -139,6 +146,22 @@ class Oracle:
         hist = np.zeros(257, dtype=np.int64)
         lin = self.L.sdto_sets_mark(self.h, hist.ctypes.data)
         return hist, lin
+
+    # graph cleaning (cutTipPreGraph.c); each returns (count printed by the pass, "linear nodes" of its closing mark)
+    def remove_minor_out(self, dd=5):
+        ml = C.c_uint64()
+        return self.L.sdto_remove_minor_out(self.h, dd, C.byref(ml)), ml.value
+
+    def remove_single_tips(self):
+        ml = C.c_uint64()
+        return self.L.sdto_remove_single_tips(self.h, C.byref(ml)), ml.value
+
+    def remove_minor_tips(self):
+        ml = C.c_uint64()
+        return self.L.sdto_remove_minor_tips(self.h, C.byref(ml)), ml.value
+
+    def write_vertex(self, path):
+        return self.L.sdto_write_vertex(self.h, path.encode())
 
     def export(self):
         n = self.node_count()

@@ -129,6 +129,45 @@ def test_case_kmerfreq(name):
     assert f" K {K}\n" in gu.golden_text(info, "preGraphBasic")
 
 
+def run_oracle_pregraph(info, pkg):
+    """pass 1 + the three cleaning passes in call_pregraph's order (pregraph.c:63-89)"""
+    variant = info["variant"]
+    K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
+    codes, offs = gu.case_reads(info)
+    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant])
+    o.add_reads(codes, offs)
+    if info["d"]:
+        o.delow(info["d"])
+    _, linear0 = o.mark()
+    counters = {"linear_after": [linear0], "tips_off": []}
+    k, ml = o.remove_minor_out(5)
+    counters["kmers_off"] = k
+    counters["linear_after"].append(ml)
+    if not info["d"]:                                  # pregraph.c:73-80: single tips only when -d is off
+        t, ml = o.remove_single_tips()
+        counters["tips_off"].append(t)
+        counters["linear_after"].append(ml)
+    t, ml = o.remove_minor_tips()
+    counters["tips_off"].append(t)
+    counters["linear_after"].append(ml)
+    return o, counters
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_case_vertex(name, tmp_path, pkg):
+    """minor-out + tip cutting (cutTipPreGraph.c) restated: the counters every pass prints and the final
+    *.vertex file (every surviving non-linear node, in the reference's table order) are byte-identical to what
+    the reference binary produced at the same -p"""
+    info = gu.load_case(name)
+    o, c = run_oracle_pregraph(info, pkg)
+    assert c["kmers_off"] == info["kmers_off"]
+    assert c["tips_off"] == info["tips_off"]
+    assert c["linear_after"] == info["linear_after"]
+    out = str(tmp_path / "out.vertex")
+    assert o.write_vertex(out) == info["vertex_outputed"]
+    assert open(out).read() == gu.golden_text(info, "vertex")
+
+
 def test_chop_matches_definition():
     """chopKmer4read restatement vs. the closed form of SURVEY 9.1 (independent of the rolling update)"""
     rng = np.random.default_rng(3)
