@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 1
+#define SDT_ABI_VERSION 2
 
 enum {
 	SDT_OK       = 0,
@@ -46,6 +46,10 @@ typedef struct sdt_ctx sdt_ctx;
 /* sdt_gpu_init flags: pick the pass-1 kernel family (default: DIRECT).  Both give identical tables. */
 #define SDT_FLAG_DIRECT    1u   /* always one device atomic per k-mer occurrence (k_count_reads) */
 #define SDT_FLAG_PARTITION 2u   /* always partition -> count in LDS -> one merge per distinct key (K <= 31) */
+/* Track, per node, the ordinal of its first occurrence in the read stream: (read ordinal << 16) | position.
+ * The reference's table layout -- hence the visiting order of its cutting passes, the order of *.vertex and the
+ * edge ids -- is a function of exactly this order; the host replays it (csrc/host/graph). */
+#define SDT_FLAG_TRACK_FIRST 4u
 
 /* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
  * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
@@ -74,6 +78,11 @@ int sdt_gpu_reset(sdt_ctx *ctx);
  * buffered) and returns once the buffers may be reused.  Reads shorter than K+1 are skipped (:592). */
 int sdt_gpu_push_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords,
                        const uint64_t *offsets, uint64_t nreads);
+
+/* Read ordinals of the NEXT batch: read i of it gets ordinal base + i*stride; afterwards the base advances by
+ * nreads*stride.  Only needed with SDT_FLAG_TRACK_FIRST when the stream is not consumed file after file: the
+ * reference interleaves paired files read1, read2, read1, ... (prlHashReads.c:493-567) = stride 2, base 0 / 1. */
+int sdt_gpu_set_read_ordinal(sdt_ctx *ctx, uint64_t base, uint64_t stride);
 
 /* Same, for a batch that is already resident in device memory (device pointers; the bench and the
  * multi-GPU driver use this).  Asynchronous on the context's stream.  max_read_len bounds the longest
@@ -119,9 +128,10 @@ int sdt_gpu_mark_and_hist(sdt_ctx *ctx, int64_t hist[257], uint64_t *linear);
  *   r_flags  : the second 32-bit word of kmer_t (inc/newhash.h:69-75): r_links:24 | linear<<24 |
  *              deleted<<25 | checked<<26 | single<<27 | twin<<28 | inEdge<<30
  *   count    : kmer_t.count
+ *   first    : first-occurrence ordinal (needs SDT_FLAG_TRACK_FIRST)
  * Any array may be NULL.  *n receives the node count. */
 int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags,
-                         uint32_t *count, uint64_t max_nodes, uint64_t *n);
+                         uint32_t *count, uint64_t *first, uint64_t max_nodes, uint64_t *n);
 
 /* ---- introspection / measurement --------------------------------------------------------------- */
 int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */

@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
-SDT_FLAG_DIRECT, SDT_FLAG_PARTITION = 1, 2
+SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST = 1, 2, 4
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
@@ -45,7 +45,9 @@ _ABI = [
     ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_mark_and_hist", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_nodes", _c.c_int,
-     [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+     [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
+      _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_set_read_ordinal", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
     ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),
@@ -200,18 +202,24 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_mark_and_hist(self._ctx, _ptr(hist), ctypes.byref(lin)))
         return hist, lin.value
 
-    def export_nodes(self):
+    def export_nodes(self, with_first: bool = False):
         n = ctypes.c_uint64()
-        self._check(self.lib.sdt_gpu_export_nodes(self._ctx, None, None, None, None, 0, ctypes.byref(n)))
+        self._check(self.lib.sdt_gpu_export_nodes(self._ctx, None, None, None, None, None, 0, ctypes.byref(n)))
         m = max(n.value, 1)
         keys = np.zeros((m, self.nw), dtype=np.uint64)
         l_links = np.zeros(m, dtype=np.uint32)
         r_flags = np.zeros(m, dtype=np.uint32)
         count = np.zeros(m, dtype=np.uint32)
+        first = np.zeros(m, dtype=np.uint64) if with_first else None
         self._check(self.lib.sdt_gpu_export_nodes(self._ctx, _ptr(keys), _ptr(l_links), _ptr(r_flags),
-                                                  _ptr(count), m, ctypes.byref(n)))
+                                                  _ptr(count), _ptr(first), m, ctypes.byref(n)))
         k = n.value
+        if with_first:
+            return keys[:k], l_links[:k], r_flags[:k], count[:k], first[:k]
         return keys[:k], l_links[:k], r_flags[:k], count[:k]
+
+    def set_read_ordinal(self, base: int, stride: int = 1):
+        self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))
 
     # -- introspection
     def table_slots(self) -> int:

@@ -1,0 +1,241 @@
+/* cuttip.c -- minor-branch removal and tip cutting on the host graph, in the reference's visiting order.
+ *
+ * What each pass must reproduce (cutTipPreGraph.c; decision rules also in SURVEY.md 9.7):
+ *   removeMinorOut (:1012-1076)   one sweep; at a node with more than one predecessor (then: successor) every
+ *                                 linked neighbour whose occurrence count is < dd% of the largest such count
+ *                                 is marked deleted and unlinked from all of ITS neighbours (:591-1010)
+ *   removeSingleTips (:339-370)   one sweep, THIN: dead ends whose chain is made of single-occurrence k-mers
+ *   removeMinorTips (:372-437)    per set, sweeps until nothing changes: a dead-end chain of <= 2K nodes is cut
+ *                                 when its link into the junction is not the strongest on that side (:43-337)
+ *   Mark1in1outNode (:1193-1229)  after each pass: not-deleted, not-yet-linear nodes with 1 in / 1 out -> linear
+ * All of them mutate neighbours while sweeping, so the sweep order (graph.h) is part of the result.
+ */
+#include "graph.h"
+#include <stdlib.h>
+
+enum { LEFT = 0, RIGHT = 1 };
+
+static inline unsigned link_of(const gnode_t *n, int side, unsigned b)
+{
+	return ((side == LEFT ? n->l_links : n->r_links) >> (6 * b)) & 63u;
+}
+static inline void drop_link(gnode_t *n, int side, unsigned b)
+{
+	if (side == LEFT) n->l_links &= ~(63u << (6 * b));
+	else n->r_links = n->r_links & ~(63u << (6 * b));
+}
+static inline int degree(const gnode_t *n, int side)
+{
+	int d = 0;
+	for (unsigned b = 0; b < 4; b++) d += link_of(n, side, b) != 0;
+	return d;
+}
+static inline int one_in_one_out(const gnode_t *n) { return degree(n, LEFT) == 1 && degree(n, RIGHT) == 1; }
+
+/* forget the link of `n` (reached in orientation `smaller`) towards the k-mer that precedes / follows it in
+ * the walk and whose adjacent base is ch (dislink2prevUncertain / dislink2nextUncertain, newhash.c:540-562) */
+static inline void unlink_prev(gnode_t *n, unsigned ch, int smaller) { if (smaller) drop_link(n, LEFT, ch); else drop_link(n, RIGHT, ch ^ 2u); }
+static inline void unlink_next(gnode_t *n, unsigned ch, int smaller) { if (smaller) drop_link(n, RIGHT, ch); else drop_link(n, LEFT, ch ^ 2u); }
+
+static uint64_t mark_linear(graph_t *g)
+{
+	uint64_t c = 0;
+	for (uint64_t i = 0; i < g->n; i++) {
+		gnode_t *n = &g->nodes[i];
+		if (n->deleted || n->linear) continue;
+		if (one_in_one_out(n)) { n->linear = 1; c++; }
+	}
+	printf("%d thread created for cutTipPreGraph\n", g->p);
+	printf("%llu linear nodes\n", (unsigned long long)c);
+	return c;
+}
+
+/* neighbour of the CANONICAL k-mer of n across its `side` link with base b */
+static gnode_t *neighbour(graph_t *g, const gnode_t *n, int side, unsigned b, int *smaller)
+{
+	return graph_find_oriented(g, side == LEFT ? kw_prev(n->seq, b, g->K) : kw_next(n->seq, b, g->K), smaller);
+}
+
+static void isolate(graph_t *g, gnode_t *q)
+{
+	const kw_t qs = q->seq;
+	int sm;
+	q->deleted = 1;
+	for (unsigned b = 0; b < 4; b++)
+		if (link_of(q, LEFT, b)) {
+			gnode_t *x = neighbour(g, q, LEFT, b, &sm);
+			unlink_next(x, kw_last(&qs), sm);
+			x->linear = one_in_one_out(x);
+		}
+	for (unsigned b = 0; b < 4; b++)
+		if (link_of(q, RIGHT, b)) {
+			gnode_t *y = neighbour(g, q, RIGHT, b, &sm);
+			unlink_prev(y, kw_first(&qs, g->K), sm);
+			y->linear = one_in_one_out(y);
+		}
+}
+
+static void prune_side(graph_t *g, gnode_t *n, int side, double threshold, uint64_t *off)
+{
+	int sm, best = 0;
+	for (unsigned b = 0; b < 4; b++)
+		if (link_of(n, side, b)) {
+			const int c = (int)neighbour(g, n, side, b, &sm)->count;
+			if (c > best) best = c;
+		}
+	if (!best) return;
+	for (unsigned b = 0; b < 4; b++) {
+		if (!link_of(n, side, b)) continue;                   /* live: an earlier cut may have removed it */
+		gnode_t *q = neighbour(g, n, side, b, &sm);
+		const int c = (int)q->count;
+		if (c && (double)c / best < threshold) {
+			(*off)++;
+			isolate(g, q);
+		}
+	}
+}
+
+uint64_t graph_remove_minor_out(graph_t *g, int dd)
+{
+	const double threshold = (double)dd / 100;
+	uint64_t off = 0;
+	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
+	for (uint64_t i = 0; i < g->n; i++) {
+		gnode_t *n = &g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		const int in = degree(n, LEFT), out = degree(n, RIGHT);        /* both sampled before any cut (:616-617) */
+		if (in <= 1 && out <= 1) continue;
+		if (in > 1) prune_side(g, n, LEFT, threshold, &off);
+		if (out > 1) prune_side(g, n, RIGHT, threshold, &off);
+	}
+	printf("%llu kmers off\n", (unsigned long long)off);
+	mark_linear(g);
+	return off;
+}
+
+/* one dead end: returns 1 when something was cut */
+static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *tips)
+{
+	const int K = g->K;
+	if (tip->linear || tip->deleted) return 0;
+	if (thin && !tip->single) return 0;
+	const int in = degree(tip, LEFT), out = degree(tip, RIGHT);
+	kw_t at;                      /* oriented k-mer we are standing on; the walk always moves "forward" from it */
+	unsigned b;
+	if (in == 0 && out == 1) {
+		at = tip->seq;
+		for (b = 0; b < 4 && !link_of(tip, RIGHT, b); b++) ;
+	} else if (in == 1 && out == 0) {
+		at = kw_rc(tip->seq, K);
+		for (b = 0; b < 4 && !link_of(tip, LEFT, b); b++) ;
+		b ^= 2u;
+	} else {
+		return 0;
+	}
+	int steps = 1, sm;
+	kw_t step = kw_next(at, b, K);
+	gnode_t *o = graph_find_oriented(g, step, &sm);
+	while (o->linear) {
+		steps++;
+		if (thin && !o->single) break;
+		if (steps > cut_len) return 0;
+		at = step;                                                       /* oriented word of o */
+		if (sm) { for (b = 0; b < 4 && !link_of(o, RIGHT, b); b++) ; }
+		else { for (b = 0; b < 4 && !link_of(o, LEFT, b); b++) ; b ^= 2u; }
+		step = kw_next(at, b, K);
+		o = graph_find_oriented(g, step, &sm);
+	}
+	if (degree(o, LEFT) + degree(o, RIGHT) == 1) {                       /* the whole path is an island */
+		(*tips)++;
+		tip->deleted = 1;
+		o->deleted = 1;
+		return 1;
+	}
+	const unsigned ch = kw_first(&at, K);                                /* base by which o sees the chain */
+	if (thin) {
+		(*tips)++;
+		tip->deleted = 1;
+		unlink_prev(o, ch, sm);
+		o->linear = 0;
+		return 1;
+	}
+	const int side = sm ? LEFT : RIGHT;                                  /* side of o the chain enters */
+	unsigned strongest = 0;
+	for (unsigned c = 0; c < 4; c++)
+		if (link_of(o, side, c) > strongest) strongest = link_of(o, side, c);
+	if (link_of(o, side, sm ? ch : ch ^ 2u) < strongest) {
+		(*tips)++;
+		tip->deleted = 1;
+		unlink_prev(o, ch, sm);
+		if (one_in_one_out(o)) o->linear = 1;
+		return 1;
+	}
+	return 0;
+}
+
+uint64_t graph_remove_single_tips(graph_t *g)
+{
+	uint64_t tips = 0;
+	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
+	for (uint64_t i = 0; i < g->n; i++)
+		clip_tip(g, &g->nodes[i], 2 * g->K, 1, &tips);
+	printf("%llu tips off\n", (unsigned long long)tips);
+	mark_linear(g);
+	return tips;
+}
+
+uint64_t graph_remove_minor_tips(graph_t *g)
+{
+	uint64_t tips = 0;
+	printf("Start to remove tips which don't contribute the most links\n");
+	for (int s = 0; s < g->p; s++) {
+		int changed = 1;
+		while (changed) {
+			changed = 0;
+			for (uint64_t i = g->set_start[s]; i < g->set_start[s + 1]; i++)
+				changed += clip_tip(g, &g->nodes[i], 2 * g->K, 0, &tips);
+		}
+		printf("kmer set %d done\n", s);
+	}
+	printf("%llu tips off\n", (unsigned long long)tips);
+	mark_linear(g);
+	return tips;
+}
+
+/* output_vertex (output_pregraph.c:29-81) with print_kmer of the emulated variant (kmer.c:499-516) */
+uint64_t graph_write_vertex(graph_t *g, const char *prefix)
+{
+	char name[4200];
+	snprintf(name, sizeof name, "%s.vertex", prefix);
+	FILE *fp = fopen(name, "w");
+	if (!fp) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	uint64_t c = 0;
+	for (uint64_t i = 0; i < g->n; i++) {
+		const gnode_t *n = &g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		c++;
+		const uint64_t *w = n->seq.w;
+		if (g->nw == 4) fprintf(fp, "%llx %llx %llx %llx ", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
+		else if (g->nw == 2) fprintf(fp, "%llx %llx ", (unsigned long long)w[2], (unsigned long long)w[3]);
+		else if (w[3]) fprintf(fp, "%llx ", (unsigned long long)w[3]);
+		else fprintf(fp, "0x0 ");
+		if (c % 8 == 0) fputc('\n', fp);
+	}
+	fputc('\n', fp);
+	fclose(fp);
+	printf("%llu vertex outputed\n", (unsigned long long)c);
+	return c;
+}
+
+int graph_write_basic(const char *prefix, uint64_t vertices, int K, uint64_t num_ed, int max_read_len)
+{
+	char name[4200];
+	snprintf(name, sizeof name, "%s.preGraphBasic", prefix);
+	FILE *fp = fopen(name, "w");
+	if (!fp) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	fprintf(fp, "VERTEX %llu K %d\n", (unsigned long long)vertices, K);
+	fprintf(fp, "\nEDGEs %llu\n", (unsigned long long)num_ed);
+	fprintf(fp, "\nMaxReadLen %d MinReadLen %d MaxNameLen %d\n", max_read_len, 0, 256);
+	fclose(fp);
+	return 0;
+}

@@ -1,0 +1,232 @@
+/* graph.c -- see graph.h: layout replay, flat node array, lookup index, hash_kmer. */
+#include "graph.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- hash_kmer: table-driven CRC-32 with a SIGNED 32-bit state (arithmetic >> 8), hashFunction.c:83-122 ---- */
+static int32_t crc_tab[256];
+static int crc_init_done;
+
+uint64_t ref_hash_kmer(const kw_t *k, int nw)
+{
+	if (!crc_init_done) {
+		for (uint32_t n = 0; n < 256; n++) {
+			uint32_t c = n;
+			for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+			crc_tab[n] = (int32_t)c;
+		}
+		crc_init_done = 1;
+	}
+	/* raw bytes of the variant's Kmer struct: words high..low, each little endian */
+	const unsigned char *raw = (const unsigned char *)&k->w[4 - nw];
+	int32_t crc = ~0;
+	for (int i = 0; i < 8 * nw; i++)
+		crc = crc_tab[(crc ^ raw[i]) & 0xff] ^ (crc >> 8);       /* >> on a negative int: sign bits shift in */
+	crc = ~crc;
+	return (uint64_t)(int64_t)crc & 0xffffffULL;
+}
+
+/* ---- layout replay --------------------------------------------------------------------------------------
+ * put_kmerset + encap_kmerset (newhash.c:293-462) reduced to what fixes the slot of every key: a table of
+ * node ids.  size: "prime" >= request found by trial division with bound i < (ubyte8)sqrt((float)n)
+ * (:116-158); max = size * 0.77f at init (float product, :176) and size * (double)0.77f after growth (:350);
+ * growth doubles below 2^28-1 else adds 0xFFFFFF, until n * lf >= count + 1 (:318-330); the rehash is IN PLACE:
+ * old entries are visited by slot, each is re-probed in the new geometry and an occupant that has not moved
+ * yet is carried onward (:359-406). */
+static int prime_kh(uint64_t num)
+{
+	if (num < 4) return 1;
+	if (num % 2 == 0) return 0;
+	uint64_t lim = (uint64_t)sqrt((float)num);
+	for (uint64_t i = 3; i < lim; i += 2)
+		if (num % i == 0) return 0;
+	return 1;
+}
+static uint64_t next_prime_kh(uint64_t n)
+{
+	if (n % 2 == 0) n++;
+	while (!prime_kh(n)) n += 2;
+	return n;
+}
+
+typedef struct {
+	int64_t *slot;         /* node id or -1 */
+	uint8_t *moved;        /* scratch for the rehash */
+	uint64_t size, count, max;
+	double lf;
+} replay_t;
+
+static uint64_t home_slot(const kw_t *k, int nw, uint64_t size)
+{
+	if (nw == 1) return k->w[3] % size;                                  /* newhash.c:428 */
+	if (nw == 2) {                                                       /* :423-425 */
+		unsigned __int128 v = ((unsigned __int128)k->w[2] << 64) | k->w[3];
+		return (uint64_t)(v % size);
+	}
+	uint64_t t = k->w[0] % size;                                         /* :43-55, 32 bits at a time */
+	const uint64_t part[6] = {k->w[1] >> 32, k->w[1] & 0xffffffffu, k->w[2] >> 32, k->w[2] & 0xffffffffu,
+	                          k->w[3] >> 32, k->w[3] & 0xffffffffu};
+	for (int i = 0; i < 6; i++)
+		t = ((t << 32) | part[i]) % size;
+	return t;
+}
+
+static void replay_grow(replay_t *r, const gnode_t *nodes, int nw)
+{
+	uint64_t n = r->size;
+	do {
+		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
+		n = next_prime_kh(n);
+	} while (n * r->lf < (double)(r->count + 1));
+	const uint64_t old = r->size;
+	int64_t *ns = (int64_t *)malloc(n * sizeof(int64_t));
+	/* the reference reallocs in place and tells old from new by two flag arrays; here: ns = new geometry,
+	 * r->slot = old geometry, moved[i] = old entry i has left its old slot */
+	for (uint64_t i = 0; i < n; i++) ns[i] = -1;
+	r->moved = (uint8_t *)realloc(r->moved, old);
+	memset(r->moved, 0, old);
+	for (uint64_t i = 0; i < old; i++) {
+		if (r->slot[i] < 0 || r->moved[i]) continue;
+		int64_t carry = r->slot[i];
+		r->moved[i] = 1;
+		for (;;) {
+			uint64_t h = home_slot(&nodes[carry].seq, nw, n);
+			while (ns[h] >= 0) h = h + 1 == n ? 0 : h + 1;
+			/* the new array aliases the old one below `old`: a slot h < old that still holds an unmoved old
+			 * entry is "empty" in the new flags, and its occupant gets evicted and carried on */
+			if (h < old && r->slot[h] >= 0 && !r->moved[h]) {
+				const int64_t evicted = r->slot[h];
+				r->moved[h] = 1;
+				ns[h] = carry;
+				carry = evicted;
+				continue;
+			}
+			ns[h] = carry;
+			break;
+		}
+	}
+	free(r->slot);
+	r->slot = ns;
+	r->size = n;
+	r->max = (uint64_t)(n * r->lf);
+}
+
+static void replay_put(replay_t *r, const gnode_t *nodes, int64_t id, int nw)
+{
+	if (r->count + 1 > r->max)
+		replay_grow(r, nodes, nw);
+	uint64_t h = home_slot(&nodes[id].seq, nw, r->size);
+	while (r->slot[h] >= 0) h = h + 1 == r->size ? 0 : h + 1;
+	r->slot[h] = id;
+	r->count++;
+}
+
+/* ---- our own lookup index ---- */
+static inline uint64_t mix_key(const kw_t *k)
+{
+	uint64_t h = 0x9E3779B97F4A7C15ULL;
+	for (int i = 0; i < 4; i++) {
+		h ^= k->w[i];
+		h ^= h >> 32; h *= 0xD6E8FEB86659FD93ULL; h ^= h >> 32;
+	}
+	return h;
+}
+
+gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller)
+{
+	kw_t bal = kw_rc(word, g->K);
+	const kw_t *canon = &word;
+	*smaller = 1;
+	if (kw_less(&bal, &word)) {       /* KmerLarger(word, bal_word): keep the smaller strand */
+		canon = &bal;
+		*smaller = 0;
+	}
+	uint64_t h = mix_key(canon) & g->index_mask;
+	for (;;) {
+		const uint64_t v = g->index[h];
+		if (!v) break;
+		if (kw_eq(&g->nodes[v - 1].seq, canon)) return &g->nodes[v - 1];
+		h = (h + 1) & g->index_mask;
+	}
+	printf("kmer %llx %llx %llx %llx not found\n", (unsigned long long)canon->w[0], (unsigned long long)canon->w[1],
+	       (unsigned long long)canon->w[2], (unsigned long long)canon->w[3]);
+	exit(1);
+}
+
+typedef struct { uint64_t first; uint64_t id; } ord_t;
+static int cmp_ord(const void *a, const void *b)
+{
+	const ord_t *x = (const ord_t *)a, *y = (const ord_t *)b;
+	return x->first < y->first ? -1 : x->first > y->first;
+}
+
+graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
+                     const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first)
+{
+	graph_t *g = (graph_t *)calloc(1, sizeof *g);
+	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
+	gnode_t *tmp = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	uint64_t *per_set = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
+	uint32_t *set_of = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+	for (uint64_t i = 0; i < n; i++) {
+		gnode_t *nd = &tmp[i];
+		for (int w = 0; w < nw_keys; w++) nd->seq.w[4 - nw_keys + w] = keys[i * nw_keys + w];
+		nd->l_links = l_links[i];
+		nd->r_links = r_flags[i] & 0xFFFFFFu;
+		nd->linear = (r_flags[i] >> 24) & 1; nd->deleted = (r_flags[i] >> 25) & 1; nd->single = (r_flags[i] >> 27) & 1;
+		nd->count = count[i];
+		set_of[i] = (uint32_t)(ref_hash_kmer(&nd->seq, nw_variant) % (uint64_t)p);
+		per_set[set_of[i] + 1]++;
+	}
+	for (int s = 0; s < p; s++) per_set[s + 1] += per_set[s];
+	/* group node ids by set, then order each group by first occurrence */
+	ord_t *ord = (ord_t *)malloc((n ? n : 1) * sizeof(ord_t));
+	uint64_t *fill = (uint64_t *)malloc((size_t)p * sizeof(uint64_t));
+	memcpy(fill, per_set, (size_t)p * sizeof(uint64_t));
+	for (uint64_t i = 0; i < n; i++) {
+		ord_t *o = &ord[fill[set_of[i]]++];
+		o->first = first[i];
+		o->id = i;
+	}
+	g->nodes = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
+	uint64_t out = 0;
+	for (int s = 0; s < p; s++) {
+		const uint64_t b = per_set[s], e = per_set[s + 1];
+		qsort(ord + b, (size_t)(e - b), sizeof(ord_t), cmp_ord);
+		replay_t r;
+		memset(&r, 0, sizeof r);
+		r.size = next_prime_kh(1024);                     /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
+		r.max = (uint64_t)(r.size * 0.77f);
+		r.lf = (double)0.77f;
+		r.slot = (int64_t *)malloc(r.size * sizeof(int64_t));
+		for (uint64_t i = 0; i < r.size; i++) r.slot[i] = -1;
+		for (uint64_t i = b; i < e; i++)
+			replay_put(&r, tmp, (int64_t)ord[i].id, nw_variant);
+		g->set_start[s] = out;
+		for (uint64_t i = 0; i < r.size; i++)
+			if (r.slot[i] >= 0) g->nodes[out++] = tmp[r.slot[i]];
+		free(r.slot);
+		free(r.moved);
+	}
+	g->set_start[p] = out;
+	free(ord); free(fill); free(per_set); free(set_of); free(tmp);
+	/* index */
+	uint64_t cap = 1024;
+	while (cap < 2 * n + 2) cap <<= 1;
+	g->index = (uint64_t *)calloc(cap, sizeof(uint64_t));
+	g->index_mask = cap - 1;
+	for (uint64_t i = 0; i < n; i++) {
+		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
+		while (g->index[h]) h = (h + 1) & g->index_mask;
+		g->index[h] = i + 1;
+	}
+	return g;
+}
+
+void graph_free(graph_t *g)
+{
+	if (!g) return;
+	free(g->nodes); free(g->set_start); free(g->index); free(g);
+}

@@ -1,0 +1,56 @@
+/* graph.h -- the k-mer graph on the host after the GPU hashing pass, in the REFERENCE's visiting order.
+ *
+ * The reference keeps `thrd_num` open-addressing tables (newhash.c) and every later phase walks them
+ * "set 0..p-1, slot 0..size-1" while mutating neighbours (cutTipPreGraph.c, node2edge.c), so its results are a
+ * function of that slot order.  The slot order in turn is a function of (a) which set a key
+ * hashes to (hash_kmer % p, hashFunction.c) and (b) the order in which the distinct keys of a set were first
+ * inserted (put_kmerset + encap_kmerset growth/rehash, newhash.c:293-462) -- repeat hits never move entries.
+ * graph_build() therefore takes the nodes exported by sdt_gpu_export_nodes with their first-occurrence
+ * ordinals, replays only that layout (slot -> node id; no payload moves), and stores the nodes in one flat
+ * array in visiting order.  Lookups go through an index of our own (not the reference's probing).
+ */
+#ifndef SDT_GRAPH_H
+#define SDT_GRAPH_H
+#include <stdint.h>
+#include <stdio.h>
+#include "kw.h"
+
+typedef struct {
+	kw_t seq;
+	uint32_t l_links;                  /* 4 x 6 bit; edge id once edges are built (node2edge.c:493-519) */
+	uint32_t r_links : 24, linear : 1, deleted : 1, checked : 1, single : 1, twin : 2, inEdge : 2;
+	uint32_t count;
+} gnode_t;
+
+typedef struct {
+	int K, nw, p;
+	uint64_t n;
+	gnode_t *nodes;                    /* visiting order */
+	uint64_t *set_start;               /* p + 1 offsets into nodes[] */
+	uint64_t *index;                   /* open addressing: node id + 1, 0 = empty */
+	uint64_t index_mask;
+} graph_t;
+
+/* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
+ * single<<27).  Returns NULL after printing a message on failure. */
+graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
+                     const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first);
+void graph_free(graph_t *g);
+
+/* hash_kmer (hashFunction.c:83-122) for an nw-word variant */
+uint64_t ref_hash_kmer(const kw_t *k, int nw);
+
+/* canonical lookup of an ORIENTED k-mer; *smaller = 1 when the oriented word is the stored (smaller) strand.
+ * A miss is fatal in the reference (cutTipPreGraph.c:124-140): prints and exit(1). */
+gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller);
+
+/* cutTipPreGraph.c */
+uint64_t graph_remove_minor_out(graph_t *g, int dd);       /* prints the reference's lines, returns kmers off */
+uint64_t graph_remove_single_tips(graph_t *g);
+uint64_t graph_remove_minor_tips(graph_t *g);
+
+/* output_pregraph.c:47-81 */
+uint64_t graph_write_vertex(graph_t *g, const char *prefix);
+int graph_write_basic(const char *prefix, uint64_t vertices, int K, uint64_t num_ed, int max_read_len);
+
+#endif

@@ -16,6 +16,7 @@
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
+#include "graph/graph.h"
 
 #ifndef SDT_MAX_K
 #define SDT_MAX_K 127        /* one binary covers the 31/63/127mer variants; --max-k emulates a smaller one */
@@ -53,11 +54,12 @@ static int push_batch(void *user, const sdt_batch *b)
 int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", prefix[4096] = "";
-	int K = 23, threads = 8, d = 0, max_k = SDT_MAX_K, device = 0;
+	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0;
 	int have_s = 0, have_o = 0, c;
 	unsigned long long est = 0;
 	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
-	                                   {"est-distinct", required_argument, 0, 1002}, {0, 0, 0, 0}};
+	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003},
+	                                   {0, 0, 0, 0}};
 	/* accept an optional leading "pregraph" sub-command like the reference's dispatcher (main.c:49-106) */
 	if (argc > 1 && strcmp(argv[1], "pregraph") == 0) { argv++; argc--; }
 	while ((c = getopt_long(argc, argv, "a:s:o:K:p:d:Di:n", longopts, NULL)) != -1) {
@@ -67,17 +69,22 @@ int main(int argc, char **argv)
 		case 'K': K = atoi(optarg); break;
 		case 'p': threads = atoi(optarg); break;
 		case 'd': d = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;          /* pregraph.c:159 */
-		case 'a': case 'i': case 'D': break;                                 /* accepted; no effect on this path */
+		case 'i': dd = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;          /* pregraph.c:170-173 */
+		case 'a': case 'D': break;                                           /* accepted; no effect on this path */
 		case 'n':
 			fprintf(stderr, "-n (N-aware k-mers) is not supported: the reference path is broken (survey 9.3-q11)\n");
 			return 1;
 		case 1000: max_k = atoi(optarg); break;
 		case 1001: device = atoi(optarg); break;
 		case 1002: est = strtoull(optarg, NULL, 10); break;
+		case 1003: hash_only = 1; break;
 		default:
-			if (!have_s || !have_o) { usage(max_k); return 255; }
+			if (!have_s || !have_o) { usage(max_k ? max_k : SDT_MAX_K); return 255; }
 		}
 	}
+	/* which reference binary is being stood in for: it fixes the words per printed k-mer and the bytes hash_kmer
+	 * runs over (31mer / 63mer / 127mer); default = the smallest shipped variant that can hold K */
+	if (max_k == 0) max_k = K <= 31 ? 31 : SDT_MAX_K;
 	if (!have_s || !have_o) { usage(max_k); return 255; }
 	if (d > 127) d = (signed char)d;                                        /* deLowKmer is a char (survey q12) */
 	/* pregraph.c:38-59 */
@@ -92,11 +99,12 @@ int main(int argc, char **argv)
 	printf("In %s, %d libs, max seq len %d, max name len %d\n\n", cfgfile, cfg.nlibs, max_read_len, 256);
 
 	sdt_ctx *gpu = NULL;
-	if (sdt_gpu_init(&gpu, device, K, est, 0) != SDT_OK) {
+	if (sdt_gpu_init(&gpu, device, K, est, hash_only ? 0 : SDT_FLAG_TRACK_FIRST) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
 	push_state st = {gpu, 0};
+	uint64_t ordinal = 0;
 	const size_t chunk = 32u << 20;
 	int rc = 0;
 	for (int i = 0; i < cfg.nlibs && rc == 0; i++) {
@@ -110,14 +118,24 @@ int main(int argc, char **argv)
 			rc = -1;
 			break;
 		}
-		/* file-type order of nextValidIndex (readseq1by1.c:579-632): f1/f2, q1/q2, p, [b], f, q */
-		struct { char **names; int n; int fmt; int type; } groups[] = {
-			{l->f1, l->nf1, 'a', 1}, {l->f2, l->nf2, 'a', 1}, {l->q1, l->nq1, 'q', 2}, {l->q2, l->nq2, 'q', 2},
-			{l->p, l->np, 'a', 3}, {l->f, l->nf, 'a', 5}, {l->q, l->nq, 'q', 6}};
+		/* file-type order of nextValidIndex (readseq1by1.c:579-632): f1/f2 pairs, q1/q2 pairs, p, [b], f, q.
+		 * Read ordinals follow the reference's consumption order: paired files alternate read1, read2, ...
+		 * (prlHashReads.c:493-567), so file 1 gets ordinals base, base+2, ... and file 2 base+1, base+3, ... */
+		struct { char **a; char **b; int n; int fmt; int type; } groups[] = {
+			{l->f1, l->f2, l->nf1 < l->nf2 ? l->nf1 : l->nf2, 'a', 1}, {l->q1, l->q2, l->nq1 < l->nq2 ? l->nq1 : l->nq2, 'q', 2},
+			{l->p, NULL, l->np, 'a', 3}, {l->f, NULL, l->nf, 'a', 5}, {l->q, NULL, l->nq, 'q', 6}};
 		for (unsigned g = 0; g < sizeof groups / sizeof groups[0] && rc == 0; g++)
 			for (int f = 0; f < groups[g].n && rc == 0; f++) {
-				printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].names[f]);
-				rc = sdt_read_file(groups[g].names[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, NULL);
+				uint64_t n1 = 0, n2 = 0;
+				printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].a[f]);
+				if (groups[g].b) printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].b[f]);
+				sdt_gpu_set_read_ordinal(gpu, ordinal, groups[g].b ? 2 : 1);
+				rc = sdt_read_file(groups[g].a[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, &n1);
+				if (rc == 0 && groups[g].b) {
+					sdt_gpu_set_read_ordinal(gpu, ordinal + 1, 2);
+					rc = sdt_read_file(groups[g].b[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, &n2);
+				}
+				ordinal += groups[g].b ? 2 * (n1 > n2 ? n1 : n2) : n1;
 			}
 	}
 	if (rc != 0) { sdt_gpu_destroy(gpu); return 1; }
@@ -147,8 +165,31 @@ int main(int argc, char **argv)
 		fprintf(fo, "%lld\n", (long long)hist[i]);
 	fclose(fo);
 	printf("time spent on pre-graph construction: %ds\n\n", (int)(time(NULL) - t_start));
-	printf("deLowKmer %d, deLowEdge %d\n", d, 0);
-	sdt_gpu_destroy(gpu);
+	printf("deLowKmer %d, deLowEdge %d\n", d, 1);
+	if (!hash_only) {
+		/* hand the node table to the host graph phases in the reference's visiting order (graph/graph.h) */
+		uint64_t n = 0;
+		const int nwk = sdt_gpu_key_words(gpu), nwv = max_k <= 31 ? 1 : (max_k <= 63 ? 2 : 4);
+		if (sdt_gpu_export_nodes(gpu, NULL, NULL, NULL, NULL, NULL, 0, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		uint64_t *keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8), *first = (uint64_t *)malloc((n + 1) * 8);
+		uint32_t *ll = (uint32_t *)malloc((n + 1) * 4), *rf = (uint32_t *)malloc((n + 1) * 4), *cnt = (uint32_t *)malloc((n + 1) * 4);
+		if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		sdt_gpu_destroy(gpu);
+		gpu = NULL;
+		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
+		free(keys); free(first); free(ll); free(rf); free(cnt);
+		time_t t0 = time(NULL);
+		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
+		printf("time spent on cut kmer: %ds\n\n", (int)(time(NULL) - t0));
+		t0 = time(NULL);
+		if (!d) graph_remove_single_tips(G);                               /* pregraph.c:75-88 */
+		graph_remove_minor_tips(G);
+		printf("time spent on cutTipe: %ds\n\n", (int)(time(NULL) - t0));
+		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
+		graph_write_basic(prefix, nv, K, 0, max_read_len);
+		graph_free(G);
+	}
+	if (gpu) sdt_gpu_destroy(gpu);
 	sdt_cfg_free(&cfg);
 	return 0;
 }

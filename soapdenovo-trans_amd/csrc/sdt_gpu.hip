@@ -145,7 +145,8 @@ static_assert(TILE_READS == 64, "the scan and the binary search assume 64 reads 
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict__ packed,
                                                      const uint64_t *__restrict__ offs, uint64_t nreads, int K,
-                                                     int max_tile_words, Table<NW> tbl, Stats *stats)
+                                                     int max_tile_words, Table<NW> tbl, Stats *stats,
+                                                     uint64_t ord_base, uint64_t ord_stride)
 {
 	extern __shared__ uint32_t smem[];
 	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict_
 			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
 			uint32_t prev, next;
 			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
-			if (!table_put<NW>(tbl, key, prev, next, claimed))
+			// ordinal of this occurrence in the reference's stream order: (read ordinal, position in read)
+			const uint64_t ord = tbl.first ? ((ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride) << 16) | (uint64_t)j : ORD_NONE;
+			if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
 				failed++;
 			done++;
 		}
@@ -282,6 +285,8 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_clear(Table<NW> tbl)
 		e.val = 0;
 		tbl.ent[s] = e;
 		tbl.aux[s] = 0;
+		if (tbl.first)
+			tbl.first[s] = ORD_NONE;
 	}
 }
 
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(TPB) void k_mark_hist(Table<NW> tbl, unsigned long 
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_export(Table<NW> tbl, uint64_t *__restrict__ keys, uint32_t *__restrict__ l_links,
                                                 uint32_t *__restrict__ r_flags, uint32_t *__restrict__ count,
-                                                unsigned long long max_nodes, Stats *stats)
+                                                uint64_t *__restrict__ first, unsigned long long max_nodes, Stats *stats)
 {
 	const uint64_t slots = tbl.mask + 1;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(TPB) void k_export(Table<NW> tbl, uint64_t *__restr
 			r_flags[pos] = (uint32_t)((e.val >> 24) & 0xFFFFFFu) | ((aux & AUX_LINEAR) ? 1u << 24 : 0u) |
 			               ((aux & AUX_DELETED) ? 1u << 25 : 0u) | (cnt == 1 ? 1u << 27 : 0u);
 		if (count) count[pos] = cnt;
+		if (first) first[pos] = tbl.first ? tbl.first[s] : ORD_NONE;
 	}
 }
 
@@ -410,6 +416,8 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 					dst.ent[slot].key[i] = e.key[i];
 				dst.ent[slot].val = e.val;
 				dst.aux[slot] = src.aux[s];
+				if (dst.first)
+					dst.first[slot] = src.first[s];
 				placed = true;
 				break;
 			}
@@ -439,6 +447,8 @@ struct sdt_ctx {
 	uint64_t slots = 0;
 	void *d_ent = nullptr;
 	uint32_t *d_aux = nullptr;
+	uint64_t *d_first = nullptr;       // SDT_FLAG_TRACK_FIRST
+	uint64_t ord_base = 0, ord_stride = 1;
 	Stats *d_stats = nullptr;
 	Stats *h_stats = nullptr;          // pinned
 	unsigned long long *d_hist = nullptr;
@@ -475,6 +485,7 @@ template <int NW> static Table<NW> table_of(const sdt_ctx *c)
 	t.ent = (Entry<NW> *)c->d_ent;
 	t.aux = c->d_aux;
 	t.mask = c->slots - 1;
+	t.first = c->d_first;
 	return t;
 }
 
@@ -489,27 +500,33 @@ static int scan_grid(const sdt_ctx *c, uint64_t items)
 	return (int)blocks;
 }
 
-static int launch_clear(sdt_ctx *c, void *ent, uint32_t *aux, uint64_t slots)
+static int launch_clear(sdt_ctx *c, void *ent, uint32_t *aux, uint64_t *first, uint64_t slots)
 {
 	const int g = scan_grid(c, slots);
-	if (c->nw == 1) { Table<1> t{(Entry<1> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<1>, dim3(g), dim3(TPB), 0, c->stream, t); }
-	else if (c->nw == 2) { Table<2> t{(Entry<2> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<2>, dim3(g), dim3(TPB), 0, c->stream, t); }
-	else { Table<4> t{(Entry<4> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_clear<4>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	if (c->nw == 1) { Table<1> t{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<1>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else if (c->nw == 2) { Table<2> t{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<2>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else { Table<4> t{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<4>, dim3(g), dim3(TPB), 0, c->stream, t); }
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
 }
 
-static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux)
+static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, uint64_t **first)
 {
+	*ent = nullptr;
+	*aux = nullptr;
+	*first = nullptr;
 	hipError_t e = hipMalloc(ent, slots * entry_bytes(c->nw));
-	if (e != hipSuccess)
-		return fail(SDT_ENOMEM, "node table: hipMalloc(%llu slots x %zu B) failed: %s", (unsigned long long)slots,
-		            entry_bytes(c->nw), hipGetErrorString(e));
-	e = hipMalloc((void **)aux, slots * sizeof(uint32_t));
+	if (e == hipSuccess)
+		e = hipMalloc((void **)aux, slots * sizeof(uint32_t));
+	if (e == hipSuccess && (c->flags & SDT_FLAG_TRACK_FIRST))
+		e = hipMalloc((void **)first, slots * sizeof(uint64_t));
 	if (e != hipSuccess) {
-		(void)hipFree(*ent);
+		if (*ent) (void)hipFree(*ent);
+		if (*aux) (void)hipFree(*aux);
 		*ent = nullptr;
-		return fail(SDT_ENOMEM, "node table aux: hipMalloc failed: %s", hipGetErrorString(e));
+		*aux = nullptr;
+		return fail(SDT_ENOMEM, "node table: hipMalloc(%llu slots x %zu B) failed: %s", (unsigned long long)slots,
+		            entry_bytes(c->nw) + 4, hipGetErrorString(e));
 	}
 	return SDT_OK;
 }
@@ -533,22 +550,25 @@ static int grow_table(sdt_ctx *c, uint64_t need_nodes)
 		slots <<= 1;
 	void *ent = nullptr;
 	uint32_t *aux = nullptr;
-	int rc = alloc_table(c, slots, &ent, &aux);
+	uint64_t *first = nullptr;
+	int rc = alloc_table(c, slots, &ent, &aux, &first);
 	if (rc != SDT_OK)
 		return fail(SDT_EFULL, "cannot grow node table to %llu slots: %s", (unsigned long long)slots, g_err);
-	rc = launch_clear(c, ent, aux, slots);
+	rc = launch_clear(c, ent, aux, first, slots);
 	if (rc != SDT_OK)
 		return rc;
 	const int g = scan_grid(c, c->slots);
-	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d, c->d_stats); }
-	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d, c->d_stats); }
-	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d, c->d_stats); }
+	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d, c->d_stats); }
+	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d, c->d_stats); }
+	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d, c->d_stats); }
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipFree(c->d_ent));
 	HIPCHK(hipFree(c->d_aux));
+	if (c->d_first) HIPCHK(hipFree(c->d_first));
 	c->d_ent = ent;
 	c->d_aux = aux;
+	c->d_first = first;
 	c->slots = slots;
 	return SDT_OK;
 }
@@ -665,7 +685,7 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	INIT_CHK(hipHostMalloc((void **)&c->h_stats, sizeof(Stats), hipHostMallocDefault));
 	INIT_CHK(hipMalloc((void **)&c->d_hist, 257 * sizeof(unsigned long long)));
 	INIT_CHK(hipMalloc((void **)&c->d_cursors, 64 * sizeof(unsigned long long)));
-	int rc = alloc_table(c, c->slots, &c->d_ent, &c->d_aux);
+	int rc = alloc_table(c, c->slots, &c->d_ent, &c->d_aux, &c->d_first);
 	if (rc != SDT_OK) {
 		sdt_gpu_destroy(c);
 		return rc;
@@ -695,6 +715,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	}
 	if (c->d_ent) (void)hipFree(c->d_ent);
 	if (c->d_aux) (void)hipFree(c->d_aux);
+	if (c->d_first) (void)hipFree(c->d_first);
 	if (c->d_stats) (void)hipFree(c->d_stats);
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
@@ -718,13 +739,15 @@ int sdt_gpu_reset(sdt_ctx *c)
 	if (!c)
 		return fail(SDT_EINVAL, "ctx is NULL");
 	HIPCHK(hipSetDevice(c->device));
-	int rc = launch_clear(c, c->d_ent, c->d_aux, c->slots);
+	int rc = launch_clear(c, c->d_ent, c->d_aux, c->d_first, c->slots);
 	if (rc != SDT_OK)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
 	c->distinct_known = 0;
 	c->kmers_since_sync = 0;
 	c->kmers_total_host = 0;
+	c->ord_base = 0;
+	c->ord_stride = 1;
 	return SDT_OK;
 }
 
@@ -732,6 +755,15 @@ int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
 uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int sdt_gpu_record_bytes(const sdt_ctx *c) { return c ? (c->nw + 1) * 8 : 0; }
+
+int sdt_gpu_set_read_ordinal(sdt_ctx *c, uint64_t base, uint64_t stride)
+{
+	if (!c || stride == 0)
+		return fail(SDT_EINVAL, "bad argument");
+	c->ord_base = base;
+	c->ord_stride = stride;
+	return SDT_OK;
+}
 
 // run the kernels on a stream the caller owns (e.g. the stream a collective library orders against)
 int sdt_gpu_set_stream(sdt_ctx *c, void *hip_stream)
@@ -874,7 +906,7 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	const uint64_t per_read = max_read_len - c->K + 1;
 	// The locality pipeline is opt-in in round 1: on MI355X it measures 11 G k-mers/s against the direct
 	// kernel's 19.5 G (profiles/r1/partition_pipeline_50M.md has the per-stage rates and what has to change).
-	if (c->nw == 1 && (c->flags & SDT_FLAG_PARTITION) && !(c->flags & SDT_FLAG_DIRECT))
+	if (c->nw == 1 && (c->flags & SDT_FLAG_PARTITION) && !(c->flags & (SDT_FLAG_DIRECT | SDT_FLAG_TRACK_FIRST)))
 		return launch_count_partitioned(c, d_words, d_offs, nreads, max_read_len);
 	uint64_t chunk_reads = CHUNK_KMERS / per_read;
 	chunk_reads = chunk_reads / TILE_READS * TILE_READS;
@@ -897,15 +929,16 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 		HIPCHK(hipEventRecord(ev->a, c->stream));
 		// offsets are absolute base indices into d_words, so a sub-range of reads is just a shifted pointer
 		if (c->nw == 1)
-			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats);
+			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else if (c->nw == 2)
-			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats);
+			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else
-			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats);
+			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev->b, c->stream));
 		c->kmers_since_sync += upper;
 	}
+	c->ord_base += nreads * c->ord_stride;         // the next batch continues the read stream
 	return SDT_OK;
 }
 
@@ -1096,7 +1129,7 @@ int sdt_gpu_mark_and_hist(sdt_ctx *c, int64_t hist[257], uint64_t *linear)
 }
 
 int sdt_gpu_export_nodes(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count,
-                         uint64_t max_nodes, uint64_t *n)
+                         uint64_t *first, uint64_t max_nodes, uint64_t *n)
 {
 	if (!c)
 		return fail(SDT_EINVAL, "ctx is NULL");
@@ -1106,13 +1139,16 @@ int sdt_gpu_export_nodes(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t
 		return rc;
 	const uint64_t nodes = c->h_stats->distinct;
 	if (n) *n = nodes;
-	if (!keys && !l_links && !r_flags && !count)
+	if (!keys && !l_links && !r_flags && !count && !first)
 		return SDT_OK;
+	if (first && !c->d_first)
+		return fail(SDT_ESTATE, "first-occurrence ordinals were not tracked: init with SDT_FLAG_TRACK_FIRST");
 	if (max_nodes < nodes)
 		return fail(SDT_EINVAL, "export arrays hold %llu nodes, table has %llu", (unsigned long long)max_nodes,
 		            (unsigned long long)nodes);
 	uint64_t *d_keys = nullptr;
 	uint32_t *d_l = nullptr, *d_r = nullptr, *d_c = nullptr;
+	uint64_t *d_f = nullptr;
 	const uint64_t m = nodes ? nodes : 1;
 	int ret = SDT_OK;
 #define EXP_CHK(expr)                                                                                  \
@@ -1127,24 +1163,27 @@ int sdt_gpu_export_nodes(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t
 	if (l_links) EXP_CHK(hipMalloc((void **)&d_l, m * sizeof(uint32_t)));
 	if (r_flags) EXP_CHK(hipMalloc((void **)&d_r, m * sizeof(uint32_t)));
 	if (count) EXP_CHK(hipMalloc((void **)&d_c, m * sizeof(uint32_t)));
+	if (first) EXP_CHK(hipMalloc((void **)&d_f, m * sizeof(uint64_t)));
 	EXP_CHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 	{
 		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_export<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_export<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
-		else hipLaunchKernelGGL(k_export<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_keys, d_l, d_r, d_c, (unsigned long long)nodes, c->d_stats);
+		if (c->nw == 1) hipLaunchKernelGGL(k_export<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_export<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
+		else hipLaunchKernelGGL(k_export<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
 	}
 	EXP_CHK(hipGetLastError());
 	if (keys) EXP_CHK(hipMemcpyAsync(keys, d_keys, nodes * c->nw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	if (l_links) EXP_CHK(hipMemcpyAsync(l_links, d_l, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	if (r_flags) EXP_CHK(hipMemcpyAsync(r_flags, d_r, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	if (count) EXP_CHK(hipMemcpyAsync(count, d_c, nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if (first) EXP_CHK(hipMemcpyAsync(first, d_f, nodes * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	EXP_CHK(hipStreamSynchronize(c->stream));
 done:
 	if (d_keys) (void)hipFree(d_keys);
 	if (d_l) (void)hipFree(d_l);
 	if (d_r) (void)hipFree(d_r);
 	if (d_c) (void)hipFree(d_c);
+	if (d_f) (void)hipFree(d_f);
 	return ret;
 }
 

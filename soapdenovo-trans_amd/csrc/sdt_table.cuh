@@ -47,7 +47,22 @@ template <int NW> struct Table {
 	Entry<NW> *ent;
 	uint32_t *aux;
 	uint64_t mask;        // slots - 1 (slots is a power of two)
+	uint64_t *first;      // optional (SDT_FLAG_TRACK_FIRST): smallest ordinal of an occurrence of the key, ~0 = none
 };
+
+constexpr uint64_t ORD_NONE = ~0ULL;
+
+// first-occurrence tracking: the reference's table layout (and with it the visiting order of the cutting passes
+// and the edge ids) is a function of the order in which distinct keys first appear in the read stream (survey
+// 7.3-1).  Reads are processed roughly in order, so the stored ordinal is almost always already smaller and the
+// atomic is skipped.
+__device__ inline void note_first(uint64_t *first, uint64_t slot, uint64_t ord)
+{
+	if (first && ord != ORD_NONE) {
+		if (ord < __hip_atomic_load(first + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+			atomicMin((unsigned long long *)(first + slot), (unsigned long long)ord);
+	}
+}
 
 struct Stats {             // device counters, one cache line each would be nicer; they are cold
 	unsigned long long kmers;      // occurrences inserted
@@ -145,7 +160,7 @@ __device__ inline bool table_merge(const Table<1> &t, uint64_t key, uint64_t add
 // put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
 template <int NW>
 __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_t prev, uint32_t next,
-                                 uint32_t &claimed)
+                                 uint32_t &claimed, uint64_t ord = ORD_NONE)
 {
 	uint64_t slot = key_hash<NW>(key) & t.mask;
 	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
@@ -173,6 +188,7 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				node_update(&e->val, t.aux + slot, 0, prev, next);
+				note_first(t.first, slot, ord);
 				return true;
 			}
 			k0 = old;        // somebody else got it first: fall through and look at what they put
@@ -194,6 +210,7 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 		}
 		if (same) {
 			node_update(&e->val, t.aux + slot, seen, prev, next);
+			note_first(t.first, slot, ord);
 			return true;
 		}
 		slot = (slot + 1) & t.mask;

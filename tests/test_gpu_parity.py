@@ -215,3 +215,32 @@ def test_route_then_insert_equals_direct(pkg, synth):
         kmers, nodes = g.finish_count()
         assert (kmers, nodes) == (total, o.node_count())
         assert (g.mark_and_hist()[0] == ohist).all()
+
+
+@pytest.mark.parametrize("K,stride,base", [(21, 1, 0), (35, 2, 1)])
+def test_first_occurrence_ordinals(pkg, synth, K, stride, base):
+    """SDT_FLAG_TRACK_FIRST: per node, the smallest (read ordinal << 16 | position) over its occurrences --
+    the order the reference's table layout is a function of"""
+    tx = synth.make_transcriptome(10, seed=2)
+    codes, offs = synth.sample_reads(*tx, n_reads=1500, read_len=80, seed=3, ragged=True)
+    want = {}
+    for r in range(len(offs) - 1):
+        keys, _, _, _ = ob.chop_read(codes[int(offs[r]):int(offs[r + 1])], K)
+        for j, kw in enumerate(keys_to_int(keys)):
+            o = ((base + r * stride) << 16) | j
+            if kw not in want or o < want[kw]:
+                want[kw] = o
+    with pkg.PregraphGPU(K, est_distinct=1 << 14, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:      # small table: growth keeps them
+        g.set_read_ordinal(base, stride)
+        half = 700
+        g.push_reads(synth.pack_2bit(codes[: int(offs[half])]), offs[: half + 1])
+        g.push_reads(synth.pack_2bit(codes[int(offs[half]):]), offs[half:] - offs[half])      # ordinals continue
+        g.finish_count()
+        keys, l, rf, cnt, first = g.export_nodes(with_first=True)
+        got = dict(zip(keys_to_int(keys), (int(x) for x in first)))
+        assert got == want
+    with pkg.PregraphGPU(K) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        with pytest.raises(pkg.SdtError):
+            g.export_nodes(with_first=True)

@@ -76,16 +76,18 @@ def test_config_parser(pkg, tmp_path):
 def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name):
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
-    cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", "3", "-o",
+    cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
            str(tmp_path / "out"), "--max-k", str(gu.VARIANT_MAXK[info["variant"]])]
     if info["d"]:
         cmd += ["-d", str(info["d"])]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")
+    assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")      # same -p => same order
+    assert [int(x) for x in re.findall(r"(\d+) tips off", r.stdout)] == info["tips_off"]
     m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", r.stdout)
     assert (int(m.group(1)), int(m.group(2))) == (info["nodes_allocated"], info["kmer_in_reads"])
-    assert int(re.search(r"(\d+) linear nodes", r.stdout).group(1)) == info["linear_nodes"]
+    assert [int(x) for x in re.findall(r"(\d+) linear nodes", r.stdout)] == info["linear_after"]
     if info["d"]:
         assert int(re.search(r"(\d+) kmer removed", r.stdout).group(1)) == info["kmer_removed"]
 
@@ -98,3 +100,58 @@ def test_cli_usage_and_errors(pkg, tmp_path):
     r = subprocess.run([exe, "-s", str(tmp_path / "missing.cfg"), "-o", str(tmp_path / "o")], capture_output=True,
                        text=True)
     assert r.returncode != 0 and "Cannot open" in r.stdout
+
+
+def first_ordinals(info, K, codes, offs):
+    """(read ordinal << 16 | position) of the first occurrence of every canonical k-mer, in the reference's read
+    order (case_reads already interleaves paired files)"""
+    import oracle_binding as ob
+    first = {}
+    for r in range(len(offs) - 1):
+        keys, _, _, _ = ob.chop_read(codes[int(offs[r]):int(offs[r + 1])], K)
+        for j in range(len(keys)):
+            kw = tuple(int(x) for x in keys[j])
+            if kw not in first:
+                first[kw] = (r << 16) | j
+    return first
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
+    """csrc/host/graph (layout replay from first-occurrence order + minor-out + tip cutting + output_vertex) on the
+    node table a GPU run would export (built here with the oracle): *.vertex byte-identical to the reference at the
+    same -p, for 31/63/127mer variants"""
+    import struct
+    import oracle_binding as ob
+    info = gu.load_case(name)
+    variant = info["variant"]
+    K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
+    codes, offs = gu.case_reads(info)
+    nwv, nwk = gu.VARIANT_WORDS[variant], ob.key_words_for(K)
+    o = ob.Oracle(K, nsets=3, nw=nwk)                 # any partition: only the node contents are taken from here
+    o.add_reads(codes, offs)
+    if info["d"]:
+        o.delow(info["d"])
+    o.mark()
+    keys, l, r, cnt, fl = o.export()
+    first = first_ordinals(info, K, codes, offs)
+    n = len(keys)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(n)                          # the GPU exports in arbitrary order
+    rflags = (r.astype(np.uint32) | ((fl & 1).astype(np.uint32) << 24) | (((fl >> 1) & 1).astype(np.uint32) << 25)
+              | (((fl >> 2) & 1).astype(np.uint32) << 27))
+    fo = np.array([first[tuple(int(x) for x in k)] for k in keys], dtype=np.uint64)
+    dump = tmp_path / "nodes.bin"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<6iQ", K, nwv, nwk, info["p"], info["d"], 5, n))
+        f.write(np.ascontiguousarray(keys[perm][:, 4 - nwk:]).tobytes())
+        f.write(l[perm].astype(np.uint32).tobytes())
+        f.write(rflags[perm].tobytes())
+        f.write(cnt[perm].astype(np.uint32).tobytes())
+        f.write(fo[perm].tobytes())
+    out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out")], check=True,
+                         capture_output=True, text=True).stdout
+    assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
+    assert int(re.search(r"(\d+) kmers off", out).group(1)) == info["kmers_off"]
+    assert [int(x) for x in re.findall(r"(\d+) tips off", out)] == info["tips_off"]
+    assert [int(x) for x in re.findall(r"(\d+) linear nodes", out)] == info["linear_after"][1:]
