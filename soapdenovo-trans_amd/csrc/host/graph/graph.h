@@ -22,6 +22,14 @@ typedef struct {
 	uint32_t count;
 } gnode_t;
 
+/* (K+1)-mer of an edge of length 1 (two adjacent junction k-mers): the reference keeps these in a second
+ * set of tables, KmerSetsPatch (node2edge.c:404-463), looked up by prlRead2edge */
+typedef struct {
+	kw_t seq;              /* canonical (K+1)-mer */
+	uint32_t edge;         /* kmer_t.l_links of the patch node */
+	uint8_t twin, used;
+} gpatch_t;
+
 typedef struct {
 	int K, nw, p;
 	uint64_t n;
@@ -29,6 +37,9 @@ typedef struct {
 	uint64_t *set_start;               /* p + 1 offsets into nodes[] */
 	uint64_t *index;                   /* open addressing: node id + 1, 0 = empty */
 	uint64_t index_mask;
+	gpatch_t *patch;                   /* open addressing over canonical (K+1)-mers */
+	uint64_t patch_mask, patch_n;
+	uint64_t num_ed;                   /* edge_c of kmer2edges: ids handed out, twins included */
 } graph_t;
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
@@ -48,6 +59,12 @@ gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller);
 uint64_t graph_remove_minor_out(graph_t *g, int dd);       /* prints the reference's lines, returns kmers off */
 uint64_t graph_remove_single_tips(graph_t *g);
 uint64_t graph_remove_minor_tips(graph_t *g);
+
+/* kmer2edges (node2edge.c:46-56): walks every unbranched chain between two non-linear nodes once, writes
+ * <prefix>.edge.gz, numbers the edges in visiting order, stamps interior nodes with their edge id.
+ * Returns num_ed. */
+uint64_t graph_build_edges(graph_t *g, const char *prefix);
+const gpatch_t *graph_find_patch(const graph_t *g, const kw_t *canon_kplus1);
 
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);

@@ -26,8 +26,9 @@ int main(int argc, char **argv)
 	graph_remove_minor_out(G, dd);
 	if (!d) graph_remove_single_tips(G);
 	graph_remove_minor_tips(G);
+	uint64_t ne = graph_build_edges(G, argv[2]);
 	uint64_t nv = graph_write_vertex(G, argv[2]);
-	graph_write_basic(argv[2], nv, K, 0, 0);
+	graph_write_basic(argv[2], nv, K, ne, 0);
 	graph_free(G);
 	return 0;
 }

@@ -185,8 +185,11 @@ int main(int argc, char **argv)
 		if (!d) graph_remove_single_tips(G);                               /* pregraph.c:75-88 */
 		graph_remove_minor_tips(G);
 		printf("time spent on cutTipe: %ds\n\n", (int)(time(NULL) - t0));
+		t0 = time(NULL);
+		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */
+		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
 		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
-		graph_write_basic(prefix, nv, K, 0, max_read_len);
+		graph_write_basic(prefix, nv, K, ne, max_read_len);
 		graph_free(G);
 	}
 	if (gpu) sdt_gpu_destroy(gpu);

@@ -84,6 +84,8 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name):
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")      # same -p => same order
+    assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
+    assert open(tmp_path / "out.preGraphBasic").read() == gu.golden_text(info, "preGraphBasic")
     assert [int(x) for x in re.findall(r"(\d+) tips off", r.stdout)] == info["tips_off"]
     m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", r.stdout)
     assert (int(m.group(1)), int(m.group(2))) == (info["nodes_allocated"], info["kmer_in_reads"])
@@ -152,6 +154,9 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
     out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out")], check=True,
                          capture_output=True, text=True).stdout
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
+    assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
+    basic = open(tmp_path / "out.preGraphBasic").read().split("\n\nMaxReadLen")[0]
+    assert basic == gu.golden_text(info, "preGraphBasic").split("\n\nMaxReadLen")[0]      # VERTEX n K k / EDGEs n
     assert int(re.search(r"(\d+) kmers off", out).group(1)) == info["kmers_off"]
     assert [int(x) for x in re.findall(r"(\d+) tips off", out)] == info["tips_off"]
     assert [int(x) for x in re.findall(r"(\d+) linear nodes", out)] == info["linear_after"][1:]
