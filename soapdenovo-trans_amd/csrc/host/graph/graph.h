@@ -66,6 +66,13 @@ uint64_t graph_remove_minor_tips(graph_t *g);
 uint64_t graph_build_edges(graph_t *g, const char *prefix);
 const gpatch_t *graph_find_patch(const graph_t *g, const kw_t *canon_kplus1);
 
+/* prlRead2edge (prlRead2path.c:817-1335): reads -> edge paths -> arcs -> <prefix>.preArc */
+struct arcs;
+struct arcs *arcs_new(void);
+void arcs_free(struct arcs *A);
+void arcs_add_read(graph_t *g, struct arcs *A, const uint8_t *codes, int len, uint64_t ordinal);
+int arcs_write(struct arcs *A, const char *prefix);
+
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);
 int graph_write_basic(const char *prefix, uint64_t vertices, int K, uint64_t num_ed, int max_read_len);

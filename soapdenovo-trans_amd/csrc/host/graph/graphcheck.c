@@ -1,10 +1,26 @@
 /* graphcheck.c -- host-logic self test (no GPU): run the host graph phases of sdt-pregraph on a node dump.
  * dump (little endian): int32 K, nw_variant, nw_keys, p, d, dd; uint64 n; then keys[n*nw_keys] u64,
  * l_links[n] u32, r_flags[n] u32, count[n] u32, first[n] u64 -- exactly what sdt_gpu_export_nodes returns.
- * usage: sdt-graphcheck <dump> <out prefix> */
+ * usage: sdt-graphcheck <dump> <out prefix> [<lib.cfg>]   (with a config: also the second read pass -> .preArc) */
 #include <stdio.h>
 #include <stdlib.h>
 #include "graph.h"
+#include "../readstream.h"
+
+typedef struct { graph_t *G; struct arcs *A; } arc_state;
+static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
+{
+	arc_state *st = (arc_state *)user;
+	uint8_t *codes = (uint8_t *)malloc(1 << 16);
+	for (uint64_t r = 0; r < b->nreads; r++) {
+		const uint64_t o = b->offsets[r], len = b->offsets[r + 1] - o;
+		for (uint64_t i = 0; i < len && i < (1 << 16); i++)
+			codes[i] = (uint8_t)((b->words[(o + i) >> 4] >> (30 - 2 * ((o + i) & 15))) & 3u);
+		arcs_add_read(st->G, st->A, codes, (int)len, ord_base + r * ord_stride);
+	}
+	free(codes);
+	return 0;
+}
 
 #define RD(ptr, sz, cnt) do { if (fread(ptr, sz, cnt, fi) != (size_t)(cnt)) { fprintf(stderr, "short dump\n"); return 2; } } while (0)
 
@@ -27,6 +43,15 @@ int main(int argc, char **argv)
 	if (!d) graph_remove_single_tips(G);
 	graph_remove_minor_tips(G);
 	uint64_t ne = graph_build_edges(G, argv[2]);
+	if (argc > 3) {
+		sdt_cfg cfg;
+		if (sdt_cfg_load(argv[3], &cfg) != 0) return 2;
+		arc_state as = {G, arcs_new()};
+		if (sdt_stream_reads(&cfg, cfg.max_rd_len ? cfg.max_rd_len : 100, 3, 50000, 0, arc_batch, &as, NULL) != 0) return 2;
+		arcs_write(as.A, argv[2]);
+		arcs_free(as.A);
+		sdt_cfg_free(&cfg);
+	}
 	uint64_t nv = graph_write_vertex(G, argv[2]);
 	graph_write_basic(argv[2], nv, K, ne, 0);
 	graph_free(G);

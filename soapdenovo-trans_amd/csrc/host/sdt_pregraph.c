@@ -16,6 +16,7 @@
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
+#include "readstream.h"
 #include "graph/graph.h"
 
 #ifndef SDT_MAX_K
@@ -37,17 +38,42 @@ typedef struct {
 	unsigned long long reads;
 } push_state;
 
-static int push_batch(void *user, const sdt_batch *b)
+static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
 {
 	push_state *st = (push_state *)user;
 	unsigned long long before = st->reads / 1000000ULL;
 	st->reads += b->nreads;
 	if (st->reads / 1000000ULL != before)
 		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);    /* prlHashReads.c:587-588 */
+	sdt_gpu_set_read_ordinal(st->gpu, ord_base, ord_stride);
 	if (sdt_gpu_push_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_push_reads: %s\n", sdt_gpu_last_error());
 		return -1;
 	}
+	return 0;
+}
+
+/* second pass (prlRead2edge): unpack each read and thread it through the edge graph */
+typedef struct {
+	graph_t *G;
+	struct arcs *A;
+	unsigned long long reads;
+} arc_state;
+
+static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
+{
+	arc_state *st = (arc_state *)user;
+	uint8_t *codes = NULL;
+	size_t cap = 0;
+	for (uint64_t r = 0; r < b->nreads; r++) {
+		const uint64_t o = b->offsets[r], len = b->offsets[r + 1] - o;
+		if (len > cap) { cap = len * 2 + 64; codes = (uint8_t *)realloc(codes, cap); }
+		for (uint64_t i = 0; i < len; i++)
+			codes[i] = (uint8_t)((b->words[(o + i) >> 4] >> (30 - 2 * ((o + i) & 15))) & 3u);
+		arcs_add_read(st->G, st->A, codes, (int)len, ord_base + r * ord_stride);
+	}
+	st->reads += b->nreads;
+	free(codes);
 	return 0;
 }
 
@@ -104,40 +130,8 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	push_state st = {gpu, 0};
-	uint64_t ordinal = 0;
 	const size_t chunk = 32u << 20;
-	int rc = 0;
-	for (int i = 0; i < cfg.nlibs && rc == 0; i++) {
-		sdt_lib *l = &cfg.libs[i];
-		if (l->asm_flag != 1 && l->asm_flag != 3)                           /* readseq1by1.c:563 */
-			continue;
-		int mrl = max_read_len;                                              /* prlHashReads.c:820-823 */
-		if (l->rd_len_cutoff > 0 && l->rd_len_cutoff < mrl) mrl = l->rd_len_cutoff;
-		if (l->nb) {
-			fprintf(stderr, "b= (BAM) input is not supported by this build\n");
-			rc = -1;
-			break;
-		}
-		/* file-type order of nextValidIndex (readseq1by1.c:579-632): f1/f2 pairs, q1/q2 pairs, p, [b], f, q.
-		 * Read ordinals follow the reference's consumption order: paired files alternate read1, read2, ...
-		 * (prlHashReads.c:493-567), so file 1 gets ordinals base, base+2, ... and file 2 base+1, base+3, ... */
-		struct { char **a; char **b; int n; int fmt; int type; } groups[] = {
-			{l->f1, l->f2, l->nf1 < l->nf2 ? l->nf1 : l->nf2, 'a', 1}, {l->q1, l->q2, l->nq1 < l->nq2 ? l->nq1 : l->nq2, 'q', 2},
-			{l->p, NULL, l->np, 'a', 3}, {l->f, NULL, l->nf, 'a', 5}, {l->q, NULL, l->nq, 'q', 6}};
-		for (unsigned g = 0; g < sizeof groups / sizeof groups[0] && rc == 0; g++)
-			for (int f = 0; f < groups[g].n && rc == 0; f++) {
-				uint64_t n1 = 0, n2 = 0;
-				printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].a[f]);
-				if (groups[g].b) printf("read from file - type %d:\n %s\n", groups[g].type, groups[g].b[f]);
-				sdt_gpu_set_read_ordinal(gpu, ordinal, groups[g].b ? 2 : 1);
-				rc = sdt_read_file(groups[g].a[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, &n1);
-				if (rc == 0 && groups[g].b) {
-					sdt_gpu_set_read_ordinal(gpu, ordinal + 1, 2);
-					rc = sdt_read_file(groups[g].b[f], groups[g].fmt, mrl, l->reverse, threads, chunk, push_batch, &st, &n2);
-				}
-				ordinal += groups[g].b ? 2 * (n1 > n2 ? n1 : n2) : n1;
-			}
-	}
+	int rc = sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, push_batch, &st, NULL);
 	if (rc != 0) { sdt_gpu_destroy(gpu); return 1; }
 	uint64_t kmers = 0, nodes = 0, removed = 0, linear = 0;
 	if (sdt_gpu_finish_count(gpu, &kmers, &nodes) != SDT_OK) {
@@ -188,6 +182,14 @@ int main(int argc, char **argv)
 		t0 = time(NULL);
 		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */
 		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
+		t0 = time(NULL);
+		arc_state as = {G, arcs_new(), 0};                                 /* pregraph.c:101-104 */
+		printf("%d thread created prlRead2path\n", threads);
+		if (sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, arc_batch, &as, NULL) != 0) return 1;
+		printf("%llu reads processed\n", as.reads);
+		arcs_write(as.A, prefix);
+		arcs_free(as.A);
+		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
 		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
 		graph_write_basic(prefix, nv, K, ne, max_read_len);
 		graph_free(G);

@@ -86,6 +86,7 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name):
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")      # same -p => same order
     assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
     assert open(tmp_path / "out.preGraphBasic").read() == gu.golden_text(info, "preGraphBasic")
+    assert open(tmp_path / "out.preArc").read() == gu.golden_text(info, "preArc")
     assert [int(x) for x in re.findall(r"(\d+) tips off", r.stdout)] == info["tips_off"]
     m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", r.stdout)
     assert (int(m.group(1)), int(m.group(2))) == (info["nodes_allocated"], info["kmer_in_reads"])
@@ -151,8 +152,10 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
         f.write(rflags[perm].tobytes())
         f.write(cnt[perm].astype(np.uint32).tobytes())
         f.write(fo[perm].tobytes())
-    out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out")], check=True,
+    cfg = materialise(info, tmp_path)
+    out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out"), cfg], check=True,
                          capture_output=True, text=True).stdout
+    assert open(tmp_path / "out.preArc").read() == gu.golden_text(info, "preArc")
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
     assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
     basic = open(tmp_path / "out.preGraphBasic").read().split("\n\nMaxReadLen")[0]
@@ -160,3 +163,34 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
     assert int(re.search(r"(\d+) kmers off", out).group(1)) == info["kmers_off"]
     assert [int(x) for x in re.findall(r"(\d+) tips off", out)] == info["tips_off"]
     assert [int(x) for x in re.findall(r"(\d+) linear nodes", out)] == info["linear_after"][1:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["se100_k23_p8", "pe150_k31_p8"])
+def test_reference_contig_runs_unchanged_on_our_pregraph_output(pkg, tmp_path, name):
+    """north star: contig (unmodified reference binary) consumes sdt-pregraph's files and produces the same
+    *.contig as on the reference's own pregraph output"""
+    import oracle_binding as ob
+    import shutil
+    ref = ob.ref_binary(31)
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    info = gu.load_case(name)
+    ours, theirs = tmp_path / "ours", tmp_path / "theirs"
+    ours.mkdir()
+    theirs.mkdir()
+    cfg = materialise(info, ours)
+    for f in os.listdir(ours):
+        shutil.copy(ours / f, theirs / f)
+    cfg2 = str(theirs / "lib.cfg")
+    open(cfg2, "w").write(open(cfg).read().replace(str(ours), str(theirs)))
+    r = subprocess.run([bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]),
+                        "-o", str(ours / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    subprocess.run([ref, "pregraph", "-s", cfg2, "-K", str(info["K"]), "-p", str(info["p"]), "-o", str(theirs / "out")],
+                   check=True, capture_output=True, timeout=600)
+    for d in (ours, theirs):
+        subprocess.run([ref, "contig", "-g", str(d / "out")], check=True, capture_output=True, timeout=600)
+    for ext in ("contig", "updated.edge", "Arc", "ContigIndex"):
+        assert open(ours / f"out.{ext}").read() == open(theirs / f"out.{ext}").read(), ext
+    assert os.path.getsize(ours / "out.contig") > 0
