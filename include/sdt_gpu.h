@@ -50,6 +50,9 @@ typedef struct sdt_ctx sdt_ctx;
  * The reference's table layout -- hence the visiting order of its cutting passes, the order of *.vertex and the
  * edge ids -- is a function of exactly this order; the host replays it (csrc/host/graph). */
 #define SDT_FLAG_TRACK_FIRST 4u
+/* Keep every pushed batch of packed reads resident in HBM so that the second pass over the reads
+ * (prlRead2edge, sdt_gpu_map_reads) needs no re-parse: 0.25 B/base, 7.5 GB for 200 M x 150 bp. */
+#define SDT_FLAG_KEEP_READS 8u
 
 /* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
  * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
@@ -132,6 +135,21 @@ int sdt_gpu_mark_and_hist(sdt_ctx *ctx, int64_t hist[257], uint64_t *linear);
  * Any array may be NULL.  *n receives the node count. */
 int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags,
                          uint32_t *count, uint64_t *first, uint64_t max_nodes, uint64_t *n);
+
+/* ---- pass 2: reads -> edge paths -> arcs (prlRead2edge, prlRead2path.c:817-1335) --------------------------
+ * After the host graph phases (minor-out, tip cutting, kmer2edges) every node gets one path word
+ *     bit 0 skip = deleted || (linear && !inEdge) (:650) | bit 1 linear | bits 2..3 twin | bits 32..63 l_links = edge id
+ * and the (K+1)-mers of length-1 edges (KmerSetsPatch, node2edge.c:404-463) come as patch_keys (key_words()
+ * words each, most significant first) with patch_info = edge id | twin << 32.  load_paths overwrites the
+ * nodes' counters with the path words (export the table first).  map_reads then replays parse1read (:617-789),
+ * search1kmerPlus (:575-615) and the arc counting (:190-241,415-430) over the kept reads; export_arcs returns
+ * every arc with its multiplicity and the ordinal of its first appearance ((read ordinal << 16) | item index):
+ * per from-edge the reference prints arcs most-recent-first-appearance first (:427-428,472-496). */
+int sdt_gpu_load_paths(sdt_ctx *ctx, const uint64_t *keys, const uint64_t *path_words, uint64_t n,
+                       const uint64_t *patch_keys, const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed);
+int sdt_gpu_map_reads(sdt_ctx *ctx, uint64_t *reads_processed, uint64_t *arcs);
+int sdt_gpu_export_arcs(sdt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *mult, uint64_t *first,
+                        uint64_t max_arcs, uint64_t *n);
 
 /* ---- introspection / measurement --------------------------------------------------------------- */
 int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */

@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
-SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST = 1, 2, 4
+SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST, SDT_FLAG_KEEP_READS = 1, 2, 4, 8
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
@@ -48,6 +48,11 @@ _ABI = [
      [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
       _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_set_read_ordinal", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_load_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p,
+                                      _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_map_reads", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_export_arcs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
+                                       _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
     ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),

@@ -72,6 +72,8 @@ struct arcs *arcs_new(void);
 void arcs_free(struct arcs *A);
 void arcs_add_read(graph_t *g, struct arcs *A, const uint8_t *codes, int len, uint64_t ordinal);
 int arcs_write(struct arcs *A, const char *prefix);
+int arcs_write_arrays(const char *prefix, const uint32_t *from, const uint32_t *to, const uint32_t *mult,
+                      const uint64_t *first, uint64_t n);
 
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);

@@ -163,3 +163,21 @@ int arcs_write(struct arcs *A, const char *prefix)
 	free(v);
 	return 0;
 }
+
+/* same file from arcs accumulated elsewhere (the GPU second pass): arrays of (from, to, multiplicity, first) */
+int arcs_write_arrays(const char *prefix, const uint32_t *from, const uint32_t *to, const uint32_t *mult,
+                      const uint64_t *first, uint64_t n)
+{
+	struct arcs A;
+	A.tab = (arc_t *)calloc(n + 1, sizeof(arc_t));
+	A.mask = n;             /* arcs_write scans 0..mask */
+	A.n = n;
+	for (uint64_t i = 0; i < n; i++) {
+		A.tab[i].key = ((uint64_t)from[i] << 32) | to[i];
+		A.tab[i].first = first[i];
+		A.tab[i].mult = mult[i];
+	}
+	const int rc = arcs_write(&A, prefix);
+	free(A.tab);
+	return rc;
+}

@@ -80,11 +80,11 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
 int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", prefix[4096] = "";
-	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0;
+	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0, host_map = 0;
 	int have_s = 0, have_o = 0, c;
 	unsigned long long est = 0;
 	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
-	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003},
+	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003}, {"host-map", no_argument, 0, 1004},
 	                                   {0, 0, 0, 0}};
 	/* accept an optional leading "pregraph" sub-command like the reference's dispatcher (main.c:49-106) */
 	if (argc > 1 && strcmp(argv[1], "pregraph") == 0) { argv++; argc--; }
@@ -104,6 +104,7 @@ int main(int argc, char **argv)
 		case 1001: device = atoi(optarg); break;
 		case 1002: est = strtoull(optarg, NULL, 10); break;
 		case 1003: hash_only = 1; break;
+		case 1004: host_map = 1; break;
 		default:
 			if (!have_s || !have_o) { usage(max_k ? max_k : SDT_MAX_K); return 255; }
 		}
@@ -125,7 +126,7 @@ int main(int argc, char **argv)
 	printf("In %s, %d libs, max seq len %d, max name len %d\n\n", cfgfile, cfg.nlibs, max_read_len, 256);
 
 	sdt_ctx *gpu = NULL;
-	if (sdt_gpu_init(&gpu, device, K, est, hash_only ? 0 : SDT_FLAG_TRACK_FIRST) != SDT_OK) {
+	if (sdt_gpu_init(&gpu, device, K, est, hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | (host_map ? 0 : SDT_FLAG_KEEP_READS))) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
@@ -168,8 +169,7 @@ int main(int argc, char **argv)
 		uint64_t *keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8), *first = (uint64_t *)malloc((n + 1) * 8);
 		uint32_t *ll = (uint32_t *)malloc((n + 1) * 4), *rf = (uint32_t *)malloc((n + 1) * 4), *cnt = (uint32_t *)malloc((n + 1) * 4);
 		if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
-		sdt_gpu_destroy(gpu);
-		gpu = NULL;
+		if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
 		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
 		free(keys); free(first); free(ll); free(rf); free(cnt);
 		time_t t0 = time(NULL);
@@ -183,12 +183,43 @@ int main(int argc, char **argv)
 		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */
 		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
-		arc_state as = {G, arcs_new(), 0};                                 /* pregraph.c:101-104 */
-		printf("%d thread created prlRead2path\n", threads);
-		if (sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, arc_batch, &as, NULL) != 0) return 1;
-		printf("%llu reads processed\n", as.reads);
-		arcs_write(as.A, prefix);
-		arcs_free(as.A);
+		printf("%d thread created prlRead2path\n", threads);                /* pregraph.c:101-104 */
+		if (host_map) {
+			arc_state as = {G, arcs_new(), 0};
+			if (sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, arc_batch, &as, NULL) != 0) return 1;
+			printf("%llu reads processed\n", as.reads);
+			arcs_write(as.A, prefix);
+			arcs_free(as.A);
+		} else {
+			/* second pass on the GPU over the reads kept in HBM: send the cleaned graph back as path words */
+			uint64_t *pk = (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8), *pw = (uint64_t *)malloc((G->n + 1) * 8);
+			for (uint64_t i = 0; i < G->n; i++) {
+				const gnode_t *nd = &G->nodes[i];
+				for (int w = 0; w < nwk; w++) pk[i * nwk + w] = nd->seq.w[4 - nwk + w];
+				const int skip = nd->deleted || (nd->linear && !nd->inEdge);
+				pw[i] = (uint64_t)skip | ((uint64_t)nd->linear << 1) | ((uint64_t)nd->twin << 2) | ((uint64_t)nd->l_links << 32);
+			}
+			uint64_t np = 0;
+			uint64_t *qk = (uint64_t *)malloc((G->patch_n + 1) * (size_t)nwk * 8), *qi = (uint64_t *)malloc((G->patch_n + 1) * 8);
+			for (uint64_t i = 0; G->patch && i <= G->patch_mask; i++)
+				if (G->patch[i].used) {
+					for (int w = 0; w < nwk; w++) qk[np * nwk + w] = G->patch[i].seq.w[4 - nwk + w];
+					qi[np++] = (uint64_t)G->patch[i].edge | ((uint64_t)G->patch[i].twin << 32);
+				}
+			uint64_t nreads2 = 0, narcs = 0;
+			if (sdt_gpu_load_paths(gpu, pk, pw, G->n, qk, qi, np, G->num_ed) != SDT_OK ||
+			    sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
+				fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error());
+				return 1;
+			}
+			free(pk); free(pw); free(qk); free(qi);
+			uint32_t *af = (uint32_t *)malloc((narcs + 1) * 4), *at = (uint32_t *)malloc((narcs + 1) * 4), *am = (uint32_t *)malloc((narcs + 1) * 4);
+			uint64_t *ao = (uint64_t *)malloc((narcs + 1) * 8);
+			if (sdt_gpu_export_arcs(gpu, af, at, am, ao, narcs, &narcs) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+			printf("%llu reads processed\n", (unsigned long long)nreads2);
+			arcs_write_arrays(prefix, af, at, am, ao, narcs);
+			free(af); free(at); free(am); free(ao);
+		}
 		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
 		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
 		graph_write_basic(prefix, nv, K, ne, max_read_len);

@@ -431,6 +431,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 }
 
 #include "sdt_partition_kernels.cuh"
+#include "sdt_map_kernels.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -471,6 +472,14 @@ struct sdt_ctx {
 	PartBufs pb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	uint64_t part_cap = 0;             // records A and B can hold
 	unsigned long long *h_off2 = nullptr;   // pinned copy of off2 (NBF + 1)
+	// second pass (prlRead2edge): reads kept from pass 1, path words, patch table, arcs
+	struct KeptBatch { uint32_t *d_words; uint64_t *d_offs; uint64_t nwords, nreads, ord_base, ord_stride, maxlen; };
+	std::vector<KeptBatch> kept;
+	void *d_patch = nullptr;
+	uint64_t patch_slots = 0;
+	ArcEnt *d_arcs = nullptr;
+	uint64_t arc_slots = 0;
+	bool paths_loaded = false;
 	// timing
 	std::vector<EventPair> ev;
 	size_t ev_used = 0;
@@ -616,6 +625,34 @@ static int tile_words_for(uint64_t max_read_len)
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+template <int NW>
+static int build_patch_table(sdt_ctx *c, const uint64_t *pkeys, const uint64_t *pinfo, uint64_t np)
+{
+	uint64_t slots = 1024;
+	while (slots < 2 * np + 2)
+		slots <<= 1;
+	std::vector<PatchEnt<NW>> tab(slots);
+	for (auto &e : tab) {
+		for (int w = 0; w < NW; w++) e.key[w] = KEY_EMPTY;
+		e.info = 0;
+	}
+	for (uint64_t i = 0; i < np; i++) {
+		Key<NW> k;
+		for (int w = 0; w < NW; w++) k.w[w] = pkeys[i * NW + w];
+		uint64_t s = key_hash<NW>(k) & (slots - 1);
+		while (tab[s].key[0] != KEY_EMPTY) s = (s + 1) & (slots - 1);
+		for (int w = 0; w < NW; w++) tab[s].key[w] = k.w[w];
+		tab[s].info = pinfo[i];
+	}
+	if (c->d_patch) HIPCHK(hipFree(c->d_patch));
+	c->d_patch = nullptr;
+	HIPCHK(hipMalloc(&c->d_patch, slots * sizeof(PatchEnt<NW>)));
+	HIPCHK(hipMemcpy(c->d_patch, tab.data(), slots * sizeof(PatchEnt<NW>), hipMemcpyHostToDevice));
+	c->patch_slots = slots;
+	return SDT_OK;
+}
+
+
 extern "C" {
 
 const char *sdt_gpu_last_error(void) { return g_err; }
@@ -720,6 +757,9 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
 	if (c->d_cursors) (void)hipFree(c->d_cursors);
+	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
+	if (c->d_patch) (void)hipFree(c->d_patch);
+	if (c->d_arcs) (void)hipFree(c->d_arcs);
 	if (c->pb.hist) (void)hipFree(c->pb.hist);
 	if (c->pb.off2) (void)hipFree(c->pb.off2);
 	if (c->pb.cursor1) (void)hipFree(c->pb.cursor1);
@@ -748,6 +788,9 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->kmers_total_host = 0;
 	c->ord_base = 0;
 	c->ord_stride = 1;
+	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
+	c->kept.clear();
+	c->paths_loaded = false;
 	return SDT_OK;
 }
 
@@ -962,6 +1005,26 @@ int sdt_gpu_push_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords
 	if (((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
 		return fail(SDT_EINVAL, "packed_words too short: need %llu words incl. %d pad words, got %llu",
 		            (unsigned long long)(((offsets[nreads] + 15) >> 4) + TAIL_PAD), TAIL_PAD, (unsigned long long)nwords);
+	if (c->flags & SDT_FLAG_KEEP_READS) {
+		// the batch stays resident for the second pass: own buffers instead of the recycled staging pair
+		sdt_ctx::KeptBatch kb;
+		kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->ord_base; kb.ord_stride = c->ord_stride; kb.maxlen = maxlen;
+		kb.d_words = nullptr; kb.d_offs = nullptr;
+		HIPCHK(hipMalloc((void **)&kb.d_words, nwords * sizeof(uint32_t)));
+		hipError_t e2 = hipMalloc((void **)&kb.d_offs, (nreads + 1) * sizeof(uint64_t));
+		if (e2 != hipSuccess) { (void)hipFree(kb.d_words); return fail(SDT_ENOMEM, "kept reads: %s", hipGetErrorString(e2)); }
+		c->kept.push_back(kb);
+		HIPCHK(hipMemcpyAsync(kb.d_words, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+		HIPCHK(hipMemcpyAsync(kb.d_offs, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+		HIPCHK(hipEventRecord(c->copied[0], c->copy_stream));
+		HIPCHK(hipStreamWaitEvent(c->stream, c->copied[0], 0));
+		int rck = launch_count(c, kb.d_words, kb.d_offs, nreads, maxlen);
+		if (rck != SDT_OK)
+			return rck;
+		c->kmers_total_host += kmers;
+		HIPCHK(hipStreamSynchronize(c->copy_stream));
+		return SDT_OK;
+	}
 	const int b = c->next_buf;
 	c->next_buf ^= 1;
 	// the kernel that last read this staging buffer must be done before we overwrite it
@@ -1184,6 +1247,145 @@ done:
 	if (d_r) (void)hipFree(d_r);
 	if (d_c) (void)hipFree(d_c);
 	if (d_f) (void)hipFree(d_f);
+	return ret;
+}
+
+// ---- second pass: prlRead2edge on the device ---------------------------------------------------------------
+int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
+                       const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed)
+{
+	if (!c || (n && (!keys || !path_words)) || (npatch && (!patch_keys || !patch_info)))
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	uint64_t *d_k = nullptr, *d_i = nullptr;
+	if (n) {
+		HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
+		hipError_t e = hipMalloc((void **)&d_i, n * sizeof(uint64_t));
+		if (e != hipSuccess) { (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
+		HIPCHK(hipMemcpyAsync(d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_i, path_words, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		const int g = scan_grid(c, n);
+		if (c->nw == 1) hipLaunchKernelGGL(k_set_paths<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_i, n, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_set_paths<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_i, n, c->d_stats);
+		else hipLaunchKernelGGL(k_set_paths<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_i, n, c->d_stats);
+		hipError_t le = hipGetLastError();
+		hipError_t se = hipStreamSynchronize(c->stream);
+		(void)hipFree(d_k);
+		(void)hipFree(d_i);
+		if (le != hipSuccess || se != hipSuccess)
+			return fail(SDT_EHIP, "k_set_paths: %s", hipGetErrorString(le != hipSuccess ? le : se));
+	}
+	int rc = c->nw == 1 ? build_patch_table<1>(c, patch_keys, patch_info, npatch)
+	       : c->nw == 2 ? build_patch_table<2>(c, patch_keys, patch_info, npatch)
+	                    : build_patch_table<4>(c, patch_keys, patch_info, npatch);
+	if (rc != SDT_OK)
+		return rc;
+	// arcs: a few per edge in practice; the map doubles (and the pass is redone) if it ever fills up
+	uint64_t slots = 1 << 16;
+	while (slots < 8 * (num_ed + 1))
+		slots <<= 1;
+	if (c->d_arcs) HIPCHK(hipFree(c->d_arcs));
+	c->d_arcs = nullptr;
+	HIPCHK(hipMalloc((void **)&c->d_arcs, slots * sizeof(ArcEnt)));
+	c->arc_slots = slots;
+	rc = sync_stats(c);
+	if (rc != SDT_OK)
+		return fail(SDT_ESTATE, "sdt_gpu_load_paths: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
+	c->paths_loaded = true;
+	return SDT_OK;
+}
+
+int sdt_gpu_map_reads(sdt_ctx *c, uint64_t *reads_processed, uint64_t *arcs)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	if (!c->paths_loaded)
+		return fail(SDT_ESTATE, "call sdt_gpu_load_paths first");
+	if (!(c->flags & SDT_FLAG_KEEP_READS))
+		return fail(SDT_ESTATE, "the reads were not kept: init with SDT_FLAG_KEEP_READS");
+	HIPCHK(hipSetDevice(c->device));
+	for (int attempt = 0; attempt < 8; attempt++) {
+		// ArcEnt.first starts at ~0 (atomicMin), key/mult at 0
+		HIPCHK(hipMemsetAsync(c->d_arcs, 0, c->arc_slots * sizeof(ArcEnt), c->stream));
+		HIPCHK(hipMemset2DAsync(&c->d_arcs[0].first, sizeof(ArcEnt), 0xFF, sizeof(unsigned long long), c->arc_slots, c->stream));
+		HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
+		uint64_t reads = 0;
+		for (auto &kb : c->kept) {
+			const int g = scan_grid(c, kb.nreads);
+			if (c->nw == 1) hipLaunchKernelGGL(k_map_reads<1>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<1>(c), (const PatchEnt<1> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_map_reads<2>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<2>(c), (const PatchEnt<2> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			else hipLaunchKernelGGL(k_map_reads<4>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<4>(c), (const PatchEnt<4> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			HIPCHK(hipGetLastError());
+			reads += kb.nreads;
+		}
+		HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (c->h_stats->scratch)
+			return fail(SDT_ESTATE, "%llu reads hold a k-mer that is not in the node table (different reads than pass 1?)",
+			            (unsigned long long)c->h_stats->scratch);
+		if (c->h_stats->probe_fail == 0) {
+			if (reads_processed) *reads_processed = reads;
+			if (arcs) {
+				// count occupied slots by exporting nothing but the cursor
+				unsigned long long *d_cur = nullptr;
+				HIPCHK(hipMalloc((void **)&d_cur, sizeof(unsigned long long)));
+				HIPCHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream));
+				hipLaunchKernelGGL(k_export_arcs, dim3(scan_grid(c, c->arc_slots)), dim3(TPB), 0, c->stream, c->d_arcs, c->arc_slots, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, 0ULL, d_cur);
+				unsigned long long h = 0;
+				HIPCHK(hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(hipStreamSynchronize(c->stream));
+				(void)hipFree(d_cur);
+				*arcs = h;
+			}
+			return SDT_OK;
+		}
+		// arc map too small: double it and redo the pass (arc adds are idempotent only from a clean map)
+		HIPCHK(hipMemsetAsync(&c->d_stats->probe_fail, 0, sizeof(unsigned long long), c->stream));
+		HIPCHK(hipFree(c->d_arcs));
+		c->d_arcs = nullptr;
+		c->arc_slots <<= 1;
+		HIPCHK(hipMalloc((void **)&c->d_arcs, c->arc_slots * sizeof(ArcEnt)));
+	}
+	return fail(SDT_EFULL, "arc map keeps overflowing");
+}
+
+int sdt_gpu_export_arcs(sdt_ctx *c, uint32_t *from, uint32_t *to, uint32_t *mult, uint64_t *first, uint64_t max_arcs, uint64_t *n)
+{
+	if (!c || !from || !to || !mult || !first)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_arcs)
+		return fail(SDT_ESTATE, "no arcs: call sdt_gpu_map_reads first");
+	HIPCHK(hipSetDevice(c->device));
+	uint32_t *d_f = nullptr, *d_t = nullptr, *d_m = nullptr;
+	uint64_t *d_o = nullptr;
+	unsigned long long *d_cur = nullptr;
+	const uint64_t m = max_arcs ? max_arcs : 1;
+	int ret = SDT_OK;
+	unsigned long long h = 0;
+#define ARC_CHK(expr) do { hipError_t e4_ = (expr); if (e4_ != hipSuccess) { ret = fail(SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e4_)); goto done; } } while (0)
+	ARC_CHK(hipMalloc((void **)&d_f, m * 4));
+	ARC_CHK(hipMalloc((void **)&d_t, m * 4));
+	ARC_CHK(hipMalloc((void **)&d_m, m * 4));
+	ARC_CHK(hipMalloc((void **)&d_o, m * 8));
+	ARC_CHK(hipMalloc((void **)&d_cur, 8));
+	ARC_CHK(hipMemsetAsync(d_cur, 0, 8, c->stream));
+	hipLaunchKernelGGL(k_export_arcs, dim3(scan_grid(c, c->arc_slots)), dim3(TPB), 0, c->stream, c->d_arcs, c->arc_slots, d_f, d_t, d_m, d_o, (unsigned long long)max_arcs, d_cur);
+	ARC_CHK(hipGetLastError());
+	ARC_CHK(hipMemcpyAsync(&h, d_cur, 8, hipMemcpyDeviceToHost, c->stream));
+	ARC_CHK(hipStreamSynchronize(c->stream));
+	if (h > max_arcs) { ret = fail(SDT_EINVAL, "arc arrays hold %llu, need %llu", (unsigned long long)max_arcs, h); goto done; }
+	ARC_CHK(hipMemcpy(from, d_f, h * 4, hipMemcpyDeviceToHost));
+	ARC_CHK(hipMemcpy(to, d_t, h * 4, hipMemcpyDeviceToHost));
+	ARC_CHK(hipMemcpy(mult, d_m, h * 4, hipMemcpyDeviceToHost));
+	ARC_CHK(hipMemcpy(first, d_o, h * 8, hipMemcpyDeviceToHost));
+	if (n) *n = h;
+done:
+	if (d_f) (void)hipFree(d_f);
+	if (d_t) (void)hipFree(d_t);
+	if (d_m) (void)hipFree(d_m);
+	if (d_o) (void)hipFree(d_o);
+	if (d_cur) (void)hipFree(d_cur);
 	return ret;
 }
 

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""End-to-end wall-clock: reference `pregraph` vs `sdt-pregraph` on the same synthetic FASTQ, all five output
+files compared byte for byte (edge.gz after gunzip).  Run on the GPU box:
+    python tools/e2e_pregraph.py --reads 2000000 --read-len 150 --K 31 --p 8
+"""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+from soapdenovo_trans_amd import synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=2_000_000)
+ap.add_argument("--read-len", type=int, default=150)
+ap.add_argument("--K", type=int, default=31)
+ap.add_argument("--p", type=int, default=8)
+ap.add_argument("--T", type=int, default=2000)
+ap.add_argument("--skip-ref", action="store_true")
+args = ap.parse_args()
+
+tmp = tempfile.mkdtemp(prefix="sdt_e2e_")
+try:
+    tx = synth.make_transcriptome(args.T, seed=42)
+    fq = os.path.join(tmp, "reads.fq")
+    t0 = time.time()
+    with open(fq, "wb") as fo:
+        done = 0
+        chunk = 250_000
+        while done < args.reads:
+            n = min(chunk, args.reads - done)
+            codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=args.read_len, seed=1000 + done, err=0.002)
+            letters = synth.BASES[codes].reshape(n, args.read_len)
+            qual = b"I" * args.read_len
+            fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i].tobytes(), qual) for i in range(n)))
+            done += n
+    if os.path.getsize(fq) % 32768 == 0:
+        open(fq, "ab").write(b"\n")
+    synth.write_config(os.path.join(tmp, "lib.cfg"), args.read_len, fastq=[fq])
+    gen_s = time.time() - t0
+    res = {"reads": args.reads, "read_len": args.read_len, "K": args.K, "p": args.p, "fastq_bytes": os.path.getsize(fq),
+           "kmers": args.reads * (args.read_len - args.K + 1), "gen_s": round(gen_s, 1)}
+    subprocess.run(["cat", fq], stdout=subprocess.DEVNULL)                     # warm the page cache
+    ours = os.path.join(pkg.CSRC_DIR, "sdt-pregraph")
+    t0 = time.time()
+    r = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                        os.path.join(tmp, "ours")], capture_output=True, text=True)
+    res["ours_wall_s"] = round(time.time() - t0, 2)
+    if r.returncode != 0:
+        print(r.stdout[-2000:], r.stderr[-2000:])
+        raise SystemExit("sdt-pregraph failed")
+    t0 = time.time()
+    r2 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                         os.path.join(tmp, "ours_hash"), "--hash-only"], capture_output=True, text=True)
+    res["ours_hash_only_wall_s"] = round(time.time() - t0, 2)
+    if not args.skip_ref:
+        ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-Trans-{31 if args.K <= 31 else 127}mer")
+        t0 = time.time()
+        rr = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                             os.path.join(tmp, "ref")], capture_output=True, text=True)
+        res["ref_wall_s"] = round(time.time() - t0, 2)
+        res["ref_phase_lines"] = [l for l in rr.stdout.splitlines() if l.startswith("time spent")]
+        same = {}
+        for ext in ("kmerFreq", "vertex", "preGraphBasic", "preArc"):
+            same[ext] = open(os.path.join(tmp, "ours." + ext), "rb").read() == open(os.path.join(tmp, "ref." + ext), "rb").read()
+        same["edge"] = gzip.open(os.path.join(tmp, "ours.edge.gz")).read() == gzip.open(os.path.join(tmp, "ref.edge.gz")).read()
+        res["identical"] = same
+        res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
+    res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
+    print(json.dumps(res, indent=1))
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
