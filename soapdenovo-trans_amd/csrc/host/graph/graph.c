@@ -1,6 +1,7 @@
 /* graph.c -- see graph.h: layout replay, flat node array, lookup index, hash_kmer. */
 #include "graph.h"
 #include <math.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -161,40 +162,73 @@ static int cmp_ord(const void *a, const void *b)
 	return x->first < y->first ? -1 : x->first > y->first;
 }
 
-graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
-                     const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first)
+/* ---- small fork/join helper: the replay of one set is independent of every other set, and so are node
+ * unpacking and index insertion (the reference itself builds its p tables with p threads) ---- */
+typedef struct build_job build_job;
+typedef void (*job_fn)(build_job *J, int tid);
+struct build_job {
+	job_fn fn;
+	int nthreads;
+	/* inputs */
+	graph_t *g;
+	int nw_keys;
+	uint64_t n;
+	const uint64_t *keys, *first;
+	const uint32_t *l_links, *r_flags, *count;
+	/* shared state */
+	gnode_t *tmp;
+	uint32_t *set_of;
+	uint64_t *per_set;       /* p + 1 prefix */
+	ord_t *ord;
+	volatile int next_set;
+};
+typedef struct { build_job *J; int tid; } job_arg;
+
+static void *job_thread(void *a)
 {
-	graph_t *g = (graph_t *)calloc(1, sizeof *g);
-	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
-	gnode_t *tmp = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
-	uint64_t *per_set = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
-	uint32_t *set_of = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-	for (uint64_t i = 0; i < n; i++) {
-		gnode_t *nd = &tmp[i];
-		for (int w = 0; w < nw_keys; w++) nd->seq.w[4 - nw_keys + w] = keys[i * nw_keys + w];
-		nd->l_links = l_links[i];
-		nd->r_links = r_flags[i] & 0xFFFFFFu;
-		nd->linear = (r_flags[i] >> 24) & 1; nd->deleted = (r_flags[i] >> 25) & 1; nd->single = (r_flags[i] >> 27) & 1;
-		nd->count = count[i];
-		set_of[i] = (uint32_t)(ref_hash_kmer(&nd->seq, nw_variant) % (uint64_t)p);
-		per_set[set_of[i] + 1]++;
+	job_arg *ja = (job_arg *)a;
+	ja->J->fn(ja->J, ja->tid);
+	return NULL;
+}
+
+#include <pthread.h>
+static void run_parallel(build_job *J, job_fn fn)
+{
+	J->fn = fn;
+	pthread_t th[64];
+	job_arg args[64];
+	for (int t = 1; t < J->nthreads; t++) {
+		args[t].J = J; args[t].tid = t;
+		pthread_create(&th[t], NULL, job_thread, &args[t]);
 	}
-	for (int s = 0; s < p; s++) per_set[s + 1] += per_set[s];
-	/* group node ids by set, then order each group by first occurrence */
-	ord_t *ord = (ord_t *)malloc((n ? n : 1) * sizeof(ord_t));
-	uint64_t *fill = (uint64_t *)malloc((size_t)p * sizeof(uint64_t));
-	memcpy(fill, per_set, (size_t)p * sizeof(uint64_t));
-	for (uint64_t i = 0; i < n; i++) {
-		ord_t *o = &ord[fill[set_of[i]]++];
-		o->first = first[i];
-		o->id = i;
+	fn(J, 0);
+	for (int t = 1; t < J->nthreads; t++) pthread_join(th[t], NULL);
+}
+
+static void job_unpack(build_job *J, int tid)
+{
+	const uint64_t lo = J->n * (uint64_t)tid / J->nthreads, hi = J->n * (uint64_t)(tid + 1) / J->nthreads;
+	const int nwk = J->nw_keys;
+	for (uint64_t i = lo; i < hi; i++) {
+		gnode_t *nd = &J->tmp[i];
+		for (int w = 0; w < nwk; w++) nd->seq.w[4 - nwk + w] = J->keys[i * nwk + w];
+		nd->l_links = J->l_links[i];
+		nd->r_links = J->r_flags[i] & 0xFFFFFFu;
+		nd->linear = (J->r_flags[i] >> 24) & 1; nd->deleted = (J->r_flags[i] >> 25) & 1; nd->single = (J->r_flags[i] >> 27) & 1;
+		nd->count = J->count[i];
+		J->set_of[i] = (uint32_t)(ref_hash_kmer(&nd->seq, J->g->nw) % (uint64_t)J->g->p);
 	}
-	g->nodes = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
-	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
-	uint64_t out = 0;
-	for (int s = 0; s < p; s++) {
-		const uint64_t b = per_set[s], e = per_set[s + 1];
-		qsort(ord + b, (size_t)(e - b), sizeof(ord_t), cmp_ord);
+}
+
+static void job_replay(build_job *J, int tid)
+{
+	(void)tid;
+	graph_t *g = J->g;
+	for (;;) {
+		const int s = __sync_fetch_and_add(&J->next_set, 1);
+		if (s >= g->p) break;
+		const uint64_t b = J->per_set[s], e = J->per_set[s + 1];
+		qsort(J->ord + b, (size_t)(e - b), sizeof(ord_t), cmp_ord);
 		replay_t r;
 		memset(&r, 0, sizeof r);
 		r.size = next_prime_kh(1024);                     /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
@@ -203,25 +237,65 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 		r.slot = (int64_t *)malloc(r.size * sizeof(int64_t));
 		for (uint64_t i = 0; i < r.size; i++) r.slot[i] = -1;
 		for (uint64_t i = b; i < e; i++)
-			replay_put(&r, tmp, (int64_t)ord[i].id, nw_variant);
-		g->set_start[s] = out;
+			replay_put(&r, J->tmp, (int64_t)J->ord[i].id, g->nw);
+		uint64_t out = b;                                  /* every node of the set is placed: the set fills [b, e) */
 		for (uint64_t i = 0; i < r.size; i++)
-			if (r.slot[i] >= 0) g->nodes[out++] = tmp[r.slot[i]];
+			if (r.slot[i] >= 0) g->nodes[out++] = J->tmp[r.slot[i]];
 		free(r.slot);
 		free(r.moved);
 	}
-	g->set_start[p] = out;
-	free(ord); free(fill); free(per_set); free(set_of); free(tmp);
+}
+
+static void job_index(build_job *J, int tid)
+{
+	graph_t *g = J->g;
+	const uint64_t lo = g->n * (uint64_t)tid / J->nthreads, hi = g->n * (uint64_t)(tid + 1) / J->nthreads;
+	for (uint64_t i = lo; i < hi; i++) {
+		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
+		while (!__sync_bool_compare_and_swap(&g->index[h], 0, i + 1))
+			h = (h + 1) & g->index_mask;
+	}
+}
+
+graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
+                     const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first)
+{
+	graph_t *g = (graph_t *)calloc(1, sizeof *g);
+	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
+	build_job J;
+	memset(&J, 0, sizeof J);
+	long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+	J.nthreads = (int)(ncpu < 1 ? 1 : (ncpu > 32 ? 32 : ncpu));
+	J.g = g; J.nw_keys = nw_keys; J.n = n; J.keys = keys; J.first = first;
+	J.l_links = l_links; J.r_flags = r_flags; J.count = count;
+	J.tmp = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	J.set_of = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+	J.per_set = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
+	run_parallel(&J, job_unpack);
+	for (uint64_t i = 0; i < n; i++) J.per_set[J.set_of[i] + 1]++;
+	for (int s = 0; s < p; s++) J.per_set[s + 1] += J.per_set[s];
+	/* group node ids by set; each group is then ordered by first occurrence and replayed by one worker */
+	J.ord = (ord_t *)malloc((n ? n : 1) * sizeof(ord_t));
+	uint64_t *fill = (uint64_t *)malloc((size_t)p * sizeof(uint64_t));
+	memcpy(fill, J.per_set, (size_t)p * sizeof(uint64_t));
+	for (uint64_t i = 0; i < n; i++) {
+		ord_t *o = &J.ord[fill[J.set_of[i]]++];
+		o->first = first[i];
+		o->id = i;
+	}
+	free(fill);
+	g->nodes = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
+	memcpy(g->set_start, J.per_set, ((size_t)p + 1) * sizeof(uint64_t));
+	J.next_set = 0;
+	run_parallel(&J, job_replay);
+	free(J.ord); free(J.per_set); free(J.set_of); free(J.tmp);
 	/* index */
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
 	g->index = (uint64_t *)calloc(cap, sizeof(uint64_t));
 	g->index_mask = cap - 1;
-	for (uint64_t i = 0; i < n; i++) {
-		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
-		while (g->index[h]) h = (h + 1) & g->index_mask;
-		g->index[h] = i + 1;
-	}
+	run_parallel(&J, job_index);
 	return g;
 }
 

@@ -38,6 +38,21 @@ typedef struct {
 	unsigned long long reads;
 } push_state;
 
+/* millisecond phase timer on stderr (the reference's own lines on stdout have 1 s resolution) */
+static double now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static double g_t_last;
+static void phase(const char *name)
+{
+	const double t = now_ms();
+	fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", name, t - g_t_last);
+	g_t_last = t;
+}
+
 static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
 {
 	push_state *st = (push_state *)user;
@@ -120,6 +135,7 @@ int main(int argc, char **argv)
 	else if (K > max_k) K = max_k;
 
 	time_t t_start = time(NULL);
+	g_t_last = now_ms();
 	sdt_cfg cfg;
 	if (sdt_cfg_load(cfgfile, &cfg) != 0) return 255;
 	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;                /* prlHashReads.c:361-364 */
@@ -130,6 +146,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
+	phase("config + gpu init");
 	push_state st = {gpu, 0};
 	const size_t chunk = 32u << 20;
 	int rc = sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, push_batch, &st, NULL);
@@ -139,6 +156,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "sdt_gpu_finish_count: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
+	phase("parse + hash (GPU)");
 	printf("time spent on hash reads: %ds, %llu reads processed\n", (int)(time(NULL) - t_start), st.reads);
 	printf("%llu nodes allocated, %llu kmer in reads, %llu kmer processed\n", (unsigned long long)nodes,
 	       (unsigned long long)kmers, (unsigned long long)kmers);
@@ -159,6 +177,7 @@ int main(int argc, char **argv)
 	for (int i = 1; i < 256; i++)
 		fprintf(fo, "%lld\n", (long long)hist[i]);
 	fclose(fo);
+	phase("delow/mark/kmerFreq (GPU)");
 	printf("time spent on pre-graph construction: %ds\n\n", (int)(time(NULL) - t_start));
 	printf("deLowKmer %d, deLowEdge %d\n", d, 1);
 	if (!hash_only) {
@@ -170,17 +189,22 @@ int main(int argc, char **argv)
 		uint32_t *ll = (uint32_t *)malloc((n + 1) * 4), *rf = (uint32_t *)malloc((n + 1) * 4), *cnt = (uint32_t *)malloc((n + 1) * 4);
 		if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 		if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
+		phase("export nodes (D2H)");
 		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
 		free(keys); free(first); free(ll); free(rf); free(cnt);
+		phase("layout replay + index (host)");
 		time_t t0 = time(NULL);
 		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
+		phase("removeMinorOut (host)");
 		printf("time spent on cut kmer: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		if (!d) graph_remove_single_tips(G);                               /* pregraph.c:75-88 */
 		graph_remove_minor_tips(G);
+		phase("tip cutting (host)");
 		printf("time spent on cutTipe: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */
+		phase("kmer2edges (host)");
 		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		printf("%d thread created prlRead2path\n", threads);                /* pregraph.c:101-104 */
@@ -220,10 +244,12 @@ int main(int argc, char **argv)
 			arcs_write_arrays(prefix, af, at, am, ao, narcs);
 			free(af); free(at); free(am); free(ao);
 		}
+		phase(host_map ? "read2edge (host)" : "read2edge (GPU)");
 		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
 		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
 		graph_write_basic(prefix, nv, K, ne, max_read_len);
 		graph_free(G);
+		phase("vertex + preGraphBasic");
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
 	sdt_cfg_free(&cfg);
