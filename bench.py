@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU baseline (0 = skip)")
     ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
     ap.add_argument("--est-distinct", type=int, default=0)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (extract_route -> all-to-all -> insert_records) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -150,9 +152,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
-    if world > 1:
+    sharded_path = world > 1 or args.force_sharded
+    if sharded_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -179,32 +185,32 @@ def main():
     log(f"node table: {g.table_slots()} slots")
 
     sharded = None
-    if world > 1:
+    if sharded_path:
         from soapdenovo_trans_amd.sharding import ShardedCounter, allreduce_stats
         sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
 
-    def one_step():
+    def one_step(verify=False):
         g.reset()
-        if world == 1:
+        if not sharded_path:
             g.count_reads_device(words, nwords, offsets, n_local, L)
         else:
             with torch.cuda.stream(stream):
-                sharded.count_reads(words, nwords, offsets, n_local)
+                sharded.count_reads(words, nwords, offsets, n_local, verify=verify)
         kmers, nodes = g.finish_count()
         hist, linear = g.mark_and_hist()
-        if world > 1:
+        if sharded_path:
             hist, kmers, nodes, linear = allreduce_stats(hist, kmers, nodes, linear, dev)
         return kmers, nodes, linear, hist
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded_path:
             dist.barrier()
         torch.cuda.synchronize()
 
     res = None
     for _ in range(args.warmup):
-        res = one_step()
+        res = one_step(verify=True)        # checksum the exchange once, outside the timed region
     g.kernel_time(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -212,7 +218,7 @@ def main():
         res = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded_path:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -226,7 +232,7 @@ def main():
     # kernel-level: this rank's k-mers over this rank's kernel time (N=1: whole job)
     local_kmers = n_local * (L - K + 1) if world == 1 else None
     roof = None
-    if world == 1 and kms > 0:
+    if world == 1 and not sharded_path and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
         tpk, tsrc = pmc_traffic_per_kmer()
         per_launch_kmers = local_kmers * args.steps / max(launches, 1)
@@ -244,10 +250,10 @@ def main():
         "config": {"workload": f"{n_total} x {L} bp synthetic transcriptome reads (T={args.T}, err={args.err}), "
                                f"K={K}, pass-1 chop+hash+count+kmerFreq", "reads": n_total, "read_len": L, "K": K,
                    "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
-                   "parallelism": f"owner-sharded x{world}" if world > 1 else "single-GPU table"},
+                   "parallelism": f"owner-sharded x{world}" if sharded_path else "single-GPU table"},
         "roofline": roof,
     }
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and not sharded_path and args.cpu_sample > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log)
         except Exception as e:     # the baseline is reported, never required
@@ -258,7 +264,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     g.close()
-    if world > 1:
+    if sharded_path:
         dist.destroy_process_group()
 
 

@@ -11,6 +11,10 @@ from __future__ import annotations
 
 import numpy as np
 
+# Measured on MI355X / RCCL 2.26 / torch 2.10: all_to_all_single silently delivers garbage once one split
+# exceeds 2^27 int64 elements (1 GiB) -- tools/dbg_exchange.py.  Stay well below and fail loudly above.
+MAX_SPLIT_WORDS = 1 << 26
+
 
 def owner_of(lib, key_words_msw_first: np.ndarray, nranks: int) -> int:
     """host copy of the device owner function (one key: uint64[nw], most significant word first)"""
@@ -19,7 +23,7 @@ def owner_of(lib, key_words_msw_first: np.ndarray, nranks: int) -> int:
     return ((h >> 32) * nranks) >> 32
 
 
-def exchange_records(send, counts, cap_per_rank: int, rec_words: int, recv, group=None):
+def exchange_records(send, counts, cap_per_rank: int, rec_words: int, recv, group=None, verify: bool = False):
     """all-to-all(v) of routed records.
 
     send   : int64 tensor, nranks slices of cap_per_rank records (rec_words int64 each); slice r holds
@@ -38,12 +42,21 @@ def exchange_records(send, counts, cap_per_rank: int, rec_words: int, recv, grou
     total = int(sum(rc))
     if total * rec_words > recv.numel():
         raise RuntimeError(f"receive buffer too small: need {total} records, have {recv.numel() // rec_words}")
+    if max(c + rc) * rec_words > MAX_SPLIT_WORDS:
+        raise RuntimeError(f"all-to-all split of {max(c + rc) * rec_words} words exceeds {MAX_SPLIT_WORDS}: "
+                           "use fewer reads per round")
     # compact the fixed-capacity slices (cheap device copy), then ONE all-to-all(v) of 8-byte words
     ins = [send[(i * cap_per_rank) * rec_words:(i * cap_per_rank + c[i]) * rec_words] for i in range(world)]
     packed = torch.cat(ins) if world > 1 else ins[0]
     dist.all_to_all_single(recv[: total * rec_words], packed,
                            output_split_sizes=[x * rec_words for x in rc],
                            input_split_sizes=[x * rec_words for x in c], group=group)
+    if verify:
+        # every word sent somewhere must arrive somewhere: compare the global wrap-around sums
+        chk = torch.stack([packed.sum(), recv[: total * rec_words].sum()])
+        dist.all_reduce(chk, group=group)
+        if int(chk[0].item()) != int(chk[1].item()):
+            raise RuntimeError("all-to-all checksum mismatch: records were lost or corrupted in the exchange")
     return total, rc
 
 
@@ -69,8 +82,12 @@ class ShardedCounter:
 
         self.g, self.world, self.L, self.device = g, world, max_read_len, device
         self.rec_words = g.record_bytes() // 8
-        self.per_round = reads_per_round
-        kmers_round = reads_per_round * max(max_read_len - g.K + 1, 1)
+        per_read = max(max_read_len - g.K + 1, 1)
+        # keep every per-peer split below the collective's safe size (with head room for owner imbalance)
+        limit = int(MAX_SPLIT_WORDS / self.rec_words * world / 1.3 / per_read)
+        self.per_round = max(64, min(reads_per_round, limit))
+        reads_per_round = self.per_round
+        kmers_round = reads_per_round * per_read
         self.cap = int(kmers_round / world * 1.25) + 4096
         n = self.cap * world * self.rec_words
         self.send = torch.empty(n, dtype=torch.int64, device=device)
@@ -78,11 +95,11 @@ class ShardedCounter:
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.displs = torch.zeros(world, dtype=torch.int64, device=device)
 
-    def count_reads(self, words, nwords: int, offsets, nreads: int, group=None):
+    def count_reads(self, words, nwords: int, offsets, nreads: int, group=None, verify: bool = False):
         g = self.g
         for r0 in range(0, nreads, self.per_round):
             nr = min(self.per_round, nreads - r0)
             g.extract_route(words, nwords, offsets[r0:], nr, self.L, self.world, self.send, self.cap * self.world,
                             self.counts, self.displs)
-            total, _ = exchange_records(self.send, self.counts, self.cap, self.rec_words, self.recv, group)
+            total, _ = exchange_records(self.send, self.counts, self.cap, self.rec_words, self.recv, group, verify)
             g.insert_records(self.recv, total)
