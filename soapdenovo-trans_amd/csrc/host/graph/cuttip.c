@@ -11,7 +11,30 @@
  * All of them mutate neighbours while sweeping, so the sweep order (graph.h) is part of the result.
  */
 #include "graph.h"
+#include "par.h"
 #include <stdlib.h>
+#include <string.h>
+
+/* ---- speculate in parallel, commit in order ---------------------------------------------------------------
+ * The passes are order dependent only through the few nodes they WRITE: a clip writes its tip and the node the
+ * chain runs into; a minor-branch cut writes the cut neighbour and that neighbour's neighbours.  Everything
+ * else a visit reads is immutable during the pass (occurrence counts, `single`, and every node that is linear
+ * at the start of a sweep: walks only ever stop at -- and therefore write -- non-linear nodes, and nothing in a
+ * sweep clears `linear` on a node a walk could pass through).  So each sweep is run as
+ *   1. a read-only dry run of every visit on the untouched graph, in parallel: "would this visit write
+ *      anything?" and "which node did its walk end at?";
+ *   2. the reference's sweep, in order, executing a visit for real only if its node has been written since the
+ *      dry run, or the dry run said it writes, or the node its walk ended at has been written; every other
+ *      visit would read exactly what the dry run read and do nothing, so it is skipped.
+ * Writes happen only in step 2, in the reference's order, by the same code as before: results are identical,
+ * and the expensive part (the walks of the ~95 % of visits that change nothing) is parallel. */
+#define NO_NODE (~(uint64_t)0)
+typedef struct { int would_write; uint64_t end; } dry_t;
+
+static inline void touch(graph_t *g, const gnode_t *n)
+{
+	if (g->touched) g->touched[n - g->nodes] = 1;
+}
 
 enum { LEFT = 0, RIGHT = 1 };
 
@@ -61,21 +84,24 @@ static void isolate(graph_t *g, gnode_t *q)
 	const kw_t qs = q->seq;
 	int sm;
 	q->deleted = 1;
+	touch(g, q);
 	for (unsigned b = 0; b < 4; b++)
 		if (link_of(q, LEFT, b)) {
 			gnode_t *x = neighbour(g, q, LEFT, b, &sm);
 			unlink_next(x, kw_last(&qs), sm);
 			x->linear = one_in_one_out(x);
+			touch(g, x);
 		}
 	for (unsigned b = 0; b < 4; b++)
 		if (link_of(q, RIGHT, b)) {
 			gnode_t *y = neighbour(g, q, RIGHT, b, &sm);
 			unlink_prev(y, kw_first(&qs, g->K), sm);
 			y->linear = one_in_one_out(y);
+			touch(g, y);
 		}
 }
 
-static void prune_side(graph_t *g, gnode_t *n, int side, double threshold, uint64_t *off)
+static void prune_side(graph_t *g, gnode_t *n, int side, double threshold, uint64_t *off, dry_t *dry)
 {
 	int sm, best = 0;
 	for (unsigned b = 0; b < 4; b++)
@@ -89,9 +115,34 @@ static void prune_side(graph_t *g, gnode_t *n, int side, double threshold, uint6
 		gnode_t *q = neighbour(g, n, side, b, &sm);
 		const int c = (int)q->count;
 		if (c && (double)c / best < threshold) {
+			if (dry) { dry->would_write = 1; return; }
 			(*off)++;
 			isolate(g, q);
 		}
+	}
+}
+
+static void visit_minor_out(graph_t *g, gnode_t *n, double threshold, uint64_t *off, dry_t *dry)
+{
+	if (n->linear || n->deleted) return;
+	const int in = degree(n, LEFT), out = degree(n, RIGHT);            /* both sampled before any cut (:616-617) */
+	if (in <= 1 && out <= 1) return;
+	if (in > 1) prune_side(g, n, LEFT, threshold, off, dry);
+	if (dry && dry->would_write) return;
+	if (out > 1) prune_side(g, n, RIGHT, threshold, off, dry);
+}
+
+typedef struct { graph_t *g; double threshold; int cut_len, thin; uint8_t *writes; uint64_t *ends; } spec_ctx;
+
+static void spec_minor_out(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	spec_ctx *c = (spec_ctx *)vc;
+	for (uint64_t i = lo; i < hi; i++) {
+		dry_t d = {0, NO_NODE};
+		uint64_t dummy = 0;
+		visit_minor_out(c->g, &c->g->nodes[i], c->threshold, &dummy, &d);
+		c->writes[i] = (uint8_t)d.would_write;
 	}
 }
 
@@ -100,21 +151,23 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	const double threshold = (double)dd / 100;
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
-	for (uint64_t i = 0; i < g->n; i++) {
-		gnode_t *n = &g->nodes[i];
-		if (n->linear || n->deleted) continue;
-		const int in = degree(n, LEFT), out = degree(n, RIGHT);        /* both sampled before any cut (:616-617) */
-		if (in <= 1 && out <= 1) continue;
-		if (in > 1) prune_side(g, n, LEFT, threshold, &off);
-		if (out > 1) prune_side(g, n, RIGHT, threshold, &off);
-	}
+	spec_ctx c = {g, threshold, 0, 0, (uint8_t *)malloc(g->n + 1), NULL};
+	g->touched = NULL;
+	par_for(0, g->n, 8192, spec_minor_out, &c);
+	g->touched = (uint8_t *)calloc(g->n + 1, 1);
+	for (uint64_t i = 0; i < g->n; i++)
+		if (c.writes[i] || g->touched[i])
+			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
+	free(g->touched);
+	g->touched = NULL;
+	free(c.writes);
 	printf("%llu kmers off\n", (unsigned long long)off);
 	mark_linear(g);
 	return off;
 }
 
 /* one dead end: returns 1 when something was cut */
-static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *tips)
+static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *tips, dry_t *dry)
 {
 	const int K = g->K;
 	if (tip->linear || tip->deleted) return 0;
@@ -145,18 +198,23 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 		step = kw_next(at, b, K);
 		o = graph_find_oriented(g, step, &sm);
 	}
+	if (dry) dry->end = (uint64_t)(o - g->nodes);
 	if (degree(o, LEFT) + degree(o, RIGHT) == 1) {                       /* the whole path is an island */
+		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		o->deleted = 1;
+		touch(g, tip); touch(g, o);
 		return 1;
 	}
 	const unsigned ch = kw_first(&at, K);                                /* base by which o sees the chain */
 	if (thin) {
+		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		unlink_prev(o, ch, sm);
 		o->linear = 0;
+		touch(g, tip); touch(g, o);
 		return 1;
 	}
 	const int side = sm ? LEFT : RIGHT;                                  /* side of o the chain enters */
@@ -164,21 +222,56 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 	for (unsigned c = 0; c < 4; c++)
 		if (link_of(o, side, c) > strongest) strongest = link_of(o, side, c);
 	if (link_of(o, side, sm ? ch : ch ^ 2u) < strongest) {
+		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		unlink_prev(o, ch, sm);
 		if (one_in_one_out(o)) o->linear = 1;
+		touch(g, tip); touch(g, o);
 		return 1;
 	}
 	return 0;
+}
+
+static void spec_tips(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	spec_ctx *c = (spec_ctx *)vc;
+	for (uint64_t i = lo; i < hi; i++) {
+		dry_t d = {0, NO_NODE};
+		uint64_t dummy = 0;
+		clip_tip(c->g, &c->g->nodes[i], c->cut_len, c->thin, &dummy, &d);
+		c->writes[i] = (uint8_t)d.would_write;
+		c->ends[i] = d.end;
+	}
+}
+
+/* one sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips */
+static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, spec_ctx *c)
+{
+	c->cut_len = cut_len;
+	c->thin = thin;
+	g->touched = NULL;                                   /* dry run: nothing is written, nothing to record */
+	par_for(lo, hi, 8192, spec_tips, c);
+	g->touched = c->writes + g->n + 1;                   /* second half of the scratch: written-since-dry-run marks */
+	int clipped = 0;
+	for (uint64_t i = lo; i < hi; i++) {
+		const uint64_t e = c->ends[i];
+		if (c->writes[i] || g->touched[i] || (e != NO_NODE && g->touched[e]))
+			clipped += clip_tip(g, &g->nodes[i], cut_len, thin, tips, NULL);
+	}
+	g->touched = NULL;
+	return clipped;
 }
 
 uint64_t graph_remove_single_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
-	for (uint64_t i = 0; i < g->n; i++)
-		clip_tip(g, &g->nodes[i], 2 * g->K, 1, &tips);
+	spec_ctx c = {g, 0, 0, 0, (uint8_t *)calloc(2 * (g->n + 1), 1), (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t))};
+	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c);
+	free(c.writes);
+	free(c.ends);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	return tips;
@@ -188,15 +281,18 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
+	spec_ctx c = {g, 0, 0, 0, (uint8_t *)calloc(2 * (g->n + 1), 1), (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t))};
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
 		while (changed) {
-			changed = 0;
-			for (uint64_t i = g->set_start[s]; i < g->set_start[s + 1]; i++)
-				changed += clip_tip(g, &g->nodes[i], 2 * g->K, 0, &tips);
+			/* the written-marks of a sweep must not leak into the next one: each sweep is its own dry run */
+			memset(c.writes + g->n + 1, 0, g->n + 1);
+			changed = sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c);
 		}
 		printf("kmer set %d done\n", s);
 	}
+	free(c.writes);
+	free(c.ends);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	return tips;

@@ -40,6 +40,7 @@ typedef struct {
 	gpatch_t *patch;                   /* open addressing over canonical (K+1)-mers */
 	uint64_t patch_mask, patch_n;
 	uint64_t num_ed;                   /* edge_c of kmer2edges: ids handed out, twins included */
+	uint8_t *touched;                  /* per node, during a cleaning sweep: written since the dry run (cuttip.c) */
 } graph_t;
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
