@@ -166,10 +166,20 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	return off;
 }
 
-/* one dead end: returns 1 when something was cut */
-static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *tips, dry_t *dry)
+/* what a walk from a dead end found: everything here depends only on nodes that cannot change during a sweep
+ * (the chain), so a dry run may compute it once and the ordered commit can reuse it */
+typedef struct {
+	uint64_t end;          /* index of the node the walk stopped at, NO_NODE = no decision to take */
+	uint8_t ch, sm;        /* base by which that node sees the chain; strand on which it was reached */
+	uint8_t thin_stop;     /* THIN: stopped at a linear node that is not single (:163-166) */
+} walk_t;
+
+/* the walk of clipTipFromNode (:43-281).  Returns 0 when there is nothing to decide: not a dead end, or the
+ * chain is longer than cut_len. */
+static int walk_from_tip(graph_t *g, const gnode_t *tip, int cut_len, int thin, walk_t *w)
 {
 	const int K = g->K;
+	w->end = NO_NODE;
 	if (tip->linear || tip->deleted) return 0;
 	if (thin && !tip->single) return 0;
 	const int in = degree(tip, LEFT), out = degree(tip, RIGHT);
@@ -188,9 +198,10 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 	int steps = 1, sm;
 	kw_t step = kw_next(at, b, K);
 	gnode_t *o = graph_find_oriented(g, step, &sm);
+	w->thin_stop = 0;
 	while (o->linear) {
 		steps++;
-		if (thin && !o->single) break;
+		if (thin && !o->single) { w->thin_stop = 1; break; }
 		if (steps > cut_len) return 0;
 		at = step;                                                       /* oriented word of o */
 		if (sm) { for (b = 0; b < 4 && !link_of(o, RIGHT, b); b++) ; }
@@ -198,18 +209,26 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 		step = kw_next(at, b, K);
 		o = graph_find_oriented(g, step, &sm);
 	}
-	if (dry) dry->end = (uint64_t)(o - g->nodes);
+	w->end = (uint64_t)(o - g->nodes);
+	w->ch = (uint8_t)kw_first(&at, K);                                   /* base by which o sees the chain */
+	w->sm = (uint8_t)sm;
+	return 1;
+}
+
+/* the decision at the end of the walk (:282-336); reads and writes only `tip` and the end node */
+static int decide_tip(graph_t *g, gnode_t *tip, const walk_t *w, int thin, uint64_t *tips)
+{
+	gnode_t *o = &g->nodes[w->end];
+	const unsigned ch = w->ch;
+	const int sm = w->sm;
 	if (degree(o, LEFT) + degree(o, RIGHT) == 1) {                       /* the whole path is an island */
-		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		o->deleted = 1;
 		touch(g, tip); touch(g, o);
 		return 1;
 	}
-	const unsigned ch = kw_first(&at, K);                                /* base by which o sees the chain */
 	if (thin) {
-		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		unlink_prev(o, ch, sm);
@@ -222,7 +241,6 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 	for (unsigned c = 0; c < 4; c++)
 		if (link_of(o, side, c) > strongest) strongest = link_of(o, side, c);
 	if (link_of(o, side, sm ? ch : ch ^ 2u) < strongest) {
-		if (dry) { dry->would_write = 1; return 1; }
 		(*tips)++;
 		tip->deleted = 1;
 		unlink_prev(o, ch, sm);
@@ -233,32 +251,50 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 	return 0;
 }
 
+/* one dead end, live: returns 1 when something was cut */
+static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *tips)
+{
+	walk_t w;
+	if (!walk_from_tip(g, tip, cut_len, thin, &w)) return 0;
+	return decide_tip(g, tip, &w, thin, tips);
+}
+
+typedef struct { graph_t *g; int cut_len, thin; walk_t *walks; } tips_ctx;
+
 static void spec_tips(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
-	spec_ctx *c = (spec_ctx *)vc;
-	for (uint64_t i = lo; i < hi; i++) {
-		dry_t d = {0, NO_NODE};
-		uint64_t dummy = 0;
-		clip_tip(c->g, &c->g->nodes[i], c->cut_len, c->thin, &dummy, &d);
-		c->writes[i] = (uint8_t)d.would_write;
-		c->ends[i] = d.end;
-	}
+	tips_ctx *c = (tips_ctx *)vc;
+	for (uint64_t i = lo; i < hi; i++)
+		walk_from_tip(c->g, &c->g->nodes[i], c->cut_len, c->thin, &c->walks[i]);
 }
 
-/* one sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips */
-static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, spec_ctx *c)
+/* One sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips.
+ * Dry run: every walk, in parallel, on the graph as the sweep finds it.  Commit, in order:
+ *   - a node written since the dry run is visited for real (it may have become a dead end, or stopped being one);
+ *   - a walk whose end node was non-linear and has been made linear since would now run on: visited for real;
+ *   - otherwise the recorded walk is still what the reference would walk (chains cannot change inside a
+ *     sweep), and only the O(1) decision at its end node is taken, on the live state of that node. */
+static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, tips_ctx *c, uint8_t *marks)
 {
 	c->cut_len = cut_len;
 	c->thin = thin;
-	g->touched = NULL;                                   /* dry run: nothing is written, nothing to record */
+	g->touched = NULL;
 	par_for(lo, hi, 8192, spec_tips, c);
-	g->touched = c->writes + g->n + 1;                   /* second half of the scratch: written-since-dry-run marks */
+	memset(marks, 0, g->n + 1);
+	g->touched = marks;
 	int clipped = 0;
 	for (uint64_t i = lo; i < hi; i++) {
-		const uint64_t e = c->ends[i];
-		if (c->writes[i] || g->touched[i] || (e != NO_NODE && g->touched[e]))
-			clipped += clip_tip(g, &g->nodes[i], cut_len, thin, tips, NULL);
+		gnode_t *tip = &g->nodes[i];
+		const walk_t *w = &c->walks[i];
+		if (marks[i]) {
+			clipped += clip_tip(g, tip, cut_len, thin, tips);
+		} else if (w->end != NO_NODE) {
+			if (!w->thin_stop && g->nodes[w->end].linear)
+				clipped += clip_tip(g, tip, cut_len, thin, tips);
+			else
+				clipped += decide_tip(g, tip, w, thin, tips);
+		}
 	}
 	g->touched = NULL;
 	return clipped;
@@ -268,10 +304,11 @@ uint64_t graph_remove_single_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
-	spec_ctx c = {g, 0, 0, 0, (uint8_t *)calloc(2 * (g->n + 1), 1), (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t))};
-	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c);
-	free(c.writes);
-	free(c.ends);
+	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
+	uint8_t *marks = (uint8_t *)malloc(g->n + 1);
+	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
+	free(marks);
+	free(c.walks);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	return tips;
@@ -281,18 +318,16 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
-	spec_ctx c = {g, 0, 0, 0, (uint8_t *)calloc(2 * (g->n + 1), 1), (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t))};
+	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
+	uint8_t *marks = (uint8_t *)malloc(g->n + 1);
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
-		while (changed) {
-			/* the written-marks of a sweep must not leak into the next one: each sweep is its own dry run */
-			memset(c.writes + g->n + 1, 0, g->n + 1);
-			changed = sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c);
-		}
+		while (changed)                                /* fixed point PER SET before the next set (:385-408) */
+			changed = sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
 		printf("kmer set %d done\n", s);
 	}
-	free(c.writes);
-	free(c.ends);
+	free(marks);
+	free(c.walks);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	return tips;
