@@ -176,7 +176,7 @@ static void emit_edge(graph_t *g, chain_t *c, gzFile fp, char **seqbuf, size_t *
 	g->num_ed += (uint64_t)bal_edge;                                      /* the twin takes the next id (:553) */
 }
 
-uint64_t graph_build_edges(graph_t *g, const char *prefix)
+static uint64_t build_edges_sequential(graph_t *g, const char *prefix)
 {
 	char name[4200];
 	snprintf(name, sizeof name, "%s.edge.gz", prefix);
@@ -214,4 +214,217 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	free(c.b);
 	free(seqbuf);
 	return g->num_ed;
+}
+
+/* ---- parallel kmer2edges -------------------------------------------------------------------------------------
+ * A chain of linear nodes between two non-linear nodes is one edge, discoverable from either end; the reference
+ * emits it from whichever end it visits first and zeroes the link at the other end so that it is not emitted
+ * twice.  The walks never change while edges are built (interior nodes keep `linear` and their two links until
+ * they are stamped, and nobody walks through a stamped chain again when chains are symmetric), so:
+ *   1. dry run, parallel: walk from every live port (node, side, base) of every start-eligible node; record where
+ *      the walk ends (node + port), its length, palindrome flag and coverage sum;
+ *   2. ordered pass, sequential but O(#ports): replay the reference's visiting order on port flags only, hand out
+ *      edge ids (twin = next id), register length-1 edges in the patch table; if any chain turns out not to be
+ *      symmetric (walking back from its far port does not return to the near port) give up BEFORE anything has
+ *      been modified and let build_edges_sequential do the whole job the reference's way;
+ *   3. parallel: re-walk every emitted chain, stamp its interior nodes, zero the two end links, format the record;
+ *   4. write the records in id order. */
+#include "par.h"
+
+typedef struct {
+	uint64_t far_node;     /* NO_WALK = port not live / node not eligible */
+	uint32_t length;
+	uint8_t far_port, bal_edge, emitted;
+	uint32_t id;
+	char *text;            /* formatted record (phase 3) */
+	size_t text_len;
+} port_t;
+#define NO_WALK (~(uint64_t)0)
+
+typedef struct { graph_t *g; uint64_t *starts; uint64_t nstarts; port_t *ports; } edges_ctx;
+
+static inline int port_live(const gnode_t *n, int p) { return p < 4 ? rlink(n, (unsigned)p) != 0 : llink(n, (unsigned)(p - 4)) != 0; }
+
+static void walk_port(graph_t *g, gnode_t *n, int p, chain_t *c)
+{
+	c->n = 0;
+	if (p < 4) { chain_push(c, n, n->seq, 1); follow(g, c, (unsigned)p); }
+	else { chain_push(c, n, kw_rc(n->seq, g->K), 0); follow(g, c, (unsigned)(p - 4) ^ 2u); }
+}
+
+static void dry_ports(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	edges_ctx *E = (edges_ctx *)vc;
+	graph_t *g = E->g;
+	chain_t c = {NULL, 0, 0};
+	for (uint64_t s = lo; s < hi; s++) {
+		gnode_t *n = &g->nodes[E->starts[s]];
+		for (int p = 0; p < 8; p++) {
+			port_t *P = &E->ports[s * 8 + p];
+			P->far_node = NO_WALK;
+			if (!port_live(n, p)) continue;
+			walk_port(g, n, p, &c);
+			const size_t cnt = c.n;
+			const bead_t *last = &c.b[cnt - 1], *second_last = &c.b[cnt - 2];
+			P->far_node = (uint64_t)(last->node - g->nodes);
+			const unsigned fc = kw_first(&second_last->kmer, g->K);
+			P->far_port = (uint8_t)(last->smaller ? 4 + fc : (fc ^ 2u));
+			P->length = (uint32_t)(cnt - 1);
+			P->bal_edge = 0;
+			for (size_t i = 0; i < cnt; i++) {
+				kw_t r = kw_rc(c.b[i].kmer, g->K);
+				if (!kw_eq(&c.b[cnt - 1 - i].kmer, &r)) { P->bal_edge = 1; break; }
+			}
+		}
+	}
+	free(c.b);
+}
+
+typedef struct { graph_t *g; edges_ctx *E; uint64_t *emit; uint64_t nemit; } stamp_ctx;
+
+static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	stamp_ctx *S = (stamp_ctx *)vc;
+	graph_t *g = S->g;
+	const int K = g->K;
+	chain_t c = {NULL, 0, 0};
+	for (uint64_t e = lo; e < hi; e++) {
+		const uint64_t pi = S->emit[e];
+		port_t *P = &S->E->ports[pi];
+		gnode_t *n = &g->nodes[S->E->starts[pi / 8]];
+		walk_port(g, n, (int)(pi % 8), &c);
+		const size_t cnt = c.n;
+		const int length = (int)cnt - 1, bal_edge = P->bal_edge;
+		bead_t *first = &c.b[0], *second = &c.b[1], *last = &c.b[cnt - 1], *second_last = &c.b[cnt - 2];
+		{   /* the two end links (node2edge.c:387-399); each port belongs to exactly one chain */
+			const unsigned fc = kw_first(&second_last->kmer, K);
+			if (last->smaller) __sync_fetch_and_and(&last->node->l_links, ~(63u << (6 * fc)));
+			else { const uint32_t m = ~(63u << (6 * (fc ^ 2u))); uint32_t *w = (uint32_t *)&last->node->l_links + 1; __sync_fetch_and_and(w, m | 0xFF000000u); }
+			const unsigned lc = kw_last(&second->kmer);
+			if (first->smaller) { const uint32_t m = ~(63u << (6 * lc)); uint32_t *w = (uint32_t *)&first->node->l_links + 1; __sync_fetch_and_and(w, m | 0xFF000000u); }
+			else __sync_fetch_and_and(&first->node->l_links, ~(63u << (6 * (lc ^ 2u))));
+		}
+		/* interior nodes, last to first: add up the LEFT link counters, then overwrite them with the edge id
+		 * (node2edge.c:493-521).  In a palindromic chain a node occurs twice; its second visit then reads the id
+		 * it was just stamped with -- upstream behaviour, kept. */
+		long long symbol = length == 1 ? (long long)first->node->count : 0;
+		for (size_t i = cnt - 2; i >= 1; i--) {
+			bead_t *b = &c.b[i];
+			gnode_t *nd = b->node;
+			nd->inEdge = 1;
+			symbol += llink(nd, 0) + llink(nd, 1) + llink(nd, 2) + llink(nd, 3);
+			if (b->smaller) { nd->l_links = P->id; nd->twin = (unsigned)(bal_edge + 1); }
+			else { nd->l_links = P->id + (uint32_t)bal_edge; nd->twin = (unsigned)(1 - bal_edge); }
+		}
+		/* record text: header + bases with a newline every 100 and at the end (output_pregraph.c:83-100) */
+		const size_t cap = 256 + (size_t)length + (size_t)length / 100 + 8;
+		char *t = (char *)malloc(cap);
+		size_t o = 0;
+		o += (size_t)snprintf(t + o, cap - o, ">length %d,", length);
+		for (int k = 0; k < 2; k++) {
+			const uint64_t *w = (k == 0 ? first : last)->kmer.w;
+			if (g->nw == 4) o += (size_t)snprintf(t + o, cap - o, "%llx %llx %llx %llx,", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
+			else if (g->nw == 2) o += (size_t)snprintf(t + o, cap - o, "%llx %llx,", (unsigned long long)w[2], (unsigned long long)w[3]);
+			else if (w[3]) o += (size_t)snprintf(t + o, cap - o, "%llx,", (unsigned long long)w[3]);
+			else o += (size_t)snprintf(t + o, cap - o, "0x0,");
+		}
+		long long cvg = length > 1 ? symbol / (length - 1) * 10 : symbol / length * 10;
+		if (cvg > MAX_EDGE_COV) cvg = MAX_EDGE_COV;
+		o += (size_t)snprintf(t + o, cap - o, "cvg %d, %d\n", (int)cvg, bal_edge);
+		for (size_t i = 1; i < cnt; i++) {
+			t[o++] = "ACTG"[kw_last(&c.b[i].kmer)];
+			if (i % 100 == 0) t[o++] = '\n';
+		}
+		t[o++] = '\n';
+		P->text = t;
+		P->text_len = o;
+	}
+	free(c.b);
+}
+
+uint64_t graph_build_edges(graph_t *g, const char *prefix)
+{
+	edges_ctx E;
+	E.g = g;
+	E.starts = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
+	E.nstarts = 0;
+	for (uint64_t i = 0; i < g->n; i++)
+		if (!g->nodes[i].linear && !g->nodes[i].deleted) E.starts[E.nstarts++] = i;
+	E.ports = (port_t *)calloc(E.nstarts * 8 + 8, sizeof(port_t));
+	par_for(0, E.nstarts, 256, dry_ports, &E);
+	/* node index -> start slot, for far ends that are start-eligible themselves */
+	uint64_t *slot_of = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
+	memset(slot_of, 0xFF, (g->n + 1) * sizeof(uint64_t));
+	for (uint64_t s = 0; s < E.nstarts; s++) slot_of[E.starts[s]] = s;
+	/* ordered pass on port flags */
+	uint8_t *zeroed = (uint8_t *)calloc(g->n + 1, 1);
+	uint64_t *emit = (uint64_t *)malloc((E.nstarts * 8 + 8) * sizeof(uint64_t));
+	uint64_t nemit = 0, num_ed = 0;
+	int symmetric = 1;
+	for (uint64_t s = 0; s < E.nstarts && symmetric; s++) {
+		const uint64_t ni = E.starts[s];
+		for (int p = 0; p < 8; p++) {
+			port_t *P = &E.ports[s * 8 + p];
+			if (P->far_node == NO_WALK || (zeroed[ni] >> p) & 1) continue;
+			/* symmetric? the far port, if a walk starts there, must come back to this port */
+			const uint64_t fs = slot_of[P->far_node];
+			if (fs != NO_WALK) {
+				const port_t *Q = &E.ports[fs * 8 + P->far_port];
+				if (Q->far_node != NO_WALK && !(Q->far_node == ni && Q->far_port == p)) { symmetric = 0; break; }
+			}
+			P->emitted = 1;
+			P->id = (uint32_t)(++num_ed);
+			num_ed += P->bal_edge;
+			zeroed[ni] |= (uint8_t)(1u << p);
+			zeroed[P->far_node] |= (uint8_t)(1u << P->far_port);
+			emit[nemit++] = s * 8 + (uint64_t)p;
+		}
+	}
+	free(zeroed);
+	free(slot_of);
+	if (!symmetric) {
+		free(emit); free(E.ports); free(E.starts);
+		return build_edges_sequential(g, prefix);
+	}
+	/* length-1 edges: canonical (K+1)-mer -> edge id, in emission order (node2edge.c:404-463) */
+	g->patch_mask = 1023;
+	g->patch = (gpatch_t *)calloc(1024, sizeof(gpatch_t));
+	g->patch_n = 0;
+	uint64_t extra = 0;
+	for (uint64_t e = 0; e < nemit; e++) {
+		const port_t *P = &E.ports[emit[e]];
+		if (P->length != 1) continue;
+		extra++;
+		const gnode_t *n = &g->nodes[E.starts[emit[e] / 8]];
+		const int p = (int)(emit[e] % 8);
+		const kw_t from = p < 4 ? n->seq : kw_rc(n->seq, g->K);
+		const unsigned b = p < 4 ? (unsigned)p : (unsigned)(p - 4) ^ 2u;      /* last base of the far k-mer */
+		kw_t plus;
+		plus.w[0] = (from.w[0] << 2) | (from.w[1] >> 62);
+		plus.w[1] = (from.w[1] << 2) | (from.w[2] >> 62);
+		plus.w[2] = (from.w[2] << 2) | (from.w[3] >> 62);
+		plus.w[3] = (from.w[3] << 2) | b;
+		kw_t bal = kw_rc(plus, g->K + 1);
+		if (kw_less(&plus, &bal)) patch_put(g, &plus, P->id, (uint8_t)(P->bal_edge + 1));
+		else patch_put(g, &bal, P->id + (uint32_t)P->bal_edge, (uint8_t)(1 - P->bal_edge));
+	}
+	stamp_ctx S = {g, &E, emit, nemit};
+	par_for(0, nemit, 64, stamp_edges, &S);
+	char name[4200];
+	snprintf(name, sizeof name, "%s.edge.gz", prefix);
+	gzFile fp = gzopen(name, "w1");
+	if (!fp) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	gzbuffer(fp, 1 << 20);
+	for (uint64_t e = 0; e < nemit; e++) {
+		port_t *P = &E.ports[emit[e]];
+		gzwrite(fp, P->text, (unsigned)P->text_len);
+		free(P->text);
+	}
+	gzclose(fp);
+	g->num_ed = num_ed;
+	printf("%llu (%llu) edges %llu extra nodes\n", (unsigned long long)num_ed, (unsigned long long)nemit, (unsigned long long)extra);
+	free(emit); free(E.ports); free(E.starts);
+	return num_ed;
 }
