@@ -33,7 +33,15 @@ typedef struct { int would_write; uint64_t end; } dry_t;
 
 static inline void touch(graph_t *g, const gnode_t *n)
 {
-	if (g->touched) g->touched[n - g->nodes] = 1;
+	if (!g->touched) return;
+	const uint64_t i = (uint64_t)(n - g->nodes);
+	if (g->touched[i]) return;
+	g->touched[i] = 1;
+	if (g->tn == g->tcap) {
+		g->tcap = g->tcap ? g->tcap * 2 : 4096;
+		g->tlist = (uint64_t *)realloc(g->tlist, g->tcap * sizeof(uint64_t));
+	}
+	g->tlist[g->tn++] = i;                     /* so that a sweep can un-mark what it marked without a full clear */
 }
 
 enum { LEFT = 0, RIGHT = 1 };
@@ -76,6 +84,18 @@ static uint64_t mark_linear(graph_t *g)
 /* neighbour of the CANONICAL k-mer of n across its `side` link with base b */
 static gnode_t *neighbour(graph_t *g, const gnode_t *n, int side, unsigned b, int *smaller)
 {
+	/* who the neighbour IS depends only on n's k-mer and b, never on the state of the graph: a pass may look
+	 * the neighbours of the nodes it is going to need up front, in parallel, and the ordered commit reads them here */
+	if (g->nb_slot) {
+		const uint32_t s = g->nb_slot[n - g->nodes];
+		if (s) {
+			const uint64_t v = g->nb_pool[(uint64_t)(s - 1) * 8 + (uint64_t)side * 4 + b];
+			if (v != NO_NODE) {
+				*smaller = (int)(v & 1);
+				return &g->nodes[v >> 1];
+			}
+		}
+	}
 	return graph_find_oriented(g, side == LEFT ? kw_prev(n->seq, b, g->K) : kw_next(n->seq, b, g->K), smaller);
 }
 
@@ -132,18 +152,84 @@ static void visit_minor_out(graph_t *g, gnode_t *n, double threshold, uint64_t *
 	if (out > 1) prune_side(g, n, RIGHT, threshold, off, dry);
 }
 
-typedef struct { graph_t *g; double threshold; int cut_len, thin; uint8_t *writes; uint64_t *ends; } spec_ctx;
+/* removeMinorOut, parallel part: for every node that is a junction when the pass starts, look its neighbours up
+ * (needed for the counts) and flag the neighbours that the ratio test would cut on the untouched graph -- links
+ * only ever disappear during the pass, so the largest count on a side can only go down and the live cut set is a
+ * subset of this one; then look up the neighbours of the flagged nodes as well (isolate() needs them). */
+typedef struct { graph_t *g; double threshold; uint8_t *need; volatile uint32_t cursor; uint32_t cap; } mo_ctx;
 
-static void spec_minor_out(void *vc, uint64_t lo, uint64_t hi, int tid)
+static void fill_slot(graph_t *g, uint64_t i, uint32_t slot)
+{
+	const gnode_t *n = &g->nodes[i];
+	uint64_t *e = &g->nb_pool[(uint64_t)(slot - 1) * 8];
+	for (int side = 0; side < 2; side++)
+		for (unsigned b = 0; b < 4; b++) {
+			e[side * 4 + b] = NO_NODE;
+			if (!link_of(n, side, b)) continue;
+			int sm;
+			const gnode_t *x = graph_find_oriented(g, side == LEFT ? kw_prev(n->seq, b, g->K) : kw_next(n->seq, b, g->K), &sm);
+			e[side * 4 + b] = ((uint64_t)(x - g->nodes) << 1) | (uint64_t)sm;
+		}
+}
+
+static void mo_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
-	spec_ctx *c = (spec_ctx *)vc;
+	mo_ctx *c = (mo_ctx *)vc;
+	graph_t *g = c->g;
 	for (uint64_t i = lo; i < hi; i++) {
-		dry_t d = {0, NO_NODE};
-		uint64_t dummy = 0;
-		visit_minor_out(c->g, &c->g->nodes[i], c->threshold, &dummy, &d);
-		c->writes[i] = (uint8_t)d.would_write;
+		const gnode_t *n = &g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		const int in = degree(n, LEFT), out = degree(n, RIGHT);
+		if (in <= 1 && out <= 1) continue;
+		const uint32_t slot = __sync_add_and_fetch(&c->cursor, 1);
+		if (slot > c->cap) continue;                                      /* cannot happen: cap = number of junctions */
+		fill_slot(g, i, slot);
+		g->nb_slot[i] = slot;
+		const uint64_t *e = &g->nb_pool[(uint64_t)(slot - 1) * 8];
+		for (int side = 0; side < 2; side++) {
+			if ((side == LEFT ? in : out) <= 1) continue;
+			int best = 0;
+			for (unsigned b = 0; b < 4; b++)
+				if (e[side * 4 + b] != NO_NODE) {
+					const int cnt = (int)g->nodes[e[side * 4 + b] >> 1].count;
+					if (cnt > best) best = cnt;
+				}
+			if (!best) continue;
+			for (unsigned b = 0; b < 4; b++)
+				if (e[side * 4 + b] != NO_NODE) {
+					const int cnt = (int)g->nodes[e[side * 4 + b] >> 1].count;
+					if (cnt && (double)cnt / best < c->threshold) c->need[e[side * 4 + b] >> 1] = 1;
+				}
+		}
 	}
+}
+
+static void mo_candidates(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	mo_ctx *c = (mo_ctx *)vc;
+	graph_t *g = c->g;
+	for (uint64_t i = lo; i < hi; i++) {
+		if (!c->need[i] || g->nb_slot[i]) continue;
+		const uint32_t slot = __sync_add_and_fetch(&c->cursor, 1);
+		if (slot > c->cap) continue;
+		fill_slot(g, i, slot);
+		g->nb_slot[i] = slot;
+	}
+}
+
+static void count_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	mo_ctx *c = (mo_ctx *)vc;
+	uint32_t k = 0;
+	for (uint64_t i = lo; i < hi; i++) {
+		const gnode_t *n = &c->g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		if (degree(n, LEFT) > 1 || degree(n, RIGHT) > 1) k++;
+	}
+	__sync_fetch_and_add(&c->cursor, k);
 }
 
 uint64_t graph_remove_minor_out(graph_t *g, int dd)
@@ -151,16 +237,27 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	const double threshold = (double)dd / 100;
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
-	spec_ctx c = {g, threshold, 0, 0, (uint8_t *)malloc(g->n + 1), NULL};
-	g->touched = NULL;
-	par_for(0, g->n, 8192, spec_minor_out, &c);
-	g->touched = (uint8_t *)calloc(g->n + 1, 1);
-	for (uint64_t i = 0; i < g->n; i++)
-		if (c.writes[i] || g->touched[i])
-			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
-	free(g->touched);
-	g->touched = NULL;
-	free(c.writes);
+	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), 0, 0};
+	par_for(0, g->n, 16384, count_junctions, &c);
+	const uint64_t njunc = c.cursor;
+	/* every junction has at most 8 neighbours that could be flagged; in practice far fewer are */
+	uint64_t cap = njunc * 3 + 1024;
+	if (cap > 0xFFFFFFF0ULL) cap = 0xFFFFFFF0ULL;
+	g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
+	g->nb_pool = (uint64_t *)malloc(cap * 8 * sizeof(uint64_t));
+	c.cursor = 0;
+	c.cap = (uint32_t)cap;
+	par_for(0, g->n, 8192, mo_junctions, &c);
+	par_for(0, g->n, 16384, mo_candidates, &c);
+	/* the pass itself: the reference's sweep, in order; neighbour() now finds most answers precomputed */
+	for (uint64_t i = 0; i < g->n; i++) {
+		gnode_t *n = &g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		visit_minor_out(g, n, threshold, &off, NULL);
+	}
+	free(g->nb_slot); g->nb_slot = NULL;
+	free(g->nb_pool); g->nb_pool = NULL;
+	free(c.need);
 	printf("%llu kmers off\n", (unsigned long long)off);
 	mark_linear(g);
 	return off;
@@ -281,8 +378,8 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 	c->thin = thin;
 	g->touched = NULL;
 	par_for(lo, hi, 8192, spec_tips, c);
-	memset(marks, 0, g->n + 1);
-	g->touched = marks;
+	g->touched = marks;                                  /* all zero on entry (calloc / un-marked below) */
+	g->tn = 0;
 	int clipped = 0;
 	for (uint64_t i = lo; i < hi; i++) {
 		gnode_t *tip = &g->nodes[i];
@@ -296,6 +393,8 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 				clipped += decide_tip(g, tip, w, thin, tips);
 		}
 	}
+	for (size_t k = 0; k < g->tn; k++) marks[g->tlist[k]] = 0;
+	g->tn = 0;
 	g->touched = NULL;
 	return clipped;
 }
@@ -305,7 +404,7 @@ uint64_t graph_remove_single_tips(graph_t *g)
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
 	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
-	uint8_t *marks = (uint8_t *)malloc(g->n + 1);
+	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
 	free(marks);
 	free(c.walks);
@@ -319,7 +418,7 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
 	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
-	uint8_t *marks = (uint8_t *)malloc(g->n + 1);
+	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
 		while (changed)                                /* fixed point PER SET before the next set (:385-408) */

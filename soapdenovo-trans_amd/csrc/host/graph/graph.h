@@ -41,6 +41,10 @@ typedef struct {
 	uint64_t patch_mask, patch_n;
 	uint64_t num_ed;                   /* edge_c of kmer2edges: ids handed out, twins included */
 	uint8_t *touched;                  /* per node, during a cleaning sweep: written since the dry run (cuttip.c) */
+	uint64_t *tlist;                   /* indices marked in `touched` during the current sweep */
+	size_t tn, tcap;
+	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
+	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */
 } graph_t;
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
