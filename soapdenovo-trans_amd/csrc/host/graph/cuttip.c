@@ -156,7 +156,7 @@ static void visit_minor_out(graph_t *g, gnode_t *n, double threshold, uint64_t *
  * (needed for the counts) and flag the neighbours that the ratio test would cut on the untouched graph -- links
  * only ever disappear during the pass, so the largest count on a side can only go down and the live cut set is a
  * subset of this one; then look up the neighbours of the flagged nodes as well (isolate() needs them). */
-typedef struct { graph_t *g; double threshold; uint8_t *need; volatile uint32_t cursor; uint32_t cap; } mo_ctx;
+typedef struct { graph_t *g; double threshold; uint8_t *need, *writes; volatile uint32_t cursor; uint32_t cap; } mo_ctx;
 
 static void fill_slot(graph_t *g, uint64_t i, uint32_t slot)
 {
@@ -182,11 +182,17 @@ static void mo_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
 		if (n->linear || n->deleted) continue;
 		const int in = degree(n, LEFT), out = degree(n, RIGHT);
 		if (in <= 1 && out <= 1) continue;
-		const uint32_t slot = __sync_add_and_fetch(&c->cursor, 1);
-		if (slot > c->cap) continue;                                      /* cannot happen: cap = number of junctions */
-		fill_slot(g, i, slot);
-		g->nb_slot[i] = slot;
-		const uint64_t *e = &g->nb_pool[(uint64_t)(slot - 1) * 8];
+		/* neighbours + the ratio test on the untouched graph */
+		uint64_t e[8];
+		int any = 0;
+		for (int side = 0; side < 2; side++)
+			for (unsigned b = 0; b < 4; b++) {
+				e[side * 4 + b] = NO_NODE;
+				if (!link_of(n, side, b)) continue;
+				int sm;
+				const gnode_t *x = graph_find_oriented(g, side == LEFT ? kw_prev(n->seq, b, g->K) : kw_next(n->seq, b, g->K), &sm);
+				e[side * 4 + b] = ((uint64_t)(x - g->nodes) << 1) | (uint64_t)sm;
+			}
 		for (int side = 0; side < 2; side++) {
 			if ((side == LEFT ? in : out) <= 1) continue;
 			int best = 0;
@@ -199,9 +205,15 @@ static void mo_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
 			for (unsigned b = 0; b < 4; b++)
 				if (e[side * 4 + b] != NO_NODE) {
 					const int cnt = (int)g->nodes[e[side * 4 + b] >> 1].count;
-					if (cnt && (double)cnt / best < c->threshold) c->need[e[side * 4 + b] >> 1] = 1;
+					if (cnt && (double)cnt / best < c->threshold) { c->need[e[side * 4 + b] >> 1] = 1; any = 1; }
 				}
 		}
+		if (!any) continue;                       /* the visit would change nothing unless somebody writes this node first */
+		c->writes[i] = 1;
+		const uint32_t slot = __sync_add_and_fetch(&c->cursor, 1);
+		if (slot > c->cap) continue;              /* pool full: the commit simply looks these up itself */
+		memcpy(&g->nb_pool[(uint64_t)(slot - 1) * 8], e, sizeof e);
+		g->nb_slot[i] = slot;
 	}
 }
 
@@ -237,7 +249,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	const double threshold = (double)dd / 100;
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
-	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), 0, 0};
+	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
 	par_for(0, g->n, 16384, count_junctions, &c);
 	const uint64_t njunc = c.cursor;
 	/* every junction has at most 8 neighbours that could be flagged; in practice far fewer are */
@@ -249,15 +261,22 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	c.cap = (uint32_t)cap;
 	par_for(0, g->n, 8192, mo_junctions, &c);
 	par_for(0, g->n, 16384, mo_candidates, &c);
-	/* the pass itself: the reference's sweep, in order; neighbour() now finds most answers precomputed */
-	for (uint64_t i = 0; i < g->n; i++) {
-		gnode_t *n = &g->nodes[i];
-		if (n->linear || n->deleted) continue;
-		visit_minor_out(g, n, threshold, &off, NULL);
-	}
+	/* the pass itself, in the reference's order.  A visit is executed only if the dry run found something to cut
+	 * or the node has been written since (a junction that nobody wrote reads what the dry run read: nothing to
+	 * do); neighbour() finds the answers of the executed visits precomputed. */
+	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
+	g->touched = marks;
+	g->tn = 0;
+	for (uint64_t i = 0; i < g->n; i++)
+		if (c.writes[i] || marks[i])
+			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
+	g->touched = NULL;
+	g->tn = 0;
+	free(marks);
 	free(g->nb_slot); g->nb_slot = NULL;
 	free(g->nb_pool); g->nb_pool = NULL;
 	free(c.need);
+	free(c.writes);
 	printf("%llu kmers off\n", (unsigned long long)off);
 	mark_linear(g);
 	return off;
