@@ -54,6 +54,18 @@ def pmc_traffic_per_kmer(kernel="k_count_reads"):
     return best or (None, None)
 
 
+def usable_cpus():
+    """online CPUs capped by the cgroup v2 quota (the GPU boxes give 16 CPUs of a 256-thread host)"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
     """Rank 0, N=1 only.  Time the reference binary (oracle/_ref, kind 'reference') on the first
     `sample_reads` reads of the same workload, from process start until <prefix>.kmerFreq is complete
@@ -67,7 +79,7 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
     codes = ((hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
     del idx
     kmers = n * (L - K + 1)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     exe = ob.ref_binary(31 if K <= 31 else 127)
     if exe and os.access(exe, os.X_OK):
         from soapdenovo_trans_amd import synth

@@ -449,10 +449,15 @@ void sdto_sets_add_read(sdto_sets *S, const uint8_t *codes, int len)
 	static uint8_t pc[MAXL], nc[MAXL];
 	static uint64_t hb[MAXL];
 	if (len > MAXL) len = MAXL;
-	int n = sdto_chop_read(codes, len, S->K, S->nw, keys, pc, nc, hb);
+	int n = sdto_chop_read(codes, len, S->K, S->nw, keys, pc, nc, hb);     /* 0 records for a short read; it still has an ordinal */
 	S->kmers_in_reads += (uint64_t)n;
-	for (int i = 0; i < n; i++)
-		sdto_set_put(S->sets[hb[i] % (uint64_t)S->nsets], keys[i], pc[i], nc[i], S->nw, NULL);
+	for (int i = 0; i < n; i++) {
+		sdto_set *set = S->sets[hb[i] % (uint64_t)S->nsets];
+		uint64_t slot;
+		if (!sdto_set_put(set, keys[i], pc[i], nc[i], S->nw, &slot))
+			set->array[slot].first = (S->reads_seen << 16) | (uint64_t)i;
+	}
+	S->reads_seen++;
 }
 
 void sdto_sets_add_reads(sdto_sets *S, const uint8_t *codes, const uint64_t *offsets, uint64_t nreads)
@@ -532,6 +537,17 @@ int sdto_write_kmerfreq(const char *path, const int64_t hist[257])
 		fprintf(fo, "%lld\n", (long long)hist[i]);
 	fclose(fo);
 	return 0;
+}
+
+uint64_t sdto_sets_export_first(const sdto_sets *S, uint64_t *first)
+{
+	uint64_t n = 0;
+	for (int t = 0; t < S->nsets; t++) {
+		const sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++)
+			if (!FL_NULL(s->flags, i)) first[n++] = s->array[i].first;
+	}
+	return n;
 }
 
 uint64_t sdto_sets_export(const sdto_sets *S, uint64_t *keys4, uint32_t *l_links, uint32_t *r_links,

@@ -28,6 +28,9 @@
  *      visit would read exactly what the dry run read and do nothing, so it is skipped.
  * Writes happen only in step 2, in the reference's order, by the same code as before: results are identical,
  * and the expensive part (the walks of the ~95 % of visits that change nothing) is parallel. */
+#include <time.h>
+static double cut_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define SUBPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = cut_now_ms(); fprintf(stderr, "[cuttip]   %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 #define NO_NODE (~(uint64_t)0)
 typedef struct { int would_write; uint64_t end; } dry_t;
 
@@ -249,8 +252,10 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	const double threshold = (double)dd / 100;
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
+	double t_sub = cut_now_ms();
 	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
 	par_for(0, g->n, 16384, count_junctions, &c);
+	SUBPHASE("count junctions");
 	const uint64_t njunc = c.cursor;
 	/* every junction has at most 8 neighbours that could be flagged; in practice far fewer are */
 	uint64_t cap = njunc * 3 + 1024;
@@ -259,8 +264,11 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	g->nb_pool = (uint64_t *)malloc(cap * 8 * sizeof(uint64_t));
 	c.cursor = 0;
 	c.cap = (uint32_t)cap;
+	SUBPHASE("alloc");
 	par_for(0, g->n, 8192, mo_junctions, &c);
+	SUBPHASE("junction dry run");
 	par_for(0, g->n, 16384, mo_candidates, &c);
+	SUBPHASE("candidate neighbours");
 	/* the pass itself, in the reference's order.  A visit is executed only if the dry run found something to cut
 	 * or the node has been written since (a junction that nobody wrote reads what the dry run read: nothing to
 	 * do); neighbour() finds the answers of the executed visits precomputed. */
@@ -272,6 +280,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
 	g->touched = NULL;
 	g->tn = 0;
+	SUBPHASE("ordered commit");
 	free(marks);
 	free(g->nb_slot); g->nb_slot = NULL;
 	free(g->nb_pool); g->nb_pool = NULL;
@@ -279,6 +288,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	free(c.writes);
 	printf("%llu kmers off\n", (unsigned long long)off);
 	mark_linear(g);
+	SUBPHASE("free + mark linear");
 	return off;
 }
 

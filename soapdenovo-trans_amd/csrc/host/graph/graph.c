@@ -191,7 +191,7 @@ static void *job_thread(void *a)
 	return NULL;
 }
 
-#include <pthread.h>
+#include "par.h"
 static void run_parallel(build_job *J, job_fn fn)
 {
 	J->fn = fn;
@@ -264,8 +264,7 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
 	build_job J;
 	memset(&J, 0, sizeof J);
-	long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-	J.nthreads = (int)(ncpu < 1 ? 1 : (ncpu > 32 ? 32 : ncpu));
+	J.nthreads = par_threads();
 	J.g = g; J.nw_keys = nw_keys; J.n = n; J.keys = keys; J.first = first;
 	J.l_links = l_links; J.r_flags = r_flags; J.count = count;
 	J.tmp = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));

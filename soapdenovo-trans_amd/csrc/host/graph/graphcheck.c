@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "graph.h"
+#include <time.h>
 #include "../readstream.h"
 
 typedef struct { graph_t *G; struct arcs *A; } arc_state;
@@ -22,6 +23,10 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
 	return 0;
 }
 
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static double t_last;
+static void phase(const char *name) { double t = now_ms(); fprintf(stderr, "[graphcheck] %-24s %9.1f ms\n", name, t - t_last); t_last = t; }
+
 #define RD(ptr, sz, cnt) do { if (fread(ptr, sz, cnt, fi) != (size_t)(cnt)) { fprintf(stderr, "short dump\n"); return 2; } } while (0)
 
 int main(int argc, char **argv)
@@ -38,11 +43,17 @@ int main(int argc, char **argv)
 	uint32_t *ll = (uint32_t *)malloc((n + 1) * 4), *rf = (uint32_t *)malloc((n + 1) * 4), *cnt = (uint32_t *)malloc((n + 1) * 4);
 	RD(keys, 8, n * nwk); RD(ll, 4, n); RD(rf, 4, n); RD(cnt, 4, n); RD(first, 8, n);
 	fclose(fi);
+	t_last = now_ms();
 	graph_t *G = graph_build(K, nwv, nwk, p, n, keys, ll, rf, cnt, first);
+	phase("build");
 	graph_remove_minor_out(G, dd);
+	phase("minor-out");
 	if (!d) graph_remove_single_tips(G);
+	phase("single tips");
 	graph_remove_minor_tips(G);
+	phase("minor tips");
 	uint64_t ne = graph_build_edges(G, argv[2]);
+	phase("edges");
 	if (argc > 3) {
 		sdt_cfg cfg;
 		if (sdt_cfg_load(argv[3], &cfg) != 0) return 2;

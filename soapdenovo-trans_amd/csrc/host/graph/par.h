@@ -3,6 +3,8 @@
 #define SDT_PAR_H
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <unistd.h>
 
 typedef void (*par_body)(void *ctx, uint64_t lo, uint64_t hi, int tid);
@@ -21,10 +23,27 @@ static void *par_thread(void *a)
 	return NULL;
 }
 
+/* usable CPUs: online CPUs, capped by the cgroup v2 CPU quota when there is one (more runnable threads than
+ * quota only buys CFS throttling) */
 static inline int par_threads(void)
 {
+	static int cached;
+	if (cached) return cached;
 	long n = sysconf(_SC_NPROCESSORS_ONLN);
-	return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+	if (n < 1) n = 1;
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		long long quota = -1, period = 0;
+		char q[64];
+		if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && q[0] != 'm') {
+			quota = atoll(q);
+			if (quota > 0 && (quota + period - 1) / period < n) n = (long)((quota + period - 1) / period);
+		}
+		fclose(f);
+	}
+	if (n > 64) n = 64;
+	cached = (int)n;
+	return cached;
 }
 
 static inline void par_for(uint64_t lo, uint64_t hi, uint64_t chunk, par_body fn, void *ctx)

@@ -86,6 +86,8 @@ def lib():
     L.sdto_write_kmerfreq.argtypes = [C.c_char_p, C.c_void_p]
     L.sdto_sets_export.restype = C.c_uint64
     L.sdto_sets_export.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.sdto_sets_export_first.restype = C.c_uint64
+    L.sdto_sets_export_first.argtypes = [C.c_void_p, C.c_void_p]
     for name in ("sdto_remove_single_tips", "sdto_remove_minor_tips"):
         getattr(L, name).restype = C.c_uint64
         getattr(L, name).argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -104,7 +106,7 @@ class SetStruct(C.Structure):      # sdto_set
 
 class SetsStruct(C.Structure):     # sdto_sets
     _fields_ = [("nsets", C.c_int), ("nw", C.c_int), ("K", C.c_int), ("sets", C.c_void_p),
-                ("kmers_in_reads", C.c_uint64)]
+                ("kmers_in_reads", C.c_uint64), ("reads_seen", C.c_uint64)]
 
 
 def key_words_for(K):
@@ -173,6 +175,12 @@ class Oracle:
         m = self.L.sdto_sets_export(self.h, keys.ctypes.data, l.ctypes.data, r.ctypes.data, c.ctypes.data, f.ctypes.data)
         assert m == n
         return keys[:n], l[:n], r[:n], c[:n], f[:n]
+
+    def export_first(self):
+        n = self.node_count()
+        first = np.zeros(max(n, 1), dtype=np.uint64)
+        assert self.L.sdto_sets_export_first(self.h, first.ctypes.data) == n
+        return first[:n]
 
 
 def kmerfreq_text(hist):

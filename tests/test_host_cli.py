@@ -142,13 +142,12 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
         o.delow(info["d"])
     o.mark()
     keys, l, r, cnt, fl = o.export()
-    first = first_ordinals(info, K, codes, offs)
+    fo = o.export_first()
     n = len(keys)
     rng = np.random.default_rng(1)
     perm = rng.permutation(n)                          # the GPU exports in arbitrary order
     rflags = (r.astype(np.uint32) | ((fl & 1).astype(np.uint32) << 24) | (((fl >> 1) & 1).astype(np.uint32) << 25)
               | (((fl >> 2) & 1).astype(np.uint32) << 27))
-    fo = np.array([first[tuple(int(x) for x in k)] for k in keys], dtype=np.uint64)
     dump = tmp_path / "nodes.bin"
     with open(dump, "wb") as f:
         f.write(struct.pack("<6iQ", K, nwv, nwk, info["p"], info["d"], 5, n))

@@ -27,6 +27,7 @@ ap.add_argument("--K", type=int, default=31)
 ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
+ap.add_argument("--timeout", type=int, default=300)
 args = ap.parse_args()
 
 tmp = tempfile.mkdtemp(prefix="sdt_e2e_")
@@ -52,9 +53,14 @@ try:
            "kmers": args.reads * (args.read_len - args.K + 1), "gen_s": round(gen_s, 1)}
     subprocess.run(["cat", fq], stdout=subprocess.DEVNULL)                     # warm the page cache
     ours = os.path.join(pkg.CSRC_DIR, "sdt-pregraph")
+    os.environ["SDT_TIMING"] = "1"
     t0 = time.time()
-    r = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                        os.path.join(tmp, "ours")], capture_output=True, text=True)
+    try:
+        r = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                            os.path.join(tmp, "ours")], capture_output=True, text=True, timeout=args.timeout)
+    except subprocess.TimeoutExpired as e:
+        print("sdt-pregraph timed out; stderr so far:\n", (e.stderr or b"").decode()[-3000:])
+        raise SystemExit(1)
     res["ours_wall_s"] = round(time.time() - t0, 2)
     if r.returncode != 0:
         print(r.stdout[-2000:], r.stderr[-2000:])
@@ -66,8 +72,12 @@ try:
     if not args.skip_ref:
         ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-Trans-{31 if args.K <= 31 else 127}mer")
         t0 = time.time()
-        rr = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                             os.path.join(tmp, "ref")], capture_output=True, text=True)
+        try:
+            rr = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                                 os.path.join(tmp, "ref")], capture_output=True, text=True, timeout=max(args.timeout, 900))
+        except subprocess.TimeoutExpired:
+            print(json.dumps(res, indent=1))
+            raise SystemExit("the reference binary did not finish (its AIO reader can spin forever, SURVEY 9.3-q9)")
         res["ref_wall_s"] = round(time.time() - t0, 2)
         res["ref_phase_lines"] = [l for l in rr.stdout.splitlines() if l.startswith("time spent")]
         same = {}
@@ -77,7 +87,7 @@ try:
         res["identical"] = same
         res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
-    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith("[sdt-pregraph]")]
+    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith("[sdt-pregraph]") or l.startswith("[cuttip]")]
     print(json.dumps(res, indent=1))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
