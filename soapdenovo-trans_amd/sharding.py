@@ -11,9 +11,10 @@ from __future__ import annotations
 
 import numpy as np
 
-# Measured on MI355X / RCCL 2.26 / torch 2.10: all_to_all_single silently delivers garbage once one split
-# exceeds 2^27 int64 elements (1 GiB) -- tools/dbg_exchange.py.  Stay well below and fail loudly above.
-MAX_SPLIT_WORDS = 1 << 26
+# Measured on MI355X / RCCL 2.26 / torch 2.10 (one rank): all_to_all_single silently delivers garbage once the
+# message exceeds 2^27 int64 elements (1 GiB) -- tools/dbg_exchange.py.  Whether the limit is per split or per call
+# could not be told apart on one GPU, so the WHOLE call is kept below half of it, and anything larger fails loudly.
+MAX_CALL_WORDS = 1 << 26
 
 
 def owner_of(lib, key_words_msw_first: np.ndarray, nranks: int) -> int:
@@ -42,8 +43,8 @@ def exchange_records(send, counts, cap_per_rank: int, rec_words: int, recv, grou
     total = int(sum(rc))
     if total * rec_words > recv.numel():
         raise RuntimeError(f"receive buffer too small: need {total} records, have {recv.numel() // rec_words}")
-    if max(c + rc) * rec_words > MAX_SPLIT_WORDS:
-        raise RuntimeError(f"all-to-all split of {max(c + rc) * rec_words} words exceeds {MAX_SPLIT_WORDS}: "
+    if max(sum(c), sum(rc)) * rec_words > MAX_CALL_WORDS:
+        raise RuntimeError(f"all-to-all of {max(sum(c), sum(rc)) * rec_words} words exceeds {MAX_CALL_WORDS}: "
                            "use fewer reads per round")
     # compact the fixed-capacity slices (cheap device copy), then ONE all-to-all(v) of 8-byte words
     ins = [send[(i * cap_per_rank) * rec_words:(i * cap_per_rank + c[i]) * rec_words] for i in range(world)]
@@ -83,8 +84,9 @@ class ShardedCounter:
         self.g, self.world, self.L, self.device = g, world, max_read_len, device
         self.rec_words = g.record_bytes() // 8
         per_read = max(max_read_len - g.K + 1, 1)
-        # keep every per-peer split below the collective's safe size (with head room for owner imbalance)
-        limit = int(MAX_SPLIT_WORDS / self.rec_words * world / 1.3 / per_read)
+        # keep every exchange below the collective's safe size (with head room: what a rank RECEIVES can exceed
+        # what it sends when owners are unevenly loaded)
+        limit = int(MAX_CALL_WORDS / self.rec_words / 1.3 / per_read)
         self.per_round = max(64, min(reads_per_round, limit))
         reads_per_round = self.per_round
         kmers_round = reads_per_round * per_read
