@@ -34,13 +34,20 @@ constexpr uint32_t AUX_LINEAR = 1u << 16;
 constexpr uint32_t AUX_DELETED = 1u << 17;
 constexpr uint64_t VAL_COUNT_ONE = 1ULL << 48;
 
-template <int NW> struct Entry {
-	uint64_t key[NW];
-	uint64_t val;
-};
-template <> struct alignas(16) Entry<1> {   // one global_load_dwordx4 fetches key + val
+template <int NW> struct Entry;
+template <> struct alignas(16) Entry<1> {   // 16 B: one global_load_dwordx4 fetches key + val
 	uint64_t key[1];
 	uint64_t val;
+};
+template <> struct alignas(32) Entry<2> {   // 32 B, never straddles a 64-B sector: two dwordx4 loads
+	uint64_t key[2];
+	uint64_t val;
+	uint64_t pad;
+};
+template <> struct alignas(16) Entry<4> {   // 48 B: three dwordx4 loads
+	uint64_t key[4];
+	uint64_t val;
+	uint64_t pad;
 };
 
 template <int NW> struct Table {
@@ -167,12 +174,40 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 	for (uint64_t probe = 0; probe < max_probe;) {
 		Entry<NW> *e = t.ent + slot;
 		uint64_t k0, seen = 0;
-		if (NW == 1) {
+		if constexpr (NW == 1) {
 			// one 16-byte load: key + val (val may be stale: see node_update)
 			const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(e);
 			k0 = kv.x;
 			seen = kv.y;
 		} else {
+			// Fast path with plain 16-byte loads.  A published key never changes (write once) and its low words
+			// are written before key[0], so: a full match is a match; a different published key[0] is a definite
+			// mismatch; anything else (empty, locked, or key[0] equal but low words not (yet) visible in this
+			// XCD's L2) goes through the careful agent-scope path below.
+			const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(e);
+			const ulonglong2 a = q[0];
+			k0 = a.x;
+			if (k0 != KEY_EMPTY && k0 != KEY_LOCKED) {
+				if (k0 != key.w[0]) {
+					slot = (slot + 1) & t.mask;
+					probe++;
+					continue;
+				}
+				bool eq = a.y == key.w[1];
+				uint64_t v;
+				if constexpr (NW == 4) {
+					const ulonglong2 b = q[1];
+					eq = eq && b.x == key.w[2] && b.y == key.w[3];
+					v = q[2].x;
+				} else {
+					v = q[1].x;
+				}
+				if (eq) {
+					node_update(&e->val, t.aux + slot, v, prev, next);
+					note_first(t.first, slot, ord);
+					return true;
+				}
+			}
 			k0 = ld_relaxed(&e->key[0]);
 		}
 		if (k0 == KEY_EMPTY) {
@@ -185,7 +220,13 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 #pragma unroll
 					for (int i = 1; i < NW; i++)
 						__hip_atomic_store(&e->key[i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					// Publish key[0] only after the low words have been acknowledged.  All of these are agent-scope
+					// (sc1, write-through) stores to ONE entry, and every reader either takes a single-sector
+					// snapshot or re-reads with agent-scope loads, so waiting for this lane's own stores is
+					// enough; a release fence here would write back the whole XCD L2 (~2-6 us per NEW key,
+					// MI355X_MICROARCH.md) and was measured to cap 2-word keys at 3.5 G k-mers/s.
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				node_update(&e->val, t.aux + slot, 0, prev, next);
 				note_first(t.first, slot, ord);

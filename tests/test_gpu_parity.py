@@ -244,3 +244,28 @@ def test_first_occurrence_ordinals(pkg, synth, K, stride, base):
         g.finish_count()
         with pytest.raises(pkg.SdtError):
             g.export_nodes(with_first=True)
+
+
+@pytest.mark.parametrize("K", [63, 127])
+def test_wide_key_publication_stress(pkg, synth, K):
+    """multi-word keys are claimed with a CAS on the first word and published without a release fence
+    (csrc/sdt_table.cuh): a lost or duplicated node would change the node count / histogram.  ~100 M occurrences,
+    ~10 M new keys, every lane of the chip inserting at once."""
+    import torch
+    dev = torch.device("cuda:0")
+    L, n = 250, 500_000
+    words, offsets, nwords = synth.torch_workload(n, L, T=200, device=dev, seed=5)
+    torch.cuda.synchronize()
+    hw = words.cpu().numpy().view(np.uint32)
+    idx = np.arange(n * L, dtype=np.int64)
+    codes = ((hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
+    o = ob.Oracle(K, nsets=8)
+    o.add_reads(codes, (np.arange(n + 1, dtype=np.uint64) * L))
+    ohist, olinear = o.mark()
+    for rep in range(3):
+        with pkg.PregraphGPU(K, est_distinct=1 << 20) as g:       # small table: growth under load too
+            g.count_reads_device(words, nwords, offsets, n, L)
+            kmers, nodes = g.finish_count()
+            assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+            hist, linear = g.mark_and_hist()
+            assert linear == olinear and (hist == ohist).all()
