@@ -342,11 +342,19 @@ static int walk_from_tip(graph_t *g, const gnode_t *tip, int cut_len, int thin, 
 }
 
 /* the decision at the end of the walk (:282-336); reads and writes only `tip` and the end node */
-static int decide_tip(graph_t *g, gnode_t *tip, const walk_t *w, int thin, uint64_t *tips)
+static int decide_tip(graph_t *g, gnode_t *tip, const walk_t *w, int thin, uint64_t *tips, int dry)
 {
 	gnode_t *o = &g->nodes[w->end];
 	const unsigned ch = w->ch;
 	const int sm = w->sm;
+	if (dry) {                                                          /* would this decision write? (no side effects) */
+		if (degree(o, LEFT) + degree(o, RIGHT) == 1 || thin) return 1;
+		const int side = sm ? LEFT : RIGHT;
+		unsigned strongest = 0;
+		for (unsigned c = 0; c < 4; c++)
+			if (link_of(o, side, c) > strongest) strongest = link_of(o, side, c);
+		return link_of(o, side, sm ? ch : ch ^ 2u) < strongest;
+	}
 	if (degree(o, LEFT) + degree(o, RIGHT) == 1) {                       /* the whole path is an island */
 		(*tips)++;
 		tip->deleted = 1;
@@ -382,17 +390,20 @@ static int clip_tip(graph_t *g, gnode_t *tip, int cut_len, int thin, uint64_t *t
 {
 	walk_t w;
 	if (!walk_from_tip(g, tip, cut_len, thin, &w)) return 0;
-	return decide_tip(g, tip, &w, thin, tips);
+	return decide_tip(g, tip, &w, thin, tips, 0);
 }
 
-typedef struct { graph_t *g; int cut_len, thin; walk_t *walks; } tips_ctx;
+typedef struct { graph_t *g; int cut_len, thin; walk_t *walks; volatile uint64_t would_cut; } tips_ctx;
 
 static void spec_tips(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
 	tips_ctx *c = (tips_ctx *)vc;
+	uint64_t cuts = 0;
 	for (uint64_t i = lo; i < hi; i++)
-		walk_from_tip(c->g, &c->g->nodes[i], c->cut_len, c->thin, &c->walks[i]);
+		if (walk_from_tip(c->g, &c->g->nodes[i], c->cut_len, c->thin, &c->walks[i]))
+			cuts += (uint64_t)decide_tip(c->g, &c->g->nodes[i], &c->walks[i], c->thin, NULL, 1);
+	if (cuts) __sync_fetch_and_add(&c->would_cut, cuts);
 }
 
 /* One sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips.
@@ -406,7 +417,10 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 	c->cut_len = cut_len;
 	c->thin = thin;
 	g->touched = NULL;
+	c->would_cut = 0;
 	par_for(lo, hi, 8192, spec_tips, c);
+	if (c->would_cut == 0)
+		return 0;                                        /* nothing writes on the untouched graph => the sweep is a no-op */
 	g->touched = marks;                                  /* all zero on entry (calloc / un-marked below) */
 	g->tn = 0;
 	int clipped = 0;
@@ -419,7 +433,7 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 			if (!w->thin_stop && g->nodes[w->end].linear)
 				clipped += clip_tip(g, tip, cut_len, thin, tips);
 			else
-				clipped += decide_tip(g, tip, w, thin, tips);
+				clipped += decide_tip(g, tip, w, thin, tips, 0);
 		}
 	}
 	for (size_t k = 0; k < g->tn; k++) marks[g->tlist[k]] = 0;
@@ -432,7 +446,7 @@ uint64_t graph_remove_single_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
-	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
+	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
 	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
 	free(marks);
@@ -446,7 +460,7 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
-	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t))};
+	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
 	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;

@@ -180,6 +180,7 @@ struct build_job {
 	uint32_t *set_of;
 	uint64_t *per_set;       /* p + 1 prefix */
 	ord_t *ord;
+	uint64_t *hist;          /* nthreads x p */
 	volatile int next_set;
 };
 typedef struct { build_job *J; int tid; } job_arg;
@@ -211,6 +212,7 @@ static void job_unpack(build_job *J, int tid)
 	const int nwk = J->nw_keys;
 	for (uint64_t i = lo; i < hi; i++) {
 		gnode_t *nd = &J->tmp[i];
+		memset(nd, 0, sizeof *nd);                       /* tmp is malloc'd: first touch happens here, in parallel */
 		for (int w = 0; w < nwk; w++) nd->seq.w[4 - nwk + w] = J->keys[i * nwk + w];
 		nd->l_links = J->l_links[i];
 		nd->r_links = J->r_flags[i] & 0xFFFFFFu;
@@ -257,9 +259,32 @@ static void job_index(build_job *J, int tid)
 	}
 }
 
+static void job_count_sets(build_job *J, int tid)
+{
+	const uint64_t lo = J->n * (uint64_t)tid / J->nthreads, hi = J->n * (uint64_t)(tid + 1) / J->nthreads;
+	uint64_t *h = J->hist + (size_t)tid * J->g->p;
+	for (uint64_t i = lo; i < hi; i++) h[J->set_of[i]]++;
+}
+
+static void job_scatter_sets(build_job *J, int tid)
+{
+	const uint64_t lo = J->n * (uint64_t)tid / J->nthreads, hi = J->n * (uint64_t)(tid + 1) / J->nthreads;
+	uint64_t *h = J->hist + (size_t)tid * J->g->p;
+	for (uint64_t i = lo; i < hi; i++) {
+		ord_t *o = &J->ord[h[J->set_of[i]]++];
+		o->first = J->first[i];
+		o->id = i;
+	}
+}
+
+#include <time.h>
+static double gb_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
+
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first)
 {
+	double t_sub = gb_now();
 	graph_t *g = (graph_t *)calloc(1, sizeof *g);
 	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
 	build_job J;
@@ -267,27 +292,37 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	J.nthreads = par_threads();
 	J.g = g; J.nw_keys = nw_keys; J.n = n; J.keys = keys; J.first = first;
 	J.l_links = l_links; J.r_flags = r_flags; J.count = count;
-	J.tmp = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	J.tmp = (gnode_t *)malloc((n ? n : 1) * sizeof(gnode_t));
 	J.set_of = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
 	J.per_set = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
 	run_parallel(&J, job_unpack);
-	for (uint64_t i = 0; i < n; i++) J.per_set[J.set_of[i] + 1]++;
-	for (int s = 0; s < p; s++) J.per_set[s + 1] += J.per_set[s];
-	/* group node ids by set; each group is then ordered by first occurrence and replayed by one worker */
+	GB_PHASE("unpack + hash_kmer");
+	/* group node ids by set (counting sort, per-thread histograms); each group is then ordered by first
+	 * occurrence and replayed by one worker */
 	J.ord = (ord_t *)malloc((n ? n : 1) * sizeof(ord_t));
-	uint64_t *fill = (uint64_t *)malloc((size_t)p * sizeof(uint64_t));
-	memcpy(fill, J.per_set, (size_t)p * sizeof(uint64_t));
-	for (uint64_t i = 0; i < n; i++) {
-		ord_t *o = &J.ord[fill[J.set_of[i]]++];
-		o->first = first[i];
-		o->id = i;
+	J.hist = (uint64_t *)calloc((size_t)J.nthreads * (size_t)p + 1, sizeof(uint64_t));
+	run_parallel(&J, job_count_sets);
+	{
+		uint64_t acc = 0;
+		for (int sidx = 0; sidx < p; sidx++) {
+			J.per_set[sidx] = acc;
+			for (int t = 0; t < J.nthreads; t++) {
+				const uint64_t c = J.hist[(size_t)t * p + sidx];
+				J.hist[(size_t)t * p + sidx] = acc;           /* where thread t starts writing in set sidx */
+				acc += c;
+			}
+		}
+		J.per_set[p] = acc;
 	}
-	free(fill);
-	g->nodes = (gnode_t *)calloc(n ? n : 1, sizeof(gnode_t));
+	run_parallel(&J, job_scatter_sets);
+	free(J.hist);
+	GB_PHASE("group by set");
+	g->nodes = (gnode_t *)malloc((n ? n : 1) * sizeof(gnode_t));      /* every element is written by job_replay */
 	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
 	memcpy(g->set_start, J.per_set, ((size_t)p + 1) * sizeof(uint64_t));
 	J.next_set = 0;
 	run_parallel(&J, job_replay);
+	GB_PHASE("sort + replay per set");
 	free(J.ord); free(J.per_set); free(J.set_of); free(J.tmp);
 	/* index */
 	uint64_t cap = 1024;
@@ -295,6 +330,7 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	g->index = (uint64_t *)calloc(cap, sizeof(uint64_t));
 	g->index_mask = cap - 1;
 	run_parallel(&J, job_index);
+	GB_PHASE("index");
 	return g;
 }
 
