@@ -269,3 +269,48 @@ def test_wide_key_publication_stress(pkg, synth, K):
             assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
             hist, linear = g.mark_and_hist()
             assert linear == olinear and (hist == ohist).all()
+
+
+def test_sharded_counter_world1_equals_direct(pkg, synth):
+    """the N>1 driver path (sharding.ShardedCounter: extract_route -> RCCL all-to-all(v) -> insert_records ->
+    all-reduce) with a one-rank process group on the GPU: same table as the direct kernel, several rounds,
+    exchange checksum on.  (RCCL silently corrupts all-to-alls above 2^27 words -- sharding.MAX_CALL_WORDS.)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from soapdenovo_trans_amd import sharding
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        K, L, n = 31, 150, 600_000
+        words, offsets, nwords = synth.torch_workload(n, L, T=500, device=dev, seed=9)
+        torch.cuda.synchronize()
+        with pkg.PregraphGPU(K, est_distinct=1 << 24) as g:
+            g.count_reads_device(words, nwords, offsets, n, L)
+            want = g.finish_count()
+            whist, wlin = g.mark_and_hist()
+        with pkg.PregraphGPU(K, est_distinct=1 << 24) as g:
+            stream = torch.cuda.Stream(device=dev)
+            g.set_stream(stream.cuda_stream)
+            sc = sharding.ShardedCounter(g, 1, L, 250_000, dev)          # 3 rounds
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                sc.count_reads(words, nwords, offsets, n, verify=True)
+            got = g.finish_count()
+            hist, lin = g.mark_and_hist()
+            hist, k, nodes, lin = sharding.allreduce_stats(hist, got[0], got[1], lin, dev)
+            assert (k, nodes) == want and lin == wlin and (hist == whist).all()
+        # the size guard fails loudly instead of exchanging garbage
+        big = sharding.MAX_CALL_WORDS // 2 + 8
+        send = torch.empty(16, dtype=torch.int64, device=dev)
+        counts = torch.tensor([big], dtype=torch.int64, device=dev)
+        with pytest.raises(RuntimeError):
+            sharding.exchange_records(send, counts, big, 2, send)
+    finally:
+        if created:
+            dist.destroy_process_group()
