@@ -275,9 +275,35 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 	g->touched = marks;
 	g->tn = 0;
-	for (uint64_t i = 0; i < g->n; i++)
+	/* The commit is a chain of dependent cache misses per visit (node -> its neighbour slots -> the cut
+	 * neighbours -> their neighbour slots -> the nodes those unlink).  The visits the dry run flagged are known up
+	 * front, so run a software prefetch pipeline a few visits ahead of the sweep. */
+	uint64_t nexec = 0;
+	for (uint64_t i = 0; i < g->n; i++) nexec += c.writes[i];
+	uint64_t *ex = (uint64_t *)malloc((nexec + 1) * sizeof(uint64_t));
+	nexec = 0;
+	for (uint64_t i = 0; i < g->n; i++) if (c.writes[i]) ex[nexec++] = i;
+	uint64_t cur = 0;                                   /* next flagged visit at or after the sweep position */
+	for (uint64_t i = 0; i < g->n; i++) {
+		if (c.writes[i]) {
+			/* stage 1 (far): slot number; stage 2: the 8 neighbour entries; stage 3: the neighbour nodes and their
+			 * slot numbers; stage 4 (near): the neighbours' own neighbour entries */
+			if (cur + 24 < nexec) __builtin_prefetch(&g->nb_slot[ex[cur + 24]]);
+			if (cur + 16 < nexec) { const uint32_t sl = g->nb_slot[ex[cur + 16]]; if (sl) __builtin_prefetch(&g->nb_pool[(uint64_t)(sl - 1) * 8]); __builtin_prefetch(&g->nodes[ex[cur + 16]]); }
+			if (cur + 8 < nexec) {
+				const uint32_t sl = g->nb_slot[ex[cur + 8]];
+				if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE) { __builtin_prefetch(&g->nodes[v >> 1]); __builtin_prefetch(&g->nb_slot[v >> 1]); } }
+			}
+			if (cur + 4 < nexec) {
+				const uint32_t sl = g->nb_slot[ex[cur + 4]];
+				if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE && c.need[v >> 1]) { const uint32_t s2 = g->nb_slot[v >> 1]; if (s2) __builtin_prefetch(&g->nb_pool[(uint64_t)(s2 - 1) * 8]); } }
+			}
+			cur++;
+		}
 		if (c.writes[i] || marks[i])
 			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
+	}
+	free(ex);
 	g->touched = NULL;
 	g->tn = 0;
 	SUBPHASE("ordered commit");
@@ -427,6 +453,8 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 	for (uint64_t i = lo; i < hi; i++) {
 		gnode_t *tip = &g->nodes[i];
 		const walk_t *w = &c->walks[i];
+		if (i + 64 < hi && c->walks[i + 64].end != NO_NODE)
+			__builtin_prefetch(&g->nodes[c->walks[i + 64].end]);             /* the decision reads the end node */
 		if (marks[i]) {
 			clipped += clip_tip(g, tip, cut_len, thin, tips);
 		} else if (w->end != NO_NODE) {
