@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU baseline (0 = skip)")
     ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
     ap.add_argument("--est-distinct", type=int, default=0)
+    ap.add_argument("--shard-mode", choices=["filter", "route"], default="filter",
+                    help="N>1: 'filter' = every rank holds all reads and inserts only the k-mers it owns (no exchange); "
+                         "'route' = reads are split and records travel in an RCCL all-to-all")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (extract_route -> all-to-all -> insert_records) even with one rank")
     args = ap.parse_args()
@@ -182,10 +185,15 @@ def main():
 
     K, L = pkg.clamp_K(args.K), args.read_len
     n_total = args.reads
-    n_local = n_total // world + (1 if rank < n_total % world else 0)
+    route = args.shard_mode == "route"
+    if sharded_path and not route:
+        n_local = n_total                     # owner-filter sharding: the reads are replicated, the TABLE is sharded
+    else:
+        n_local = n_total // world + (1 if rank < n_total % world else 0)
     kmers_total = n_total * (L - K + 1)
     t0 = time.time()
-    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, seed=42 + 1000 * rank, err=args.err)
+    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err,
+                                                  seed=42 + (1000 * rank if (sharded_path and route) else 0))
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
 
@@ -199,11 +207,14 @@ def main():
     sharded = None
     if sharded_path:
         from soapdenovo_trans_amd.sharding import ShardedCounter, allreduce_stats
-        sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
+        if route:
+            sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
+        else:
+            g.set_owner_filter(rank, world)
 
     def one_step(verify=False):
         g.reset()
-        if not sharded_path:
+        if not sharded_path or not route:
             g.count_reads_device(words, nwords, offsets, n_local, L)
         else:
             with torch.cuda.stream(stream):
@@ -262,7 +273,9 @@ def main():
         "config": {"workload": f"{n_total} x {L} bp synthetic transcriptome reads (T={args.T}, err={args.err}), "
                                f"K={K}, pass-1 chop+hash+count+kmerFreq", "reads": n_total, "read_len": L, "K": K,
                    "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
-                   "parallelism": f"owner-sharded x{world}" if sharded_path else "single-GPU table"},
+                   "parallelism": (f"owner-sharded table x{world}, " + ("records routed by RCCL all-to-all" if route else
+                                   "reads replicated, owner filter (no data-path collective)")) if sharded_path
+                   else "single-GPU table"},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not sharded_path and args.cpu_sample > 0:

@@ -111,6 +111,11 @@ int sdt_gpu_extract_route(sdt_ctx *ctx, const void *d_packed_words, uint64_t nwo
                           void *d_records, uint64_t max_records,
                           void *d_counts, void *d_displs);
 int sdt_gpu_insert_records(sdt_ctx *ctx, const void *d_records, uint64_t nrecords);
+/* Alternative without any exchange (the reference's own scheme across threads, prlHashReads.c:79-88): every
+ * rank is given ALL reads and sdt_gpu_push_reads / sdt_gpu_count_reads_device insert only the k-mers whose
+ * owner is `rank`.  Chopping is ~10x cheaper than inserting, so this beats the all-to-all whenever the reads
+ * can be replicated (7.5 GB packed for 200 M x 150 bp).  rank 0 / nranks 1 switches the filter off. */
+int sdt_gpu_set_owner_filter(sdt_ctx *ctx, int rank, int nranks);
 /* bytes per routed record for this context's key width */
 int sdt_gpu_record_bytes(const sdt_ctx *ctx);
 

@@ -42,6 +42,7 @@ _ABI = [
       _c.c_uint64, _c.c_void_p, _c.c_void_p]),
     ("sdt_gpu_insert_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_record_bytes", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_set_owner_filter", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_mark_and_hist", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_nodes", _c.c_int,
@@ -191,6 +192,9 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_extract_route(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets), nreads,
                                                    max_read_len, nranks, _ptr(d_records), max_records,
                                                    _ptr(d_counts), _ptr(d_displs)))
+
+    def set_owner_filter(self, rank: int, nranks: int):
+        self._check(self.lib.sdt_gpu_set_owner_filter(self._ctx, rank, nranks))
 
     def insert_records(self, d_records, nrecords: int):
         self._check(self.lib.sdt_gpu_insert_records(self._ctx, _ptr(d_records), nrecords))

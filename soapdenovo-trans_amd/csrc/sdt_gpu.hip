@@ -146,8 +146,11 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict__ packed,
                                                      const uint64_t *__restrict__ offs, uint64_t nreads, int K,
                                                      int max_tile_words, Table<NW> tbl, Stats *stats,
-                                                     uint64_t ord_base, uint64_t ord_stride)
+                                                     uint64_t ord_base, uint64_t ord_stride, int my_rank, int nranks)
 {
+	// nranks > 1: owner-filter sharding.  Every rank chops ALL reads (the chop runs at > 200 G k-mers/s) and
+	// inserts only the k-mers it owns -- the reference's own scheme across threads (prlHashReads.c:79-88),
+	// without any record exchange.
 	extern __shared__ uint32_t smem[];
 	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
 	uint32_t claimed = 0, failed = 0, done = 0;
@@ -160,6 +163,8 @@ __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict_
 			uint32_t prev, next;
 			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
 			// ordinal of this occurrence in the reference's stream order: (read ordinal, position in read)
+			if (nranks > 1 && (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32) != my_rank)
+				continue;
 			const uint64_t ord = tbl.first ? ((ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride) << 16) | (uint64_t)j : ORD_NONE;
 			if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
 				failed++;
@@ -190,54 +195,61 @@ template <int NW> struct Record {
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_extract_route(const uint32_t *__restrict__ packed,
                                                        const uint64_t *__restrict__ offs, uint64_t nreads, int K,
-                                                       int max_tile_words, int nranks, Record<NW> *__restrict__ out,
+                                                       int max_tile_words, int tile_smem_words, int nranks,
+                                                       Record<NW> *__restrict__ out,
                                                        const unsigned long long *__restrict__ displs,
                                                        unsigned long long *__restrict__ cursors,
                                                        unsigned long long cap_per_rank, Stats *stats)
 {
+	// Per tile: count the records per owner rank in LDS, reserve each owner's run with ONE global atomic, then chop
+	// again and write.  (One atomic per wave and owner was measured to serialise on the nranks cursor words:
+	// ~88 same-address atomics/us = 5.6 G records/s; the chop itself runs at > 200 G k-mers/s, so doing it twice
+	// is the cheap side of the trade.)
 	extern __shared__ uint32_t smem[];
+	uint32_t *s_cnt = smem + tile_smem_words;                           // 64
+	uint32_t *s_fill = s_cnt + 64;                                      // 64
+	unsigned long long *s_base = (unsigned long long *)(s_fill + 64);   // 64 (8-byte aligned: tile_smem_words is even)
 	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
 	uint32_t failed = 0;
 	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
-		const uint32_t rounds = (tv.nk + TPB - 1) / TPB;
-		for (uint32_t it = 0; it < rounds; it++) {
-			const uint32_t q = it * TPB + threadIdx.x;
-			const bool live = q < tv.nk;
-			Key<NW> key;
-			uint32_t prev = 4, next = 4;
-			int owner = -1;
-			if (live) {
-				const int r = tile_find_read(tv.pre, q);
-				const int j = (int)(q - tv.pre[r]);
-				const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
-				key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
-				owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
-			}
-			// wave-aggregated slot reservation: one atomic per (wave, owner) instead of one per record
-			const int lane = threadIdx.x & 63;
-			for (int rk = 0; rk < nranks; rk++) {
-				const unsigned long long m = __ballot(owner == rk);
-				if (m == 0)
-					continue;
-				const int leader = __ffsll((long long)m) - 1;
-				unsigned long long base = 0;
-				if (lane == leader)
-					base = atomicAdd(&cursors[rk], (unsigned long long)__popcll(m));
-				base = __shfl(base, leader);
-				if (owner == rk) {
-					const unsigned long long pos = base + __popcll(m & ((1ULL << lane) - 1ULL));
-					if (pos < cap_per_rank) {
-						Record<NW> rec;
+		if (threadIdx.x < 64) {
+			s_cnt[threadIdx.x] = 0;
+			s_fill[threadIdx.x] = 0;
+		}
+		__syncthreads();
+		for (uint32_t q = threadIdx.x; q < tv.nk; q += TPB) {
+			const int r = tile_find_read(tv.pre, q);
+			const int j = (int)(q - tv.pre[r]);
+			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
+			uint32_t prev, next;
+			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
+			const int owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
+			atomicAdd(&s_cnt[owner], 1u);
+		}
+		__syncthreads();
+		if (threadIdx.x < (unsigned)nranks) {
+			const uint32_t n = s_cnt[threadIdx.x];
+			s_base[threadIdx.x] = n ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)n) : 0ULL;
+		}
+		__syncthreads();
+		for (uint32_t q = threadIdx.x; q < tv.nk; q += TPB) {
+			const int r = tile_find_read(tv.pre, q);
+			const int j = (int)(q - tv.pre[r]);
+			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
+			uint32_t prev, next;
+			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
+			const int owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
+			const unsigned long long pos = s_base[owner] + atomicAdd(&s_fill[owner], 1u);
+			if (pos < cap_per_rank) {
+				Record<NW> rec;
 #pragma unroll
-						for (int i = 0; i < NW; i++)
-							rec.key[i] = key.w[i];
-						rec.meta = (uint64_t)prev | ((uint64_t)next << 3);
-						out[displs[rk] + pos] = rec;
-					} else {
-						failed++;
-					}
-				}
+				for (int i = 0; i < NW; i++)
+					rec.key[i] = key.w[i];
+				rec.meta = (uint64_t)prev | ((uint64_t)next << 3);
+				out[displs[owner] + pos] = rec;
+			} else {
+				failed++;
 			}
 		}
 		__syncthreads();
@@ -450,6 +462,7 @@ struct sdt_ctx {
 	uint32_t *d_aux = nullptr;
 	uint64_t *d_first = nullptr;       // SDT_FLAG_TRACK_FIRST
 	uint64_t ord_base = 0, ord_stride = 1;
+	int my_rank = 0, nranks = 1;       // owner-filter sharding (sdt_gpu_set_owner_filter)
 	Stats *d_stats = nullptr;
 	Stats *h_stats = nullptr;          // pinned
 	unsigned long long *d_hist = nullptr;
@@ -799,6 +812,15 @@ uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int sdt_gpu_record_bytes(const sdt_ctx *c) { return c ? (c->nw + 1) * 8 : 0; }
 
+int sdt_gpu_set_owner_filter(sdt_ctx *c, int rank, int nranks)
+{
+	if (!c || nranks < 1 || rank < 0 || rank >= nranks)
+		return fail(SDT_EINVAL, "bad rank/nranks");
+	c->my_rank = rank;
+	c->nranks = nranks;
+	return SDT_OK;
+}
+
 int sdt_gpu_set_read_ordinal(sdt_ctx *c, uint64_t base, uint64_t stride)
 {
 	if (!c || stride == 0)
@@ -972,11 +994,11 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 		HIPCHK(hipEventRecord(ev->a, c->stream));
 		// offsets are absolute base indices into d_words, so a sub-range of reads is just a shifted pointer
 		if (c->nw == 1)
-			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
 		else if (c->nw == 2)
-			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
 		else
-			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev->b, c->stream));
 		c->kmers_since_sync += upper;
@@ -1105,7 +1127,9 @@ int sdt_gpu_extract_route(sdt_ctx *c, const void *d_packed_words, uint64_t nword
 	if (max_read_len == 0)
 		return fail(SDT_EINVAL, "max_read_len must be > 0");
 	const int mtw = tile_words_for(max_read_len);
-	const size_t smem = tile_smem_bytes(mtw);
+	const size_t tile_bytes = tile_smem_bytes(mtw);
+	const int tile_words = (int)((tile_bytes / sizeof(uint32_t) + 1) & ~(size_t)1);
+	const size_t smem = (size_t)tile_words * 4 + 128 * sizeof(uint32_t) + 64 * sizeof(unsigned long long);
 	if (smem > 64 * 1024)
 		return fail(SDT_EINVAL, "max read length %llu needs %zu B of LDS per tile (limit 64 KiB)",
 		            (unsigned long long)max_read_len, smem);
@@ -1114,11 +1138,11 @@ int sdt_gpu_extract_route(sdt_ctx *c, const void *d_packed_words, uint64_t nword
 	const uint64_t gcap = (uint64_t)c->cu_count * 4;
 	if (grid > gcap) grid = gcap;
 	if (c->nw == 1)
-		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
 	else if (c->nw == 2)
-		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
 	else
-		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
 }

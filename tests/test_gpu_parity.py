@@ -314,3 +314,32 @@ def test_sharded_counter_world1_equals_direct(pkg, synth):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,nranks", [(31, 4), (47, 3)])
+def test_owner_filter_shards_add_up(pkg, synth, K, nranks):
+    """owner-filter sharding (sdt_gpu_set_owner_filter): every virtual rank sees all reads and keeps its own
+    k-mers; the shards are disjoint and their histograms / counters add up to the single-table result"""
+    tx = synth.make_transcriptome(30, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=8000, read_len=120, seed=3, ragged=True)
+    words = synth.pack_2bit(codes)
+    with pkg.PregraphGPU(K, est_distinct=1 << 18) as g:
+        g.push_reads(words, offs)
+        want = g.finish_count()
+        whist, wlin = g.mark_and_hist()
+        wkeys = set(keys_to_int(g.export_nodes()[0]))
+    tot_k = tot_n = tot_l = 0
+    hist = np.zeros(257, dtype=np.int64)
+    seen = set()
+    for r in range(nranks):
+        with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:
+            g.set_owner_filter(r, nranks)
+            g.push_reads(words, offs)
+            k, n = g.finish_count()
+            h, lin = g.mark_and_hist()
+            keys = set(keys_to_int(g.export_nodes()[0]))
+            assert not (keys & seen)
+            seen |= keys
+            tot_k += k; tot_n += n; tot_l += lin
+            hist += h
+    assert (tot_k, tot_n) == want and tot_l == wlin and (hist == whist).all() and seen == wkeys
