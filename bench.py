@@ -39,13 +39,19 @@ def algorithmic_bytes_per_kmer(L, K):
     return 0.25 * L / (L - K + 1) + 2 * E
 
 
-def pmc_traffic_per_kmer(kernel="k_count_reads"):
+def pmc_traffic_per_kmer(K, kernel="k_count_reads"):
     """HBM bytes per k-mer of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE are collected in separate rocprofv3 --pmc runs, tools/pmc_summary.py; they cannot be read live).
+    Only a profile taken with the same key width (file name ..._k<K>.json) counts.
     Returns (bytes per k-mer, source file) or (None, None)."""
     import glob
+    import re
+    words = lambda k: 1 if k <= 31 else (2 if k <= 63 else 4)
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_{kernel}*.json"))):
+        m = re.search(r"_k(\d+)\.json$", f)
+        if not m or words(int(m.group(1))) != words(K):
+            continue
         try:
             j = json.load(open(f))
             best = (j["hbm_bytes"]["per_kmer"], os.path.relpath(f, ROOT))
@@ -257,7 +263,7 @@ def main():
     roof = None
     if world == 1 and not sharded_path and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
-        tpk, tsrc = pmc_traffic_per_kmer()
+        tpk, tsrc = pmc_traffic_per_kmer(K)
         per_launch_kmers = local_kmers * args.steps / max(launches, 1)
         roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),

@@ -156,6 +156,23 @@ int sdt_gpu_map_reads(sdt_ctx *ctx, uint64_t *reads_processed, uint64_t *arcs);
 int sdt_gpu_export_arcs(sdt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *mult, uint64_t *first,
                         uint64_t max_arcs, uint64_t *n);
 
+/* ---- graph-cleaning dry runs (cutTipPreGraph.c) on the device mirror of the host graph ------------------
+ * The passes after kmerFreq are order-dependent: the host commits their writes in the reference's
+ * order.  What each sweep needs before that is read-only -- the walk from every dead end to the node it runs
+ * into (clipTipFromNode, cutTipPreGraph.c:43-281) -- and that is table look-ups: the device table, kept equal to
+ * the host graph, answers them for all nodes at once.
+ *   set_node_index: keys in the host's visiting order (index i = position in `keys`); results are indexed by it.
+ *   update_nodes:   links / linear / deleted of the nodes the host wrote since the last call (l_links, r_flags as
+ *                   in export_nodes).
+ *   tip_walks:      for every node i: end_idx[i] = index of the node the walk from i stops at, ~0 when there is
+ *                   nothing to decide (not a dead end, chain longer than cut_len, deleted, linear; thin != 0:
+ *                   removeSingleTips' rule, only `single` nodes start or continue a walk); info[i] = ch | sm << 2 |
+ *                   thin_stop << 3: the base by which the end node sees the chain, the strand it was reached on,
+ *                   and (thin) whether the walk stopped at a linear node that is not single (:163-166). */
+int sdt_gpu_set_node_index(sdt_ctx *ctx, const uint64_t *keys, uint64_t n);
+int sdt_gpu_update_nodes(sdt_ctx *ctx, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
+int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n);
+
 /* ---- introspection / measurement --------------------------------------------------------------- */
 int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */
 uint64_t sdt_gpu_table_slots(const sdt_ctx *ctx);

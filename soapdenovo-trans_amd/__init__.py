@@ -54,6 +54,9 @@ _ABI = [
     ("sdt_gpu_map_reads", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_arcs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
                                        _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_set_node_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_update_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_tip_walks", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
     ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),
@@ -226,6 +229,26 @@ class PregraphGPU:
         if with_first:
             return keys[:k], l_links[:k], r_flags[:k], count[:k], first[:k]
         return keys[:k], l_links[:k], r_flags[:k], count[:k]
+
+    # -- graph-cleaning dry runs on the device mirror (cutTipPreGraph.c)
+    def set_node_index(self, keys: np.ndarray):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, self.nw)
+        self._nidx = len(keys)
+        self._check(self.lib.sdt_gpu_set_node_index(self._ctx, _ptr(keys), len(keys)))
+
+    def update_nodes(self, keys, l_links, r_flags):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, self.nw)
+        l_links = np.ascontiguousarray(l_links, dtype=np.uint32)
+        r_flags = np.ascontiguousarray(r_flags, dtype=np.uint32)
+        assert len(l_links) == len(keys) == len(r_flags)
+        self._check(self.lib.sdt_gpu_update_nodes(self._ctx, _ptr(keys), _ptr(l_links), _ptr(r_flags), len(keys)))
+
+    def tip_walks(self, thin: bool, cut_len: int):
+        n = self._nidx
+        end = np.zeros(max(n, 1), dtype=np.uint64)
+        info = np.zeros(max(n, 1), dtype=np.uint8)
+        self._check(self.lib.sdt_gpu_tip_walks(self._ctx, int(thin), cut_len, _ptr(end), _ptr(info), n))
+        return end[:n], info[:n]
 
     def set_read_ordinal(self, base: int, stride: int = 1):
         self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))

@@ -36,9 +36,16 @@ typedef struct { int would_write; uint64_t end; } dry_t;
 
 static inline void touch(graph_t *g, const gnode_t *n)
 {
-	if (!g->touched) return;
 	const uint64_t i = (uint64_t)(n - g->nodes);
-	if (g->touched[i]) return;
+	if (g->dirty && !g->dirty[i]) {
+		g->dirty[i] = 1;
+		if (g->dn == g->dcap) {
+			g->dcap = g->dcap ? g->dcap * 2 : 4096;
+			g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
+		}
+		g->dlist[g->dn++] = i;
+	}
+	if (!g->touched || g->touched[i]) return;
 	g->touched[i] = 1;
 	if (g->tn == g->tcap) {
 		g->tcap = g->tcap ? g->tcap * 2 : 4096;
@@ -77,7 +84,7 @@ static uint64_t mark_linear(graph_t *g)
 	for (uint64_t i = 0; i < g->n; i++) {
 		gnode_t *n = &g->nodes[i];
 		if (n->deleted || n->linear) continue;
-		if (one_in_one_out(n)) { n->linear = 1; c++; }
+		if (one_in_one_out(n)) { n->linear = 1; c++; touch(g, n); }
 	}
 	printf("%d thread created for cutTipPreGraph\n", g->p);
 	printf("%llu linear nodes\n", (unsigned long long)c);
@@ -432,6 +439,28 @@ static void spec_tips(void *vc, uint64_t lo, uint64_t hi, int tid)
 	if (cuts) __sync_fetch_and_add(&c->would_cut, cuts);
 }
 
+/* the ordered part of a sweep: `stale[i]` = node i has been written since `walks` were taken */
+static int commit_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, const walk_t *walks,
+                       const uint8_t *stale)
+{
+	int clipped = 0;
+	for (uint64_t i = lo; i < hi; i++) {
+		gnode_t *tip = &g->nodes[i];
+		const walk_t *w = &walks[i];
+		if (i + 64 < hi && walks[i + 64].end != NO_NODE)
+			__builtin_prefetch(&g->nodes[walks[i + 64].end]);                /* the decision reads the end node */
+		if (stale[i]) {
+			clipped += clip_tip(g, tip, cut_len, thin, tips);
+		} else if (w->end != NO_NODE) {
+			if (!w->thin_stop && g->nodes[w->end].linear)
+				clipped += clip_tip(g, tip, cut_len, thin, tips);
+			else
+				clipped += decide_tip(g, tip, w, thin, tips, 0);
+		}
+	}
+	return clipped;
+}
+
 /* One sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips.
  * Dry run: every walk, in parallel, on the graph as the sweep finds it.  Commit, in order:
  *   - a node written since the dry run is visited for real (it may have become a dead end, or stopped being one);
@@ -449,25 +478,47 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 		return 0;                                        /* nothing writes on the untouched graph => the sweep is a no-op */
 	g->touched = marks;                                  /* all zero on entry (calloc / un-marked below) */
 	g->tn = 0;
-	int clipped = 0;
-	for (uint64_t i = lo; i < hi; i++) {
-		gnode_t *tip = &g->nodes[i];
-		const walk_t *w = &c->walks[i];
-		if (i + 64 < hi && c->walks[i + 64].end != NO_NODE)
-			__builtin_prefetch(&g->nodes[c->walks[i + 64].end]);             /* the decision reads the end node */
-		if (marks[i]) {
-			clipped += clip_tip(g, tip, cut_len, thin, tips);
-		} else if (w->end != NO_NODE) {
-			if (!w->thin_stop && g->nodes[w->end].linear)
-				clipped += clip_tip(g, tip, cut_len, thin, tips);
-			else
-				clipped += decide_tip(g, tip, w, thin, tips, 0);
-		}
-	}
+	const int clipped = commit_tips(g, lo, hi, cut_len, thin, tips, c->walks, marks);
 	for (size_t k = 0; k < g->tn; k++) marks[g->tlist[k]] = 0;
 	g->tn = 0;
 	g->touched = NULL;
 	return clipped;
+}
+
+/* The walks of ALL nodes from the device mirror of the graph (sdt_gpu_tip_walks), taken once per pass.  They stay
+ * valid across the sweeps of the pass under the same three rules as above with "since the dry run" read as
+ * "since the device answered" (g->dirty): chains are made of nodes that were linear then and nothing writes a
+ * linear node in these passes (THIN turns a linear non-single node non-linear, but every THIN walk stops there
+ * either way), so no host dry run is needed for any later sweep either. */
+static void unpack_walks(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	walk_t *w = (walk_t *)a[0];
+	const uint64_t *end = (const uint64_t *)a[1];
+	const uint8_t *info = (const uint8_t *)a[2];
+	for (uint64_t i = lo; i < hi; i++) {
+		w[i].end = end[i];
+		w[i].ch = info[i] & 3u;
+		w[i].sm = (info[i] >> 2) & 1u;
+		w[i].thin_stop = (info[i] >> 3) & 1u;
+	}
+}
+
+static void device_walks(graph_t *g, int thin, int cut_len, walk_t *walks)
+{
+	uint64_t *end = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
+	uint8_t *info = (uint8_t *)malloc(g->n + 1);
+	if (g->dev_walks(g, thin, cut_len, end, info) != 0) {
+		printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
+		exit(1);
+	}
+	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the mirror is current as of now */
+	g->dn = 0;
+	void *a[3] = {walks, end, info};
+	par_for(0, g->n, 1 << 16, unpack_walks, a);
+	free(end);
+	free(info);
 }
 
 uint64_t graph_remove_single_tips(graph_t *g)
@@ -476,7 +527,15 @@ uint64_t graph_remove_single_tips(graph_t *g)
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
 	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
 	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
-	sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
+	double t_sub = cut_now_ms();
+	if (g->dev_walks) {
+		device_walks(g, 1, 2 * g->K, c.walks);
+		SUBPHASE("single tips: device walks");
+		commit_tips(g, 0, g->n, 2 * g->K, 1, &tips, c.walks, g->dirty);
+		SUBPHASE("single tips: commit");
+	} else {
+		sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
+	}
 	free(marks);
 	free(c.walks);
 	printf("%llu tips off\n", (unsigned long long)tips);
@@ -490,16 +549,24 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 	printf("Start to remove tips which don't contribute the most links\n");
 	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
 	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
+	double t_sub = cut_now_ms();
+	if (g->dev_walks) {
+		device_walks(g, 0, 2 * g->K, c.walks);
+		SUBPHASE("minor tips: device walks");
+	}
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
 		while (changed)                                /* fixed point PER SET before the next set (:385-408) */
-			changed = sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
+			changed = g->dev_walks ? commit_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, c.walks, g->dirty)
+			                       : sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
 		printf("kmer set %d done\n", s);
 	}
+	SUBPHASE("minor tips: sweeps");
 	free(marks);
 	free(c.walks);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
+	SUBPHASE("minor tips: mark linear");
 	return tips;
 }
 

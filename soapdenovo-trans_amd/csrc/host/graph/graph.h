@@ -30,7 +30,7 @@ typedef struct {
 	uint8_t twin, used;
 } gpatch_t;
 
-typedef struct {
+typedef struct graph_s {
 	int K, nw, p;
 	uint64_t n;
 	gnode_t *nodes;                    /* visiting order */
@@ -43,6 +43,15 @@ typedef struct {
 	uint8_t *touched;                  /* per node, during a cleaning sweep: written since the dry run (cuttip.c) */
 	uint64_t *tlist;                   /* indices marked in `touched` during the current sweep */
 	size_t tn, tcap;
+	/* device dry runs (optional): when dev_walks is set, the tip passes take their walks from it instead of the
+	 * host dry run.  `dirty` lists the nodes written since the device mirror was last brought up to date; the hook
+	 * sends them over, and the commit uses the same marks to tell which recorded walks are still what the
+	 * reference would walk. */
+	uint8_t *dirty;
+	uint64_t *dlist;
+	size_t dn, dcap;
+	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t *end, uint8_t *info);   /* 0 = ok */
+	void *dev_user;
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
 	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */
 } graph_t;

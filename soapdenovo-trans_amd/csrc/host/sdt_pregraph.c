@@ -92,14 +92,51 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
 	return 0;
 }
 
+/* graph.h dev_walks: bring the device mirror up to date with what the host wrote, then take the walks of every
+ * node from it (sdt_gpu_tip_walks) */
+typedef struct { sdt_ctx *gpu; int nwk, indexed; } dev_state;
+
+static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t *end, uint8_t *info)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	const int nwk = D->nwk;
+	if (!D->indexed) {
+		uint64_t *k = (uint64_t *)malloc((g->n + 1) * (size_t)nwk * 8);
+		for (uint64_t i = 0; i < g->n; i++)
+			for (int w = 0; w < nwk; w++) k[i * nwk + w] = g->nodes[i].seq.w[4 - nwk + w];
+		const int rc = sdt_gpu_set_node_index(D->gpu, k, g->n);
+		free(k);
+		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_set_node_index: %s\n", sdt_gpu_last_error()); return 1; }
+		D->indexed = 1;
+	}
+	if (g->dn) {
+		uint64_t *k = (uint64_t *)malloc(g->dn * (size_t)nwk * 8);
+		uint32_t *l = (uint32_t *)malloc(g->dn * 4), *r = (uint32_t *)malloc(g->dn * 4);
+		for (size_t j = 0; j < g->dn; j++) {
+			const gnode_t *nd = &g->nodes[g->dlist[j]];
+			for (int w = 0; w < nwk; w++) k[j * nwk + w] = nd->seq.w[4 - nwk + w];
+			l[j] = nd->l_links;
+			r[j] = nd->r_links | ((uint32_t)nd->linear << 24) | ((uint32_t)nd->deleted << 25);
+		}
+		const int rc = sdt_gpu_update_nodes(D->gpu, k, l, r, g->dn);
+		free(k); free(l); free(r);
+		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_update_nodes: %s\n", sdt_gpu_last_error()); return 1; }
+	}
+	if (sdt_gpu_tip_walks(D->gpu, thin, cut_len, end, info, g->n) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_tip_walks: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", prefix[4096] = "";
-	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0, host_map = 0;
+	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0, host_map = 0, host_walks = 0;
 	int have_s = 0, have_o = 0, c;
 	unsigned long long est = 0;
 	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
-	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003}, {"host-map", no_argument, 0, 1004},
+	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003}, {"host-map", no_argument, 0, 1004}, {"host-walks", no_argument, 0, 1005},
 	                                   {0, 0, 0, 0}};
 	/* accept an optional leading "pregraph" sub-command like the reference's dispatcher (main.c:49-106) */
 	if (argc > 1 && strcmp(argv[1], "pregraph") == 0) { argv++; argc--; }
@@ -120,6 +157,7 @@ int main(int argc, char **argv)
 		case 1002: est = strtoull(optarg, NULL, 10); break;
 		case 1003: hash_only = 1; break;
 		case 1004: host_map = 1; break;
+		case 1005: host_walks = 1; break;
 		default:
 			if (!have_s || !have_o) { usage(max_k ? max_k : SDT_MAX_K); return 255; }
 		}
@@ -193,6 +231,12 @@ int main(int argc, char **argv)
 		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
 		free(keys); free(first); free(ll); free(rf); free(cnt);
 		phase("layout replay + index (host)");
+		dev_state D = {gpu, nwk, 0};
+		if (gpu && !host_walks) {                                          /* tip walks from the device mirror of the graph */
+			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
+			G->dev_walks = dev_walks_hook;
+			G->dev_user = &D;
+		}
 		time_t t0 = time(NULL);
 		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
 		phase("removeMinorOut (host)");
@@ -200,7 +244,7 @@ int main(int argc, char **argv)
 		t0 = time(NULL);
 		if (!d) graph_remove_single_tips(G);                               /* pregraph.c:75-88 */
 		graph_remove_minor_tips(G);
-		phase("tip cutting (host)");
+		phase(G->dev_walks ? "tip cutting (GPU walks + host commit)" : "tip cutting (host)");
 		printf("time spent on cutTipe: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */

@@ -493,6 +493,8 @@ struct sdt_ctx {
 	ArcEnt *d_arcs = nullptr;
 	uint64_t arc_slots = 0;
 	bool paths_loaded = false;
+	uint64_t *d_idx = nullptr;         // slot -> index of the node in the host's visiting order (sdt_gpu_set_node_index)
+	uint64_t idx_slots = 0, idx_n = 0;
 	// timing
 	std::vector<EventPair> ev;
 	size_t ev_used = 0;
@@ -773,6 +775,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
 	if (c->d_patch) (void)hipFree(c->d_patch);
 	if (c->d_arcs) (void)hipFree(c->d_arcs);
+	if (c->d_idx) (void)hipFree(c->d_idx);
 	if (c->pb.hist) (void)hipFree(c->pb.hist);
 	if (c->pb.off2) (void)hipFree(c->pb.off2);
 	if (c->pb.cursor1) (void)hipFree(c->pb.cursor1);
@@ -804,6 +807,9 @@ int sdt_gpu_reset(sdt_ctx *c)
 	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
 	c->kept.clear();
 	c->paths_loaded = false;
+	if (c->d_idx) (void)hipFree(c->d_idx);
+	c->d_idx = nullptr;
+	c->idx_slots = c->idx_n = 0;
 	return SDT_OK;
 }
 
@@ -1411,6 +1417,105 @@ done:
 	if (d_o) (void)hipFree(d_o);
 	if (d_cur) (void)hipFree(d_cur);
 	return ret;
+}
+
+// ---- graph-cleaning dry runs on the device mirror of the host graph ---------------------------------------
+static int upload_keys(sdt_ctx *c, const uint64_t *keys, uint64_t n, uint64_t **d_k)
+{
+	HIPCHK(hipMalloc((void **)d_k, (n ? n : 1) * c->nw * sizeof(uint64_t)));
+	hipError_t e = hipMemcpyAsync(*d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess) { (void)hipFree(*d_k); *d_k = nullptr; return fail(SDT_EHIP, "key upload: %s", hipGetErrorString(e)); }
+	return SDT_OK;
+}
+
+int sdt_gpu_set_node_index(sdt_ctx *c, const uint64_t *keys, uint64_t n)
+{
+	if (!c || (n && !keys))
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->d_idx) HIPCHK(hipFree(c->d_idx));
+	c->d_idx = nullptr;
+	c->idx_slots = c->idx_n = 0;
+	HIPCHK(hipMalloc((void **)&c->d_idx, c->slots * sizeof(uint64_t)));
+	HIPCHK(hipMemsetAsync(c->d_idx, 0xFF, c->slots * sizeof(uint64_t), c->stream));
+	uint64_t *d_k = nullptr;
+	int rc = upload_keys(c, keys, n, &d_k);
+	if (rc != SDT_OK) return rc;
+	const int g = scan_grid(c, n ? n : 1);
+	if (c->nw == 1) hipLaunchKernelGGL(k_set_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, n, c->d_idx, c->d_stats);
+	else if (c->nw == 2) hipLaunchKernelGGL(k_set_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, n, c->d_idx, c->d_stats);
+	else hipLaunchKernelGGL(k_set_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, n, c->d_idx, c->d_stats);
+	hipError_t le = hipGetLastError();
+	rc = le == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "k_set_index: %s", hipGetErrorString(le));
+	(void)hipFree(d_k);
+	if (rc != SDT_OK)
+		return fail(SDT_ESTATE, "sdt_gpu_set_node_index: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
+	c->idx_slots = c->slots;
+	c->idx_n = n;
+	return SDT_OK;
+}
+
+int sdt_gpu_update_nodes(sdt_ctx *c, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n)
+{
+	if (!c || (n && (!keys || !l_links || !r_flags)))
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!n)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *d_k = nullptr;
+	uint32_t *d_l = nullptr, *d_r = nullptr;
+	int rc = upload_keys(c, keys, n, &d_k);
+	if (rc != SDT_OK) return rc;
+	hipError_t e = hipMalloc((void **)&d_l, n * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&d_r, n * 4);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_l, l_links, n * 4, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_r, r_flags, n * 4, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		const int g = scan_grid(c, n);
+		if (c->nw == 1) hipLaunchKernelGGL(k_update_nodes<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_l, d_r, n, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_update_nodes<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_l, d_r, n, c->d_stats);
+		else hipLaunchKernelGGL(k_update_nodes<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_l, d_r, n, c->d_stats);
+		e = hipGetLastError();
+	}
+	rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_update_nodes: %s", hipGetErrorString(e));
+	(void)hipFree(d_k);
+	if (d_l) (void)hipFree(d_l);
+	if (d_r) (void)hipFree(d_r);
+	if (rc != SDT_OK && e == hipSuccess)
+		return fail(SDT_ESTATE, "sdt_gpu_update_nodes: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
+	return rc;
+}
+
+int sdt_gpu_tip_walks(sdt_ctx *c, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n)
+{
+	if (!c || !end_idx || !info)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_idx || c->idx_slots != c->slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if (n != c->idx_n)
+		return fail(SDT_EINVAL, "the node index holds %llu nodes, the output arrays %llu", (unsigned long long)c->idx_n, (unsigned long long)n);
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *d_e = nullptr;
+	uint8_t *d_i = nullptr;
+	HIPCHK(hipMalloc((void **)&d_e, (n ? n : 1) * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_i, n ? n : 1);
+	if (e == hipSuccess) {
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
+		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(end_idx, d_e, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(info, d_i, n, hipMemcpyDeviceToHost, c->stream);
+	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks: %s", hipGetErrorString(e));
+	(void)hipFree(d_e);
+	if (d_i) (void)hipFree(d_i);
+	if (rc != SDT_OK && e == hipSuccess)
+		return fail(SDT_ESTATE, "sdt_gpu_tip_walks: %llu walks left the graph (a link points at a k-mer that is not a node)",
+		            (unsigned long long)c->h_stats->probe_fail);
+	return rc;
 }
 
 int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)

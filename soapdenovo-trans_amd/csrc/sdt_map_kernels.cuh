@@ -258,3 +258,170 @@ __global__ __launch_bounds__(TPB) void k_export_arcs(const ArcEnt *__restrict__ 
 		first[pos] = e.first;
 	}
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Graph-cleaning dry runs on the device (cutTipPreGraph.c).  The host owns the ORDER (layout replay, ordered commit
+// of the few visits that write); what it needs from a sweep is the read-only part -- the walks -- and those are
+// table look-ups, which this chip does at tens of G/s.  The device table mirrors the host graph: the host sends
+// back the nodes it wrote (k_update_nodes) -- the nodes its own
+// Mark1in1outNode marked included -- and the index each node has in its visiting order (k_set_index).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW> __device__ inline bool find_slot(const Table<NW> &tbl, const Key<NW> &k, uint64_t &slot_out)
+{
+	uint64_t slot = key_hash<NW>(k) & tbl.mask;
+	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
+		const Entry<NW> *e = tbl.ent + slot;
+		if (e->key[0] == KEY_EMPTY)
+			return false;
+		bool same = true;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			same = same && e->key[w] == k.w[w];
+		if (same) {
+			slot_out = slot;
+			return true;
+		}
+	}
+	return false;
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_set_index(Table<NW> tbl, const uint64_t *__restrict__ keys, uint64_t n,
+                                                   uint64_t *__restrict__ idx, Stats *stats)
+{
+	uint32_t failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> k;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			k.w[w] = keys[i * NW + w];
+		uint64_t slot;
+		if (find_slot<NW>(tbl, k, slot)) idx[slot] = i;
+		else failed++;
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+// links + flags of the given nodes as the host has them now (count is never changed by the cleaning passes)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_update_nodes(Table<NW> tbl, const uint64_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ l_links, const uint32_t *__restrict__ r_flags,
+                                                      uint64_t n, Stats *stats)
+{
+	uint32_t failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> k;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			k.w[w] = keys[i * NW + w];
+		uint64_t slot;
+		if (!find_slot<NW>(tbl, k, slot)) { failed++; continue; }
+		const uint64_t v = tbl.ent[slot].val;
+		tbl.ent[slot].val = (v & 0xFFFF000000000000ULL) | ((uint64_t)(r_flags[i] & 0xFFFFFFu) << 24) | (uint64_t)(l_links[i] & 0xFFFFFFu);
+		const uint32_t a = tbl.aux[slot] & 0xFFFFu;
+		tbl.aux[slot] = a | ((r_flags[i] >> 24 & 1u) ? AUX_LINEAR : 0u) | ((r_flags[i] >> 25 & 1u) ? AUX_DELETED : 0u);
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+__device__ inline uint32_t dev_degree(uint64_t links24)
+{
+	uint32_t d = 0;
+#pragma unroll
+	for (int b = 0; b < 4; b++)
+		d += ((links24 >> (6 * b)) & 63u) != 0;
+	return d;
+}
+__device__ inline uint32_t first_link(uint64_t links24)
+{
+	uint32_t b = 0;
+	while (b < 4 && ((links24 >> (6 * b)) & 63u) == 0) b++;
+	return b;
+}
+
+template <int NW> __device__ inline Key<NW> key_next_masked(const Key<NW> &k, uint32_t b, const Key<NW> &mask)
+{
+	Key<NW> r = key_append<NW>(k, b);
+#pragma unroll
+	for (int i = 0; i < NW; i++)
+		r.w[i] &= mask.w[i];
+	return r;
+}
+
+// the walk of clipTipFromNode (cutTipPreGraph.c:43-281) from every node, read-only.  Output, at the HOST index of
+// the node: end = host index of the node the walk stopped at (~0 = nothing to decide), info = ch | sm << 2 |
+// thin_stop << 3 (the base by which the end node sees the chain, the strand on which it was reached).
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
+                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		const uint64_t me = idx[s];
+		end_out[me] = ~0ULL;
+		info_out[me] = 0;
+		const uint32_t a = tbl.aux[s];
+		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
+		const bool single = (e.val >> 48) == 1 && (a & 0xFFFFu) == 0;
+		if (thin && !single) continue;
+		const uint64_t ll = e.val & 0xFFFFFFu, rl = (e.val >> 24) & 0xFFFFFFu;
+		const uint32_t in = dev_degree(ll), out = dev_degree(rl);
+		Key<NW> at;
+#pragma unroll
+		for (int w = 0; w < NW; w++) at.w[w] = e.key[w];
+		uint32_t b;
+		if (in == 0 && out == 1) {
+			b = first_link(rl);
+		} else if (in == 1 && out == 0) {
+			at = key_revcomp<NW>(at, K);
+			b = first_link(ll) ^ 2u;
+		} else {
+			continue;
+		}
+		int steps = 1;
+		uint32_t thin_stop = 0;
+		bool give_up = false;
+		Key<NW> step = key_next_masked<NW>(at, b, mask);
+		Key<NW> bal = key_revcomp<NW>(step, K);
+		bool sm = !key_less<NW>(bal, step);               // KmerLarger(word, bal) -> take bal, smaller = 0
+		uint64_t os;
+		if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; continue; }
+		for (;;) {
+			const uint32_t oa = tbl.aux[os];
+			if (!(oa & AUX_LINEAR)) break;
+			steps++;
+			const uint64_t ov = tbl.ent[os].val;
+			if (thin && !((ov >> 48) == 1 && (oa & 0xFFFFu) == 0)) { thin_stop = 1; break; }
+			if (steps > cut_len) { give_up = true; break; }
+			at = step;
+			b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+			step = key_next_masked<NW>(at, b, mask);
+			bal = key_revcomp<NW>(step, K);
+			sm = !key_less<NW>(bal, step);
+			if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; give_up = true; break; }
+		}
+		if (give_up) continue;
+		// first base of `at`: bits 2(K-1)..2(K-1)+1 of the NW-word value
+		const int tb = 2 * (K - 1);
+		uint32_t ch = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			if (w == NW - 1 - (tb >> 6)) ch = (uint32_t)(at.w[w] >> (tb & 63)) & 3u;
+		end_out[me] = idx[os];
+		info_out[me] = (uint8_t)(ch | ((uint32_t)sm << 2) | (thin_stop << 3));
+	}
+	if (missing)
+		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}

@@ -343,3 +343,133 @@ def test_owner_filter_shards_add_up(pkg, synth, K, nranks):
             tot_k += k; tot_n += n; tot_l += lin
             hist += h
     assert (tot_k, tot_n) == want and tot_l == wlin and (hist == whist).all() and seen == wkeys
+
+
+# ---- graph-cleaning dry runs on the device mirror (sdt_gpu_set_node_index / update_nodes / tip_walks) --------
+def _rc_int(v, K):
+    out = 0
+    for _ in range(K):
+        out = (out << 2) | ((v & 3) ^ 2)
+        v >>= 2
+    return out
+
+
+def _first_link(links24):
+    for b in range(4):
+        if (links24 >> (6 * b)) & 63:
+            return b
+    return 4
+
+
+def _deg(links24):
+    return sum(1 for b in range(4) if (links24 >> (6 * b)) & 63)
+
+
+def py_tip_walks(keys_int, l, rf, cnt, K, thin, cut_len):
+    """the walk of clipTipFromNode (cutTipPreGraph.c:43-281), restated on Python ints: for every node, the index
+    of the node the walk stops at (or None), ch, sm, thin_stop"""
+    idx = {k: i for i, k in enumerate(keys_int)}
+    mask = (1 << (2 * K)) - 1
+    lin = [(int(x) >> 24) & 1 for x in rf]
+    dele = [(int(x) >> 25) & 1 for x in rf]
+    single = [int(c) == 1 for c in cnt]
+    out = []
+    for i, k in enumerate(keys_int):
+        if lin[i] or dele[i] or (thin and not single[i]):
+            out.append(None)
+            continue
+        ll, rl = int(l[i]) & 0xFFFFFF, int(rf[i]) & 0xFFFFFF
+        if _deg(ll) == 0 and _deg(rl) == 1:
+            at, b = k, _first_link(rl)
+        elif _deg(ll) == 1 and _deg(rl) == 0:
+            at, b = _rc_int(k, K), _first_link(ll) ^ 2
+        else:
+            out.append(None)
+            continue
+        steps, thin_stop, dead = 1, 0, False
+        while True:
+            step = ((at << 2) | b) & mask
+            bal = _rc_int(step, K)
+            sm = 0 if step > bal else 1
+            o = idx[step if sm else bal]
+            if not lin[o]:
+                break
+            steps += 1
+            if thin and not single[o]:
+                thin_stop = 1
+                break
+            if steps > cut_len:
+                dead = True
+                break
+            at = step
+            b = _first_link(int(rf[o]) & 0xFFFFFF) if sm else (_first_link(int(l[o]) & 0xFFFFFF) ^ 2)
+        out.append(None if dead else (o, (at >> (2 * (K - 1))) & 3, sm, thin_stop))
+    return out
+
+
+@pytest.mark.parametrize("K,L", [(21, 100), (31, 100), (41, 150), (63, 150), (75, 200), (127, 250)])
+def test_tip_walks_equal_reference_walk(pkg, synth, K, L):
+    """the device dry run of removeSingleTips / removeMinorTips: every node's walk == the restated walk, on the
+    table as counted and again after the host 'writes' nodes (update_nodes: deletions, cleared linear flags,
+    dropped links on junctions) -- results indexed by an arbitrary host order"""
+    tx = synth.make_transcriptome(20, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=3000, read_len=L, seed=K + 3, err=0.004, ragged=True)
+    rng = np.random.default_rng(K)
+    with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        perm = rng.permutation(len(keys))
+        keys, l, rf, cnt = keys[perm], l[perm].copy(), rf[perm].copy(), cnt[perm]
+        ki = keys_to_int(keys)
+        g.set_node_index(keys)
+        for round_ in range(2):
+            for thin in (0, 1):
+                end, info = g.tip_walks(bool(thin), 2 * K)
+                want = py_tip_walks(ki, l, rf, cnt, K, thin, 2 * K)
+                n_walks = 0
+                for i, w in enumerate(want):
+                    if w is None:
+                        assert end[i] == np.uint64(0xFFFFFFFFFFFFFFFF), (i, thin)
+                    else:
+                        n_walks += 1
+                        assert (int(end[i]), int(info[i])) == (w[0], w[1] | (w[2] << 2) | (w[3] << 3)), (i, thin, w)
+                assert n_walks > 0 or thin
+            # short chains are cut off by cut_len
+            end_short, _ = g.tip_walks(False, 3)
+            want = py_tip_walks(ki, l, rf, cnt, K, 0, 3)
+            assert [None if e == np.uint64(0xFFFFFFFFFFFFFFFF) else int(e) for e in end_short] == [None if w is None else w[0] for w in want]
+            if round_ == 0:
+                # the host writes: delete some nodes, un-linear some chain nodes, drop one link of some junctions
+                pick = rng.choice(len(keys), size=len(keys) // 20, replace=False)
+                rf[pick[: len(pick) // 3]] |= np.uint32(1 << 25)
+                mid = pick[len(pick) // 3: 2 * len(pick) // 3]
+                rf[mid] &= np.uint32(~(1 << 24) & 0xFFFFFFFF)
+                for j in pick[2 * len(pick) // 3:]:
+                    if not (int(rf[j]) >> 24) & 1:
+                        b = _first_link(int(l[j]) & 0xFFFFFF)
+                        if b < 4:
+                            l[j] &= np.uint32(~(63 << (6 * b)) & 0xFFFFFFFF)
+                g.update_nodes(keys[pick], l[pick], rf[pick])
+        # the mirror now equals what we sent: export agrees (flags and links), counts untouched
+        k2, l2, rf2, c2 = g.export_nodes()
+        got = {k: (int(a), int(b) & 0x3FFFFFF, int(c)) for k, a, b, c in zip(keys_to_int(k2), l2, rf2, c2)}
+        assert got == {k: (int(a), int(b) & 0x3FFFFFF, int(c)) for k, a, b, c in zip(ki, l, rf, cnt)}
+
+
+def test_tip_walks_need_an_index(pkg, synth):
+    tx = synth.make_transcriptome(3, seed=1)
+    codes, offs = synth.sample_reads(*tx, n_reads=200, read_len=80, seed=2)
+    with pkg.PregraphGPU(25, est_distinct=1 << 12) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g._nidx = 5
+        with pytest.raises(pkg.SdtError):
+            g.tip_walks(False, 50)
+        keys, l, rf, cnt = g.export_nodes()
+        bogus = keys.copy()
+        bogus[0, -1] ^= np.uint64(1)                     # almost surely not a node
+        if keys_to_int(bogus[:1])[0] not in set(keys_to_int(keys)):
+            with pytest.raises(pkg.SdtError):
+                g.set_node_index(bogus)

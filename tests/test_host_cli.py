@@ -72,11 +72,12 @@ def test_config_parser(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("second_pass", ["gpu", "host"])
+@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks"])
 @pytest.mark.parametrize("name", gu.case_names())
 def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     """sdt-pregraph end to end: all five files of the reference's pregraph, byte for byte, with the second read
-    pass (prlRead2edge) on the GPU over the reads kept in HBM (default) or on the host (--host-map)"""
+    pass (prlRead2edge) on the GPU over the reads kept in HBM (default) or on the host (--host-map), and with the
+    tip-cutting dry runs on the device (default) or on the host (--host-walks, and always with --host-map)"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
@@ -85,6 +86,8 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
         cmd += ["-d", str(info["d"])]
     if second_pass == "host":
         cmd += ["--host-map"]
+    if second_pass == "host-walks":      # default: the tip walks come from the device mirror of the graph
+        cmd += ["--host-walks"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")

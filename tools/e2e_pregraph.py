@@ -28,6 +28,7 @@ ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
+ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 args = ap.parse_args()
 
 tmp = tempfile.mkdtemp(prefix="sdt_e2e_")
@@ -69,6 +70,16 @@ try:
     r2 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
                          os.path.join(tmp, "ours_hash"), "--hash-only"], capture_output=True, text=True)
     res["ours_hash_only_wall_s"] = round(time.time() - t0, 2)
+    if args.compare_host_walks:
+        t0 = time.time()
+        r3 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                             os.path.join(tmp, "hw"), "--host-walks"], capture_output=True, text=True, timeout=args.timeout)
+        res["ours_host_walks_wall_s"] = round(time.time() - t0, 2)
+        res["host_walks_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r3.stderr.splitlines() if l.startswith("[sdt-pregraph]")]
+        res["same_as_host_walks"] = {ext: open(os.path.join(tmp, "ours." + ext), "rb").read() == open(os.path.join(tmp, "hw." + ext), "rb").read()
+                                     for ext in ("kmerFreq", "vertex", "preGraphBasic", "preArc", "edge.gz")}
+        strip = lambda t: [l for l in t.splitlines() if not l.startswith("time spent")]
+        res["same_stdout_as_host_walks"] = strip(r.stdout) == strip(r3.stdout)
     if not args.skip_ref:
         ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-Trans-{31 if args.K <= 31 else 127}mer")
         t0 = time.time()
