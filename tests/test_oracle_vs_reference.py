@@ -194,3 +194,23 @@ def test_chop_matches_definition():
                 got = (got << 64) | int(x)
             assert got == key and p[j] == pv and q[j] == nx
             assert h[j] == L.sdto_hash_kmer(ob.Kmer.of(keys[j]), nw)
+
+
+# ---- `map` stage: oracle/sdt_oracle_map.c vs the reference's own `map` output ------------
+import map_util as mu  # noqa: E402
+
+
+@pytest.mark.parametrize("name", mu.case_names())
+def test_map_oracle_matches_reference_files(tmp_path, name):
+    """prlContig2nodes + prlRead2Ctg restated: node / k-mer counters of the contig index and every byte of
+    *.readOnContig, *.ctg2Read, *.readInGap (incl. the stale bits of the shared tight-string buffer) and
+    *.readInformation (-r) as the reference binary wrote them"""
+    info = mu.load_case(name)
+    o = mu.build_oracle(info)
+    assert o.counts() == (info["nodes_allocated"], info["kmer_in_contigs"])
+    codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
+    counters = o.run(codes, offs, lib_of, [l["avg_ins"] for l in libs], [l["map_len"] for l in libs], max_rd_len, info["p"],
+                     tmp_path / "o", trace=bool(info.get("trace")))
+    assert counters[:3] == [info["reads"], info["reads_mapped"], info["reads_in_gap"]] and counters[3] == 0
+    for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []):
+        assert open(str(tmp_path / "o") + "." + ext, "rb").read() == mu.gz_bytes(info, ext), ext
