@@ -53,6 +53,8 @@ typedef struct sdt_ctx sdt_ctx;
 /* Keep every pushed batch of packed reads resident in HBM so that the second pass over the reads
  * (prlRead2edge, sdt_gpu_map_reads) needs no re-parse: 0.25 B/base, 7.5 GB for 200 M x 150 bp. */
 #define SDT_FLAG_KEEP_READS 8u
+/* map stage: the table indexes the k-mers of the contigs (sdt_gpu_index_contigs; implies TRACK_FIRST) */
+#define SDT_FLAG_CONTIG_INDEX 16u
 
 /* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
  * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
@@ -172,6 +174,42 @@ int sdt_gpu_export_arcs(sdt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *mu
 int sdt_gpu_set_node_index(sdt_ctx *ctx, const uint64_t *keys, uint64_t n);
 int sdt_gpu_update_nodes(sdt_ctx *ctx, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
 int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n);
+
+/* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
+ * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:
+ *   index_contigs: contigs packed like reads (2 bit / base, offsets in bases, 4 pad words), ids[i] = the id the
+ *                  reference takes from the record name (getID, prlHashCtg.c:276-285) -- the caller has applied
+ *                  the length cut (:343-350).  May be called repeatedly; contig order = call order, array order.
+ *                  The first occurrence of a k-mer (contig order, then position) owns contig id / position /
+ *                  strand, every further one marks it deleted (singleKmer :110-139).
+ *                  sdt_gpu_finish_count then reports "kmer in reads" and "nodes allocated" (:397).
+ *   set_contig_table: contig_array[0..num_ctg] of basicContigInfo (prlRead2Ctg.c:610-648): length, and
+ *                  twin[i] = getTwinCtg(i) (attachPEinfo.c:479-482).
+ *   align_reads:   chopKmer4read + searchKmer + parse1read (prlRead2Ctg.c:129-353) for a batch of reads.
+ *                  align_len: per-read ALIGNLEN (the value of the global when the read's batch is parsed,
+ *                  :774-791), or NULL and align_len_all for every read.
+ *                  read_info[r] = hit_start (40 bits) | nhits << 40 | best << 48 | footprint << 56 | overflow << 57;
+ *                  nhits = count_Contig (0: ctgIdArray[t] = 0), hits[hit_start .. +nhits) = ctg2read[t][..] in the
+ *                  reference's order, best = index of the hit that sets ctgIdArray / posArray / orienArray
+ *                  (posArray = contig_offset - read_offset + 1), overflow: more than 20 candidate contigs -- the
+ *                  reference overruns pos_temp[20] there; such a read is reported unmapped.
+ *                  SDT_EFULL when hits[] is too small: *nhits says how many the batch needs.
+ *   align_reads_device: the same on buffers already in device memory (outputs too). */
+typedef struct {
+	uint32_t contig;             /* READSET.contigID */
+	int32_t contig_offset;       /* READSET.contigOffset */
+	uint32_t read_offset;        /* READSET.readOffset (1-based k-mer index) */
+	uint32_t align_len_orien;    /* READSET.alignLength | (orien == '-' ? 1u << 31 : 0) */
+} sdt_hit;
+int sdt_gpu_index_contigs(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
+                          const uint32_t *ids, uint64_t ncontigs);
+int sdt_gpu_set_contig_table(sdt_ctx *ctx, const uint32_t *length, const uint32_t *twin, uint64_t num_ctg);
+int sdt_gpu_align_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
+                        uint64_t nreads, const int32_t *align_len, int align_len_all, uint64_t *read_info,
+                        sdt_hit *hits, uint64_t max_hits, uint64_t *nhits);
+int sdt_gpu_align_reads_device(sdt_ctx *ctx, const void *d_packed_words, const void *d_offsets, uint64_t nreads,
+                               uint64_t max_read_len, const void *d_align_len, int align_len_all, void *d_read_info,
+                               void *d_hits, uint64_t max_hits, uint64_t *nhits);
 
 /* ---- introspection / measurement --------------------------------------------------------------- */
 int sdt_gpu_key_words(const sdt_ctx *ctx);         /* 1 (K<=31), 2 (K<=63), 4 (K<=127) */

@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
-SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST, SDT_FLAG_KEEP_READS = 1, 2, 4, 8
+SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST, SDT_FLAG_KEEP_READS, SDT_FLAG_CONTIG_INDEX = 1, 2, 4, 8, 16
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
@@ -57,6 +57,12 @@ _ABI = [
     ("sdt_gpu_set_node_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_update_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_tip_walks", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_set_contig_table", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_align_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_int,
+                                       _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_align_reads_device", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_void_p,
+                                              _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_key_words", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_table_slots", _c.c_uint64, [_c.c_void_p]),
     ("sdt_gpu_stream", _c.c_void_p, [_c.c_void_p]),
@@ -249,6 +255,42 @@ class PregraphGPU:
         info = np.zeros(max(n, 1), dtype=np.uint8)
         self._check(self.lib.sdt_gpu_tip_walks(self._ctx, int(thin), cut_len, _ptr(end), _ptr(info), n))
         return end[:n], info[:n]
+
+    # -- map stage (prlContig2nodes / prlRead2Ctg); the context must be created with FLAG_CONTIG_INDEX
+    def index_contigs(self, packed_words: np.ndarray, offsets: np.ndarray, ids: np.ndarray):
+        packed_words = np.ascontiguousarray(packed_words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert len(ids) == len(offsets) - 1
+        self._check(self.lib.sdt_gpu_index_contigs(self._ctx, _ptr(packed_words), packed_words.size, _ptr(offsets),
+                                                   _ptr(ids), len(ids)))
+
+    def set_contig_table(self, length: np.ndarray, twin: np.ndarray):
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        twin = np.ascontiguousarray(twin, dtype=np.uint32)
+        assert len(length) == len(twin)
+        self._check(self.lib.sdt_gpu_set_contig_table(self._ctx, _ptr(length), _ptr(twin), len(length) - 1))
+
+    def align_reads(self, packed_words, offsets, align_len=None, align_len_all: int = 0, max_hits=None):
+        """-> (read_info uint64[nreads], hits uint32[nhits, 4]); see include/sdt_gpu.h for the bit layout"""
+        packed_words = np.ascontiguousarray(packed_words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if align_len is not None:
+            align_len = np.ascontiguousarray(align_len, dtype=np.int32)
+            assert len(align_len) == n
+        info = np.zeros(max(n, 1), dtype=np.uint64)
+        cap = max_hits if max_hits is not None else 2 * n + 16
+        while True:
+            hits = np.zeros((max(cap, 1), 4), dtype=np.uint32)
+            got = ctypes.c_uint64()
+            rc = self.lib.sdt_gpu_align_reads(self._ctx, _ptr(packed_words), packed_words.size, _ptr(offsets), n,
+                                              _ptr(align_len), align_len_all, _ptr(info), _ptr(hits), cap, ctypes.byref(got))
+            if rc == SDT_EFULL and max_hits is None and got.value > cap:      # SDT_EFULL: the hit array was too small
+                cap = got.value
+                continue
+            self._check(rc)
+            return info[:n], hits[: got.value]
 
     def set_read_ordinal(self, base: int, stride: int = 1):
         self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))

@@ -473,3 +473,125 @@ def test_tip_walks_need_an_index(pkg, synth):
         if keys_to_int(bogus[:1])[0] not in set(keys_to_int(keys)):
             with pytest.raises(pkg.SdtError):
                 g.set_node_index(bogus)
+
+
+# ---- map stage: sdt_gpu_index_contigs / set_contig_table / align_reads vs oracle/sdt_oracle_map.c --------------
+import map_util as mu  # noqa: E402
+
+
+def _contig_table(num_all, lens, bals):
+    """contig_array of basicContigInfo (prlRead2Ctg.c:610-648) -> (length[0..num], twin[0..num])"""
+    length = np.zeros(num_all + 1, dtype=np.uint32)
+    twin = np.zeros(num_all + 1, dtype=np.uint32)
+    k = 0
+    for ln, b in zip(lens, bals):
+        k += 1
+        length[k], twin[k] = ln, k + (int(b) + 1) - 1
+        if b == 0:
+            continue
+        k += 1
+        length[k], twin[k] = ln, k + (-int(b) + 1) - 1
+    return length, twin
+
+
+def _index_case(pkg, synth, info, g):
+    K, ctgs, num_all, lens, bals = mu.case_contigs(info)
+    offs = np.zeros(len(ctgs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(c) for _, c in ctgs])
+    codes = np.concatenate([c for _, c in ctgs])
+    half = len(ctgs) // 2                                   # two calls: the contig ordinal carries over
+    cut = int(offs[half])
+    g.index_contigs(synth.pack_2bit(codes[:cut]), offs[: half + 1], [i for i, _ in ctgs[:half]])
+    g.index_contigs(synth.pack_2bit(codes[cut:]), offs[half:] - offs[half], [i for i, _ in ctgs[half:]])
+    g.set_contig_table(*_contig_table(num_all, lens, bals))
+    return K
+
+
+@pytest.mark.parametrize("name", mu.case_names())
+def test_map_stage_equals_oracle(pkg, synth, name):
+    """contig index counters and, for every read of the case, parse1read's result: hits in order (contig, offset,
+    read offset, k-mers, strand), the best hit, the footprint flag -- for ALIGNLEN as the case's libraries set it and
+    for a short one (more, smaller hits)"""
+    info = mu.load_case(name)
+    o = mu.build_oracle(info)
+    K = o.K
+    codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
+    with pkg.PregraphGPU(K, est_distinct=1 << 12, flags=pkg.SDT_FLAG_CONTIG_INDEX) as g:     # small table: grows while indexing
+        assert _index_case(pkg, synth, info, g) == K
+        kmers, nodes = g.finish_count()
+        assert (nodes, kmers) == o.counts() == (info["nodes_allocated"], info["kmer_in_contigs"])
+        words = synth.pack_2bit(codes)
+        rng = np.random.default_rng(3)
+        per_read = rng.integers(K, 80, size=len(offs) - 1).astype(np.int32)
+        for mode in ("all", "per_read"):
+            if mode == "all":
+                info_w, hits = g.align_reads(words, offs, align_len_all=32)
+                al = np.full(len(offs) - 1, 32, dtype=np.int32)
+            else:
+                info_w, hits = g.align_reads(words, offs, align_len=per_read)
+                al = per_read
+            mapped = 0
+            for r in range(len(offs) - 1):
+                n, want, best, foot = o.map_read(codes[int(offs[r]):int(offs[r + 1])], int(al[r]))
+                w = int(info_w[r])
+                start, nh, b, f, ov = w & ((1 << 40) - 1), (w >> 40) & 255, (w >> 48) & 255, (w >> 56) & 1, (w >> 57) & 1
+                assert ov == 0 and n >= 0
+                assert nh == n, (r, mode)
+                if n == 0:
+                    assert w == 0
+                    continue
+                mapped += 1
+                got = [(int(h[0]), int(np.int32(h[1])), int(h[2]), int(h[3]) & 0x7FFFFFFF, "-" if int(h[3]) >> 31 else "+")
+                       for h in hits[start:start + nh]]
+                assert got == want, (r, mode)
+                assert (b, f) == (best, foot), (r, mode)
+            assert mapped > 0
+
+
+def test_map_stage_edge_cases(pkg, synth):
+    """repeated k-mers across contigs are 'deleted' (never hit), reads shorter than K+1, more than 20 candidate
+    contigs (undefined upstream: flagged), hit array too small -> SDT_EFULL with the needed size"""
+    K = 21
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, size=40).astype(np.uint8)
+    ctgs = [rng.integers(0, 4, size=300).astype(np.uint8) for _ in range(30)]
+    ctgs[3][100:140] = unit                       # the same 40 bases in two contigs: their 20 k-mers are deleted
+    ctgs[7][10:50] = unit
+    ids = np.arange(1, 31, dtype=np.uint32)
+    o = mu.MapOracle(K, 4, 1)
+    lens = np.full(30, 300, dtype=np.uint32)
+    bals = np.zeros(30, dtype=np.int32)           # palindromic flag: every contig is its own twin
+    o.set_contig_index(lens, bals, 30)
+    for i, c in zip(ids, ctgs):
+        o.add_contig(c, int(i))
+    offs = np.arange(0, 31 * 300, 300, dtype=np.uint64)
+    with pkg.PregraphGPU(K, est_distinct=1 << 14, flags=pkg.SDT_FLAG_CONTIG_INDEX) as g:
+        g.index_contigs(synth.pack_2bit(np.concatenate(ctgs)), offs, ids)
+        length = np.concatenate([[0], lens]).astype(np.uint32)
+        g.set_contig_table(length, np.arange(31, dtype=np.uint32))
+        kmers, nodes = g.finish_count()
+        assert (nodes, kmers) == o.counts()
+        reads = [unit.copy(),                                         # only deleted k-mers -> unmapped
+                 ctgs[3][90:150].copy(),                              # flanks map, the repeat does not count
+                 ctgs[5][:K].copy(),                                  # shorter than K+1
+                 np.concatenate([c[50:50 + K + 4] for c in ctgs[8:30]]),   # 22 contigs x 5 k-mers: > 20 candidates
+                 (ctgs[9][200:280][::-1] ^ 2).astype(np.uint8)]       # reverse strand
+        roffs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        roffs[1:] = np.cumsum([len(r) for r in reads])
+        rcodes = np.concatenate(reads)
+        info_w, hits = g.align_reads(synth.pack_2bit(rcodes), roffs, align_len_all=K + 4)
+        want = [o.map_read(r, K + 4) for r in reads]
+        assert [w[0] for w in want] == [0, 1, 0, -1, 1]
+        assert int(info_w[0]) == 0 and int(info_w[2]) == 0
+        assert (int(info_w[3]) >> 57) & 1 == 1 and (int(info_w[3]) >> 40) & 255 == 0
+        for r in (1, 4):
+            w = int(info_w[r])
+            h = hits[w & ((1 << 40) - 1)]
+            assert [(int(h[0]), int(np.int32(h[1])), int(h[2]), int(h[3]) & 0x7FFFFFFF, "-" if int(h[3]) >> 31 else "+")] == want[r][1]
+        assert want[4][1][0][4] == "-"
+        with pytest.raises(pkg.SdtError) as ei:
+            g.align_reads(synth.pack_2bit(rcodes), roffs, align_len_all=K + 4, max_hits=1)
+        assert ei.value.code == pkg.SDT_EFULL
+    with pkg.PregraphGPU(K, est_distinct=1 << 12) as g2:             # not a contig-index context
+        with pytest.raises(pkg.SdtError):
+            g2.index_contigs(synth.pack_2bit(ctgs[0]), np.array([0, 300], dtype=np.uint64), ids[:1])
