@@ -201,3 +201,36 @@ def test_reference_contig_runs_unchanged_on_our_pregraph_output(pkg, tmp_path, n
     for ext in ("contig", "updated.edge", "Arc", "ContigIndex"):
         assert open(ours / f"out.{ext}").read() == open(theirs / f"out.{ext}").read(), ext
     assert os.path.getsize(ours / "out.contig") > 0
+
+
+# ---- sdt-map: the reference's `map` command line ---------------------------------------------
+import map_util as mu  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", mu.case_names())
+def test_sdt_map_files_bit_identical(pkg, tmp_path, name):
+    """sdt-map -s cfg -g out [-r]: *.readOnContig, *.ctg2Read, *.readInGap, *.peGrads (and *.readInformation) byte
+    for byte what the reference's map wrote for the same contigs and reads; same stdout counters"""
+    info = mu.load_case(name)
+    cfg = mu.materialise(info, tmp_path)
+    cmd = [bin_path(pkg, "sdt-map"), "map", "-s", cfg, "-g", str(tmp_path / "out"), "-p", str(info["p"])]
+    if info.get("trace"):
+        cmd.append("-r")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for ext in ["readOnContig", "ctg2Read", "readInGap", "peGrads"] + (["readInformation"] if info.get("trace") else []):
+        assert open(str(tmp_path / "out") + "." + ext, "rb").read() == mu.gz_bytes(info, ext), ext
+    strip = lambda t: [l for l in t.splitlines() if "time spent" not in l and str(tmp_path) not in l and "overall time" not in l
+                       and not l.startswith("Version")]
+    golden = [l for l in open(os.path.join(info["dir"], "stdout.log")).read().splitlines() if not l.startswith("Version")]
+    assert [l for l in strip(r.stdout) if l.strip()] == [l for l in golden if l.strip()]
+
+
+@pytest.mark.gpu
+def test_sdt_map_usage_and_errors(pkg, tmp_path):
+    exe = bin_path(pkg, "sdt-map")
+    r = subprocess.run([exe, "map"], capture_output=True, text=True)
+    assert r.returncode != 0 and "map -s configFile -g inputGraph" in r.stdout
+    r = subprocess.run([exe, "map", "-s", str(tmp_path / "x.cfg"), "-g", str(tmp_path / "nothing")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Cannot open" in r.stdout
