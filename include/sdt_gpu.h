@@ -182,18 +182,21 @@ int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, ui
  *                  the length cut (:343-350).  May be called repeatedly; contig order = call order, array order.
  *                  The first occurrence of a k-mer (contig order, then position) owns contig id / position /
  *                  strand, every further one marks it deleted (singleKmer :110-139).
- *                  sdt_gpu_finish_count then reports "kmer in reads" and "nodes allocated" (:397).
+ *                  sdt_gpu_finish_count then reports "kmer in reads" and "nodes allocated" (:397).  The first
+ *                  align call freezes the index (nodes are rewritten into their look-up form): SDT_ESTATE after.
  *   set_contig_table: contig_array[0..num_ctg] of basicContigInfo (prlRead2Ctg.c:610-648): length, and
  *                  twin[i] = getTwinCtg(i) (attachPEinfo.c:479-482).
  *   align_reads:   chopKmer4read + searchKmer + parse1read (prlRead2Ctg.c:129-353) for a batch of reads.
  *                  align_len: per-read ALIGNLEN (the value of the global when the read's batch is parsed,
  *                  :774-791), or NULL and align_len_all for every read.
- *                  read_info[r] = hit_start (40 bits) | nhits << 40 | best << 48 | footprint << 56 | overflow << 57;
- *                  nhits = count_Contig (0: ctgIdArray[t] = 0), hits[hit_start .. +nhits) = ctg2read[t][..] in the
- *                  reference's order, best = index of the hit that sets ctgIdArray / posArray / orienArray
- *                  (posArray = contig_offset - read_offset + 1), overflow: more than 20 candidate contigs -- the
- *                  reference overruns pos_temp[20] there; such a read is reported unmapped.
- *                  SDT_EFULL when hits[] is too small: *nhits says how many the batch needs.
+ *                  read_info[r] = more_start (40 bits) | nhits << 40 | best << 48 | footprint << 56 | overflow << 57;
+ *                  nhits = count_Contig (0: ctgIdArray[t] = 0).  ctg2read[t][0] = hits[r]; ctg2read[t][m], m >= 1,
+ *                  = hits[more_start + m - 1] (the tail of hits[] past the first nreads entries, in the reference's
+ *                  order); best = index m of the hit that sets ctgIdArray / posArray / orienArray (posArray =
+ *                  contig_offset - read_offset + 1); overflow: more than 20 candidate contigs -- the reference
+ *                  overruns pos_temp[20] there; such a read is reported unmapped.
+ *                  max_hits >= nreads; *nhits = entries of hits[] in use (nreads + all further hits); SDT_EFULL
+ *                  when hits[] is too small: *nhits says how many the batch needs.
  *   align_reads_device: the same on buffers already in device memory (outputs too). */
 typedef struct {
 	uint32_t contig;             /* READSET.contigID */

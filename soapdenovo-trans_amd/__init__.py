@@ -272,7 +272,8 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_set_contig_table(self._ctx, _ptr(length), _ptr(twin), len(length) - 1))
 
     def align_reads(self, packed_words, offsets, align_len=None, align_len_all: int = 0, max_hits=None):
-        """-> (read_info uint64[nreads], hits uint32[nhits, 4]); see include/sdt_gpu.h for the bit layout"""
+        """-> (read_info uint64[nreads], hits uint32[nhits, 4]); hits[r] = first hit of read r, further hits in the tail;
+        see include/sdt_gpu.h for the bit layout"""
         packed_words = np.ascontiguousarray(packed_words, dtype=np.uint32)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1

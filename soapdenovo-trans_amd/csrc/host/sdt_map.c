@@ -20,6 +20,7 @@
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
+#include "graph/par.h"
 
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static double g_t_last;
@@ -227,6 +228,119 @@ static int load_contigs(const char *path, int K, int len_cut, contigs_t *C)
 	if (!C->words) { C->cap = 16; C->words = (uint32_t *)calloc(C->cap, sizeof(uint32_t)); }
 	C->nwords = ((C->nbases + 15) >> 4) + 4;
 	return 0;
+}
+
+
+static void cur_seek(cursor *c, const mstream *S, int ns, uint64_t g)
+{
+	memset(c, 0, sizeof *c);
+	c->s = S;
+	c->ns = ns;
+	int si = 0;
+	while (si + 1 < ns && S[si + 1].base <= g) si++;
+	c->si = si;
+	if (si >= ns || g >= S[si].base + S[si].nreads) { c->si = ns; return; }
+	const mstream *s = &S[si];
+	c->k = g - s->base;
+	const uint64_t na = s->paired ? (c->k + 1) / 2 : c->k, nb = s->paired ? c->k / 2 : 0;
+	rref a = file_read(&s->A, na);
+	c->ba = (size_t)(a.b - s->A.b);
+	c->ia = a.i;
+	if (s->paired) {
+		rref b = file_read(&s->B, nb);
+		c->bb = (size_t)(b.b - s->B.b);
+		c->ib = b.i;
+	}
+}
+
+/* ---- text formatting of *.readOnContig / *.ctg2Read / *.readInformation, in parallel per block of reads ---- */
+typedef struct { char *p; size_t n, cap; } tbuf;
+static inline void tb_room(tbuf *b, size_t more)
+{
+	if (b->n + more <= b->cap) return;
+	b->cap = b->cap ? b->cap * 2 : 1 << 20;
+	while (b->cap < b->n + more) b->cap *= 2;
+	b->p = (char *)realloc(b->p, b->cap);
+}
+static inline void tb_u64(tbuf *b, unsigned long long v)
+{
+	char tmp[24];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	while (n) b->p[b->n++] = tmp[--n];
+}
+static inline void tb_i64(tbuf *b, long long v)
+{
+	if (v < 0) { b->p[b->n++] = '-'; tb_u64(b, (unsigned long long)(-v)); }
+	else tb_u64(b, (unsigned long long)v);
+}
+
+typedef struct {
+	const mstream *S;
+	int ns, K, read_trace;
+	const uint32_t *ctg_len, *ctg_twin;
+	uint64_t total, block, wave_first;      /* reads per block; first block of this wave */
+	tbuf *ro, *c2, *ri;                     /* one per block of the wave */
+	long long *mapped, *overflowed;
+} fmt_ctx;
+
+static void fmt_blocks(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	fmt_ctx *F = (fmt_ctx *)vc;
+	for (uint64_t bi = lo; bi < hi; bi++) {
+		const uint64_t g0 = (F->wave_first + bi) * F->block, g1 = g0 + F->block < F->total ? g0 + F->block : F->total;
+		tbuf *ro = &F->ro[bi], *c2 = &F->c2[bi], *ri = &F->ri[bi];
+		ro->n = c2->n = ri->n = 0;
+		long long mapped = 0, over = 0;
+		cursor cu;
+		cur_seek(&cu, F->S, F->ns, g0);
+		rref x;
+		int lib;
+		for (uint64_t g = g0; g < g1 && cur_next(&cu, &x, &lib); g++) {
+			const uint64_t w = x.b->info[x.i];
+			const int nh = (int)((w >> 40) & 255);
+			if ((w >> 57) & 1) over++;
+			if (!nh) continue;
+			mapped++;
+			const unsigned long long rc = g + 1;                                     /* readCounter */
+			const sdt_hit *more = &x.b->hits[w & ((1ULL << 40) - 1)];               /* hits 1.. of the read; hit 0 = hits[read] */
+#define HIT(m) ((m) == 0 ? &x.b->hits[x.i] : &more[(m) - 1])
+			const sdt_hit *h = (rc % 2 == 1) ? HIT(nh - 1) : HIT(0);                 /* :566-569 */
+			tb_room(ro, 64);
+			tb_u64(ro, rc); ro->p[ro->n++] = '\t';
+			tb_u64(ro, h->contig); ro->p[ro->n++] = '\t';
+			tb_i64(ro, (long long)h->contig_offset - (long long)h->read_offset + 1); ro->p[ro->n++] = '\t';
+			ro->p[ro->n++] = (h->align_len_orien >> 31) ? '-' : '+'; ro->p[ro->n++] = '\n';
+			for (int m = 0; m < nh; m++) {
+				const sdt_hit *hm = HIT(m);
+				const int al = (int)(hm->align_len_orien & 0x7FFFFFFFu);
+				const char orien = (hm->align_len_orien >> 31) ? '-' : '+';
+				if (al < 5) continue;
+				tb_room(c2, 64);
+				tb_u64(c2, rc); c2->p[c2->n++] = '\t';
+				tb_u64(c2, hm->contig); c2->p[c2->n++] = '\t';
+				tb_i64(c2, (long long)hm->read_offset - (long long)hm->contig_offset); c2->p[c2->n++] = '\t';
+				c2->p[c2->n++] = orien; c2->p[c2->n++] = '\n';
+				if (!F->read_trace) continue;
+				const int span = al + F->K - 1;                                       /* :573-582 */
+				tb_room(ri, 128);
+				tb_u64(ri, rc); ri->p[ri->n++] = '\t';
+				tb_i64(ri, (long long)hm->read_offset - 1); ri->p[ri->n++] = '\t';
+				if (orien == '+') {
+					tb_u64(ri, hm->contig); ri->p[ri->n++] = '\t';
+					tb_i64(ri, hm->contig_offset); ri->p[ri->n++] = '\t';
+				} else {
+					tb_u64(ri, F->ctg_twin[hm->contig]); ri->p[ri->n++] = '\t';
+					tb_i64(ri, (long long)(int)F->ctg_len[hm->contig] - hm->contig_offset - span); ri->p[ri->n++] = '\t';
+				}
+				tb_i64(ri, span); ri->p[ri->n++] = '\t';
+				ri->p[ri->n++] = orien; ri->p[ri->n++] = '\n';
+			}
+		}
+		F->mapped[bi] = mapped;
+		F->overflowed[bi] = over;
+	}
 }
 
 static void usage(void)
@@ -441,7 +555,7 @@ int main(int argc, char **argv)
 				mbatch *m = &f->b[bi];
 				if (!m->nreads) continue;
 				m->info = (uint64_t *)malloc(m->nreads * sizeof(uint64_t));
-				uint64_t cap = m->nreads + m->nreads / 4 + 64, got = 0;
+				uint64_t cap = m->nreads + m->nreads / 8 + 64, got = 0;       /* first hit of every read + the further hits */
 				for (;;) {
 					m->hits = (sdt_hit *)malloc(cap * sizeof(sdt_hit));
 					const int rc = sdt_gpu_align_reads(gpu, m->words, m->nwords, m->offs, m->nreads, m->alen, 0, m->info, m->hits, cap, &got);
@@ -471,11 +585,34 @@ int main(int argc, char **argv)
 		f4 = fopen(name, "w");
 		if (!f4) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
 	}
-	setvbuf(fo, NULL, _IOFBF, 1 << 22);
-	setvbuf(f3, NULL, _IOFBF, 1 << 22);
 	fprintf(fo, "read\tcontig\tpos\n");
 	fprintf(f3, "read\tcontig\tpos\n");
-	long long read_counter = 0, map_counter = 0, overflowed = 0;
+	long long map_counter = 0, overflowed = 0;
+	{
+		/* the text files depend on each read alone: format blocks of reads in parallel, write them in order */
+		const int nt = par_threads();
+		const uint64_t block = 1 << 18;
+		const uint64_t nblocks = (total + block - 1) / block;
+		fmt_ctx F = {S, ns, K, read_trace, ctg_len, ctg_twin, total, block, 0, (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)),
+		             (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)), (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)),
+		             (long long *)calloc((size_t)nt * 2, sizeof(long long)), (long long *)calloc((size_t)nt * 2, sizeof(long long))};
+		for (uint64_t first = 0; first < nblocks; first += (uint64_t)nt * 2) {
+			const uint64_t n = nblocks - first < (uint64_t)nt * 2 ? nblocks - first : (uint64_t)nt * 2;
+			F.wave_first = first;
+			par_for(0, n, 1, fmt_blocks, &F);
+			for (uint64_t b = 0; b < n; b++) {
+				fwrite(F.ro[b].p, 1, F.ro[b].n, fo);
+				fwrite(F.c2[b].p, 1, F.c2[b].n, f3);
+				if (f4) fwrite(F.ri[b].p, 1, F.ri[b].n, f4);
+				map_counter += F.mapped[b];
+				overflowed += F.overflowed[b];
+			}
+		}
+		for (int b = 0; b < nt * 2; b++) { free(F.ro[b].p); free(F.c2[b].p); free(F.ri[b].p); }
+		free(F.ro); free(F.c2); free(F.ri); free(F.mapped); free(F.overflowed);
+	}
+	phase("text files (parallel format)");
+	long long read_counter = 0;
 	{
 		cursor cu = {S, ns, 0, 0, 0, 0, 0, 0};
 		rref x, prev = {NULL, 0};
@@ -520,10 +657,9 @@ int main(int argc, char **argv)
 			read_counter++;
 			const uint64_t w = x.b->info[x.i];
 			const int nh = (int)((w >> 40) & 255), best = (int)((w >> 48) & 255), foot = (int)((w >> 56) & 1);
-			if ((w >> 57) & 1) overflowed++;
-			const sdt_hit *H = nh ? &x.b->hits[w & ((1ULL << 40) - 1)] : NULL;
-			int ctg = nh ? (int)H[best].contig : 0;
-			int pos = nh ? H[best].contig_offset - (int)H[best].read_offset + 1 : 0;
+			const sdt_hit *hb = !nh ? NULL : (best == 0 ? &x.b->hits[x.i] : &x.b->hits[(w & ((1ULL << 40) - 1)) + (uint64_t)best - 1]);
+			int ctg = nh ? (int)hb->contig : 0;
+			int pos = nh ? hb->contig_offset - (int)hb->read_offset + 1 : 0;
 			const int ctg_at_top = ctg;
 			int rd1gap = 0, rd2gap = 0;
 			if (t % 2 == 1 && prev.b) {
@@ -540,22 +676,6 @@ int main(int argc, char **argv)
 				}
 			}
 			if (ctg_at_top >= 1) {
-				map_counter++;
-				const sdt_hit *h = (read_counter % 2 == 1) ? &H[nh - 1] : &H[0];
-				fprintf(fo, "%lld\t%u\t%d\t%c\n", read_counter, h->contig, h->contig_offset - (int)h->read_offset + 1, (h->align_len_orien >> 31) ? '-' : '+');
-				for (int m = 0; m < nh; m++) {
-					const int al = (int)(H[m].align_len_orien & 0x7FFFFFFFu);
-					const char orien = (H[m].align_len_orien >> 31) ? '-' : '+';
-					if (al >= 5) fprintf(f3, "%lld\t%u\t%d\t%c\n", read_counter, H[m].contig, (int)H[m].read_offset - H[m].contig_offset, orien);
-					if (read_trace && al >= 5) {
-						const int span = al + K - 1;
-						if (orien == '+')
-							fprintf(f4, "%lld\t%d\t%llu\t%d\t%d\t%c\n", read_counter, (int)H[m].read_offset - 1, (unsigned long long)H[m].contig, H[m].contig_offset, span, orien);
-						else
-							fprintf(f4, "%lld\t%d\t%llu\t%d\t%d\t%c\n", read_counter, (int)H[m].read_offset - 1, (unsigned long long)ctg_twin[H[m].contig],
-							        (int)ctg_len[H[m].contig] - H[m].contig_offset - span, span, orien);
-					}
-				}
 				if (t % 2 == 1 && prev.b) {
 					/* "reads are not located by pe info but across edges" (:591-606); a footprint read is always mapped, so
 					 * locate1read is never reached */
@@ -575,7 +695,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%lld reads touch more than 20 contigs with >= ALIGNLEN-K+1 k-mers each (the reference overruns a 20-entry array there); reported unmapped\n", overflowed);
 	fclose(fo); fclose(f3); fclose(G.gap);
 	if (f4) fclose(f4);
-	phase("recordAlldgn (host)");
+	phase("readInGap (ordered pass)");
 	/* *.peGrads (:825-846): one line per library that delivered reads, boundaries in reads */
 	snprintf(name, sizeof name, "%s.peGrads", graph);
 	fo = fopen(name, "w");

@@ -75,6 +75,31 @@ __global__ __launch_bounds__(TPB) void k_index_contigs(const uint32_t *__restric
 	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+// After the last contig: turn every node into what a look-up needs, in place -- val = PL_VALID | contig id |
+// position << 32 | smaller_in_contig << 56 for a k-mer that occurs once, 0 for a repeated ("deleted") one -- so that
+// searchKmer is ONE 16..48-byte entry read instead of entry + count high word + first-occurrence word.
+constexpr uint64_t PL_VALID = 1ULL << 63;
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_finalize_contig_index(Table<NW> tbl, const uint32_t *__restrict__ ctg_ids, uint64_t n_ord, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	uint32_t bad = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
+		const uint64_t cnt = (tbl.ent[s].val >> 48) | ((uint64_t)(tbl.aux[s] & 0xFFFFu) << 16);
+		uint64_t v = 0;
+		if (cnt == 1) {                                  /* found && !node->deleted */
+			const uint64_t f = tbl.first[s];
+			const uint64_t ord = f >> (CTG_POS_BITS + 1);
+			if (ord < n_ord) v = PL_VALID | (uint64_t)ctg_ids[ord] | (((f >> 1) & ((1ULL << CTG_POS_BITS) - 1)) << 32) | ((f & 1ULL) << 56);
+			else bad++;
+		}
+		tbl.ent[s].val = v;
+	}
+	if (bad) atomicAdd(&stats->probe_fail, (unsigned long long)bad);
+}
+
 template <int NW> __device__ inline bool lookup_slot(const Table<NW> &tbl, const Key<NW> &k, uint64_t &slot_out)
 {
 	uint64_t slot = key_hash<NW>(k) & tbl.mask;
@@ -89,15 +114,33 @@ template <int NW> __device__ inline bool lookup_slot(const Table<NW> &tbl, const
 	return false;
 }
 
-// LDS word per k-mer of the read: contig id (32) | position (24) << 32 | smaller_in_contig << 56 | smaller_in_read << 57
-// | valid << 63
-constexpr uint64_t PL_VALID = 1ULL << 63;
+// searchKmer on the finalized index: the node's val (0 = absent or deleted)
+template <int NW> __device__ inline uint64_t lookup_val(const Table<NW> &tbl, const Key<NW> &k)
+{
+	uint64_t slot = key_hash<NW>(k) & tbl.mask;
+	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
+		if constexpr (NW == 1) {
+			const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(tbl.ent + slot);     // key + val in one 16-byte load
+			if (kv.x == KEY_EMPTY) return 0;
+			if (kv.x == k.w[0]) return kv.y;
+		} else {
+			const Entry<NW> *e = tbl.ent + slot;
+			if (e->key[0] == KEY_EMPTY) return 0;
+			bool same = true;
+#pragma unroll
+			for (int w = 0; w < NW; w++) same = same && e->key[w] == k.w[w];
+			if (same) return e->val;
+		}
+	}
+	return 0;
+}
+
+// LDS word per k-mer of the read: the node's finalized val | smaller_in_read << 57
 
 // read_info[r] = hit_start (40 bits) | nhits << 40 | best << 48 | footprint << 56 | overflow << 57
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_align_reads(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs, uint64_t nreads,
                                                      const int32_t *__restrict__ align_len, int align_len_all, int K, Table<NW> tbl,
-                                                     const uint32_t *__restrict__ ctg_ids, uint64_t n_ord,
                                                      const uint32_t *__restrict__ ctg_len, const uint32_t *__restrict__ ctg_twin, uint64_t num_ctg,
                                                      int max_kmers, int waves_per_block, uint64_t *__restrict__ read_info, Hit *__restrict__ hits,
                                                      unsigned long long max_hits, unsigned long long *hit_cursor, Stats *stats)
@@ -122,19 +165,8 @@ __global__ __launch_bounds__(TPB) void k_align_reads(const uint32_t *__restrict_
 			const Key<NW> fw = global_kmer<NW>(words, start + (uint64_t)j, K);
 			const Key<NW> rc = key_revcomp<NW>(fw, K);
 			const bool smaller = key_less<NW>(fw, rc);
-			uint64_t slot, v = 0;
-			if (lookup_slot<NW>(tbl, smaller ? fw : rc, slot)) {
-				const uint64_t cnt = (tbl.ent[slot].val >> 48) | ((uint64_t)(tbl.aux[slot] & 0xFFFFu) << 16);
-				if (cnt == 1) {                                          // found && !node->deleted
-					const uint64_t f = tbl.first[slot];
-					const uint64_t ord = f >> (CTG_POS_BITS + 1);
-					if (ord < n_ord)
-						v = PL_VALID | (uint64_t)ctg_ids[ord] | (((f >> 1) & ((1ULL << CTG_POS_BITS) - 1)) << 32) | ((f & 1ULL) << 56) |
-						    ((uint64_t)smaller << 57);
-					else
-						bad++;
-				}
-			}
+			uint64_t v = lookup_val<NW>(tbl, smaller ? fw : rc);
+			if (v) v |= (uint64_t)smaller << 57;
 			pl[j] = v;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -145,63 +177,68 @@ __global__ __launch_bounds__(TPB) void k_align_reads(const uint32_t *__restrict_
 		const int multi = alldgn - K + 1 < 5 ? 5 : alldgn - K + 1;
 		int nh = 0, counter2 = 0, overflow = 0;
 		uint32_t best_key = 0;                                           // count << 8 | (255 - hit index): max = most k-mers, first such
-		for (int base = 0; base < n; base += 64) {
-			const int j = base + lane;
-			const uint64_t me = j < n ? pl[j] : 0;
+		// Groups in order of first appearance (the reference's outer loop over j with its NULL-ing of later k-mers of
+		// the same contig, :258-291): the leader is the first k-mer still standing; one ballot per 64 positions counts
+		// its contig's k-mers and takes them out.  Everything below is uniform across the wavefront.
+		for (int lead_base = 0; lead_base < n;) {
+			const int lj = lead_base + lane;
+			const uint64_t lv = lj < n ? pl[lj] : 0;
+			const unsigned long long lm = __ballot((lv & PL_VALID) != 0);
+			if (!lm) { lead_base += 64; continue; }
+			const int ll = __ffsll((long long)lm) - 1;
+			const int j = lead_base + ll;                                   // first k-mer of the group
+			const uint64_t me = __shfl(lv, ll);
+			const uint32_t ctg = (uint32_t)me;
 			int cnt = 0;
-			bool first = (me & PL_VALID) != 0;
-			if (__any(first)) {
-				const uint32_t ctg = (uint32_t)me;
-				for (int s = 0; s < n; s++) {
-					const uint64_t o = pl[s];                            // same address for all lanes: LDS broadcast
-					const bool same = (o & PL_VALID) && (uint32_t)o == ctg;
-					cnt += same;
-					if (same && s < j) first = false;
-				}
+			for (int base = lead_base; base < n; base += 64) {
+				const int s = base + lane;
+				const uint64_t o = s < n ? pl[s] : 0;
+				const bool same = (o & PL_VALID) && (uint32_t)o == ctg;
+				cnt += __popcll(__ballot(same));
+				if (same) pl[s] = 0;
 			}
-			first = first && (me & PL_VALID);
-			counter2 += __popcll(__ballot(first && cnt >= 2));
-			const bool rec = first && cnt >= multi;
-			const unsigned long long m = __ballot(rec);
-			if (rec) {
-				const int idx = nh + __popcll(m & ((1ULL << lane) - 1ULL));
-				if (idx < MAX_HITS) {
-					const uint32_t ctg = (uint32_t)me, pos = (uint32_t)(me >> 32) & 0xFFFFFFu;
-					const bool sm_ctg = (me >> 56) & 1ULL, sm_read = (me >> 57) & 1ULL;
-					Hit h;
-					h.read_offset = (uint32_t)j + 1u;
-					if (ctg > num_ctg) {
-						bad++;
-						h.contig = 0; h.contig_offset = 0; h.align_len_orien = (uint32_t)cnt;
-					} else if (sm_ctg != sm_read) {                       // node->twin == isSmaller  (twin = !smaller_in_contig)
-						h.contig = ctg_twin[ctg];
-						h.contig_offset = (int32_t)(ctg_len[ctg] - pos - (uint32_t)K);
-						h.align_len_orien = (uint32_t)cnt | (1u << 31);
-					} else {
-						h.contig = ctg;
-						h.contig_offset = (int32_t)pos;
-						h.align_len_orien = (uint32_t)cnt;
-					}
-					my_hits[idx] = h;
-					const uint32_t key = ((uint32_t)cnt << 8) | (uint32_t)(255 - idx);
-					if (key > best_key) best_key = key;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			counter2 += cnt >= 2;
+			if (cnt < multi) continue;
+			if (nh < MAX_HITS && lane == 0) {
+				const uint32_t pos = (uint32_t)(me >> 32) & 0xFFFFFFu;
+				const bool sm_ctg = (me >> 56) & 1ULL, sm_read = (me >> 57) & 1ULL;
+				Hit h;
+				h.read_offset = (uint32_t)j + 1u;
+				if (ctg > num_ctg) {
+					bad++;
+					h.contig = 0; h.contig_offset = 0; h.align_len_orien = (uint32_t)cnt;
+				} else if (sm_ctg != sm_read) {                               // node->twin == isSmaller  (twin = !smaller_in_contig)
+					h.contig = ctg_twin[ctg];
+					h.contig_offset = (int32_t)(ctg_len[ctg] - pos - (uint32_t)K);
+					h.align_len_orien = (uint32_t)cnt | (1u << 31);
+				} else {
+					h.contig = ctg;
+					h.contig_offset = (int32_t)pos;
+					h.align_len_orien = (uint32_t)cnt;
 				}
+				my_hits[nh] = h;
 			}
-			nh += __popcll(m);
+			if (nh < MAX_HITS) {
+				const uint32_t key = ((uint32_t)cnt << 8) | (uint32_t)(255 - nh);
+				if (key > best_key) best_key = key;
+			}
+			nh++;
 		}
 		if (nh > MAX_HITS) { overflow = 1; nh = 0; }                     // the reference writes past pos_temp[20] here: undefined
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) {
-			const uint32_t o = __shfl_xor(best_key, d);
-			if (o > best_key) best_key = o;
-		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		// hits[r] = the read's first hit; further hits (rare) go to the tail of hits[], handed out by one shared cursor
+		// that starts at nreads -- a cursor bump per READ would serialise at the ~80 M/s of same-address atomics
 		unsigned long long hstart = 0;
 		if (nh) {
-			if (lane == 0) hstart = atomicAdd(hit_cursor, (unsigned long long)nh);
-			hstart = __shfl(hstart, 0);
-			if (lane < nh && hstart + (unsigned long long)lane < max_hits) hits[hstart + lane] = my_hits[lane];
+			if (lane == 0 && r < max_hits) hits[r] = my_hits[0];
+			if (nh > 1) {
+				if (lane == 0) hstart = atomicAdd(hit_cursor, (unsigned long long)(nh - 1));
+				hstart = __shfl(hstart, 0);
+				if (lane >= 1 && lane < nh && hstart + (unsigned long long)(lane - 1) < max_hits) hits[hstart + lane - 1] = my_hits[lane];
+			}
 		}
 		if (lane == 0) {
 			const uint64_t best = nh ? (uint64_t)(255 - (best_key & 255u)) : 0;

@@ -504,6 +504,7 @@ struct sdt_ctx {
 	void *ab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // words, offsets, align_len, read_info, hits
 	size_t ab_cap[5] = {0, 0, 0, 0, 0};
 	unsigned long long *d_hit_cursor = nullptr;
+	bool index_final = false;            // k_finalize_contig_index has run: look-ups only from here on
 	// timing
 	std::vector<EventPair> ev;
 	size_t ev_used = 0;
@@ -821,6 +822,7 @@ int sdt_gpu_reset(sdt_ctx *c)
 	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
 	c->kept.clear();
 	c->ctg_ord = 0;
+	c->index_final = false;
 	c->paths_loaded = false;
 	if (c->d_idx) (void)hipFree(c->d_idx);
 	c->d_idx = nullptr;
@@ -1554,6 +1556,8 @@ int sdt_gpu_index_contigs(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwo
 		return fail(SDT_EINVAL, "NULL argument");
 	if (!(c->flags & SDT_FLAG_CONTIG_INDEX))
 		return fail(SDT_ESTATE, "init with SDT_FLAG_CONTIG_INDEX to index contigs");
+	if (c->index_final)
+		return fail(SDT_ESTATE, "the contig index is final once reads have been aligned: sdt_gpu_reset to start over");
 	if (ncontigs == 0)
 		return SDT_OK;
 	uint64_t kmers = 0;
@@ -1630,8 +1634,22 @@ static int launch_align(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	while (waves > 1 && per_wave * waves > 48 * 1024) waves >>= 1;
 	if (per_wave > 64 * 1024)
 		return fail(SDT_EINVAL, "reads of %llu bases do not fit the per-wavefront LDS window", (unsigned long long)max_read_len);
+	if (!c->index_final) {
+		int rcs = sync_stats(c);                          // counts stay readable through finish_count (host copy)
+		if (rcs != SDT_OK) return rcs;
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_finalize_contig_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_finalize_contig_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
+		else hipLaunchKernelGGL(k_finalize_contig_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
+		HIPCHK(hipGetLastError());
+		c->index_final = true;
+	}
 	if (!c->d_hit_cursor) HIPCHK(hipMalloc((void **)&c->d_hit_cursor, sizeof(unsigned long long)));
-	HIPCHK(hipMemsetAsync(c->d_hit_cursor, 0, sizeof(unsigned long long), c->stream));
+	{
+		const unsigned long long first_extra = nreads;      // hits[0 .. nreads) = first hit of each read, the rest follows
+		HIPCHK(hipMemcpyAsync(c->d_hit_cursor, &first_extra, sizeof first_extra, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
 	uint64_t blocks = (nreads + waves - 1) / waves;
 	const uint64_t cap = (uint64_t)c->cu_count * 32;
 	if (blocks > cap) blocks = cap;
@@ -1639,7 +1657,7 @@ static int launch_align(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	EventPair *ev = next_event(c);
 	if (ev) HIPCHK(hipEventRecord(ev->a, c->stream));
 #define ALIGN_LAUNCH(NWV) hipLaunchKernelGGL(k_align_reads<NWV>, dim3((unsigned)blocks), dim3(TPB), per_wave * waves, c->stream, d_words, d_offs, nreads, \
-	d_align_len, align_len_all, c->K, table_of<NWV>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, (const uint32_t *)c->d_ctg_len, \
+	d_align_len, align_len_all, c->K, table_of<NWV>(c), (const uint32_t *)c->d_ctg_len, \
 	(const uint32_t *)c->d_ctg_twin, c->num_ctg, max_kmers, waves, d_info, d_hits, (unsigned long long)max_hits, c->d_hit_cursor, c->d_stats)
 	if (c->nw == 1) ALIGN_LAUNCH(1);
 	else if (c->nw == 2) ALIGN_LAUNCH(2);
@@ -1659,6 +1677,8 @@ int sdt_gpu_align_reads_device(sdt_ctx *c, const void *d_packed_words, const voi
 {
 	if (!c || !d_packed_words || !d_offsets || !d_read_info || !d_hits)
 		return fail(SDT_EINVAL, "NULL argument");
+	if (max_hits < nreads)
+		return fail(SDT_EINVAL, "hits[] must hold at least one entry per read (%llu < %llu)", (unsigned long long)max_hits, (unsigned long long)nreads);
 	if (!(c->flags & SDT_FLAG_CONTIG_INDEX))
 		return fail(SDT_ESTATE, "init with SDT_FLAG_CONTIG_INDEX");
 	HIPCHK(hipSetDevice(c->device));
@@ -1699,6 +1719,8 @@ int sdt_gpu_align_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nword
 	if (rc == SDT_OK) rc = ab_reserve(c, 1, (nreads + 1) * sizeof(uint64_t));
 	if (rc == SDT_OK && align_len) rc = ab_reserve(c, 2, nreads * sizeof(int32_t));
 	if (rc == SDT_OK) rc = ab_reserve(c, 3, nreads * sizeof(uint64_t));
+	if (max_hits < nreads)
+		return fail(SDT_EINVAL, "hits[] must hold at least one entry per read (%llu < %llu)", (unsigned long long)max_hits, (unsigned long long)nreads);
 	if (rc == SDT_OK) rc = ab_reserve(c, 4, (max_hits ? max_hits : 1) * sizeof(Hit));
 	if (rc != SDT_OK) return rc;
 	HIPCHK(hipMemcpyAsync(c->ab[0], packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));

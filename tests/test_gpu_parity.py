@@ -542,7 +542,7 @@ def test_map_stage_equals_oracle(pkg, synth, name):
                     continue
                 mapped += 1
                 got = [(int(h[0]), int(np.int32(h[1])), int(h[2]), int(h[3]) & 0x7FFFFFFF, "-" if int(h[3]) >> 31 else "+")
-                       for h in hits[start:start + nh]]
+                       for h in [hits[r]] + list(hits[start:start + nh - 1])]       # hit 0 sits at hits[read], the rest in the tail
                 assert got == want, (r, mode)
                 assert (b, f) == (best, foot), (r, mode)
             assert mapped > 0
@@ -586,12 +586,19 @@ def test_map_stage_edge_cases(pkg, synth):
         assert (int(info_w[3]) >> 57) & 1 == 1 and (int(info_w[3]) >> 40) & 255 == 0
         for r in (1, 4):
             w = int(info_w[r])
-            h = hits[w & ((1 << 40) - 1)]
+            assert (w >> 40) & 255 == 1
+            h = hits[r]
             assert [(int(h[0]), int(np.int32(h[1])), int(h[2]), int(h[3]) & 0x7FFFFFFF, "-" if int(h[3]) >> 31 else "+")] == want[r][1]
         assert want[4][1][0][4] == "-"
         with pytest.raises(pkg.SdtError) as ei:
             g.align_reads(synth.pack_2bit(rcodes), roffs, align_len_all=K + 4, max_hits=1)
+        assert ei.value.code == pkg.SDT_EINVAL            # fewer entries than reads
+        two = np.concatenate([ctgs[1][:100], ctgs[2][:100]])                       # one read, two contigs -> needs a tail entry
+        with pytest.raises(pkg.SdtError) as ei:
+            g.align_reads(synth.pack_2bit(two), np.array([0, 200], dtype=np.uint64), align_len_all=K + 4, max_hits=1)
         assert ei.value.code == pkg.SDT_EFULL
+        info2, hits2 = g.align_reads(synth.pack_2bit(two), np.array([0, 200], dtype=np.uint64), align_len_all=K + 4)
+        assert (int(info2[0]) >> 40) & 255 == 2 and len(hits2) == 2 and [int(hits2[0][0]), int(hits2[1][0])] == [2, 3]
     with pkg.PregraphGPU(K, est_distinct=1 << 12) as g2:             # not a contig-index context
         with pytest.raises(pkg.SdtError):
             g2.index_contigs(synth.pack_2bit(ctgs[0]), np.array([0, 300], dtype=np.uint64), ids[:1])
