@@ -180,8 +180,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SDT_BENCH_SHARE_DEVICE=1 (validation only, never for a reported number): all ranks on cuda:0 with a gloo
+        # control plane, so that the N>1 code path can be exercised on a 1-GPU box (RCCL refuses two ranks per device)
+        share = os.environ.get("SDT_BENCH_SHARE_DEVICE") == "1"
+        if share:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 

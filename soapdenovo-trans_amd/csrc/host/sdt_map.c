@@ -382,7 +382,9 @@ int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", graph[4096] = "";
 	int threads = 8, max_k = 0, device = 0, read_trace = 0, have_s = 0, have_g = 0, c;
-	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001}, {0, 0, 0, 0}};
+	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
+	                                   {"batch-kmers", required_argument, 0, 1002}, {0, 0, 0, 0}};
+	int batch_kmers = 100000000;                           /* buffer_size of prlRead2Ctg.c:31; --batch-kmers exists for the tests */
 	if (argc > 1 && strcmp(argv[1], "map") == 0) { argv++; argc--; }
 	while ((c = getopt_long(argc, argv, "s:g:K:p:rfR", longopts, NULL)) != -1) {
 		switch (c) {
@@ -395,6 +397,7 @@ int main(int argc, char **argv)
 		case 'f': fprintf(stderr, "-f (gap-filling read dumps) is not supported by this build\n"); return 1;
 		case 1000: max_k = atoi(optarg); break;
 		case 1001: device = atoi(optarg); break;
+		case 1002: batch_kmers = atoi(optarg); break;
 		default: usage(); return 255;
 		}
 	}
@@ -519,7 +522,7 @@ int main(int argc, char **argv)
 
 	/* ALIGNLEN: a global the main thread keeps updating while it fills a batch; parse1read sees what the LAST read
 	 * of the batch left (prlRead2Ctg.c:774-805).  maxReadNum reads per batch (:689-690). */
-	int max_read_num = 100000000 / (max_read_len - K + 1 > 0 ? max_read_len - K + 1 : 1);
+	int max_read_num = batch_kmers / (max_read_len - K + 1 > 0 ? max_read_len - K + 1 : 1);
 	if (max_read_num % 2) max_read_num--;
 	if (max_read_num < 2) max_read_num = 2;
 	const uint64_t nbatch = total ? (total + (uint64_t)max_read_num - 1) / (uint64_t)max_read_num : 0;

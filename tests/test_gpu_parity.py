@@ -602,3 +602,27 @@ def test_map_stage_edge_cases(pkg, synth):
     with pkg.PregraphGPU(K, est_distinct=1 << 12) as g2:             # not a contig-index context
         with pytest.raises(pkg.SdtError):
             g2.index_contigs(synth.pack_2bit(ctgs[0]), np.array([0, 300], dtype=np.uint64), ids[:1])
+
+
+def test_bench_two_ranks_on_one_device_equal_one_rank(pkg, tmp_path):
+    """the N>1 path of bench.py (owner-filter sharding, all-reduced kmerFreq / counters) run for real on the GPU:
+    two ranks sharing cuda:0 over a gloo control plane (SDT_BENCH_SHARE_DEVICE=1, validation only) must report the
+    same node and linear-node counts as one rank"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--reads", "1000000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--T", "2000"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, SDT_BENCH_SHARE_DEVICE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and "owner-sharded" in b["config"]["parallelism"]
+    for k in ("kmers", "distinct_nodes", "linear_nodes"):
+        assert a["config"][k] == b["config"][k], k

@@ -234,3 +234,27 @@ def test_sdt_map_usage_and_errors(pkg, tmp_path):
     assert r.returncode != 0 and "map -s configFile -g inputGraph" in r.stdout
     r = subprocess.run([exe, "map", "-s", str(tmp_path / "x.cfg"), "-g", str(tmp_path / "nothing")], capture_output=True, text=True)
     assert r.returncode != 0 and "Cannot open" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch_kmers", [("map_longins_ragged_k31_p5", 9000), ("map_fa100_k23_p4_two_libs", 20000),
+                                              ("map_pe250_k63_127mer_p3", 30000)])
+def test_sdt_map_batch_logic_equals_oracle(pkg, tmp_path, name, batch_kmers):
+    """many small batches instead of one: ALIGNLEN as left by the last read of each batch (a batch that spans two
+    libraries takes the later one's), thread 0's reverse-complement scratch under the *.readInGap records of every
+    batch -- sdt-map --batch-kmers N vs the oracle run with the same buffer_size (the oracle itself is pinned to the
+    reference at the reference's 10^8)"""
+    info = mu.load_case(name)
+    cfg = mu.materialise(info, tmp_path)
+    o = mu.build_oracle(info)
+    codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
+    counters = o.run(codes, offs, lib_of, [l["avg_ins"] for l in libs], [l["map_len"] for l in libs], max_rd_len, info["p"],
+                     tmp_path / "o", buffer_size=batch_kmers, trace=bool(info.get("trace")))
+    cmd = [bin_path(pkg, "sdt-map"), "map", "-s", cfg, "-g", str(tmp_path / "out"), "-p", str(info["p"]), "--batch-kmers", str(batch_kmers)]
+    if info.get("trace"):
+        cmd.append("-r")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []):
+        assert open(str(tmp_path / "out") + "." + ext, "rb").read() == open(str(tmp_path / "o") + "." + ext, "rb").read(), ext
+    assert f"{counters[1]} out of {counters[0]} " in r.stdout
