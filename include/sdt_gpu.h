@@ -174,6 +174,15 @@ int sdt_gpu_export_arcs(sdt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *mu
 int sdt_gpu_set_node_index(sdt_ctx *ctx, const uint64_t *keys, uint64_t n);
 int sdt_gpu_update_nodes(sdt_ctx *ctx, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
 int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n);
+/*   minor_out_dry:  removeMinorOut's read-only part (cutTipPreGraph.c:1012-1076): every junction whose ratio test
+ *                   (count / largest count on that side < threshold = dd / 100.0, clipKmerFromNode :591-1010)
+ *                   would cut at least one neighbour on the graph as it is now, and who the neighbours of those
+ *                   junctions and of the neighbours to cut are.  records: 9 words each -- node index, then
+ *                   (neighbour index << 1 | smaller) or ~0 for the four left and the four right links;
+ *                   [0, n_junctions) are the junctions, [n_junctions, n_records) the neighbours to cut that are not
+ *                   junctions themselves.  SDT_EFULL when records[] is too small: *n_records says what is needed. */
+int sdt_gpu_minor_out_dry(sdt_ctx *ctx, double threshold, uint64_t *records, uint64_t max_records,
+                          uint64_t *n_junctions, uint64_t *n_records);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

@@ -57,6 +57,8 @@ _ABI = [
     ("sdt_gpu_set_node_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_update_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_tip_walks", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_minor_out_dry", _c.c_int, [_c.c_void_p, _c.c_double, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64),
+                                         _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_set_contig_table", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_align_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_int,
@@ -255,6 +257,19 @@ class PregraphGPU:
         info = np.zeros(max(n, 1), dtype=np.uint8)
         self._check(self.lib.sdt_gpu_tip_walks(self._ctx, int(thin), cut_len, _ptr(end), _ptr(info), n))
         return end[:n], info[:n]
+
+    def minor_out_dry(self, threshold: float):
+        """-> (records uint64[n, 9], n_junctions): see sdt_gpu_minor_out_dry"""
+        cap = max(self._nidx // 8, 1024)
+        while True:
+            rec = np.zeros((cap, 9), dtype=np.uint64)
+            nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
+            rc = self.lib.sdt_gpu_minor_out_dry(self._ctx, ctypes.c_double(threshold), _ptr(rec), cap, ctypes.byref(nj), ctypes.byref(nr))
+            if rc == SDT_EFULL and nr.value > cap:
+                cap = nr.value
+                continue
+            self._check(rc)
+            return rec[: nr.value], nj.value
 
     # -- map stage (prlContig2nodes / prlRead2Ctg); the context must be created with FLAG_CONTIG_INDEX
     def index_contigs(self, packed_words: np.ndarray, offsets: np.ndarray, ids: np.ndarray):

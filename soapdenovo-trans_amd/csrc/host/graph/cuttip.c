@@ -44,6 +44,7 @@ static inline void touch(graph_t *g, const gnode_t *n)
 			g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
 		}
 		g->dlist[g->dn++] = i;
+		if (g->vbits) g->vbits[i >> 6] |= 1ULL << (i & 63);
 	}
 	if (!g->touched || g->touched[i]) return;
 	g->touched[i] = 1;
@@ -254,6 +255,22 @@ static void count_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
 	__sync_fetch_and_add(&c->cursor, k);
 }
 
+static void mo_scatter_records(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	graph_t *g = (graph_t *)a[0];
+	const uint64_t *rec = (const uint64_t *)a[1];
+	uint8_t *writes = (uint8_t *)a[2];
+	const uint64_t nj = *(const uint64_t *)a[3];
+	for (uint64_t r = lo; r < hi; r++) {
+		const uint64_t i = rec[r * 9];
+		memcpy(&g->nb_pool[r * 8], &rec[r * 9 + 1], 8 * sizeof(uint64_t));
+		g->nb_slot[i] = (uint32_t)(r + 1);
+		if (r < nj) writes[i] = 1;
+	}
+}
+
 uint64_t graph_remove_minor_out(graph_t *g, int dd)
 {
 	const double threshold = (double)dd / 100;
@@ -261,6 +278,25 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
 	double t_sub = cut_now_ms();
 	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
+	if (g->dev_minor_out) {
+		/* junction dry run + neighbour look-ups answered by the device mirror of the graph (sdt_gpu_minor_out_dry) */
+		uint64_t *rec = NULL, nj = 0, nr = 0;
+		if (g->dev_minor_out(g, threshold, &rec, &nj, &nr) != 0) {
+			printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
+			exit(1);
+		}
+		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		g->dn = 0;
+		SUBPHASE("device dry run");
+		if (nr > 0xFFFFFFF0ULL) { printf("too many junction records\n"); exit(1); }
+		g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
+		g->nb_pool = (uint64_t *)malloc((nr + 1) * 8 * sizeof(uint64_t));
+		void *sa[4] = {g, rec, c.writes, &nj};
+		par_for(0, nr, 4096, mo_scatter_records, sa);
+		free(rec);
+		c.cap = (uint32_t)nr;
+		SUBPHASE("scatter records");
+	} else {
 	par_for(0, g->n, 16384, count_junctions, &c);
 	SUBPHASE("count junctions");
 	const uint64_t njunc = c.cursor;
@@ -276,12 +312,11 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	SUBPHASE("junction dry run");
 	par_for(0, g->n, 16384, mo_candidates, &c);
 	SUBPHASE("candidate neighbours");
-	/* the pass itself, in the reference's order.  A visit is executed only if the dry run found something to cut
-	 * or the node has been written since (a junction that nobody wrote reads what the dry run read: nothing to
-	 * do); neighbour() finds the answers of the executed visits precomputed. */
-	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
-	g->touched = marks;
-	g->tn = 0;
+	}
+	/* the pass itself, in the reference's order.  Only the junctions the dry run flagged are visited: links only
+	 * disappear during the pass, so on any junction the live largest count per side is <= the dry run's and every
+	 * live ratio >= the dry run's -- a junction with nothing under the threshold then has nothing under it now,
+	 * whatever was written around it.  neighbour() finds the answers of the executed visits precomputed. */
 	/* The commit is a chain of dependent cache misses per visit (node -> its neighbour slots -> the cut
 	 * neighbours -> their neighbour slots -> the nodes those unlink).  The visits the dry run flagged are known up
 	 * front, so run a software prefetch pipeline a few visits ahead of the sweep. */
@@ -290,31 +325,25 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	uint64_t *ex = (uint64_t *)malloc((nexec + 1) * sizeof(uint64_t));
 	nexec = 0;
 	for (uint64_t i = 0; i < g->n; i++) if (c.writes[i]) ex[nexec++] = i;
-	uint64_t cur = 0;                                   /* next flagged visit at or after the sweep position */
-	for (uint64_t i = 0; i < g->n; i++) {
-		if (c.writes[i]) {
-			/* stage 1 (far): slot number; stage 2: the 8 neighbour entries; stage 3: the neighbour nodes and their
-			 * slot numbers; stage 4 (near): the neighbours' own neighbour entries */
-			if (cur + 24 < nexec) __builtin_prefetch(&g->nb_slot[ex[cur + 24]]);
-			if (cur + 16 < nexec) { const uint32_t sl = g->nb_slot[ex[cur + 16]]; if (sl) __builtin_prefetch(&g->nb_pool[(uint64_t)(sl - 1) * 8]); __builtin_prefetch(&g->nodes[ex[cur + 16]]); }
-			if (cur + 8 < nexec) {
-				const uint32_t sl = g->nb_slot[ex[cur + 8]];
-				if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE) { __builtin_prefetch(&g->nodes[v >> 1]); __builtin_prefetch(&g->nb_slot[v >> 1]); } }
-			}
-			if (cur + 4 < nexec) {
-				const uint32_t sl = g->nb_slot[ex[cur + 4]];
-				if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE && c.need[v >> 1]) { const uint32_t s2 = g->nb_slot[v >> 1]; if (s2) __builtin_prefetch(&g->nb_pool[(uint64_t)(s2 - 1) * 8]); } }
-			}
-			cur++;
+	for (uint64_t cur = 0; cur < nexec; cur++) {
+		/* stage 1 (far): slot number; stage 2: the 8 neighbour entries; stage 3: the neighbour nodes and their
+		 * slot numbers; stage 4 (near): the neighbours' own neighbour entries */
+		if (cur + 24 < nexec) __builtin_prefetch(&g->nb_slot[ex[cur + 24]]);
+		if (cur + 16 < nexec) { const uint32_t sl = g->nb_slot[ex[cur + 16]]; if (sl) __builtin_prefetch(&g->nb_pool[(uint64_t)(sl - 1) * 8]); __builtin_prefetch(&g->nodes[ex[cur + 16]]); }
+		if (cur + 8 < nexec) {
+			const uint32_t sl = g->nb_slot[ex[cur + 8]];
+			if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE) { __builtin_prefetch(&g->nodes[v >> 1]); __builtin_prefetch(&g->nb_slot[v >> 1]); } }
 		}
-		if (c.writes[i] || marks[i])
-			visit_minor_out(g, &g->nodes[i], threshold, &off, NULL);
+		if (cur + 4 < nexec) {
+			const uint32_t sl = g->nb_slot[ex[cur + 4]];
+			if (sl) for (int k = 0; k < 8; k++) { const uint64_t v = g->nb_pool[(uint64_t)(sl - 1) * 8 + k]; if (v != NO_NODE) { const uint32_t s2 = g->nb_slot[v >> 1]; if (s2) __builtin_prefetch(&g->nb_pool[(uint64_t)(s2 - 1) * 8]); } }
+		}
+		visit_minor_out(g, &g->nodes[ex[cur]], threshold, &off, NULL);
 	}
 	free(ex);
 	g->touched = NULL;
 	g->tn = 0;
 	SUBPHASE("ordered commit");
-	free(marks);
 	free(g->nb_slot); g->nb_slot = NULL;
 	free(g->nb_pool); g->nb_pool = NULL;
 	free(c.need);
@@ -461,6 +490,45 @@ static int commit_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int th
 	return clipped;
 }
 
+/* the same sweep driven by g->vbits (device-walk passes): only nodes with a recorded walk or written since the walks
+ * were taken can do anything, and touch() adds the latter while the sweep runs -- a node written AHEAD of the sweep
+ * position is still visited in this sweep, one written behind it waits for the next, exactly as in the full scan */
+static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, const walk_t *walks)
+{
+	int clipped = 0;
+	if (hi <= lo) return 0;
+	const uint64_t k0 = lo >> 6, k1 = (hi - 1) >> 6;
+	for (uint64_t k = k0; k <= k1; k++) {
+		uint64_t range = ~0ULL;
+		if (k == k0) range &= ~0ULL << (lo & 63);
+		if (k == k1 && ((hi & 63) != 0)) range &= (1ULL << (hi & 63)) - 1ULL;
+		if (k + 1 <= k1)                                                   /* the decisions of the next word read these nodes */
+			for (uint64_t t = g->vbits[k + 1]; t; t &= t - 1) {
+				const uint64_t j = ((k + 1) << 6) + (uint64_t)__builtin_ctzll(t);
+				if (j < g->n && walks[j].end != NO_NODE) __builtin_prefetch(&g->nodes[walks[j].end]);
+			}
+		uint64_t done = 0;
+		for (;;) {
+			const uint64_t w = g->vbits[k] & range & ~done;
+			if (!w) break;
+			const int b = __builtin_ctzll(w);
+			done |= (b == 63) ? ~0ULL : ((2ULL << b) - 1ULL);
+			const uint64_t i = (k << 6) + (uint64_t)b;
+			gnode_t *tip = &g->nodes[i];
+			const walk_t *wk = &walks[i];
+			if (g->dirty[i]) {
+				clipped += clip_tip(g, tip, cut_len, thin, tips);
+			} else if (wk->end != NO_NODE) {
+				if (!wk->thin_stop && g->nodes[wk->end].linear)
+					clipped += clip_tip(g, tip, cut_len, thin, tips);
+				else
+					clipped += decide_tip(g, tip, wk, thin, tips, 0);
+			}
+		}
+	}
+	return clipped;
+}
+
 /* One sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips.
  * Dry run: every walk, in parallel, on the graph as the sweep finds it.  Commit, in order:
  *   - a node written since the dry run is visited for real (it may have become a dead end, or stopped being one);
@@ -497,7 +565,9 @@ static void unpack_walks(void *vc, uint64_t lo, uint64_t hi, int tid)
 	walk_t *w = (walk_t *)a[0];
 	const uint64_t *end = (const uint64_t *)a[1];
 	const uint8_t *info = (const uint8_t *)a[2];
+	uint64_t *vbits = (uint64_t *)a[3];                        /* chunks are multiples of 64 nodes: no word is shared */
 	for (uint64_t i = lo; i < hi; i++) {
+		if (end[i] != NO_NODE) vbits[i >> 6] |= 1ULL << (i & 63);
 		w[i].end = end[i];
 		w[i].ch = info[i] & 3u;
 		w[i].sm = (info[i] >> 2) & 1u;
@@ -515,7 +585,9 @@ static void device_walks(graph_t *g, int thin, int cut_len, walk_t *walks)
 	}
 	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the mirror is current as of now */
 	g->dn = 0;
-	void *a[3] = {walks, end, info};
+	if (!g->vbits) g->vbits = (uint64_t *)malloc(((g->n >> 6) + 2) * sizeof(uint64_t));
+	memset(g->vbits, 0, ((g->n >> 6) + 2) * sizeof(uint64_t));
+	void *a[4] = {walks, end, info, g->vbits};
 	par_for(0, g->n, 1 << 16, unpack_walks, a);
 	free(end);
 	free(info);
@@ -531,7 +603,7 @@ uint64_t graph_remove_single_tips(graph_t *g)
 	if (g->dev_walks) {
 		device_walks(g, 1, 2 * g->K, c.walks);
 		SUBPHASE("single tips: device walks");
-		commit_tips(g, 0, g->n, 2 * g->K, 1, &tips, c.walks, g->dirty);
+		commit_tips_sparse(g, 0, g->n, 2 * g->K, 1, &tips, c.walks);
 		SUBPHASE("single tips: commit");
 	} else {
 		sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
@@ -557,7 +629,7 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
 		while (changed)                                /* fixed point PER SET before the next set (:385-408) */
-			changed = g->dev_walks ? commit_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, c.walks, g->dirty)
+			changed = g->dev_walks ? commit_tips_sparse(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, c.walks)
 			                       : sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
 		printf("kmer set %d done\n", s);
 	}

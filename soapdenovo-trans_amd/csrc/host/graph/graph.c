@@ -123,6 +123,63 @@ static void replay_put(replay_t *r, const gnode_t *nodes, int64_t id, int nw)
 	r->count++;
 }
 
+/* ---- the same replay for 1-word keys with the key kept next to the node id: a rehash then walks the old slots
+ * in order and touches one random cache line per entry (its new slot) instead of two (plus the 48-byte node) ---- */
+typedef struct { int64_t id; uint64_t key; } rslot1;
+typedef struct {
+	rslot1 *slot;
+	uint8_t *moved;
+	uint64_t size, count, max;
+	double lf;
+} replay1_t;
+
+static void replay1_grow(replay1_t *r)
+{
+	uint64_t n = r->size;
+	do {
+		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
+		n = next_prime_kh(n);
+	} while (n * r->lf < (double)(r->count + 1));
+	const uint64_t old = r->size;
+	rslot1 *ns = (rslot1 *)malloc(n * sizeof(rslot1));
+	for (uint64_t i = 0; i < n; i++) ns[i].id = -1;
+	r->moved = (uint8_t *)realloc(r->moved, old);
+	memset(r->moved, 0, old);
+	for (uint64_t i = 0; i < old; i++) {
+		if (r->slot[i].id < 0 || r->moved[i]) continue;
+		rslot1 carry = r->slot[i];
+		r->moved[i] = 1;
+		for (;;) {
+			uint64_t h = carry.key % n;
+			while (ns[h].id >= 0) h = h + 1 == n ? 0 : h + 1;
+			if (h < old && r->slot[h].id >= 0 && !r->moved[h]) {        /* see replay_grow */
+				const rslot1 evicted = r->slot[h];
+				r->moved[h] = 1;
+				ns[h] = carry;
+				carry = evicted;
+				continue;
+			}
+			ns[h] = carry;
+			break;
+		}
+	}
+	free(r->slot);
+	r->slot = ns;
+	r->size = n;
+	r->max = (uint64_t)(n * r->lf);
+}
+
+static inline void replay1_put(replay1_t *r, int64_t id, uint64_t key)
+{
+	if (r->count + 1 > r->max)
+		replay1_grow(r);
+	uint64_t h = key % r->size;
+	while (r->slot[h].id >= 0) h = h + 1 == r->size ? 0 : h + 1;
+	r->slot[h].id = id;
+	r->slot[h].key = key;
+	r->count++;
+}
+
 /* ---- our own lookup index ---- */
 static inline uint64_t mix_key(const kw_t *k)
 {
@@ -155,11 +212,36 @@ gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller)
 	exit(1);
 }
 
+#include <time.h>
+static double gb_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 typedef struct { uint64_t first; uint64_t id; } ord_t;
 static int cmp_ord(const void *a, const void *b)
 {
 	const ord_t *x = (const ord_t *)a, *y = (const ord_t *)b;
 	return x->first < y->first ? -1 : x->first > y->first;
+}
+
+/* first-occurrence ordinals are unique, dense-ish 64-bit integers: LSD radix sort, 8 bits per pass, skipping the
+ * bytes that are the same in every key (a qsort of the 23 M nodes of one set of a 50 M-read run took ~3 s) */
+static void sort_ord(ord_t *a, uint64_t n)
+{
+	if (n < 4096) { qsort(a, (size_t)n, sizeof(ord_t), cmp_ord); return; }
+	ord_t *tmp = (ord_t *)malloc((size_t)n * sizeof(ord_t));
+	if (!tmp) { qsort(a, (size_t)n, sizeof(ord_t), cmp_ord); return; }
+	uint64_t all_or = 0, all_and = ~(uint64_t)0;
+	for (uint64_t i = 0; i < n; i++) { all_or |= a[i].first; all_and &= a[i].first; }
+	const uint64_t varying = all_or ^ all_and;
+	ord_t *src = a, *dst = tmp;
+	for (int shift = 0; shift < 64; shift += 8) {
+		if (!((varying >> shift) & 0xFF)) continue;
+		uint64_t cnt[257] = {0};
+		for (uint64_t i = 0; i < n; i++) cnt[((src[i].first >> shift) & 0xFF) + 1]++;
+		for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+		for (uint64_t i = 0; i < n; i++) dst[cnt[(src[i].first >> shift) & 0xFF]++] = src[i];
+		ord_t *t = src; src = dst; dst = t;
+	}
+	if (src != a) memcpy(a, src, (size_t)n * sizeof(ord_t));
+	free(tmp);
 }
 
 /* ---- small fork/join helper: the replay of one set is independent of every other set, and so are node
@@ -230,7 +312,31 @@ static void job_replay(build_job *J, int tid)
 		const int s = __sync_fetch_and_add(&J->next_set, 1);
 		if (s >= g->p) break;
 		const uint64_t b = J->per_set[s], e = J->per_set[s + 1];
-		qsort(J->ord + b, (size_t)(e - b), sizeof(ord_t), cmp_ord);
+		const double t_s0 = getenv("SDT_TIMING") ? gb_now() : 0;
+		sort_ord(J->ord + b, e - b);
+		if (t_s0 > 0 && s == 0) fprintf(stderr, "[graph]      set 0: sort %9.1f ms (%llu nodes)\n", gb_now() - t_s0, (unsigned long long)(e - b));
+		uint64_t out = b;                                  /* every node of the set is placed: the set fills [b, e) */
+		if (g->nw == 1) {
+			replay1_t r;
+			memset(&r, 0, sizeof r);
+			r.size = next_prime_kh(1024);                 /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
+			r.max = (uint64_t)(r.size * 0.77f);
+			r.lf = (double)0.77f;
+			r.slot = (rslot1 *)malloc(r.size * sizeof(rslot1));
+			for (uint64_t i = 0; i < r.size; i++) r.slot[i].id = -1;
+			for (uint64_t i = b; i < e; i++) {
+				if (i + 16 < e) __builtin_prefetch(&J->tmp[J->ord[i + 16].id].seq.w[3]);
+				replay1_put(&r, (int64_t)J->ord[i].id, J->tmp[J->ord[i].id].seq.w[3]);
+			}
+			if (t_s0 > 0 && s == 0) fprintf(stderr, "[graph]      set 0: sort + puts %9.1f ms\n", gb_now() - t_s0);
+			for (uint64_t i = 0; i < r.size; i++) {
+				if (i + 8 < r.size && r.slot[i + 8].id >= 0) __builtin_prefetch(&J->tmp[r.slot[i + 8].id]);
+				if (r.slot[i].id >= 0) g->nodes[out++] = J->tmp[r.slot[i].id];
+			}
+			free(r.slot);
+			free(r.moved);
+			continue;
+		}
 		replay_t r;
 		memset(&r, 0, sizeof r);
 		r.size = next_prime_kh(1024);                     /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
@@ -240,7 +346,6 @@ static void job_replay(build_job *J, int tid)
 		for (uint64_t i = 0; i < r.size; i++) r.slot[i] = -1;
 		for (uint64_t i = b; i < e; i++)
 			replay_put(&r, J->tmp, (int64_t)J->ord[i].id, g->nw);
-		uint64_t out = b;                                  /* every node of the set is placed: the set fills [b, e) */
 		for (uint64_t i = 0; i < r.size; i++)
 			if (r.slot[i] >= 0) g->nodes[out++] = J->tmp[r.slot[i]];
 		free(r.slot);
@@ -277,8 +382,6 @@ static void job_scatter_sets(build_job *J, int tid)
 	}
 }
 
-#include <time.h>
-static double gb_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 #define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
@@ -337,5 +440,5 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 void graph_free(graph_t *g)
 {
 	if (!g) return;
-	free(g->nodes); free(g->set_start); free(g->index); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g);
+	free(g->nodes); free(g->set_start); free(g->index); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g->vbits); free(g);
 }

@@ -48,9 +48,12 @@ typedef struct graph_s {
 	 * sends them over, and the commit uses the same marks to tell which recorded walks are still what the
 	 * reference would walk. */
 	uint8_t *dirty;
+	uint64_t *vbits;                   /* 1 bit per node: a sweep has to look at it (recorded walk, or written since) */
 	uint64_t *dlist;
 	size_t dn, dcap;
 	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t *end, uint8_t *info);   /* 0 = ok */
+	/* removeMinorOut's dry run from the device: malloc'ed records (9 words each, sdt_gpu_minor_out_dry) */
+	int (*dev_minor_out)(struct graph_s *g, double threshold, uint64_t **records, uint64_t *n_junctions, uint64_t *n_records);
 	void *dev_user;
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
 	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */

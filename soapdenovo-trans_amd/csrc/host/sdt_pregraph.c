@@ -96,7 +96,8 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
  * node from it (sdt_gpu_tip_walks) */
 typedef struct { sdt_ctx *gpu; int nwk, indexed; } dev_state;
 
-static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t *end, uint8_t *info)
+/* the device table mirrors the host graph: node order known to the device, nodes written since the last call sent over */
+static int dev_mirror_sync(graph_t *g)
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	const int nwk = D->nwk;
@@ -122,6 +123,30 @@ static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t *end, uint
 		free(k); free(l); free(r);
 		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_update_nodes: %s\n", sdt_gpu_last_error()); return 1; }
 	}
+	return 0;
+}
+
+static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, uint64_t *nj, uint64_t *nr)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	if (dev_mirror_sync(g) != 0) return 1;
+	uint64_t cap = g->n / 16 + 4096;
+	for (;;) {
+		uint64_t *rec = (uint64_t *)malloc(cap * 9 * sizeof(uint64_t));
+		if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)cap); return 1; }
+		const int rc = sdt_gpu_minor_out_dry(D->gpu, threshold, rec, cap, nj, nr);
+		if (rc == SDT_OK) { *records = rec; return 0; }
+		free(rec);
+		if (rc == SDT_EFULL && *nr > cap) { cap = *nr; continue; }
+		fprintf(stderr, "sdt_gpu_minor_out_dry: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+}
+
+static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t *end, uint8_t *info)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	if (dev_mirror_sync(g) != 0) return 1;
 	if (sdt_gpu_tip_walks(D->gpu, thin, cut_len, end, info, g->n) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_tip_walks: %s\n", sdt_gpu_last_error());
 		return 1;
@@ -235,11 +260,12 @@ int main(int argc, char **argv)
 		if (gpu && !host_walks) {                                          /* tip walks from the device mirror of the graph */
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
 			G->dev_walks = dev_walks_hook;
+			G->dev_minor_out = dev_minor_out_hook;
 			G->dev_user = &D;
 		}
 		time_t t0 = time(NULL);
 		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
-		phase("removeMinorOut (host)");
+		phase(G->dev_minor_out ? "removeMinorOut (GPU dry run + host commit)" : "removeMinorOut (host)");
 		printf("time spent on cut kmer: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		if (!d) graph_remove_single_tips(G);                               /* pregraph.c:75-88 */

@@ -1737,6 +1737,61 @@ int sdt_gpu_align_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nword
 	return SDT_OK;
 }
 
+int sdt_gpu_minor_out_dry(sdt_ctx *c, double threshold, uint64_t *records, uint64_t max_records, uint64_t *n_junctions, uint64_t *n_records)
+{
+	if (!c || (!records && max_records) || !n_junctions || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_idx || c->idx_slots != c->slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	HIPCHK(hipSetDevice(c->device));
+	uint8_t *d_need = nullptr, *d_flag = nullptr;
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr;
+	unsigned long long h1 = 0, h2 = 0;
+	int ret = SDT_OK;
+	const uint64_t n = c->idx_n ? c->idx_n : 1, m = max_records ? max_records : 1;
+#define MO_CHK(expr) do { hipError_t e5_ = (expr); if (e5_ != hipSuccess) { ret = fail(e5_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e5_)); goto done; } } while (0)
+	MO_CHK(hipMalloc((void **)&d_need, n));
+	MO_CHK(hipMalloc((void **)&d_flag, n));
+	MO_CHK(hipMalloc((void **)&d_rec, m * 9 * sizeof(uint64_t)));
+	MO_CHK(hipMalloc((void **)&d_cur, sizeof(unsigned long long)));
+	MO_CHK(hipMemsetAsync(d_need, 0, n, c->stream));
+	MO_CHK(hipMemsetAsync(d_flag, 0, n, c->stream));
+	MO_CHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream));
+	{
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_minor_out_junctions<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_minor_out_junctions<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else hipLaunchKernelGGL(k_minor_out_junctions<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		MO_CHK(hipGetLastError());
+		MO_CHK(hipMemcpyAsync(&h1, d_cur, sizeof h1, hipMemcpyDeviceToHost, c->stream));
+		if (c->nw == 1) hipLaunchKernelGGL(k_minor_out_candidates<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_minor_out_candidates<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else hipLaunchKernelGGL(k_minor_out_candidates<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		MO_CHK(hipGetLastError());
+		MO_CHK(hipMemcpyAsync(&h2, d_cur, sizeof h2, hipMemcpyDeviceToHost, c->stream));
+	}
+	ret = sync_stats(c);
+	if (ret != SDT_OK) {
+		ret = fail(SDT_ESTATE, "sdt_gpu_minor_out_dry: %llu links point at k-mers that are not nodes", (unsigned long long)c->h_stats->probe_fail);
+		goto done;
+	}
+	*n_junctions = h1;
+	*n_records = h2;
+	if (h2 > max_records) {
+		ret = fail(SDT_EFULL, "record array holds %llu, the pass needs %llu", (unsigned long long)max_records, h2);
+		goto done;
+	}
+	if (h2) MO_CHK(hipMemcpy(records, d_rec, h2 * 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+done:
+#undef MO_CHK
+	if (d_need) (void)hipFree(d_need);
+	if (d_flag) (void)hipFree(d_flag);
+	if (d_rec) (void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return ret;
+}
+
 int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)
 {
 	if (!c)

@@ -425,3 +425,135 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
 	if (missing)
 		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// removeMinorOut's read-only part (cutTipPreGraph.c:1012-1076, clipKmerFromNode :591-1010, getmaxofprev/next :439-589)
+// on the device mirror: for every junction (in > 1 or out > 1, not linear, not deleted) look its neighbours up,
+// take the largest occurrence count per branching side and flag the neighbours whose count / max is under the
+// threshold.  Links only disappear during the pass, so the cuts the ordered commit really makes are a subset of
+// these; the host needs, per flagged junction and per flagged neighbour, who their neighbours ARE -- which never
+// changes -- to run that commit without a single hash look-up.
+// Record = 9 words: host index of the node, then (neighbour host index << 1 | smaller) or ~0 for LEFT 0..3, RIGHT 0..3.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW> __device__ inline Key<NW> key_prev_base(const Key<NW> &k, uint32_t b, int K)
+{
+	Key<NW> r = key_shr<NW>(k, 2);
+	const int tb = 2 * (K - 1);
+#pragma unroll
+	for (int w = 0; w < NW; w++)
+		if (w == NW - 1 - (tb >> 6)) r.w[w] |= (uint64_t)b << (tb & 63);
+	return r;
+}
+
+template <int NW>
+__device__ inline void neighbours_of(const Table<NW> &tbl, const uint64_t *__restrict__ idx, const Entry<NW> &e, int K, const Key<NW> &mask,
+                                     uint64_t out[8], uint32_t cnt[8], uint32_t &missing)
+{
+	Key<NW> me;
+#pragma unroll
+	for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+#pragma unroll
+	for (int side = 0; side < 2; side++)
+#pragma unroll
+		for (uint32_t b = 0; b < 4; b++) {
+			const int q = side * 4 + (int)b;
+			out[q] = ~0ULL;
+			cnt[q] = 0;
+			if (!((e.val >> (24 * side + 6 * b)) & 63u)) continue;
+			const Key<NW> word = side == 0 ? key_prev_base<NW>(me, b, K) : key_next_masked<NW>(me, b, mask);
+			const Key<NW> bal = key_revcomp<NW>(word, K);
+			const bool sm = !key_less<NW>(bal, word);
+			uint64_t ns;
+			if (!find_slot<NW>(tbl, sm ? word : bal, ns)) { missing++; continue; }
+			out[q] = (idx[ns] << 1) | (uint64_t)sm;
+			cnt[q] = (uint32_t)(tbl.ent[ns].val >> 48) | ((tbl.aux[ns] & 0xFFFFu) << 16);
+		}
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, double threshold,
+                                                             uint8_t *__restrict__ need, uint8_t *__restrict__ flagged,
+                                                             uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
+                                                             Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
+		const uint32_t in = dev_degree(e.val & 0xFFFFFFu), out = dev_degree((e.val >> 24) & 0xFFFFFFu);
+		if (in <= 1 && out <= 1) continue;
+		uint64_t nb[8];
+		uint32_t cnt[8];
+		neighbours_of<NW>(tbl, idx, e, K, mask, nb, cnt, missing);
+		bool any = false;
+#pragma unroll
+		for (int side = 0; side < 2; side++) {
+			if ((side == 0 ? in : out) <= 1) continue;
+			int best = 0;
+#pragma unroll
+			for (int b = 0; b < 4; b++)
+				if (nb[side * 4 + b] != ~0ULL && (int)cnt[side * 4 + b] > best) best = (int)cnt[side * 4 + b];
+			if (!best) continue;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int c = (int)cnt[side * 4 + b];
+				if (nb[side * 4 + b] != ~0ULL && c && (double)c / best < threshold) {
+					need[nb[side * 4 + b] >> 1] = 1;
+					any = true;
+				}
+			}
+		}
+		if (!any) continue;
+		const uint64_t me = idx[s];
+		flagged[me] = 1;
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		if (r < max_rec) {
+			rec[r * 9] = me;
+#pragma unroll
+			for (int q = 0; q < 8; q++) rec[r * 9 + 1 + q] = nb[q];
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+// neighbours of the flagged neighbours (isolate() walks them), unless the node already has a junction record
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, const uint64_t *__restrict__ idx, int K,
+                                                              const uint8_t *__restrict__ need, const uint8_t *__restrict__ flagged,
+                                                              uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
+                                                              Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		const uint64_t me = idx[s];
+		if (!need[me] || flagged[me]) continue;
+		uint64_t nb[8];
+		uint32_t cnt[8];
+		neighbours_of<NW>(tbl, idx, e, K, mask, nb, cnt, missing);
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		if (r < max_rec) {
+			rec[r * 9] = me;
+#pragma unroll
+			for (int q = 0; q < 8; q++) rec[r * 9 + 1 + q] = nb[q];
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}

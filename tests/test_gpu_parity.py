@@ -626,3 +626,76 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(pkg, tmp_path):
     assert b["n_gpus"] == 2 and "owner-sharded" in b["config"]["parallelism"]
     for k in ("kmers", "distinct_nodes", "linear_nodes"):
         assert a["config"][k] == b["config"][k], k
+
+
+def py_minor_out_dry(keys_int, l, rf, cnt, K, threshold):
+    """removeMinorOut's junction test (cutTipPreGraph.c:591-1010, 1012-1076) restated on Python ints:
+    {junction index: [8 neighbour entries]} for the junctions that would cut, and the set of neighbours to cut"""
+    idx = {k: i for i, k in enumerate(keys_int)}
+    mask = (1 << (2 * K)) - 1
+    NONE = (1 << 64) - 1
+
+    def nbrs(i):
+        k, out = keys_int[i], []
+        for side in range(2):
+            links = int(l[i]) & 0xFFFFFF if side == 0 else int(rf[i]) & 0xFFFFFF
+            for b in range(4):
+                if not (links >> (6 * b)) & 63:
+                    out.append(NONE)
+                    continue
+                word = ((k >> 2) | (b << (2 * (K - 1)))) if side == 0 else (((k << 2) | b) & mask)
+                bal = _rc_int(word, K)
+                sm = 0 if word > bal else 1
+                out.append((idx[word if sm else bal] << 1) | sm)
+        return out
+
+    junc, need = {}, set()
+    for i in range(len(keys_int)):
+        if (int(rf[i]) >> 24) & 3:                       # linear or deleted
+            continue
+        deg = [_deg(int(l[i]) & 0xFFFFFF), _deg(int(rf[i]) & 0xFFFFFF)]
+        if deg[0] <= 1 and deg[1] <= 1:
+            continue
+        e = nbrs(i)
+        hit = False
+        for side in range(2):
+            if deg[side] <= 1:
+                continue
+            cs = [int(cnt[v >> 1]) if v != NONE else None for v in e[side * 4: side * 4 + 4]]
+            best = max([c for c in cs if c is not None] + [0])
+            if not best:
+                continue
+            for v, c in zip(e[side * 4: side * 4 + 4], cs):
+                if c and c / best < threshold:
+                    need.add(v >> 1)
+                    hit = True
+        if hit:
+            junc[i] = e
+    return junc, need, nbrs
+
+
+@pytest.mark.parametrize("K,L", [(21, 100), (31, 150), (47, 150), (75, 200)])
+def test_minor_out_dry_run_equals_reference_rule(pkg, synth, K, L):
+    """the device dry run of removeMinorOut: the set of junctions that would cut, the neighbours to cut, and the
+    neighbour tables of both == the restated rule, on an arbitrary host order"""
+    tx = synth.make_transcriptome(15, seed=K + 1)
+    codes, offs = synth.sample_reads(*tx, n_reads=4000, read_len=L, seed=K + 5, err=0.006)
+    rng = np.random.default_rng(K)
+    with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        perm = rng.permutation(len(keys))
+        keys, l, rf, cnt = keys[perm], l[perm], rf[perm], cnt[perm]
+        ki = keys_to_int(keys)
+        g.set_node_index(keys)
+        for thr in (0.05, 0.3):
+            rec, nj = g.minor_out_dry(thr)
+            junc, need, nbrs = py_minor_out_dry(ki, l, rf, cnt, K, thr)
+            got_j = {int(r[0]): [int(x) for x in r[1:]] for r in rec[:nj]}
+            assert got_j == junc and len(junc) > 0
+            got_c = {int(r[0]): [int(x) for x in r[1:]] for r in rec[nj:]}
+            assert set(got_c) == need - set(junc)
+            for i, e in got_c.items():
+                assert e == nbrs(i)
