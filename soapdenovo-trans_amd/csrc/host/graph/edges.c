@@ -344,8 +344,13 @@ static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
 	free(c.b);
 }
 
+#include <time.h>
+static double ed_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define EPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = ed_now(); fprintf(stderr, "[edges]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
+
 uint64_t graph_build_edges(graph_t *g, const char *prefix)
 {
+	double t_sub = ed_now();
 	edges_ctx E;
 	E.g = g;
 	E.starts = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
@@ -353,7 +358,9 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	for (uint64_t i = 0; i < g->n; i++)
 		if (!g->nodes[i].linear && !g->nodes[i].deleted) E.starts[E.nstarts++] = i;
 	E.ports = (port_t *)calloc(E.nstarts * 8 + 8, sizeof(port_t));
+	EPHASE("collect starts");
 	par_for(0, E.nstarts, 256, dry_ports, &E);
+	EPHASE("dry walks");
 	/* node index -> start slot, for far ends that are start-eligible themselves */
 	uint64_t *slot_of = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
 	memset(slot_of, 0xFF, (g->n + 1) * sizeof(uint64_t));
@@ -384,6 +391,7 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	}
 	free(zeroed);
 	free(slot_of);
+	EPHASE("ordered ids");
 	if (!symmetric) {
 		free(emit); free(E.ports); free(E.starts);
 		return build_edges_sequential(g, prefix);
@@ -410,8 +418,10 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		if (kw_less(&plus, &bal)) patch_put(g, &plus, P->id, (uint8_t)(P->bal_edge + 1));
 		else patch_put(g, &bal, P->id + (uint32_t)P->bal_edge, (uint8_t)(1 - P->bal_edge));
 	}
+	EPHASE("patch table");
 	stamp_ctx S = {g, &E, emit, nemit};
 	par_for(0, nemit, 64, stamp_edges, &S);
+	EPHASE("stamp + text");
 	char name[4200];
 	snprintf(name, sizeof name, "%s.edge.gz", prefix);
 	gzFile fp = gzopen(name, "w1");
@@ -423,6 +433,7 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		free(P->text);
 	}
 	gzclose(fp);
+	EPHASE("gzip write");
 	g->num_ed = num_ed;
 	printf("%llu (%llu) edges %llu extra nodes\n", (unsigned long long)num_ed, (unsigned long long)nemit, (unsigned long long)extra);
 	free(emit); free(E.ports); free(E.starts);

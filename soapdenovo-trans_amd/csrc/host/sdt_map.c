@@ -343,6 +343,28 @@ static void fmt_blocks(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
+typedef struct { fmt_ctx *F; int fd[3]; off_t *off[3]; volatile int failed; } pw_ctx;
+
+static void pwrite_all(pw_ctx *W, int fd, const char *p, size_t n, off_t off)
+{
+	while (n) {
+		const ssize_t w = pwrite(fd, p, n, off);
+		if (w <= 0) { W->failed = 1; return; }
+		p += w; n -= (size_t)w; off += w;
+	}
+}
+
+static void pwrite_blocks(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	pw_ctx *W = (pw_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		pwrite_all(W, W->fd[0], W->F->ro[b].p, W->F->ro[b].n, W->off[0][b]);
+		pwrite_all(W, W->fd[1], W->F->c2[b].p, W->F->c2[b].n, W->off[1][b]);
+		if (W->fd[2] >= 0) pwrite_all(W, W->fd[2], W->F->ri[b].p, W->F->ri[b].n, W->off[2][b]);
+	}
+}
+
 static void usage(void)
 {
 	printf("\nmap -s configFile -g inputGraph [-p n_cpu -K kmer -r]\n");
@@ -596,6 +618,8 @@ int main(int argc, char **argv)
 		const int nt = par_threads();
 		const uint64_t block = 1 << 18;
 		const uint64_t nblocks = (total + block - 1) / block;
+		fflush(fo); fflush(f3);
+		off_t pos_ro = ftello(fo), pos_c2 = ftello(f3), pos_ri = 0;
 		fmt_ctx F = {S, ns, K, read_trace, ctg_len, ctg_twin, total, block, 0, (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)),
 		             (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)), (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)),
 		             (long long *)calloc((size_t)nt * 2, sizeof(long long)), (long long *)calloc((size_t)nt * 2, sizeof(long long))};
@@ -603,13 +627,20 @@ int main(int argc, char **argv)
 			const uint64_t n = nblocks - first < (uint64_t)nt * 2 ? nblocks - first : (uint64_t)nt * 2;
 			F.wave_first = first;
 			par_for(0, n, 1, fmt_blocks, &F);
+			/* every block knows its size now: give it its place in the file and let the threads write side by side */
+			fflush(fo); fflush(f3);
+			if (f4) fflush(f4);
+			pw_ctx W = {&F, {fileno(fo), fileno(f3), f4 ? fileno(f4) : -1}, {(off_t *)malloc(n * sizeof(off_t)), (off_t *)malloc(n * sizeof(off_t)), (off_t *)malloc(n * sizeof(off_t))}, 0};
 			for (uint64_t b = 0; b < n; b++) {
-				fwrite(F.ro[b].p, 1, F.ro[b].n, fo);
-				fwrite(F.c2[b].p, 1, F.c2[b].n, f3);
-				if (f4) fwrite(F.ri[b].p, 1, F.ri[b].n, f4);
+				W.off[0][b] = pos_ro; pos_ro += (off_t)F.ro[b].n;
+				W.off[1][b] = pos_c2; pos_c2 += (off_t)F.c2[b].n;
+				W.off[2][b] = pos_ri; pos_ri += (off_t)F.ri[b].n;
 				map_counter += F.mapped[b];
 				overflowed += F.overflowed[b];
 			}
+			par_for(0, n, 1, pwrite_blocks, &W);
+			free(W.off[0]); free(W.off[1]); free(W.off[2]);
+			if (W.failed) { printf("write error on the read-to-contig files\n"); return 255; }
 		}
 		for (int b = 0; b < nt * 2; b++) { free(F.ro[b].p); free(F.c2[b].p); free(F.ri[b].p); }
 		free(F.ro); free(F.c2); free(F.ri); free(F.mapped); free(F.overflowed);
