@@ -57,8 +57,10 @@ typedef struct sdt_ctx sdt_ctx;
 #define SDT_FLAG_CONTIG_INDEX 16u
 
 /* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
- * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 with
- * prev/next the neighbour base codes 0..3 or SDT_REC_NB_NONE (prlHashReads.c:215-230,275-308). */
+ * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 | (ordinal + 1) << 6
+ * with prev/next the neighbour base codes 0..3 or SDT_REC_NB_NONE (prlHashReads.c:215-230,275-308) and, when the
+ * extracting context tracks first occurrences, the occurrence's ordinal (read ordinal << 16 | position; 0 = none), so
+ * that a table filled through the exchange orders its nodes exactly like one filled directly. */
 #define SDT_REC_NB_NONE 4
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(TPB) void k_extract_route(const uint32_t *__restric
                                                        Record<NW> *__restrict__ out,
                                                        const unsigned long long *__restrict__ displs,
                                                        unsigned long long *__restrict__ cursors,
-                                                       unsigned long long cap_per_rank, Stats *stats)
+                                                       unsigned long long cap_per_rank, Stats *stats,
+                                                       uint64_t ord_base, uint64_t ord_stride, int with_ord)
 {
 	// Per tile: count the records per owner rank in LDS, reserve each owner's run with ONE global atomic, then chop
 	// again and write.  (One atomic per wave and owner was measured to serialise on the nranks cursor words:
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(TPB) void k_extract_route(const uint32_t *__restric
 #pragma unroll
 				for (int i = 0; i < NW; i++)
 					rec.key[i] = key.w[i];
-				rec.meta = (uint64_t)prev | ((uint64_t)next << 3);
+				// first-occurrence tracking travels with the record: ordinal + 1 above the two neighbour codes
+				const uint64_t ord = ((ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride) << 16) | (uint64_t)j;
+				rec.meta = (uint64_t)prev | ((uint64_t)next << 3) | (with_ord ? (ord + 1) << 6 : 0ULL);
 				out[displs[owner] + pos] = rec;
 			} else {
 				failed++;
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(TPB) void k_insert_records(const Record<NW> *__rest
 #pragma unroll
 		for (int w = 0; w < NW; w++)
 			key.w[w] = rec.key[w];
-		if (!table_put<NW>(tbl, key, (uint32_t)(rec.meta & 7u), (uint32_t)((rec.meta >> 3) & 7u), claimed))
+		const uint64_t ordp1 = rec.meta >> 6;
+		if (!table_put<NW>(tbl, key, (uint32_t)(rec.meta & 7u), (uint32_t)((rec.meta >> 3) & 7u), claimed, ordp1 ? ordp1 - 1 : ORD_NONE))
 			failed++;
 		done++;
 	}
@@ -1161,12 +1165,13 @@ int sdt_gpu_extract_route(sdt_ctx *c, const void *d_packed_words, uint64_t nword
 	const uint64_t gcap = (uint64_t)c->cu_count * 4;
 	if (grid > gcap) grid = gcap;
 	if (c->nw == 1)
-		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
 	else if (c->nw == 2)
-		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
 	else
-		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats);
+		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
 	HIPCHK(hipGetLastError());
+	c->ord_base += nreads * c->ord_stride;         // the next batch continues the read stream
 	return SDT_OK;
 }
 

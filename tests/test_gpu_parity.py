@@ -215,6 +215,30 @@ def test_route_then_insert_equals_direct(pkg, synth):
         kmers, nodes = g.finish_count()
         assert (kmers, nodes) == (total, o.node_count())
         assert (g.mark_and_hist()[0] == ohist).all()
+    # first-occurrence ordinals travel with the records: routed + inserted == counted directly (two extract calls:
+    # the ordinal base carries over like between pushes)
+    with pkg.PregraphGPU(K, est_distinct=1 << 20, flags=pkg.SDT_FLAG_TRACK_FIRST) as g, \
+            pkg.PregraphGPU(K, est_distinct=1 << 20, flags=pkg.SDT_FLAG_TRACK_FIRST) as d:
+        d.push_reads(synth.pack_2bit(codes), offs)
+        d.finish_count()
+        half = n // 2
+        w2 = torch.from_numpy(synth.pack_2bit(codes[int(offs[half]):]).view(np.int32)).to(dev)
+        o2 = torch.from_numpy((offs[half:] - offs[half]).astype(np.int64)).to(dev)
+        for wv, ov, nr in ((words, offsets, half), (w2, o2, n - half)):
+            counts.zero_()
+            torch.cuda.synchronize()
+            g.extract_route(wv, wv.numel(), ov, nr, L, nranks, recs, cap, counts, displs)
+            g.finish_count()
+            torch.cuda.synchronize()
+            c, dd = counts.cpu().numpy(), displs.cpu().numpy()
+            for r in range(nranks):
+                g.insert_records(recs.view(-1, 2)[dd[r]: dd[r] + c[r]].contiguous(), int(c[r]))
+            g.finish_count()
+        ka, la, ra, ca, fa = g.export_nodes(with_first=True)
+        kb, lb, rb_, cb, fb = d.export_nodes(with_first=True)
+        A = {int(k[0]): (int(x), int(y), int(z), int(f)) for k, x, y, z, f in zip(ka, la, ra, ca, fa)}
+        B = {int(k[0]): (int(x), int(y), int(z), int(f)) for k, x, y, z, f in zip(kb, lb, rb_, cb, fb)}
+        assert A == B
 
 
 @pytest.mark.parametrize("K,stride,base", [(21, 1, 0), (35, 2, 1)])
