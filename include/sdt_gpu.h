@@ -150,7 +150,8 @@ int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32
  *     bit 0 skip = deleted || (linear && !inEdge) (:650) | bit 1 linear | bits 2..3 twin | bits 32..63 l_links = edge id
  * and the (K+1)-mers of length-1 edges (KmerSetsPatch, node2edge.c:404-463) come as patch_keys (key_words()
  * words each, most significant first) with patch_info = edge id | twin << 32.  load_paths overwrites the
- * nodes' counters with the path words (export the table first).  map_reads then replays parse1read (:617-789),
+ * nodes' counters with the path words (export the table first); keys == NULL: path_words[i] belongs to node i of
+ * sdt_gpu_set_node_index (no keys to send, no look-ups).  map_reads then replays parse1read (:617-789),
  * search1kmerPlus (:575-615) and the arc counting (:190-241,415-430) over the kept reads; export_arcs returns
  * every arc with its multiplicity and the ordinal of its first appearance ((read ordinal << 16) | item index):
  * per from-edge the reference prints arcs most-recent-first-appearance first (:427-428,472-496). */
@@ -185,6 +186,10 @@ int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, ui
  *                   junctions themselves.  SDT_EFULL when records[] is too small: *n_records says what is needed. */
 int sdt_gpu_minor_out_dry(sdt_ctx *ctx, double threshold, uint64_t *records, uint64_t max_records,
                           uint64_t *n_junctions, uint64_t *n_records);
+/*   build_host_index: the host's k-mer -> node look-up table for the ordered commits (csrc/host/graph/graph.c:
+ *                   open addressing over index_slots = 2^m >= 2n words, home slot = mix_key(4-word k-mer) & (slots-1),
+ *                   linear probing, value = node index + 1, 0 = empty), filled by the device from its node index. */
+int sdt_gpu_build_host_index(sdt_ctx *ctx, uint64_t *index, uint64_t index_slots);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

@@ -384,6 +384,9 @@ static void job_scatter_sets(build_job *J, int tid)
 
 #define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
+int (*graph_index_hook)(graph_t *g, void *user) = NULL;
+void *graph_index_hook_user = NULL;
+
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first)
 {
@@ -428,6 +431,10 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	GB_PHASE("sort + replay per set");
 	free(J.ord); free(J.per_set); free(J.set_of); free(J.tmp);
 	/* index */
+	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {
+		GB_PHASE("index (device)");
+		return g;
+	}
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
 	g->index = (uint64_t *)calloc(cap, sizeof(uint64_t));

@@ -18,6 +18,7 @@
 #include "seqio.h"
 #include "readstream.h"
 #include "graph/graph.h"
+#include "graph/par.h"
 
 #ifndef SDT_MAX_K
 #define SDT_MAX_K 127        /* one binary covers the 31/63/127mer variants; --max-k emulates a smaller one */
@@ -96,6 +97,33 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
  * node from it (sdt_gpu_tip_walks) */
 typedef struct { sdt_ctx *gpu; int nwk, indexed; } dev_state;
 
+static void gather_keys(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	const graph_t *g = (const graph_t *)a[0];
+	uint64_t *k = (uint64_t *)a[1];
+	const int nwk = (int)(intptr_t)a[2];
+	for (uint64_t i = lo; i < hi; i++)
+		for (int w = 0; w < nwk; w++) k[i * nwk + w] = g->nodes[i].seq.w[4 - nwk + w];
+}
+
+/* what the second read pass needs of every node (sdt_gpu_load_paths): skip flag, linear, twin, edge id */
+static void gather_paths(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	const graph_t *G = (const graph_t *)a[0];
+	uint64_t *pk = (uint64_t *)a[1], *pw = (uint64_t *)a[2];
+	const int nwk = (int)(intptr_t)a[3];
+	for (uint64_t i = lo; i < hi; i++) {
+		const gnode_t *nd = &G->nodes[i];
+		if (pk) for (int w = 0; w < nwk; w++) pk[i * nwk + w] = nd->seq.w[4 - nwk + w];
+		const int skip = nd->deleted || (nd->linear && !nd->inEdge);
+		pw[i] = (uint64_t)skip | ((uint64_t)nd->linear << 1) | ((uint64_t)nd->twin << 2) | ((uint64_t)nd->l_links << 32);
+	}
+}
+
 /* the device table mirrors the host graph: node order known to the device, nodes written since the last call sent over */
 static int dev_mirror_sync(graph_t *g)
 {
@@ -103,8 +131,8 @@ static int dev_mirror_sync(graph_t *g)
 	const int nwk = D->nwk;
 	if (!D->indexed) {
 		uint64_t *k = (uint64_t *)malloc((g->n + 1) * (size_t)nwk * 8);
-		for (uint64_t i = 0; i < g->n; i++)
-			for (int w = 0; w < nwk; w++) k[i * nwk + w] = g->nodes[i].seq.w[4 - nwk + w];
+		void *ga[3] = {g, k, (void *)(intptr_t)nwk};
+		par_for(0, g->n, 1 << 16, gather_keys, ga);
 		const int rc = sdt_gpu_set_node_index(D->gpu, k, g->n);
 		free(k);
 		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_set_node_index: %s\n", sdt_gpu_last_error()); return 1; }
@@ -122,6 +150,23 @@ static int dev_mirror_sync(graph_t *g)
 		const int rc = sdt_gpu_update_nodes(D->gpu, k, l, r, g->dn);
 		free(k); free(l); free(r);
 		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_update_nodes: %s\n", sdt_gpu_last_error()); return 1; }
+	}
+	return 0;
+}
+
+/* graph_index_hook: the device knows every node's place in the host array, let it build the host's look-up index */
+static int dev_index_hook(graph_t *g, void *user)
+{
+	dev_state *D = (dev_state *)user;
+	g->dev_user = D;
+	if (dev_mirror_sync(g) != 0) exit(1);
+	uint64_t cap = 1024;
+	while (cap < 2 * g->n + 2) cap <<= 1;
+	g->index = (uint64_t *)malloc(cap * sizeof(uint64_t));
+	g->index_mask = cap - 1;
+	if (!g->index || sdt_gpu_build_host_index(D->gpu, g->index, cap) != SDT_OK) {
+		fprintf(stderr, "sdt_gpu_build_host_index: %s\n", sdt_gpu_last_error());
+		exit(1);
 	}
 	return 0;
 }
@@ -253,11 +298,15 @@ int main(int argc, char **argv)
 		if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 		if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
 		phase("export nodes (D2H)");
+		dev_state D = {gpu, nwk, 0};
+		if (gpu && !host_walks) {
+			graph_index_hook = dev_index_hook;
+			graph_index_hook_user = &D;
+		}
 		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
 		free(keys); free(first); free(ll); free(rf); free(cnt);
 		phase("layout replay + index (host)");
-		dev_state D = {gpu, nwk, 0};
-		if (gpu && !host_walks) {                                          /* tip walks from the device mirror of the graph */
+		if (gpu && !host_walks) {                                          /* dry runs from the device mirror of the graph */
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
 			G->dev_walks = dev_walks_hook;
 			G->dev_minor_out = dev_minor_out_hook;
@@ -286,13 +335,11 @@ int main(int argc, char **argv)
 			arcs_free(as.A);
 		} else {
 			/* second pass on the GPU over the reads kept in HBM: send the cleaned graph back as path words */
-			uint64_t *pk = (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8), *pw = (uint64_t *)malloc((G->n + 1) * 8);
-			for (uint64_t i = 0; i < G->n; i++) {
-				const gnode_t *nd = &G->nodes[i];
-				for (int w = 0; w < nwk; w++) pk[i * nwk + w] = nd->seq.w[4 - nwk + w];
-				const int skip = nd->deleted || (nd->linear && !nd->inEdge);
-				pw[i] = (uint64_t)skip | ((uint64_t)nd->linear << 1) | ((uint64_t)nd->twin << 2) | ((uint64_t)nd->l_links << 32);
-			}
+			/* with the device mirror in place the path words go over by node index; otherwise with their keys */
+			const int by_index = G->dev_walks != NULL && D.indexed;
+			uint64_t *pk = by_index ? NULL : (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8), *pw = (uint64_t *)malloc((G->n + 1) * 8);
+			void *pa[4] = {G, pk, pw, (void *)(intptr_t)nwk};
+			par_for(0, G->n, 1 << 16, gather_paths, pa);
 			uint64_t np = 0;
 			uint64_t *qk = (uint64_t *)malloc((G->patch_n + 1) * (size_t)nwk * 8), *qi = (uint64_t *)malloc((G->patch_n + 1) * 8);
 			for (uint64_t i = 0; G->patch && i <= G->patch_mask; i++)

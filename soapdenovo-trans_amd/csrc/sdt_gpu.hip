@@ -1306,24 +1306,34 @@ done:
 int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
                        const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed)
 {
-	if (!c || (n && (!keys || !path_words)) || (npatch && (!patch_keys || !patch_info)))
+	if (!c || (n && !path_words) || (npatch && (!patch_keys || !patch_info)))
 		return fail(SDT_EINVAL, "NULL argument");
+	const bool by_index = keys == nullptr;
+	if (by_index && n && (!c->d_idx || c->idx_slots != c->slots || c->idx_n != n))
+		return fail(SDT_ESTATE, "keys == NULL needs the node index of sdt_gpu_set_node_index for the same %llu nodes", (unsigned long long)n);
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	uint64_t *d_k = nullptr, *d_i = nullptr;
 	if (n) {
-		HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
+		if (!by_index) HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
 		hipError_t e = hipMalloc((void **)&d_i, n * sizeof(uint64_t));
-		if (e != hipSuccess) { (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
-		HIPCHK(hipMemcpyAsync(d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		if (e != hipSuccess) { if (d_k) (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
+		if (!by_index) HIPCHK(hipMemcpyAsync(d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipMemcpyAsync(d_i, path_words, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-		const int g = scan_grid(c, n);
-		if (c->nw == 1) hipLaunchKernelGGL(k_set_paths<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_i, n, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_set_paths<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_i, n, c->d_stats);
-		else hipLaunchKernelGGL(k_set_paths<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_i, n, c->d_stats);
+		if (by_index) {
+			const int g = scan_grid(c, c->slots);
+			if (c->nw == 1) hipLaunchKernelGGL(k_set_paths_by_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_i, n, c->d_stats);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_set_paths_by_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, d_i, n, c->d_stats);
+			else hipLaunchKernelGGL(k_set_paths_by_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, d_i, n, c->d_stats);
+		} else {
+			const int g = scan_grid(c, n);
+			if (c->nw == 1) hipLaunchKernelGGL(k_set_paths<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_i, n, c->d_stats);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_set_paths<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_i, n, c->d_stats);
+			else hipLaunchKernelGGL(k_set_paths<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_i, n, c->d_stats);
+		}
 		hipError_t le = hipGetLastError();
 		hipError_t se = hipStreamSynchronize(c->stream);
-		(void)hipFree(d_k);
+		if (d_k) (void)hipFree(d_k);
 		(void)hipFree(d_i);
 		if (le != hipSuccess || se != hipSuccess)
 			return fail(SDT_EHIP, "k_set_paths: %s", hipGetErrorString(le != hipSuccess ? le : se));
@@ -1795,6 +1805,33 @@ done:
 	if (d_rec) (void)hipFree(d_rec);
 	if (d_cur) (void)hipFree(d_cur);
 	return ret;
+}
+
+int sdt_gpu_build_host_index(sdt_ctx *c, uint64_t *index, uint64_t index_slots)
+{
+	if (!c || !index)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_idx || c->idx_slots != c->slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if (index_slots < 2 * c->idx_n || (index_slots & (index_slots - 1)))
+		return fail(SDT_EINVAL, "index_slots must be a power of two >= 2 x nodes");
+	HIPCHK(hipSetDevice(c->device));
+	unsigned long long *d_index = nullptr;
+	HIPCHK(hipMalloc((void **)&d_index, index_slots * sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d_index, 0, index_slots * sizeof(unsigned long long), c->stream);
+	if (e == hipSuccess) {
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_build_host_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_index, index_slots - 1);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_build_host_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, d_index, index_slots - 1);
+		else hipLaunchKernelGGL(k_build_host_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, d_index, index_slots - 1);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(d_index);
+	if (e != hipSuccess)
+		return fail(SDT_EHIP, "sdt_gpu_build_host_index: %s", hipGetErrorString(e));
+	return SDT_OK;
 }
 
 int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)

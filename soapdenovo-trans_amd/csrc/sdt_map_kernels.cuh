@@ -557,3 +557,50 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
+
+
+// the host's own look-up index over its node array (csrc/host/graph/graph.c: open addressing on mix_key of the
+// 4-word k-mer, value = node index + 1), built here because the device already knows every node's index
+__device__ inline uint64_t host_mix_key4(const uint64_t w[4])
+{
+	uint64_t h = 0x9E3779B97F4A7C15ULL;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		h ^= w[i];
+		h ^= h >> 32; h *= 0xD6E8FEB86659FD93ULL; h ^= h >> 32;
+	}
+	return h;
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const uint64_t *__restrict__ idx, unsigned long long *__restrict__ index,
+                                                          uint64_t index_mask)
+{
+	const uint64_t slots = tbl.mask + 1;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
+		uint64_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int i = 0; i < NW; i++) w[4 - NW + i] = tbl.ent[s].key[i];
+		uint64_t h = host_mix_key4(w) & index_mask;
+		const unsigned long long v = idx[s] + 1;
+		while (atomicCAS(&index[h], 0ULL, v) != 0ULL) h = (h + 1) & index_mask;
+	}
+}
+
+
+// k_set_paths when the device already knows each node's host index (sdt_gpu_set_node_index): no keys, no probing
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_set_paths_by_index(Table<NW> tbl, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ info, uint64_t n,
+                                                            Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	uint32_t failed = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
+		const uint64_t i = idx[s];
+		if (i < n) tbl.ent[s].val = info[i];
+		else failed++;
+	}
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
