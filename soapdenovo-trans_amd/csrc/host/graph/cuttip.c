@@ -79,13 +79,38 @@ static inline int one_in_one_out(const gnode_t *n) { return degree(n, LEFT) == 1
 static inline void unlink_prev(gnode_t *n, unsigned ch, int smaller) { if (smaller) drop_link(n, LEFT, ch); else drop_link(n, RIGHT, ch ^ 2u); }
 static inline void unlink_next(gnode_t *n, unsigned ch, int smaller) { if (smaller) drop_link(n, RIGHT, ch); else drop_link(n, LEFT, ch ^ 2u); }
 
-static uint64_t mark_linear(graph_t *g)
+/* Mark1in1outNode (cutTipPreGraph.c:1121-1229): a scan; the few nodes it marks are reported to touch() afterwards
+ * (the device mirror has to hear about them) */
+typedef struct { graph_t *g; uint64_t *list[64]; size_t n[64], cap[64]; } ml_ctx;
+
+static void mark_linear_part(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
-	uint64_t c = 0;
-	for (uint64_t i = 0; i < g->n; i++) {
+	ml_ctx *M = (ml_ctx *)vc;
+	graph_t *g = M->g;
+	for (uint64_t i = lo; i < hi; i++) {
 		gnode_t *n = &g->nodes[i];
 		if (n->deleted || n->linear) continue;
-		if (one_in_one_out(n)) { n->linear = 1; c++; touch(g, n); }
+		if (!one_in_one_out(n)) continue;
+		n->linear = 1;
+		if (M->n[tid] == M->cap[tid]) {
+			M->cap[tid] = M->cap[tid] ? M->cap[tid] * 2 : 1024;
+			M->list[tid] = (uint64_t *)realloc(M->list[tid], M->cap[tid] * sizeof(uint64_t));
+		}
+		M->list[tid][M->n[tid]++] = i;
+	}
+}
+
+static uint64_t mark_linear(graph_t *g)
+{
+	ml_ctx M;
+	memset(&M, 0, sizeof M);
+	M.g = g;
+	par_for(0, g->n, 1 << 16, mark_linear_part, &M);
+	uint64_t c = 0;
+	for (int t = 0; t < 64; t++) {
+		for (size_t k = 0; k < M.n[t]; k++) touch(g, &g->nodes[M.list[t][k]]);
+		c += M.n[t];
+		free(M.list[t]);
 	}
 	printf("%d thread created for cutTipPreGraph\n", g->p);
 	printf("%llu linear nodes\n", (unsigned long long)c);
@@ -642,6 +667,58 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 	return tips;
 }
 
+/* blocks of nodes are counted, then formatted, in parallel; a block needs the number of vertices before it for the
+ * newline after every 8th */
+typedef struct { graph_t *g; uint64_t block, nblocks, first; uint64_t *before; char **txt; size_t *len; } vx_ctx;
+
+static void vx_count(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	vx_ctx *V = (vx_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		const uint64_t i0 = b * V->block, i1 = i0 + V->block < V->g->n ? i0 + V->block : V->g->n;
+		uint64_t c = 0;
+		for (uint64_t i = i0; i < i1; i++) c += !(V->g->nodes[i].linear || V->g->nodes[i].deleted);
+		V->before[b + 1] = c;
+	}
+}
+
+static inline size_t hex_u64(char *p, uint64_t v)
+{
+	char tmp[16];
+	int n = 0;
+	do { tmp[n++] = "0123456789abcdef"[v & 15]; v >>= 4; } while (v);
+	for (int k = 0; k < n; k++) p[k] = tmp[n - 1 - k];
+	return (size_t)n;
+}
+
+static void vx_format(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	vx_ctx *V = (vx_ctx *)vc;
+	const graph_t *g = V->g;
+	for (uint64_t k = lo; k < hi; k++) {
+		const uint64_t b = V->first + k;
+		const uint64_t i0 = b * V->block, i1 = i0 + V->block < g->n ? i0 + V->block : g->n;
+		uint64_t c = V->before[b];
+		const uint64_t mine = V->before[b + 1] - V->before[b];
+		char *t = (char *)malloc(mine * (size_t)(17 * g->nw + 2) + 16);
+		size_t o = 0;
+		for (uint64_t i = i0; i < i1; i++) {
+			const gnode_t *n = &g->nodes[i];
+			if (n->linear || n->deleted) continue;
+			c++;
+			const uint64_t *w = n->seq.w;                                        /* print_kmer, kmer.c:499-516 */
+			if (g->nw == 1 && !w[3]) { memcpy(t + o, "0x0 ", 4); o += 4; }
+			else
+				for (int q = 4 - g->nw; q < 4; q++) { o += hex_u64(t + o, w[q]); t[o++] = ' '; }
+			if (c % 8 == 0) t[o++] = '\n';
+		}
+		V->txt[k] = t;
+		V->len[k] = o;
+	}
+}
+
 /* output_vertex (output_pregraph.c:29-81) with print_kmer of the emulated variant (kmer.c:499-516) */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix)
 {
@@ -649,18 +726,23 @@ uint64_t graph_write_vertex(graph_t *g, const char *prefix)
 	snprintf(name, sizeof name, "%s.vertex", prefix);
 	FILE *fp = fopen(name, "w");
 	if (!fp) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
-	uint64_t c = 0;
-	for (uint64_t i = 0; i < g->n; i++) {
-		const gnode_t *n = &g->nodes[i];
-		if (n->linear || n->deleted) continue;
-		c++;
-		const uint64_t *w = n->seq.w;
-		if (g->nw == 4) fprintf(fp, "%llx %llx %llx %llx ", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
-		else if (g->nw == 2) fprintf(fp, "%llx %llx ", (unsigned long long)w[2], (unsigned long long)w[3]);
-		else if (w[3]) fprintf(fp, "%llx ", (unsigned long long)w[3]);
-		else fprintf(fp, "0x0 ");
-		if (c % 8 == 0) fputc('\n', fp);
+	vx_ctx V;
+	V.g = g;
+	V.block = 1 << 18;
+	V.nblocks = (g->n + V.block - 1) / V.block;
+	V.before = (uint64_t *)calloc(V.nblocks + 2, sizeof(uint64_t));
+	par_for(0, V.nblocks, 1, vx_count, &V);
+	for (uint64_t b = 0; b < V.nblocks; b++) V.before[b + 1] += V.before[b];
+	const uint64_t c = V.before[V.nblocks];
+	const uint64_t wave = (uint64_t)par_threads() * 2;
+	V.txt = (char **)calloc(wave, sizeof(char *));
+	V.len = (size_t *)calloc(wave, sizeof(size_t));
+	for (V.first = 0; V.first < V.nblocks; V.first += wave) {
+		const uint64_t n = V.nblocks - V.first < wave ? V.nblocks - V.first : wave;
+		par_for(0, n, 1, vx_format, &V);
+		for (uint64_t k = 0; k < n; k++) { fwrite(V.txt[k], 1, V.len[k], fp); free(V.txt[k]); }
 	}
+	free(V.before); free(V.txt); free(V.len);
 	fputc('\n', fp);
 	fclose(fp);
 	printf("%llu vertex outputed\n", (unsigned long long)c);

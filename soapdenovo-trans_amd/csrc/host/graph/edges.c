@@ -344,6 +344,37 @@ static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
 	free(c.b);
 }
 
+#include <unistd.h>
+typedef struct { edges_ctx *E; const uint64_t *emit, *cut; unsigned char **out; size_t *len; volatile int failed; } gz_ctx;
+
+static void gz_chunks(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	gz_ctx *Z = (gz_ctx *)vc;
+	for (uint64_t k = lo; k < hi; k++) {
+		size_t total = 0;
+		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) total += Z->E->ports[Z->emit[e]].text_len;
+		z_stream zs;
+		memset(&zs, 0, sizeof zs);
+		if (deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { Z->failed = 1; return; }
+		const size_t cap = deflateBound(&zs, (uLong)total) + 64;
+		unsigned char *out = (unsigned char *)malloc(cap);
+		zs.next_out = out;
+		zs.avail_out = (uInt)cap;
+		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) {
+			port_t *P = &Z->E->ports[Z->emit[e]];
+			zs.next_in = (Bytef *)P->text;
+			zs.avail_in = (uInt)P->text_len;
+			if (deflate(&zs, e + 1 == Z->cut[k + 1] ? Z_FINISH : Z_NO_FLUSH) == Z_STREAM_ERROR) { Z->failed = 1; break; }
+			free(P->text);
+			P->text = NULL;
+		}
+		Z->len[k] = cap - zs.avail_out;
+		Z->out[k] = out;
+		deflateEnd(&zs);
+	}
+}
+
 #include <time.h>
 static double ed_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 #define EPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = ed_now(); fprintf(stderr, "[edges]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
@@ -422,17 +453,35 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	stamp_ctx S = {g, &E, emit, nemit};
 	par_for(0, nemit, 64, stamp_edges, &S);
 	EPHASE("stamp + text");
+	/* <prefix>.edge.gz as a sequence of gzip members, each deflated by one thread over ~4 MB of records: gzopen /
+	 * gzgets (loadPreGraph.c:439-449) read through member boundaries */
 	char name[4200];
 	snprintf(name, sizeof name, "%s.edge.gz", prefix);
-	gzFile fp = gzopen(name, "w1");
-	if (!fp) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
-	gzbuffer(fp, 1 << 20);
-	for (uint64_t e = 0; e < nemit; e++) {
-		port_t *P = &E.ports[emit[e]];
-		gzwrite(fp, P->text, (unsigned)P->text_len);
-		free(P->text);
+	FILE *fz = fopen(name, "wb");
+	if (!fz) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	{
+		uint64_t *cut = (uint64_t *)malloc((nemit + 2) * sizeof(uint64_t));
+		uint64_t ncut = 0;
+		size_t acc = 0;
+		const size_t chunk_bytes = getenv("SDT_GZ_CHUNK") ? (size_t)atol(getenv("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
+		cut[ncut++] = 0;
+		for (uint64_t e = 0; e < nemit; e++) {
+			acc += E.ports[emit[e]].text_len;
+			if (acc >= chunk_bytes) { cut[ncut++] = e + 1; acc = 0; }
+		}
+		if (cut[ncut - 1] != nemit) cut[ncut++] = nemit;
+		const uint64_t nchunks = ncut - 1;
+		gz_ctx Z = {&E, emit, cut, (unsigned char **)calloc(nchunks + 1, sizeof(unsigned char *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
+		par_for(0, nchunks, 1, gz_chunks, &Z);
+		if (Z.failed) { printf("deflate failed on %s\n", name); exit(-1); }
+		for (uint64_t k = 0; k < nchunks; k++) { fwrite(Z.out[k], 1, Z.len[k], fz); free(Z.out[k]); }
+		if (nchunks == 0) {                                  /* no edges: still a valid (empty) gzip file */
+			gzFile fe = gzdopen(dup(fileno(fz)), "w1");
+			if (fe) gzclose(fe);
+		}
+		free(Z.out); free(Z.len); free(cut);
 	}
-	gzclose(fp);
+	fclose(fz);
 	EPHASE("gzip write");
 	g->num_ed = num_ed;
 	printf("%llu (%llu) edges %llu extra nodes\n", (unsigned long long)num_ed, (unsigned long long)nemit, (unsigned long long)extra);

@@ -98,7 +98,7 @@ try:
         res["identical"] = same
         res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
-    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]"))]
+    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]"))]
     print(json.dumps(res, indent=1))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
