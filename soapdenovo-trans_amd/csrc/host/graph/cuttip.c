@@ -34,9 +34,24 @@ static double cut_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTON
 #define NO_NODE (~(uint64_t)0)
 typedef struct { int would_write; uint64_t end; } dry_t;
 
+/* parallel commits (removeMinorOut by components): a thread only ever touches nodes of its own component, so the
+ * per-node marks need no synchronisation; the shared list is replaced by one list per thread, merged afterwards */
+static __thread struct { uint64_t *v; size_t n, cap; int on; } tl_dirty;
+
 static inline void touch(graph_t *g, const gnode_t *n)
 {
 	const uint64_t i = (uint64_t)(n - g->nodes);
+	if (tl_dirty.on) {
+		if (g->dirty && !g->dirty[i]) {
+			g->dirty[i] = 1;
+			if (tl_dirty.n == tl_dirty.cap) {
+				tl_dirty.cap = tl_dirty.cap ? tl_dirty.cap * 2 : 4096;
+				tl_dirty.v = (uint64_t *)realloc(tl_dirty.v, tl_dirty.cap * sizeof(uint64_t));
+			}
+			tl_dirty.v[tl_dirty.n++] = i;
+		}
+		return;
+	}
 	if (g->dirty && !g->dirty[i]) {
 		g->dirty[i] = 1;
 		if (g->dn == g->dcap) {
@@ -280,6 +295,161 @@ static void count_junctions(void *vc, uint64_t lo, uint64_t hi, int tid)
 	__sync_fetch_and_add(&c->cursor, k);
 }
 
+/* ---- removeMinorOut, commit by components -------------------------------------------------------------------
+ * A visit at junction i reads and writes only  T(i) = {i} + N(i) + N(q) for the neighbours q it may cut  (isolate(q)
+ * unlinks q from its neighbours), all known from the dry run's neighbour tables.  Visits whose T() are disjoint
+ * commute, so: union the visits that share a node (lock-free union-find, in parallel), then run every component's
+ * visits in the reference's order on one thread, components side by side. */
+typedef struct {
+	graph_t *g;
+	const uint64_t *ex;
+	uint64_t nexec;
+	uint32_t *owner;          /* per node: a visit that touches it, ~0 = none yet */
+	uint32_t *parent;         /* union-find over visits */
+	double threshold;
+	uint64_t *order;          /* visits grouped by component, ascending inside each */
+	uint64_t *cstart;         /* ncomp + 1 */
+	uint64_t ncomp;
+	volatile uint64_t off;
+	uint64_t **tl;            /* merged after the run */
+	size_t *tln;
+	volatile int ntl;
+} cc_ctx;
+
+static inline uint32_t cc_find(uint32_t *parent, uint32_t v)
+{
+	for (;;) {
+		const uint32_t p = __atomic_load_n(&parent[v], __ATOMIC_RELAXED);
+		if (p == v) return v;
+		const uint32_t gp = __atomic_load_n(&parent[p], __ATOMIC_RELAXED);
+		if (gp != p) __sync_bool_compare_and_swap(&parent[v], p, gp);   /* path halving */
+		v = p;
+	}
+}
+
+static inline void cc_union(uint32_t *parent, uint32_t a, uint32_t b)
+{
+	for (;;) {
+		a = cc_find(parent, a);
+		b = cc_find(parent, b);
+		if (a == b) return;
+		if (a < b) { const uint32_t t = a; a = b; b = t; }               /* the larger root goes under the smaller */
+		if (__sync_bool_compare_and_swap(&parent[a], a, b)) return;
+	}
+}
+
+static inline void cc_claim(cc_ctx *C, uint32_t v, uint64_t node)
+{
+	const uint32_t old = __sync_val_compare_and_swap(&C->owner[node], 0xFFFFFFFFu, v);
+	if (old != 0xFFFFFFFFu && old != v) cc_union(C->parent, v, old);
+}
+
+static void cc_clear(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	memset((uint32_t *)vc + lo, 0xFF, (size_t)(hi - lo) * sizeof(uint32_t));
+}
+
+static void cc_link(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	cc_ctx *C = (cc_ctx *)vc;
+	graph_t *g = C->g;
+	for (uint64_t v = lo; v < hi; v++) {
+		const uint64_t i = C->ex[v];
+		cc_claim(C, (uint32_t)v, i);
+		const uint32_t sl = g->nb_slot[i];
+		if (!sl) continue;                                                 /* cannot happen when the tables are complete */
+		const uint64_t *e = &g->nb_pool[(uint64_t)(sl - 1) * 8];
+		for (int k = 0; k < 8; k++) {
+			if (e[k] == NO_NODE) continue;
+			const uint64_t q = e[k] >> 1;
+			cc_claim(C, (uint32_t)v, q);
+			const uint32_t s2 = g->nb_slot[q];                              /* q may be cut only if the dry run gave it a table */
+			if (!s2) continue;
+			const uint64_t *e2 = &g->nb_pool[(uint64_t)(s2 - 1) * 8];
+			for (int k2 = 0; k2 < 8; k2++)
+				if (e2[k2] != NO_NODE) cc_claim(C, (uint32_t)v, e2[k2] >> 1);
+		}
+	}
+}
+
+static void cc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	cc_ctx *C = (cc_ctx *)vc;
+	uint64_t off = 0;
+	tl_dirty.on = 1;
+	tl_dirty.v = NULL;
+	tl_dirty.n = tl_dirty.cap = 0;
+	for (uint64_t c = lo; c < hi; c++)
+		for (uint64_t k = C->cstart[c]; k < C->cstart[c + 1]; k++)
+			visit_minor_out(C->g, &C->g->nodes[C->ex[C->order[k]]], C->threshold, &off, NULL);
+	tl_dirty.on = 0;
+	const int slot = __sync_fetch_and_add(&C->ntl, 1);
+	C->tl[slot] = tl_dirty.v;
+	C->tln[slot] = tl_dirty.n;
+	__sync_fetch_and_add(&C->off, off);
+}
+
+/* returns 0 when the pass was committed here, 1 when the caller has to do it the sequential way */
+static int commit_minor_out_by_components(graph_t *g, const uint64_t *ex, uint64_t nexec, double threshold, uint64_t *off)
+{
+	if (nexec < 4096 || nexec > 0xFFFFFFF0ULL || par_threads() < 2) return 1;
+	cc_ctx C;
+	memset(&C, 0, sizeof C);
+	C.g = g; C.ex = ex; C.nexec = nexec; C.threshold = threshold;
+	C.owner = (uint32_t *)malloc((g->n + 1) * sizeof(uint32_t));
+	C.parent = (uint32_t *)malloc((nexec + 1) * sizeof(uint32_t));
+	if (!C.owner || !C.parent) { free(C.owner); free(C.parent); return 1; }
+	double t_sub = cut_now_ms();
+	par_for(0, g->n + 1, 1 << 20, cc_clear, C.owner);
+	for (uint64_t v = 0; v < nexec; v++) C.parent[v] = (uint32_t)v;
+	SUBPHASE("  components: clear");
+	par_for(0, nexec, 2048, cc_link, &C);
+	free(C.owner);
+	SUBPHASE("  components: union");
+	/* group: component id = its smallest visit (roots are minima), members in ascending order */
+	uint64_t *count = (uint64_t *)calloc(nexec + 1, sizeof(uint64_t));
+	uint32_t *root = (uint32_t *)malloc((nexec + 1) * sizeof(uint32_t));
+	for (uint64_t v = 0; v < nexec; v++) { root[v] = cc_find(C.parent, (uint32_t)v); count[root[v]]++; }
+	C.cstart = (uint64_t *)malloc((nexec + 2) * sizeof(uint64_t));
+	uint64_t *where = (uint64_t *)malloc((nexec + 1) * sizeof(uint64_t));
+	uint64_t pos = 0;
+	for (uint64_t v = 0; v < nexec; v++)
+		if (count[v]) { where[v] = pos; C.cstart[C.ncomp++] = pos; pos += count[v]; }
+	C.cstart[C.ncomp] = pos;
+	C.order = (uint64_t *)malloc((nexec + 1) * sizeof(uint64_t));
+	for (uint64_t v = 0; v < nexec; v++) C.order[where[root[v]]++] = v;
+	free(count); free(root); free(where); free(C.parent);
+	SUBPHASE("  components: group");
+	/* dynamic chunks of a few components (transcripts differ wildly in size); one dirty list per chunk */
+	const uint64_t per = 16;
+	const uint64_t nchunks = (C.ncomp + per - 1) / per;
+	C.tl = (uint64_t **)calloc(nchunks + 1, sizeof(uint64_t *));
+	C.tln = (size_t *)calloc(nchunks + 1, sizeof(size_t));
+	uint64_t biggest = 0;
+	for (uint64_t c = 0; c < C.ncomp; c++) if (C.cstart[c + 1] - C.cstart[c] > biggest) biggest = C.cstart[c + 1] - C.cstart[c];
+	par_for(0, C.ncomp, per, cc_run, &C);
+	SUBPHASE("  components: run");
+	for (int t = 0; t < C.ntl; t++) {
+		for (size_t k = 0; k < C.tln[t]; k++) {
+			const uint64_t i = C.tl[t][k];
+			if (g->dn == g->dcap) {
+				g->dcap = g->dcap ? g->dcap * 2 : 4096;
+				g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
+			}
+			g->dlist[g->dn++] = i;
+			if (g->vbits) g->vbits[i >> 6] |= 1ULL << (i & 63);
+		}
+		free(C.tl[t]);
+	}
+	if (getenv("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nexec, (unsigned long long)C.ncomp, (unsigned long long)biggest);
+	free(C.tl); free(C.tln); free(C.order); free(C.cstart);
+	*off += C.off;
+	return 0;
+}
+
 static void mo_scatter_records(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
@@ -350,7 +520,10 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	uint64_t *ex = (uint64_t *)malloc((nexec + 1) * sizeof(uint64_t));
 	nexec = 0;
 	for (uint64_t i = 0; i < g->n; i++) if (c.writes[i]) ex[nexec++] = i;
-	for (uint64_t cur = 0; cur < nexec; cur++) {
+	/* every visit and every node it may cut has its neighbour table (no pool overflow)? then by components */
+	const int complete = c.cursor <= c.cap;
+	const int sequential = !complete || getenv("SDT_SEQUENTIAL_COMMIT") || commit_minor_out_by_components(g, ex, nexec, threshold, &off);
+	for (uint64_t cur = 0; sequential && cur < nexec; cur++) {
 		/* stage 1 (far): slot number; stage 2: the 8 neighbour entries; stage 3: the neighbour nodes and their
 		 * slot numbers; stage 4 (near): the neighbours' own neighbour entries */
 		if (cur + 24 < nexec) __builtin_prefetch(&g->nb_slot[ex[cur + 24]]);

@@ -260,3 +260,40 @@ def test_sdt_map_batch_logic_equals_oracle(pkg, tmp_path, name, batch_kmers):
     for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []):
         assert open(str(tmp_path / "out") + "." + ext, "rb").read() == open(str(tmp_path / "o") + "." + ext, "rb").read(), ext
     assert f"{counters[1]} out of {counters[0]} " in r.stdout
+
+
+def test_minor_out_commit_by_components_equals_sequential(pkg, tmp_path, synth):
+    """removeMinorOut's commit: visits grouped into components that share no node and run side by side (default when
+    there are >= 4096 visits) == the plain sequential sweep (SDT_SEQUENTIAL_COMMIT=1), on a graph big enough to take
+    the parallel route: same counters, same *.vertex, same edges"""
+    import struct
+    import oracle_binding as ob
+    K, L, n, p = 25, 100, 120000, 4
+    tx = synth.make_transcriptome(60, seed=11)
+    codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=L, seed=12, err=0.01)
+    o = ob.Oracle(K, nsets=3)
+    o.add_reads(codes, offs)
+    o.mark()
+    keys, l, r, cnt, fl = o.export()
+    fo = o.export_first()
+    rflags = (r.astype(np.uint32) | ((fl & 1).astype(np.uint32) << 24) | (((fl >> 1) & 1).astype(np.uint32) << 25)
+              | (((fl >> 2) & 1).astype(np.uint32) << 27))
+    dump = tmp_path / "nodes.bin"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<6iQ", K, 1, 1, p, 0, 5, len(keys)))
+        f.write(np.ascontiguousarray(keys[:, 3:]).tobytes())
+        f.write(l.astype(np.uint32).tobytes())
+        f.write(rflags.tobytes())
+        f.write(cnt.astype(np.uint32).tobytes())
+        f.write(fo.tobytes())
+    exe = bin_path(pkg, "sdt-graphcheck")
+    outs = {}
+    for mode, env in (("par", dict(os.environ, SDT_TIMING="1")), ("seq", dict(os.environ, SDT_TIMING="1", SDT_SEQUENTIAL_COMMIT="1"))):
+        rr = subprocess.run([exe, str(dump), str(tmp_path / mode)], capture_output=True, text=True, env=env, timeout=600)
+        assert rr.returncode == 0, rr.stdout + rr.stderr
+        outs[mode] = ([x for x in rr.stdout.splitlines() if " off" in x or "linear nodes" in x or "edges" in x], rr.stderr)
+    if os.cpu_count() and os.cpu_count() > 1:
+        assert "components" in outs["par"][1] and "components" not in outs["seq"][1]
+    assert outs["par"][0] == outs["seq"][0]
+    assert open(tmp_path / "par.vertex").read() == open(tmp_path / "seq.vertex").read()
+    assert gzip.open(tmp_path / "par.edge.gz", "rb").read() == gzip.open(tmp_path / "seq.edge.gz", "rb").read()
