@@ -290,7 +290,9 @@ static void fmt_blocks(void *vc, uint64_t lo, uint64_t hi, int tid)
 	fmt_ctx *F = (fmt_ctx *)vc;
 	for (uint64_t bi = lo; bi < hi; bi++) {
 		const uint64_t g0 = (F->wave_first + bi) * F->block, g1 = g0 + F->block < F->total ? g0 + F->block : F->total;
-		tbuf *ro = &F->ro[bi], *c2 = &F->c2[bi], *ri = &F->ri[bi];
+		/* work on private copies: the tbuf structs of neighbouring blocks share cache lines, and `n` moves per byte */
+		tbuf ro_l = F->ro[bi], c2_l = F->c2[bi], ri_l = F->ri[bi];
+		tbuf *ro = &ro_l, *c2 = &c2_l, *ri = &ri_l;
 		ro->n = c2->n = ri->n = 0;
 		long long mapped = 0, over = 0;
 		cursor cu;
@@ -338,6 +340,7 @@ static void fmt_blocks(void *vc, uint64_t lo, uint64_t hi, int tid)
 				ri->p[ri->n++] = orien; ri->p[ri->n++] = '\n';
 			}
 		}
+		F->ro[bi] = ro_l; F->c2[bi] = c2_l; F->ri[bi] = ri_l;
 		F->mapped[bi] = mapped;
 		F->overflowed[bi] = over;
 	}
@@ -618,6 +621,7 @@ int main(int argc, char **argv)
 		const int nt = par_threads();
 		const uint64_t block = 1 << 18;
 		const uint64_t nblocks = (total + block - 1) / block;
+		double t_fmt = 0, t_wr = 0;
 		fflush(fo); fflush(f3);
 		off_t pos_ro = ftello(fo), pos_c2 = ftello(f3), pos_ri = 0;
 		fmt_ctx F = {S, ns, K, read_trace, ctg_len, ctg_twin, total, block, 0, (tbuf *)calloc((size_t)nt * 2, sizeof(tbuf)),
@@ -626,7 +630,9 @@ int main(int argc, char **argv)
 		for (uint64_t first = 0; first < nblocks; first += (uint64_t)nt * 2) {
 			const uint64_t n = nblocks - first < (uint64_t)nt * 2 ? nblocks - first : (uint64_t)nt * 2;
 			F.wave_first = first;
+			const double tf0 = now_ms();
 			par_for(0, n, 1, fmt_blocks, &F);
+			t_fmt += now_ms() - tf0;
 			/* every block knows its size now: give it its place in the file and let the threads write side by side */
 			fflush(fo); fflush(f3);
 			if (f4) fflush(f4);
@@ -638,12 +644,15 @@ int main(int argc, char **argv)
 				map_counter += F.mapped[b];
 				overflowed += F.overflowed[b];
 			}
+			const double tw0 = now_ms();
 			par_for(0, n, 1, pwrite_blocks, &W);
+			t_wr += now_ms() - tw0;
 			free(W.off[0]); free(W.off[1]); free(W.off[2]);
 			if (W.failed) { printf("write error on the read-to-contig files\n"); return 255; }
 		}
 		for (int b = 0; b < nt * 2; b++) { free(F.ro[b].p); free(F.c2[b].p); free(F.ri[b].p); }
 		free(F.ro); free(F.c2); free(F.ri); free(F.mapped); free(F.overflowed);
+		if (getenv("SDT_TIMING")) fprintf(stderr, "[sdt-map]   format %.1f ms, pwrite %.1f ms\n", t_fmt, t_wr);
 	}
 	phase("text files (parallel format)");
 	long long read_counter = 0;
