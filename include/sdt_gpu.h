@@ -187,9 +187,9 @@ int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, ui
 int sdt_gpu_minor_out_dry(sdt_ctx *ctx, double threshold, uint64_t *records, uint64_t max_records,
                           uint64_t *n_junctions, uint64_t *n_records);
 /*   build_host_index: the host's k-mer -> node look-up table for the ordered commits (csrc/host/graph/graph.c:
- *                   open addressing over index_slots = 2^m >= 2n words, home slot = mix_key(4-word k-mer) & (slots-1),
- *                   linear probing, value = node index + 1, 0 = empty), filled by the device from its node index. */
-int sdt_gpu_build_host_index(sdt_ctx *ctx, uint64_t *index, uint64_t index_slots);
+ *                   open addressing over index_slots = 2^m >= 2n 32-bit words, home slot = mix_key(4-word k-mer) &
+ *                   (slots-1), linear probing, value = node index + 1, 0 = empty), filled by the device from its node index. */
+int sdt_gpu_build_host_index(sdt_ctx *ctx, uint32_t *index, uint64_t index_slots);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

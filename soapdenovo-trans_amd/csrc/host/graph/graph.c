@@ -146,6 +146,8 @@ static void replay1_grow(replay1_t *r)
 	r->moved = (uint8_t *)realloc(r->moved, old);
 	memset(r->moved, 0, old);
 	for (uint64_t i = 0; i < old; i++) {
+		/* the old slots are walked in order, so the new home of the entry a few steps ahead is known: have it in cache */
+		if (i + 12 < old && r->slot[i + 12].id >= 0) __builtin_prefetch(&ns[r->slot[i + 12].key % n], 1);
 		if (r->slot[i].id < 0 || r->moved[i]) continue;
 		rslot1 carry = r->slot[i];
 		r->moved[i] = 1;
@@ -325,7 +327,8 @@ static void job_replay(build_job *J, int tid)
 			r.slot = (rslot1 *)malloc(r.size * sizeof(rslot1));
 			for (uint64_t i = 0; i < r.size; i++) r.slot[i].id = -1;
 			for (uint64_t i = b; i < e; i++) {
-				if (i + 16 < e) __builtin_prefetch(&J->tmp[J->ord[i + 16].id].seq.w[3]);
+				if (i + 24 < e) __builtin_prefetch(&J->tmp[J->ord[i + 24].id].seq.w[3]);
+				if (i + 8 < e) __builtin_prefetch(&r.slot[J->tmp[J->ord[i + 8].id].seq.w[3] % r.size], 1);   /* its home slot, if the table does not grow first */
 				replay1_put(&r, (int64_t)J->ord[i].id, J->tmp[J->ord[i].id].seq.w[3]);
 			}
 			if (t_s0 > 0 && s == 0) fprintf(stderr, "[graph]      set 0: sort + puts %9.1f ms\n", gb_now() - t_s0);
@@ -359,7 +362,7 @@ static void job_index(build_job *J, int tid)
 	const uint64_t lo = g->n * (uint64_t)tid / J->nthreads, hi = g->n * (uint64_t)(tid + 1) / J->nthreads;
 	for (uint64_t i = lo; i < hi; i++) {
 		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
-		while (!__sync_bool_compare_and_swap(&g->index[h], 0, i + 1))
+		while (!__sync_bool_compare_and_swap(&g->index[h], 0u, (uint32_t)(i + 1)))
 			h = (h + 1) & g->index_mask;
 	}
 }
@@ -431,13 +434,14 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	GB_PHASE("sort + replay per set");
 	free(J.ord); free(J.per_set); free(J.set_of); free(J.tmp);
 	/* index */
+	if (n >= 0xFFFFFFFEULL) { printf("%llu nodes: the host index holds 32-bit node ids\n", (unsigned long long)n); exit(1); }
 	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {
 		GB_PHASE("index (device)");
 		return g;
 	}
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
-	g->index = (uint64_t *)calloc(cap, sizeof(uint64_t));
+	g->index = (uint32_t *)calloc(cap, sizeof(uint32_t));
 	g->index_mask = cap - 1;
 	run_parallel(&J, job_index);
 	GB_PHASE("index");

@@ -35,7 +35,7 @@ typedef struct graph_s {
 	uint64_t n;
 	gnode_t *nodes;                    /* visiting order */
 	uint64_t *set_start;               /* p + 1 offsets into nodes[] */
-	uint64_t *index;                   /* open addressing: node id + 1, 0 = empty */
+	uint32_t *index;                   /* open addressing: node id + 1, 0 = empty (n < 2^32 - 1) */
 	uint64_t index_mask;
 	gpatch_t *patch;                   /* open addressing over canonical (K+1)-mers */
 	uint64_t patch_mask, patch_n;

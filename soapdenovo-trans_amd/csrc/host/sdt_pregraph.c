@@ -162,7 +162,7 @@ static int dev_index_hook(graph_t *g, void *user)
 	if (dev_mirror_sync(g) != 0) exit(1);
 	uint64_t cap = 1024;
 	while (cap < 2 * g->n + 2) cap <<= 1;
-	g->index = (uint64_t *)malloc(cap * sizeof(uint64_t));
+	g->index = (uint32_t *)malloc(cap * sizeof(uint32_t));
 	g->index_mask = cap - 1;
 	if (!g->index || sdt_gpu_build_host_index(D->gpu, g->index, cap) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_build_host_index: %s\n", sdt_gpu_last_error());

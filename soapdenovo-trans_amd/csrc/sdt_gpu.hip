@@ -1807,7 +1807,7 @@ done:
 	return ret;
 }
 
-int sdt_gpu_build_host_index(sdt_ctx *c, uint64_t *index, uint64_t index_slots)
+int sdt_gpu_build_host_index(sdt_ctx *c, uint32_t *index, uint64_t index_slots)
 {
 	if (!c || !index)
 		return fail(SDT_EINVAL, "NULL argument");
@@ -1815,10 +1815,12 @@ int sdt_gpu_build_host_index(sdt_ctx *c, uint64_t *index, uint64_t index_slots)
 		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
 	if (index_slots < 2 * c->idx_n || (index_slots & (index_slots - 1)))
 		return fail(SDT_EINVAL, "index_slots must be a power of two >= 2 x nodes");
+	if (c->idx_n >= 0xFFFFFFFEULL)
+		return fail(SDT_EINVAL, "%llu nodes do not fit 32-bit index entries", (unsigned long long)c->idx_n);
 	HIPCHK(hipSetDevice(c->device));
-	unsigned long long *d_index = nullptr;
-	HIPCHK(hipMalloc((void **)&d_index, index_slots * sizeof(unsigned long long)));
-	hipError_t e = hipMemsetAsync(d_index, 0, index_slots * sizeof(unsigned long long), c->stream);
+	unsigned int *d_index = nullptr;
+	HIPCHK(hipMalloc((void **)&d_index, index_slots * sizeof(unsigned int)));
+	hipError_t e = hipMemsetAsync(d_index, 0, index_slots * sizeof(unsigned int), c->stream);
 	if (e == hipSuccess) {
 		const int g = scan_grid(c, c->slots);
 		if (c->nw == 1) hipLaunchKernelGGL(k_build_host_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_index, index_slots - 1);
@@ -1826,7 +1828,7 @@ int sdt_gpu_build_host_index(sdt_ctx *c, uint64_t *index, uint64_t index_slots)
 		else hipLaunchKernelGGL(k_build_host_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, d_index, index_slots - 1);
 		e = hipGetLastError();
 	}
-	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	(void)hipFree(d_index);
 	if (e != hipSuccess)

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
 
 
 // the host's own look-up index over its node array (csrc/host/graph/graph.c: open addressing on mix_key of the
-// 4-word k-mer, value = node index + 1), built here because the device already knows every node's index
+// 4-word k-mer, 32-bit value = node index + 1), built here because the device already knows every node's index
 __device__ inline uint64_t host_mix_key4(const uint64_t w[4])
 {
 	uint64_t h = 0x9E3779B97F4A7C15ULL;
@@ -573,7 +573,7 @@ __device__ inline uint64_t host_mix_key4(const uint64_t w[4])
 }
 
 template <int NW>
-__global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const uint64_t *__restrict__ idx, unsigned long long *__restrict__ index,
+__global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const uint64_t *__restrict__ idx, unsigned int *__restrict__ index,
                                                           uint64_t index_mask)
 {
 	const uint64_t slots = tbl.mask + 1;
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const u
 #pragma unroll
 		for (int i = 0; i < NW; i++) w[4 - NW + i] = tbl.ent[s].key[i];
 		uint64_t h = host_mix_key4(w) & index_mask;
-		const unsigned long long v = idx[s] + 1;
-		while (atomicCAS(&index[h], 0ULL, v) != 0ULL) h = (h + 1) & index_mask;
+		const unsigned int v = (unsigned int)(idx[s] + 1);
+		while (atomicCAS(&index[h], 0u, v) != 0u) h = (h + 1) & index_mask;
 	}
 }
 
