@@ -190,6 +190,13 @@ int sdt_gpu_minor_out_dry(sdt_ctx *ctx, double threshold, uint64_t *records, uin
  *                   open addressing over index_slots = 2^m >= 2n 32-bit words, home slot = mix_key(4-word k-mer) &
  *                   (slots-1), linear probing, value = node index + 1, 0 = empty), filled by the device from its node index. */
 int sdt_gpu_build_host_index(sdt_ctx *ctx, uint32_t *index, uint64_t index_slots);
+/*   edge_ports:     kmer2edges' walks (node2edge.c:46-191): for every node that is neither linear nor deleted one
+ *                   record of 17 words -- node index, then for each of its 8 ports (right links 0..3 on the stored
+ *                   strand, left links 0..3 on the reverse strand) the index of the first non-linear node the chain
+ *                   of linear nodes leads to (~0: no link) and  length | far_port << 32 | bal_edge << 40  (the port
+ *                   the chain arrives through; bal_edge = 0 when the chain is its own reverse complement,
+ *                   check_iden_kmerList :563-588).  SDT_EFULL when records[] is too small (*n_records = needed). */
+int sdt_gpu_edge_ports(sdt_ctx *ctx, uint64_t *records, uint64_t max_records, uint64_t *n_records);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

@@ -59,6 +59,7 @@ _ABI = [
     ("sdt_gpu_tip_walks", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_minor_out_dry", _c.c_int, [_c.c_void_p, _c.c_double, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64),
                                          _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_edge_ports", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_build_host_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_set_contig_table", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
@@ -271,6 +272,19 @@ class PregraphGPU:
                 continue
             self._check(rc)
             return rec[: nr.value], nj.value
+
+    def edge_ports(self):
+        """-> records uint64[n, 17]: see sdt_gpu_edge_ports"""
+        cap = max(self._nidx // 4, 1024)
+        while True:
+            rec = np.zeros((cap, 17), dtype=np.uint64)
+            nr = ctypes.c_uint64()
+            rc = self.lib.sdt_gpu_edge_ports(self._ctx, _ptr(rec), cap, ctypes.byref(nr))
+            if rc == SDT_EFULL and nr.value > cap:
+                cap = nr.value
+                continue
+            self._check(rc)
+            return rec[: nr.value]
 
     # -- map stage (prlContig2nodes / prlRead2Ctg); the context must be created with FLAG_CONTIG_INDEX
     def index_contigs(self, packed_words: np.ndarray, offsets: np.ndarray, ids: np.ndarray):

@@ -281,6 +281,26 @@ static void dry_ports(void *vc, uint64_t lo, uint64_t hi, int tid)
 	free(c.b);
 }
 
+static void scatter_ports(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	edges_ctx *E = (edges_ctx *)a[0];
+	const uint64_t *rec = (const uint64_t *)a[1];
+	const uint64_t *slot_of = (const uint64_t *)a[2];
+	for (uint64_t r = lo; r < hi; r++) {
+		const uint64_t s = slot_of[rec[r * 17]];
+		for (int p = 0; p < 8; p++) {
+			port_t *P = &E->ports[s * 8 + p];
+			const uint64_t far = rec[r * 17 + 1 + 2 * p], meta = rec[r * 17 + 2 + 2 * p];
+			P->far_node = far;
+			P->length = (uint32_t)meta;
+			P->far_port = (uint8_t)(meta >> 32);
+			P->bal_edge = (uint8_t)(meta >> 40);
+		}
+	}
+}
+
 typedef struct { graph_t *g; edges_ctx *E; uint64_t *emit; uint64_t nemit; } stamp_ctx;
 
 static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
@@ -390,12 +410,27 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		if (!g->nodes[i].linear && !g->nodes[i].deleted) E.starts[E.nstarts++] = i;
 	E.ports = (port_t *)calloc(E.nstarts * 8 + 8, sizeof(port_t));
 	EPHASE("collect starts");
-	par_for(0, E.nstarts, 256, dry_ports, &E);
-	EPHASE("dry walks");
 	/* node index -> start slot, for far ends that are start-eligible themselves */
 	uint64_t *slot_of = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
 	memset(slot_of, 0xFF, (g->n + 1) * sizeof(uint64_t));
 	for (uint64_t s = 0; s < E.nstarts; s++) slot_of[E.starts[s]] = s;
+	if (g->dev_edge_ports) {
+		/* the walks answered by the device mirror of the graph (sdt_gpu_edge_ports), scattered to their start slots */
+		uint64_t *rec = NULL, nrec = 0;
+		if (g->dev_edge_ports(g, &rec, &nrec) != 0 || nrec != E.nstarts) {
+			printf("the device dry run failed (%llu records for %llu start nodes). Now exit to system...\n", (unsigned long long)nrec, (unsigned long long)E.nstarts);
+			exit(1);
+		}
+		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		g->dn = 0;
+		void *sa[3] = {&E, rec, slot_of};
+		par_for(0, nrec, 4096, scatter_ports, sa);
+		free(rec);
+		EPHASE("device walks");
+	} else {
+		par_for(0, E.nstarts, 256, dry_ports, &E);
+		EPHASE("dry walks");
+	}
 	/* ordered pass on port flags */
 	uint8_t *zeroed = (uint8_t *)calloc(g->n + 1, 1);
 	uint64_t *emit = (uint64_t *)malloc((E.nstarts * 8 + 8) * sizeof(uint64_t));

@@ -171,6 +171,23 @@ static int dev_index_hook(graph_t *g, void *user)
 	return 0;
 }
 
+static int dev_edge_ports_hook(graph_t *g, uint64_t **records, uint64_t *nr)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	if (dev_mirror_sync(g) != 0) return 1;
+	uint64_t cap = g->n / 8 + 4096;
+	for (;;) {
+		uint64_t *rec = (uint64_t *)malloc(cap * 17 * sizeof(uint64_t));
+		if (!rec) { fprintf(stderr, "out of memory for %llu port records\n", (unsigned long long)cap); return 1; }
+		const int rc = sdt_gpu_edge_ports(D->gpu, rec, cap, nr);
+		if (rc == SDT_OK) { *records = rec; return 0; }
+		free(rec);
+		if (rc == SDT_EFULL && *nr > cap) { cap = *nr; continue; }
+		fprintf(stderr, "sdt_gpu_edge_ports: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+}
+
 static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, uint64_t *nj, uint64_t *nr)
 {
 	dev_state *D = (dev_state *)g->dev_user;
@@ -310,6 +327,7 @@ int main(int argc, char **argv)
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
 			G->dev_walks = dev_walks_hook;
 			G->dev_minor_out = dev_minor_out_hook;
+			G->dev_edge_ports = dev_edge_ports_hook;
 			G->dev_user = &D;
 		}
 		time_t t0 = time(NULL);
@@ -323,7 +341,7 @@ int main(int argc, char **argv)
 		printf("time spent on cutTipe: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		uint64_t ne = graph_build_edges(G, prefix);                        /* pregraph.c:95-98 */
-		phase("kmer2edges (host)");
+		phase(G->dev_edge_ports ? "kmer2edges (GPU walks + host ids, stamping)" : "kmer2edges (host)");
 		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		printf("%d thread created prlRead2path\n", threads);                /* pregraph.c:101-104 */

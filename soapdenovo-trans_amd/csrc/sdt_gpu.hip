@@ -1836,6 +1836,40 @@ int sdt_gpu_build_host_index(sdt_ctx *c, uint32_t *index, uint64_t index_slots)
 	return SDT_OK;
 }
 
+int sdt_gpu_edge_ports(sdt_ctx *c, uint64_t *records, uint64_t max_records, uint64_t *n_records)
+{
+	if (!c || (!records && max_records) || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_idx || c->idx_slots != c->slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr, h = 0;
+	const uint64_t m = max_records ? max_records : 1;
+	HIPCHK(hipMalloc((void **)&d_rec, m * 17 * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream);
+	if (e == hipSuccess) {
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_edge_ports<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_edge_ports<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		else hipLaunchKernelGGL(k_edge_ports<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, c->stream);
+	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_edge_ports: %s", hipGetErrorString(e));
+	if (rc != SDT_OK && e == hipSuccess)
+		rc = fail(SDT_ESTATE, "sdt_gpu_edge_ports: %llu chains leave the graph or never end", (unsigned long long)c->h_stats->probe_fail);
+	if (rc == SDT_OK) {
+		*n_records = h;
+		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, the graph has %llu non-linear nodes", (unsigned long long)max_records, h);
+		else if (h && hipMemcpy(records, d_rec, h * 17 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "edge port records: copy failed");
+	}
+	(void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return rc;
+}
+
 int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)
 {
 	if (!c)

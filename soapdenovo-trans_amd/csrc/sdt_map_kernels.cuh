@@ -604,3 +604,78 @@ __global__ __launch_bounds__(TPB) void k_set_paths_by_index(Table<NW> tbl, const
 	}
 	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// kmer2edges' read-only part (node2edge.c:46-191, stringBeads): from every node that is neither linear nor deleted,
+// over each of its 8 ports (right links 0..3 on the stored strand, then left links 0..3 on the reverse strand) follow
+// the chain of linear nodes to the first non-linear node.  Per port: the host index of that node, the port the chain
+// arrives through, the chain length and whether the chain is its own reverse complement (bal_edge = 0,
+// check_iden_kmerList :563-588).  The walk is forced after its first step, so the k-mer list equals its own
+// reversed complement list exactly when the last k-mer is the complement of the first AND the second-to-last is the
+// complement of the second -- four k-mers instead of the list.
+// Record = 17 words: node index, then per port (far node index or ~0, length | far_port << 32 | bal_edge << 40).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_edge_ports(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, uint64_t max_steps,
+                                                    uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	const int tb = 2 * (K - 1);
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		const bool keep = r < max_rec;
+		if (keep) rec[r * 17] = idx[s];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+		const Key<NW> me_rc = key_revcomp<NW>(me, K);
+		for (int p = 0; p < 8; p++) {
+			uint64_t far = ~0ULL, meta = 0;
+			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
+			if (live) {
+				const Key<NW> k0 = p < 4 ? me : me_rc;
+				uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+				Key<NW> prev = k0, word = key_next_masked<NW>(k0, b, mask), k1 = word;
+				uint64_t len = 1;
+				bool ok = true, sm;
+				uint64_t os;
+				for (;;) {
+					const Key<NW> bal = key_revcomp<NW>(word, K);
+					sm = !key_less<NW>(bal, word);
+					if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+					if (!(tbl.aux[os] & AUX_LINEAR)) break;
+					if (++len > max_steps) { missing++; ok = false; break; }
+					const uint64_t ov = tbl.ent[os].val;
+					b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+					prev = word;
+					word = key_next_masked<NW>(word, b, mask);
+				}
+				if (ok) {
+					// word = last k-mer, prev = second to last (== k0 when len == 1), k1 = second (== word when len == 1)
+					uint32_t fc = 0;
+#pragma unroll
+					for (int w = 0; w < NW; w++)
+						if (w == NW - 1 - (tb >> 6)) fc = (uint32_t)(prev.w[w] >> (tb & 63)) & 3u;
+					const uint32_t far_port = sm ? 4u + fc : (fc ^ 2u);
+					const Key<NW> rc0 = key_revcomp<NW>(k0, K), rc1 = key_revcomp<NW>(k1, K);
+					const bool palin = key_eq<NW>(word, rc0) && key_eq<NW>(prev, rc1);
+					far = idx[os];
+					meta = len | ((uint64_t)far_port << 32) | ((uint64_t)(palin ? 0 : 1) << 40);
+				}
+			}
+			if (keep) { rec[r * 17 + 1 + 2 * p] = far; rec[r * 17 + 2 + 2 * p] = meta; }
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}

@@ -723,3 +723,78 @@ def test_minor_out_dry_run_equals_reference_rule(pkg, synth, K, L):
             assert set(got_c) == need - set(junc)
             for i, e in got_c.items():
                 assert e == nbrs(i)
+
+
+def py_edge_ports(keys_int, l, rf, K):
+    """stringBeads + check_iden_kmerList (node2edge.c:58-191, 563-588) restated: {node: [(far, far_port, length, bal) or None] * 8}"""
+    idx = {k: i for i, k in enumerate(keys_int)}
+    mask = (1 << (2 * K)) - 1
+    lin = [(int(x) >> 24) & 1 for x in rf]
+    dele = [(int(x) >> 25) & 1 for x in rf]
+    out = {}
+    for i, k in enumerate(keys_int):
+        if lin[i] or dele[i]:
+            continue
+        ports = []
+        for p in range(8):
+            links = int(rf[i]) & 0xFFFFFF if p < 4 else int(l[i]) & 0xFFFFFF
+            if not (links >> (6 * (p & 3))) & 63:
+                ports.append(None)
+                continue
+            word = k if p < 4 else _rc_int(k, K)
+            b = p if p < 4 else (p - 4) ^ 2
+            chain = [word]
+            while True:
+                word = ((word << 2) | b) & mask
+                bal = _rc_int(word, K)
+                sm = 0 if word > bal else 1
+                o = idx[word if sm else bal]
+                chain.append(word)
+                if not lin[o]:
+                    break
+                b = _first_link(int(rf[o]) & 0xFFFFFF) if sm else (_first_link(int(l[o]) & 0xFFFFFF) ^ 2)
+            fc = (chain[-2] >> (2 * (K - 1))) & 3
+            palin = all(chain[len(chain) - 1 - j] == _rc_int(chain[j], K) for j in range(len(chain)))
+            ports.append((o, 4 + fc if sm else fc ^ 2, len(chain) - 1, 0 if palin else 1))
+        out[i] = ports
+    return out
+
+
+@pytest.mark.parametrize("K,L", [(21, 100), (31, 120), (47, 150), (75, 200)])
+def test_edge_port_walks_equal_reference_rule(pkg, synth, K, L):
+    """the device dry run of kmer2edges: every port of every non-linear node -- far node, arrival port, length and
+    the palindrome flag (decided from 4 k-mers on the device, from the whole list here); reads that spell X + rc(X)
+    put self-complementary chains into the graph"""
+    tx = synth.make_transcriptome(12, seed=K + 2)
+    codes, offs = synth.sample_reads(*tx, n_reads=2500, read_len=L, seed=K + 7, err=0.004)
+    rng = np.random.default_rng(K)
+    extra = []
+    for j in range(6):                                    # hairpins: X + rc(X), several copies each
+        x = tx[0][200 * j + 17: 200 * j + 17 + L // 2]
+        hp = np.concatenate([x, (x[::-1] ^ 2)]).astype(np.uint8)
+        extra += [hp] * 5
+    codes = np.concatenate([codes] + extra)
+    offs = np.concatenate([offs, offs[-1] + np.cumsum([len(e) for e in extra]).astype(np.uint64)])
+    with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        perm = rng.permutation(len(keys))
+        keys, l, rf = keys[perm], l[perm], rf[perm]
+        ki = keys_to_int(keys)
+        g.set_node_index(keys)
+        rec = g.edge_ports()
+        want = py_edge_ports(ki, l, rf, K)
+        assert len(rec) == len(want) > 0
+        NONE = (1 << 64) - 1
+        palins = 0
+        for r in rec:
+            i = int(r[0])
+            got = []
+            for p in range(8):
+                far, meta = int(r[1 + 2 * p]), int(r[2 + 2 * p])
+                got.append(None if far == NONE else (far, (meta >> 32) & 255, meta & 0xFFFFFFFF, (meta >> 40) & 1))
+            assert got == want[i], i
+            palins += sum(1 for x in got if x is not None and x[3] == 0)
+        assert palins > 0
