@@ -297,3 +297,31 @@ def test_minor_out_commit_by_components_equals_sequential(pkg, tmp_path, synth):
     assert outs["par"][0] == outs["seq"][0]
     assert open(tmp_path / "par.vertex").read() == open(tmp_path / "seq.vertex").read()
     assert gzip.open(tmp_path / "par.edge.gz", "rb").read() == gzip.open(tmp_path / "seq.edge.gz", "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "--host-walks"])
+def test_cli_degenerate_inputs(pkg, tmp_path, mode):
+    """no k-mers at all (every read shorter than K+1), and a single read: the device-mirror path must cope with
+    empty tables / no junctions / no tips / one edge"""
+    exe = bin_path(pkg, "sdt-pregraph")
+    rng = np.random.default_rng(9)
+    long_read = "".join("ACGT"[i] for i in rng.integers(0, 4, size=160))     # > 2K + K: survives the tip cutting
+    for name, seqs in (("short", ["ACGTACGTACGTAAC"] * 20), ("one", [long_read] * 3)):
+        fq = tmp_path / f"{name}.fq"
+        fq.write_text("".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(seqs)))
+        cfg = tmp_path / f"{name}.cfg"
+        cfg.write_text(f"max_rd_len=200\n[LIB]\navg_ins=200\nasm_flags=3\nq={fq}\n")
+        cmd = [exe, "pregraph", "-s", str(cfg), "-K", "31", "-p", "4", "-o", str(tmp_path / name)]
+        if mode != "default":
+            cmd.append(mode)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for ext in ("kmerFreq", "vertex", "preGraphBasic", "preArc", "edge.gz"):
+            assert os.path.exists(str(tmp_path / name) + "." + ext)
+        nodes = int(re.search(r"(\d+) nodes allocated", r.stdout).group(1))
+        edges = gzip.open(str(tmp_path / name) + ".edge.gz", "rt").read()
+        if name == "short":
+            assert nodes == 0 and edges == ""
+        else:
+            assert nodes == len(seqs[0]) - 31 + 1 and edges.startswith(">length %d," % (nodes - 1))
