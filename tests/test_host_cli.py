@@ -325,3 +325,21 @@ def test_cli_degenerate_inputs(pkg, tmp_path, mode):
             assert nodes == 0 and edges == ""
         else:
             assert nodes == len(seqs[0]) - 31 + 1 and edges.startswith(">length %d," % (nodes - 1))
+
+
+@pytest.mark.gpu
+def test_sdt_map_without_paired_input(pkg, tmp_path):
+    """the reference's map reads PAIRED inputs only (read1seqInLib with pair=1): a single-end library gives header-only
+    files, 'grads&num: 0 0 <max_rd_len>' and the lines below (checked against a run of the reference binary)"""
+    info = mu.load_case("map_pe150_k31_p8")
+    mu.materialise(info, tmp_path)
+    cfg = tmp_path / "se.cfg"
+    cfg.write_text(f"max_rd_len=150\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq={tmp_path}/lib0_1.fq\n")
+    r = subprocess.run([bin_path(pkg, "sdt-map"), "map", "-s", str(cfg), "-g", str(tmp_path / "out"), "-p", "4"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(tmp_path / "out.readOnContig").read() == "read\tcontig\tpos\n"
+    assert open(tmp_path / "out.ctg2Read").read() == "read\tcontig\tpos\n"
+    assert open(tmp_path / "out.readInGap", "rb").read() == b""
+    assert open(tmp_path / "out.peGrads").read() == "grads&num: 0\t0\t150\n"
+    assert "0 out of 0 (-nan)% reads mapped to contigs\nno paired reads found\n[LIB] 0, avg_ins 200, reverse 0 \n" in r.stdout
