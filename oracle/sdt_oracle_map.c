@@ -178,10 +178,11 @@ typedef struct {
 	FILE *gap;
 	char *rc1;                  /* rcSeq[1]: thread 0's reverse-complement scratch AND the tight-string buffer (:430-437) */
 	long long reads_in_gap;
+	FILE *fill_gap, *fill_pe;   /* -f: the CONTENT of shortreadInGap.gz / PEreadOnContig.gz, uncompressed */
 } gap_out;
 
-/* output1read (prlRead2Ctg.c:423-446) without the `fill` branch */
-static void output1read(gap_out *G, const uint8_t *codes, int len, int ctg, int pos)
+/* output1read (prlRead2Ctg.c:423-446) */
+static void output1read(gap_out *G, const uint8_t *codes, int len, int ctg, int pos, char orien, int ins, int dhflag)
 {
 	G->reads_in_gap++;
 	for (int i = 0; i < len; i++) tight_put((char)codes[i], G->rc1, i);
@@ -189,6 +190,32 @@ static void output1read(gap_out *G, const uint8_t *codes, int len, int ctg, int 
 	fwrite(&ctg, sizeof(int), 1, G->gap);
 	fwrite(&pos, sizeof(int), 1, G->gap);
 	fwrite(G->rc1, 1, (size_t)(len / 4 + 1), G->gap);
+	if (G->fill_gap && ins < 2000 && len > 0) {                                    /* :439-444 */
+		fprintf(G->fill_gap, ">%d\t%d\t%d\t%c\t%d\t%d\n", len, ctg, pos, orien, ins, dhflag);
+		for (int i = 0; i < len; i++) fputc("ACTG"[codes[i]], G->fill_gap);
+		fputc('\n', G->fill_gap);
+	}
+}
+
+/* getPEreadOnContig (:493-524): both mates mapped; the tight strings go through the same shared buffer */
+static void pe_on_contig(gap_out *G, const uint8_t *c1, int len1, int ctg1, int pos1, char o1, int ins1,
+                         const uint8_t *c2, int len2, int ctg2, int pos2, char o2, int ins2)
+{
+	if (!(ins2 < 2000 && ins2 == ins1)) return;
+	fwrite(&len1, sizeof(int), 1, G->fill_pe);
+	fwrite(&ctg1, sizeof(int), 1, G->fill_pe);
+	fwrite(&pos1, sizeof(int), 1, G->fill_pe);
+	fwrite(&o1, 1, 1, G->fill_pe);
+	fwrite(&ins1, sizeof(int), 1, G->fill_pe);
+	for (int i = 0; i < len1; i++) tight_put((char)c1[i], G->rc1, i);
+	fwrite(G->rc1, 1, (size_t)(len1 / 4 + 1), G->fill_pe);
+	fwrite(&len2, sizeof(int), 1, G->fill_pe);
+	fwrite(&ctg2, sizeof(int), 1, G->fill_pe);
+	fwrite(&pos2, sizeof(int), 1, G->fill_pe);
+	fwrite(&o2, 1, 1, G->fill_pe);
+	fwrite(&ins2, sizeof(int), 1, G->fill_pe);
+	for (int i = 0; i < len2; i++) tight_put((char)c2[i], G->rc1, i);
+	fwrite(G->rc1, 1, (size_t)(len2 / 4 + 1), G->fill_pe);
 }
 
 /* prlRead2Ctg's main loop + recordAlldgn (prlRead2Ctg.c:561-608 part of it, 656-860) over reads that are already
@@ -197,12 +224,19 @@ static void output1read(gap_out *G, const uint8_t *codes, int len, int ctg, int 
  * counters[0] = reads, [1] = mapped, [2] = reads in gap, [3] = reads with > 20 candidate contigs (undefined upstream). */
 int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offsets, uint64_t nreads, const int32_t *lib_of_read,
                  const int32_t *lib_ins, const int32_t *lib_map_len, int max_read_len, int thrd_num, int buffer_size,
-                 int read_trace, const char *prefix, long long counters[4])
+                 int read_trace, int fill, const char *prefix, long long counters[4])
 {
 	const int K = M->S->K;
 	char name[4200];
 	snprintf(name, sizeof name, "%s.readInGap", prefix);
-	gap_out G = {fopen(name, "wb"), (char *)calloc((size_t)max_read_len + 8, 1), 0};
+	gap_out G = {fopen(name, "wb"), (char *)calloc((size_t)max_read_len + 8, 1), 0, NULL, NULL};
+	if (fill) {
+		snprintf(name, sizeof name, "%s.shortreadInGap", prefix);
+		G.fill_gap = fopen(name, "w");
+		snprintf(name, sizeof name, "%s.PEreadOnContig", prefix);
+		G.fill_pe = fopen(name, "wb");
+		if (!G.fill_gap || !G.fill_pe) return -1;
+	}
 	snprintf(name, sizeof name, "%s.readOnContig", prefix);
 	FILE *fo = fopen(name, "w");
 	snprintf(name, sizeof name, "%s.ctg2Read", prefix);
@@ -218,6 +252,8 @@ int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offset
 	/* per-batch state */
 	int *ctg_id = (int *)calloc((size_t)max_read_num + 1, sizeof(int)), *posv = (int *)calloc((size_t)max_read_num + 1, sizeof(int));
 	int *nh = (int *)calloc((size_t)max_read_num + 1, sizeof(int)), *foot = (int *)calloc((size_t)max_read_num + 1, sizeof(int));
+	char *orien = (char *)calloc((size_t)max_read_num + 1, 1);     /* orienArray: written for mapped reads only, so an unmapped read shows
+	                                                                 * what an earlier batch left at its index (:318-327) */
 	sdto_hit *hits = (sdto_hit *)calloc(((size_t)max_read_num + 1) * MAP_MAX_HITS, sizeof(sdto_hit));
 	int align_len = 0, prev_lib = -1;
 	uint64_t start = 0;
@@ -256,6 +292,7 @@ int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offset
 				const sdto_hit *h = &hits[(size_t)t * MAP_MAX_HITS + best];
 				ctg_id[t] = (int)h->contigID;
 				posv[t] = h->contigOffset - (int)h->readOffset + 1;
+				orien[t] = h->orien;
 			} else {
 				ctg_id[t] = 0;
 			}
@@ -271,14 +308,17 @@ int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offset
 					const int len2 = (int)(offsets[r + 1] - offsets[r]);
 					ctg_id[t] = ctg_id[t - 1];
 					posv[t] = posv[t - 1] + lib_ins[lib_of_read[r]] - len2;
-					output1read(&G, codes + offsets[r], len2, ctg_id[t], posv[t]);
+					output1read(&G, codes + offsets[r], len2, ctg_id[t], posv[t], orien[t - 1] == '+' ? '-' : '+', lib_ins[lib_of_read[r]], 1);
 					rd2gap = 1;
 				} else if (ctg_id[t] > 0 && ctg_id[t - 1] < 1) {                 /* read 1 in gap */
 					const int len1 = (int)(offsets[r] - offsets[r - 1]);
 					ctg_id[t - 1] = ctg_id[t];
 					posv[t - 1] = posv[t] + lib_ins[lib_of_read[r - 1]] - len1;
-					output1read(&G, codes + offsets[r - 1], len1, ctg_id[t - 1], posv[t - 1]);
+					output1read(&G, codes + offsets[r - 1], len1, ctg_id[t - 1], posv[t - 1], orien[t] == '+' ? '-' : '+', lib_ins[lib_of_read[r - 1]], 1);
 					rd1gap = 1;
+				} else if (ctg_id[t] > 0 && ctg_id[t - 1] > 0 && fill) {          /* PE read on contig :554-558 */
+					pe_on_contig(&G, codes + offsets[r - 1], (int)(offsets[r] - offsets[r - 1]), ctg_id[t - 1], posv[t - 1], orien[t - 1], lib_ins[lib_of_read[r - 1]],
+					             codes + offsets[r], (int)(offsets[r + 1] - offsets[r]), ctg_id[t], posv[t], orien[t], lib_ins[lib_of_read[r]]);
 				}
 			}
 			if (ctg < 1) continue;
@@ -302,9 +342,11 @@ int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offset
 			if (t % 2 == 0) continue;
 			/* "reads are not located by pe info but across edges" (:591-606); locate1read is unreachable: a footprint read is mapped */
 			if (foot[t - 1] && !rd1gap)
-				output1read(&G, codes + offsets[r - 1], (int)(offsets[r] - offsets[r - 1]), ctg_id[t - 1], posv[t - 1]);
+				output1read(&G, codes + offsets[r - 1], (int)(offsets[r] - offsets[r - 1]), ctg_id[t - 1], posv[t - 1], orien[t] == '+' ? '-' : '+',
+				            lib_ins[lib_of_read[r - 1]], 1);
 			if (foot[t] && !rd2gap)
-				output1read(&G, codes + offsets[r], (int)(offsets[r + 1] - offsets[r]), ctg_id[t], posv[t]);
+				output1read(&G, codes + offsets[r], (int)(offsets[r + 1] - offsets[r]), ctg_id[t], posv[t], orien[t - 1] == '+' ? '-' : '+',
+				            lib_ins[lib_of_read[r]], 2);
 		}
 		start = end;
 	}
@@ -314,6 +356,8 @@ int sdto_map_run(const sdto_map *M, const uint8_t *codes, const uint64_t *offset
 	counters[3] = overflowed;
 	fclose(G.gap); fclose(fo); fclose(f3);
 	if (f4) fclose(f4);
-	free(G.rc1); free(ctg_id); free(posv); free(nh); free(foot); free(hits);
+	if (G.fill_gap) fclose(G.fill_gap);
+	if (G.fill_pe) fclose(G.fill_pe);
+	free(G.rc1); free(ctg_id); free(posv); free(nh); free(foot); free(hits); free(orien);
 	return 0;
 }

@@ -8,7 +8,8 @@
  * prlRead2Ctg.c:656-894).  The hashing and the per-read alignment (chop, look-up, parse1read) run on the GPU
  * (sdt_gpu_index_contigs / sdt_gpu_align_reads); this file keeps the reference's read order, batch geometry
  * (ALIGNLEN is a global that parse1read samples per 10^8-k-mer batch), stdout lines and file writers.
- * Not supported: -f (gap-filling read dumps), b= BAM input, single-end files (the reference's map ignores them).
+ * -f adds <g>.shortreadInGap.gz and <g>.PEreadOnContig.gz (:439-444, 493-524).
+ * Not supported: b= BAM input; single-end files are ignored as in the reference's map.
  * Written from the reference's behaviour; no reference code is used. */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -17,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <zlib.h>
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
@@ -375,6 +377,7 @@ static void usage(void)
 	printf("  -g <string>      inputGraph: prefix of input graph file names\n");
 	printf("  -p <int>         n_cpu: number of cpu for use, [8]\n");
 	printf("  -K <int>         kmer(min 13, max 127): kmer size, [23]\n");
+	printf("  -f (optional)    output gap related reads for SRkgf to fill gap, [NO]\n");
 	printf("  -r (optional)    output the information between read and scaffold, [NO]\n");
 }
 
@@ -390,9 +393,10 @@ static inline void tight_put(unsigned nt, char *tight, int pos)
 	}
 }
 
-typedef struct { FILE *gap; char *rc1; long long reads_in_gap; } gap_out;
+typedef struct { FILE *gap; char *rc1; long long reads_in_gap; gzFile fill_gap, fill_pe; } gap_out;
 
-static void output1read(gap_out *G, rref x, int ctg, int pos)
+/* output1read (prlRead2Ctg.c:423-446) */
+static void output1read(gap_out *G, rref x, int ctg, int pos, char orien, int ins, int dhflag)
 {
 	const int len = rlen(x);
 	G->reads_in_gap++;
@@ -401,12 +405,30 @@ static void output1read(gap_out *G, rref x, int ctg, int pos)
 	fwrite(&ctg, sizeof(int), 1, G->gap);
 	fwrite(&pos, sizeof(int), 1, G->gap);
 	fwrite(G->rc1, 1, (size_t)(len / 4 + 1), G->gap);
+	if (G->fill_gap && ins < 2000 && len > 0) {
+		gzprintf(G->fill_gap, ">%d\t%d\t%d\t%c\t%d\t%d\n", len, ctg, pos, orien, ins, dhflag);
+		for (int i = 0; i < len; i++) gzputc(G->fill_gap, "ACTG"[rbase(x, i)]);
+		gzputc(G->fill_gap, '\n');
+	}
+}
+
+/* getPEreadOnContig (:493-524): both mates on contigs; their tight strings pass through the same shared buffer */
+static void pe_half(gap_out *G, rref x, int ctg, int pos, char orien, int ins)
+{
+	const int len = rlen(x);
+	gzwrite(G->fill_pe, &len, sizeof(int));
+	gzwrite(G->fill_pe, &ctg, sizeof(int));
+	gzwrite(G->fill_pe, &pos, sizeof(int));
+	gzwrite(G->fill_pe, &orien, 1);
+	gzwrite(G->fill_pe, &ins, sizeof(int));
+	for (int i = 0; i < len; i++) tight_put(rbase(x, i), G->rc1, i);
+	gzwrite(G->fill_pe, G->rc1, (unsigned)(len / 4 + 1));
 }
 
 int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", graph[4096] = "";
-	int threads = 8, max_k = 0, device = 0, read_trace = 0, have_s = 0, have_g = 0, c;
+	int threads = 8, max_k = 0, device = 0, read_trace = 0, fill = 0, have_s = 0, have_g = 0, c;
 	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
 	                                   {"batch-kmers", required_argument, 0, 1002}, {0, 0, 0, 0}};
 	int batch_kmers = 100000000;                           /* buffer_size of prlRead2Ctg.c:31; --batch-kmers exists for the tests */
@@ -419,7 +441,7 @@ int main(int argc, char **argv)
 		case 'p': threads = atoi(optarg); break;
 		case 'r': read_trace = 1; break;
 		case 'R': break;                                   /* RPKM: used by later stages only */
-		case 'f': fprintf(stderr, "-f (gap-filling read dumps) is not supported by this build\n"); return 1;
+		case 'f': fill = 1; break;
 		case 1000: max_k = atoi(optarg); break;
 		case 1001: device = atoi(optarg); break;
 		case 1002: batch_kmers = atoi(optarg); break;
@@ -599,7 +621,7 @@ int main(int argc, char **argv)
 
 	/* ---- recordAlldgn (prlRead2Ctg.c:526-608) ---- */
 	snprintf(name, sizeof name, "%s.readInGap", graph);
-	gap_out G = {fopen(name, "wb"), (char *)calloc((size_t)max_read_len + 8, 1), 0};
+	gap_out G = {fopen(name, "wb"), (char *)calloc((size_t)max_read_len + 8, 1), 0, NULL, NULL};
 	if (!G.gap) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
 	snprintf(name, sizeof name, "%s.readOnContig", graph);
 	FILE *fo = fopen(name, "w");
@@ -607,6 +629,13 @@ int main(int argc, char **argv)
 	snprintf(name, sizeof name, "%s.ctg2Read", graph);
 	FILE *f3 = fopen(name, "w");
 	if (!f3) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
+	if (fill) {
+		snprintf(name, sizeof name, "%s.shortreadInGap.gz", graph);
+		G.fill_gap = gzopen(name, "w");
+		snprintf(name, sizeof name, "%s.PEreadOnContig.gz", graph);
+		G.fill_pe = gzopen(name, "wb");
+		if (!G.fill_gap || !G.fill_pe) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
+	}
 	FILE *f4 = NULL;
 	if (read_trace) {
 		snprintf(name, sizeof name, "%s.readInformation", graph);
@@ -661,6 +690,8 @@ int main(int argc, char **argv)
 		rref x, prev = {NULL, 0};
 		int lib, prev_lib_seen = -1, prev_stream = -1;
 		int ctg_prev = 0, pos_prev = 0, foot_prev = 0, lib_prev = 0;
+		/* orienArray: written for mapped reads only, so an unmapped read shows what an earlier batch left at its index */
+		char *orien_at = (char *)calloc((size_t)max_read_num + 2, 1);
 		for (uint64_t g = 0; cur_next(&cu, &x, &lib); g++) {
 			/* the lines the reference prints while it opens files and switches libraries */
 			if (cu.si != prev_stream) {
@@ -703,33 +734,39 @@ int main(int argc, char **argv)
 			const sdt_hit *hb = !nh ? NULL : (best == 0 ? &x.b->hits[x.i] : &x.b->hits[(w & ((1ULL << 40) - 1)) + (uint64_t)best - 1]);
 			int ctg = nh ? (int)hb->contig : 0;
 			int pos = nh ? hb->contig_offset - (int)hb->read_offset + 1 : 0;
+			if (nh) orien_at[t] = (hb->align_len_orien >> 31) ? '-' : '+';
+			const int ins = cfg.libs[lib].avg_ins, ins_prev = cfg.libs[lib_prev].avg_ins;
 			const int ctg_at_top = ctg;
 			int rd1gap = 0, rd2gap = 0;
 			if (t % 2 == 1 && prev.b) {
 				if (ctg < 1 && ctg_prev > 0) {                                         /* read 2 in gap (:541-545, getReadIngap) */
 					ctg = ctg_prev;
-					pos = pos_prev + cfg.libs[lib].avg_ins - rlen(x);
-					output1read(&G, x, ctg, pos);
+					pos = pos_prev + ins - rlen(x);
+					output1read(&G, x, ctg, pos, orien_at[t - 1] == '+' ? '-' : '+', ins, 1);
 					rd2gap = 1;
 				} else if (ctg > 0 && ctg_prev < 1) {                                  /* read 1 in gap */
 					ctg_prev = ctg;
-					pos_prev = pos + cfg.libs[lib_prev].avg_ins - rlen(prev);
-					output1read(&G, prev, ctg_prev, pos_prev);
+					pos_prev = pos + ins_prev - rlen(prev);
+					output1read(&G, prev, ctg_prev, pos_prev, orien_at[t] == '+' ? '-' : '+', ins_prev, 1);
 					rd1gap = 1;
+				} else if (ctg > 0 && ctg_prev > 0 && fill && ins < 2000 && ins == ins_prev) {   /* :554-558, 504 */
+					pe_half(&G, prev, ctg_prev, pos_prev, orien_at[t - 1], ins_prev);
+					pe_half(&G, x, ctg, pos, orien_at[t], ins);
 				}
 			}
 			if (ctg_at_top >= 1) {
 				if (t % 2 == 1 && prev.b) {
 					/* "reads are not located by pe info but across edges" (:591-606); a footprint read is always mapped, so
 					 * locate1read is never reached */
-					if (foot_prev && !rd1gap) output1read(&G, prev, ctg_prev, pos_prev);
-					if (foot && !rd2gap) output1read(&G, x, ctg, pos);
+					if (foot_prev && !rd1gap) output1read(&G, prev, ctg_prev, pos_prev, orien_at[t] == '+' ? '-' : '+', ins_prev, 1);
+					if (foot && !rd2gap) output1read(&G, x, ctg, pos, orien_at[t - 1] == '+' ? '-' : '+', ins, 2);
 				}
 			}
 			prev = x;
 			ctg_prev = ctg; pos_prev = pos; foot_prev = foot; lib_prev = lib;
 			if (t % 2 == 1) prev.b = NULL;                                             /* pairs never straddle (t-1, t) with t even */
 		}
+		free(orien_at);
 	}
 	if (total % (uint64_t)max_read_num)                                               /* printed only when the last batch was not empty (:813-821) */
 		printf("Output %lld out of %lld (%.1f)%% reads in gaps\n", G.reads_in_gap, read_counter, (float)G.reads_in_gap / read_counter * 100);
@@ -738,6 +775,8 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%lld reads touch more than 20 contigs with >= ALIGNLEN-K+1 k-mers each (the reference overruns a 20-entry array there); reported unmapped\n", overflowed);
 	fclose(fo); fclose(f3); fclose(G.gap);
 	if (f4) fclose(f4);
+	if (G.fill_gap) gzclose(G.fill_gap);
+	if (G.fill_pe) gzclose(G.fill_pe);
 	phase("readInGap (ordered pass)");
 	/* *.peGrads (:825-846): one line per library that delivered reads, boundaries in reads */
 	snprintf(name, sizeof name, "%s.peGrads", graph);

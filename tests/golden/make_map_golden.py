@@ -77,6 +77,10 @@ CASES = [
                dict(kind="q", n=600, L=120, ins=180, extra="", ragged=28)]),
     dict(name="map_k47_63mer_p2", variant=63, K=47, p=2, T=20,
          libs=[dict(kind="q", n=900, L=150, ins=250, extra="")]),
+    # -f: the gap-filling dumps (shortreadInGap.gz, PEreadOnContig.gz); the 2500 library is filtered out of them (:439,:505)
+    dict(name="map_fill_two_libs_k31_p3", variant=31, K=31, p=3, T=25, fill=True,
+         libs=[dict(kind="q", n=600, L=100, ins=2500, extra="", ragged=25),
+               dict(kind="q", n=800, L=100, ins=220, extra="", ragged=40)]),
 ]
 
 
@@ -127,7 +131,8 @@ def make_case(c):
     run = lambda args: subprocess.run([exe] + args, check=True, capture_output=True, text=True, timeout=120).stdout
     run(["pregraph", "-s", os.path.join(tmp, "pg.cfg"), "-K", str(c["K"]), "-p", str(c["p"]), "-o", out])
     run(["contig", "-g", out])
-    log = run(["map", "-s", os.path.join(tmp, "lib.cfg"), "-g", out, "-p", str(c["p"])] + (["-r"] if c.get("trace") else []))
+    log = run(["map", "-s", os.path.join(tmp, "lib.cfg"), "-g", out, "-p", str(c["p"])] + (["-r"] if c.get("trace") else [])
+              + (["-f"] if c.get("fill") else []))
     info = dict(c)
     m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", log)
     info["nodes_allocated"], info["kmer_in_contigs"] = int(m.group(1)), int(m.group(2))
@@ -145,6 +150,11 @@ def make_case(c):
     exts = ["contig", "ContigIndex", "preGraphBasic", "readOnContig", "ctg2Read", "peGrads", "readInGap"]
     if c.get("trace"):
         exts.append("readInformation")
+    if c.get("fill"):                      # stored decompressed: the gzip bytes themselves are not part of the contract
+        for ext in ("shortreadInGap", "PEreadOnContig"):
+            with gzip.open(out + "." + ext + ".gz", "rb") as fi, open(out + "." + ext, "wb") as fo:
+                fo.write(fi.read())
+            exts.append(ext)
     for ext in exts:
         with open(out + "." + ext, "rb") as fi, gzip.GzipFile(os.path.join(cdir, "out." + ext + ".gz"), "wb", mtime=0) as fo:
             fo.write(fi.read())
@@ -155,5 +165,7 @@ def make_case(c):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for c in CASES:
-        make_case(c)
+        if not only or c["name"] in only:
+            make_case(c)

@@ -196,7 +196,7 @@ class MapOracle:
         L.sdto_map_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.sdto_map_run.restype = C.c_int
         L.sdto_map_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
         self.h = L.sdto_map_new(nsets, nw, K)
         self.K = K
 
@@ -226,7 +226,7 @@ class MapOracle:
         n = self.L.sdto_map_read(self.h, codes.ctypes.data, len(codes), align_len, hits, C.byref(best), C.byref(foot))
         return n, [(h.contigID, h.contigOffset, h.readOffset, h.alignLength, h.orien.decode()) for h in hits[: max(n, 0)]], best.value, foot.value
 
-    def run(self, codes, offs, lib_of, lib_ins, lib_map_len, max_read_len, p, prefix, buffer_size=100000000, trace=False):
+    def run(self, codes, offs, lib_of, lib_ins, lib_map_len, max_read_len, p, prefix, buffer_size=100000000, trace=False, fill=False):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         lib_of = np.ascontiguousarray(lib_of, dtype=np.int32)
@@ -234,7 +234,7 @@ class MapOracle:
         lib_map_len = np.ascontiguousarray(lib_map_len, dtype=np.int32)
         counters = np.zeros(4, dtype=np.int64)
         rc = self.L.sdto_map_run(self.h, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, lib_of.ctypes.data,
-                                 lib_ins.ctypes.data, lib_map_len.ctypes.data, max_read_len, p, buffer_size, int(trace),
+                                 lib_ins.ctypes.data, lib_map_len.ctypes.data, max_read_len, p, buffer_size, int(trace), int(fill),
                                  str(prefix).encode(), counters.ctypes.data)
         assert rc == 0
         return [int(x) for x in counters]

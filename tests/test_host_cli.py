@@ -219,10 +219,15 @@ def test_sdt_map_files_bit_identical(pkg, tmp_path, name):
     cmd = [bin_path(pkg, "sdt-map"), "map", "-s", cfg, "-g", str(tmp_path / "out"), "-p", str(info["p"])]
     if info.get("trace"):
         cmd.append("-r")
+    if info.get("fill"):
+        cmd.append("-f")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     for ext in ["readOnContig", "ctg2Read", "readInGap", "peGrads"] + (["readInformation"] if info.get("trace") else []):
         assert open(str(tmp_path / "out") + "." + ext, "rb").read() == mu.gz_bytes(info, ext), ext
+    if info.get("fill"):                       # the gap-filling dumps: compared after decompression
+        for ext in ("shortreadInGap", "PEreadOnContig"):
+            assert gzip.open(str(tmp_path / "out") + "." + ext + ".gz", "rb").read() == mu.gz_bytes(info, ext), ext
     strip = lambda t: [l for l in t.splitlines() if "time spent" not in l and str(tmp_path) not in l and "overall time" not in l
                        and not l.startswith("Version")]
     golden = [l for l in open(os.path.join(info["dir"], "stdout.log")).read().splitlines() if not l.startswith("Version")]
@@ -240,7 +245,7 @@ def test_sdt_map_usage_and_errors(pkg, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,batch_kmers", [("map_longins_ragged_k31_p5", 9000), ("map_fa100_k23_p4_two_libs", 20000),
-                                              ("map_pe250_k63_127mer_p3", 30000)])
+                                              ("map_pe250_k63_127mer_p3", 30000), ("map_fill_two_libs_k31_p3", 7000)])
 def test_sdt_map_batch_logic_equals_oracle(pkg, tmp_path, name, batch_kmers):
     """many small batches instead of one: ALIGNLEN as left by the last read of each batch (a batch that spans two
     libraries takes the later one's), thread 0's reverse-complement scratch under the *.readInGap records of every
@@ -251,14 +256,19 @@ def test_sdt_map_batch_logic_equals_oracle(pkg, tmp_path, name, batch_kmers):
     o = mu.build_oracle(info)
     codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
     counters = o.run(codes, offs, lib_of, [l["avg_ins"] for l in libs], [l["map_len"] for l in libs], max_rd_len, info["p"],
-                     tmp_path / "o", buffer_size=batch_kmers, trace=bool(info.get("trace")))
+                     tmp_path / "o", buffer_size=batch_kmers, trace=bool(info.get("trace")), fill=bool(info.get("fill")))
     cmd = [bin_path(pkg, "sdt-map"), "map", "-s", cfg, "-g", str(tmp_path / "out"), "-p", str(info["p"]), "--batch-kmers", str(batch_kmers)]
     if info.get("trace"):
         cmd.append("-r")
+    if info.get("fill"):
+        cmd.append("-f")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []):
         assert open(str(tmp_path / "out") + "." + ext, "rb").read() == open(str(tmp_path / "o") + "." + ext, "rb").read(), ext
+    if info.get("fill"):        # stale orientations of unmapped reads come from earlier batches at the same index
+        for ext in ("shortreadInGap", "PEreadOnContig"):
+            assert gzip.open(str(tmp_path / "out") + "." + ext + ".gz", "rb").read() == open(str(tmp_path / "o") + "." + ext, "rb").read(), ext
     assert f"{counters[1]} out of {counters[0]} " in r.stdout
 
 

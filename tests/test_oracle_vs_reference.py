@@ -210,7 +210,8 @@ def test_map_oracle_matches_reference_files(tmp_path, name):
     assert o.counts() == (info["nodes_allocated"], info["kmer_in_contigs"])
     codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
     counters = o.run(codes, offs, lib_of, [l["avg_ins"] for l in libs], [l["map_len"] for l in libs], max_rd_len, info["p"],
-                     tmp_path / "o", trace=bool(info.get("trace")))
+                     tmp_path / "o", trace=bool(info.get("trace")), fill=bool(info.get("fill")))
     assert counters[:3] == [info["reads"], info["reads_mapped"], info["reads_in_gap"]] and counters[3] == 0
-    for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []):
+    for ext in ["readOnContig", "ctg2Read", "readInGap"] + (["readInformation"] if info.get("trace") else []) + \
+            (["shortreadInGap", "PEreadOnContig"] if info.get("fill") else []):
         assert open(str(tmp_path / "o") + "." + ext, "rb").read() == mu.gz_bytes(info, ext), ext
