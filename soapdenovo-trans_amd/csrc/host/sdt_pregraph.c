@@ -192,7 +192,7 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
-	uint64_t cap = g->n / 16 + 4096;
+	uint64_t cap = g->n / 6 + 4096;                        /* junction + candidate records: ~5-10 % of the nodes */
 	for (;;) {
 		uint64_t *rec = (uint64_t *)malloc(cap * 9 * sizeof(uint64_t));
 		if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)cap); return 1; }
