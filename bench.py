@@ -226,6 +226,8 @@ def main():
         else:
             g.set_owner_filter(rank, world)
 
+    local_inserted = [0]
+
     def one_step(verify=False):
         g.reset()
         if not sharded_path or not route:
@@ -234,6 +236,7 @@ def main():
             with torch.cuda.stream(stream):
                 sharded.count_reads(words, nwords, offsets, n_local, verify=verify)
         kmers, nodes = g.finish_count()
+        local_inserted[0] = kmers              # this rank's share (owner filter / routed records) before the all-reduce
         hist, linear = g.mark_and_hist()
         if sharded_path:
             hist, kmers, nodes, linear = allreduce_stats(hist, kmers, nodes, linear, dev)
@@ -267,11 +270,14 @@ def main():
     value = kmers_total * args.steps / dt
     B = algorithmic_bytes_per_kmer(L, K)
     # kernel-level: this rank's k-mers over this rank's kernel time (N=1: whole job)
-    local_kmers = n_local * (L - K + 1) if world == 1 else None
+    # N > 1, owner filter: rank 0's chop+insert launches walk ALL reads and insert its share of the k-mers; the bytes
+    # that count are those of the k-mers it inserted
+    filter_path = sharded_path and not route
+    local_kmers = n_local * (L - K + 1) if not sharded_path else (local_inserted[0] if filter_path else None)
     roof = None
-    if world == 1 and not sharded_path and kms > 0:
+    if local_kmers and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
-        tpk, tsrc = pmc_traffic_per_kmer(K)
+        tpk, tsrc = pmc_traffic_per_kmer(K) if not sharded_path else (None, None)
         per_launch_kmers = local_kmers * args.steps / max(launches, 1)
         roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
@@ -280,6 +286,9 @@ def main():
                 "algorithmic_bytes_per_launch": round(B * per_launch_kmers), "kernel": "k_count_reads",
                 "bytes_per_kmer": round(B, 3), "launches": int(launches),
                 "avg_launch_ms": round(kms / max(launches, 1), 4), "kernel_ms_per_step": round(kms / args.steps, 3)}
+        if sharded_path:
+            roof["rank"] = 0
+            roof["note"] = "rank 0 only: its launches chop every read and insert the k-mers it owns"
     out = {
         "metric": "pregraph k-mers hashed/sec", "value": value, "unit": "kmers/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,

@@ -648,6 +648,7 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(pkg, tmp_path):
     assert two.returncode == 0, two.stderr[-2000:]
     b = json.loads(two.stdout.strip().splitlines()[-1])
     assert b["n_gpus"] == 2 and "owner-sharded" in b["config"]["parallelism"]
+    assert b["roofline"] and b["roofline"]["rank"] == 0 and 0 < b["roofline"]["frac"] < 1     # rank 0's kernel, its own k-mers
     for k in ("kmers", "distinct_nodes", "linear_nodes"):
         assert a["config"][k] == b["config"][k], k
 
