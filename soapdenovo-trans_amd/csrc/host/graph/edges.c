@@ -146,7 +146,7 @@ static void emit_edge(graph_t *g, chain_t *c, gzFile fp, char **seqbuf, size_t *
 		plus.w[1] = (first->kmer.w[1] << 2) | (first->kmer.w[2] >> 62);
 		plus.w[2] = (first->kmer.w[2] << 2) | (first->kmer.w[3] >> 62);
 		plus.w[3] = (first->kmer.w[3] << 2) | kw_last(&last->kmer);
-		kw_t bal = kw_rc(plus, K + 1);
+		kw_t bal = kw_rc_kplus1(plus, K);
 		if (kw_less(&plus, &bal)) patch_put(g, &plus, id, (uint8_t)(bal_edge + 1));
 		else patch_put(g, &bal, id + (uint32_t)bal_edge, (uint8_t)(1 - bal_edge));
 		symbol = first->node->count;                                      /* :474-478 */
@@ -480,7 +480,7 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		plus.w[1] = (from.w[1] << 2) | (from.w[2] >> 62);
 		plus.w[2] = (from.w[2] << 2) | (from.w[3] >> 62);
 		plus.w[3] = (from.w[3] << 2) | b;
-		kw_t bal = kw_rc(plus, g->K + 1);
+		kw_t bal = kw_rc_kplus1(plus, g->K);
 		if (kw_less(&plus, &bal)) patch_put(g, &plus, P->id, (uint8_t)(P->bal_edge + 1));
 		else patch_put(g, &bal, P->id + (uint32_t)P->bal_edge, (uint8_t)(1 - P->bal_edge));
 	}

@@ -78,6 +78,17 @@ static inline kw_t kw_rc(kw_t k, int K)
 	}
 	return r;
 }
+/* reverseComplement(x, K + 1) as the reference computes it for the (K+1)-mers of length-1 edges (node2edge.c:404-463,
+ * prlRead2path.c:719-738): fastReverseComp takes the length as a `char` (kmer.c:548), so 128 (K = 127) arrives as
+ * -128, takes the "shorter than 32" branch and only complements + reverses the LAST word (its shift count, 320, acts
+ * as 0 on x86-64).  The 127mer binary's patch table and its look-ups both live with that; so do we. */
+static inline kw_t kw_rc_kplus1(kw_t plus, int K)
+{
+	if (K + 1 < 128) return kw_rc(plus, K + 1);
+	kw_t r = plus;
+	r.w[3] = kw_rev2(plus.w[3] ^ 0xAAAAAAAAAAAAAAAAULL);
+	return r;
+}
 static inline unsigned kw_first(const kw_t *k, int K) { return kw_get2(k, 2 * (K - 1)); }
 static inline unsigned kw_last(const kw_t *k) { return (unsigned)k->w[3] & 3u; }
 

@@ -112,7 +112,7 @@ void arcs_add_read(graph_t *g, struct arcs *A, const uint8_t *codes, int len, ui
 				plus.w[1] = (prev_kmer.w[1] << 2) | (prev_kmer.w[2] >> 62);
 				plus.w[2] = (prev_kmer.w[2] << 2) | (prev_kmer.w[3] >> 62);
 				plus.w[3] = (prev_kmer.w[3] << 2) | kw_last(&word);
-				kw_t bal = kw_rc(plus, K + 1);
+				kw_t bal = kw_rc_kplus1(plus, K);
 				const int plus_smaller = kw_less(&plus, &bal);
 				const gpatch_t *p = graph_find_patch(g, plus_smaller ? &plus : &bal);
 				mix[pos++] = !p ? 0 : (plus_smaller ? p->edge : (uint64_t)p->edge + p->twin - 1);

@@ -124,6 +124,14 @@ __device__ inline void arc_add(ArcEnt *arcs, uint64_t amask, uint32_t from, uint
 }
 
 // shift the NW-word value left by one base and append b (no mask)
+template <int NW> __device__ inline Key<NW> key_revcomp_kplus1(const Key<NW> &plus, int K)
+{
+	if (K + 1 < 128) return key_revcomp<NW>(plus, K + 1);
+	Key<NW> r = plus;
+	r.w[NW - 1] = rev2bit(plus.w[NW - 1] ^ 0xAAAAAAAAAAAAAAAAULL);
+	return r;
+}
+
 template <int NW> __device__ inline Key<NW> key_append(const Key<NW> &k, uint32_t b)
 {
 	Key<NW> r;
@@ -210,7 +218,8 @@ __global__ __launch_bounds__(TPB) void k_map_reads(const uint32_t *__restrict__ 
 				if (have_prev) {
 					// (K+1)-mer = previous vertex k-mer (as read) + last base of this one; canonical over K+1
 					Key<NW> plus = key_append<NW>(prev_kmer, b);
-					Key<NW> bal = key_revcomp<NW>(plus, K + 1);
+					// K = 127: the reference's reverse complement of a 128-mer touches the last word only (host/graph/kw.h)
+					Key<NW> bal = key_revcomp_kplus1<NW>(plus, K);
 					const bool ps = key_less<NW>(plus, bal);
 					const uint64_t pi = lookup_patch<NW>(patch, pmask, ps ? plus : bal);
 					const uint64_t id = pi & 0xFFFFFFFFULL, twin = (pi >> 32) & 3u;

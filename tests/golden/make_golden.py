@@ -77,6 +77,9 @@ CASES = [
     dict(name="dirty_ragged_k25_cut80", variant=31, K=25, p=8, d=0, n=3000, L=120, T=30, kind="dirty", max_rd_len=80),
     dict(name="evenK24_p2", variant=31, K=24, p=2, d=0, n=1500, L=100, T=20, kind="se"),
     dict(name="smallK11_p8", variant=31, K=11, p=8, d=0, n=800, L=60, T=10, kind="se"),
+    # K = 127: the (K+1)-mers of length-1 edges are 128 bases long, where the reference's reverseComplement misfires
+    # (its length parameter is a char); *.preArc shows it
+    dict(name="alleles250_k127_p5_127mer", variant=127, K=127, p=5, d=0, n=6000, L=250, T=5, kind="alleles"),
 ]
 
 
@@ -101,6 +104,27 @@ def make_case(c):
         synth.write_fastq(p2, c2, o2)
         files = [p1, p2]
         cfg = f"max_rd_len={max_rd_len}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq1=@DIR@/reads_1.fq\nq2=@DIR@/reads_2.fq\n"
+    elif c["kind"] == "alleles":
+        # three alleles of every transcript: the original, one with substitutions at positions p, one with substitutions
+        # at p + 1 -- equally covered, so both branchings survive the cleaning and sit on ADJACENT k-mers: length-1 edges
+        codes0, starts0, _ = tx
+        seqs = []
+        for t in range(len(starts0) - 1):
+            a = codes0[starts0[t]:starts0[t + 1]].copy()
+            b, d = a.copy(), a.copy()
+            for pos in range(300, len(a) - 300, 350):
+                b[pos] = (b[pos] + 1) & 3
+                d[pos + 1] = (d[pos + 1] + 2) & 3
+            seqs += [a, b, d]
+        st = np.zeros(len(seqs) + 1, dtype=np.int64)
+        st[1:] = np.cumsum([len(x) for x in seqs])
+        w3 = np.array([float(len(x)) for x in seqs])
+        tx3 = (np.concatenate(seqs), st, w3 / w3.sum())
+        codes, offs = synth.sample_reads(*tx3, n_reads=c["n"], read_len=c["L"], seed=5, err=0.001)
+        p = os.path.join(tmp, "reads.fq")
+        synth.write_fastq(p, codes, offs)
+        files = [p]
+        cfg = f"max_rd_len={max_rd_len}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq=@DIR@/reads.fq\n"
     else:  # dirty ragged single-end
         rng = np.random.default_rng(77)
         codes, offs = synth.sample_reads(*tx, n_reads=c["n"], read_len=c["L"], seed=5, err=0.004, ragged=True)
@@ -150,7 +174,10 @@ def make_case(c):
 
 
 if __name__ == "__main__":
-    for v in (31, 63, 127):
-        run_probe(v)
+    only = sys.argv[1:]
+    if not only:
+        for v in (31, 63, 127):
+            run_probe(v)
     for c in CASES:
-        make_case(c)
+        if not only or c["name"] in only:
+            make_case(c)

@@ -96,6 +96,14 @@ try:
             same[ext] = open(os.path.join(tmp, "ours." + ext), "rb").read() == open(os.path.join(tmp, "ref." + ext), "rb").read()
         same["edge"] = gzip.open(os.path.join(tmp, "ours.edge.gz")).read() == gzip.open(os.path.join(tmp, "ref.edge.gz")).read()
         res["identical"] = same
+        if not same["preArc"]:
+            a = open(os.path.join(tmp, "ours.preArc")).read().splitlines()
+            b = open(os.path.join(tmp, "ref.preArc")).read().splitlines()
+            res["preArc_lines"] = [len(a), len(b)]
+            res["preArc_diff"] = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y][:6]
+            rh = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                                 os.path.join(tmp, "hm"), "--host-map"], capture_output=True, text=True, timeout=args.timeout)
+            res["host_map_preArc_same_as_ref"] = open(os.path.join(tmp, "hm.preArc")).read() == open(os.path.join(tmp, "ref.preArc")).read()
         res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
     res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]"))]
