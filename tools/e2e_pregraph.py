@@ -28,6 +28,8 @@ ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
+ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
+ap.add_argument("--variant", type=int, default=0, choices=[0, 31, 63, 127], help="reference binary to compare with (default: 31 for K <= 31, else 127)")
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 args = ap.parse_args()
 
@@ -54,11 +56,14 @@ try:
            "kmers": args.reads * (args.read_len - args.K + 1), "gen_s": round(gen_s, 1)}
     subprocess.run(["cat", fq], stdout=subprocess.DEVNULL)                     # warm the page cache
     ours = os.path.join(pkg.CSRC_DIR, "sdt-pregraph")
+    variant = args.variant or (31 if args.K <= 31 else 127)
+    extra = ["--max-k", str(variant)] + (["-d", str(args.d)] if args.d else [])
+    res["variant"], res["d"] = variant, args.d
     os.environ["SDT_TIMING"] = "1"
     t0 = time.time()
     try:
         r = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                            os.path.join(tmp, "ours")], capture_output=True, text=True, timeout=args.timeout)
+                            os.path.join(tmp, "ours")] + extra, capture_output=True, text=True, timeout=args.timeout)
     except subprocess.TimeoutExpired as e:
         print("sdt-pregraph timed out; stderr so far:\n", (e.stderr or b"").decode()[-3000:])
         raise SystemExit(1)
@@ -68,12 +73,12 @@ try:
         raise SystemExit("sdt-pregraph failed")
     t0 = time.time()
     r2 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                         os.path.join(tmp, "ours_hash"), "--hash-only"], capture_output=True, text=True)
+                         os.path.join(tmp, "ours_hash"), "--hash-only"] + extra, capture_output=True, text=True)
     res["ours_hash_only_wall_s"] = round(time.time() - t0, 2)
     if args.compare_host_walks:
         t0 = time.time()
         r3 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                             os.path.join(tmp, "hw"), "--host-walks"], capture_output=True, text=True, timeout=args.timeout)
+                             os.path.join(tmp, "hw"), "--host-walks"] + extra, capture_output=True, text=True, timeout=args.timeout)
         res["ours_host_walks_wall_s"] = round(time.time() - t0, 2)
         res["host_walks_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r3.stderr.splitlines() if l.startswith("[sdt-pregraph]")]
         res["same_as_host_walks"] = {ext: open(os.path.join(tmp, "ours." + ext), "rb").read() == open(os.path.join(tmp, "hw." + ext), "rb").read()
@@ -81,11 +86,11 @@ try:
         strip = lambda t: [l for l in t.splitlines() if not l.startswith("time spent")]
         res["same_stdout_as_host_walks"] = strip(r.stdout) == strip(r3.stdout)
     if not args.skip_ref:
-        ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-Trans-{31 if args.K <= 31 else 127}mer")
+        ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-Trans-{variant}mer")
         t0 = time.time()
         try:
             rr = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                                 os.path.join(tmp, "ref")], capture_output=True, text=True, timeout=max(args.timeout, 900))
+                                 os.path.join(tmp, "ref")] + (["-d", str(args.d)] if args.d else []), capture_output=True, text=True, timeout=max(args.timeout, 900))
         except subprocess.TimeoutExpired:
             print(json.dumps(res, indent=1))
             raise SystemExit("the reference binary did not finish (its AIO reader can spin forever, SURVEY 9.3-q9)")
@@ -102,7 +107,7 @@ try:
             res["preArc_lines"] = [len(a), len(b)]
             res["preArc_diff"] = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y][:6]
             rh = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                                 os.path.join(tmp, "hm"), "--host-map"], capture_output=True, text=True, timeout=args.timeout)
+                                 os.path.join(tmp, "hm"), "--host-map"] + extra, capture_output=True, text=True, timeout=args.timeout)
             res["host_map_preArc_same_as_ref"] = open(os.path.join(tmp, "hm.preArc")).read() == open(os.path.join(tmp, "ref.preArc")).read()
         res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
