@@ -28,6 +28,7 @@ ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
+ap.add_argument("--layout", choices=["se", "pe", "mixed"], default="se", help="library layout of the synthetic input")
 ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
 ap.add_argument("--variant", type=int, default=0, choices=[0, 31, 63, 127], help="reference binary to compare with (default: 31 for K <= 31, else 127)")
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
@@ -38,23 +39,64 @@ try:
     tx = synth.make_transcriptome(args.T, seed=42)
     fq = os.path.join(tmp, "reads.fq")
     t0 = time.time()
-    with open(fq, "wb") as fo:
-        done = 0
-        chunk = 250_000
-        while done < args.reads:
-            n = min(chunk, args.reads - done)
-            codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=args.read_len, seed=1000 + done, err=0.002)
-            letters = synth.BASES[codes].reshape(n, args.read_len)
-            qual = b"I" * args.read_len
-            fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i].tobytes(), qual) for i in range(n)))
-            done += n
-    if os.path.getsize(fq) % 32768 == 0:
-        open(fq, "ab").write(b"\n")
-    synth.write_config(os.path.join(tmp, "lib.cfg"), args.read_len, fastq=[fq])
+
+    def write_se(path, n_reads, seed0):
+        with open(path, "wb") as fo:
+            done = 0
+            while done < n_reads:
+                n = min(250_000, n_reads - done)
+                codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=args.read_len, seed=seed0 + done, err=0.002)
+                letters = synth.BASES[codes].reshape(n, args.read_len)
+                qual = b"I" * args.read_len
+                fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i].tobytes(), qual) for i in range(n)))
+                done += n
+        if os.path.getsize(path) % 32768 == 0:
+            open(path, "ab").write(b"\n")
+
+    def write_pe(p1, p2, n_pairs, seed0):
+        qual = b"I" * args.read_len
+        with open(p1, "wb") as o1, open(p2, "wb") as o2:
+            done = 0
+            while done < n_pairs:
+                n = min(250_000, n_pairs - done)
+                (c1, _), (c2, _) = synth.sample_pairs(*tx, n_pairs=n, read_len=args.read_len, seed=seed0 + done, err=0.002, avg_ins=300)
+                l1, l2 = synth.BASES[c1].reshape(n, args.read_len), synth.BASES[c2].reshape(n, args.read_len)
+                o1.write(b"".join(b"@r%d/1\n%s\n+\n%s\n" % (done + i, l1[i].tobytes(), qual) for i in range(n)))
+                o2.write(b"".join(b"@r%d/2\n%s\n+\n%s\n" % (done + i, l2[i].tobytes(), qual) for i in range(n)))
+                done += n
+        for f in (p1, p2):
+            if os.path.getsize(f) % 32768 == 0:
+                open(f, "ab").write(b"\n")
+
+    cfg_path = os.path.join(tmp, "lib.cfg")
+    if args.layout == "se":
+        write_se(fq, args.reads, 1000)
+        synth.write_config(cfg_path, args.read_len, fastq=[fq])
+    elif args.layout == "pe":
+        p1, p2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
+        write_pe(p1, p2, args.reads // 2, 1000)
+        fq = p1
+        open(cfg_path, "w").write(f"max_rd_len={args.read_len}\n[LIB]\navg_ins=300\nreverse_seq=0\nasm_flags=3\nq1={p1}\nq2={p2}\n")
+    else:
+        # mixed: the config lists a 500-bp single-end library FIRST and a 200-bp paired one second, with a second pair of
+        # files and a reverse_seq library; the reference sorts libraries by avg_ins and reads pairs before singles
+        a1, a2 = os.path.join(tmp, "a_1.fq"), os.path.join(tmp, "a_2.fq")
+        b1, b2 = os.path.join(tmp, "b_1.fq"), os.path.join(tmp, "b_2.fq")
+        s1, s2 = os.path.join(tmp, "s1.fq"), os.path.join(tmp, "s2.fq")
+        q = args.reads // 8
+        write_pe(a1, a2, q, 1000)
+        write_pe(b1, b2, q, 5000000)
+        write_se(s1, 2 * q, 9000000)
+        write_se(s2, args.reads - 6 * q, 13000000)
+        fq = a1
+        open(cfg_path, "w").write(
+            f"max_rd_len={args.read_len}\n[LIB]\navg_ins=500\nreverse_seq=1\nasm_flags=3\nq={s1}\n"
+            f"[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq1={a1}\nq2={a2}\nq1={b1}\nq2={b2}\nq={s2}\n"
+            f"[LIB]\navg_ins=300\nasm_flags=2\nq={s1}\n")
     gen_s = time.time() - t0
-    res = {"reads": args.reads, "read_len": args.read_len, "K": args.K, "p": args.p, "fastq_bytes": os.path.getsize(fq),
+    res = {"reads": args.reads, "read_len": args.read_len, "K": args.K, "p": args.p, "layout": args.layout, "fastq_bytes": os.path.getsize(fq),
            "kmers": args.reads * (args.read_len - args.K + 1), "gen_s": round(gen_s, 1)}
-    subprocess.run(["cat", fq], stdout=subprocess.DEVNULL)                     # warm the page cache
+    subprocess.run("cat %s/*.fq > /dev/null" % tmp, shell=True)                 # warm the page cache
     ours = os.path.join(pkg.CSRC_DIR, "sdt-pregraph")
     variant = args.variant or (31 if args.K <= 31 else 127)
     extra = ["--max-k", str(variant)] + (["-d", str(args.d)] if args.d else [])
