@@ -30,6 +30,7 @@ ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
 ap.add_argument("--layout", choices=["se", "pe", "mixed"], default="se", help="library layout of the synthetic input")
 ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
+ap.add_argument("--i", type=int, default=None, help="-i: minor-branch threshold in percent (reference default 5)")
 ap.add_argument("--variant", type=int, default=0, choices=[0, 31, 63, 127], help="reference binary to compare with (default: 31 for K <= 31, else 127)")
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 args = ap.parse_args()
@@ -99,7 +100,8 @@ try:
     subprocess.run("cat %s/*.fq > /dev/null" % tmp, shell=True)                 # warm the page cache
     ours = os.path.join(pkg.CSRC_DIR, "sdt-pregraph")
     variant = args.variant or (31 if args.K <= 31 else 127)
-    extra = ["--max-k", str(variant)] + (["-d", str(args.d)] if args.d else [])
+    common = (["-d", str(args.d)] if args.d else []) + (["-i", str(args.i)] if args.i is not None else [])
+    extra = ["--max-k", str(variant)] + common
     res["variant"], res["d"] = variant, args.d
     os.environ["SDT_TIMING"] = "1"
     t0 = time.time()
@@ -132,7 +134,7 @@ try:
         t0 = time.time()
         try:
             rr = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                                 os.path.join(tmp, "ref")] + (["-d", str(args.d)] if args.d else []), capture_output=True, text=True, timeout=max(args.timeout, 900))
+                                 os.path.join(tmp, "ref")] + common, capture_output=True, text=True, timeout=max(args.timeout, 900))
         except subprocess.TimeoutExpired:
             print(json.dumps(res, indent=1))
             raise SystemExit("the reference binary did not finish (its AIO reader can spin forever, SURVEY 9.3-q9)")
