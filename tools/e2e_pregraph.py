@@ -28,6 +28,7 @@ ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
+ap.add_argument("--dirty", action="store_true", help="SE layout only: N, lowercase, '.', IUPAC letters, ragged lengths, max_rd_len 20 below the read length")
 ap.add_argument("--layout", choices=["se", "pe", "mixed"], default="se", help="library layout of the synthetic input")
 ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
 ap.add_argument("--i", type=int, default=None, help="-i: minor-branch threshold in percent (reference default 5)")
@@ -49,7 +50,21 @@ try:
                 codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=args.read_len, seed=seed0 + done, err=0.002)
                 letters = synth.BASES[codes].reshape(n, args.read_len)
                 qual = b"I" * args.read_len
-                fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i].tobytes(), qual) for i in range(n)))
+                if args.dirty:
+                    import numpy as np
+                    rng = np.random.default_rng(seed0 + done)
+                    letters = letters.copy()
+                    u = rng.random(letters.shape)
+                    letters[u < 0.004] = ord("N")
+                    letters[(u >= 0.004) & (u < 0.006)] = ord(".")
+                    low = (u >= 0.006) & (u < 0.03)
+                    letters[low] = letters[low] + 32
+                    letters[(u >= 0.03) & (u < 0.031)] = ord("n")
+                    letters[(u >= 0.031) & (u < 0.032)] = ord("R")
+                    lens = rng.integers(args.K - 5, args.read_len + 1, size=n)
+                    fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i, :lens[i]].tobytes(), qual[:lens[i]]) for i in range(n)))
+                else:
+                    fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done + i, letters[i].tobytes(), qual) for i in range(n)))
                 done += n
         if os.path.getsize(path) % 32768 == 0:
             open(path, "ab").write(b"\n")
@@ -72,7 +87,7 @@ try:
     cfg_path = os.path.join(tmp, "lib.cfg")
     if args.layout == "se":
         write_se(fq, args.reads, 1000)
-        synth.write_config(cfg_path, args.read_len, fastq=[fq])
+        synth.write_config(cfg_path, args.read_len - (20 if args.dirty else 0), fastq=[fq])
     elif args.layout == "pe":
         p1, p2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
         write_pe(p1, p2, args.reads // 2, 1000)
