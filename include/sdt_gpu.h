@@ -177,6 +177,10 @@ int sdt_gpu_export_arcs(sdt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *mu
 int sdt_gpu_set_node_index(sdt_ctx *ctx, const uint64_t *keys, uint64_t n);
 int sdt_gpu_update_nodes(sdt_ctx *ctx, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
 int sdt_gpu_tip_walks(sdt_ctx *ctx, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n);
+/*   tip_walks_compact: the same walks, only for the nodes that have one, in no particular order: records of 2 words,
+ *                   [0] = node index | info << 56, [1] = end index.  SDT_EFULL: *n_records says how many there are. */
+int sdt_gpu_tip_walks_compact(sdt_ctx *ctx, int thin, int cut_len, uint64_t *records, uint64_t max_records,
+                              uint64_t *n_records);
 /*   minor_out_dry:  removeMinorOut's read-only part (cutTipPreGraph.c:1012-1076): every junction whose ratio test
  *                   (count / largest count on that side < threshold = dd / 100.0, clipKmerFromNode :591-1010)
  *                   would cut at least one neighbour on the graph as it is now, and who the neighbours of those

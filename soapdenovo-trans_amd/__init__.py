@@ -57,6 +57,7 @@ _ABI = [
     ("sdt_gpu_set_node_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_update_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_tip_walks", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_tip_walks_compact", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_minor_out_dry", _c.c_int, [_c.c_void_p, _c.c_double, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64),
                                          _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_edge_ports", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
@@ -322,6 +323,19 @@ class PregraphGPU:
                 continue
             self._check(rc)
             return info[:n], hits[: got.value]
+
+    def tip_walks_compact(self, thin: bool, cut_len: int):
+        """-> records uint64[n, 2]: node index | info << 56, end index"""
+        cap = max(self._nidx // 8, 1024)
+        while True:
+            rec = np.zeros((cap, 2), dtype=np.uint64)
+            nr = ctypes.c_uint64()
+            rc = self.lib.sdt_gpu_tip_walks_compact(self._ctx, int(thin), cut_len, _ptr(rec), cap, ctypes.byref(nr))
+            if rc == SDT_EFULL and nr.value > cap:
+                cap = nr.value
+                continue
+            self._check(rc)
+            return rec[: nr.value]
 
     def set_read_ordinal(self, base: int, stride: int = 1):
         self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))

@@ -691,20 +691,31 @@ static int commit_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int th
 /* the same sweep driven by g->vbits (device-walk passes): only nodes with a recorded walk or written since the walks
  * were taken can do anything, and touch() adds the latter while the sweep runs -- a node written AHEAD of the sweep
  * position is still visited in this sweep, one written behind it waits for the next, exactly as in the full scan */
-static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, const walk_t *walks)
+typedef struct { uint64_t *rec; uint64_t n; } cwalks_t;      /* 2 words per walk, sorted by node index (low 56 bits of [0]) */
+#define CW_NODE(c, r) ((c)->rec[2 * (r)] & 0x00FFFFFFFFFFFFFFULL)
+
+static uint64_t cw_lower_bound(const cwalks_t *cw, uint64_t node)
+{
+	uint64_t lo = 0, hi = cw->n;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (CW_NODE(cw, mid) < node) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, const cwalks_t *cw)
 {
 	int clipped = 0;
 	if (hi <= lo) return 0;
 	const uint64_t k0 = lo >> 6, k1 = (hi - 1) >> 6;
+	uint64_t ptr = cw_lower_bound(cw, lo), pf = ptr;               /* next recorded walk at or after the sweep position */
 	for (uint64_t k = k0; k <= k1; k++) {
 		uint64_t range = ~0ULL;
 		if (k == k0) range &= ~0ULL << (lo & 63);
 		if (k == k1 && ((hi & 63) != 0)) range &= (1ULL << (hi & 63)) - 1ULL;
-		if (k + 1 <= k1)                                                   /* the decisions of the next word read these nodes */
-			for (uint64_t t = g->vbits[k + 1]; t; t &= t - 1) {
-				const uint64_t j = ((k + 1) << 6) + (uint64_t)__builtin_ctzll(t);
-				if (j < g->n && walks[j].end != NO_NODE) __builtin_prefetch(&g->nodes[walks[j].end]);
-			}
+		/* the decisions of the next two words read these nodes */
+		while (pf < cw->n && CW_NODE(cw, pf) < ((k + 3) << 6)) { __builtin_prefetch(&g->nodes[cw->rec[2 * pf + 1]]); pf++; }
 		uint64_t done = 0;
 		for (;;) {
 			const uint64_t w = g->vbits[k] & range & ~done;
@@ -713,14 +724,20 @@ static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len,
 			done |= (b == 63) ? ~0ULL : ((2ULL << b) - 1ULL);
 			const uint64_t i = (k << 6) + (uint64_t)b;
 			gnode_t *tip = &g->nodes[i];
-			const walk_t *wk = &walks[i];
+			while (ptr < cw->n && CW_NODE(cw, ptr) < i) ptr++;
 			if (g->dirty[i]) {
 				clipped += clip_tip(g, tip, cut_len, thin, tips);
-			} else if (wk->end != NO_NODE) {
-				if (!wk->thin_stop && g->nodes[wk->end].linear)
+			} else if (ptr < cw->n && CW_NODE(cw, ptr) == i) {
+				const unsigned inf = (unsigned)(cw->rec[2 * ptr] >> 56);
+				walk_t wk;
+				wk.end = cw->rec[2 * ptr + 1];
+				wk.ch = (uint8_t)(inf & 3u);
+				wk.sm = (uint8_t)((inf >> 2) & 1u);
+				wk.thin_stop = (uint8_t)((inf >> 3) & 1u);
+				if (!wk.thin_stop && g->nodes[wk.end].linear)
 					clipped += clip_tip(g, tip, cut_len, thin, tips);
 				else
-					clipped += decide_tip(g, tip, wk, thin, tips, 0);
+					clipped += decide_tip(g, tip, &wk, thin, tips, 0);
 			}
 		}
 	}
@@ -756,52 +773,75 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
  * "since the device answered" (g->dirty): chains are made of nodes that were linear then and nothing writes a
  * linear node in these passes (THIN turns a linear non-single node non-linear, but every THIN walk stops there
  * either way), so no host dry run is needed for any later sweep either. */
-static void unpack_walks(void *vc, uint64_t lo, uint64_t hi, int tid)
+static void cw_mark(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
 	void **a = (void **)vc;
-	walk_t *w = (walk_t *)a[0];
-	const uint64_t *end = (const uint64_t *)a[1];
-	const uint8_t *info = (const uint8_t *)a[2];
-	uint64_t *vbits = (uint64_t *)a[3];                        /* chunks are multiples of 64 nodes: no word is shared */
-	for (uint64_t i = lo; i < hi; i++) {
-		if (end[i] != NO_NODE) vbits[i >> 6] |= 1ULL << (i & 63);
-		w[i].end = end[i];
-		w[i].ch = info[i] & 3u;
-		w[i].sm = (info[i] >> 2) & 1u;
-		w[i].thin_stop = (info[i] >> 3) & 1u;
+	const cwalks_t *cw = (const cwalks_t *)a[0];
+	uint64_t *vbits = (uint64_t *)a[1];
+	for (uint64_t r = lo; r < hi; r++) {
+		const uint64_t i = CW_NODE(cw, r);
+		__sync_fetch_and_or(&vbits[i >> 6], 1ULL << (i & 63));
 	}
 }
 
-static void device_walks(graph_t *g, int thin, int cut_len, walk_t *walks)
+/* LSD radix sort of the 2-word records by node index */
+static void cw_sort(cwalks_t *cw)
 {
-	uint64_t *end = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
-	uint8_t *info = (uint8_t *)malloc(g->n + 1);
-	if (g->dev_walks(g, thin, cut_len, end, info) != 0) {
+	const uint64_t n = cw->n;
+	if (n < 2) return;
+	uint64_t *tmp = (uint64_t *)malloc(2 * n * sizeof(uint64_t));
+	uint64_t all_or = 0, all_and = ~0ULL;
+	for (uint64_t r = 0; r < n; r++) { const uint64_t k = CW_NODE(cw, r); all_or |= k; all_and &= k; }
+	const uint64_t varying = all_or ^ all_and;
+	uint64_t *src = cw->rec, *dst = tmp;
+	for (int shift = 0; shift < 56; shift += 8) {
+		if (!((varying >> shift) & 0xFF)) continue;
+		uint64_t cnt[257] = {0};
+		for (uint64_t r = 0; r < n; r++) cnt[((src[2 * r] >> shift) & 0xFF) + 1]++;
+		for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+		for (uint64_t r = 0; r < n; r++) {
+			const uint64_t d = cnt[(src[2 * r] >> shift) & 0xFF]++;
+			dst[2 * d] = src[2 * r];
+			dst[2 * d + 1] = src[2 * r + 1];
+		}
+		uint64_t *t = src; src = dst; dst = t;
+	}
+	if (src != cw->rec) memcpy(cw->rec, src, 2 * n * sizeof(uint64_t));
+	free(tmp);
+}
+
+static void device_walks(graph_t *g, int thin, int cut_len, cwalks_t *cw)
+{
+	free(cw->rec);
+	cw->rec = NULL;
+	cw->n = 0;
+	if (g->dev_walks(g, thin, cut_len, &cw->rec, &cw->n) != 0) {
 		printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
 		exit(1);
 	}
 	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the mirror is current as of now */
 	g->dn = 0;
+	cw_sort(cw);
 	if (!g->vbits) g->vbits = (uint64_t *)malloc(((g->n >> 6) + 2) * sizeof(uint64_t));
 	memset(g->vbits, 0, ((g->n >> 6) + 2) * sizeof(uint64_t));
-	void *a[4] = {walks, end, info, g->vbits};
-	par_for(0, g->n, 1 << 16, unpack_walks, a);
-	free(end);
-	free(info);
+	void *a[2] = {cw, g->vbits};
+	par_for(0, cw->n, 1 << 14, cw_mark, a);
 }
 
 uint64_t graph_remove_single_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
-	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
-	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
+	tips_ctx c = {g, 0, 0, g->dev_walks ? NULL : (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
+	uint8_t *marks = g->dev_walks ? NULL : (uint8_t *)calloc(g->n + 1, 1);
+	cwalks_t cw = {NULL, 0};
 	double t_sub = cut_now_ms();
 	if (g->dev_walks) {
-		device_walks(g, 1, 2 * g->K, c.walks);
+		device_walks(g, 1, 2 * g->K, &cw);
 		SUBPHASE("single tips: device walks");
-		commit_tips_sparse(g, 0, g->n, 2 * g->K, 1, &tips, c.walks);
+		commit_tips_sparse(g, 0, g->n, 2 * g->K, 1, &tips, &cw);
+		free(cw.rec);
 		SUBPHASE("single tips: commit");
 	} else {
 		sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
@@ -817,23 +857,25 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
-	tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
-	uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
+	tips_ctx c = {g, 0, 0, g->dev_walks ? NULL : (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
+	uint8_t *marks = g->dev_walks ? NULL : (uint8_t *)calloc(g->n + 1, 1);
+	cwalks_t cw = {NULL, 0};
 	double t_sub = cut_now_ms();
 	if (g->dev_walks) {
-		device_walks(g, 0, 2 * g->K, c.walks);
+		device_walks(g, 0, 2 * g->K, &cw);
 		SUBPHASE("minor tips: device walks");
 	}
 	for (int s = 0; s < g->p; s++) {
 		int changed = 1;
 		while (changed)                                /* fixed point PER SET before the next set (:385-408) */
-			changed = g->dev_walks ? commit_tips_sparse(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, c.walks)
+			changed = g->dev_walks ? commit_tips_sparse(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &cw)
 			                       : sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
 		printf("kmer set %d done\n", s);
 	}
 	SUBPHASE("minor tips: sweeps");
 	free(marks);
 	free(c.walks);
+	free(cw.rec);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	SUBPHASE("minor tips: mark linear");

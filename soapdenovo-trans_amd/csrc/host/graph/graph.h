@@ -51,7 +51,8 @@ typedef struct graph_s {
 	uint64_t *vbits;                   /* 1 bit per node: a sweep has to look at it (recorded walk, or written since) */
 	uint64_t *dlist;
 	size_t dn, dcap;
-	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t *end, uint8_t *info);   /* 0 = ok */
+	/* malloc'ed records of 2 words (node index | info << 56, end index) for the nodes that have a walk, any order */
+	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t **records, uint64_t *n_records);   /* 0 = ok */
 	/* kmer2edges' port walks from the device: malloc'ed records (17 words each, sdt_gpu_edge_ports) */
 	int (*dev_edge_ports)(struct graph_s *g, uint64_t **records, uint64_t *n_records);
 	/* removeMinorOut's dry run from the device: malloc'ed records (9 words each, sdt_gpu_minor_out_dry) */

@@ -124,6 +124,22 @@ static void gather_paths(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
+static void gather_dirty(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	void **a = (void **)vc;
+	const graph_t *g = (const graph_t *)a[0];
+	uint64_t *k = (uint64_t *)a[1];
+	uint32_t *l = (uint32_t *)a[2], *r = (uint32_t *)a[3];
+	const int nwk = (int)(intptr_t)a[4];
+	for (uint64_t j = lo; j < hi; j++) {
+		const gnode_t *nd = &g->nodes[g->dlist[j]];
+		for (int w = 0; w < nwk; w++) k[j * nwk + w] = nd->seq.w[4 - nwk + w];
+		l[j] = nd->l_links;
+		r[j] = nd->r_links | ((uint32_t)nd->linear << 24) | ((uint32_t)nd->deleted << 25);
+	}
+}
+
 /* the device table mirrors the host graph: node order known to the device, nodes written since the last call sent over */
 static int dev_mirror_sync(graph_t *g)
 {
@@ -141,12 +157,8 @@ static int dev_mirror_sync(graph_t *g)
 	if (g->dn) {
 		uint64_t *k = (uint64_t *)malloc(g->dn * (size_t)nwk * 8);
 		uint32_t *l = (uint32_t *)malloc(g->dn * 4), *r = (uint32_t *)malloc(g->dn * 4);
-		for (size_t j = 0; j < g->dn; j++) {
-			const gnode_t *nd = &g->nodes[g->dlist[j]];
-			for (int w = 0; w < nwk; w++) k[j * nwk + w] = nd->seq.w[4 - nwk + w];
-			l[j] = nd->l_links;
-			r[j] = nd->r_links | ((uint32_t)nd->linear << 24) | ((uint32_t)nd->deleted << 25);
-		}
+		void *da[5] = {g, k, l, r, (void *)(intptr_t)nwk};
+		par_for(0, g->dn, 1 << 14, gather_dirty, da);
 		const int rc = sdt_gpu_update_nodes(D->gpu, k, l, r, g->dn);
 		free(k); free(l); free(r);
 		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_update_nodes: %s\n", sdt_gpu_last_error()); return 1; }
@@ -205,15 +217,21 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 	}
 }
 
-static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t *end, uint8_t *info)
+static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records, uint64_t *nr)
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
-	if (sdt_gpu_tip_walks(D->gpu, thin, cut_len, end, info, g->n) != SDT_OK) {
-		fprintf(stderr, "sdt_gpu_tip_walks: %s\n", sdt_gpu_last_error());
+	uint64_t cap = g->n / 8 + 4096;
+	for (;;) {
+		uint64_t *rec = (uint64_t *)malloc(cap * 2 * sizeof(uint64_t));
+		if (!rec) { fprintf(stderr, "out of memory for %llu walk records\n", (unsigned long long)cap); return 1; }
+		const int rc = sdt_gpu_tip_walks_compact(D->gpu, thin, cut_len, rec, cap, nr);
+		if (rc == SDT_OK) { *records = rec; return 0; }
+		free(rec);
+		if (rc == SDT_EFULL && *nr > cap) { cap = *nr; continue; }
+		fprintf(stderr, "sdt_gpu_tip_walks_compact: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
-	return 0;
 }
 
 int main(int argc, char **argv)

@@ -1534,9 +1534,9 @@ int sdt_gpu_tip_walks(sdt_ctx *c, int thin, int cut_len, uint64_t *end_idx, uint
 	hipError_t e = hipMalloc((void **)&d_i, n ? n : 1);
 	if (e == hipSuccess) {
 		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
-		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats);
+		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
+		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(end_idx, d_e, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
@@ -1864,6 +1864,42 @@ int sdt_gpu_edge_ports(sdt_ctx *c, uint64_t *records, uint64_t max_records, uint
 		*n_records = h;
 		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, the graph has %llu non-linear nodes", (unsigned long long)max_records, h);
 		else if (h && hipMemcpy(records, d_rec, h * 17 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "edge port records: copy failed");
+	}
+	(void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return rc;
+}
+
+int sdt_gpu_tip_walks_compact(sdt_ctx *c, int thin, int cut_len, uint64_t *records, uint64_t max_records, uint64_t *n_records)
+{
+	if (!c || (!records && max_records) || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->d_idx || c->idx_slots != c->slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if (c->idx_n >= (1ULL << 56))
+		return fail(SDT_EINVAL, "node indices do not fit 56 bits");
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr, h = 0;
+	const uint64_t m = max_records ? max_records : 1;
+	HIPCHK(hipMalloc((void **)&d_rec, m * 2 * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream);
+	if (e == hipSuccess) {
+		const int g = scan_grid(c, c->slots);
+		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
+		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, c->stream);
+	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks_compact: %s", hipGetErrorString(e));
+	if (rc != SDT_OK && e == hipSuccess)
+		rc = fail(SDT_ESTATE, "sdt_gpu_tip_walks_compact: %llu walks left the graph", (unsigned long long)c->h_stats->probe_fail);
+	if (rc == SDT_OK) {
+		*n_records = h;
+		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, %llu nodes have a walk", (unsigned long long)max_records, h);
+		else if (h && hipMemcpy(records, d_rec, h * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "tip walk records: copy failed");
 	}
 	(void)hipFree(d_rec);
 	if (d_cur) (void)hipFree(d_cur);

@@ -365,7 +365,9 @@ template <int NW> __device__ inline Key<NW> key_next_masked(const Key<NW> &k, ui
 // thin_stop << 3 (the base by which the end node sees the chain, the strand on which it was reached).
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
-                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats)
+                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
+                                                   uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
+                                                   unsigned long long *cursor = nullptr)
 {
 	const uint64_t slots = tbl.mask + 1;
 	Key<NW> mask;
@@ -379,8 +381,10 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
 		const Entry<NW> e = tbl.ent[s];
 		if (e.key[0] == KEY_EMPTY) continue;
 		const uint64_t me = idx[s];
-		end_out[me] = ~0ULL;
-		info_out[me] = 0;
+		if (end_out) {
+			end_out[me] = ~0ULL;
+			info_out[me] = 0;
+		}
 		const uint32_t a = tbl.aux[s];
 		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
 		const bool single = (e.val >> 48) == 1 && (a & 0xFFFFu) == 0;
@@ -428,8 +432,17 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
 #pragma unroll
 		for (int w = 0; w < NW; w++)
 			if (w == NW - 1 - (tb >> 6)) ch = (uint32_t)(at.w[w] >> (tb & 63)) & 3u;
-		end_out[me] = idx[os];
-		info_out[me] = (uint8_t)(ch | ((uint32_t)sm << 2) | (thin_stop << 3));
+		const uint32_t inf = ch | ((uint32_t)sm << 2) | (thin_stop << 3);
+		if (end_out) {
+			end_out[me] = idx[os];
+			info_out[me] = (uint8_t)inf;
+		} else {                                             // compact: only the nodes that have a walk, in any order
+			const unsigned long long r = atomicAdd(cursor, 1ULL);
+			if (r < max_rec) {
+				rec[2 * r] = me | ((uint64_t)inf << 56);
+				rec[2 * r + 1] = idx[os];
+			}
+		}
 	}
 	if (missing)
 		atomicAdd(&stats->probe_fail, (unsigned long long)missing);

@@ -460,6 +460,10 @@ def test_tip_walks_equal_reference_walk(pkg, synth, K, L):
                         n_walks += 1
                         assert (int(end[i]), int(info[i])) == (w[0], w[1] | (w[2] << 2) | (w[3] << 3)), (i, thin, w)
                 assert n_walks > 0 or thin
+                # the compact form: the same walks, only for the nodes that have one
+                rec = g.tip_walks_compact(bool(thin), 2 * K)
+                got = {int(a) & ((1 << 56) - 1): (int(b), int(a) >> 56) for a, b in rec}
+                assert got == {i: (w[0], w[1] | (w[2] << 2) | (w[3] << 3)) for i, w in enumerate(want) if w is not None}
             # short chains are cut off by cut_len
             end_short, _ = g.tip_walks(False, 3)
             want = py_tip_walks(ki, l, rf, cnt, K, 0, 3)
