@@ -542,10 +542,9 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	g->touched = NULL;
 	g->tn = 0;
 	SUBPHASE("ordered commit");
-	free(g->nb_slot); g->nb_slot = NULL;
-	free(g->nb_pool); g->nb_pool = NULL;
-	free(c.need);
-	free(c.writes);
+	graph_free_later(g->nb_slot, g->nb_pool, c.need, c.writes);
+	g->nb_slot = NULL;
+	g->nb_pool = NULL;
 	printf("%llu kmers off\n", (unsigned long long)off);
 	mark_linear(g);
 	SUBPHASE("free + mark linear");

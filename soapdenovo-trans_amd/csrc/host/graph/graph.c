@@ -147,7 +147,11 @@ static void replay1_grow(replay1_t *r)
 	memset(r->moved, 0, old);
 	for (uint64_t i = 0; i < old; i++) {
 		/* the old slots are walked in order, so the new home of the entry a few steps ahead is known: have it in cache */
-		if (i + 12 < old && r->slot[i + 12].id >= 0) __builtin_prefetch(&ns[r->slot[i + 12].key % n], 1);
+		if (i + 12 < old && r->slot[i + 12].id >= 0) {
+			const uint64_t hp = r->slot[i + 12].key % n;
+			__builtin_prefetch(&ns[hp], 1);
+			if (hp < old) { __builtin_prefetch(&r->slot[hp]); __builtin_prefetch(&r->moved[hp], 1); }   /* the eviction test reads both */
+		}
 		if (r->slot[i].id < 0 || r->moved[i]) continue;
 		rslot1 carry = r->slot[i];
 		r->moved[i] = 1;
@@ -387,6 +391,24 @@ static void job_scatter_sets(build_job *J, int tid)
 
 #define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
+static void *free_worker(void *v)
+{
+	void **p = (void **)v;
+	for (int i = 0; i < 4; i++) free(p[i]);
+	free(p);
+	return NULL;
+}
+
+void graph_free_later(void *a, void *b, void *c, void *d)
+{
+	void **p = (void **)malloc(4 * sizeof(void *));
+	pthread_t th;
+	if (!p) { free(a); free(b); free(c); free(d); return; }
+	p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+	if (pthread_create(&th, NULL, free_worker, p) == 0) pthread_detach(th);
+	else free_worker(p);
+}
+
 int (*graph_index_hook)(graph_t *g, void *user) = NULL;
 void *graph_index_hook_user = NULL;
 
@@ -432,7 +454,8 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	J.next_set = 0;
 	run_parallel(&J, job_replay);
 	GB_PHASE("sort + replay per set");
-	free(J.ord); free(J.per_set); free(J.set_of); free(J.tmp);
+	/* gigabytes of scratch: returning them to the kernel takes a fraction of a second, off the critical path */
+	graph_free_later(J.ord, J.per_set, J.set_of, J.tmp);
 	/* index */
 	if (n >= 0xFFFFFFFEULL) { printf("%llu nodes: the host index holds 32-bit node ids\n", (unsigned long long)n); exit(1); }
 	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {

@@ -67,6 +67,8 @@ typedef struct graph_s {
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first);
 void graph_free(graph_t *g);
+/* free() of up to four large blocks on a detached thread (munmap of gigabytes is not free) */
+void graph_free_later(void *a, void *b, void *c, void *d);
 /* optional: called by graph_build once the nodes are in visiting order; returns 0 after filling g->index /
  * g->index_mask itself (the GPU host does, from the device's copy of the nodes), non-zero to let the host build it */
 extern int (*graph_index_hook)(graph_t *g, void *user);

@@ -171,7 +171,9 @@ static int dev_index_hook(graph_t *g, void *user)
 {
 	dev_state *D = (dev_state *)user;
 	g->dev_user = D;
+	const double t0 = now_ms();
 	if (dev_mirror_sync(g) != 0) exit(1);
+	const double t1 = now_ms();
 	uint64_t cap = 1024;
 	while (cap < 2 * g->n + 2) cap <<= 1;
 	g->index = (uint32_t *)malloc(cap * sizeof(uint32_t));
@@ -180,6 +182,7 @@ static int dev_index_hook(graph_t *g, void *user)
 		fprintf(stderr, "sdt_gpu_build_host_index: %s\n", sdt_gpu_last_error());
 		exit(1);
 	}
+	if (getenv("SDT_TIMING")) fprintf(stderr, "[graph]      node order to the device %.1f ms, index built + copied back %.1f ms\n", t1 - t0, now_ms() - t1);
 	return 0;
 }
 
@@ -339,7 +342,8 @@ int main(int argc, char **argv)
 			graph_index_hook_user = &D;
 		}
 		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
-		free(keys); free(first); free(ll); free(rf); free(cnt);
+		graph_free_later(keys, first, ll, rf);
+		free(cnt);
 		phase("layout replay + index (host)");
 		if (gpu && !host_walks) {                                          /* dry runs from the device mirror of the graph */
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
@@ -401,8 +405,7 @@ int main(int argc, char **argv)
 		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
 		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
 		graph_write_basic(prefix, nv, K, ne, max_read_len);
-		graph_free(G);
-		phase("vertex + preGraphBasic");
+		phase("vertex + preGraphBasic");              /* G is not freed: the process ends here and the kernel is faster at it */
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
 	sdt_cfg_free(&cfg);
