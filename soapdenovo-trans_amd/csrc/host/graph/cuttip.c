@@ -12,6 +12,7 @@
  */
 #include "graph.h"
 #include "par.h"
+#include "big.h"
 #include <stdlib.h>
 #include <string.h>
 

@@ -230,6 +230,7 @@ static uint64_t build_edges_sequential(graph_t *g, const char *prefix)
  *   3. parallel: re-walk every emitted chain, stamp its interior nodes, zero the two end links, format the record;
  *   4. write the records in id order. */
 #include "par.h"
+#include "big.h"
 
 typedef struct {
 	uint64_t far_node;     /* NO_WALK = port not live / node not eligible */

@@ -281,6 +281,7 @@ static void *job_thread(void *a)
 }
 
 #include "par.h"
+#include "big.h"
 static void run_parallel(build_job *J, job_fn fn)
 {
 	J->fn = fn;

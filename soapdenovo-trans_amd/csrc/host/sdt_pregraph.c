@@ -19,6 +19,7 @@
 #include "readstream.h"
 #include "graph/graph.h"
 #include "graph/par.h"
+#include "graph/big.h"
 
 #ifndef SDT_MAX_K
 #define SDT_MAX_K 127        /* one binary covers the 31/63/127mer variants; --max-k emulates a smaller one */
