@@ -4,7 +4,7 @@
  * *.readOnContig / *.ctg2Read / *.readInGap / *.peGrads [/ *.readInformation]).
  *
  * TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).  Pinned by tests/test_oracle_vs_reference.py against the files the
- * reference's own `map` wrote for tests/golden/map_cases/* (tests/golden/make_map_golden.py).
+ * reference's own `map` wrote for the cases under tests/golden/map_cases (tests/golden/make_map_golden.py).
  * Citations are relative to /root/reference/src.
  */
 #include "sdt_oracle.h"
