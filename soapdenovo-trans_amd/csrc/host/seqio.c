@@ -48,12 +48,86 @@ static inline void pk_put(packer_t *p, unsigned code)
 	p->nbases++;
 }
 
+/* Fast path for the common line -- nothing but letters: 32 characters per step.  The base code is bits 1..2 of the
+ * character in either case ((c & 6) >> 1, inc/def.h:39-42), so after a check that all 32 bytes are letters the codes
+ * are one shift and one mask away, and PEXT squeezes the 2-bit codes of 8 bytes into 16 bits (first base on top).
+ * Returns how many leading characters it consumed (all of them unless a block holds a non-letter); the caller's
+ * scalar loop does the rest. */
+#include <immintrin.h>
+__attribute__((target("avx2,bmi2")))
+static inline int letters32(const char *p32, uint32_t g[2])
+{
+	const __m256i lower = _mm256_set1_epi8(0x20), a = _mm256_set1_epi8('a'), z = _mm256_set1_epi8(25), three = _mm256_set1_epi8(3);
+	const __m256i c = _mm256_loadu_si256((const __m256i *)p32);
+	const __m256i t = _mm256_sub_epi8(_mm256_or_si256(c, lower), a);               /* letter <=> 0..25 (unsigned) */
+	if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_min_epu8(t, z), t)) != -1) return 0;
+	const __m256i codes = _mm256_and_si256(_mm256_srli_epi16(c, 1), three);
+	uint64_t lane[4];
+	_mm256_storeu_si256((__m256i *)lane, codes);
+	for (int h = 0; h < 2; h++) {
+		const uint64_t hi = _pext_u64(__builtin_bswap64(lane[2 * h]), 0x0303030303030303ULL);
+		const uint64_t lo = _pext_u64(__builtin_bswap64(lane[2 * h + 1]), 0x0303030303030303ULL);
+		g[h] = (uint32_t)((hi << 16) | lo);
+	}
+	return 1;
+}
+
+/* OR 32 bits (16 bases, first base on top) into the stream at base position pos; words past the stream end are zero */
+static inline void append16(packer_t *pk, uint64_t pos, uint32_t g)
+{
+	const uint64_t wi = pos >> 4;
+	const int bo = 2 * (int)(pos & 15);
+	const uint64_t v = (uint64_t)g << (32 - bo);
+	pk->w[wi] |= (uint32_t)(v >> 32);
+	pk->w[wi + 1] |= (uint32_t)v;
+}
+
+__attribute__((target("avx2,bmi2")))
+static int encode_letters_avx2(packer_t *pk, const char *s, int n)
+{
+	int i = 0;
+	uint32_t g[2];
+	for (; i + 32 <= n; i += 32) {
+		if (!letters32(s + i, g)) return i;
+		append16(pk, pk->nbases, g[0]);
+		append16(pk, pk->nbases + 16, g[1]);
+		pk->nbases += 32;
+	}
+	if (i < n) {
+		/* the last 1..31 characters, padded with 'A' (code 0: OR-ing its bits changes nothing) */
+		char buf[32];
+		const int r = n - i;
+		memcpy(buf, s + i, (size_t)r);
+		memset(buf + r, 'A', (size_t)(32 - r));
+		if (!letters32(buf, g)) return i;
+		append16(pk, pk->nbases, g[0]);
+		append16(pk, pk->nbases + 16, g[1]);
+		pk->nbases += (uint64_t)r;
+		i = n;
+	}
+	return i;
+}
+
+static int have_avx2_bmi2(void)
+{
+	static int cached = -1;
+	if (cached < 0) cached = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SDT_NO_SIMD");
+	return cached;
+}
+
 /* one sequence line -> stream; returns coded length */
 static int encode_line(packer_t *pk, const char *s, int n, int max_read_len, int reverse)
 {
 	unsigned char tmp[8192];
 	unsigned char *codes = tmp;
 	if (n > max_read_len) n = max_read_len;
+	int fast = 0;
+	if (!reverse && n >= 8 && have_avx2_bmi2()) {
+		pk_reserve(pk, (uint64_t)n);
+		fast = encode_letters_avx2(pk, s, n);
+		s += fast;
+		n -= fast;
+	}
 	if (n > (int)sizeof tmp) codes = (unsigned char *)malloc((size_t)n);
 	int m = 0;
 	for (int i = 0; i < n; i++) {
@@ -68,7 +142,7 @@ static int encode_line(packer_t *pk, const char *s, int n, int max_read_len, int
 	else
 		for (int i = m - 1; i >= 0; i--) pk_put(pk, codes[i] ^ 2u);
 	if (codes != tmp) free(codes);
-	return m;
+	return m + fast;
 }
 
 static inline const char *line_end(const char *p, const char *end)

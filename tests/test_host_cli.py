@@ -353,3 +353,15 @@ def test_sdt_map_without_paired_input(pkg, tmp_path):
     assert open(tmp_path / "out.readInGap", "rb").read() == b""
     assert open(tmp_path / "out.peGrads").read() == "grads&num: 0\t0\t150\n"
     assert "0 out of 0 (-nan)% reads mapped to contigs\nno paired reads found\n[LIB] 0, avg_ins 200, reverse 0 \n" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["dirty_ragged_k25_cut80", "pe150_k31_p8", "se250_k63_p8_127mer"])
+def test_reader_simd_path_equals_scalar(pkg, tmp_path, name):
+    """the AVX2 / BMI2 fast path of the read encoder (lines that are letters only, 32 characters per step) and the
+    scalar loop give the same packed stream; lines with N / '.' / digits fall back mid-line"""
+    info = gu.load_case(name)
+    cfg = materialise(info, tmp_path)
+    exe = bin_path(pkg, "sdt-readdump")
+    a = subprocess.run([exe, cfg, "3", "50000"], check=True, capture_output=True, text=True).stdout
+    b = subprocess.run([exe, cfg, "3", "50000"], check=True, capture_output=True, text=True, env=dict(os.environ, SDT_NO_SIMD="1")).stdout
+    assert a == b and len(a) > 1000
