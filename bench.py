@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--K", type=int, default=31)
     ap.add_argument("--T", type=int, default=20000, help="synthetic transcripts")
     ap.add_argument("--err", type=float, default=0.002)
-    ap.add_argument("--cpu-sample", type=int, default=4000000_000_000, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
     ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
     ap.add_argument("--est-distinct", type=int, default=0)
     ap.add_argument("--shard-mode", choices=["filter", "route"], default="filter",
