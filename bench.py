@@ -81,9 +81,12 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
     n = min(sample_reads, n_reads_total)
     nw = (n * L + 15) // 16
     hw = words_dev[:nw].cpu().numpy().view(np.uint32)
-    idx = np.arange(n * L, dtype=np.int64)
-    codes = ((hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
-    del idx
+
+    def unpack(r0, r1):
+        """codes of reads [r0, r1) from the packed stream"""
+        idx = np.arange(r0 * L, r1 * L, dtype=np.int64)
+        return ((hw[idx >> 4] >> (30 - 2 * (idx & 15)).astype(np.uint32)) & 3).astype(np.uint8)
+
     kmers = n * (L - K + 1)
     cores = usable_cpus()
     exe = ob.ref_binary(31 if K <= 31 else 127)
@@ -92,16 +95,12 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
         tmp = tempfile.mkdtemp(prefix="sdt_cpu_")
         try:
             fq = os.path.join(tmp, "reads.fq")
-            letters = synth.BASES[codes].reshape(n, L)
             with open(fq, "wb") as fo:
                 qual = b"I" * L
-                parts = []
-                for i in range(n):
-                    parts.append(b"@r%d\n%s\n+\n%s\n" % (i, letters[i].tobytes(), qual))
-                    if len(parts) == 65536:
-                        fo.write(b"".join(parts))
-                        parts = []
-                fo.write(b"".join(parts))
+                for r0 in range(0, n, 250_000):
+                    r1 = min(n, r0 + 250_000)
+                    letters = synth.BASES[unpack(r0, r1)].reshape(r1 - r0, L)
+                    fo.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (r0 + i, letters[i].tobytes(), qual) for i in range(r1 - r0)))
             if os.path.getsize(fq) % 32768 == 0:       # reference hangs on exact multiples (survey q9)
                 with open(fq, "ab") as fo:
                     fo.write(b"\n")
@@ -131,6 +130,9 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
             log("reference binary did not produce kmerFreq; falling back to the oracle port")
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    n = min(n, 300_000)                      # the single-threaded port: keep it to some tens of seconds
+    kmers = n * (L - K + 1)
+    codes = unpack(0, n)
     o = ob.Oracle(K, nsets=8)
     offs = (np.arange(n + 1, dtype=np.uint64) * L)
     t0 = time.time()
