@@ -28,6 +28,8 @@ ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
 ap.add_argument("--timeout", type=int, default=300)
+ap.add_argument("--no-max-rd-len", action="store_true", help="drop max_rd_len from the config (reference default: reads cut to 100)")
+ap.add_argument("--cutoff", type=int, default=0, help="rd_len_cutoff for the library")
 ap.add_argument("--dirty", action="store_true", help="SE layout only: N, lowercase, '.', IUPAC letters, ragged lengths, max_rd_len 20 below the read length")
 ap.add_argument("--layout", choices=["se", "pe", "mixed"], default="se", help="library layout of the synthetic input")
 ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
@@ -109,6 +111,13 @@ try:
             f"max_rd_len={args.read_len}\n[LIB]\navg_ins=500\nreverse_seq=1\nasm_flags=3\nq={s1}\n"
             f"[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq1={a1}\nq2={a2}\nq1={b1}\nq2={b2}\nq={s2}\n"
             f"[LIB]\navg_ins=300\nasm_flags=2\nq={s1}\n")
+    if args.no_max_rd_len or args.cutoff:
+        txt = open(cfg_path).read()
+        if args.no_max_rd_len:
+            txt = "\n".join(l for l in txt.splitlines() if not l.startswith("max_rd_len")) + "\n"
+        if args.cutoff:
+            txt = txt.replace("[LIB]\n", "[LIB]\nrd_len_cutoff=%d\n" % args.cutoff)
+        open(cfg_path, "w").write(txt)
     gen_s = time.time() - t0
     res = {"reads": args.reads, "read_len": args.read_len, "K": args.K, "p": args.p, "layout": args.layout, "fastq_bytes": os.path.getsize(fq),
            "kmers": args.reads * (args.read_len - args.K + 1), "gen_s": round(gen_s, 1)}
