@@ -803,3 +803,69 @@ def test_edge_port_walks_equal_reference_rule(pkg, synth, K, L):
             assert got == want[i], i
             palins += sum(1 for x in got if x is not None and x[3] == 0)
         assert palins > 0
+
+
+@pytest.mark.parametrize("K,L", [(21, 90), (45, 160), (81, 300)])
+def test_map_stage_randomised_vs_oracle(pkg, synth, K, L):
+    """random contigs that share stretches (repeated k-mers = 'deleted'), reads that hop between contigs and
+    strands, reads shorter than K+1, lengths that need several 64-k-mer rounds per wavefront; 1-, 2- and 4-word keys"""
+    rng = np.random.default_rng(K * 7 + L)
+    nctg = 40
+    ctgs = [rng.integers(0, 4, size=int(rng.integers(K + 2, 900))).astype(np.uint8) for _ in range(nctg)]
+    for _ in range(12):                                   # shared stretches between random contig pairs
+        a, b = rng.integers(0, nctg, size=2)
+        n = int(rng.integers(K, 2 * K))
+        if len(ctgs[a]) > n + 2 and len(ctgs[b]) > n + 2:
+            pa, pb = int(rng.integers(0, len(ctgs[a]) - n)), int(rng.integers(0, len(ctgs[b]) - n))
+            ctgs[b][pb:pb + n] = ctgs[a][pa:pa + n]
+    ids = np.arange(1, 2 * nctg, 2, dtype=np.uint32)      # odd ids, twin = id + 1
+    lens = np.array([len(c) for c in ctgs], dtype=np.uint32)
+    o = mu.MapOracle(K, 5, 1 if K <= 31 else (2 if K <= 63 else 4))
+    o.set_contig_index(lens, np.ones(nctg, dtype=np.int32), 2 * nctg)
+    for i, c in zip(ids, ctgs):
+        o.add_contig(c, int(i))
+    length = np.zeros(2 * nctg + 1, dtype=np.uint32)
+    twin = np.zeros(2 * nctg + 1, dtype=np.uint32)
+    length[1::2], length[2::2] = lens, lens
+    twin[1::2], twin[2::2] = ids + 1, ids
+    reads = []
+    for _ in range(600):
+        parts, want = [], int(rng.integers(10, L + 1))
+        while sum(len(p) for p in parts) < want:           # 1..3 pieces from random contigs / strands
+            c = ctgs[int(rng.integers(0, nctg))]
+            n = int(rng.integers(5, min(len(c), want) + 1))
+            p0 = int(rng.integers(0, len(c) - n + 1))
+            piece = c[p0:p0 + n]
+            if rng.random() < 0.5:
+                piece = (piece[::-1] ^ 2).astype(np.uint8)
+            parts.append(piece)
+        r = np.concatenate(parts)[:want].copy()
+        flips = rng.random(len(r)) < 0.01
+        r[flips] = (r[flips] + 1) & 3
+        reads.append(r)
+    roffs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    roffs[1:] = np.cumsum([len(r) for r in reads])
+    rcodes = np.concatenate(reads)
+    offs = np.zeros(nctg + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    with pkg.PregraphGPU(K, est_distinct=1 << 13, flags=pkg.SDT_FLAG_CONTIG_INDEX) as g:
+        g.index_contigs(synth.pack_2bit(np.concatenate(ctgs)), offs, ids)
+        g.set_contig_table(length, twin)
+        kmers, nodes = g.finish_count()
+        assert (nodes, kmers) == o.counts()
+        al = rng.integers(K, K + 40, size=len(reads)).astype(np.int32)
+        info_w, hits = g.align_reads(synth.pack_2bit(rcodes), roffs, align_len=al)
+        multi = 0
+        for r in range(len(reads)):
+            n, want, best, foot = o.map_read(reads[r], int(al[r]))
+            w = int(info_w[r])
+            start, nh, b, f = w & ((1 << 40) - 1), (w >> 40) & 255, (w >> 48) & 255, (w >> 56) & 1
+            assert n >= 0 and nh == n, r
+            if not n:
+                assert w == 0
+                continue
+            got = [(int(h[0]), int(np.int32(h[1])), int(h[2]), int(h[3]) & 0x7FFFFFFF, "-" if int(h[3]) >> 31 else "+")
+                   for h in [hits[r]] + list(hits[start:start + nh - 1])]
+            assert got == want and (b, f) == (best, foot), r
+            multi += n > 1
+        assert multi > 0
