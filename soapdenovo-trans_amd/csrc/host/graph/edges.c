@@ -34,6 +34,15 @@ static void chain_push(chain_t *c, gnode_t *node, kw_t kmer, int smaller)
 static inline unsigned rlink(const gnode_t *n, unsigned b) { return (n->r_links >> (6 * b)) & 63u; }
 static inline unsigned llink(const gnode_t *n, unsigned b) { return (n->l_links >> (6 * b)) & 63u; }
 
+/* `linear` of a node that may be the END of somebody else's chain: during the parallel stamping that thread clears one
+ * of the node's links with an atomic AND on the same 32-bit word (the flag bits themselves never change there), so
+ * read the word with a relaxed atomic load instead of through the bit-field */
+static inline int node_is_linear(const gnode_t *n)
+{
+	const uint32_t w = __atomic_load_n((const uint32_t *)&n->l_links + 1, __ATOMIC_RELAXED);
+	return (int)((w >> 24) & 1u);
+}
+
 static uint64_t mix_kw(const kw_t *k)
 {
 	uint64_t h = 0xA0761D6478BD642FULL;
@@ -99,7 +108,7 @@ static void follow(graph_t *g, chain_t *c, unsigned nextch)
 	int sm;
 	kw_t word = kw_next(c->b[0].kmer, nextch, K);
 	gnode_t *o = graph_find_oriented(g, word, &sm);
-	while (o->linear) {
+	while (node_is_linear(o)) {
 		chain_push(c, o, word, sm);
 		unsigned b;
 		if (sm) { for (b = 0; b < 4 && !rlink(o, b); b++) ; }

@@ -1,5 +1,6 @@
 /* graph.c -- see graph.h: layout replay, flat node array, lookup index, hash_kmer. */
 #include "graph.h"
+#include <pthread.h>
 #include <math.h>
 #include <unistd.h>
 #include <stdlib.h>
@@ -7,18 +8,20 @@
 
 /* ---- hash_kmer: table-driven CRC-32 with a SIGNED 32-bit state (arithmetic >> 8), hashFunction.c:83-122 ---- */
 static int32_t crc_tab[256];
-static int crc_init_done;
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
+
+static void crc_init(void)
+{
+	for (uint32_t n = 0; n < 256; n++) {
+		uint32_t c = n;
+		for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+		crc_tab[n] = (int32_t)c;
+	}
+}
 
 uint64_t ref_hash_kmer(const kw_t *k, int nw)
 {
-	if (!crc_init_done) {
-		for (uint32_t n = 0; n < 256; n++) {
-			uint32_t c = n;
-			for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
-			crc_tab[n] = (int32_t)c;
-		}
-		crc_init_done = 1;
-	}
+	pthread_once(&crc_once, crc_init);               /* called from the unpack threads */
 	/* raw bytes of the variant's Kmer struct: words high..low, each little endian */
 	const unsigned char *raw = (const unsigned char *)&k->w[4 - nw];
 	int32_t crc = ~0;
