@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--K", type=int, default=31)
     ap.add_argument("--T", type=int, default=20000, help="synthetic transcripts")
     ap.add_argument("--err", type=float, default=0.002)
+    ap.add_argument("--sigma", type=float, default=2.0, help="log-normal sigma of the expression weights (SURVEY C5: 2.5)")
+    ap.add_argument("--d", type=int, default=0, help="-d: also run the low-coverage filter (k_delow) in every step")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
     ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
     ap.add_argument("--est-distinct", type=int, default=0)
@@ -208,7 +210,7 @@ def main():
         n_local = n_total // world + (1 if rank < n_total % world else 0)
     kmers_total = n_total * (L - K + 1)
     t0 = time.time()
-    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err,
+    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err, sigma=args.sigma,
                                                   seed=42 + (1000 * rank if (sharded_path and route) else 0))
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
@@ -239,6 +241,8 @@ def main():
                 sharded.count_reads(words, nwords, offsets, n_local, verify=verify)
         kmers, nodes = g.finish_count()
         local_inserted[0] = kmers              # this rank's share (owner filter / routed records) before the all-reduce
+        if args.d:
+            g.delow(args.d)
         hist, linear = g.mark_and_hist()
         if sharded_path:
             hist, kmers, nodes, linear = allreduce_stats(hist, kmers, nodes, linear, dev)
@@ -296,7 +300,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{n_total} x {L} bp synthetic transcriptome reads (T={args.T}, err={args.err}), "
-                               f"K={K}, pass-1 chop+hash+count+kmerFreq", "reads": n_total, "read_len": L, "K": K,
+                               f"K={K}, pass-1 chop+hash+count" + (f"+delow(-d {args.d})" if args.d else "") + "+kmerFreq"
+                               + (f", sigma={args.sigma}" if args.sigma != 2.0 else ""), "reads": n_total, "read_len": L, "K": K,
                    "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
                    "parallelism": (f"owner-sharded table x{world}, " + ("records routed by RCCL all-to-all" if route else
                                    "reads replicated, owner filter (no data-path collective)")) if sharded_path
