@@ -869,3 +869,50 @@ def test_map_stage_randomised_vs_oracle(pkg, synth, K, L):
             assert got == want and (b, f) == (best, foot), r
             multi += n > 1
         assert multi > 0
+
+
+def test_kernel_rate_floors(pkg, synth):
+    """not a benchmark -- a guard against order-of-magnitude regressions (a shared atomic cursor once cost the look-up
+    kernel 5x without changing any result): pass-1 counting >= 8 G k-mers/s (measured 19.6), contig look-ups >= 15 G
+    k-mers/s (measured 50), on a workload generated in HBM"""
+    import ctypes
+    import torch
+    dev = torch.device("cuda:0")
+    K, L, n, T = 31, 150, 4_000_000, 2000
+    words, offsets, nwords = synth.torch_workload(n, L, T, dev)
+    torch.cuda.synchronize()
+    kmers = n * (L - K + 1)
+    with pkg.PregraphGPU(K, est_distinct=1 << 26) as g:
+        for _ in range(2):
+            g.reset()
+            g.kernel_time(reset=True)
+            g.count_reads_device(words, nwords, offsets, n, L)
+            got, _ = g.finish_count()
+            ms, _, _ = g.kernel_time(reset=True)
+        assert got == kmers
+        assert kmers / (ms * 1e-3) > 8e9, f"k_count_reads: {kmers / ms / 1e6:.1f} G k-mers/s"
+    codes, starts, _ = synth.make_transcriptome(T, seed=42)
+    ids = np.arange(1, 2 * T, 2, dtype=np.uint32)
+    lens = (starts[1:] - starts[:-1]).astype(np.uint32)
+    length = np.zeros(2 * T + 1, dtype=np.uint32)
+    twin = np.zeros(2 * T + 1, dtype=np.uint32)
+    length[1::2], length[2::2] = lens, lens
+    twin[1::2], twin[2::2] = ids + 1, ids
+    with pkg.PregraphGPU(K, est_distinct=int(starts[-1]) + 1024, flags=pkg.SDT_FLAG_CONTIG_INDEX) as g:
+        g.index_contigs(synth.pack_2bit(codes), starts.astype(np.uint64), ids)
+        g.finish_count()
+        g.set_contig_table(length, twin)
+        info = torch.zeros(n, dtype=torch.int64, device=dev)
+        cap = n + n // 4
+        hits = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        nh = ctypes.c_uint64()
+        for _ in range(2):
+            g.kernel_time(reset=True)
+            rc = g.lib.sdt_gpu_align_reads_device(g._ctx, words.data_ptr(), offsets.data_ptr(), n, L, None, 32, info.data_ptr(),
+                                                  hits.data_ptr(), cap, ctypes.byref(nh))
+            assert rc == 0, g.lib.sdt_gpu_last_error().decode()
+            ms, _, _ = g.kernel_time(reset=True)
+        mapped = int((((info >> 40) & 255) > 0).sum().item())
+        assert mapped > 0.99 * n
+        assert kmers / (ms * 1e-3) > 15e9, f"k_align_reads: {kmers / ms / 1e6:.1f} G k-mers/s"
