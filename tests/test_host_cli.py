@@ -365,3 +365,53 @@ def test_reader_simd_path_equals_scalar(pkg, tmp_path, name):
     a = subprocess.run([exe, cfg, "3", "50000"], check=True, capture_output=True, text=True).stdout
     b = subprocess.run([exe, cfg, "3", "50000"], check=True, capture_output=True, text=True, env=dict(os.environ, SDT_NO_SIMD="1")).stdout
     assert a == b and len(a) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["map_pe150_k31_p8", "map_fa100_k23_p4_two_libs"])
+def test_whole_pipeline_with_the_reference_in_between(pkg, tmp_path, name):
+    """north star, end to end: sdt-pregraph -> reference contig -> sdt-map -> reference scaff gives the same scaffolds
+    (and every intermediate file the reference's stages exchange) as the reference running all four stages itself"""
+    import oracle_binding as ob
+    import shutil
+    info = mu.load_case(name)
+    ref = ob.ref_binary(31)
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    K, p = info["K"], info["p"]
+    dirs = {}
+    for who in ("ours", "theirs"):
+        d = tmp_path / who
+        d.mkdir()
+        cfg = mu.materialise(info, d)                     # reads + lib.cfg (the graph files are overwritten below)
+        # the map cases' FASTA libraries cannot go through the reference's pregraph (it hangs on them): give both
+        # pipelines FASTQ copies of the same reads for the first stage
+        codes, offs, lib_of, libs, max_rd_len = mu.case_reads(info)
+        fq = d / "pg.fq"
+        letters = np.frombuffer(b"ACTG", dtype=np.uint8)[codes].tobytes()
+        o = offs.astype(np.int64)
+        with open(fq, "wb") as fo:
+            for i in range(len(o) - 1):
+                s = letters[o[i]:o[i + 1]]
+                fo.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+        pg_cfg = d / "pg.cfg"
+        pg_cfg.write_text(f"max_rd_len={max_rd_len}\n[LIB]\navg_ins=200\nasm_flags=3\nq={fq}\n")
+        dirs[who] = (d, cfg, str(pg_cfg))
+    d, cfg, pg_cfg = dirs["theirs"]
+    for args in (["pregraph", "-s", pg_cfg, "-K", str(K), "-p", str(p), "-o", str(d / "out")], ["contig", "-g", str(d / "out")],
+                 ["map", "-s", cfg, "-g", str(d / "out"), "-p", str(p)], ["scaff", "-g", str(d / "out")]):
+        subprocess.run([ref] + args, check=True, capture_output=True, timeout=600)
+    d, cfg, pg_cfg = dirs["ours"]
+    r = subprocess.run([bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", pg_cfg, "-K", str(K), "-p", str(p), "-o", str(d / "out")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    subprocess.run([ref, "contig", "-g", str(d / "out")], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([bin_path(pkg, "sdt-map"), "map", "-s", cfg, "-g", str(d / "out"), "-p", str(p)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    subprocess.run([ref, "scaff", "-g", str(d / "out")], check=True, capture_output=True, timeout=600)
+    for ext in ("kmerFreq", "vertex", "preArc", "contig", "ContigIndex", "readOnContig", "ctg2Read", "readInGap", "peGrads", "links",
+                "scaf", "scafSeq", "contigPosInscaff"):
+        a, b = dirs["ours"][0] / f"out.{ext}", dirs["theirs"][0] / f"out.{ext}"
+        assert open(a, "rb").read() == open(b, "rb").read(), ext
+    assert os.path.getsize(dirs["ours"][0] / "out.scafSeq") > 0
