@@ -6,7 +6,7 @@
  * The reference has no FFI layer: the path sits behind the C functions that call_pregraph() calls
  * (inc/extfunc.h:82,156-163) with state in globals.  Each entry point below names the reference
  * function / call site it replaces (paths relative to /root/reference/src).  A host written in C
- * (soapdenovo-trans_amd/csrc/host/pregraph_main.c), Python/ctypes (soapdenovo-trans_amd/__init__.py)
+ * (soapdenovo-trans_amd/csrc/host/sdt_pregraph.c), Python/ctypes (soapdenovo-trans_amd/__init__.py)
  * or the reference's own prlHashReads.c binds exactly these symbols.
  *
  * Conventions: plain C types only; every function returns 0 on success or a negative SDT_E* code and

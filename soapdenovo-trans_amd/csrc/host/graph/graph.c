@@ -38,6 +38,8 @@ uint64_t ref_hash_kmer(const kw_t *k, int nw)
  * growth doubles below 2^28-1 else adds 0xFFFFFF, until n * lf >= count + 1 (:318-330); the rehash is IN PLACE:
  * old entries are visited by slot, each is re-probed in the new geometry and an occupant that has not moved
  * yet is carried onward (:359-406). */
+int graph_init_kmerset_size = 0;      /* -a (initKmerSetSize, pregraph.c:160-162); only the 2- and 4-word variants look at it */
+
 static int prime_kh(uint64_t num)
 {
 	if (num < 4) return 1;
@@ -350,7 +352,9 @@ static void job_replay(build_job *J, int tid)
 		}
 		replay_t r;
 		memset(&r, 0, sizeof r);
-		r.size = next_prime_kh(1024);                     /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
+		/* init_kmerset(1024, 0.77f), prlHashReads.c:402-423; with -a <n != 0> the 63mer / 127mer binaries ask for
+		 * k * 0xFFFFFF slots with k == 0 (:404-413), and init_kmerset turns anything below 3 into 3 (newhash.c:163-166) */
+		r.size = graph_init_kmerset_size ? 3 : next_prime_kh(1024);
 		r.max = (uint64_t)(r.size * 0.77f);
 		r.lf = (double)0.77f;
 		r.slot = (int64_t *)malloc(r.size * sizeof(int64_t));

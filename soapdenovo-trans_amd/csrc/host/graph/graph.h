@@ -64,6 +64,8 @@ typedef struct graph_s {
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
  * single<<27).  Returns NULL after printing a message on failure. */
+/* -a n (initKmerSetSize): non-zero changes the initial set size of the 63mer / 127mer variants (prlHashReads.c:404-413) */
+extern int graph_init_kmerset_size;
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first);
 void graph_free(graph_t *g);

@@ -44,6 +44,7 @@ int main(int argc, char **argv)
 	RD(keys, 8, n * nwk); RD(ll, 4, n); RD(rf, 4, n); RD(cnt, 4, n); RD(first, 8, n);
 	fclose(fi);
 	t_last = now_ms();
+	if (getenv("SDT_GRAPHCHECK_A")) graph_init_kmerset_size = atoi(getenv("SDT_GRAPHCHECK_A"));      /* -a of the CLI */
 	graph_t *G = graph_build(K, nwv, nwk, p, n, keys, ll, rf, cnt, first);
 	phase("build");
 	graph_remove_minor_out(G, dd);

@@ -257,7 +257,8 @@ int main(int argc, char **argv)
 		case 'p': threads = atoi(optarg); break;
 		case 'd': d = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;          /* pregraph.c:159 */
 		case 'i': dd = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;          /* pregraph.c:170-173 */
-		case 'a': case 'D': break;                                           /* accepted; no effect on this path */
+		case 'a': graph_init_kmerset_size = atoi(optarg); break;             /* pregraph.c:160-162; layout replay, graph/graph.c */
+		case 'D': break;                                                     /* accepted, commented out upstream (pregraph.c:155-158) */
 		case 'n':
 			fprintf(stderr, "-n (N-aware k-mers) is not supported: the reference path is broken (survey 9.3-q11)\n");
 			return 1;

@@ -110,9 +110,13 @@ static int encode_letters_avx2(packer_t *pk, const char *s, int n)
 
 static int have_avx2_bmi2(void)
 {
-	static int cached = -1;
-	if (cached < 0) cached = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SDT_NO_SIMD");
-	return cached;
+	static int cached = -1;                              /* parser threads race to fill it: relaxed atomics, same value */
+	int c = __atomic_load_n(&cached, __ATOMIC_RELAXED);
+	if (c < 0) {
+		c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SDT_NO_SIMD");
+		__atomic_store_n(&cached, c, __ATOMIC_RELAXED);
+	}
+	return c;
 }
 
 /* one sequence line -> stream; returns coded length */

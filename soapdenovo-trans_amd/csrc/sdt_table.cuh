@@ -196,8 +196,12 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 				bool eq = a.y == key.w[1];
 				uint64_t v;
 				if constexpr (NW == 4) {
+					// key[2..3] of a 48-byte entry can sit in another cache line than key[0..1]; a stale copy of
+					// that line in this XCD's L2 still holds k_clear's ~0,~0 -- which is a LEGAL low half (64
+					// trailing G's, the poly-G tail).  Low words that equal the sentinel are therefore never
+					// conclusive here: such candidates take the agent-scope path below.
 					const ulonglong2 b = q[1];
-					eq = eq && b.x == key.w[2] && b.y == key.w[3];
+					eq = eq && b.x == key.w[2] && b.y == key.w[3] && b.x != KEY_EMPTY && b.y != KEY_EMPTY;
 					v = q[2].x;
 				} else {
 					v = q[1].x;

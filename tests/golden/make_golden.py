@@ -74,6 +74,9 @@ CASES = [
     dict(name="se250_k63_p8_127mer", variant=127, K=63, p=8, d=0, n=1500, L=250, T=30, kind="se"),
     dict(name="se150_k47_p4_63mer", variant=63, K=47, p=4, d=0, n=2000, L=150, T=30, kind="se"),
     dict(name="se150_k95_p3_127mer_d2", variant=127, K=95, p=3, d=2, n=2000, L=150, T=30, kind="se"),
+    # -a <n != 0>: the 63mer / 127mer binaries start every set at init_kmerset(k * 0xFFFFFF) with k == 0, i.e. 3 slots
+    # (prlHashReads.c:404-413): another growth sequence, another visiting order
+    dict(name="se150_k47_p4_63mer_a1", variant=63, K=47, p=4, d=0, n=2000, L=150, T=30, kind="se", a=1),
     dict(name="dirty_ragged_k25_cut80", variant=31, K=25, p=8, d=0, n=3000, L=120, T=30, kind="dirty", max_rd_len=80),
     dict(name="evenK24_p2", variant=31, K=24, p=2, d=0, n=1500, L=100, T=20, kind="se"),
     dict(name="smallK11_p8", variant=31, K=11, p=8, d=0, n=800, L=60, T=10, kind="se"),
@@ -141,6 +144,8 @@ def make_case(c):
     cmd = [exe, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(c["K"]), "-p", str(c["p"]), "-o", os.path.join(tmp, "out")]
     if c["d"]:
         cmd += ["-d", str(c["d"])]
+    if c.get("a"):
+        cmd += ["-a", str(c["a"])]
     log = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout
     m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", log)
     info = dict(c)

@@ -84,6 +84,8 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
            str(tmp_path / "out"), "--max-k", str(gu.VARIANT_MAXK[info["variant"]])]
     if info["d"]:
         cmd += ["-d", str(info["d"])]
+    if info.get("a"):
+        cmd += ["-a", str(info["a"])]
     if second_pass == "host":
         cmd += ["--host-map"]
     if second_pass == "host-walks":      # default: the tip walks come from the device mirror of the graph
@@ -127,14 +129,10 @@ def first_ordinals(info, K, codes, offs):
     return first
 
 
-@pytest.mark.parametrize("name", gu.case_names())
-def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
-    """csrc/host/graph (layout replay from first-occurrence order + minor-out + tip cutting + output_vertex) on the
-    node table a GPU run would export (built here with the oracle): *.vertex byte-identical to the reference at the
-    same -p, for 31/63/127mer variants"""
+def write_node_dump(pkg, info, path):
+    """the node table a GPU run would export for a golden case (built with the oracle), in sdt-graphcheck's dump format"""
     import struct
     import oracle_binding as ob
-    info = gu.load_case(name)
     variant = info["variant"]
     K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
     codes, offs = gu.case_reads(info)
@@ -151,17 +149,27 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
     perm = rng.permutation(n)                          # the GPU exports in arbitrary order
     rflags = (r.astype(np.uint32) | ((fl & 1).astype(np.uint32) << 24) | (((fl >> 1) & 1).astype(np.uint32) << 25)
               | (((fl >> 2) & 1).astype(np.uint32) << 27))
-    dump = tmp_path / "nodes.bin"
-    with open(dump, "wb") as f:
+    with open(path, "wb") as f:
         f.write(struct.pack("<6iQ", K, nwv, nwk, info["p"], info["d"], 5, n))
         f.write(np.ascontiguousarray(keys[perm][:, 4 - nwk:]).tobytes())
         f.write(l[perm].astype(np.uint32).tobytes())
         f.write(rflags[perm].tobytes())
         f.write(cnt[perm].astype(np.uint32).tobytes())
         f.write(fo[perm].tobytes())
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
+    """csrc/host/graph (layout replay from first-occurrence order + minor-out + tip cutting + output_vertex) on the
+    node table a GPU run would export (built here with the oracle): *.vertex byte-identical to the reference at the
+    same -p, for 31/63/127mer variants"""
+    info = gu.load_case(name)
+    dump = tmp_path / "nodes.bin"
+    write_node_dump(pkg, info, dump)
     cfg = materialise(info, tmp_path)
+    env = dict(os.environ, SDT_GRAPHCHECK_A=str(info["a"])) if info.get("a") else None     # -a of the reference's CLI
     out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out"), cfg], check=True,
-                         capture_output=True, text=True).stdout
+                         capture_output=True, text=True, env=env).stdout
     assert open(tmp_path / "out.preArc").read() == gu.golden_text(info, "preArc")
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
     assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
@@ -170,6 +178,26 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name):
     assert int(re.search(r"(\d+) kmers off", out).group(1)) == info["kmers_off"]
     assert [int(x) for x in re.findall(r"(\d+) tips off", out)] == info["tips_off"]
     assert [int(x) for x in re.findall(r"(\d+) linear nodes", out)] == info["linear_after"][1:]
+
+
+@pytest.mark.parametrize("name", ["pe150_k31_p8", "se150_k95_p3_127mer_d2"])
+def test_graph_phases_clean_under_sanitizers(pkg, tmp_path, name):
+    """`make -C csrc/host sanitize`: the host graph phases (parallel layout replay, component-parallel commits, parallel
+    stamping and writers) under AddressSanitizer + UBSan and under ThreadSanitizer, same files as the reference"""
+    host = os.path.join(os.path.dirname(bin_path(pkg, "sdt-graphcheck")), "host")
+    subprocess.run(["make", "-C", host, "sanitize"], check=True, capture_output=True)
+    info = gu.load_case(name)
+    dump = tmp_path / "nodes.bin"
+    write_node_dump(pkg, info, dump)
+    cfg = materialise(info, tmp_path)
+    for exe, env in (("sdt-graphcheck-asan", {"ASAN_OPTIONS": "detect_leaks=0", "UBSAN_OPTIONS": "halt_on_error=1"}),
+                     ("sdt-graphcheck-tsan", {"TSAN_OPTIONS": "halt_on_error=1"})):
+        r = subprocess.run([bin_path(pkg, exe), str(dump), str(tmp_path / exe), cfg], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+        assert open(str(tmp_path / exe) + ".vertex").read() == gu.golden_text(info, "vertex")
+        assert open(str(tmp_path / exe) + ".preArc").read() == gu.golden_text(info, "preArc")
 
 
 @pytest.mark.gpu
