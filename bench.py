@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--shard-mode", choices=["filter", "route"], default="filter",
                     help="N>1: 'filter' = every rank holds all reads and inserts only the k-mers it owns (no exchange); "
                          "'route' = reads are split and records travel in an RCCL all-to-all")
+    ap.add_argument("--pipeline", choices=["auto", "direct", "superkmer"], default="auto",
+                    help="pass-1 kernel family: 'direct' = one device atomic per occurrence (k_count_reads); 'superkmer' = "
+                         "minimizer buckets of super-k-mers counted in LDS (k_sk_*); 'auto' = the library's default")
+    ap.add_argument("--track-first", action="store_true", help="SDT_FLAG_TRACK_FIRST: what the five-file pipeline runs with")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (extract_route -> all-to-all -> insert_records) even with one rank")
     args = ap.parse_args()
@@ -217,7 +221,10 @@ def main():
 
     # distinct k-mers ~ true k-mers + errors * K; table sized so that MAX_LOAD is not hit
     est = args.est_distinct or int(args.T * 2250 + n_total * L * args.err * K * 1.1) // world + (1 << 20)
-    g = pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0)
+    flags = {"auto": 0, "direct": pkg.SDT_FLAG_DIRECT, "superkmer": pkg.SDT_FLAG_PARTITION}[args.pipeline]
+    if args.track_first:
+        flags |= pkg.SDT_FLAG_TRACK_FIRST
+    g = pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0, flags=flags)
     stream = torch.cuda.Stream(device=dev)
     g.set_stream(stream.cuda_stream)
     log(f"node table: {g.table_slots()} slots")

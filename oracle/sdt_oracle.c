@@ -419,15 +419,22 @@ int sdto_set_search(const sdto_set *s, sdto_kmer seq, int nw, uint64_t *slot)
 
 /* ------------------------------------------------------------------ pass-1 driver */
 
-/* prlHashReads.c:402-423: thrd_num sets, init_kmerset(1024, 0.77f) (the -a option is ignored here) */
-sdto_sets *sdto_sets_new(int nsets, int nw, int K)
+/* prlHashReads.c:402-423: thrd_num sets, init_kmerset(1024, 0.77f).  -a n (initKmerSetSize, pregraph.c:160-162)
+ * with n != 0: the MER63 / MER127 builds ask for k * 0xFFFFFF slots with k == 0 (:404-413), which init_kmerset
+ * turns into 3 (newhash.c:163-166); the MER31 build ignores -a (:414-416). */
+sdto_sets *sdto_sets_new_a(int nsets, int nw, int K, int init_kmerset_size)
 {
 	sdto_sets *S = (sdto_sets *)calloc(1, sizeof *S);
 	S->nsets = nsets; S->nw = nw; S->K = K;
 	S->sets = (sdto_set **)calloc(nsets, sizeof(sdto_set *));
 	for (int i = 0; i < nsets; i++)
-		S->sets[i] = sdto_set_new(1024, 0.77f);
+		S->sets[i] = sdto_set_new(init_kmerset_size && nw > 1 ? 0 : 1024, 0.77f);
 	return S;
+}
+
+sdto_sets *sdto_sets_new(int nsets, int nw, int K)
+{
+	return sdto_sets_new_a(nsets, nw, K, 0);
 }
 
 void sdto_sets_free(sdto_sets *S)

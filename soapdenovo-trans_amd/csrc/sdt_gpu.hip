@@ -26,7 +26,7 @@
 #include "../../include/sdt_gpu.h"
 #include "sdt_kmer.cuh"
 #include "sdt_table.cuh"
-#include "sdt_partition.cuh"
+#include "sdt_superkmer.cuh"
 
 using namespace sdt;
 
@@ -446,7 +446,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
-#include "sdt_partition_kernels.cuh"
+#include "sdt_superkmer_kernels.cuh"
 #include "sdt_map_kernels.cuh"
 #include "sdt_ctg_kernels.cuh"
 
@@ -485,11 +485,27 @@ struct sdt_ctx {
 	uint64_t kmers_total_host = 0;
 	// route scratch
 	unsigned long long *d_cursors = nullptr;
-	// locality pipeline (1-word keys)
 	uint32_t flags = 0;
-	PartBufs pb = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-	uint64_t part_cap = 0;             // records A and B can hold
-	unsigned long long *h_off2 = nullptr;   // pinned copy of off2 (NBF + 1)
+	// locality pipeline (sdt_superkmer.cuh): chunk pools of the two scatter levels, chunk lists, pending work
+	struct SkState {
+		bool ready = false;
+		uint64_t cap_kmers = 0;            // k-mers the pools are sized for (one batch)
+		uint64_t pending_kmers = 0;        // scattered into pool 1, not yet counted
+		SkPool p1 = {nullptr, nullptr, nullptr, 0}, p2 = {nullptr, nullptr, nullptr, 0};
+		unsigned long long *cursors = nullptr;   // [wgs][SK_NB1] open chunks of the level-1 scatter
+		uint32_t wgs = 0;
+		uint32_t *cnt1 = nullptr, *off1 = nullptr, *fill1 = nullptr, *list1 = nullptr;
+		uint32_t *cnt2 = nullptr, *off2 = nullptr, *fill2 = nullptr, *list2 = nullptr, *kmers2 = nullptr;
+		unsigned long long *kpre2 = nullptr;
+		SkItem *items = nullptr;
+		uint32_t items_cap = 0;
+		uint32_t *h_off1 = nullptr, *h_off2 = nullptr;      // pinned
+		unsigned long long *h_kpre2 = nullptr;              // pinned
+		SkItem *h_items = nullptr;                          // pinned
+		bool flushing = false;
+		// statistics of the last flush (sdt_gpu_pipeline_stats)
+		uint64_t st_records = 0, st_chunks1 = 0, st_chunks2 = 0, st_flushes = 0;
+	} sk;
 	// second pass (prlRead2edge): reads kept from pass 1, path words, patch table, arcs
 	struct KeptBatch { uint32_t *d_words; uint64_t *d_offs; uint64_t nwords, nreads, ord_base, ord_stride, maxlen; };
 	std::vector<KeptBatch> kept;
@@ -569,8 +585,16 @@ static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, u
 	return SDT_OK;
 }
 
+static int sk_flush(sdt_ctx *c);
+
 static int sync_stats(sdt_ctx *c)
 {
+	// work parked in the locality pipeline belongs to the table before anybody looks at it
+	if (c->sk.pending_kmers && !c->sk.flushing) {
+		const int rcf = sk_flush(c);
+		if (rcf != SDT_OK)
+			return rcf;
+	}
 	HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	if (c->h_stats->probe_fail)
@@ -649,6 +673,268 @@ static int tile_words_for(uint64_t max_read_len)
 {
 	const uint64_t bases = (uint64_t)TILE_READS * max_read_len + 16;
 	return (int)((bases + 15) / 16) + TAIL_PAD + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// locality pipeline (sdt_superkmer.cuh): scatter super-k-mers -> split -> count in LDS -> merge
+// ------------------------------------------------------------------------------------------------
+static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << 33;      // k-mers per batch at most (pools: ~11 B per k-mer)
+static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
+static const uint64_t SK_COUNT_KMERS = 1ULL << 28;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
+
+static void sk_free(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	void *dev[] = {k.p1.recs, k.p1.meta, k.p1.next, k.p2.recs, k.p2.meta, k.p2.next, k.cursors, k.cnt1, k.off1, k.fill1, k.list1,
+	               k.cnt2, k.off2, k.fill2, k.list2, k.kmers2, k.kpre2, k.items};
+	for (void *p : dev)
+		if (p) (void)hipFree(p);
+	void *host[] = {k.h_off1, k.h_off2, k.h_kpre2, k.h_items};
+	for (void *p : host)
+		if (p) (void)hipHostFree(p);
+	k = sdt_ctx::SkState();
+}
+
+// LDS bytes of the level-1 scatter for a maximum read length
+struct SkGeo { int mtw, tile_words, hv_words, bits_words; size_t smem; };
+static SkGeo sk_geo(int K, uint64_t max_read_len)
+{
+	SkGeo g;
+	g.mtw = tile_words_for(max_read_len);
+	g.tile_words = (int)((tile_smem_bytes(g.mtw) / sizeof(uint32_t) + 1) & ~(size_t)1);
+	g.hv_words = (int)((TILE_READS * max_read_len + 16 + 1) & ~(uint64_t)1);
+	const uint64_t nk_max = (uint64_t)TILE_READS * (max_read_len - K + 1);
+	g.bits_words = (int)(nk_max / 64 + 2);
+	g.smem = (size_t)g.tile_words * 4 + (size_t)SK_NB1 * 8 + (size_t)g.hv_words * 4 + (size_t)g.bits_words * 8 + (size_t)(g.bits_words + 2) * 4;
+	return g;
+}
+
+template <int NW> static size_t sk_count_smem(bool track)
+{
+	constexpr int SLOTS = SkCnt<NW>::SLOTS, BW = SkFmt<NW>::BW;
+	return (size_t)(NW + 1 + (track ? 1 : 0)) * SLOTS * 8 + (size_t)SK_CNT_TPB * 8 + (size_t)(SK_CNT_TPB + 2) * 4 +
+	       (size_t)(LDS_LEAD + SK_CNT_TPB * BW * 2 + TAIL_PAD) * 4;
+}
+
+static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
+{
+	if (c->nranks > 1 || (c->flags & SDT_FLAG_CONTIG_INDEX))
+		return false;
+	if (max_read_len < (uint64_t)c->K + 1 || max_read_len > 65535)
+		return false;
+	return sk_geo(c->K, max_read_len).smem <= 160 * 1024;
+}
+
+static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
+{
+	sdt_ctx::SkState &k = c->sk;
+	if (k.ready && k.cap_kmers >= want_kmers)
+		return SDT_OK;
+	if (k.ready)
+		sk_free(c);
+	const int rw = sk_rec_words(c->nw);
+	const int w = c->K - sk_minimizer_len(c->K) + 1;
+	// records: a run is (w + 1) / 2 k-mers long on average; leave room for twice as many
+	uint64_t div = (uint64_t)(w + 1) / 4;
+	if (div < 2) div = 2;
+	if (div > 6) div = 6;
+	size_t free_b = 0, total_b = 0;
+	HIPCHK(hipMemGetInfo(&free_b, &total_b));
+	uint64_t cap = want_kmers < (1ULL << 24) ? (1ULL << 24) : want_kmers;
+	if (cap > SK_BATCH_MAX_KMERS) cap = SK_BATCH_MAX_KMERS;
+	const uint32_t wgs = (uint32_t)c->cu_count * 3;
+	for (;; cap /= 2) {
+		const uint64_t recs = cap / div;
+		const uint64_t chunks1 = recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
+		const uint64_t items = chunks1 / SK_ITEM_CHUNKS + SK_NB1 + 1;
+		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
+		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;
+		if (chunks2 >= 0xFFFFFF00ULL || bytes > free_b / 2) {
+			if (cap <= (1ULL << 24))
+				return fail(SDT_ENOMEM, "super-k-mer pools: %llu MiB needed for the smallest batch, %zu MiB free",
+				            (unsigned long long)(bytes >> 20), free_b >> 20);
+			continue;
+		}
+		k.p1.chunks = (uint32_t)chunks1;
+		k.p2.chunks = (uint32_t)chunks2;
+		k.items_cap = (uint32_t)items;
+		break;
+	}
+	k.wgs = wgs;
+	HIPCHK(hipMalloc((void **)&k.p1.recs, (size_t)k.p1.chunks * SK_CAP1 * rw * 8));
+	HIPCHK(hipMalloc((void **)&k.p1.meta, (size_t)k.p1.chunks * 4));
+	HIPCHK(hipMalloc((void **)&k.p1.next, 64));
+	HIPCHK(hipMalloc((void **)&k.p2.recs, (size_t)k.p2.chunks * SK_CAP2 * rw * 8));
+	HIPCHK(hipMalloc((void **)&k.p2.meta, (size_t)k.p2.chunks * 4));
+	HIPCHK(hipMalloc((void **)&k.p2.next, 64));
+	HIPCHK(hipMalloc((void **)&k.cursors, (size_t)wgs * SK_NB1 * 8));
+	HIPCHK(hipMalloc((void **)&k.cnt1, SK_NB1 * 4));
+	HIPCHK(hipMalloc((void **)&k.off1, (SK_NB1 + 1) * 4));
+	HIPCHK(hipMalloc((void **)&k.fill1, SK_NB1 * 4));
+	HIPCHK(hipMalloc((void **)&k.list1, (size_t)k.p1.chunks * 4));
+	HIPCHK(hipMalloc((void **)&k.cnt2, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&k.off2, (SK_NBF + 1) * 4));
+	HIPCHK(hipMalloc((void **)&k.fill2, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&k.list2, (size_t)k.p2.chunks * 4));
+	HIPCHK(hipMalloc((void **)&k.kmers2, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&k.kpre2, (SK_NBF + 1) * 8));
+	HIPCHK(hipMalloc((void **)&k.items, (size_t)k.items_cap * sizeof(SkItem)));
+	HIPCHK(hipHostMalloc((void **)&k.h_off1, (SK_NB1 + 1) * 4, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&k.h_off2, (SK_NBF + 1) * 4, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&k.h_kpre2, (SK_NBF + 1) * 8, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&k.h_items, (size_t)k.items_cap * sizeof(SkItem), hipHostMallocDefault));
+	HIPCHK(hipMemsetAsync(k.p1.next, 0, 4, c->stream));
+	hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, k.cursors, wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
+	HIPCHK(hipGetLastError());
+	k.cap_kmers = cap;
+	k.pending_kmers = 0;
+	k.ready = true;
+	return SDT_OK;
+}
+
+template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t f0, uint32_t f1)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const bool track = c->d_first != nullptr;
+	const size_t smem = sk_count_smem<NW>(track);
+	if (track) {
+		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+		hipLaunchKernelGGL((k_sk_count<NW, true>), dim3(f1 - f0), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.off2, f0, c->K, table_of<NW>(c), c->d_stats);
+	} else {
+		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+		hipLaunchKernelGGL((k_sk_count<NW, false>), dim3(f1 - f0), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.off2, f0, c->K, table_of<NW>(c), c->d_stats);
+	}
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+// everything scattered so far goes into the node table: seal + list the level-1 chunks, split every level-1 bucket,
+// list the level-2 chunks, count bucket by bucket
+static int sk_flush(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	if (!k.ready || k.pending_kmers == 0 || k.flushing)
+		return SDT_OK;
+	k.flushing = true;
+	EventPair *ev = next_event(c);
+	if (!ev) { k.flushing = false; return fail(SDT_EHIP, "hipEventCreate failed"); }
+	ev->kmers = 0;
+	int rc = SDT_OK;
+#define SK_CHK(expr)                                                                                   \
+	do {                                                                                               \
+		hipError_t e4_ = (expr);                                                                       \
+		if (e4_ != hipSuccess) {                                                                       \
+			k.flushing = false;                                                                        \
+			return fail(e4_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e4_), __FILE__, __LINE__); \
+		}                                                                                              \
+	} while (0)
+	SK_CHK(hipEventRecord(ev->a, c->stream));
+	const int g = c->cu_count * 8;
+	// level 1: lists
+	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.p1, (uint32_t)SK_CAP1);
+	SK_CHK(hipMemsetAsync(k.cnt1, 0, SK_NB1 * 4, c->stream));
+	hipLaunchKernelGGL(k_sk_chunk_hist, dim3(g), dim3(256), 0, c->stream, k.p1, k.cnt1);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
+	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1);
+	SK_CHK(hipGetLastError());
+	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+	SK_CHK(hipStreamSynchronize(c->stream));
+	// level 2: work items of at most SK_ITEM_CHUNKS chunks, never across level-1 buckets
+	uint32_t nitems = 0;
+	for (uint32_t b = 0; b < (uint32_t)SK_NB1; b++)
+		for (uint32_t c0 = k.h_off1[b]; c0 < k.h_off1[b + 1]; c0 += SK_ITEM_CHUNKS) {
+			if (nitems >= k.items_cap) { k.flushing = false; return fail(SDT_EHIP, "super-k-mer pipeline: item table overflow"); }
+			const uint32_t c1 = c0 + SK_ITEM_CHUNKS < k.h_off1[b + 1] ? c0 + SK_ITEM_CHUNKS : k.h_off1[b + 1];
+			k.h_items[nitems++] = SkItem{b, c0, c1, 0};
+		}
+	k.st_chunks1 = k.h_off1[SK_NB1];
+	SK_CHK(hipMemsetAsync(k.p2.next, 0, 4, c->stream));
+	SK_CHK(hipMemsetAsync(k.kmers2, 0, SK_NBF * 4, c->stream));
+	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
+	if (nitems) {
+		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
+		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
+		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
+		SK_CHK(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_sk_chunk_hist, dim3(g), dim3(256), 0, c->stream, k.p2, k.cnt2);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const uint32_t *)k.kmers2, k.kpre2);
+	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p2, k.off2, k.fill2, k.list2);
+	SK_CHK(hipGetLastError());
+	SK_CHK(hipMemcpyAsync(k.h_kpre2, k.kpre2, (SK_NBF + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	SK_CHK(hipMemcpyAsync(k.h_off2, k.off2, (SK_NBF + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+	// pool 1 is free again: the next batch may scatter while this one is counted (same stream: in order)
+	SK_CHK(hipMemsetAsync(k.p1.next, 0, 4, c->stream));
+	hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
+	SK_CHK(hipStreamSynchronize(c->stream));
+	k.st_chunks2 = k.h_off2[SK_NBF];
+	k.st_flushes++;
+	k.pending_kmers = 0;
+	// count: ranges of final buckets of at most SK_COUNT_KMERS k-mers (every one might be a new node)
+	uint32_t f0 = 0;
+	while (f0 < (uint32_t)SK_NBF && rc == SDT_OK) {
+		uint32_t f1 = f0 + 1;
+		while (f1 < (uint32_t)SK_NBF && k.h_kpre2[f1 + 1] - k.h_kpre2[f0] <= SK_COUNT_KMERS)
+			f1++;
+		const uint64_t kmers = k.h_kpre2[f1] - k.h_kpre2[f0];
+		if (kmers) {
+			rc = ensure_room(c, kmers);
+			if (rc == SDT_OK)
+				rc = c->nw == 1 ? sk_launch_count<1>(c, f0, f1) : c->nw == 2 ? sk_launch_count<2>(c, f0, f1) : sk_launch_count<4>(c, f0, f1);
+			c->kmers_since_sync += kmers;
+		}
+		f0 = f1;
+	}
+	if (rc == SDT_OK)
+		SK_CHK(hipEventRecord(ev->b, c->stream));
+	k.flushing = false;
+	return rc;
+#undef SK_CHK
+}
+
+// chop + scatter a device-resident batch into the level-1 buckets (flushing whenever the pools are full)
+static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads, uint64_t max_read_len)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const uint64_t per_read = max_read_len - c->K + 1;
+	int rc = sk_alloc(c, k.pending_kmers + nreads * per_read);
+	if (rc != SDT_OK)
+		return rc;
+	const SkGeo geo = sk_geo(c->K, max_read_len);
+	const int m = sk_minimizer_len(c->K), ncap = sk_max_run(c->K, c->nw);
+	for (uint64_t r0 = 0; r0 < nreads;) {
+		if (k.pending_kmers + per_read * TILE_READS > k.cap_kmers) {
+			rc = sk_flush(c);
+			if (rc != SDT_OK)
+				return rc;
+		}
+		uint64_t nr = (k.cap_kmers - k.pending_kmers) / per_read / TILE_READS * TILE_READS;
+		if (nr > nreads - r0) nr = nreads - r0;
+		const uint64_t ntiles = (nr + TILE_READS - 1) / TILE_READS;
+		const unsigned grid = (unsigned)(ntiles < k.wgs ? ntiles : k.wgs);
+		EventPair *ev = next_event(c);
+		if (!ev)
+			return fail(SDT_EHIP, "hipEventCreate failed");
+		ev->kmers = nr * per_read;
+		HIPCHK(hipEventRecord(ev->a, c->stream));
+		const uint64_t ob = c->ord_base + r0 * c->ord_stride;
+#define SK_SCATTER(NW)                                                                                                             \
+		do {                                                                                                                       \
+			HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
+			hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs + r0, nr, c->K, m, ncap, \
+			                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
+		} while (0)
+		if (c->nw == 1) SK_SCATTER(1);
+		else if (c->nw == 2) SK_SCATTER(2);
+		else SK_SCATTER(4);
+#undef SK_SCATTER
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(ev->b, c->stream));
+		k.pending_kmers += nr * per_read;
+		r0 += nr;
+	}
+	return SDT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,14 +1081,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_ctg_twin) (void)hipFree(c->d_ctg_twin);
 	if (c->d_hit_cursor) (void)hipFree(c->d_hit_cursor);
 	for (int i = 0; i < 5; i++) if (c->ab[i]) (void)hipFree(c->ab[i]);
-	if (c->pb.hist) (void)hipFree(c->pb.hist);
-	if (c->pb.off2) (void)hipFree(c->pb.off2);
-	if (c->pb.cursor1) (void)hipFree(c->pb.cursor1);
-	if (c->pb.cursor2) (void)hipFree(c->pb.cursor2);
-	if (c->pb.tile1) (void)hipFree(c->pb.tile1);
-	if (c->pb.A) (void)hipFree(c->pb.A);
-	if (c->pb.B) (void)hipFree(c->pb.B);
-	if (c->h_off2) (void)hipHostFree(c->h_off2);
+	sk_free(c);
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	delete c;
@@ -823,6 +1102,12 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->kmers_total_host = 0;
 	c->ord_base = 0;
 	c->ord_stride = 1;
+	if (c->sk.ready) {                               // records scattered but not counted belong to the run being forgotten
+		HIPCHK(hipMemsetAsync(c->sk.p1.next, 0, 4, c->stream));
+		hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, c->sk.cursors, c->sk.wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
+		HIPCHK(hipGetLastError());
+		c->sk.pending_kmers = 0;
+	}
 	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
 	c->kept.clear();
 	c->ctg_ord = 0;
@@ -883,106 +1168,6 @@ static const uint64_t CHUNK_KMERS = 1ULL << 27;
 
 
 
-// ------------------------------------------------------------------------------------------------
-// locality pipeline (sdt_partition.cuh): partition -> LDS count -> one merge per distinct key
-// ------------------------------------------------------------------------------------------------
-static const uint64_t PART_BATCH_RECORDS = 1ULL << 31;      // records per batch (A and B: 16 GiB each at most)
-
-static int part_alloc(sdt_ctx *c, uint64_t records)
-{
-	if (!c->pb.hist) {
-		HIPCHK(hipMalloc((void **)&c->pb.hist, NBF * sizeof(unsigned int)));
-		HIPCHK(hipMalloc((void **)&c->pb.off2, (NBF + 1) * sizeof(unsigned long long)));
-		HIPCHK(hipMalloc((void **)&c->pb.cursor1, NB1 * sizeof(unsigned long long)));
-		HIPCHK(hipMalloc((void **)&c->pb.cursor2, NBF * sizeof(unsigned long long)));
-		HIPCHK(hipMalloc((void **)&c->pb.tile1, (NB1 + 1) * sizeof(unsigned int)));
-		HIPCHK(hipHostMalloc((void **)&c->h_off2, (NBF + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-	}
-	if (c->part_cap < records) {
-		HIPCHK(hipStreamSynchronize(c->stream));
-		if (c->pb.A) HIPCHK(hipFree(c->pb.A));
-		if (c->pb.B) HIPCHK(hipFree(c->pb.B));
-		c->pb.A = c->pb.B = nullptr;
-		c->part_cap = 0;
-		hipError_t e = hipMalloc((void **)&c->pb.A, records * sizeof(uint64_t));
-		if (e == hipSuccess)
-			e = hipMalloc((void **)&c->pb.B, records * sizeof(uint64_t));
-		if (e != hipSuccess)
-			return fail(SDT_ENOMEM, "partition buffers (2 x %llu records): %s", (unsigned long long)records, hipGetErrorString(e));
-		c->part_cap = records;
-	}
-	return SDT_OK;
-}
-
-static int launch_count_partitioned(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads,
-                                    uint64_t max_read_len)
-{
-	const int mtw = tile_words_for(max_read_len);
-	const size_t tile_bytes = tile_smem_bytes(mtw);
-	const int tile_words = (int)((tile_bytes / sizeof(uint32_t) + 1) & ~(size_t)1);      // even: 8-byte alignment behind it
-	const size_t smem_hist = (size_t)tile_words * 4 + NBF * sizeof(uint32_t);
-	const size_t smem_l1 = (size_t)tile_words * 4 + 2 * NB1 * sizeof(uint32_t) + NB1 * sizeof(unsigned long long);
-	if (smem_hist > 160 * 1024)
-		return fail(SDT_EINVAL, "max read length %llu does not fit the LDS tile of the partition path", (unsigned long long)max_read_len);
-	static bool attr_set = false;
-	if (!attr_set) {
-		HIPCHK(hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		attr_set = true;
-	}
-	const PartGeom geo{2 * c->K, 2 * c->K - L1BITS - L2BITS};
-	const uint64_t per_read = max_read_len - c->K + 1;
-	uint64_t batch_reads = PART_BATCH_RECORDS / per_read;
-	batch_reads = batch_reads / TILE_READS * TILE_READS;
-	if (batch_reads > nreads)
-		batch_reads = (nreads + TILE_READS - 1) / TILE_READS * TILE_READS;
-	int rc = part_alloc(c, batch_reads * per_read);
-	if (rc != SDT_OK)
-		return rc;
-	for (uint64_t r0 = 0; r0 < nreads; r0 += batch_reads) {
-		const uint64_t nr = nreads - r0 < batch_reads ? nreads - r0 : batch_reads;
-		const uint64_t ntiles = (nr + TILE_READS - 1) / TILE_READS;
-		unsigned grid = (unsigned)(ntiles < (uint64_t)c->cu_count * 2 ? ntiles : (uint64_t)c->cu_count * 2);
-		EventPair *ev = next_event(c);
-		if (!ev)
-			return fail(SDT_EHIP, "hipEventCreate failed");
-		ev->kmers = nr * per_read;
-		HIPCHK(hipEventRecord(ev->a, c->stream));
-		HIPCHK(hipMemsetAsync(c->pb.hist, 0, NBF * sizeof(unsigned int), c->stream));
-		hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(PT_TPB), smem_hist, c->stream, d_words, d_offs + r0, nr, c->K, mtw,
-		                   tile_words, geo, c->pb.hist);
-		HIPCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, c->stream, c->pb);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(c->h_off2, c->pb.off2, (NBF + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-		unsigned grid1 = (unsigned)(ntiles < (uint64_t)c->cu_count * 8 ? ntiles : (uint64_t)c->cu_count * 8);
-		hipLaunchKernelGGL(k_part_l1, dim3(grid1), dim3(PT_TPB), smem_l1, c->stream, d_words, d_offs + r0, nr, c->K, mtw, tile_words,
-		                   geo, c->pb);
-		HIPCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_part_l2, dim3((unsigned)c->cu_count * 8), dim3(PT_TPB), 0, c->stream, geo, c->pb);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipStreamSynchronize(c->stream));          // h_off2 is valid; A/B are complete
-		// final stage in slices of buckets small enough for the "every record is a new node" growth bound
-		unsigned f0 = 0;
-		while (f0 < (unsigned)NBF) {
-			unsigned f1 = f0;
-			while (f1 < (unsigned)NBF && (f1 == f0 || c->h_off2[f1 + 1] - c->h_off2[f0] <= CHUNK_KMERS))
-				f1++;
-			const uint64_t recs = c->h_off2[f1] - c->h_off2[f0];
-			if (recs) {
-				rc = ensure_room(c, recs);
-				if (rc != SDT_OK)
-					return rc;
-				hipLaunchKernelGGL(k_part_final, dim3(f1 - f0), dim3(FIN_TPB), 0, c->stream, geo, c->pb, f0, table_of<1>(c), c->d_stats);
-				HIPCHK(hipGetLastError());
-				c->kmers_since_sync += recs;
-			}
-			f0 = f1;
-		}
-		HIPCHK(hipEventRecord(ev->b, c->stream));
-	}
-	return SDT_OK;
-}
-
 static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads,
                         uint64_t max_read_len)
 {
@@ -998,8 +1183,12 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	const uint64_t per_read = max_read_len - c->K + 1;
 	// The locality pipeline is opt-in in round 1: on MI355X it measures 11 G k-mers/s against the direct
 	// kernel's 19.5 G (profiles/r1/partition_pipeline_50M.md has the per-stage rates and what has to change).
-	if (c->nw == 1 && (c->flags & SDT_FLAG_PARTITION) && !(c->flags & (SDT_FLAG_DIRECT | SDT_FLAG_TRACK_FIRST)))
-		return launch_count_partitioned(c, d_words, d_offs, nreads, max_read_len);
+	if ((c->flags & SDT_FLAG_PARTITION) && !(c->flags & SDT_FLAG_DIRECT) && sk_applicable(c, max_read_len)) {
+		const int rcs = sk_scatter(c, d_words, d_offs, nreads, max_read_len);
+		if (rcs == SDT_OK)
+			c->ord_base += nreads * c->ord_stride;     // the next batch continues the read stream
+		return rcs;
+	}
 	uint64_t chunk_reads = CHUNK_KMERS / per_read;
 	chunk_reads = chunk_reads / TILE_READS * TILE_READS;
 	if (chunk_reads < TILE_READS)

@@ -1,0 +1,147 @@
+// sdt_superkmer.cuh -- the locality pipeline of pass 1 on gfx950: minimizer buckets of super-k-mers.
+//
+// Why.  put_kmerset (newhash.c:411-462) is one random read-modify-write of a node per k-mer occurrence, and on
+// MI355X a memory-side atomic costs the same ~20 G/s whatever the footprint (profiles/r1/microbench_atomics.txt):
+// the direct kernel (k_count_reads) sits on that ceiling.  Transcriptome reads repeat a k-mer hundreds of
+// times, so the way past it is to bring the occurrences of a key TOGETHER, count them where atomics are cheap
+// (LDS), and touch the node table once per distinct key.
+//
+// How.  A k-mer's bucket is a function of its canonical minimizer: the smallest hash among the canonical
+// m-mers it contains (m = 7..11).  A k-mer and its reverse complement contain the same canonical m-mers, so
+// every occurrence of a canonical key -- on either strand, in any read -- falls into the same bucket.
+// Consecutive k-mers of a read mostly share their minimizer; a maximal run with one bucket is cut out of the
+// read as ONE record (a "super-k-mer"): 8 B of header + the run's bases with one base of context either side
+// (the prev / next neighbour codes of chopKmer4read, prlHashReads.c:215-230,275-308, are read off them).  That
+// is ~3 B per k-mer occurrence instead of the 16-B (key, meta) record of the per-k-mer exchange.
+//
+//   k_sk_scatter_reads   chop + minimizers per tile of 64 reads in LDS, cut the runs, append each record to
+//                        its level-1 bucket (256 of them).  Space comes from a pool of fixed-size chunks; every
+//                        workgroup owns one open chunk per bucket and reserves slots with LDS atomics, so the
+//                        only global atomic is the pool bump once per 32 records.
+//   k_sk_scatter_records level 2: every level-1 bucket is split 1024 ways the same way (records only move).
+//   k_sk_count           one workgroup per final bucket (2^18): records -> LDS -> k-mers -> an LDS hash table
+//                        whose entries have the layout of the node table's (key, val); LDS atomics do the
+//                        counting (wave64, 4096 slots); at the end every LDS entry is merged into the node table
+//                        with ONE saturating CAS (table_merge).  min(63, a + b) per 6-bit link counter and the
+//                        plain sum of counts is exactly what replaying the occurrences one by one leaves
+//                        (newhash.c:71-96), so the node table -- and *.kmerFreq -- is bit-identical.
+// Nothing depends on a bucket fitting: a full LDS table is flushed and refilled, a k-mer that finds no LDS slot
+// and a record that finds no chunk go through table_put directly.
+#pragma once
+#include "sdt_kmer.cuh"
+#include "sdt_table.cuh"
+
+namespace sdt {
+
+constexpr int SK_L1BITS = 8;
+constexpr int SK_L2BITS = 10;
+constexpr int SK_NB1 = 1 << SK_L1BITS;
+constexpr int SK_NB2 = 1 << SK_L2BITS;
+constexpr int SK_NBF = SK_NB1 * SK_NB2;          // final buckets
+constexpr int SK_CAP1 = 32;                      // records per level-1 chunk
+constexpr int SK_CAP2 = 8;                       // records per level-2 chunk
+constexpr uint32_t SK_NOCHUNK = 0xFFFFFFFFu;
+constexpr int SK_MAX_RUN = 64;                   // k-mers per record (6-bit field holds n - 1)
+
+// record: REC_WORDS 64-bit words
+//   [0] read ordinal << 24 | position of the run's first k-mer in its read << 8 | (n - 1) << 2 | has_prev << 1 | has_next
+//   [1] bucket hash (low 32 bits)
+//   [2..] the bases [first k-mer - has_prev, last k-mer + K + has_next), 2 bits each, first base in the MOST
+//         significant pair of word 2 (the packed-read convention of include/sdt_gpu.h), zero padded
+template <int NW> struct SkFmt {
+	static constexpr int BW = NW == 1 ? 2 : (NW == 2 ? 4 : 6);     // base words: 64 / 128 / 192 bases
+	static constexpr int REC_WORDS = 2 + BW;                       // 32 / 48 / 64 bytes
+	static constexpr int CAP_BASES = 32 * BW;
+};
+
+__host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 4 : (nw == 2 ? 6 : 8); }
+
+// minimizer length for a k-mer size (window w = K - m + 1 m-mers)
+__host__ __device__ inline int sk_minimizer_len(int K) { return K >= 23 ? 11 : (K >= 17 ? 9 : 7); }
+
+// longest run a record can hold: n + K - 1 bases + 2 context bases must fit the base words
+__host__ __device__ inline int sk_max_run(int K, int nw)
+{
+	const int cap = 32 * (nw == 1 ? 2 : (nw == 2 ? 4 : 6)) - K - 1;
+	return cap < SK_MAX_RUN ? cap : SK_MAX_RUN;
+}
+
+// order of the canonical m-mers (any fixed bijection-like mixer: which m-mer wins is a layout detail)
+__host__ __device__ inline uint32_t sk_mmer_hash(uint32_t canon)
+{
+	uint32_t h = canon * 0x9E3779B1u + 0x7F4A7C15u;
+	h ^= h >> 15; h *= 0x85EBCA77u;
+	h ^= h >> 13; h *= 0xC2B2AE3Du;
+	h ^= h >> 16;
+	return h;
+}
+
+// bucket hash of a k-mer = a second mix of its smallest m-mer hash (the minimum itself is biased towards 0)
+__host__ __device__ inline uint32_t sk_bucket_hash(uint32_t hvmin)
+{
+	uint32_t h = hvmin ^ 0x5BD1E995u;
+	h *= 0x2C1B3C6Du; h ^= h >> 15;
+	h *= 0x297A2D39u; h ^= h >> 15;
+	return h;
+}
+__host__ __device__ inline uint32_t sk_final_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS - SK_L2BITS); }
+__host__ __device__ inline uint32_t sk_l1_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS); }
+__host__ __device__ inline uint32_t sk_l2_bucket(uint32_t bh) { return (bh >> (32 - SK_L1BITS - SK_L2BITS)) & (SK_NB2 - 1); }
+
+// reverse the order of the 16 two-bit groups of a 32-bit word
+__host__ __device__ inline uint32_t sk_rev2bit32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	x = __brev(x);
+#else
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+	x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+	x = (x >> 16) | (x << 16);
+#endif
+	return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
+
+// canonical m-mer (m <= 15) from its right-aligned forward value
+__host__ __device__ inline uint32_t sk_canon_mmer(uint32_t fw, int m)
+{
+	const uint32_t rc = sk_rev2bit32(fw ^ 0xAAAAAAAAu) >> (32 - 2 * m);
+	return fw < rc ? fw : rc;
+}
+
+// the m bases starting at base index p of a packed word stream (16 bases per uint32, first base in bits 31..30)
+__host__ __device__ inline uint32_t sk_stream_mmer(const uint32_t *words, int p, int m)
+{
+	const int s = 2 * p, wi = s >> 5, sh = s & 31;
+	const uint64_t win = ((uint64_t)words[wi] << 32) | words[wi + 1];
+	return (uint32_t)((win << sh) >> (64 - 2 * m));
+}
+
+// 32 bases starting at base index p as one 64-bit word (first base most significant)
+__host__ __device__ inline uint64_t sk_stream_word(const uint32_t *words, int p)
+{
+	const int s = 2 * p, wi = s >> 5, sh = s & 31;
+	const uint64_t hi = ((uint64_t)words[wi] << 32) | words[wi + 1];
+	return sh ? ((hi << sh) | ((uint64_t)words[wi + 2] >> (32 - sh))) : hi;
+}
+
+__host__ __device__ inline uint64_t sk_header(uint64_t read_ord, uint32_t pos, int n, int has_prev, int has_next)
+{
+	return (read_ord << 24) | ((uint64_t)(pos & 0xFFFFu) << 8) | ((uint64_t)(n - 1) << 2) | ((uint64_t)has_prev << 1) | (uint64_t)has_next;
+}
+__host__ __device__ inline int sk_hdr_n(uint64_t h) { return (int)((h >> 2) & 63u) + 1; }
+__host__ __device__ inline int sk_hdr_prev(uint64_t h) { return (int)((h >> 1) & 1u); }
+__host__ __device__ inline int sk_hdr_next(uint64_t h) { return (int)(h & 1u); }
+__host__ __device__ inline uint32_t sk_hdr_pos(uint64_t h) { return (uint32_t)((h >> 8) & 0xFFFFu); }
+__host__ __device__ inline uint64_t sk_hdr_read(uint64_t h) { return h >> 24; }
+
+// device state of the pipeline (all device pointers)
+struct SkPool {
+	uint64_t *recs;            // chunks * cap * REC_WORDS words
+	uint32_t *meta;            // per chunk: bucket (24 bits) | records in use << 24
+	uint32_t *next;            // bump allocator: chunks handed out
+	uint32_t chunks;           // capacity
+};
+
+} // namespace sdt

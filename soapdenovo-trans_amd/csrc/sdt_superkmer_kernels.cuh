@@ -1,0 +1,552 @@
+// sdt_superkmer_kernels.cuh -- kernels of the super-k-mer pipeline (design notes: sdt_superkmer.cuh).
+// Included by sdt_gpu.hip after stage_tile / TileView / tile_find_read / chop_record are defined.
+#pragma once
+
+constexpr int SK_CNT_TPB = 512;                  // k_sk_count: 8 waves
+constexpr int SK_L2_TPB = 256;
+template <int NW> struct SkCnt {
+	static constexpr int SLOTS = NW == 4 ? 2048 : 4096;          // LDS table entries
+	static constexpr int MAXFILL = SLOTS * 3 / 4;                // no new key past this load
+	static constexpr int FLUSH_AT = SLOTS / 2;                   // flush + clear between tiles past this load
+};
+
+// Reserve one record slot in the open chunk of local bucket `lb` (s_cur[lb] = chunk << 32 | records used).  The lane
+// that takes the slot one past the end replaces the chunk: a pool bump, the only global atomic of the scatter.
+// false: the pool is exhausted (the caller takes its slow path).
+__device__ inline bool sk_reserve(unsigned long long *s_cur, uint32_t lb, uint32_t meta_bucket, uint32_t cap, const SkPool &pool,
+                                  uint32_t &chunk, uint32_t &pos)
+{
+	for (;;) {
+		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
+		pos = (uint32_t)cur;
+		chunk = (uint32_t)(cur >> 32);
+		if (pos < cap)
+			return chunk != SK_NOCHUNK;
+		if (pos == cap) {
+			uint32_t id = atomicAdd(pool.next, 1u);
+			if (id >= pool.chunks)
+				id = SK_NOCHUNK;
+			else
+				pool.meta[id] = meta_bucket | (cap << 24);
+			atomicExch(&s_cur[lb], ((unsigned long long)id << 32) | 1ULL);
+			chunk = id;
+			pos = 0;
+			return id != SK_NOCHUNK;
+		}
+		// pos > cap: another lane of this workgroup is replacing the chunk -- look again
+	}
+}
+
+template <int RW> __device__ inline void sk_store_record(uint64_t *dst, const uint64_t (&rec)[RW])
+{
+	ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst);
+#pragma unroll
+	for (int i = 0; i < RW / 2; i++)
+		d[i] = make_ulonglong2(rec[2 * i], rec[2 * i + 1]);
+}
+
+// ---- level 1: reads -> super-k-mer records in 256 buckets ----------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offs,
+                                                          uint64_t nreads, int K, int m, int ncap, int max_tile_words,
+                                                          int tile_smem_words, int hv_words, int bits_words, SkPool pool,
+                                                          unsigned long long *__restrict__ g_cursors, Table<NW> tbl, Stats *stats,
+                                                          uint64_t ord_base, uint64_t ord_stride)
+{
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS;
+	extern __shared__ uint32_t smem[];
+	unsigned long long *s_cur = (unsigned long long *)(smem + tile_smem_words);           // SK_NB1 (tile_smem_words is even)
+	uint32_t *s_hv = (uint32_t *)(s_cur + SK_NB1);                                        // hv_words (even)
+	unsigned long long *s_bits = (unsigned long long *)(s_hv + hv_words);                 // bits_words
+	uint32_t *s_pc = (uint32_t *)(s_bits + bits_words);                                   // bits_words + 1
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SK_NB1; i += TPB)
+		s_cur[i] = g_cursors[(size_t)blockIdx.x * SK_NB1 + i];
+	const int w = K - m + 1;                         // m-mers per k-mer
+	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	uint32_t claimed = 0, failed = 0, done = 0;
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
+		const int npos = (int)tv.rb[tv.nr];
+		// hash of the canonical m-mer at every base position of the tile
+		for (int p = tid; p < npos; p += TPB)
+			s_hv[p] = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+		__syncthreads();
+		// which k-mers start a run: first of a read, bucket differs from the k-mer before it, or the record is full
+		const uint32_t nk = tv.nk, nkr = (nk + 63u) & ~63u;
+		for (uint32_t q = tid; q < nkr; q += TPB) {
+			bool start = false;
+			if (q < nk) {
+				const int r = tile_find_read(tv.pre, q);
+				const int j = (int)(q - tv.pre[r]);
+				const int p = (int)tv.rb[r] + j;
+				uint32_t sh = s_hv[p];                                  // m-mers this k-mer shares with its predecessor
+				for (int i = 1; i <= w - 2; i++) {
+					const uint32_t v = s_hv[p + i];
+					sh = v < sh ? v : sh;
+				}
+				if (j == 0 || j % ncap == 0) {
+					start = true;
+				} else {
+					const uint32_t a = s_hv[p + w - 1], b = s_hv[p - 1];
+					const uint32_t mine = a < sh ? a : sh, prevm = b < sh ? b : sh;
+					start = sk_final_bucket(sk_bucket_hash(mine)) != sk_final_bucket(sk_bucket_hash(prevm));
+				}
+			}
+			const unsigned long long mask = __ballot(start);
+			if ((tid & 63) == 0)
+				s_bits[q >> 6] = mask;
+		}
+		__syncthreads();
+		// exclusive prefix of the popcounts: s_pc[i] = run starts before word i
+		const int nw64 = (int)(nkr >> 6);
+		if (tid < 64) {
+			uint32_t run = 0;
+			for (int base = 0; base < nw64; base += 64) {
+				const int i = base + tid;
+				const uint32_t c = i < nw64 ? (uint32_t)__popcll(s_bits[i]) : 0u;
+				uint32_t x = c;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t y = __shfl_up(x, d);
+					if (tid >= d)
+						x += y;
+				}
+				if (i < nw64)
+					s_pc[i] = run + x - c;
+				run += __shfl(x, 63);
+			}
+			if (tid == 0)
+				s_pc[nw64] = run;
+		}
+		__syncthreads();
+		const uint32_t ns = nw64 ? s_pc[nw64] : 0u;
+		// one lane per run: cut the record out of the tile and append it to its bucket
+		for (uint32_t i = tid; i < ns; i += TPB) {
+			int lo = 0, hi = nw64;
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (s_pc[mid] <= i) lo = mid; else hi = mid;
+			}
+			unsigned long long x = s_bits[lo];
+			for (uint32_t k = i - s_pc[lo]; k; k--)
+				x &= x - 1;
+			const uint32_t q = (uint32_t)lo * 64u + (uint32_t)(__ffsll((long long)x) - 1);
+			const unsigned long long rest = x & (x - 1);
+			uint32_t qn;
+			if (rest) {
+				qn = (uint32_t)lo * 64u + (uint32_t)(__ffsll((long long)rest) - 1);
+			} else {
+				int wd = lo + 1;
+				while (wd < nw64 && s_bits[wd] == 0)
+					wd++;
+				qn = wd < nw64 ? (uint32_t)wd * 64u + (uint32_t)(__ffsll((long long)s_bits[wd]) - 1) : nk;
+			}
+			const int n = (int)(qn - q);
+			const int r = tile_find_read(tv.pre, q);
+			const int j = (int)(q - tv.pre[r]);
+			const int nk_r = (int)(tv.pre[r + 1] - tv.pre[r]);
+			const int p0 = (int)tv.rb[r] + j;
+			const int hp = j > 0, hn = j + n < nk_r;
+			uint32_t mn = s_hv[p0];
+			for (int t = 1; t < w; t++) {
+				const uint32_t v = s_hv[p0 + t];
+				mn = v < mn ? v : mn;
+			}
+			const uint32_t bh = sk_bucket_hash(mn);
+			const uint64_t read_ord = ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride;
+			uint32_t chunk, pos;
+			if (sk_reserve(s_cur, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, chunk, pos)) {
+				const int len = hp + n + K - 1 + hn, ps = p0 - hp;
+				uint64_t rec[RW];
+				rec[0] = sk_header(read_ord, (uint32_t)j, n, hp, hn);
+				rec[1] = bh;
+#pragma unroll
+				for (int k = 0; k < BW; k++) {
+					uint64_t wv = 0;
+					if (32 * k < len) {
+						wv = sk_stream_word(tv.words, ps + 32 * k);
+						const int keep = len - 32 * k;
+						if (keep < 32)
+							wv &= ~0ULL << (64 - 2 * keep);
+					}
+					rec[2 + k] = wv;
+				}
+				sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
+			} else {
+				// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
+				const int len_r = (int)(tv.rb[r + 1] - tv.rb[r]);
+				for (int jj = j; jj < j + n; jj++) {
+					uint32_t prev, next;
+					const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len_r, jj, K, prev, next);
+					const uint64_t ord = tbl.first ? (read_ord << 16) | (uint64_t)jj : ORD_NONE;
+					if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
+						failed++;
+					done++;
+				}
+			}
+		}
+		__syncthreads();                             // the tile buffers are reused
+	}
+	for (int i = tid; i < SK_NB1; i += TPB)
+		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
+	if (done) atomicAdd(&stats->kmers, (unsigned long long)done);
+	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+// every workgroup's open chunks: write the number of records they hold
+__global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__restrict__ cursors, uint32_t n, SkPool pool, uint32_t cap)
+{
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const unsigned long long cur = cursors[i];
+		const uint32_t chunk = (uint32_t)(cur >> 32), pos = (uint32_t)cur;
+		if (chunk != SK_NOCHUNK)
+			pool.meta[chunk] = (pool.meta[chunk] & 0xFFFFFFu) | ((pos < cap ? pos : cap) << 24);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cursors, uint32_t n, uint32_t cap)
+{
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+		cursors[i] = ((unsigned long long)SK_NOCHUNK << 32) | cap;           // "one past the end": the first record opens a chunk
+}
+
+// ---- chunk lists per bucket (counting sort of chunk ids by bucket) ---------------------------------------------
+__global__ __launch_bounds__(256) void k_sk_chunk_hist(SkPool pool, uint32_t *__restrict__ cnt)
+{
+	const uint32_t used = *pool.next, n = used < pool.chunks ? used : pool.chunks;
+	for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n; c += gridDim.x * 256u)
+		atomicAdd(&cnt[pool.meta[c] & 0xFFFFFFu], 1u);
+}
+
+// exclusive scans over nb buckets by ONE workgroup of 1024: off[0..nb] of cnt, and (kmers != NULL) kpre[0..nb] of kmers
+__global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
+                                                  int nb, const uint32_t *__restrict__ kmers, unsigned long long *__restrict__ kpre)
+{
+	__shared__ unsigned long long s_a[1024], s_b[1024];
+	const int t = threadIdx.x, per = (nb + 1023) / 1024;
+	const int i0 = t * per, i1 = i0 + per < nb ? i0 + per : nb;
+	unsigned long long a = 0, b = 0;
+	for (int i = i0; i < i1; i++) {
+		a += cnt[i];
+		if (kmers) b += kmers[i];
+	}
+	s_a[t] = a;
+	s_b[t] = b;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		const unsigned long long va = t >= d ? s_a[t - d] : 0, vb = t >= d ? s_b[t - d] : 0;
+		__syncthreads();
+		s_a[t] += va;
+		s_b[t] += vb;
+		__syncthreads();
+	}
+	a = t ? s_a[t - 1] : 0;
+	b = t ? s_b[t - 1] : 0;
+	for (int i = i0; i < i1; i++) {
+		off[i] = (uint32_t)a;
+		fillcur[i] = 0;
+		a += cnt[i];
+		if (kmers) {
+			kpre[i] = b;
+			b += kmers[i];
+		}
+	}
+	if (t == 1023) {
+		off[nb] = (uint32_t)s_a[1023];
+		if (kmers) kpre[nb] = s_b[1023];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
+                                                        uint32_t *__restrict__ list)
+{
+	const uint32_t used = *pool.next, n = used < pool.chunks ? used : pool.chunks;
+	for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n; c += gridDim.x * 256u) {
+		const uint32_t b = pool.meta[c] & 0xFFFFFFu;
+		list[off[b] + atomicAdd(&fillcur[b], 1u)] = c;
+	}
+}
+
+// ---- level 2: one item = a run of chunks of ONE level-1 bucket, split into its 1024 sub-buckets ---------------
+struct SkItem { uint32_t b1, c0, c1, pad; };
+
+template <int NW>
+__global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, const uint32_t *__restrict__ list1,
+                                                                  const SkItem *__restrict__ items, SkPool dst,
+                                                                  uint32_t *__restrict__ g_kmers, Stats *stats)
+{
+	constexpr int RW = SkFmt<NW>::REC_WORDS;
+	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
+	__shared__ unsigned long long s_cur[SK_NB2];
+	__shared__ uint32_t s_kc[SK_NB2];
+	const SkItem it = items[blockIdx.x];
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+		s_cur[i] = ((unsigned long long)SK_NOCHUNK << 32) | (unsigned)SK_CAP2;
+		s_kc[i] = 0;
+	}
+	__syncthreads();
+	uint32_t failed = 0;
+	for (uint32_t cb = it.c0; cb < it.c1; cb += CPT) {
+		const uint32_t ci = cb + (uint32_t)tid / SK_CAP1, slot = (uint32_t)tid % SK_CAP1;
+		if (ci >= it.c1)
+			continue;
+		const uint32_t chunk = list1[ci];
+		if (slot >= (src.meta[chunk] >> 24))
+			continue;
+		uint64_t rec[RW];
+		const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(src.recs + ((size_t)chunk * SK_CAP1 + slot) * RW);
+#pragma unroll
+		for (int i = 0; i < RW / 2; i++) {
+			const ulonglong2 v = s[i];
+			rec[2 * i] = v.x;
+			rec[2 * i + 1] = v.y;
+		}
+		const uint32_t b2 = sk_l2_bucket((uint32_t)rec[1]);
+		atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
+		uint32_t dchunk, pos;
+		if (sk_reserve(s_cur, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, dchunk, pos))
+			sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
+		else
+			failed++;                                // the pool is sized for the worst case: never expected
+	}
+	__syncthreads();
+	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+		const unsigned long long cur = s_cur[i];
+		const uint32_t chunk = (uint32_t)(cur >> 32), pos = (uint32_t)cur;
+		if (chunk != SK_NOCHUNK)
+			dst.meta[chunk] = (it.b1 * SK_NB2 + (uint32_t)i) | ((pos < (uint32_t)SK_CAP2 ? pos : (uint32_t)SK_CAP2) << 24);
+		if (s_kc[i])
+			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], s_kc[i]);
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+// ---- count: one workgroup per final bucket ----------------------------------------------------------------------
+// one occurrence into an LDS node word (same layout as the node table's val); true: the 16-bit count wrapped
+__device__ inline bool sk_lds_update(unsigned long long *val, uint32_t prev, uint32_t next)
+{
+	const int ls = 6 * (int)prev, rs = 24 + 6 * (int)next;
+	uint64_t seen = *(volatile unsigned long long *)val;
+	for (;;) {
+		const bool l_done = prev >= 4u || ((seen >> ls) & 63u) >= 63u;
+		const bool r_done = next >= 4u || ((seen >> rs) & 63u) >= 63u;
+		if (l_done && r_done) {
+			const uint64_t old = atomicAdd(val, (unsigned long long)VAL_COUNT_ONE);
+			return (old >> 48) == 0xFFFFu;
+		}
+		uint64_t nv = seen + VAL_COUNT_ONE;
+		if (!l_done) nv += 1ULL << ls;
+		if (!r_done) nv += 1ULL << rs;
+		const uint64_t got = atomicCAS(val, (unsigned long long)seen, (unsigned long long)nv);
+		if (got == seen)
+			return (seen >> 48) == 0xFFFFu;
+		seen = got;
+	}
+}
+
+template <int NW> __device__ inline uint32_t sk_lds_hash(const Key<NW> &k)
+{
+	uint32_t h = 0;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		h = (h ^ (uint32_t)k.w[i]) * 0x9E3779B1u;
+		h = (h ^ (uint32_t)(k.w[i] >> 32)) * 0x85EBCA77u;
+	}
+	return h ^ (h >> 15);
+}
+
+// find-or-claim in the LDS table; -1: no room (full table or too many probes)
+template <int NW, int SLOTS>
+__device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key)
+{
+	uint32_t s = sk_lds_hash<NW>(key) & (SLOTS - 1);
+	for (int probe = 0; probe < 96;) {
+		uint64_t k0 = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (k0 == KEY_EMPTY) {
+			if (__hip_atomic_load(s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)SkCnt<NW>::MAXFILL)
+				return -1;
+			const uint64_t old = atomicCAS(&s_key[s], (unsigned long long)KEY_EMPTY, (unsigned long long)(NW == 1 ? key.w[0] : KEY_LOCKED));
+			if (old == KEY_EMPTY) {
+				atomicAdd(s_fill, 1u);
+				if (NW > 1) {
+#pragma unroll
+					for (int i = 1; i < NW; i++)
+						s_key[i * SLOTS + s] = key.w[i];
+					__hip_atomic_store(&s_key[s], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				return (int)s;
+			}
+			k0 = old;
+		}
+		if (NW > 1 && k0 == KEY_LOCKED)
+			continue;                                // the claimer is writing the low words: look again
+		bool same = k0 == key.w[0];
+		if (NW > 1 && same) {
+			__atomic_thread_fence(__ATOMIC_ACQUIRE);
+#pragma unroll
+			for (int i = 1; i < NW; i++)
+				same = same && (*(volatile unsigned long long *)&s_key[i * SLOTS + s] == key.w[i]);
+		}
+		if (same)
+			return (int)s;
+		s = (s + 1) & (SLOTS - 1);
+		probe++;
+	}
+	return -1;
+}
+
+template <int NW, bool TRACK>
+__global__ __launch_bounds__(SK_CNT_TPB) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint32_t *__restrict__ off2,
+                                                         uint32_t bucket0, int K, Table<NW> tbl, Stats *stats)
+{
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCnt<NW>::SLOTS;
+	constexpr int CPT = SK_CNT_TPB / SK_CAP2;        // chunks per tile
+	constexpr int NWAVES = SK_CNT_TPB / 64;
+	extern __shared__ unsigned long long sm64[];
+	unsigned long long *s_key = sm64;                                    // NW x SLOTS, word-major
+	unsigned long long *s_val = s_key + NW * SLOTS;                      // SLOTS
+	unsigned long long *s_ord = s_val + SLOTS;                           // SLOTS when TRACK
+	unsigned long long *s_h0 = s_ord + (TRACK ? SLOTS : 0);              // SK_CNT_TPB
+	uint32_t *s_pre = (uint32_t *)(s_h0 + SK_CNT_TPB);                   // SK_CNT_TPB + 2
+	uint32_t *s_words = s_pre + SK_CNT_TPB + 2;                          // LDS_LEAD + SK_CNT_TPB * BW * 2 + TAIL_PAD
+	__shared__ uint32_t s_fill, s_wsum[NWAVES];
+	const uint32_t bucket = bucket0 + blockIdx.x;
+	const uint32_t c0 = off2[bucket], c1 = off2[bucket + 1];
+	if (c0 == c1)
+		return;
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+		s_key[i] = KEY_EMPTY;
+		s_val[i] = 0;
+		if (TRACK) s_ord[i] = ORD_NONE;
+	}
+	if (tid < LDS_LEAD)
+		s_words[tid] = 0;
+	if (tid < TAIL_PAD)
+		s_words[LDS_LEAD + SK_CNT_TPB * BW * 2 + tid] = 0;
+	if (tid == 0)
+		s_fill = 0;
+	__syncthreads();
+	uint32_t claimed = 0, failed = 0;
+	unsigned long long done = 0;
+	uint32_t *words = s_words + LDS_LEAD;
+	for (uint32_t cb = c0; cb < c1; cb += CPT) {
+		// every lane brings one record into LDS
+		uint32_t n = 0;
+		{
+			const uint32_t ci = cb + (uint32_t)tid / SK_CAP2, slot = (uint32_t)tid % SK_CAP2;
+			uint64_t h0 = 0;
+			if (ci < c1) {
+				const uint32_t chunk = list2[ci];
+				if (slot < (pool.meta[chunk] >> 24)) {
+					const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW);
+					const ulonglong2 hd = s[0];
+					h0 = hd.x;
+					n = (uint32_t)sk_hdr_n(h0);
+#pragma unroll
+					for (int i = 0; i < BW / 2; i++) {
+						const ulonglong2 v = s[1 + i];
+						uint32_t *d = words + tid * BW * 2 + i * 4;
+						d[0] = (uint32_t)(v.x >> 32); d[1] = (uint32_t)v.x;
+						d[2] = (uint32_t)(v.y >> 32); d[3] = (uint32_t)v.y;
+					}
+				}
+			}
+			s_h0[tid] = h0;
+		}
+		// exclusive prefix sum of the k-mers per record
+		uint32_t x = n;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t y = __shfl_up(x, d);
+			if ((tid & 63) >= d)
+				x += y;
+		}
+		if ((tid & 63) == 63)
+			s_wsum[tid >> 6] = x;
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+#pragma unroll
+		for (int wv = 0; wv < NWAVES; wv++) {
+			const uint32_t v = s_wsum[wv];
+			if (wv < (tid >> 6)) wbase += v;
+			total += v;
+		}
+		s_pre[tid] = wbase + x - n;
+		if (tid == 0)
+			s_pre[SK_CNT_TPB] = total;
+		__syncthreads();
+		for (uint32_t q = tid; q < total; q += SK_CNT_TPB) {
+			int lo = 0, hi = SK_CNT_TPB;
+#pragma unroll
+			for (int st = 0; st < 9; st++) {
+				const int mid = (lo + hi) >> 1;
+				if (s_pre[mid] <= q) lo = mid; else hi = mid;
+			}
+			const int r = lo, j = (int)(q - s_pre[r]);
+			const uint64_t h0 = s_h0[r];
+			const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
+			const int len = hp + nr + K - 1 + sk_hdr_next(h0);
+			uint32_t prev, next;
+			const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
+			const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
+			const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
+			if (s >= 0) {
+				if (sk_lds_update(&s_val[s], prev, next)) {
+					if (!table_merge<NW>(tbl, key, 0, 1u, claimed))          // 65536 occurrences: carry into the node's high count
+						failed++;
+				}
+				if (TRACK) {
+					if (ord < *(volatile unsigned long long *)&s_ord[s])
+						atomicMin(&s_ord[s], (unsigned long long)ord);
+				}
+			} else if (!table_put<NW>(tbl, key, prev, next, claimed, ord)) {
+				failed++;
+			}
+		}
+		done += tid == 0 ? total : 0;
+		__syncthreads();
+		const bool last = cb + CPT >= c1;
+		if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
+			// merge every LDS node into the node table: one saturating CAS per distinct key
+			for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+				const uint64_t k0 = s_key[i];
+				if (k0 == KEY_EMPTY)
+					continue;
+				Key<NW> key;
+				key.w[0] = k0;
+#pragma unroll
+				for (int wv = 1; wv < NW; wv++)
+					key.w[wv] = s_key[wv * SLOTS + i];
+				if (!table_merge<NW>(tbl, key, s_val[i], 0u, claimed, TRACK ? (uint64_t)s_ord[i] : ORD_NONE))
+					failed++;
+				if (!last) {
+					s_key[i] = KEY_EMPTY;
+					s_val[i] = 0;
+					if (TRACK) s_ord[i] = ORD_NONE;
+				}
+			}
+			if (!last) {
+				__syncthreads();
+				if (tid == 0)
+					s_fill = 0;
+				__syncthreads();
+			}
+		}
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		claimed += __shfl_down(claimed, d);
+		failed += __shfl_down(failed, d);
+	}
+	if ((tid & 63) == 0) {
+		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+	}
+	if (tid == 0)
+		atomicAdd(&stats->kmers, done);
+}

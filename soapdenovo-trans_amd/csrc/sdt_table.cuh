@@ -134,40 +134,12 @@ __device__ inline void node_merge(uint64_t *val, uint32_t *aux, uint64_t seen, u
 	}
 }
 
-// put_kmerset for an aggregated record (1-word keys)
-__device__ inline bool table_merge(const Table<1> &t, uint64_t key, uint64_t add, uint32_t &claimed)
-{
-	Key<1> k{{key}};
-	uint64_t slot = key_hash<1>(k) & t.mask;
-	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
-	for (uint64_t probe = 0; probe < max_probe; probe++) {
-		Entry<1> *e = t.ent + slot;
-		const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(e);
-		uint64_t k0 = kv.x, seen = kv.y;
-		if (k0 == KEY_EMPTY) {
-			const uint64_t old = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY,
-			                               (unsigned long long)key);
-			if (old == KEY_EMPTY) {
-				claimed++;
-				k0 = key;
-			} else {
-				k0 = old;
-			}
-			seen = 0;
-		}
-		if (k0 == key) {
-			node_merge(&e->val, t.aux + slot, seen, add);
-			return true;
-		}
-		slot = (slot + 1) & t.mask;
-	}
-	return false;
-}
-
-// put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
+// Find the slot of `key`, claiming an empty one when the key is new (the probe / claim half of put_kmerset,
+// newhash.c:411-462).  On success `slot` is the key's slot and `seen` a (possibly stale) value of its counter
+// word: good enough as the first guess of the CAS loops above.  Returns false when the probe budget ran out.
 template <int NW>
-__device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_t prev, uint32_t next,
-                                 uint32_t &claimed, uint64_t ord = ORD_NONE)
+__device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint32_t &claimed, uint64_t &slot_out,
+                                    uint64_t &seen_out)
 {
 	uint64_t slot = key_hash<NW>(key) & t.mask;
 	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
@@ -207,8 +179,8 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 					v = q[1].x;
 				}
 				if (eq) {
-					node_update(&e->val, t.aux + slot, v, prev, next);
-					note_first(t.first, slot, ord);
+					slot_out = slot;
+					seen_out = v;
 					return true;
 				}
 			}
@@ -232,8 +204,8 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				node_update(&e->val, t.aux + slot, 0, prev, next);
-				note_first(t.first, slot, ord);
+				slot_out = slot;
+				seen_out = 0;
 				return true;
 			}
 			k0 = old;        // somebody else got it first: fall through and look at what they put
@@ -254,14 +226,44 @@ __device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_
 				seen = ld_relaxed(&e->val);
 		}
 		if (same) {
-			node_update(&e->val, t.aux + slot, seen, prev, next);
-			note_first(t.first, slot, ord);
+			slot_out = slot;
+			seen_out = seen;
 			return true;
 		}
 		slot = (slot + 1) & t.mask;
 		probe++;
 	}
 	return false;
+}
+
+// put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
+template <int NW>
+__device__ inline bool table_put(const Table<NW> &t, const Key<NW> &key, uint32_t prev, uint32_t next,
+                                 uint32_t &claimed, uint64_t ord = ORD_NONE)
+{
+	uint64_t slot, seen;
+	if (!table_locate<NW>(t, key, claimed, slot, seen))
+		return false;
+	node_update(&t.ent[slot].val, t.aux + slot, seen, prev, next);
+	note_first(t.first, slot, ord);
+	return true;
+}
+
+// put_kmerset for many occurrences of one key counted elsewhere (LDS): `add` as in node_merge, `hi` = multiples of
+// 65536 occurrences on top of add's 16-bit count, `ord` = the smallest ordinal among them
+template <int NW>
+__device__ inline bool table_merge(const Table<NW> &t, const Key<NW> &key, uint64_t add, uint32_t hi, uint32_t &claimed,
+                                   uint64_t ord = ORD_NONE)
+{
+	uint64_t slot, seen;
+	if (!table_locate<NW>(t, key, claimed, slot, seen))
+		return false;
+	if (add)
+		node_merge(&t.ent[slot].val, t.aux + slot, seen, add);
+	if (hi)
+		atomicAdd(t.aux + slot, hi);
+	note_first(t.first, slot, ord);
+	return true;
 }
 
 } // namespace sdt

@@ -74,6 +74,8 @@ def lib():
     L.sdto_set_first_probe.argtypes = [C.c_void_p, Kmer, C.c_int]
     L.sdto_sets_new.restype = C.c_void_p
     L.sdto_sets_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sdto_sets_new_a.restype = C.c_void_p
+    L.sdto_sets_new_a.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.sdto_sets_free.argtypes = [C.c_void_p]
     L.sdto_sets_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.sdto_sets_node_count.restype = C.c_uint64
@@ -116,11 +118,11 @@ def key_words_for(K):
 class Oracle:
     """prlRead2HashTable restated: nsets = thrd_num, nw = key words of the reference variant."""
 
-    def __init__(self, K, nsets=8, nw=None):
+    def __init__(self, K, nsets=8, nw=None, a=0):
         self.L = lib()
         self.K = K
         self.nw = nw or key_words_for(K)
-        self.h = self.L.sdto_sets_new(nsets, self.nw, K)
+        self.h = self.L.sdto_sets_new_a(nsets, self.nw, K, a)        # a = the reference's -a option
 
     def __del__(self):
         try:

@@ -35,7 +35,7 @@ def node_dict_oracle(o):
     return {k: (int(a), int(b), f(c), int(d)) for k, a, b, c, d in zip(ki, l, r, fl, cnt)}
 
 
-MODES = [1, 2]     # SDT_FLAG_DIRECT, SDT_FLAG_PARTITION (the latter only changes the K <= 31 path)
+MODES = [1, 2]     # SDT_FLAG_DIRECT (one atomic per occurrence), SDT_FLAG_PARTITION (super-k-mer buckets counted in LDS)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -63,8 +63,6 @@ def test_golden_case_kmerfreq_bit_identical(pkg, name, mode):
 @pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (31, 150, True), (33, 150, True),
                                         (63, 250, False), (65, 200, True), (127, 250, True)])
 def test_node_table_equals_oracle(pkg, synth, K, L, ragged, mode):
-    if mode == 2 and K > 31:
-        pytest.skip("the partition path is the 1-word-key path")
     """every node: key, 8 saturating link counters, count, single/linear/deleted flags"""
     tx = synth.make_transcriptome(25, seed=K)
     codes, offs = synth.sample_reads(*tx, n_reads=6000, read_len=L, seed=K + 1, err=0.003, ragged=ragged)
@@ -241,8 +239,9 @@ def test_route_then_insert_equals_direct(pkg, synth):
         assert A == B
 
 
-@pytest.mark.parametrize("K,stride,base", [(21, 1, 0), (35, 2, 1)])
-def test_first_occurrence_ordinals(pkg, synth, K, stride, base):
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("K,stride,base", [(21, 1, 0), (35, 2, 1), (71, 2, 0)])
+def test_first_occurrence_ordinals(pkg, synth, K, stride, base, mode):
     """SDT_FLAG_TRACK_FIRST: per node, the smallest (read ordinal << 16 | position) over its occurrences --
     the order the reference's table layout is a function of"""
     tx = synth.make_transcriptome(10, seed=2)
@@ -254,7 +253,7 @@ def test_first_occurrence_ordinals(pkg, synth, K, stride, base):
             o = ((base + r * stride) << 16) | j
             if kw not in want or o < want[kw]:
                 want[kw] = o
-    with pkg.PregraphGPU(K, est_distinct=1 << 14, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:      # small table: growth keeps them
+    with pkg.PregraphGPU(K, est_distinct=1 << 14, flags=pkg.SDT_FLAG_TRACK_FIRST | mode) as g:      # small table: growth keeps them
         g.set_read_ordinal(base, stride)
         half = 700
         g.push_reads(synth.pack_2bit(codes[: int(offs[half])]), offs[: half + 1])
@@ -293,6 +292,42 @@ def test_wide_key_publication_stress(pkg, synth, K):
             assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
             hist, linear = g.mark_and_hist()
             assert linear == olinear and (hist == ohist).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("K", [95, 127])
+def test_wide_key_poly_g_tails(pkg, synth, K, mode):
+    """4-word keys whose LOW words are all ones (64+ trailing G's, the NextSeq poly-G tail) equal the cleared-slot
+    sentinel in key[2..3]: the plain-load fast path must not take a half-published entry for them (csrc/sdt_table.cuh).
+    Reads = transcript prefixes of varying length followed by a G run, so thousands of distinct keys share ~0 low words
+    with many different high words and are inserted from every CU at once."""
+    rng = np.random.default_rng(K)
+    tx = synth.make_transcriptome(40, seed=K + 3)
+    codes0, starts0 = tx[0], tx[1]
+    n, L = 60000, 250
+    reads = np.full((n, L), 3, dtype=np.uint8)                   # G = 3
+    t = rng.integers(0, len(starts0) - 1, size=n)
+    pre = rng.integers(K - 70 if K > 70 else 5, L - 70, size=n)  # prefix length: the G tail is at least 70 bases
+    pos = starts0[t] + rng.integers(0, 200, size=n)
+    for i in range(n):
+        reads[i, : pre[i]] = codes0[pos[i]: pos[i] + pre[i]]
+    flip = rng.random(n) < 0.5                                   # the other strand: poly-C heads, canonical form decides
+    reads[flip] = (reads[flip][:, ::-1] ^ 2)
+    codes = reads.reshape(-1)
+    offs = (np.arange(n + 1, dtype=np.uint64) * L)
+    o = ob.Oracle(K, nsets=4)
+    o.add_reads(codes, offs)
+    ohist, olinear = o.mark()
+    words = synth.pack_2bit(codes)
+    for rep in range(2):
+        with pkg.PregraphGPU(K, est_distinct=1 << 18, flags=mode) as g:
+            g.push_reads(words, offs)
+            kmers, nodes = g.finish_count()
+            assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+            hist, linear = g.mark_and_hist()
+            assert linear == olinear and (hist == ohist).all()
+            if rep == 0:
+                assert node_dict_gpu(g) == node_dict_oracle(o)
 
 
 def test_sharded_counter_world1_equals_direct(pkg, synth):

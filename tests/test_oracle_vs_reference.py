@@ -117,7 +117,7 @@ def test_case_kmerfreq(name):
     pkg = ge.load_package()
     K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
     codes, offs = gu.case_reads(info)
-    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant])
+    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant], a=info.get("a", 0))
     o.add_reads(codes, offs)
     assert o.kmers_in_reads() == info["kmer_in_reads"]
     assert o.node_count() == info["nodes_allocated"]
@@ -134,7 +134,7 @@ def run_oracle_pregraph(info, pkg):
     variant = info["variant"]
     K = pkg.clamp_K(info["K"], gu.VARIANT_MAXK[variant])
     codes, offs = gu.case_reads(info)
-    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant])
+    o = ob.Oracle(K, nsets=info["p"], nw=gu.VARIANT_WORDS[variant], a=info.get("a", 0))
     o.add_reads(codes, offs)
     if info["d"]:
         o.delow(info["d"])
