@@ -278,7 +278,9 @@ def main():
     kmers, nodes, linear, hist = res
     assert kmers == kmers_total, f"processed {kmers} k-mers, expected {kmers_total}"
     assert int(hist.sum()) == nodes, "kmerFreq bins do not add up to the node count"
+    stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
+    log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms], sk_counters)
     ms_per_step = dt / args.steps * 1e3
     value = kmers_total * args.steps / dt
     B = algorithmic_bytes_per_kmer(L, K)

@@ -251,6 +251,20 @@ int sdt_gpu_set_stream(sdt_ctx *ctx, void *hip_stream);
 /* HIP-event timing of the dominant (chop+insert) kernel accumulated since the last call with reset!=0:
  * total milliseconds, number of launches, k-mer occurrences those launches processed. */
 int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches, uint64_t *kmers);
+/* Where the time of pass 1 went, by stage (HIP events on the context's stream, summed since the last
+ * sdt_gpu_kernel_time(reset != 0)), and the locality pipeline's counters since the last reset:
+ *   counters[0] LDS nodes merged into the table   [1] k-mers that took the direct path out of a full LDS table
+ *           [2] k-mers that took it because the chunk pool was exhausted   [3] early flushes of a full LDS table
+ *           [4] / [5] level-1 / level-2 chunks of the last batch   [6] batches counted   [7] k-mers per batch the pools hold
+ *           [8..11] k_sk_count: 100 MHz clock ticks summed over workgroups in set-up / tile fill / counting / merging
+ *           [12..15] k_sk_scatter_reads: the same for tile staging / window minima / run starts / emission */
+#define SDT_STAGE_DIRECT      0   /* k_count_reads / k_insert_records: one atomic per occurrence */
+#define SDT_STAGE_SK_SCATTER  1   /* k_sk_scatter_reads: chop + minimizers + level-1 scatter */
+#define SDT_STAGE_SK_SPLIT    2   /* chunk lists + k_sk_scatter_records (level 2) */
+#define SDT_STAGE_SK_COUNT    3   /* k_sk_count: LDS counting + merges */
+#define SDT_NSTAGES           4
+#define SDT_NCOUNTERS         16
+int sdt_gpu_stage_times(sdt_ctx *ctx, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS]);
 /* the hash used for sharding (host-callable, identical to the device function):
  * owner rank = ((sdt_owner_hash(key) >> 32) * nranks) >> 32 */
 uint64_t sdt_owner_hash(const uint64_t *key_words_msw_first, int nwords);

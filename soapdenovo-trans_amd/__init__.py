@@ -74,6 +74,7 @@ _ABI = [
     ("sdt_gpu_set_stream", _c.c_int, [_c.c_void_p, _c.c_void_p]),
     ("sdt_gpu_kernel_time", _c.c_int,
      [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_stage_times", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
     ("sdt_owner_hash", _c.c_uint64, [_c.c_void_p, _c.c_int]),
 ]
 ABI_SYMBOLS = [n for n, _, _ in _ABI]
@@ -355,6 +356,16 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_kernel_time(self._ctx, int(reset), ctypes.byref(ms), ctypes.byref(launches),
                                                  ctypes.byref(kmers)))
         return ms.value, launches.value, kmers.value
+
+    def stage_times(self):
+        """(ms per stage [direct, sk scatter, sk split, sk count], pipeline counters) since the last kernel_time(reset=True)"""
+        ms = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_uint64 * 16)()
+        self._check(self.lib.sdt_gpu_stage_times(self._ctx, ms, cnt))
+        names = ("merges", "lds_spills", "pool_direct", "early_flushes", "chunks_l1", "chunks_l2", "batches", "batch_kmers", "cnt_ticks_setup",
+                 "cnt_ticks_fill", "cnt_ticks_count", "cnt_ticks_merge", "sc_ticks_stage", "sc_ticks_minima", "sc_ticks_starts",
+                 "sc_ticks_emit")
+        return [float(x) for x in ms], dict(zip(names, (int(x) for x in cnt)))
 
 
 def write_kmerfreq(path: str, hist) -> None:

@@ -72,13 +72,14 @@ struct TileView {
 };
 
 __device__ inline TileView stage_tile(uint32_t *smem, int max_tile_words, const uint32_t *__restrict__ packed,
-                                      const uint64_t *__restrict__ offs, uint64_t r0, uint64_t nreads, int K)
+                                      const uint64_t *__restrict__ offs, uint64_t r0, uint64_t nreads, int K,
+                                      int tile_reads = TILE_READS)
 {
 	uint32_t *s_rb = smem;                           // TILE_READS + 1
 	uint32_t *s_pre = smem + (TILE_READS + 1);       // TILE_READS + 1
 	uint32_t *s_words = smem + 2 * (TILE_READS + 1) + 2;   // keep 16-byte alignment irrelevant: b32 reads
 	const int tid = threadIdx.x;
-	const int nr = (int)((nreads - r0) < (uint64_t)TILE_READS ? (nreads - r0) : (uint64_t)TILE_READS);
+	const int nr = (int)((nreads - r0) < (uint64_t)tile_reads ? (nreads - r0) : (uint64_t)tile_reads);
 	const uint64_t base0 = offs[r0];
 	const uint64_t word0 = base0 >> 4;
 	const uint64_t base_end = offs[r0 + nr];
@@ -456,6 +457,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 struct EventPair {
 	hipEvent_t a, b;
 	uint64_t kmers;
+	int stage;               // SDT_STAGE_*
 };
 
 struct sdt_ctx {
@@ -490,15 +492,20 @@ struct sdt_ctx {
 	struct SkState {
 		bool ready = false;
 		uint64_t cap_kmers = 0;            // k-mers the pools are sized for (one batch)
+		bool cap_is_max = false;           // the device has no room for larger pools: do not try again
 		uint64_t pending_kmers = 0;        // scattered into pool 1, not yet counted
 		SkPool p1 = {nullptr, nullptr, nullptr, 0}, p2 = {nullptr, nullptr, nullptr, 0};
 		unsigned long long *cursors = nullptr;   // [wgs][SK_NB1] open chunks of the level-1 scatter
+		unsigned long long *blk = nullptr;       // [wgs] block of chunk ids each workgroup is handing out
 		uint32_t wgs = 0;
 		uint32_t *cnt1 = nullptr, *off1 = nullptr, *fill1 = nullptr, *list1 = nullptr;
 		uint32_t *cnt2 = nullptr, *off2 = nullptr, *fill2 = nullptr, *list2 = nullptr, *kmers2 = nullptr;
 		unsigned long long *kpre2 = nullptr;
 		SkItem *items = nullptr;
 		uint32_t items_cap = 0;
+		uint2 *citems = nullptr, *h_citems = nullptr;       // work items of k_sk_count: [c0, c1) in list2 (device / pinned)
+		uint32_t citems_cap = 0;
+		uint32_t *next_item = nullptr;                      // one counter per k_sk_count launch
 		uint32_t *h_off1 = nullptr, *h_off2 = nullptr;      // pinned
 		unsigned long long *h_kpre2 = nullptr;              // pinned
 		SkItem *h_items = nullptr;                          // pinned
@@ -657,8 +664,10 @@ static EventPair *next_event(sdt_ctx *c)
 		if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)
 			return nullptr;
 		p.kmers = 0;
+		p.stage = 0;
 		c->ev.push_back(p);
 	}
+	c->ev[c->ev_used].stage = 0;
 	return &c->ev[c->ev_used++];
 }
 
@@ -680,16 +689,18 @@ static int tile_words_for(uint64_t max_read_len)
 // ------------------------------------------------------------------------------------------------
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << 33;      // k-mers per batch at most (pools: ~11 B per k-mer)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
-static const uint64_t SK_COUNT_KMERS = 1ULL << 28;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
+static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
+static const uint32_t SK_COUNT_ITEM_CHUNKS = 512;           // level-2 chunks per k_sk_count work item (4096 records)
+static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 static void sk_free(sdt_ctx *c)
 {
 	sdt_ctx::SkState &k = c->sk;
-	void *dev[] = {k.p1.recs, k.p1.meta, k.p1.next, k.p2.recs, k.p2.meta, k.p2.next, k.cursors, k.cnt1, k.off1, k.fill1, k.list1,
-	               k.cnt2, k.off2, k.fill2, k.list2, k.kmers2, k.kpre2, k.items};
+	void *dev[] = {k.p1.recs, k.p1.meta, k.p1.next, k.p2.recs, k.p2.meta, k.p2.next, k.cursors, k.blk, k.cnt1, k.off1, k.fill1, k.list1,
+	               k.cnt2, k.off2, k.fill2, k.list2, k.kmers2, k.kpre2, k.items, k.citems, k.next_item};
 	for (void *p : dev)
 		if (p) (void)hipFree(p);
-	void *host[] = {k.h_off1, k.h_off2, k.h_kpre2, k.h_items};
+	void *host[] = {k.h_off1, k.h_off2, k.h_kpre2, k.h_items, k.h_citems};
 	for (void *p : host)
 		if (p) (void)hipHostFree(p);
 	k = sdt_ctx::SkState();
@@ -700,10 +711,10 @@ struct SkGeo { int mtw, tile_words, hv_words, bits_words; size_t smem; };
 static SkGeo sk_geo(int K, uint64_t max_read_len)
 {
 	SkGeo g;
-	g.mtw = tile_words_for(max_read_len);
+	g.mtw = (int)(((uint64_t)SK_TILE_READS * max_read_len + 16 + 15) / 16) + TAIL_PAD + 1;
 	g.tile_words = (int)((tile_smem_bytes(g.mtw) / sizeof(uint32_t) + 1) & ~(size_t)1);
-	g.hv_words = (int)((TILE_READS * max_read_len + 16 + 1) & ~(uint64_t)1);
-	const uint64_t nk_max = (uint64_t)TILE_READS * (max_read_len - K + 1);
+	g.hv_words = (int)((SK_TILE_READS * max_read_len + 16 + 1) & ~(uint64_t)1);
+	const uint64_t nk_max = (uint64_t)SK_TILE_READS * (max_read_len - K + 1);
 	g.bits_words = (int)(nk_max / 64 + 2);
 	g.smem = (size_t)g.tile_words * 4 + (size_t)SK_NB1 * 8 + (size_t)g.hv_words * 4 + (size_t)g.bits_words * 8 + (size_t)(g.bits_words + 2) * 4;
 	return g;
@@ -712,8 +723,8 @@ static SkGeo sk_geo(int K, uint64_t max_read_len)
 template <int NW> static size_t sk_count_smem(bool track)
 {
 	constexpr int SLOTS = SkCnt<NW>::SLOTS, BW = SkFmt<NW>::BW;
-	return (size_t)(NW + 1 + (track ? 1 : 0)) * SLOTS * 8 + (size_t)SK_CNT_TPB * 8 + (size_t)(SK_CNT_TPB + 2) * 4 +
-	       (size_t)(LDS_LEAD + SK_CNT_TPB * BW * 2 + TAIL_PAD) * 4;
+	return (size_t)(NW + (track ? 1 : 0)) * SLOTS * 8 + (size_t)SK_CNT_TILE * 8 + (size_t)SLOTS * 20 + (size_t)(SK_CNT_TILE + 2) * 4 +
+	       (size_t)(LDS_LEAD + SK_CNT_TILE * BW * 2 + TAIL_PAD) * 4;
 }
 
 static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
@@ -725,13 +736,29 @@ static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
 	return sk_geo(c->K, max_read_len).smem <= 160 * 1024;
 }
 
+// pool 1 empty, every workgroup without an open chunk
+static int sk_reset_pool1(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	HIPCHK(hipMemsetAsync(k.p1.next, 0, 4, c->stream));
+	HIPCHK(hipMemsetAsync(k.cnt1, 0, SK_NB1 * 4, c->stream));
+	hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1, k.blk, k.wgs);
+	HIPCHK(hipGetLastError());
+	k.pending_kmers = 0;
+	return SDT_OK;
+}
+
 static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 {
 	sdt_ctx::SkState &k = c->sk;
-	if (k.ready && k.cap_kmers >= want_kmers)
+	if (want_kmers > SK_BATCH_MAX_KMERS)
+		want_kmers = SK_BATCH_MAX_KMERS;
+	if (k.ready && (k.cap_kmers >= want_kmers || k.cap_is_max))
 		return SDT_OK;
-	if (k.ready)
+	if (k.ready) {
+		HIPCHK(hipStreamSynchronize(c->stream));
 		sk_free(c);
+	}
 	const int rw = sk_rec_words(c->nw);
 	const int w = c->K - sk_minimizer_len(c->K) + 1;
 	// records: a run is (w + 1) / 2 k-mers long on average; leave room for twice as many
@@ -741,8 +768,8 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	uint64_t cap = want_kmers < (1ULL << 24) ? (1ULL << 24) : want_kmers;
-	if (cap > SK_BATCH_MAX_KMERS) cap = SK_BATCH_MAX_KMERS;
-	const uint32_t wgs = (uint32_t)c->cu_count * 3;
+	k.cap_is_max = cap >= SK_BATCH_MAX_KMERS;
+	const uint32_t wgs = (uint32_t)c->cu_count * 6;
 	for (;; cap /= 2) {
 		const uint64_t recs = cap / div;
 		const uint64_t chunks1 = recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
@@ -750,6 +777,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;
 		if (chunks2 >= 0xFFFFFF00ULL || bytes > free_b / 2) {
+			k.cap_is_max = true;
 			if (cap <= (1ULL << 24))
 				return fail(SDT_ENOMEM, "super-k-mer pools: %llu MiB needed for the smallest batch, %zu MiB free",
 				            (unsigned long long)(bytes >> 20), free_b >> 20);
@@ -768,6 +796,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	HIPCHK(hipMalloc((void **)&k.p2.meta, (size_t)k.p2.chunks * 4));
 	HIPCHK(hipMalloc((void **)&k.p2.next, 64));
 	HIPCHK(hipMalloc((void **)&k.cursors, (size_t)wgs * SK_NB1 * 8));
+	HIPCHK(hipMalloc((void **)&k.blk, (size_t)wgs * 8));
 	HIPCHK(hipMalloc((void **)&k.cnt1, SK_NB1 * 4));
 	HIPCHK(hipMalloc((void **)&k.off1, (SK_NB1 + 1) * 4));
 	HIPCHK(hipMalloc((void **)&k.fill1, SK_NB1 * 4));
@@ -783,26 +812,30 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	HIPCHK(hipHostMalloc((void **)&k.h_off2, (SK_NBF + 1) * 4, hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void **)&k.h_kpre2, (SK_NBF + 1) * 8, hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void **)&k.h_items, (size_t)k.items_cap * sizeof(SkItem), hipHostMallocDefault));
-	HIPCHK(hipMemsetAsync(k.p1.next, 0, 4, c->stream));
-	hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, k.cursors, wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
-	HIPCHK(hipGetLastError());
+	k.citems_cap = (uint32_t)SK_NBF + k.p2.chunks / SK_COUNT_ITEM_CHUNKS + 1;
+	HIPCHK(hipMalloc((void **)&k.citems, (size_t)k.citems_cap * sizeof(uint2)));
+	HIPCHK(hipHostMalloc((void **)&k.h_citems, (size_t)k.citems_cap * sizeof(uint2), hipHostMallocDefault));
+	HIPCHK(hipMalloc((void **)&k.next_item, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t)));
 	k.cap_kmers = cap;
-	k.pending_kmers = 0;
 	k.ready = true;
-	return SDT_OK;
+	return sk_reset_pool1(c);
 }
 
-template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t f0, uint32_t f1)
+template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
 {
 	sdt_ctx::SkState &k = c->sk;
 	const bool track = c->d_first != nullptr;
 	const size_t smem = sk_count_smem<NW>(track);
+	// persistent workgroups: as many as the LDS tables let the chip hold; they take work items first come first served
+	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 256));
+	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+	if (grid > i1 - i0) grid = i1 - i0;
 	if (track) {
 		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		hipLaunchKernelGGL((k_sk_count<NW, true>), dim3(f1 - f0), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.off2, f0, c->K, table_of<NW>(c), c->d_stats);
+		hipLaunchKernelGGL((k_sk_count<NW, true>), dim3(grid), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1, k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
 	} else {
 		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		hipLaunchKernelGGL((k_sk_count<NW, false>), dim3(f1 - f0), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.off2, f0, c->K, table_of<NW>(c), c->d_stats);
+		hipLaunchKernelGGL((k_sk_count<NW, false>), dim3(grid), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1, k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
 	}
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
@@ -816,9 +849,12 @@ static int sk_flush(sdt_ctx *c)
 	if (!k.ready || k.pending_kmers == 0 || k.flushing)
 		return SDT_OK;
 	k.flushing = true;
-	EventPair *ev = next_event(c);
-	if (!ev) { k.flushing = false; return fail(SDT_EHIP, "hipEventCreate failed"); }
-	ev->kmers = 0;
+	EventPair *ev = next_event(c), *ev2 = next_event(c);
+	if (!ev || !ev2) { k.flushing = false; return fail(SDT_EHIP, "hipEventCreate failed"); }
+	ev = ev2 - 1;                                    // next_event may have moved the vector
+	ev->kmers = ev2->kmers = 0;
+	ev->stage = SDT_STAGE_SK_SPLIT;
+	ev2->stage = SDT_STAGE_SK_COUNT;
 	int rc = SDT_OK;
 #define SK_CHK(expr)                                                                                   \
 	do {                                                                                               \
@@ -831,9 +867,7 @@ static int sk_flush(sdt_ctx *c)
 	SK_CHK(hipEventRecord(ev->a, c->stream));
 	const int g = c->cu_count * 8;
 	// level 1: lists
-	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.p1, (uint32_t)SK_CAP1);
-	SK_CHK(hipMemsetAsync(k.cnt1, 0, SK_NB1 * 4, c->stream));
-	hipLaunchKernelGGL(k_sk_chunk_hist, dim3(g), dim3(256), 0, c->stream, k.p1, k.cnt1);
+	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.blk, k.wgs, k.p1, (uint32_t)SK_CAP1);
 	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
 	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1);
 	SK_CHK(hipGetLastError());
@@ -853,41 +887,65 @@ static int sk_flush(sdt_ctx *c)
 	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
 	if (nitems) {
 		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
-		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
-		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.kmers2, c->d_stats);
+		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
 		SK_CHK(hipGetLastError());
 	}
-	hipLaunchKernelGGL(k_sk_chunk_hist, dim3(g), dim3(256), 0, c->stream, k.p2, k.cnt2);
 	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const uint32_t *)k.kmers2, k.kpre2);
 	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p2, k.off2, k.fill2, k.list2);
 	SK_CHK(hipGetLastError());
 	SK_CHK(hipMemcpyAsync(k.h_kpre2, k.kpre2, (SK_NBF + 1) * 8, hipMemcpyDeviceToHost, c->stream));
 	SK_CHK(hipMemcpyAsync(k.h_off2, k.off2, (SK_NBF + 1) * 4, hipMemcpyDeviceToHost, c->stream));
 	// pool 1 is free again: the next batch may scatter while this one is counted (same stream: in order)
-	SK_CHK(hipMemsetAsync(k.p1.next, 0, 4, c->stream));
-	hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
+	{
+		const int rcr = sk_reset_pool1(c);
+		if (rcr != SDT_OK) { k.flushing = false; return rcr; }
+	}
+	SK_CHK(hipEventRecord(ev->b, c->stream));
+	SK_CHK(hipEventRecord(ev2->a, c->stream));
 	SK_CHK(hipStreamSynchronize(c->stream));
 	k.st_chunks2 = k.h_off2[SK_NBF];
 	k.st_flushes++;
 	k.pending_kmers = 0;
-	// count: ranges of final buckets of at most SK_COUNT_KMERS k-mers (every one might be a new node)
-	uint32_t f0 = 0;
-	while (f0 < (uint32_t)SK_NBF && rc == SDT_OK) {
-		uint32_t f1 = f0 + 1;
-		while (f1 < (uint32_t)SK_NBF && k.h_kpre2[f1 + 1] - k.h_kpre2[f0] <= SK_COUNT_KMERS)
-			f1++;
-		const uint64_t kmers = k.h_kpre2[f1] - k.h_kpre2[f0];
-		if (kmers) {
-			rc = ensure_room(c, kmers);
-			if (rc == SDT_OK)
-				rc = c->nw == 1 ? sk_launch_count<1>(c, f0, f1) : c->nw == 2 ? sk_launch_count<2>(c, f0, f1) : sk_launch_count<4>(c, f0, f1);
-			c->kmers_since_sync += kmers;
+	// count: work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
+	// k-mers (every one might be a new node: ensure_room)
+	uint32_t nci = 0;
+	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
+	{
+		std::vector<uint32_t> first_item;            // first item of every launch
+		std::vector<uint64_t> launch_kmers;
+		uint64_t acc = 0;
+		first_item.push_back(0);
+		for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
+			const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
+			if (acc && acc + km > SK_COUNT_KMERS && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
+				launch_kmers.push_back(acc);
+				first_item.push_back(nci);
+				acc = 0;
+			}
+			acc += km;
+			for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
+				const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
+				k.h_citems[nci++] = make_uint2(c0, c1);
+			}
 		}
-		f0 = f1;
+		launch_kmers.push_back(acc);
+		first_item.push_back(nci);
+		if (nci)
+			SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+		for (size_t l = 0; l + 1 < first_item.size() && rc == SDT_OK; l++) {
+			const uint32_t i0 = first_item[l], i1 = first_item[l + 1];
+			if (i0 == i1)
+				continue;
+			rc = ensure_room(c, launch_kmers[l]);
+			if (rc == SDT_OK)
+				rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
+			c->kmers_since_sync += launch_kmers[l];
+		}
+		// the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained
 	}
-	if (rc == SDT_OK)
-		SK_CHK(hipEventRecord(ev->b, c->stream));
+	SK_CHK(hipEventRecord(ev2->b, c->stream));
 	k.flushing = false;
 	return rc;
 #undef SK_CHK
@@ -898,32 +956,37 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 {
 	sdt_ctx::SkState &k = c->sk;
 	const uint64_t per_read = max_read_len - c->K + 1;
-	int rc = sk_alloc(c, k.pending_kmers + nreads * per_read);
+	int rc = SDT_OK;
+	if (k.ready && k.pending_kmers && !k.cap_is_max && k.cap_kmers < k.pending_kmers + nreads * per_read)
+		rc = sk_flush(c);                            // the pools are about to be replaced by larger ones
+	if (rc == SDT_OK)
+		rc = sk_alloc(c, k.pending_kmers + nreads * per_read);
 	if (rc != SDT_OK)
 		return rc;
 	const SkGeo geo = sk_geo(c->K, max_read_len);
 	const int m = sk_minimizer_len(c->K), ncap = sk_max_run(c->K, c->nw);
 	for (uint64_t r0 = 0; r0 < nreads;) {
-		if (k.pending_kmers + per_read * TILE_READS > k.cap_kmers) {
+		if (k.pending_kmers + per_read * SK_TILE_READS > k.cap_kmers) {
 			rc = sk_flush(c);
 			if (rc != SDT_OK)
 				return rc;
 		}
-		uint64_t nr = (k.cap_kmers - k.pending_kmers) / per_read / TILE_READS * TILE_READS;
+		uint64_t nr = (k.cap_kmers - k.pending_kmers) / per_read / SK_TILE_READS * SK_TILE_READS;
 		if (nr > nreads - r0) nr = nreads - r0;
-		const uint64_t ntiles = (nr + TILE_READS - 1) / TILE_READS;
+		const uint64_t ntiles = (nr + SK_TILE_READS - 1) / SK_TILE_READS;
 		const unsigned grid = (unsigned)(ntiles < k.wgs ? ntiles : k.wgs);
 		EventPair *ev = next_event(c);
 		if (!ev)
 			return fail(SDT_EHIP, "hipEventCreate failed");
 		ev->kmers = nr * per_read;
+		ev->stage = SDT_STAGE_SK_SCATTER;
 		HIPCHK(hipEventRecord(ev->a, c->stream));
 		const uint64_t ob = c->ord_base + r0 * c->ord_stride;
 #define SK_SCATTER(NW)                                                                                                             \
 		do {                                                                                                                       \
 			HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
 			hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs + r0, nr, c->K, m, ncap, \
-			                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
+			                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
 		} while (0)
 		if (c->nw == 1) SK_SCATTER(1);
 		else if (c->nw == 2) SK_SCATTER(2);
@@ -1103,10 +1166,9 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->ord_base = 0;
 	c->ord_stride = 1;
 	if (c->sk.ready) {                               // records scattered but not counted belong to the run being forgotten
-		HIPCHK(hipMemsetAsync(c->sk.p1.next, 0, 4, c->stream));
-		hipLaunchKernelGGL(k_sk_init_cursors, dim3(256), dim3(256), 0, c->stream, c->sk.cursors, c->sk.wgs * (uint32_t)SK_NB1, (uint32_t)SK_CAP1);
-		HIPCHK(hipGetLastError());
-		c->sk.pending_kmers = 0;
+		const int rcr = sk_reset_pool1(c);
+		if (rcr != SDT_OK)
+			return rcr;
 	}
 	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
 	c->kept.clear();
@@ -2114,6 +2176,38 @@ int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, u
 	if (kmers) *kmers = km;
 	if (reset)
 		c->ev_used = 0;
+	return SDT_OK;
+}
+
+int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS])
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (ms) {
+		for (int i = 0; i < SDT_NSTAGES; i++) ms[i] = 0;
+		for (size_t i = 0; i < c->ev_used; i++) {
+			float t = 0;
+			HIPCHK(hipEventElapsedTime(&t, c->ev[i].a, c->ev[i].b));
+			ms[c->ev[i].stage] += t;
+		}
+	}
+	if (counters) {
+		HIPCHK(hipMemcpy(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost));
+		counters[0] = c->h_stats->sk_merges;
+		counters[1] = c->h_stats->sk_spills;
+		counters[2] = c->h_stats->sk_direct;
+		counters[3] = c->h_stats->sk_gens;
+		counters[4] = c->sk.st_chunks1;
+		counters[5] = c->sk.st_chunks2;
+		counters[6] = c->sk.st_flushes;
+		counters[7] = c->sk.cap_kmers;
+		for (int i = 0; i < 4; i++)
+			counters[8 + i] = c->h_stats->sk_cyc[i];
+		for (int i = 0; i < 4; i++)
+			counters[12 + i] = c->h_stats->sk_cyc1[i];
+	}
 	return SDT_OK;
 }
 

@@ -2,19 +2,52 @@
 // Included by sdt_gpu.hip after stage_tile / TileView / tile_find_read / chop_record are defined.
 #pragma once
 
-constexpr int SK_CNT_TPB = 512;                  // k_sk_count: 8 waves
+constexpr int SK_CNT_TPB = 1024;                 // k_sk_count: 16 waves, two workgroups per CU when the LDS table allows it
+constexpr int SK_CNT_TILE = 512;                 // records per tile
+constexpr int SK_CNT_TILE_LOG2 = 9;
 constexpr int SK_L2_TPB = 256;
+constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 template <int NW> struct SkCnt {
-	static constexpr int SLOTS = NW == 4 ? 2048 : 4096;          // LDS table entries
+	static constexpr int SLOTS = 2048;                           // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
 	static constexpr int MAXFILL = SLOTS * 3 / 4;                // no new key past this load
 	static constexpr int FLUSH_AT = SLOTS / 2;                   // flush + clear between tiles past this load
 };
 
+// Chunk ids come from the pool in blocks of SK_BLK per workgroup (s_blk = next id | end of block << 32): one global
+// atomic per SK_BLK chunks.  (One atomicAdd per chunk on the single pool counter was measured to cap BOTH scatter
+// kernels: same-address device atomics run at well under 1 G/s on MI355X.)
+constexpr uint32_t SK_BLK = 128;
+constexpr uint32_t SK_DEAD = 0xFFFFFFFFu;        // meta of a chunk id that was handed to a workgroup but never used
+
+__device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool)
+{
+	for (;;) {
+		const unsigned long long v = atomicAdd(s_blk, 1ULL);
+		const uint32_t id = (uint32_t)v, end = (uint32_t)(v >> 32);
+		if (id < end)
+			return id;
+		if (id == end) {
+			const uint32_t base = atomicAdd(pool.next, SK_BLK);
+			atomicExch(s_blk, ((unsigned long long)(base + SK_BLK) << 32) | (unsigned long long)(base + 1u));
+			return base;
+		}
+		// id > end: another lane of this workgroup is fetching the next block -- look again
+	}
+}
+
+// the ids of a block that were never handed out must not look like chunks of an earlier batch
+__device__ inline void sk_retire_block(unsigned long long blk, const SkPool &pool)
+{
+	const uint32_t next = (uint32_t)blk, end = (uint32_t)(blk >> 32);
+	for (uint32_t id = next; id < end && id < pool.chunks; id++)
+		pool.meta[id] = SK_DEAD;
+}
+
 // Reserve one record slot in the open chunk of local bucket `lb` (s_cur[lb] = chunk << 32 | records used).  The lane
-// that takes the slot one past the end replaces the chunk: a pool bump, the only global atomic of the scatter.
-// false: the pool is exhausted (the caller takes its slow path).
-__device__ inline bool sk_reserve(unsigned long long *s_cur, uint32_t lb, uint32_t meta_bucket, uint32_t cap, const SkPool &pool,
-                                  uint32_t &chunk, uint32_t &pos)
+// that takes the slot one past the end opens a new chunk (and counts it for its bucket: the counting sort of the
+// chunk ids by bucket needs no pass of its own).  false: the pool is exhausted (the caller takes its slow path).
+__device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long *s_blk, uint32_t lb, uint32_t meta_bucket,
+                                  uint32_t cap, const SkPool &pool, uint32_t *__restrict__ g_cnt, uint32_t &chunk, uint32_t &pos)
 {
 	for (;;) {
 		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
@@ -23,11 +56,13 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, uint32_t lb, uint32
 		if (pos < cap)
 			return chunk != SK_NOCHUNK;
 		if (pos == cap) {
-			uint32_t id = atomicAdd(pool.next, 1u);
-			if (id >= pool.chunks)
+			uint32_t id = sk_alloc_chunk(s_blk, pool);
+			if (id >= pool.chunks) {
 				id = SK_NOCHUNK;
-			else
+			} else {
 				pool.meta[id] = meta_bucket | (cap << 24);
+				atomicAdd(&g_cnt[meta_bucket], 1u);
+			}
 			atomicExch(&s_cur[lb], ((unsigned long long)id << 32) | 1ULL);
 			chunk = id;
 			pos = 0;
@@ -50,7 +85,8 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offs,
                                                           uint64_t nreads, int K, int m, int ncap, int max_tile_words,
                                                           int tile_smem_words, int hv_words, int bits_words, SkPool pool,
-                                                          unsigned long long *__restrict__ g_cursors, Table<NW> tbl, Stats *stats,
+                                                          unsigned long long *__restrict__ g_cursors, unsigned long long *__restrict__ g_blk,
+                                                          uint32_t *__restrict__ g_cnt, Table<NW> tbl, Stats *stats,
                                                           uint64_t ord_base, uint64_t ord_stride)
 {
 	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS;
@@ -59,19 +95,52 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 	uint32_t *s_hv = (uint32_t *)(s_cur + SK_NB1);                                        // hv_words (even)
 	unsigned long long *s_bits = (unsigned long long *)(s_hv + hv_words);                 // bits_words
 	uint32_t *s_pc = (uint32_t *)(s_bits + bits_words);                                   // bits_words + 1
+	__shared__ unsigned long long s_blk;
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SK_NB1; i += TPB)
 		s_cur[i] = g_cursors[(size_t)blockIdx.x * SK_NB1 + i];
+	if (tid == 0)
+		s_blk = g_blk[blockIdx.x];
 	const int w = K - m + 1;                         // m-mers per k-mer
-	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+	const uint64_t ntiles = (nreads + SK_TILE_READS - 1) / SK_TILE_READS;
 	uint32_t claimed = 0, failed = 0, done = 0;
+#ifdef SDT_SK_TICKS
+	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define SK_TICK(i) do { } while (0)
+#endif
 	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
+		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * SK_TILE_READS, nreads, K, SK_TILE_READS);
 		const int npos = (int)tv.rb[tv.nr];
-		// hash of the canonical m-mer at every base position of the tile
-		for (int p = tid; p < npos; p += TPB)
-			s_hv[p] = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+		SK_TICK(0);
+		const bool strips = w <= 49;                 // a wave's 64 lanes hold at least 16 whole windows
+		if (strips) {
+			// bucket hash of the window of w m-mers that starts at every base position: lane l of a strip hashes the
+			// m-mer at its position, a doubling min over shuffles gives min[l, l + P), two of those cover [l, l + w)
+			const int valid = 64 - (w - 1), nstrips = (npos + valid - 1) / valid, lane = tid & 63;
+			int P = 1;
+			while (2 * P <= w)
+				P *= 2;
+			for (int st = tid >> 6; st < nstrips; st += TPB / 64) {
+				const int p = st * valid + lane;
+				uint32_t x = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+				for (int d = 1; d < P; d <<= 1) {
+					const uint32_t y = __shfl_down(x, d);
+					x = y < x ? y : x;
+				}
+				const uint32_t y = __shfl_down(x, w - P);
+				x = y < x ? y : x;
+				if (lane < valid && p < npos)
+					s_hv[p] = sk_bucket_hash(x);
+			}
+		} else {
+			// hash of the canonical m-mer at every base position of the tile
+			for (int p = tid; p < npos; p += TPB)
+				s_hv[p] = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+		}
 		__syncthreads();
+		SK_TICK(1);
 		// which k-mers start a run: first of a read, bucket differs from the k-mer before it, or the record is full
 		const uint32_t nk = tv.nk, nkr = (nk + 63u) & ~63u;
 		for (uint32_t q = tid; q < nkr; q += TPB) {
@@ -80,14 +149,16 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 				const int r = tile_find_read(tv.pre, q);
 				const int j = (int)(q - tv.pre[r]);
 				const int p = (int)tv.rb[r] + j;
-				uint32_t sh = s_hv[p];                                  // m-mers this k-mer shares with its predecessor
-				for (int i = 1; i <= w - 2; i++) {
-					const uint32_t v = s_hv[p + i];
-					sh = v < sh ? v : sh;
-				}
 				if (j == 0 || j % ncap == 0) {
 					start = true;
+				} else if (strips) {
+					start = sk_final_bucket(s_hv[p]) != sk_final_bucket(s_hv[p - 1]);
 				} else {
+					uint32_t sh = s_hv[p];                              // m-mers this k-mer shares with its predecessor
+					for (int i = 1; i <= w - 2; i++) {
+						const uint32_t v = s_hv[p + i];
+						sh = v < sh ? v : sh;
+					}
 					const uint32_t a = s_hv[p + w - 1], b = s_hv[p - 1];
 					const uint32_t mine = a < sh ? a : sh, prevm = b < sh ? b : sh;
 					start = sk_final_bucket(sk_bucket_hash(mine)) != sk_final_bucket(sk_bucket_hash(prevm));
@@ -121,6 +192,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 		}
 		__syncthreads();
 		const uint32_t ns = nw64 ? s_pc[nw64] : 0u;
+		SK_TICK(2);
 		// one lane per run: cut the record out of the tile and append it to its bucket
 		for (uint32_t i = tid; i < ns; i += TPB) {
 			int lo = 0, hi = nw64;
@@ -148,15 +220,17 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 			const int nk_r = (int)(tv.pre[r + 1] - tv.pre[r]);
 			const int p0 = (int)tv.rb[r] + j;
 			const int hp = j > 0, hn = j + n < nk_r;
-			uint32_t mn = s_hv[p0];
-			for (int t = 1; t < w; t++) {
-				const uint32_t v = s_hv[p0 + t];
-				mn = v < mn ? v : mn;
+			uint32_t bh = s_hv[p0];
+			if (!strips) {
+				for (int t = 1; t < w; t++) {
+					const uint32_t v = s_hv[p0 + t];
+					bh = v < bh ? v : bh;
+				}
+				bh = sk_bucket_hash(bh);
 			}
-			const uint32_t bh = sk_bucket_hash(mn);
-			const uint64_t read_ord = ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride;
+			const uint64_t read_ord = ord_base + (tile * SK_TILE_READS + (uint64_t)r) * ord_stride;
 			uint32_t chunk, pos;
-			if (sk_reserve(s_cur, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, chunk, pos)) {
+			if (sk_reserve(s_cur, &s_blk, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, g_cnt, chunk, pos)) {
 				const int len = hp + n + K - 1 + hn, ps = p0 - hp;
 				uint64_t rec[RW];
 				rec[0] = sk_header(read_ord, (uint32_t)j, n, hp, hn);
@@ -187,16 +261,29 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 			}
 		}
 		__syncthreads();                             // the tile buffers are reused
+		SK_TICK(3);
 	}
+#undef SK_TICK
 	for (int i = tid; i < SK_NB1; i += TPB)
 		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
-	if (done) atomicAdd(&stats->kmers, (unsigned long long)done);
+	if (tid == 0) {
+		g_blk[blockIdx.x] = s_blk;
+#ifdef SDT_SK_TICKS
+		for (int i = 0; i < 4; i++)
+			atomicAdd(&stats->sk_cyc1[i], cyc[i]);
+#endif
+	}
+	if (done) {
+		atomicAdd(&stats->kmers, (unsigned long long)done);
+		atomicAdd(&stats->sk_direct, (unsigned long long)done);
+	}
 	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
 	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
-// every workgroup's open chunks: write the number of records they hold
-__global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__restrict__ cursors, uint32_t n, SkPool pool, uint32_t cap)
+// every workgroup's open chunks: write the number of records they hold; retire the rest of its block of chunk ids
+__global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__restrict__ cursors, uint32_t n, const unsigned long long *__restrict__ blk,
+                                                 uint32_t nblk, SkPool pool, uint32_t cap)
 {
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
 		const unsigned long long cur = cursors[i];
@@ -204,22 +291,19 @@ __global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__res
 		if (chunk != SK_NOCHUNK)
 			pool.meta[chunk] = (pool.meta[chunk] & 0xFFFFFFu) | ((pos < cap ? pos : cap) << 24);
 	}
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblk; i += gridDim.x * 256u)
+		sk_retire_block(blk[i], pool);
 }
 
-__global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cursors, uint32_t n, uint32_t cap)
+__global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cursors, uint32_t n, uint32_t cap, unsigned long long *blk, uint32_t nblk)
 {
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
 		cursors[i] = ((unsigned long long)SK_NOCHUNK << 32) | cap;           // "one past the end": the first record opens a chunk
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblk; i += gridDim.x * 256u)
+		blk[i] = 0;                                                          // empty block: the first chunk fetches one
 }
 
 // ---- chunk lists per bucket (counting sort of chunk ids by bucket) ---------------------------------------------
-__global__ __launch_bounds__(256) void k_sk_chunk_hist(SkPool pool, uint32_t *__restrict__ cnt)
-{
-	const uint32_t used = *pool.next, n = used < pool.chunks ? used : pool.chunks;
-	for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n; c += gridDim.x * 256u)
-		atomicAdd(&cnt[pool.meta[c] & 0xFFFFFFu], 1u);
-}
-
 // exclusive scans over nb buckets by ONE workgroup of 1024: off[0..nb] of cnt, and (kmers != NULL) kpre[0..nb] of kmers
 __global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
                                                   int nb, const uint32_t *__restrict__ kmers, unsigned long long *__restrict__ kpre)
@@ -264,7 +348,10 @@ __global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint3
 {
 	const uint32_t used = *pool.next, n = used < pool.chunks ? used : pool.chunks;
 	for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n; c += gridDim.x * 256u) {
-		const uint32_t b = pool.meta[c] & 0xFFFFFFu;
+		const uint32_t mt = pool.meta[c];
+		if (mt == SK_DEAD)
+			continue;
+		const uint32_t b = mt & 0xFFFFFFu;
 		list[off[b] + atomicAdd(&fillcur[b], 1u)] = c;
 	}
 }
@@ -275,18 +362,21 @@ struct SkItem { uint32_t b1, c0, c1, pad; };
 template <int NW>
 __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, const uint32_t *__restrict__ list1,
                                                                   const SkItem *__restrict__ items, SkPool dst,
-                                                                  uint32_t *__restrict__ g_kmers, Stats *stats)
+                                                                  uint32_t *__restrict__ g_cnt, uint32_t *__restrict__ g_kmers, Stats *stats)
 {
 	constexpr int RW = SkFmt<NW>::REC_WORDS;
 	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
 	__shared__ unsigned long long s_cur[SK_NB2];
 	__shared__ uint32_t s_kc[SK_NB2];
+	__shared__ unsigned long long s_blk;
 	const SkItem it = items[blockIdx.x];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
 		s_cur[i] = ((unsigned long long)SK_NOCHUNK << 32) | (unsigned)SK_CAP2;
 		s_kc[i] = 0;
 	}
+	if (tid == 0)
+		s_blk = 0;
 	__syncthreads();
 	uint32_t failed = 0;
 	for (uint32_t cb = it.c0; cb < it.c1; cb += CPT) {
@@ -307,7 +397,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		const uint32_t b2 = sk_l2_bucket((uint32_t)rec[1]);
 		atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
 		uint32_t dchunk, pos;
-		if (sk_reserve(s_cur, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, dchunk, pos))
+		if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, g_cnt, dchunk, pos))
 			sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
 		else
 			failed++;                                // the pool is sized for the worst case: never expected
@@ -321,33 +411,19 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		if (s_kc[i])
 			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], s_kc[i]);
 	}
+	if (tid == 0)
+		sk_retire_block(s_blk, dst);
 	if (failed)
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
-// ---- count: one workgroup per final bucket ----------------------------------------------------------------------
-// one occurrence into an LDS node word (same layout as the node table's val); true: the 16-bit count wrapped
-__device__ inline bool sk_lds_update(unsigned long long *val, uint32_t prev, uint32_t next)
-{
-	const int ls = 6 * (int)prev, rs = 24 + 6 * (int)next;
-	uint64_t seen = *(volatile unsigned long long *)val;
-	for (;;) {
-		const bool l_done = prev >= 4u || ((seen >> ls) & 63u) >= 63u;
-		const bool r_done = next >= 4u || ((seen >> rs) & 63u) >= 63u;
-		if (l_done && r_done) {
-			const uint64_t old = atomicAdd(val, (unsigned long long)VAL_COUNT_ONE);
-			return (old >> 48) == 0xFFFFu;
-		}
-		uint64_t nv = seen + VAL_COUNT_ONE;
-		if (!l_done) nv += 1ULL << ls;
-		if (!r_done) nv += 1ULL << rs;
-		const uint64_t got = atomicCAS(val, (unsigned long long)seen, (unsigned long long)nv);
-		if (got == seen)
-			return (seen >> 48) == 0xFFFFu;
-		seen = got;
-	}
-}
-
+// ---- count: persistent workgroups, one final bucket at a time ---------------------------------------------------
+// LDS node = key word(s) + 32-bit count + 8 link counters of 16 bits (two per 32-bit word), not the node table's
+// packed val: LDS adds must not need a CAS loop -- the records of a bucket are windows around ONE minimizer, so
+// the lanes of a wave keep hitting the same few keys.  A link counter is only incremented while the value read
+// just before is < 63, so it ends at min(63, n) + at most one increment per thread of the workgroup: 16 bits never
+// overflow, and clamping at 63 when the node is merged into the table is exactly the reference's saturating ++
+// (newhash.c:77-94).
 template <int NW> __device__ inline uint32_t sk_lds_hash(const Key<NW> &k)
 {
 	uint32_t h = 0;
@@ -399,154 +475,248 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 	return -1;
 }
 
+// one occurrence: s_lk[4 * slot + side * 2 + (code >> 1)] holds the counters of codes (code & ~1) and (code | 1)
+__device__ inline void sk_lds_update(uint32_t *s_cnt, uint32_t *s_lk, int s, uint32_t prev, uint32_t next)
+{
+	atomicAdd(&s_cnt[s], 1u);
+	if (prev < 4u) {
+		uint32_t *w = &s_lk[4 * s + (prev >> 1)];
+		const uint32_t sh = (prev & 1u) * 16u;
+		if (((*(volatile uint32_t *)w >> sh) & 0xFFFFu) < 63u)
+			atomicAdd(w, 1u << sh);
+	}
+	if (next < 4u) {
+		uint32_t *w = &s_lk[4 * s + 2 + (next >> 1)];
+		const uint32_t sh = (next & 1u) * 16u;
+		if (((*(volatile uint32_t *)w >> sh) & 0xFFFFu) < 63u)
+			atomicAdd(w, 1u << sh);
+	}
+}
+
+// the node table's val layout (count low 16 | r_links | l_links, 6-bit fields clamped) and the high count of an LDS node
+__device__ inline uint64_t sk_lds_val(uint32_t cnt, const uint32_t *lk, uint32_t &hi)
+{
+	uint64_t v = (uint64_t)(cnt & 0xFFFFu) << 48;
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		const uint32_t l = (lk[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu, r = (lk[2 + (b >> 1)] >> ((b & 1) * 16)) & 0xFFFFu;
+		v |= (uint64_t)(l > 63u ? 63u : l) << (6 * b);
+		v |= (uint64_t)(r > 63u ? 63u : r) << (24 + 6 * b);
+	}
+	hi = cnt >> 16;
+	return v;
+}
+
+// (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU)
 template <int NW, bool TRACK>
-__global__ __launch_bounds__(SK_CNT_TPB) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint32_t *__restrict__ off2,
-                                                         uint32_t bucket0, int K, Table<NW> tbl, Stats *stats)
+__global__ __launch_bounds__(SK_CNT_TPB, (NW == 1 && !TRACK) ? 8 : 4) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
+                                                         uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
+                                                         Table<NW> tbl, Stats *stats)
 {
 	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCnt<NW>::SLOTS;
-	constexpr int CPT = SK_CNT_TPB / SK_CAP2;        // chunks per tile
-	constexpr int NWAVES = SK_CNT_TPB / 64;
+	constexpr int TR = SK_CNT_TILE;                  // records per tile: the first TR lanes bring one each
+	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
+	constexpr int NWAVES = TR / 64;
 	extern __shared__ unsigned long long sm64[];
 	unsigned long long *s_key = sm64;                                    // NW x SLOTS, word-major
-	unsigned long long *s_val = s_key + NW * SLOTS;                      // SLOTS
-	unsigned long long *s_ord = s_val + SLOTS;                           // SLOTS when TRACK
-	unsigned long long *s_h0 = s_ord + (TRACK ? SLOTS : 0);              // SK_CNT_TPB
-	uint32_t *s_pre = (uint32_t *)(s_h0 + SK_CNT_TPB);                   // SK_CNT_TPB + 2
-	uint32_t *s_words = s_pre + SK_CNT_TPB + 2;                          // LDS_LEAD + SK_CNT_TPB * BW * 2 + TAIL_PAD
-	__shared__ uint32_t s_fill, s_wsum[NWAVES];
-	const uint32_t bucket = bucket0 + blockIdx.x;
-	const uint32_t c0 = off2[bucket], c1 = off2[bucket + 1];
-	if (c0 == c1)
-		return;
+	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
+	unsigned long long *s_h0 = s_ord + (TRACK ? SLOTS : 0);              // TR
+	uint32_t *s_cnt = (uint32_t *)(s_h0 + TR);                           // SLOTS
+	uint32_t *s_lk = s_cnt + SLOTS;                                      // 4 x SLOTS
+	uint32_t *s_pre = s_lk + 4 * SLOTS;                                  // TR + 2
+	uint32_t *s_words = s_pre + TR + 2;                                  // LDS_LEAD + TR * BW * 2 + TAIL_PAD
+	__shared__ uint32_t s_fill, s_item, s_wsum[NWAVES];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 		s_key[i] = KEY_EMPTY;
-		s_val[i] = 0;
+		s_cnt[i] = 0;
 		if (TRACK) s_ord[i] = ORD_NONE;
 	}
+	for (int i = tid; i < 4 * SLOTS; i += SK_CNT_TPB)
+		s_lk[i] = 0;
 	if (tid < LDS_LEAD)
 		s_words[tid] = 0;
 	if (tid < TAIL_PAD)
-		s_words[LDS_LEAD + SK_CNT_TPB * BW * 2 + tid] = 0;
+		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
 	if (tid == 0)
 		s_fill = 0;
-	__syncthreads();
-	uint32_t claimed = 0, failed = 0;
+	uint32_t claimed = 0, failed = 0, merges = 0, spills = 0, gens = 0;
 	unsigned long long done = 0;
 	uint32_t *words = s_words + LDS_LEAD;
-	for (uint32_t cb = c0; cb < c1; cb += CPT) {
-		// every lane brings one record into LDS
-		uint32_t n = 0;
-		{
-			const uint32_t ci = cb + (uint32_t)tid / SK_CAP2, slot = (uint32_t)tid % SK_CAP2;
-			uint64_t h0 = 0;
-			if (ci < c1) {
-				const uint32_t chunk = list2[ci];
-				if (slot < (pool.meta[chunk] >> 24)) {
-					const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW);
-					const ulonglong2 hd = s[0];
-					h0 = hd.x;
-					n = (uint32_t)sk_hdr_n(h0);
+#ifdef SDT_SK_TICKS
+	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define SK_TICK(i) do { } while (0)
+#endif
+	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
+	// its own), handed out first come first served
+	for (;;) {
+		if (tid == 0)
+			s_item = item0 + atomicAdd(next_item, 1u);
+		__syncthreads();
+		const uint32_t item = s_item;
+		__syncthreads();
+		if (item >= item1)
+			break;
+		const uint2 it = items[item];
+		const uint32_t c0 = it.x, c1 = it.y;
+		// a lane's record of the NEXT tile waits in registers while the current tile is counted
+		uint64_t nx[RW];
+		bool nx_ok = false;
+		auto fetch = [&](uint32_t cb) {
+			nx_ok = false;
+			if (tid < TR) {
+				const uint32_t ci = cb + (uint32_t)tid / SK_CAP2, slot = (uint32_t)tid % SK_CAP2;
+				if (ci < c1) {
+					const uint32_t chunk = list2[ci];
+					if (slot < (pool.meta[chunk] >> 24)) {
+						const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW);
 #pragma unroll
-					for (int i = 0; i < BW / 2; i++) {
-						const ulonglong2 v = s[1 + i];
-						uint32_t *d = words + tid * BW * 2 + i * 4;
-						d[0] = (uint32_t)(v.x >> 32); d[1] = (uint32_t)v.x;
-						d[2] = (uint32_t)(v.y >> 32); d[3] = (uint32_t)v.y;
+						for (int i = 0; i < RW / 2; i++) {
+							const ulonglong2 v = s[i];
+							nx[2 * i] = v.x;
+							nx[2 * i + 1] = v.y;
+						}
+						nx_ok = true;
 					}
 				}
 			}
-			s_h0[tid] = h0;
-		}
-		// exclusive prefix sum of the k-mers per record
-		uint32_t x = n;
+		};
+		fetch(c0);
+		__syncthreads();                             // the table is clear (start of the kernel / end of the last bucket)
+		SK_TICK(0);
+		for (uint32_t cb = c0; cb < c1; cb += CPT) {
+			// the first TR lanes put their record into LDS and start the loads of the next one
+			uint32_t n = 0;
+			if (tid < TR) {
+				uint64_t h0 = 0;
+				if (nx_ok) {
+					h0 = nx[0];
+					n = (uint32_t)sk_hdr_n(h0);
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t y = __shfl_up(x, d);
-			if ((tid & 63) >= d)
-				x += y;
-		}
-		if ((tid & 63) == 63)
-			s_wsum[tid >> 6] = x;
-		__syncthreads();
-		uint32_t wbase = 0, total = 0;
-#pragma unroll
-		for (int wv = 0; wv < NWAVES; wv++) {
-			const uint32_t v = s_wsum[wv];
-			if (wv < (tid >> 6)) wbase += v;
-			total += v;
-		}
-		s_pre[tid] = wbase + x - n;
-		if (tid == 0)
-			s_pre[SK_CNT_TPB] = total;
-		__syncthreads();
-		for (uint32_t q = tid; q < total; q += SK_CNT_TPB) {
-			int lo = 0, hi = SK_CNT_TPB;
-#pragma unroll
-			for (int st = 0; st < 9; st++) {
-				const int mid = (lo + hi) >> 1;
-				if (s_pre[mid] <= q) lo = mid; else hi = mid;
+					for (int i = 0; i < BW; i++) {
+						words[tid * BW * 2 + 2 * i] = (uint32_t)(nx[2 + i] >> 32);
+						words[tid * BW * 2 + 2 * i + 1] = (uint32_t)nx[2 + i];
+					}
+				}
+				s_h0[tid] = h0;
 			}
-			const int r = lo, j = (int)(q - s_pre[r]);
-			const uint64_t h0 = s_h0[r];
-			const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
-			const int len = hp + nr + K - 1 + sk_hdr_next(h0);
-			uint32_t prev, next;
-			const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-			const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
-			const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
-			if (s >= 0) {
-				if (sk_lds_update(&s_val[s], prev, next)) {
-					if (!table_merge<NW>(tbl, key, 0, 1u, claimed))          // 65536 occurrences: carry into the node's high count
+			if (cb + CPT < c1)
+				fetch(cb + CPT);
+			// exclusive prefix sum of the k-mers per record
+			if (tid < TR) {
+				uint32_t x = n;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t y = __shfl_up(x, d);
+					if ((tid & 63) >= d)
+						x += y;
+				}
+				if ((tid & 63) == 63)
+					s_wsum[tid >> 6] = x;
+				n = x - n;                           // exclusive within the wave
+			}
+			__syncthreads();
+			uint32_t total = 0;
+			{
+				uint32_t wbase = 0;
+#pragma unroll
+				for (int wv = 0; wv < NWAVES; wv++) {
+					const uint32_t v = s_wsum[wv];
+					if (wv < (tid >> 6)) wbase += v;
+					total += v;
+				}
+				if (tid < TR)
+					s_pre[tid] = wbase + n;
+				if (tid == 0)
+					s_pre[TR] = total;
+			}
+			__syncthreads();
+			SK_TICK(1);
+			for (uint32_t q = tid; q < total; q += SK_CNT_TPB) {
+				int lo = 0, hi = TR;
+#pragma unroll
+				for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
+					const int mid = (lo + hi) >> 1;
+					if (s_pre[mid] <= q) lo = mid; else hi = mid;
+				}
+				const int r = lo, j = (int)(q - s_pre[r]);
+				const uint64_t h0 = s_h0[r];
+				const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
+				const int len = hp + nr + K - 1 + sk_hdr_next(h0);
+				uint32_t prev, next;
+				const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
+				const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
+				if (s >= 0) {
+					sk_lds_update(s_cnt, s_lk, s, prev, next);
+					if (TRACK) {
+						const uint64_t ord = (sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j);
+						if (ord < *(volatile unsigned long long *)&s_ord[s])
+							atomicMin(&s_ord[s], (unsigned long long)ord);
+					}
+				} else {
+					spills++;
+					const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
+					if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
 						failed++;
 				}
-				if (TRACK) {
-					if (ord < *(volatile unsigned long long *)&s_ord[s])
-						atomicMin(&s_ord[s], (unsigned long long)ord);
-				}
-			} else if (!table_put<NW>(tbl, key, prev, next, claimed, ord)) {
-				failed++;
 			}
-		}
-		done += tid == 0 ? total : 0;
-		__syncthreads();
-		const bool last = cb + CPT >= c1;
-		if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
-			// merge every LDS node into the node table: one saturating CAS per distinct key
-			for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-				const uint64_t k0 = s_key[i];
-				if (k0 == KEY_EMPTY)
-					continue;
-				Key<NW> key;
-				key.w[0] = k0;
+			done += tid == 0 ? total : 0;
+			__syncthreads();
+			SK_TICK(2);
+			const bool last = cb + CPT >= c1;
+			if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
+				// merge every LDS node into the node table (one saturating CAS per distinct key) and clear it
+				for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+					const uint64_t k0 = s_key[i];
+					if (k0 == KEY_EMPTY)
+						continue;
+					Key<NW> key;
+					key.w[0] = k0;
 #pragma unroll
-				for (int wv = 1; wv < NW; wv++)
-					key.w[wv] = s_key[wv * SLOTS + i];
-				if (!table_merge<NW>(tbl, key, s_val[i], 0u, claimed, TRACK ? (uint64_t)s_ord[i] : ORD_NONE))
-					failed++;
-				if (!last) {
+					for (int wv = 1; wv < NW; wv++)
+						key.w[wv] = s_key[wv * SLOTS + i];
+					merges++;
+					uint32_t hi;
+					const uint64_t add = sk_lds_val(s_cnt[i], &s_lk[4 * i], hi);
+					if (!table_merge<NW>(tbl, key, add, hi, claimed, TRACK ? (uint64_t)s_ord[i] : ORD_NONE))
+						failed++;
 					s_key[i] = KEY_EMPTY;
-					s_val[i] = 0;
+					s_cnt[i] = 0;
+					s_lk[4 * i] = 0; s_lk[4 * i + 1] = 0; s_lk[4 * i + 2] = 0; s_lk[4 * i + 3] = 0;
 					if (TRACK) s_ord[i] = ORD_NONE;
 				}
-			}
-			if (!last) {
 				__syncthreads();
-				if (tid == 0)
+				if (tid == 0) {
 					s_fill = 0;
+					if (!last) gens++;
+				}
 				__syncthreads();
+				SK_TICK(3);
 			}
 		}
 	}
+#undef SK_TICK
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) {
 		claimed += __shfl_down(claimed, d);
 		failed += __shfl_down(failed, d);
+		merges += __shfl_down(merges, d);
+		spills += __shfl_down(spills, d);
 	}
 	if ((tid & 63) == 0) {
 		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
 		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+		if (merges) atomicAdd(&stats->sk_merges, (unsigned long long)merges);
+		if (spills) atomicAdd(&stats->sk_spills, (unsigned long long)spills);
 	}
-	if (tid == 0)
+	if (tid == 0) {
 		atomicAdd(&stats->kmers, done);
+		if (gens) atomicAdd(&stats->sk_gens, (unsigned long long)gens);
+#ifdef SDT_SK_TICKS
+		for (int i = 0; i < 4; i++)
+			atomicAdd(&stats->sk_cyc[i], cyc[i]);
+#endif
+	}
 }

@@ -76,6 +76,13 @@ struct Stats {             // device counters, one cache line each would be nice
 	unsigned long long distinct;   // slots claimed
 	unsigned long long probe_fail; // inserts that ran out of probes (table too full): fatal
 	unsigned long long scratch;    // scan kernels: removed / linear / export cursor
+	// locality pipeline (sdt_superkmer.cuh), for sdt_gpu_stage_times
+	unsigned long long sk_merges;  // LDS nodes merged into the table (one CAS each)
+	unsigned long long sk_spills;  // k-mers that found no LDS slot and took the direct path
+	unsigned long long sk_direct;  // k-mers whose record found no chunk and took the direct path
+	unsigned long long sk_gens;    // flushes of a full LDS table before its bucket was done
+	unsigned long long sk_cyc1[4]; // k_sk_scatter_reads, thread 0 of every workgroup: clock ticks in tile staging / window minima / run starts / emission
+	unsigned long long sk_cyc[4];  // k_sk_count, wave 0 of every workgroup: clock ticks in set-up / tile fill + scan / counting / merging
 };
 
 __device__ inline uint64_t ld_relaxed(const uint64_t *p)
