@@ -43,9 +43,11 @@ enum {
 
 typedef struct sdt_ctx sdt_ctx;
 
-/* sdt_gpu_init flags: pick the pass-1 kernel family (default: DIRECT).  Both give identical tables. */
+/* sdt_gpu_init flags: pick the pass-1 kernel family.  Both give identical tables.  Default (neither flag): the locality
+ * pipeline wherever its geometry applies (reads of K+1 .. ~550 bases, one rank), the direct kernel otherwise. */
 #define SDT_FLAG_DIRECT    1u   /* always one device atomic per k-mer occurrence (k_count_reads) */
-#define SDT_FLAG_PARTITION 2u   /* always partition -> count in LDS -> one merge per distinct key (K <= 31) */
+#define SDT_FLAG_PARTITION 2u   /* locality pipeline (csrc/sdt_superkmer.cuh): minimizer buckets of super-k-mers, counted in LDS,
+                                 * one merge per distinct key and batch */
 /* Track, per node, the ordinal of its first occurrence in the read stream: (read ordinal << 16) | position.
  * The reference's table layout -- hence the visiting order of its cutting passes, the order of *.vertex and the
  * edge ids -- is a function of exactly this order; the host replays it (csrc/host/graph). */

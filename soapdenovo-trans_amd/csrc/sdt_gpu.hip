@@ -593,6 +593,7 @@ static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, u
 }
 
 static int sk_flush(sdt_ctx *c);
+static void sk_free(sdt_ctx *c);
 
 static int sync_stats(sdt_ctx *c)
 {
@@ -621,6 +622,15 @@ static int grow_table(sdt_ctx *c, uint64_t need_nodes)
 	uint32_t *aux = nullptr;
 	uint64_t *first = nullptr;
 	int rc = alloc_table(c, slots, &ent, &aux, &first);
+	if (rc != SDT_OK && c->sk.ready && !c->sk.flushing) {
+		// the locality pipeline's pools are only a cache of work: count what they hold, give the memory back, try again
+		rc = sk_flush(c);
+		if (rc == SDT_OK) {
+			HIPCHK(hipStreamSynchronize(c->stream));
+			sk_free(c);
+			rc = alloc_table(c, slots, &ent, &aux, &first);
+		}
+	}
 	if (rc != SDT_OK)
 		return fail(SDT_EFULL, "cannot grow node table to %llu slots: %s", (unsigned long long)slots, g_err);
 	rc = launch_clear(c, ent, aux, first, slots);
@@ -720,11 +730,11 @@ static SkGeo sk_geo(int K, uint64_t max_read_len)
 	return g;
 }
 
-template <int NW> static size_t sk_count_smem(bool track)
+template <int NW, bool TRACK> static size_t sk_count_smem()
 {
-	constexpr int SLOTS = SkCnt<NW>::SLOTS, BW = SkFmt<NW>::BW;
-	return (size_t)(NW + (track ? 1 : 0)) * SLOTS * 8 + (size_t)SK_CNT_TILE * 8 + (size_t)SLOTS * 20 + (size_t)(SK_CNT_TILE + 2) * 4 +
-	       (size_t)(LDS_LEAD + SK_CNT_TILE * BW * 2 + TAIL_PAD) * 4;
+	constexpr int SLOTS = SkCnt<NW>::SLOTS, BW = SkFmt<NW>::BW, TR = SkCntGeo<NW, TRACK>::TILE;
+	return (size_t)(NW + (TRACK ? 1 : 0)) * SLOTS * 8 + (size_t)TR * 8 + (size_t)SLOTS * 20 + (size_t)(TR + 2) * 4 +
+	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4;
 }
 
 static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
@@ -821,24 +831,24 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	return sk_reset_pool1(c);
 }
 
-template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
 {
 	sdt_ctx::SkState &k = c->sk;
-	const bool track = c->d_first != nullptr;
-	const size_t smem = sk_count_smem<NW>(track);
+	const size_t smem = sk_count_smem<NW, TRACK>();
 	// persistent workgroups: as many as the LDS tables let the chip hold; they take work items first come first served
 	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 256));
 	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
 	if (grid > i1 - i0) grid = i1 - i0;
-	if (track) {
-		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		hipLaunchKernelGGL((k_sk_count<NW, true>), dim3(grid), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1, k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
-	} else {
-		HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		hipLaunchKernelGGL((k_sk_count<NW, false>), dim3(grid), dim3(SK_CNT_TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1, k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
-	}
+	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	hipLaunchKernelGGL((k_sk_count<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1,
+	                   k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
+}
+
+template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+{
+	return c->d_first ? sk_launch_count_t<NW, true>(c, i0, i1, launch) : sk_launch_count_t<NW, false>(c, i0, i1, launch);
 }
 
 // everything scattered so far goes into the node table: seal + list the level-1 chunks, split every level-1 bucket,
@@ -925,9 +935,10 @@ static int sk_flush(sdt_ctx *c)
 				acc = 0;
 			}
 			acc += km;
+			const uint32_t whole = k.h_off2[f + 1] - k.h_off2[f] <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
 			for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
 				const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
-				k.h_citems[nci++] = make_uint2(c0, c1);
+				k.h_citems[nci++] = make_uint2(c0, c1 | whole);    // top bit: the item is its bucket
 			}
 		}
 		launch_kmers.push_back(acc);
@@ -968,6 +979,9 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 	for (uint64_t r0 = 0; r0 < nreads;) {
 		if (k.pending_kmers + per_read * SK_TILE_READS > k.cap_kmers) {
 			rc = sk_flush(c);
+			// a stream that keeps filling the pools gets larger ones: fewer batches = fewer merges per distinct key
+			if (rc == SDT_OK && !k.cap_is_max)
+				rc = sk_alloc(c, k.cap_kmers * 2);
 			if (rc != SDT_OK)
 				return rc;
 		}
@@ -1245,7 +1259,11 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	const uint64_t per_read = max_read_len - c->K + 1;
 	// The locality pipeline is opt-in in round 1: on MI355X it measures 11 G k-mers/s against the direct
 	// kernel's 19.5 G (profiles/r1/partition_pipeline_50M.md has the per-stage rates and what has to change).
-	if ((c->flags & SDT_FLAG_PARTITION) && !(c->flags & SDT_FLAG_DIRECT) && sk_applicable(c, max_read_len)) {
+	// default: the locality pipeline wherever it applies (2.2x the direct kernel on 200 M x 150 bp, K = 31); SDT_FLAG_DIRECT /
+	// SDT_FLAG_PARTITION force one family (the latter still needs a geometry the pipeline can take)
+	// (a small job is not worth the pipeline's fixed cost -- two host syncs and scans over 2^18 buckets, ~3 ms -- unless asked for)
+	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && nreads * per_read < (1ULL << 27);
+	if (!(c->flags & SDT_FLAG_DIRECT) && !sk_small && sk_applicable(c, max_read_len)) {
 		const int rcs = sk_scatter(c, d_words, d_offs, nreads, max_read_len);
 		if (rcs == SDT_OK)
 			c->ord_base += nreads * c->ord_stride;     // the next batch continues the read stream

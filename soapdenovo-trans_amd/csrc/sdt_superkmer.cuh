@@ -59,30 +59,29 @@ __host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 4 : (nw =
 // minimizer length for a k-mer size (window w = K - m + 1 m-mers)
 __host__ __device__ inline int sk_minimizer_len(int K) { return K >= 23 ? 11 : (K >= 17 ? 9 : 7); }
 
-// longest run a record can hold: n + K - 1 bases + 2 context bases must fit the base words
+// longest run a record can hold: n + K - 1 bases + 2 context bases must fit the base words; a power of two
 __host__ __device__ inline int sk_max_run(int K, int nw)
 {
 	const int cap = 32 * (nw == 1 ? 2 : (nw == 2 ? 4 : 6)) - K - 1;
-	return cap < SK_MAX_RUN ? cap : SK_MAX_RUN;
+	int n = SK_MAX_RUN;
+	while (n > cap)
+		n >>= 1;
+	return n;
 }
 
-// order of the canonical m-mers (any fixed bijection-like mixer: which m-mer wins is a layout detail)
+// order of the canonical m-mers (which m-mer wins is a layout detail; one 32-bit multiply: v_mul_lo_u32 is quarter rate)
 __host__ __device__ inline uint32_t sk_mmer_hash(uint32_t canon)
 {
-	uint32_t h = canon * 0x9E3779B1u + 0x7F4A7C15u;
-	h ^= h >> 15; h *= 0x85EBCA77u;
-	h ^= h >> 13; h *= 0xC2B2AE3Du;
-	h ^= h >> 16;
-	return h;
+	uint32_t h = (canon + 0x7F4A7C15u) * 0x9E3779B1u;
+	return h ^ (h >> 15);
 }
 
-// bucket hash of a k-mer = a second mix of its smallest m-mer hash (the minimum itself is biased towards 0)
+// bucket hash of a k-mer = a second mix of its smallest m-mer hash (the minimum itself is biased towards 0); the
+// buckets are its TOP bits
 __host__ __device__ inline uint32_t sk_bucket_hash(uint32_t hvmin)
 {
-	uint32_t h = hvmin ^ 0x5BD1E995u;
-	h *= 0x2C1B3C6Du; h ^= h >> 15;
-	h *= 0x297A2D39u; h ^= h >> 15;
-	return h;
+	uint32_t h = (hvmin ^ 0x5BD1E995u) * 0x85EBCA77u;
+	return h ^ (h >> 13);
 }
 __host__ __device__ inline uint32_t sk_final_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS - SK_L2BITS); }
 __host__ __device__ inline uint32_t sk_l1_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS); }

@@ -2,15 +2,23 @@
 // Included by sdt_gpu.hip after stage_tile / TileView / tile_find_read / chop_record are defined.
 #pragma once
 
-constexpr int SK_CNT_TPB = 1024;                 // k_sk_count: 16 waves, two workgroups per CU when the LDS table allows it
-constexpr int SK_CNT_TILE = 512;                 // records per tile
-constexpr int SK_CNT_TILE_LOG2 = 9;
+// k_sk_count geometry: two workgroups per CU wherever the LDS table allows it (their fill / count / merge phases overlap)
+template <int NW, bool TRACK> struct SkCntGeo {
+	static constexpr bool SMALL = TRACK && NW == 1;                       // + 8 B ordinal per slot: halve the workgroup instead of the table
+	static constexpr int TPB = SMALL ? 512 : 1024;
+	static constexpr int TILE = SMALL ? 256 : 512;                        // records per tile
+	static constexpr int TILE_LOG2 = SMALL ? 8 : 9;
+};
 constexpr int SK_L2_TPB = 256;
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 template <int NW> struct SkCnt {
 	static constexpr int SLOTS = 2048;                           // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
-	static constexpr int MAXFILL = SLOTS * 3 / 4;                // no new key past this load
-	static constexpr int FLUSH_AT = SLOTS / 2;                   // flush + clear between tiles past this load
+#ifndef SDT_SK_FLUSH_AT
+#define SDT_SK_FLUSH_AT 1024
+#define SDT_SK_MAXFILL 2040
+#endif
+	static constexpr int FLUSH_AT = SDT_SK_FLUSH_AT;             // flush + clear between rounds past this load ...
+	static constexpr int MAXFILL = SDT_SK_MAXFILL;               // ... a round counts as many k-mers as there are slots left below this one
 };
 
 // Chunk ids come from the pool in blocks of SK_BLK per workgroup (s_blk = next id | end of block << 32): one global
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 				const int r = tile_find_read(tv.pre, q);
 				const int j = (int)(q - tv.pre[r]);
 				const int p = (int)tv.rb[r] + j;
-				if (j == 0 || j % ncap == 0) {
+				if (j == 0 || (j & (ncap - 1)) == 0) {    // ncap is a power of two
 					start = true;
 				} else if (strips) {
 					start = sk_final_bucket(s_hv[p]) != sk_final_bucket(s_hv[p - 1]);
@@ -462,7 +470,7 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 			continue;                                // the claimer is writing the low words: look again
 		bool same = k0 == key.w[0];
 		if (NW > 1 && same) {
-			__atomic_thread_fence(__ATOMIC_ACQUIRE);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // (a system-scope fence here cost 20x: it invalidates L2)
 #pragma unroll
 			for (int i = 1; i < NW; i++)
 				same = same && (*(volatile unsigned long long *)&s_key[i * SLOTS + s] == key.w[i]);
@@ -509,12 +517,13 @@ __device__ inline uint64_t sk_lds_val(uint32_t cnt, const uint32_t *lk, uint32_t
 
 // (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU)
 template <int NW, bool TRACK>
-__global__ __launch_bounds__(SK_CNT_TPB, (NW == 1 && !TRACK) ? 8 : 4) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
+__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8 : 4) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
                                                          Table<NW> tbl, Stats *stats)
 {
 	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCnt<NW>::SLOTS;
-	constexpr int TR = SK_CNT_TILE;                  // records per tile: the first TR lanes bring one each
+	constexpr int SK_CNT_TPB = SkCntGeo<NW, TRACK>::TPB, SK_CNT_TILE_LOG2 = SkCntGeo<NW, TRACK>::TILE_LOG2;
+	constexpr int TR = SkCntGeo<NW, TRACK>::TILE;    // records per tile: the first TR lanes bring one each
 	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
 	constexpr int NWAVES = TR / 64;
 	extern __shared__ unsigned long long sm64[];
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(SK_CNT_TPB, (NW == 1 && !TRACK) ? 8 : 4) void k_sk_
 	uint32_t *s_lk = s_cnt + SLOTS;                                      // 4 x SLOTS
 	uint32_t *s_pre = s_lk + 4 * SLOTS;                                  // TR + 2
 	uint32_t *s_words = s_pre + TR + 2;                                  // LDS_LEAD + TR * BW * 2 + TAIL_PAD
-	__shared__ uint32_t s_fill, s_item, s_wsum[NWAVES];
+	__shared__ uint32_t s_fill, s_item, s_spilled, s_wsum[NWAVES];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 		s_key[i] = KEY_EMPTY;
@@ -552,15 +561,18 @@ __global__ __launch_bounds__(SK_CNT_TPB, (NW == 1 && !TRACK) ? 8 : 4) void k_sk_
 	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
 	// its own), handed out first come first served
 	for (;;) {
-		if (tid == 0)
+		if (tid == 0) {
 			s_item = item0 + atomicAdd(next_item, 1u);
+			s_spilled = 0;
+		}
 		__syncthreads();
 		const uint32_t item = s_item;
 		__syncthreads();
 		if (item >= item1)
 			break;
 		const uint2 it = items[item];
-		const uint32_t c0 = it.x, c1 = it.y;
+		const uint32_t c0 = it.x, c1 = it.y & 0x7FFFFFFFu;
+		const bool whole = (it.y >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
 		// a lane's record of the NEXT tile waits in registers while the current tile is counted
 		uint64_t nx[RW];
 		bool nx_ok = false;
@@ -634,67 +646,77 @@ __global__ __launch_bounds__(SK_CNT_TPB, (NW == 1 && !TRACK) ? 8 : 4) void k_sk_
 			}
 			__syncthreads();
 			SK_TICK(1);
-			for (uint32_t q = tid; q < total; q += SK_CNT_TPB) {
-				int lo = 0, hi = TR;
+			// rounds of 4 k-mers per free slot: barriers are what this loop pays for, and even error-rich data brings fewer
+			// than one new key per four occurrences (a k-mer that does find the table full takes the direct path)
+			for (uint32_t qb = 0, qe; qb < total; qb = qe) {
+				const uint32_t room = 4u * ((uint32_t)SkCnt<NW>::MAXFILL - s_fill);   // s_fill < FLUSH_AT here (uniform: read after a barrier)
+				qe = qb + room < total ? qb + room : total;
+				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
+					int lo = 0, hi = TR;
 #pragma unroll
-				for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
-					const int mid = (lo + hi) >> 1;
-					if (s_pre[mid] <= q) lo = mid; else hi = mid;
-				}
-				const int r = lo, j = (int)(q - s_pre[r]);
-				const uint64_t h0 = s_h0[r];
-				const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
-				const int len = hp + nr + K - 1 + sk_hdr_next(h0);
-				uint32_t prev, next;
-				const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-				const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
-				if (s >= 0) {
-					sk_lds_update(s_cnt, s_lk, s, prev, next);
-					if (TRACK) {
-						const uint64_t ord = (sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j);
-						if (ord < *(volatile unsigned long long *)&s_ord[s])
-							atomicMin(&s_ord[s], (unsigned long long)ord);
+					for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
+						const int mid = (lo + hi) >> 1;
+						if (s_pre[mid] <= q) lo = mid; else hi = mid;
 					}
-				} else {
-					spills++;
-					const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
-					if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
-						failed++;
+					const int r = lo, j = (int)(q - s_pre[r]);
+					const uint64_t h0 = s_h0[r];
+					const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
+					const int len = hp + nr + K - 1 + sk_hdr_next(h0);
+					uint32_t prev, next;
+					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
+					const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
+					if (s >= 0) {
+						sk_lds_update(s_cnt, s_lk, s, prev, next);
+						if (TRACK) {
+							const uint64_t ord = (sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j);
+							if (ord < *(volatile unsigned long long *)&s_ord[s])
+								atomicMin(&s_ord[s], (unsigned long long)ord);
+						}
+					} else {
+						spills++;
+						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
+						const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
+						if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
+							failed++;
+					}
+				}
+				__syncthreads();
+				const bool last = qe == total && cb + CPT >= c1;
+				if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
+					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
+					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise
+					const bool owned = whole && s_spilled == 0;
+					for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+						const uint64_t k0 = s_key[i];
+						if (k0 == KEY_EMPTY)
+							continue;
+						Key<NW> key;
+						key.w[0] = k0;
+#pragma unroll
+						for (int wv = 1; wv < NW; wv++)
+							key.w[wv] = s_key[wv * SLOTS + i];
+						merges++;
+						uint32_t hi;
+						const uint64_t add = sk_lds_val(s_cnt[i], &s_lk[4 * i], hi);
+						const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
+						if (!(owned ? table_merge_owned<NW>(tbl, key, add, hi, claimed, ord) : table_merge<NW>(tbl, key, add, hi, claimed, ord)))
+							failed++;
+						s_key[i] = KEY_EMPTY;
+						s_cnt[i] = 0;
+						s_lk[4 * i] = 0; s_lk[4 * i + 1] = 0; s_lk[4 * i + 2] = 0; s_lk[4 * i + 3] = 0;
+						if (TRACK) s_ord[i] = ORD_NONE;
+					}
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a later generation of this item reads what was stored here
+					__syncthreads();
+					if (tid == 0) {
+						s_fill = 0;
+						if (!last) gens++;
+					}
+					__syncthreads();
 				}
 			}
 			done += tid == 0 ? total : 0;
-			__syncthreads();
 			SK_TICK(2);
-			const bool last = cb + CPT >= c1;
-			if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
-				// merge every LDS node into the node table (one saturating CAS per distinct key) and clear it
-				for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-					const uint64_t k0 = s_key[i];
-					if (k0 == KEY_EMPTY)
-						continue;
-					Key<NW> key;
-					key.w[0] = k0;
-#pragma unroll
-					for (int wv = 1; wv < NW; wv++)
-						key.w[wv] = s_key[wv * SLOTS + i];
-					merges++;
-					uint32_t hi;
-					const uint64_t add = sk_lds_val(s_cnt[i], &s_lk[4 * i], hi);
-					if (!table_merge<NW>(tbl, key, add, hi, claimed, TRACK ? (uint64_t)s_ord[i] : ORD_NONE))
-						failed++;
-					s_key[i] = KEY_EMPTY;
-					s_cnt[i] = 0;
-					s_lk[4 * i] = 0; s_lk[4 * i + 1] = 0; s_lk[4 * i + 2] = 0; s_lk[4 * i + 3] = 0;
-					if (TRACK) s_ord[i] = ORD_NONE;
-				}
-				__syncthreads();
-				if (tid == 0) {
-					s_fill = 0;
-					if (!last) gens++;
-				}
-				__syncthreads();
-				SK_TICK(3);
-			}
 		}
 	}
 #undef SK_TICK

@@ -273,4 +273,49 @@ __device__ inline bool table_merge(const Table<NW> &t, const Key<NW> &key, uint6
 	return true;
 }
 
+// table_merge for a caller that is the ONLY writer of this key's node during the running kernel (k_sk_count on a
+// bucket that one workgroup counts alone: every occurrence of a key lives in one bucket).  Only the slot claim of a
+// new key races with other writers (other keys, same slot) and stays a CAS; the node itself is read and written
+// with agent-scope (cache-coherent, write-through) loads and stores -- no memory-side atomic per merge.
+template <int NW>
+__device__ inline bool table_merge_owned(const Table<NW> &t, const Key<NW> &key, uint64_t add, uint32_t hi, uint32_t &claimed,
+                                         uint64_t ord = ORD_NONE)
+{
+	uint64_t slot, seen;
+	const uint32_t before = claimed;
+	if (!table_locate<NW>(t, key, claimed, slot, seen))
+		return false;
+	uint64_t *val = &t.ent[slot].val;
+	if (claimed != before) {
+		// the slot was empty a moment ago: k_clear left val = 0, aux = 0, first = none
+		__hip_atomic_store(val, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (hi)
+			__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (t.first && ord != ORD_NONE)
+			__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return true;
+	}
+	seen = ld_relaxed(val);
+	uint64_t nv = 0;
+#pragma unroll
+	for (int f = 0; f < 8; f++) {
+		const uint32_t a = (uint32_t)(seen >> (6 * f)) & 63u, b = (uint32_t)(add >> (6 * f)) & 63u;
+		const uint32_t sum = a + b > 63u ? 63u : a + b;
+		nv |= (uint64_t)sum << (6 * f);
+	}
+	const uint32_t cs = (uint32_t)(seen >> 48) + (uint32_t)(add >> 48);
+	nv |= (uint64_t)(cs & 0xFFFFu) << 48;
+	__hip_atomic_store(val, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint32_t up = hi + (cs >> 16);
+	if (up) {
+		const uint32_t a = __hip_atomic_load(t.aux + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(t.aux + slot, a + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (t.first && ord != ORD_NONE) {
+		if (ord < ld_relaxed(t.first + slot))
+			__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	return true;
+}
+
 } // namespace sdt
