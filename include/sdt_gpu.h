@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 2
+#define SDT_ABI_VERSION 3
 
 enum {
 	SDT_OK       = 0,
@@ -104,9 +104,42 @@ int sdt_gpu_count_reads_device(sdt_ctx *ctx, const void *d_packed_words, uint64_
  * ("nodes allocated" = sum of count_kmerset, :655-662). */
 int sdt_gpu_finish_count(sdt_ctx *ctx, uint64_t *kmers_processed, uint64_t *nodes);
 
-/* ---- multi-GPU: owner-computes sharding -------------------------------------------------------
- * The reference partitions records over threads by hash_kmer % thrd_num (prlHashReads.c:81).  Across
- * GPUs the owner of a canonical k-mer is sdt_owner_of(key) % nranks (a mixed hash: canonical prefixes
+/* ---- multi-GPU, bucket sharding (the product path) ---------------------------------------------------------
+ * The reference partitions records over threads by hash_kmer % thrd_num (prlHashReads.c:79-88).  Across the GPUs of a
+ * node every rank owns a contiguous range of the 256 level-1 minimizer buckets (csrc/sdt_superkmer.cuh): all
+ * occurrences of a canonical k-mer -- either strand, any read -- fall into one bucket, so they meet on one rank.
+ * What travels is the super-k-mer record (~3 B per k-mer occurrence instead of a 16-B (key, meta) record), in
+ * level-1 chunks: one grouped ncclSend / ncclRecv per peer and round over xGMI, on a stream of its own, while the
+ * next round's reads are chopped and the previous round's records are split and counted.
+ *   comm_id / comm_init      one process per GPU; rank 0 makes the id (ncclGetUniqueId) and hands it to the others
+ *   comm_init_shm            same protocol over POSIX shared memory + host staging: validation where several ranks
+ *                            share one GPU (RCCL refuses that), never for a reported number
+ *   count_reads_sharded      COLLECTIVE: every rank calls it with ITS slice of the reads (device buffers as in
+ *                            sdt_gpu_count_reads_device; nreads may be 0).  On return the k-mers of all slices are in
+ *                            the tables of their owners (asynchronously: sdt_gpu_finish_count drains).
+ *   push_reads_sharded       the same for host buffers
+ *   allreduce_i64            COLLECTIVE sum, for counters and the 257 kmerFreq bins (freqStat sums per-thread bins,
+ *                            prlHashReads.c:1004-1014)
+ *   comm_stats               bytes this rank sent / received in exchanges and the time they took on the exchange stream
+ *   sdt_kmer_owner           host copy of the owner function (tests, host graph phases): rank of a canonical k-mer */
+typedef struct { unsigned char bytes[128]; } sdt_comm_id;
+int sdt_gpu_comm_id(sdt_comm_id *id);
+int sdt_gpu_comm_init(sdt_ctx *ctx, const sdt_comm_id *id, int rank, int nranks);
+int sdt_gpu_comm_init_shm(sdt_ctx *ctx, const char *name, int rank, int nranks);
+int sdt_gpu_count_reads_sharded(sdt_ctx *ctx, const void *d_packed_words, uint64_t nwords, const void *d_offsets,
+                                uint64_t nreads, uint64_t max_read_len);
+int sdt_gpu_push_reads_sharded(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
+                               uint64_t nreads);
+int sdt_gpu_allreduce_i64(sdt_ctx *ctx, int64_t *vals, int n);
+int sdt_gpu_comm_stats(sdt_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_recv, double *exchange_ms, uint64_t *exchanges);
+int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks);
+/* host-only self test of the shared-memory transport's control plane (no device needed; the CPU tests run it with
+ * several processes) */
+int sdt_comm_selftest_shm(const char *name, int rank, int nranks, int rounds);
+
+/* ---- multi-GPU, per-k-mer routing (building blocks kept from round 1; the per-k-mer exchange of
+ * soapdenovo-trans_amd/sharding.py) -------------------------------------------------------------
+ * Here the owner of a canonical k-mer is sdt_owner_of(key) % nranks (a mixed hash: canonical prefixes
  * are skewed).  extract_route chops the batch and writes 16-byte records grouped by owner rank into
  * d_records (capacity max_records, split in nranks equal slices), with counts[r] / displs[r] (device
  * uint64[nranks], in records) describing each rank's slice: the send buffer of an all-to-all(v).

@@ -76,6 +76,16 @@ _ABI = [
      [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_stage_times", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)]),
     ("sdt_owner_hash", _c.c_uint64, [_c.c_void_p, _c.c_int]),
+    ("sdt_gpu_comm_id", _c.c_int, [_c.c_void_p]),
+    ("sdt_gpu_comm_init", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    ("sdt_gpu_comm_init_shm", _c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_int, _c.c_int]),
+    ("sdt_gpu_count_reads_sharded", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_push_reads_sharded", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_allreduce_i64", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
+    ("sdt_gpu_comm_stats", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_double),
+                                      _c.POINTER(_c.c_uint64)]),
+    ("sdt_kmer_owner", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
+    ("sdt_comm_selftest_shm", _c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int]),
 ]
 ABI_SYMBOLS = [n for n, _, _ in _ABI]
 
@@ -207,6 +217,36 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_extract_route(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets), nreads,
                                                    max_read_len, nranks, _ptr(d_records), max_records,
                                                    _ptr(d_counts), _ptr(d_displs)))
+
+    # -- multi-GPU, bucket sharding (include/sdt_gpu.h): every method below except kmer_owner is COLLECTIVE
+    def comm_init(self, comm_id: bytes, rank: int, nranks: int):
+        """RCCL communicator; comm_id = new_comm_id() of rank 0, handed to every rank"""
+        buf = ctypes.create_string_buffer(bytes(comm_id), 128)
+        self._check(self.lib.sdt_gpu_comm_init(self._ctx, buf, rank, nranks))
+
+    def comm_init_shm(self, name: str, rank: int, nranks: int):
+        """host shared-memory transport: validation where the ranks share one GPU"""
+        self._check(self.lib.sdt_gpu_comm_init_shm(self._ctx, name.encode(), rank, nranks))
+
+    def count_reads_sharded(self, d_words, nwords: int, d_offsets, nreads: int, max_read_len: int):
+        self._check(self.lib.sdt_gpu_count_reads_sharded(self._ctx, _ptr(d_words) if nreads else None, nwords,
+                                                         _ptr(d_offsets) if nreads else None, nreads, max_read_len))
+
+    def push_reads_sharded(self, words: np.ndarray, offsets: np.ndarray):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_push_reads_sharded(self._ctx, _ptr(words), words.size, _ptr(offsets), offsets.size - 1))
+
+    def allreduce(self, values) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.int64).copy()
+        self._check(self.lib.sdt_gpu_allreduce_i64(self._ctx, _ptr(v), v.size))
+        return v
+
+    def comm_stats(self):
+        """(bytes sent, bytes received, milliseconds on the exchange stream, exchanges) of this rank"""
+        a, b, n, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+        self._check(self.lib.sdt_gpu_comm_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms), ctypes.byref(n)))
+        return a.value, b.value, ms.value, n.value
 
     def set_owner_filter(self, rank: int, nranks: int):
         self._check(self.lib.sdt_gpu_set_owner_filter(self._ctx, rank, nranks))
@@ -366,6 +406,20 @@ class PregraphGPU:
                  "cnt_ticks_fill", "cnt_ticks_count", "cnt_ticks_merge", "sc_ticks_stage", "sc_ticks_minima", "sc_ticks_starts",
                  "sc_ticks_emit")
         return [float(x) for x in ms], dict(zip(names, (int(x) for x in cnt)))
+
+
+def new_comm_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to every rank)"""
+    buf = ctypes.create_string_buffer(128)
+    if load_library().sdt_gpu_comm_id(buf) != SDT_OK:
+        raise SdtError(load_library().sdt_gpu_last_error().decode())
+    return buf.raw
+
+
+def kmer_owner(key_words_msw_first, K: int, nranks: int) -> int:
+    """rank that owns a canonical k-mer under bucket sharding (host copy of the device function)"""
+    a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
+    return load_library().sdt_kmer_owner(a.ctypes.data, K, nranks)
 
 
 def write_kmerfreq(path: str, hist) -> None:

@@ -448,6 +448,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 }
 
 #include "sdt_superkmer_kernels.cuh"
+#include "sdt_comm.cuh"
 #include "sdt_map_kernels.cuh"
 #include "sdt_ctg_kernels.cuh"
 
@@ -513,6 +514,23 @@ struct sdt_ctx {
 		// statistics of the last flush (sdt_gpu_pipeline_stats)
 		uint64_t st_records = 0, st_chunks1 = 0, st_chunks2 = 0, st_flushes = 0;
 	} sk;
+	// multi-GPU (sdt_comm.cuh): communicator + double-buffered send / receive chunk buffers of the exchange
+	Comm comm;
+	struct Shard {
+		uint64_t *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};       // chunk payloads
+		uint32_t *send_meta[2] = {nullptr, nullptr}, *recv_meta[2] = {nullptr, nullptr};
+		uint32_t *iota = nullptr;                                                    // identity chunk list of a receive buffer
+		uint32_t send_chunks = 0, recv_chunks = 0;
+		hipEvent_t ev_gather[2] = {nullptr, nullptr}, ev_xdone[2] = {nullptr, nullptr}, ev_l2[2] = {nullptr, nullptr};
+		bool x_recorded[2] = {false, false}, l2_recorded[2] = {false, false};
+		uint64_t round = 0;
+		// what the last exchange delivered and sk_split has not consumed yet
+		bool pending = false;
+		int pending_slot = 0;
+		uint32_t pending_items = 0;
+		std::vector<SkItem> items;
+		uint64_t kmers_scattered = 0;
+	} sh;
 	// second pass (prlRead2edge): reads kept from pass 1, path words, patch table, arcs
 	struct KeptBatch { uint32_t *d_words; uint64_t *d_offs; uint64_t nwords, nreads, ord_base, ord_stride, maxlen; };
 	std::vector<KeptBatch> kept;
@@ -786,7 +804,9 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 		const uint64_t items = chunks1 / SK_ITEM_CHUNKS + SK_NB1 + 1;
 		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;
-		if (chunks2 >= 0xFFFFFF00ULL || bytes > free_b / 2) {
+		// (a sharded context adds two send and two receive buffers of pool-1 size: shard_alloc)
+		const uint64_t all = c->comm.nranks > 1 ? bytes + chunks1 * SK_CAP1 * rw * 8 * 9 / 2 : bytes;
+		if (chunks2 >= 0xFFFFFF00ULL || all > free_b / 2) {
 			k.cap_is_max = true;
 			if (cap <= (1ULL << 24))
 				return fail(SDT_ENOMEM, "super-k-mer pools: %llu MiB needed for the smallest batch, %zu MiB free",
@@ -851,6 +871,115 @@ template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i
 	return c->d_first ? sk_launch_count_t<NW, true>(c, i0, i1, launch) : sk_launch_count_t<NW, false>(c, i0, i1, launch);
 }
 
+#define SK_CHK(expr)                                                                                   \
+	do {                                                                                               \
+		hipError_t e4_ = (expr);                                                                       \
+		if (e4_ != hipSuccess)                                                                         \
+			return fail(e4_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e4_), __FILE__, __LINE__); \
+	} while (0)
+
+// level 1 done: close the open chunks, list the chunk ids bucket by bucket; h_off1 is valid on return (host sync)
+static int sk_list1(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const int g = c->cu_count * 8;
+	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.blk, k.wgs, k.p1, (uint32_t)SK_CAP1);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
+	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1);
+	SK_CHK(hipGetLastError());
+	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+	SK_CHK(hipStreamSynchronize(c->stream));
+	k.st_chunks1 = k.h_off1[SK_NB1];
+	return SDT_OK;
+}
+
+// level 2: the nitems work items in k.h_items (runs of chunks of `src` named by `list`) are split into pool 2, whose chunks
+// are then listed per final bucket; asynchronous (the lists are read back by sk_count_all).  `after_l2`: recorded once
+// the records have left `src`.
+static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_t nitems, hipEvent_t after_l2)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const int g = c->cu_count * 8;
+	SK_CHK(hipMemsetAsync(k.p2.next, 0, 4, c->stream));
+	SK_CHK(hipMemsetAsync(k.kmers2, 0, SK_NBF * 4, c->stream));
+	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
+	if (nitems) {
+		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
+		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		SK_CHK(hipGetLastError());
+	}
+	if (after_l2)
+		SK_CHK(hipEventRecord(after_l2, c->stream));
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const uint32_t *)k.kmers2, k.kpre2);
+	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p2, k.off2, k.fill2, k.list2);
+	SK_CHK(hipGetLastError());
+	SK_CHK(hipMemcpyAsync(k.h_kpre2, k.kpre2, (SK_NBF + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+	SK_CHK(hipMemcpyAsync(k.h_off2, k.off2, (SK_NBF + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+	return SDT_OK;
+}
+
+// count pool 2 bucket by bucket (host sync first: the chunk lists of sk_split come back)
+static int sk_count_all(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	SK_CHK(hipStreamSynchronize(c->stream));
+	k.st_chunks2 = k.h_off2[SK_NBF];
+	k.st_flushes++;
+	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
+	// k-mers (every one might be a new node: ensure_room)
+	int rc = SDT_OK;
+	uint32_t nci = 0;
+	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
+	std::vector<uint32_t> first_item;                // first item of every launch
+	std::vector<uint64_t> launch_kmers;
+	uint64_t acc = 0;
+	first_item.push_back(0);
+	for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
+		const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
+		if (acc && acc + km > SK_COUNT_KMERS && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
+			launch_kmers.push_back(acc);
+			first_item.push_back(nci);
+			acc = 0;
+		}
+		acc += km;
+		const uint32_t whole = k.h_off2[f + 1] - k.h_off2[f] <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
+		for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
+			const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
+			k.h_citems[nci++] = make_uint2(c0, c1 | whole);    // top bit: the item is its bucket
+		}
+	}
+	launch_kmers.push_back(acc);
+	first_item.push_back(nci);
+	if (nci)
+		SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+	for (size_t l = 0; l + 1 < first_item.size() && rc == SDT_OK; l++) {
+		const uint32_t i0 = first_item[l], i1 = first_item[l + 1];
+		if (i0 == i1)
+			continue;
+		rc = ensure_room(c, launch_kmers[l]);
+		if (rc == SDT_OK)
+			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
+		c->kmers_since_sync += launch_kmers[l];
+	}
+	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
+	return rc;
+}
+
+// work items of level 2 over the chunks [lo, hi) of bucket b in a list: at most SK_ITEM_CHUNKS chunks each
+static int sk_add_items(sdt_ctx::SkState &k, uint32_t &nitems, uint32_t b, uint32_t lo, uint32_t hi)
+{
+	for (uint32_t c0 = lo; c0 < hi; c0 += SK_ITEM_CHUNKS) {
+		if (nitems >= k.items_cap)
+			return fail(SDT_EHIP, "super-k-mer pipeline: item table overflow");
+		k.h_items[nitems++] = SkItem{b, c0, c0 + SK_ITEM_CHUNKS < hi ? c0 + SK_ITEM_CHUNKS : hi, 0};
+	}
+	return SDT_OK;
+}
+
+static int sk_flush_sharded(sdt_ctx *c);
+
 // everything scattered so far goes into the node table: seal + list the level-1 chunks, split every level-1 bucket,
 // list the level-2 chunks, count bucket by bucket
 static int sk_flush(sdt_ctx *c)
@@ -858,6 +987,8 @@ static int sk_flush(sdt_ctx *c)
 	sdt_ctx::SkState &k = c->sk;
 	if (!k.ready || k.pending_kmers == 0 || k.flushing)
 		return SDT_OK;
+	if (c->comm.nranks > 1)
+		return fail(SDT_ESTATE, "sharded context: the pipeline is drained by the collective calls (sdt_gpu_count_reads_sharded)");
 	k.flushing = true;
 	EventPair *ev = next_event(c), *ev2 = next_event(c);
 	if (!ev || !ev2) { k.flushing = false; return fail(SDT_EHIP, "hipEventCreate failed"); }
@@ -865,101 +996,53 @@ static int sk_flush(sdt_ctx *c)
 	ev->kmers = ev2->kmers = 0;
 	ev->stage = SDT_STAGE_SK_SPLIT;
 	ev2->stage = SDT_STAGE_SK_COUNT;
-	int rc = SDT_OK;
-#define SK_CHK(expr)                                                                                   \
-	do {                                                                                               \
-		hipError_t e4_ = (expr);                                                                       \
-		if (e4_ != hipSuccess) {                                                                       \
-			k.flushing = false;                                                                        \
-			return fail(e4_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e4_), __FILE__, __LINE__); \
-		}                                                                                              \
-	} while (0)
-	SK_CHK(hipEventRecord(ev->a, c->stream));
-	const int g = c->cu_count * 8;
-	// level 1: lists
-	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.blk, k.wgs, k.p1, (uint32_t)SK_CAP1);
-	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
-	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1);
-	SK_CHK(hipGetLastError());
-	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-	SK_CHK(hipStreamSynchronize(c->stream));
-	// level 2: work items of at most SK_ITEM_CHUNKS chunks, never across level-1 buckets
+	int rc = hipEventRecord(ev->a, c->stream) == hipSuccess ? SDT_OK : fail(SDT_EHIP, "hipEventRecord failed");
+	if (rc == SDT_OK) rc = sk_list1(c);
 	uint32_t nitems = 0;
-	for (uint32_t b = 0; b < (uint32_t)SK_NB1; b++)
-		for (uint32_t c0 = k.h_off1[b]; c0 < k.h_off1[b + 1]; c0 += SK_ITEM_CHUNKS) {
-			if (nitems >= k.items_cap) { k.flushing = false; return fail(SDT_EHIP, "super-k-mer pipeline: item table overflow"); }
-			const uint32_t c1 = c0 + SK_ITEM_CHUNKS < k.h_off1[b + 1] ? c0 + SK_ITEM_CHUNKS : k.h_off1[b + 1];
-			k.h_items[nitems++] = SkItem{b, c0, c1, 0};
-		}
-	k.st_chunks1 = k.h_off1[SK_NB1];
-	SK_CHK(hipMemsetAsync(k.p2.next, 0, 4, c->stream));
-	SK_CHK(hipMemsetAsync(k.kmers2, 0, SK_NBF * 4, c->stream));
-	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
-	if (nitems) {
-		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
-		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, k.p1, k.list1, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		SK_CHK(hipGetLastError());
-	}
-	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const uint32_t *)k.kmers2, k.kpre2);
-	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p2, k.off2, k.fill2, k.list2);
-	SK_CHK(hipGetLastError());
-	SK_CHK(hipMemcpyAsync(k.h_kpre2, k.kpre2, (SK_NBF + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-	SK_CHK(hipMemcpyAsync(k.h_off2, k.off2, (SK_NBF + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+	for (uint32_t b = 0; b < (uint32_t)SK_NB1 && rc == SDT_OK; b++)
+		rc = sk_add_items(k, nitems, b, k.h_off1[b], k.h_off1[b + 1]);
+	if (rc == SDT_OK) rc = sk_split(c, k.p1, k.list1, nitems, nullptr);
 	// pool 1 is free again: the next batch may scatter while this one is counted (same stream: in order)
-	{
-		const int rcr = sk_reset_pool1(c);
-		if (rcr != SDT_OK) { k.flushing = false; return rcr; }
-	}
-	SK_CHK(hipEventRecord(ev->b, c->stream));
-	SK_CHK(hipEventRecord(ev2->a, c->stream));
-	SK_CHK(hipStreamSynchronize(c->stream));
-	k.st_chunks2 = k.h_off2[SK_NBF];
-	k.st_flushes++;
+	if (rc == SDT_OK) rc = sk_reset_pool1(c);
+	if (rc == SDT_OK && (hipEventRecord(ev->b, c->stream) != hipSuccess || hipEventRecord(ev2->a, c->stream) != hipSuccess))
+		rc = fail(SDT_EHIP, "hipEventRecord failed");
 	k.pending_kmers = 0;
-	// count: work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
-	// k-mers (every one might be a new node: ensure_room)
-	uint32_t nci = 0;
-	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
-	{
-		std::vector<uint32_t> first_item;            // first item of every launch
-		std::vector<uint64_t> launch_kmers;
-		uint64_t acc = 0;
-		first_item.push_back(0);
-		for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
-			const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
-			if (acc && acc + km > SK_COUNT_KMERS && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
-				launch_kmers.push_back(acc);
-				first_item.push_back(nci);
-				acc = 0;
-			}
-			acc += km;
-			const uint32_t whole = k.h_off2[f + 1] - k.h_off2[f] <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
-			for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
-				const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
-				k.h_citems[nci++] = make_uint2(c0, c1 | whole);    // top bit: the item is its bucket
-			}
-		}
-		launch_kmers.push_back(acc);
-		first_item.push_back(nci);
-		if (nci)
-			SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-		for (size_t l = 0; l + 1 < first_item.size() && rc == SDT_OK; l++) {
-			const uint32_t i0 = first_item[l], i1 = first_item[l + 1];
-			if (i0 == i1)
-				continue;
-			rc = ensure_room(c, launch_kmers[l]);
-			if (rc == SDT_OK)
-				rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
-			c->kmers_since_sync += launch_kmers[l];
-		}
-		// the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained
-	}
-	SK_CHK(hipEventRecord(ev2->b, c->stream));
+	if (rc == SDT_OK) rc = sk_count_all(c);
+	if (hipEventRecord(ev2->b, c->stream) != hipSuccess && rc == SDT_OK)
+		rc = fail(SDT_EHIP, "hipEventRecord failed");
 	k.flushing = false;
 	return rc;
-#undef SK_CHK
+}
+
+// one launch of the level-1 scatter over reads [0, nr) of a device-resident batch (ordinals from `ob`)
+static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nr, uint64_t max_read_len, uint64_t ob)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const uint64_t per_read = max_read_len - c->K + 1;
+	const SkGeo geo = sk_geo(c->K, max_read_len);
+	const int m = sk_minimizer_len(c->K), ncap = sk_max_run(c->K, c->nw);
+	const uint64_t ntiles = (nr + SK_TILE_READS - 1) / SK_TILE_READS;
+	const unsigned grid = (unsigned)(ntiles < k.wgs ? ntiles : k.wgs);
+	EventPair *ev = next_event(c);
+	if (!ev)
+		return fail(SDT_EHIP, "hipEventCreate failed");
+	ev->kmers = nr * per_read;
+	ev->stage = SDT_STAGE_SK_SCATTER;
+	HIPCHK(hipEventRecord(ev->a, c->stream));
+#define SK_SCATTER(NW)                                                                                                             \
+	do {                                                                                                                       \
+		HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
+		hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, \
+		                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
+	} while (0)
+	if (c->nw == 1) SK_SCATTER(1);
+	else if (c->nw == 2) SK_SCATTER(2);
+	else SK_SCATTER(4);
+#undef SK_SCATTER
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(ev->b, c->stream));
+	k.pending_kmers += nr * per_read;
+	return SDT_OK;
 }
 
 // chop + scatter a device-resident batch into the level-1 buckets (flushing whenever the pools are full)
@@ -974,8 +1057,6 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		rc = sk_alloc(c, k.pending_kmers + nreads * per_read);
 	if (rc != SDT_OK)
 		return rc;
-	const SkGeo geo = sk_geo(c->K, max_read_len);
-	const int m = sk_minimizer_len(c->K), ncap = sk_max_run(c->K, c->nw);
 	for (uint64_t r0 = 0; r0 < nreads;) {
 		if (k.pending_kmers + per_read * SK_TILE_READS > k.cap_kmers) {
 			rc = sk_flush(c);
@@ -987,29 +1068,221 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		}
 		uint64_t nr = (k.cap_kmers - k.pending_kmers) / per_read / SK_TILE_READS * SK_TILE_READS;
 		if (nr > nreads - r0) nr = nreads - r0;
-		const uint64_t ntiles = (nr + SK_TILE_READS - 1) / SK_TILE_READS;
-		const unsigned grid = (unsigned)(ntiles < k.wgs ? ntiles : k.wgs);
-		EventPair *ev = next_event(c);
-		if (!ev)
-			return fail(SDT_EHIP, "hipEventCreate failed");
-		ev->kmers = nr * per_read;
-		ev->stage = SDT_STAGE_SK_SCATTER;
-		HIPCHK(hipEventRecord(ev->a, c->stream));
-		const uint64_t ob = c->ord_base + r0 * c->ord_stride;
-#define SK_SCATTER(NW)                                                                                                             \
-		do {                                                                                                                       \
-			HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
-			hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs + r0, nr, c->K, m, ncap, \
-			                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
-		} while (0)
-		if (c->nw == 1) SK_SCATTER(1);
-		else if (c->nw == 2) SK_SCATTER(2);
-		else SK_SCATTER(4);
-#undef SK_SCATTER
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipEventRecord(ev->b, c->stream));
-		k.pending_kmers += nr * per_read;
+		rc = sk_scatter_launch(c, d_words, d_offs + r0, nr, max_read_len, c->ord_base + r0 * c->ord_stride);
+		if (rc != SDT_OK)
+			return rc;
 		r0 += nr;
+	}
+	return SDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: ranks own contiguous ranges of the level-1 buckets; level-1 chunks travel to their owner
+// ------------------------------------------------------------------------------------------------
+static void shard_free(sdt_ctx *c)
+{
+	sdt_ctx::Shard &h = c->sh;
+	for (int i = 0; i < 2; i++) {
+		if (h.send[i]) (void)hipFree(h.send[i]);
+		if (h.recv[i]) (void)hipFree(h.recv[i]);
+		if (h.send_meta[i]) (void)hipFree(h.send_meta[i]);
+		if (h.recv_meta[i]) (void)hipFree(h.recv_meta[i]);
+		if (h.ev_gather[i]) (void)hipEventDestroy(h.ev_gather[i]);
+		if (h.ev_xdone[i]) (void)hipEventDestroy(h.ev_xdone[i]);
+		if (h.ev_l2[i]) (void)hipEventDestroy(h.ev_l2[i]);
+	}
+	if (h.iota) (void)hipFree(h.iota);
+	h = sdt_ctx::Shard();
+}
+
+static int shard_alloc(sdt_ctx *c)
+{
+	sdt_ctx::Shard &h = c->sh;
+	sdt_ctx::SkState &k = c->sk;
+	if (h.send[0] && h.send_chunks >= k.p1.chunks)
+		return SDT_OK;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	shard_free(c);
+	const size_t cw = (size_t)SK_CAP1 * sk_rec_words(c->nw) * 8;
+	h.send_chunks = k.p1.chunks;
+	h.recv_chunks = k.p1.chunks + k.p1.chunks / 4;   // a rank receives ~ what it sends; head room for unequal buckets
+	if (getenv("SDT_SHARD_RECV_CHUNKS"))             // (tests: force sub-rounds)
+		h.recv_chunks = (uint32_t)strtoul(getenv("SDT_SHARD_RECV_CHUNKS"), nullptr, 10);
+	for (int i = 0; i < 2; i++) {
+		HIPCHK(hipMalloc((void **)&h.send[i], (size_t)h.send_chunks * cw));
+		HIPCHK(hipMalloc((void **)&h.recv[i], (size_t)h.recv_chunks * cw));
+		HIPCHK(hipMalloc((void **)&h.send_meta[i], (size_t)h.send_chunks * 4));
+		HIPCHK(hipMalloc((void **)&h.recv_meta[i], (size_t)h.recv_chunks * 4));
+		HIPCHK(hipEventCreateWithFlags(&h.ev_gather[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h.ev_xdone[i], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&h.ev_l2[i], hipEventDisableTiming));
+	}
+	HIPCHK(hipMalloc((void **)&h.iota, (size_t)h.recv_chunks * 4));
+	hipLaunchKernelGGL(k_sk_iota, dim3(1024), dim3(256), 0, c->stream, h.iota, h.recv_chunks);
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+// split + count what the last exchange delivered
+static int shard_finish_pending(sdt_ctx *c)
+{
+	sdt_ctx::Shard &h = c->sh;
+	sdt_ctx::SkState &k = c->sk;
+	if (!h.pending)
+		return SDT_OK;
+	h.pending = false;
+	const int slot = h.pending_slot;
+	EventPair *ev = next_event(c), *ev2 = next_event(c);
+	if (!ev || !ev2) return fail(SDT_EHIP, "hipEventCreate failed");
+	ev = ev2 - 1;
+	ev->kmers = ev2->kmers = 0;
+	ev->stage = SDT_STAGE_SK_SPLIT;
+	ev2->stage = SDT_STAGE_SK_COUNT;
+	HIPCHK(hipStreamWaitEvent(c->stream, h.ev_xdone[slot], 0));
+	HIPCHK(hipEventRecord(ev->a, c->stream));
+	if (h.items.size() > k.items_cap)
+		return fail(SDT_EHIP, "super-k-mer pipeline: item table overflow");
+	memcpy(k.h_items, h.items.data(), h.items.size() * sizeof(SkItem));
+	SkPool src = {h.recv[slot], h.recv_meta[slot], nullptr, h.recv_chunks};
+	int rc = sk_split(c, src, h.iota, (uint32_t)h.items.size(), h.ev_l2[slot]);
+	h.l2_recorded[slot] = true;
+	if (rc != SDT_OK) return rc;
+	HIPCHK(hipEventRecord(ev->b, c->stream));
+	HIPCHK(hipEventRecord(ev2->a, c->stream));
+	rc = sk_count_all(c);
+	HIPCHK(hipEventRecord(ev2->b, c->stream));
+	return rc;
+}
+
+// COLLECTIVE.  Level-1 chunks scattered since the last call go to the ranks that own their buckets; what the previous
+// call's exchange delivered is split and counted meanwhile.  Sub-rounds when a rank would receive more than its buffer holds.
+static int sk_flush_sharded(sdt_ctx *c)
+{
+	sdt_ctx::Shard &h = c->sh;
+	sdt_ctx::SkState &k = c->sk;
+	Comm &cm = c->comm;
+	const int n = cm.nranks, me = cm.rank;
+	int rc = sk_list1(c);
+	if (rc != SDT_OK) return rc;
+	// everybody's chunk counts per bucket
+	std::vector<uint32_t> mat((size_t)n * (SK_NB1 + 1));
+	rc = cm.allgather_host(k.h_off1, mat.data(), (SK_NB1 + 1) * sizeof(uint32_t));
+	if (rc != SDT_OK) return rc;
+	auto M = [&](int r, uint32_t b) { return mat[(size_t)r * (SK_NB1 + 1) + b]; };
+	std::vector<uint32_t> blo(n + 1);
+	for (int r = 0; r < n; r++) blo[r] = sk_first_bucket(r, n);
+	blo[n] = SK_NB1;
+	// sub-rounds: every rank can see every rank's inflow, so all agree without another message
+	uint32_t S = 1;
+	for (int d = 0; d < n; d++) {
+		uint64_t in = 0;
+		for (int s2 = 0; s2 < n; s2++) in += M(s2, blo[d + 1]) - M(s2, blo[d]);
+		const uint32_t need = (uint32_t)((in + h.recv_chunks - 1) / h.recv_chunks);
+		if (need > S) S = need;
+	}
+	if (S > 1) S += 1;                               // pieces are cut by source, not by size: leave slack
+	const size_t cw = (size_t)SK_CAP1 * sk_rec_words(c->nw) * 8;
+	for (uint32_t t = 0; t < S; t++) {
+		const int slot = (int)(h.round & 1);
+		// piece of (source s -> destination d) in sub-round t, as a range of s's chunk list
+		auto piece = [&](int s2, int d, uint32_t &lo, uint32_t &hi) {
+			const uint64_t a = M(s2, blo[d]), b = M(s2, blo[d + 1]);
+			lo = (uint32_t)(a + (b - a) * t / S);
+			hi = (uint32_t)(a + (b - a) * (t + 1) / S);
+		};
+		SkGatherPlan plan;
+		memset(&plan, 0, sizeof plan);
+		plan.n = n;
+		plan.self = me;
+		std::vector<void *> sp(n), rp(n), smp(n), rmp(n);
+		std::vector<size_t> sb(n, 0), rb(n, 0), smb(n, 0), rmb(n, 0), oboff((size_t)n * n, 0), obmoff((size_t)n * n, 0);
+		uint32_t send_at = 0, recv_at = 0;
+		std::vector<SkItem> cur;                     // level-2 work items of THIS exchange (h.items still describes the last one)
+		for (int p = 0; p < n; p++) {
+			uint32_t lo, hi;
+			piece(me, p, lo, hi);
+			plan.begin[p] = lo;
+			plan.pre[p + 1] = plan.pre[p] + (hi - lo);
+			if (p != me) {
+				plan.dst0[p] = send_at;
+				sp[p] = (uint8_t *)h.send[slot] + (size_t)send_at * cw;
+				smp[p] = h.send_meta[slot] + send_at;
+				sb[p] = (size_t)(hi - lo) * cw;
+				smb[p] = (size_t)(hi - lo) * 4;
+				send_at += hi - lo;
+			}
+		}
+		for (int s2 = 0; s2 < n; s2++) {             // receive buffer: one run per source, rank order (mine included)
+			uint32_t lo, hi;
+			piece(s2, me, lo, hi);
+			if (s2 == me) plan.dst0[me] = recv_at;
+			rp[s2] = (uint8_t *)h.recv[slot] + (size_t)recv_at * cw;
+			rmp[s2] = h.recv_meta[slot] + recv_at;
+			rb[s2] = (size_t)(hi - lo) * cw;
+			rmb[s2] = (size_t)(hi - lo) * 4;
+			// level-2 work items over this run: its chunks are in bucket order
+			for (uint32_t b = blo[me]; b < blo[me + 1] && rc == SDT_OK; b++) {
+				const uint32_t x0 = M(s2, b) > lo ? M(s2, b) : lo, x1 = M(s2, b + 1) < hi ? M(s2, b + 1) : hi;
+				for (uint32_t c0 = recv_at + (x0 - lo); x1 > x0 && c0 < recv_at + (x1 - lo); c0 += SK_ITEM_CHUNKS) {
+					const uint32_t c1 = c0 + SK_ITEM_CHUNKS < recv_at + (x1 - lo) ? c0 + SK_ITEM_CHUNKS : recv_at + (x1 - lo);
+					cur.push_back(SkItem{b, c0, c1, 0});
+				}
+			}
+			recv_at += hi - lo;
+		}
+		if (send_at > h.send_chunks || recv_at > h.recv_chunks)
+			return fail(SDT_EFULL, "exchange buffers too small: %u / %u chunks to send, %u / %u to receive", send_at, h.send_chunks, recv_at, h.recv_chunks);
+		// outbox layout of every rank (shared-memory transport): destinations in rank order
+		if (cm.kind == 2)
+			for (int s2 = 0; s2 < n; s2++) {
+				size_t at = 0, mat_at = 0;
+				for (int d = 0; d < n; d++) {
+					if (d == s2) continue;
+					uint32_t lo, hi;
+					piece(s2, d, lo, hi);
+					oboff[(size_t)s2 * n + d] = at;
+					at += (size_t)(hi - lo) * cw;
+				}
+				for (int d = 0; d < n; d++) {
+					if (d == s2) continue;
+					uint32_t lo, hi;
+					piece(s2, d, lo, hi);
+					obmoff[(size_t)s2 * n + d] = at + mat_at;      // metas behind all payloads
+					mat_at += (size_t)(hi - lo) * 4;
+				}
+			}
+		// G: the send buffer of this slot must have left (exchange of two rounds ago)
+		if (h.x_recorded[slot])
+			HIPCHK(hipStreamWaitEvent(c->stream, h.ev_xdone[slot], 0));
+		if (plan.pre[n]) {
+			const unsigned g = (unsigned)c->cu_count * 8;
+			if (c->nw == 1) hipLaunchKernelGGL(k_sk_gather<4>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_sk_gather<6>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			else hipLaunchKernelGGL(k_sk_gather<8>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			HIPCHK(hipGetLastError());
+		}
+		HIPCHK(hipEventRecord(h.ev_gather[slot], c->stream));
+		if (t + 1 == S) {                            // pool 1 is free: the next round may scatter while this one travels
+			rc = sk_reset_pool1(c);
+			if (rc != SDT_OK) return rc;
+		}
+		// X: on the exchange stream, after the gather and after level 2 has drained this slot's receive buffer
+		HIPCHK(hipStreamWaitEvent(cm.xstream, h.ev_gather[slot], 0));
+		if (h.l2_recorded[slot])
+			HIPCHK(hipStreamWaitEvent(cm.xstream, h.ev_l2[slot], 0));
+		rc = cm.exchange(sp.data(), sb.data(), rp.data(), rb.data(), oboff.data());
+		if (rc == SDT_OK)
+			rc = cm.exchange(smp.data(), smb.data(), rmp.data(), rmb.data(), obmoff.data());
+		if (rc != SDT_OK) return rc;
+		HIPCHK(hipEventRecord(h.ev_xdone[slot], cm.xstream));
+		h.x_recorded[slot] = true;
+		// B: meanwhile, split + count what the previous exchange brought
+		rc = shard_finish_pending(c);
+		if (rc != SDT_OK) return rc;
+		h.items.swap(cur);
+		h.pending = true;
+		h.pending_slot = slot;
+		h.round++;
 	}
 	return SDT_OK;
 }
@@ -1159,6 +1432,8 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_hit_cursor) (void)hipFree(c->d_hit_cursor);
 	for (int i = 0; i < 5; i++) if (c->ab[i]) (void)hipFree(c->ab[i]);
 	sk_free(c);
+	shard_free(c);
+	c->comm.close_all();
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	delete c;
@@ -2195,6 +2470,220 @@ int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, u
 	if (reset)
 		c->ev_used = 0;
 	return SDT_OK;
+}
+
+// ---- multi-GPU ----------------------------------------------------------------------------------------------
+int sdt_gpu_comm_id(sdt_comm_id *id)
+{
+	if (!id)
+		return fail(SDT_EINVAL, "NULL argument");
+	int rc = rccl_load();
+	if (rc != SDT_OK)
+		return rc;
+	static_assert(sizeof(sdt_comm_id) == sizeof(NcclId), "ncclUniqueId is 128 bytes");
+	NCCLCHK(g_rccl.GetUniqueId((NcclId *)id));
+	return SDT_OK;
+}
+
+int sdt_gpu_comm_init(sdt_ctx *c, const sdt_comm_id *id, int rank, int nranks)
+{
+	if (!c || !id || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks)
+		return fail(SDT_EINVAL, "bad argument (1..64 ranks)");
+	if (c->comm.kind)
+		return fail(SDT_ESTATE, "the context already has a communicator");
+	HIPCHK(hipSetDevice(c->device));
+	return c->comm.open_rccl((const NcclId *)id, rank, nranks);
+}
+
+int sdt_gpu_comm_init_shm(sdt_ctx *c, const char *name, int rank, int nranks)
+{
+	if (!c || !name || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks)
+		return fail(SDT_EINVAL, "bad argument (1..64 ranks)");
+	if (c->comm.kind)
+		return fail(SDT_ESTATE, "the context already has a communicator");
+	HIPCHK(hipSetDevice(c->device));
+	return c->comm.open_shm(name, rank, nranks, true);
+}
+
+int sdt_comm_selftest_shm(const char *name, int rank, int nranks, int rounds)
+{
+	// host-only exercise of the shared-memory transport's control plane (no device): what the CPU tests run with
+	// several processes -- all-gather, all-reduce and barriers must agree on every rank, round after round
+	Comm cm;
+	int rc = cm.open_shm(name, rank, nranks, false);
+	if (rc != SDT_OK)
+		return rc;
+	for (int it = 0; it < rounds && rc == SDT_OK; it++) {
+		std::vector<uint32_t> mine(257), all((size_t)257 * nranks);
+		for (int i = 0; i < 257; i++) mine[i] = (uint32_t)(rank * 1000003 + it * 7919 + i);
+		rc = cm.allgather_host(mine.data(), all.data(), 257 * sizeof(uint32_t));
+		for (int r = 0; r < nranks && rc == SDT_OK; r++)
+			for (int i = 0; i < 257; i++)
+				if (all[(size_t)r * 257 + i] != (uint32_t)(r * 1000003 + it * 7919 + i))
+					rc = fail(SDT_EHIP, "all-gather: rank %d got a wrong word from rank %d in round %d", rank, r, it);
+		int64_t v[3] = {rank + 1, it, (int64_t)1 << 40};
+		if (rc == SDT_OK) rc = cm.allreduce_sum_host(v, 3);
+		if (rc == SDT_OK && (v[0] != (int64_t)nranks * (nranks + 1) / 2 || v[1] != (int64_t)it * nranks || v[2] != ((int64_t)nranks << 40)))
+			rc = fail(SDT_EHIP, "all-reduce: rank %d got wrong sums in round %d", rank, it);
+	}
+	cm.close_all();
+	return rc;
+}
+
+int sdt_gpu_allreduce_i64(sdt_ctx *c, int64_t *vals, int n)
+{
+	if (!c || !vals || n < 0 || (size_t)n * sizeof(int64_t) > SHM_CTRL_BYTES)
+		return fail(SDT_EINVAL, "bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	return c->comm.allreduce_sum_host(vals, n);
+}
+
+int sdt_gpu_comm_stats(sdt_ctx *c, uint64_t *bytes_sent, uint64_t *bytes_recv, double *exchange_ms, uint64_t *exchanges)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	if (c->comm.xstream)
+		HIPCHK(hipStreamSynchronize(c->comm.xstream));
+	c->comm.harvest_time();
+	if (bytes_sent) *bytes_sent = c->comm.bytes_sent;
+	if (bytes_recv) *bytes_recv = c->comm.bytes_recv;
+	if (exchange_ms) *exchange_ms = c->comm.exchange_ms;
+	if (exchanges) *exchanges = c->comm.exchanges;
+	return SDT_OK;
+}
+
+int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
+{
+	// the rank whose table holds a canonical k-mer under bucket sharding: minimizer -> bucket -> owner, as on the device
+	if (!key_words_msw_first || K < 13 || K > 127 || nranks < 1)
+		return -1;
+	const int nw = K <= 31 ? 1 : (K <= 63 ? 2 : 4), m = sk_minimizer_len(K);
+	uint32_t best = 0xFFFFFFFFu;
+	for (int p = 0; p + m <= K; p++) {
+		uint32_t fw = 0;
+		for (int i = 0; i < m; i++) {
+			const int bit = 2 * (K - 1 - (p + i));       // base p + i of the k-mer, counted from its low end
+			const uint64_t w = key_words_msw_first[nw - 1 - bit / 64];
+			fw = (fw << 2) | (uint32_t)((w >> (bit % 64)) & 3u);
+		}
+		const uint32_t hv = sk_mmer_hash(sk_canon_mmer(fw, m));
+		if (hv < best) best = hv;
+	}
+	return sk_owner_of_bucket(sk_l1_bucket(sk_bucket_hash(best)), nranks);
+}
+
+int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets, uint64_t nreads,
+                                uint64_t max_read_len)
+{
+	(void)nwords;
+	if (!c || (nreads && (!d_packed_words || !d_offsets)))
+		return fail(SDT_EINVAL, "NULL argument");
+	if (c->comm.kind == 0 || c->comm.nranks == 1) {
+		if (nreads == 0)
+			return SDT_OK;
+		return sdt_gpu_count_reads_device(c, d_packed_words, nwords, d_offsets, nreads, max_read_len);
+	}
+	HIPCHK(hipSetDevice(c->device));
+	Comm &cm = c->comm;
+	sdt_ctx::SkState &k = c->sk;
+	// agree on the geometry of the call: the longest read anywhere, the rank with the most reads
+	std::vector<uint64_t> all((size_t)2 * cm.nranks);
+	uint64_t mine[2] = {nreads, nreads ? max_read_len : 0};
+	int rc = cm.allgather_host(mine, all.data(), sizeof mine);
+	if (rc != SDT_OK) return rc;
+	uint64_t maxlen = 0, maxreads = 0;
+	for (int r = 0; r < cm.nranks; r++) {
+		if (all[2 * r] > maxreads) maxreads = all[2 * r];
+		if (all[2 * r + 1] > maxlen) maxlen = all[2 * r + 1];
+	}
+	if (maxreads == 0 || maxlen < (uint64_t)c->K + 1) {
+		c->ord_base += nreads * c->ord_stride;
+		return SDT_OK;
+	}
+	if (maxlen > 65535 || sk_geo(c->K, maxlen).smem > 160 * 1024)
+		return fail(SDT_EINVAL, "reads of %llu bases do not fit the LDS tile of the sharded path", (unsigned long long)maxlen);
+	const uint64_t per_read = maxlen - c->K + 1;
+	uint64_t want = maxreads * per_read;
+	if (want > (1ULL << 31)) want = 1ULL << 31;       // rounds of at most 2 G k-mers per rank: the exchange overlaps the next round
+	if (getenv("SDT_SHARD_ROUND_KMERS"))             // (tests: many small rounds)
+		want = strtoull(getenv("SDT_SHARD_ROUND_KMERS"), nullptr, 10);
+	if (!k.ready || k.cap_kmers < want) {
+		if (k.ready && !k.cap_is_max) { HIPCHK(hipStreamSynchronize(c->stream)); sk_free(c); }
+		rc = sk_alloc(c, want);
+		if (rc != SDT_OK) return rc;
+	}
+	rc = shard_alloc(c);
+	if (rc != SDT_OK) return rc;
+	// every rank must cut its reads into the same number of rounds
+	uint64_t capmine = k.cap_kmers;
+	std::vector<uint64_t> caps(cm.nranks);
+	rc = cm.allgather_host(&capmine, caps.data(), sizeof capmine);
+	if (rc != SDT_OK) return rc;
+	uint64_t cap = caps[0];
+	for (int r = 1; r < cm.nranks; r++) if (caps[r] < cap) cap = caps[r];
+	if (getenv("SDT_SHARD_ROUND_KMERS") && cap > want) cap = want;
+	uint64_t per_round = cap / per_read / SK_TILE_READS * SK_TILE_READS;
+	if (per_round < (uint64_t)SK_TILE_READS) per_round = SK_TILE_READS;
+	const uint64_t rounds = (maxreads + per_round - 1) / per_round;
+	for (uint64_t i = 0; i < rounds; i++) {
+		const uint64_t r0 = i * per_round;
+		const uint64_t nr = r0 < nreads ? (nreads - r0 < per_round ? nreads - r0 : per_round) : 0;
+		if (nr) {
+			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets + r0, nr, maxlen, c->ord_base + r0 * c->ord_stride);
+			if (rc != SDT_OK) return rc;
+			c->sh.kmers_scattered += nr * per_read;
+		}
+		k.flushing = true;                           // sync_stats must not try to drain the pipeline on its own in here
+		rc = sk_flush_sharded(c);
+		k.flushing = false;
+		if (rc != SDT_OK) return rc;
+	}
+	k.flushing = true;
+	rc = shard_finish_pending(c);
+	k.flushing = false;
+	c->ord_base += nreads * c->ord_stride;
+	return rc;
+}
+
+int sdt_gpu_push_reads_sharded(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads)
+{
+	if (!c || (nreads && (!packed_words || !offsets)))
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t maxlen = 0;
+	for (uint64_t i = 0; i < nreads; i++) {
+		if (offsets[i + 1] < offsets[i])
+			return fail(SDT_EINVAL, "offsets not monotonic at read %llu", (unsigned long long)i);
+		if (offsets[i + 1] - offsets[i] > maxlen) maxlen = offsets[i + 1] - offsets[i];
+	}
+	if (nreads && ((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
+		return fail(SDT_EINVAL, "packed_words too short");
+	// staging buffers of the single-rank path (slot 0); the call is synchronous with respect to them
+	uint32_t *dw = nullptr;
+	uint64_t *dof = nullptr;
+	if (nreads) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (c->cap_words[0] < nwords) {
+			if (c->d_words[0]) HIPCHK(hipFree(c->d_words[0]));
+			c->d_words[0] = nullptr; c->cap_words[0] = 0;
+			HIPCHK(hipMalloc((void **)&c->d_words[0], nwords * sizeof(uint32_t)));
+			c->cap_words[0] = nwords;
+		}
+		if (c->cap_offs[0] < nreads + 1) {
+			if (c->d_offs[0]) HIPCHK(hipFree(c->d_offs[0]));
+			c->d_offs[0] = nullptr; c->cap_offs[0] = 0;
+			HIPCHK(hipMalloc((void **)&c->d_offs[0], (nreads + 1) * sizeof(uint64_t)));
+			c->cap_offs[0] = nreads + 1;
+		}
+		dw = c->d_words[0]; dof = c->d_offs[0];
+		HIPCHK(hipMemcpyAsync(dw, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(dof, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+	}
+	const int rc = sdt_gpu_count_reads_sharded(c, dw, nwords, dof, nreads, maxlen);
+	if (rc == SDT_OK)
+		HIPCHK(hipStreamSynchronize(c->stream));     // the staging buffers may be overwritten by the next call
+	return rc;
 }
 
 int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS])

@@ -425,6 +425,42 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+// ---- exchange: pack the level-1 chunks of every destination rank's buckets into one contiguous run ------------------
+struct SkGatherPlan {
+	uint32_t begin[64];          // first position in the chunk list of the piece that goes to rank p
+	uint32_t pre[65];            // exclusive prefix of the piece lengths
+	uint32_t dst0[64];           // first chunk of the piece in its destination buffer
+	int n, self;                 // ranks; the piece of rank `self` goes straight into the receive buffer
+};
+
+template <int RW>
+__global__ __launch_bounds__(256) void k_sk_gather(SkPool pool, const uint32_t *__restrict__ list, SkGatherPlan plan,
+                                                   uint64_t *__restrict__ send, uint32_t *__restrict__ send_meta,
+                                                   uint64_t *__restrict__ recv, uint32_t *__restrict__ recv_meta)
+{
+	constexpr uint32_t CW = SK_CAP1 * RW;            // 64-bit words per chunk
+	const uint32_t total = plan.pre[plan.n], lane = threadIdx.x & 63u;
+	for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < total; g += gridDim.x * 4u) {
+		int p = 0;
+		while (p + 1 < plan.n && plan.pre[p + 1] <= g)
+			p++;
+		const uint32_t i = g - plan.pre[p];
+		const uint32_t chunk = list[plan.begin[p] + i], out = plan.dst0[p] + i;
+		const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(pool.recs + (size_t)chunk * CW);
+		ulonglong2 *d = reinterpret_cast<ulonglong2 *>((p == plan.self ? recv : send) + (size_t)out * CW);
+		for (uint32_t w = lane; w < CW / 2; w += 64u)
+			d[w] = s[w];
+		if (lane == 0)
+			(p == plan.self ? recv_meta : send_meta)[out] = pool.meta[chunk];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sk_iota(uint32_t *p, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+		p[i] = i;
+}
+
 // ---- count: persistent workgroups, one final bucket at a time ---------------------------------------------------
 // LDS node = key word(s) + 32-bit count + 8 link counters of 16 bits (two per 32-bit word), not the node table's
 // packed val: LDS adds must not need a CAS loop -- the records of a bucket are windows around ONE minimizer, so
