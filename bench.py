@@ -2,7 +2,8 @@
 """bench.py -- pregraph k-mers hashed per second on MI355X (BASELINE.json metric).
 
 A step = one full pass of the hot path over the workload: reset the node table, chop + insert/count every
-read (sdt_gpu_count_reads_device; N>1: extract_route -> RCCL all-to-all -> insert_records), drain,
+read (sdt_gpu_count_reads_device; N>1: sdt_gpu_count_reads_sharded = chop + minimizer buckets -> super-k-mer chunks to
+the ranks that own their buckets by grouped ncclSend/ncclRecv over xGMI -> split + count in LDS), drain,
 then the linear-mark + kmerFreq scan.  Inputs (packed 2-bit reads) are resident in HBM before the timed
 region.  value = k-mer occurrences of the WHOLE job / wall time of the step (max over ranks).
 
@@ -11,8 +12,9 @@ scaling: the same 200 M reads are split over the N ranks.  --reads/--read-len/--
 (configs[1] = --reads 50000000).
 
 One JSON line on rank 0.  roofline.achieved uses SURVEY.md 8(d)'s algorithmic bytes per k-mer occurrence,
-B = 0.25*L/(L-K+1) + 2*E (E = 24/32/48 B reference node), times the k-mers of the chop+insert launches,
-divided by their HIP-event time on the library's stream (sdt_gpu_kernel_time).
+B = 0.25*L/(L-K+1) + 2*E (E = 24/32/48 B reference node), times the k-mers of pass 1, divided by the HIP-event
+time of pass 1's kernels on the library's stream (sdt_gpu_kernel_time; the locality pipeline is three kernels --
+scatter, split, count -- every k-mer goes through all of them, so their times add).
 """
 from __future__ import annotations
 
@@ -39,25 +41,30 @@ def algorithmic_bytes_per_kmer(L, K):
     return 0.25 * L / (L - K + 1) + 2 * E
 
 
-def pmc_traffic_per_kmer(K, kernel="k_count_reads"):
-    """HBM bytes per k-mer of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE are collected in separate rocprofv3 --pmc runs, tools/pmc_summary.py; they cannot be read live).
-    Only a profile taken with the same key width (file name ..._k<K>.json) counts.
-    Returns (bytes per k-mer, source file) or (None, None)."""
+def kernel_source_id():
+    """hash of the device sources: a PMC profile only counts for the kernels it was taken with"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "soapdenovo-trans_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".cuh", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_per_kmer(K, L, reads):
+    """HBM bytes per k-mer of pass 1 from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 --pmc runs of THIS bench, tools/pmc_pipeline.sh; they cannot be read live).  Only a
+    profile of the same workload taken with the same device sources counts.  Returns (bytes per k-mer, file) or (None, None)."""
     import glob
-    import re
-    words = lambda k: 1 if k <= 31 else (2 if k <= 63 else 4)
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_{kernel}*.json"))):
-        m = re.search(r"_k(\d+)\.json$", f)
-        if not m or words(int(m.group(1))) != words(K):
-            continue
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_pass1_*.json")), reverse=True):
         try:
             j = json.load(open(f))
-            best = (j["hbm_bytes"]["per_kmer"], os.path.relpath(f, ROOT))
+            if (j["K"], j["read_len"], j["reads"]) == (K, L, reads) and j.get("kernel_source_id") == kernel_source_id():
+                return j["hbm_bytes_per_kmer"], os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return best or (None, None)
+    return None, None
 
 
 def usable_cpus():
@@ -156,17 +163,21 @@ def main():
     ap.add_argument("--sigma", type=float, default=2.0, help="log-normal sigma of the expression weights (SURVEY C5: 2.5)")
     ap.add_argument("--d", type=int, default=0, help="-d: also run the low-coverage filter (k_delow) in every step")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (N>1)")
     ap.add_argument("--est-distinct", type=int, default=0)
-    ap.add_argument("--shard-mode", choices=["filter", "route"], default="filter",
-                    help="N>1: 'filter' = every rank holds all reads and inserts only the k-mers it owns (no exchange); "
-                         "'route' = reads are split and records travel in an RCCL all-to-all")
     ap.add_argument("--pipeline", choices=["auto", "direct", "superkmer"], default="auto",
                     help="pass-1 kernel family: 'direct' = one device atomic per occurrence (k_count_reads); 'superkmer' = "
                          "minimizer buckets of super-k-mers counted in LDS (k_sk_*); 'auto' = the library's default")
     ap.add_argument("--track-first", action="store_true", help="SDT_FLAG_TRACK_FIRST: what the five-file pipeline runs with")
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="run the N>1 code path (extract_route -> all-to-all -> insert_records) even with one rank")
+    ap.add_argument("--extras", type=int, default=1, help="N=1: also time the TRACK_FIRST configuration and the PCIe-inclusive "
+                                                          "rate through sdt_gpu_push_reads (0 = skip)")
+    ap.add_argument("--shard-mode", choices=["bucket", "filter", "route"], default="bucket",
+                    help="N>1: 'bucket' = the C-level product path (reads split, super-k-mer chunks to the owners of their "
+                         "minimizer buckets over RCCL); 'filter' / 'route' = round 1's Python plumbing (A/B only)")
+    ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (--shard-mode route)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank")
+    ap.add_argument("--slice-of-whole", action="store_true",
+                    help="validation: every rank generates the WHOLE single-rank workload and keeps its slice, so that N ranks "
+                         "count exactly the reads one rank would (default: rank r draws its own reads with seed 42 + 1000 r)")
     args = ap.parse_args()
 
     import torch
@@ -177,26 +188,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
     sharded_path = world > 1 or args.force_sharded
+    share = os.environ.get("SDT_BENCH_SHARE_DEVICE") == "1"
     if sharded_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # SDT_BENCH_SHARE_DEVICE=1 (validation only, never for a reported number): all ranks on cuda:0 with a gloo
-        # control plane, so that the N>1 code path can be exercised on a 1-GPU box (RCCL refuses two ranks per device)
-        share = os.environ.get("SDT_BENCH_SHARE_DEVICE") == "1"
+        # SDT_BENCH_SHARE_DEVICE=1 (validation only, never for a reported number): all ranks on cuda:0, so that the N>1
+        # code path can be exercised on a 1-GPU box (RCCL refuses two ranks per device: shared-memory transport)
         if share:
             local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
+        torch.cuda.set_device(local_rank)
+        if args.shard_mode == "bucket" or share:
+            dist.init_process_group("gloo")          # control plane only (communicator id, barrier, max time): the data path is the library's own RCCL
         else:
-            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -207,53 +217,82 @@ def main():
 
     K, L = pkg.clamp_K(args.K), args.read_len
     n_total = args.reads
-    route = args.shard_mode == "route"
-    if sharded_path and not route:
+    mode = args.shard_mode if sharded_path else "single"
+    if mode == "filter":
         n_local = n_total                     # owner-filter sharding: the reads are replicated, the TABLE is sharded
     else:
         n_local = n_total // world + (1 if rank < n_total % world else 0)
     kmers_total = n_total * (L - K + 1)
     t0 = time.time()
-    words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err, sigma=args.sigma,
-                                                  seed=42 + (1000 * rank if (sharded_path and route) else 0))
+    if args.slice_of_whole and mode in ("route", "bucket"):
+        wf, _, _ = synth.torch_workload(n_total, L, args.T, dev, err=args.err, sigma=args.sigma, seed=42)
+        lo = (rank * n_total // world) // 16 * 16        # slices start on a word boundary (16 reads x L bases)
+        hi = ((rank + 1) * n_total // world) // 16 * 16 if rank + 1 < world else n_total
+        n_local = hi - lo
+        nwords = (n_local * L + 15) // 16 + 4
+        words = torch.zeros(nwords, dtype=torch.int32, device=dev)
+        words[: nwords - 4] = wf[lo * L // 16: lo * L // 16 + nwords - 4]
+        offsets = torch.arange(n_local + 1, dtype=torch.int64, device=dev) * L
+        del wf
+    else:
+        words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err, sigma=args.sigma,
+                                                      seed=42 + (1000 * rank if mode in ("route", "bucket") else 0))
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
 
-    # distinct k-mers ~ true k-mers + errors * K; table sized so that MAX_LOAD is not hit
+    # distinct k-mers ~ true k-mers + a share of errors * K; table sized so that MAX_LOAD is not hit
     # (measured: 0.68 G nodes for 200 M x 150 bp at err 0.002 -- most erroneous k-mers of a highly expressed transcript recur)
     est = args.est_distinct or int(args.T * 2250 + n_total * L * args.err * K * 0.35) // world + (1 << 20)
-    flags = {"auto": 0, "direct": pkg.SDT_FLAG_DIRECT, "superkmer": pkg.SDT_FLAG_PARTITION}[args.pipeline]
-    if args.track_first:
-        flags |= pkg.SDT_FLAG_TRACK_FIRST
+    base_flags = {"auto": 0, "direct": pkg.SDT_FLAG_DIRECT, "superkmer": pkg.SDT_FLAG_PARTITION}[args.pipeline]
+    flags = base_flags | (pkg.SDT_FLAG_TRACK_FIRST if args.track_first else 0)
     g = pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0, flags=flags)
     stream = torch.cuda.Stream(device=dev)
     g.set_stream(stream.cuda_stream)
     log(f"node table: {g.table_slots()} slots")
 
     sharded = None
-    if sharded_path:
-        from soapdenovo_trans_amd.sharding import ShardedCounter, allreduce_stats
-        if route:
-            sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
+    if mode == "bucket":
+        if share:
+            name = [os.environ.get("MASTER_PORT", "0") + "_" + str(os.getppid())]
+            dist.broadcast_object_list(name, src=0)
+            g.comm_init_shm("bench" + name[0], rank, world)
         else:
-            g.set_owner_filter(rank, world)
+            cid = [pkg.new_comm_id() if rank == 0 else None]
+            dist.broadcast_object_list(cid, src=0)
+            g.comm_init(cid[0], rank, world)
+    elif mode == "route":
+        from soapdenovo_trans_amd.sharding import ShardedCounter
+        sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
+    elif mode == "filter":
+        g.set_owner_filter(rank, world)
+
+    def allsum(hist, kmers, nodes, linear):
+        v = np.concatenate([np.asarray(hist, dtype=np.int64), np.array([kmers, nodes, linear], dtype=np.int64)])
+        if mode == "bucket":
+            v = g.allreduce(v)
+        elif sharded_path:
+            t = torch.from_numpy(v).to(dev)
+            dist.all_reduce(t)
+            v = t.cpu().numpy()
+        return v[:257], int(v[257]), int(v[258]), int(v[259])
 
     local_inserted = [0]
 
-    def one_step(verify=False):
-        g.reset()
-        if not sharded_path or not route:
-            g.count_reads_device(words, nwords, offsets, n_local, L)
-        else:
+    def one_step(ctx, verify=False):
+        ctx.reset()
+        if mode == "bucket":
+            ctx.count_reads_sharded(words, nwords, offsets, n_local, L)
+        elif mode == "route":
             with torch.cuda.stream(stream):
                 sharded.count_reads(words, nwords, offsets, n_local, verify=verify)
-        kmers, nodes = g.finish_count()
-        local_inserted[0] = kmers              # this rank's share (owner filter / routed records) before the all-reduce
+        else:
+            ctx.count_reads_device(words, nwords, offsets, n_local, L)
+        kmers, nodes = ctx.finish_count()
+        local_inserted[0] = kmers              # this rank's share before the all-reduce
         if args.d:
-            g.delow(args.d)
-        hist, linear = g.mark_and_hist()
-        if sharded_path:
-            hist, kmers, nodes, linear = allreduce_stats(hist, kmers, nodes, linear, dev)
+            ctx.delow(args.d)
+        hist, linear = ctx.mark_and_hist()
+        hist, kmers, nodes, linear = allsum(hist, kmers, nodes, linear)
         return kmers, nodes, linear, hist
 
     def barrier():
@@ -262,62 +301,128 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    for _ in range(args.warmup):
-        res = one_step(verify=True)        # checksum the exchange once, outside the timed region
-    g.kernel_time(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if sharded_path:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kmers, nodes, linear, hist = res
+    def timed(ctx, steps, warmup):
+        res = None
+        for _ in range(warmup):
+            res = one_step(ctx, verify=True)   # (route: checksum the exchange once, outside the timed region)
+        ctx.kernel_time(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = one_step(ctx)
+        barrier()
+        dt = time.perf_counter() - t0
+        if sharded_path:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return res, dt
+
+    (kmers, nodes, linear, hist), dt = timed(g, args.steps, args.warmup)
     assert kmers == kmers_total, f"processed {kmers} k-mers, expected {kmers_total}"
     assert int(hist.sum()) == nodes, "kmerFreq bins do not add up to the node count"
     stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
-    log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms], sk_counters)
+    log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms],
+        {k: v for k, v in sk_counters.items() if "ticks" not in k})
     ms_per_step = dt / args.steps * 1e3
     value = kmers_total * args.steps / dt
     B = algorithmic_bytes_per_kmer(L, K)
-    # kernel-level: this rank's k-mers over this rank's kernel time (N=1: whole job)
-    # N > 1, owner filter: rank 0's chop+insert launches walk ALL reads and insert its share of the k-mers; the bytes
-    # that count are those of the k-mers it inserted
-    filter_path = sharded_path and not route
-    local_kmers = n_local * (L - K + 1) if not sharded_path else (local_inserted[0] if filter_path else None)
+    # kernel level: the k-mers this rank chopped over the time of this rank's pass-1 kernels (N = 1: the whole job)
+    if mode == "filter":
+        local_kmers = local_inserted[0]         # its launches walk ALL reads and insert the k-mers it owns
+    else:
+        local_kmers = n_local * (L - K + 1)
     roof = None
     if local_kmers and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
-        tpk, tsrc = pmc_traffic_per_kmer(K) if not sharded_path else (None, None)
-        per_launch_kmers = local_kmers * args.steps / max(launches, 1)
+        pipeline = stage_ms[1] + stage_ms[3] > stage_ms[0]
+        batches = max(sk_counters["batches"] // (args.steps + args.warmup), 1) if pipeline else max(int(launches) // args.steps, 1)
+        per_launch_kmers = local_kmers / batches
+        tpk, tsrc = pmc_traffic_per_kmer(K, L, n_total) if world == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None if tpk is None else round(tpk * per_launch_kmers),
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE PMC passes)", "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": round(B * per_launch_kmers), "kernel": "k_count_reads",
-                "bytes_per_kmer": round(B, 3), "launches": int(launches),
-                "avg_launch_ms": round(kms / max(launches, 1), 4), "kernel_ms_per_step": round(kms / args.steps, 3)}
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes of this workload, this build)",
+                "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(B * per_launch_kmers),
+                "kernel": ("pass 1 = k_sk_scatter_reads + chunk lists + k_sk_scatter_records + k_sk_count (every k-mer goes through "
+                           "all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
+                "bytes_per_kmer": round(B, 3), "launches": int(batches * args.steps),
+                "avg_launch_ms": round(kms / (batches * args.steps), 4), "kernel_ms_per_step": round(kms / args.steps, 3),
+                "stage_ms_per_step": {"scatter": round(stage_ms[1] / args.steps, 2), "split": round(stage_ms[2] / args.steps, 2),
+                                      "count": round(stage_ms[3] / args.steps, 2), "direct": round(stage_ms[0] / args.steps, 2)},
+                "merges_per_kmer": round(sk_counters["merges"] / max(local_kmers, 1), 4) if pipeline else None}
         if sharded_path:
             roof["rank"] = 0
-            roof["note"] = "rank 0 only: its launches chop every read and insert the k-mers it owns"
     out = {
         "metric": "pregraph k-mers hashed/sec", "value": value, "unit": "kmers/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{n_total} x {L} bp synthetic transcriptome reads (T={args.T}, err={args.err}), "
                                f"K={K}, pass-1 chop+hash+count" + (f"+delow(-d {args.d})" if args.d else "") + "+kmerFreq"
-                               + (f", sigma={args.sigma}" if args.sigma != 2.0 else ""), "reads": n_total, "read_len": L, "K": K,
+                               + (f", sigma={args.sigma}" if args.sigma != 2.0 else "")
+                               + (", first-occurrence tracking" if args.track_first else ""), "reads": n_total, "read_len": L, "K": K,
                    "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
-                   "parallelism": (f"owner-sharded table x{world}, " + ("records routed by RCCL all-to-all" if route else
-                                   "reads replicated, owner filter (no data-path collective)")) if sharded_path
-                   else "single-GPU table"},
+                   "parallelism": {"single": "single-GPU table",
+                                   "bucket": f"reads split x{world}; tables sharded by minimizer bucket; super-k-mer chunks by grouped "
+                                             f"ncclSend/ncclRecv (C ABI: sdt_gpu_count_reads_sharded)" + (" [shared-memory transport: ranks share one GPU]" if share else ""),
+                                   "route": f"owner-sharded table x{world}, 16-B records by torch all-to-all (round-1 path)",
+                                   "filter": f"owner-sharded table x{world}, reads replicated, owner filter (round-1 path)"}[mode]},
         "roofline": roof,
     }
+    if mode == "bucket":
+        sent, recv, xms, nx = g.comm_stats()
+        tot = g.allreduce([sent, recv])
+        out["exchange"] = {"bytes_sent_rank0": sent, "bytes_sent_all_ranks": int(tot[0]), "exchanges_rank0": nx,
+                           "bytes_per_kmer": round(int(tot[0]) / max(kmers_total * (args.steps + args.warmup), 1), 3),
+                           "ms_on_exchange_stream_rank0": round(xms, 2),
+                           "GBps_out_rank0": round(sent / max(xms, 1e-9) / 1e6, 2),
+                           "GBps_per_link_rank0": round(sent / max(world - 1, 1) / max(xms, 1e-9) / 1e6, 2),
+                           "note": "per link = bytes to one peer / time of the grouped send/recv; xGMI peak ~153 GB/s per link and direction"}
+    # ---- extras (N = 1): the configuration the five-file pipeline runs with, and the rate from host buffers ----
+    out["track_first"] = None
+    out["pcie_inclusive"] = None
+    if world == 1 and not sharded_path and args.extras and not args.track_first:
+        g.close()
+        g = None
+        try:
+            with pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0, flags=base_flags | pkg.SDT_FLAG_TRACK_FIRST) as gt:
+                gt.set_stream(stream.cuda_stream)
+                (k2, n2, _, _), dt2 = timed(gt, max(args.steps - 1, 1), 1)
+                assert (k2, n2) == (kmers_total, nodes)
+                st2 = max(args.steps - 1, 1)
+                out["track_first"] = {"value": kmers_total * st2 / dt2, "unit": "kmers/s", "ms_per_step": dt2 / st2 * 1e3,
+                                      "note": "same step with SDT_FLAG_TRACK_FIRST (first-occurrence ordinals per node: what sdt-pregraph "
+                                              "needs for *.vertex / *.edge / *.preArc in the reference's order)"}
+        except Exception as e:
+            log("track-first extra failed:", repr(e))
+        try:
+            # PCIe-inclusive: pinned host batches of 2^20 reads through sdt_gpu_push_reads (H2D staged, double buffered)
+            nb = min(n_local, 40_000_000)
+            batch = 1 << 20
+            hw = torch.empty((nb * L + 15) // 16 + 4, dtype=torch.int32).pin_memory()
+            hw.copy_(words[: hw.numel()])
+            hwn = hw.numpy().view(np.uint32)
+            with pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0, flags=base_flags) as gp:
+                best = None
+                for rep in range(2):
+                    gp.reset()
+                    gp.finish_count()
+                    t0 = time.perf_counter()
+                    for r0 in range(0, nb, batch):
+                        nr = min(batch, nb - r0)
+                        w0 = r0 * L // 16
+                        gp.push_reads(hwn[w0: w0 + (nr * L + 15) // 16 + 4], np.arange(nr + 1, dtype=np.uint64) * L)
+                    kk, _ = gp.finish_count()
+                    d3 = time.perf_counter() - t0
+                    assert kk == nb * (L - K + 1)
+                    best = d3 if best is None else min(best, d3)
+            out["pcie_inclusive"] = {"value": nb * (L - K + 1) / best, "unit": "kmers/s", "reads": nb,
+                                     "note": "first reads of the workload from pinned host memory in batches of 2^20 reads through "
+                                             "sdt_gpu_push_reads (H2D + pass 1, no mark/kmerFreq)"}
+        except Exception as e:
+            log("pcie extra failed:", repr(e))
     if rank == 0 and world == 1 and not sharded_path and args.cpu_sample > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log)
@@ -328,7 +433,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    g.close()
+    if g is not None:
+        g.close()
     if sharded_path:
         dist.destroy_process_group()
 

@@ -484,8 +484,10 @@ struct sdt_ctx {
 	int next_buf = 0;
 	// bookkeeping for growth: upper bound of distinct nodes without syncing
 	uint64_t distinct_known = 0;       // as of the last sync
+	uint64_t kmers_known = 0;          // occurrences counted as of the last sync (new nodes per occurrence: bound of the next launch)
 	uint64_t kmers_since_sync = 0;     // launched since then
 	uint64_t kmers_total_host = 0;
+	uint64_t kmers_offered = 0;        // upper bound of the k-mers handed to pass 1 since the last reset (picks the kernel family)
 	// route scratch
 	unsigned long long *d_cursors = nullptr;
 	uint32_t flags = 0;
@@ -627,6 +629,7 @@ static int sync_stats(sdt_ctx *c)
 		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full or route bucket overflow)",
 		            (unsigned long long)c->h_stats->probe_fail);
 	c->distinct_known = c->h_stats->distinct;
+	c->kmers_known = c->h_stats->kmers;
 	c->kmers_since_sync = 0;
 	return SDT_OK;
 }
@@ -781,8 +784,8 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	sdt_ctx::SkState &k = c->sk;
 	if (want_kmers > SK_BATCH_MAX_KMERS)
 		want_kmers = SK_BATCH_MAX_KMERS;
-	if (k.ready && (k.cap_kmers >= want_kmers || k.cap_is_max))
-		return SDT_OK;
+	if (k.ready && (k.cap_kmers >= want_kmers || k.cap_is_max || k.pending_kmers))
+		return SDT_OK;                               // (pools that hold records are never replaced: they are flushed first)
 	if (k.ready) {
 		HIPCHK(hipStreamSynchronize(c->stream));
 		sk_free(c);
@@ -932,13 +935,18 @@ static int sk_count_all(sdt_ctx *c)
 	int rc = SDT_OK;
 	uint32_t nci = 0;
 	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
+	// A launch must find room for every node it may create.  "Every occurrence is a new node" is hopeless for a batch of
+	// 2^33 k-mers, so: a first launch of at most 2^26 k-mers under that bound, then launches bounded by twice the rate of
+	// new nodes per occurrence seen so far (later data brings fewer new nodes, not more; a wrong guess ends in SDT_EFULL,
+	// never in a silent loss: table_merge reports a full table).
 	std::vector<uint32_t> first_item;                // first item of every launch
 	std::vector<uint64_t> launch_kmers;
 	uint64_t acc = 0;
 	first_item.push_back(0);
 	for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
 		const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
-		if (acc && acc + km > SK_COUNT_KMERS && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
+		const uint64_t limit = (c->kmers_known == 0 && launch_kmers.empty()) ? (1ULL << 26) : SK_COUNT_KMERS;
+		if (acc && acc + km > limit && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
 			launch_kmers.push_back(acc);
 			first_item.push_back(nci);
 			acc = 0;
@@ -958,10 +966,20 @@ static int sk_count_all(sdt_ctx *c)
 		const uint32_t i0 = first_item[l], i1 = first_item[l + 1];
 		if (i0 == i1)
 			continue;
-		rc = ensure_room(c, launch_kmers[l]);
+		if (c->kmers_known == 0 && l > 0) {
+			rc = sync_stats(c);                      // the first launch has run: its rate of new nodes bounds the rest
+			if (rc != SDT_OK) break;
+		}
+		uint64_t bound = launch_kmers[l];
+		if (c->kmers_known) {
+			const double rate = (double)c->distinct_known / (double)c->kmers_known;
+			const uint64_t guess = (uint64_t)((double)launch_kmers[l] * (2.0 * rate < 1.0 ? 2.0 * rate : 1.0)) + (1ULL << 22);
+			if (guess < bound) bound = guess;
+		}
+		rc = ensure_room(c, bound);
 		if (rc == SDT_OK)
 			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
-		c->kmers_since_sync += launch_kmers[l];
+		c->kmers_since_sync += bound;
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
 	return rc;
@@ -1051,10 +1069,16 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 	sdt_ctx::SkState &k = c->sk;
 	const uint64_t per_read = max_read_len - c->K + 1;
 	int rc = SDT_OK;
-	if (k.ready && k.pending_kmers && !k.cap_is_max && k.cap_kmers < k.pending_kmers + nreads * per_read)
+	if (k.ready && k.pending_kmers && !k.cap_is_max && k.cap_kmers < k.pending_kmers + nreads * per_read && k.cap_kmers < (1ULL << 31))
 		rc = sk_flush(c);                            // the pools are about to be replaced by larger ones
-	if (rc == SDT_OK)
-		rc = sk_alloc(c, k.pending_kmers + nreads * per_read);
+	if (rc == SDT_OK) {
+		// without SDT_FLAG_PARTITION the pipeline only runs for jobs past 2^27 k-mers: start with pools for 2^31 at once
+		// (sk_alloc halves that until it fits the free memory) instead of growing there batch by batch
+		uint64_t want = k.pending_kmers + nreads * per_read;
+		if (!(c->flags & SDT_FLAG_PARTITION) && want < (1ULL << 31))
+			want = 1ULL << 31;
+		rc = sk_alloc(c, want);
+	}
 	if (rc != SDT_OK)
 		return rc;
 	for (uint64_t r0 = 0; r0 < nreads;) {
@@ -1450,8 +1474,10 @@ int sdt_gpu_reset(sdt_ctx *c)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
 	c->distinct_known = 0;
+	c->kmers_known = 0;
 	c->kmers_since_sync = 0;
 	c->kmers_total_host = 0;
+	c->kmers_offered = 0;
 	c->ord_base = 0;
 	c->ord_stride = 1;
 	if (c->sk.ready) {                               // records scattered but not counted belong to the run being forgotten
@@ -1537,7 +1563,8 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	// default: the locality pipeline wherever it applies (2.2x the direct kernel on 200 M x 150 bp, K = 31); SDT_FLAG_DIRECT /
 	// SDT_FLAG_PARTITION force one family (the latter still needs a geometry the pipeline can take)
 	// (a small job is not worth the pipeline's fixed cost -- two host syncs and scans over 2^18 buckets, ~3 ms -- unless asked for)
-	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && nreads * per_read < (1ULL << 27);
+	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && c->kmers_offered + nreads * per_read < (1ULL << 27);
+	c->kmers_offered += nreads * per_read;
 	if (!(c->flags & SDT_FLAG_DIRECT) && !sk_small && sk_applicable(c, max_read_len)) {
 		const int rcs = sk_scatter(c, d_words, d_offs, nreads, max_read_len);
 		if (rcs == SDT_OK)

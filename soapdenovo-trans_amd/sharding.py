@@ -3,7 +3,9 @@
 The reference routes every record to thread `hash_kmer % thrd_num` by letting each thread scan the whole
 batch (prlHashReads.c:77-90).  Across GPUs the owner of a canonical k-mer is
     owner = ((sdt_owner_hash(key) >> 32) * nranks) >> 32
-and records travel once, in an all-to-all(v) over xGMI (RCCL; `gloo` in the CPU tests).  This module is the
+and records travel once, in an all-to-all(v) over xGMI (RCCL; `gloo` in the CPU tests).  ROUND-1 PATH, kept for A/B
+(`bench.py --shard-mode route`): the product path is the C-level bucket sharding of include/sdt_gpu.h
+(sdt_gpu_count_reads_sharded), which moves ~3 B per k-mer instead of 16.  This module is the
 device-agnostic plumbing around the two kernels (`sdt_gpu_extract_route`, `sdt_gpu_insert_records`): it only
 moves opaque 8-byte words with torch.distributed.
 """
@@ -40,6 +42,14 @@ def exchange_records(send, counts, cap_per_rank: int, rec_words: int, recv, grou
     dist.all_to_all_single(rcounts, counts, group=group)
     c = counts.cpu().tolist()
     rc = rcounts.cpu().tolist()
+    # k_extract_route keeps counting past a full slice (the records themselves are dropped and flagged): a slice that
+    # overflowed would make `send[i*cap : i*cap + c[i]]` reach into the next owner's slice.  Every rank must learn of it
+    # in the same place, or the others wait in the next collective until it times out.
+    over = torch.tensor([1 if max(c) > cap_per_rank else 0], dtype=torch.int64, device=counts.device)
+    dist.all_reduce(over, op=dist.ReduceOp.MAX, group=group)
+    if int(over.item()):
+        raise RuntimeError(f"an owner's slice overflowed (most records for one owner on this rank: {max(c)}, capacity {cap_per_rank}): "
+                           "use fewer reads per round (ShardedCounter sizes the slices at 1.25 x the mean)")
     total = int(sum(rc))
     if total * rec_words > recv.numel():
         raise RuntimeError(f"receive buffer too small: need {total} records, have {recv.numel() // rec_words}")

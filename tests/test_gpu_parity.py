@@ -668,15 +668,15 @@ def test_map_stage_edge_cases(pkg, synth):
 
 
 def test_bench_two_ranks_on_one_device_equal_one_rank(pkg, tmp_path):
-    """the N>1 path of bench.py (owner-filter sharding, all-reduced kmerFreq / counters) run for real on the GPU:
-    two ranks sharing cuda:0 over a gloo control plane (SDT_BENCH_SHARE_DEVICE=1, validation only) must report the
-    same node and linear-node counts as one rank"""
+    """the N>1 path of bench.py (C-level bucket sharding: sdt_gpu_count_reads_sharded, all-reduced kmerFreq / counters)
+    run for real on the GPU: two ranks sharing cuda:0 (SDT_BENCH_SHARE_DEVICE=1: shared-memory transport, validation
+    only) on slices of the single-rank workload must report the same node and linear-node counts as one rank"""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--reads", "1000000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--T", "2000"]
+    common = ["--reads", "1000000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--T", "2000", "--extras", "0", "--slice-of-whole"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
@@ -686,7 +686,8 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(pkg, tmp_path):
                          capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     b = json.loads(two.stdout.strip().splitlines()[-1])
-    assert b["n_gpus"] == 2 and "owner-sharded" in b["config"]["parallelism"]
+    assert b["n_gpus"] == 2 and "sharded by minimizer bucket" in b["config"]["parallelism"]
+    assert b["exchange"]["bytes_sent_all_ranks"] > 0 and b["exchange"]["exchanges_rank0"] >= 2
     assert b["roofline"] and b["roofline"]["rank"] == 0 and 0 < b["roofline"]["frac"] < 1     # rank 0's kernel, its own k-mers
     for k in ("kmers", "distinct_nodes", "linear_nodes"):
         assert a["config"][k] == b["config"][k], k
