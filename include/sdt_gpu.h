@@ -133,6 +133,14 @@ int sdt_gpu_push_reads_sharded(sdt_ctx *ctx, const uint32_t *packed_words, uint6
 int sdt_gpu_allreduce_i64(sdt_ctx *ctx, int64_t *vals, int n);
 int sdt_gpu_comm_stats(sdt_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_recv, double *exchange_ms, uint64_t *exchanges);
 int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks);
+/* After pass 1 the order-dependent graph phases (cutTipPreGraph.c, node2edge.c) run on ONE host over ALL nodes: rank 0
+ * takes the other ranks' exported shards (sdt_gpu_export_nodes arrays; keys are disjoint by construction) into its own
+ * table with import_nodes -- its device mirror then answers the dry runs and the second read pass for the whole
+ * graph -- and keeps every read of the run resident with keep_reads (like SDT_FLAG_KEEP_READS, minus the counting;
+ * ordinals from sdt_gpu_set_read_ordinal as for a push). */
+int sdt_gpu_import_nodes(sdt_ctx *ctx, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags,
+                         const uint32_t *count, const uint64_t *first, uint64_t n);
+int sdt_gpu_keep_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads);
 /* host-only self test of the shared-memory transport's control plane (no device needed; the CPU tests run it with
  * several processes) */
 int sdt_comm_selftest_shm(const char *name, int rank, int nranks, int rounds);

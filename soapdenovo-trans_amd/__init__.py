@@ -86,6 +86,8 @@ _ABI = [
                                       _c.POINTER(_c.c_uint64)]),
     ("sdt_kmer_owner", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     ("sdt_comm_selftest_shm", _c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int]),
+    ("sdt_gpu_import_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_keep_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64]),
 ]
 ABI_SYMBOLS = [n for n, _, _ in _ABI]
 

@@ -12,6 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
@@ -38,6 +43,10 @@ static void usage(int max_k)
 typedef struct {
 	sdt_ctx *gpu;
 	unsigned long long reads;
+	/* --gpus N: chunk i of the stream is counted by rank i % N; one collective push per group of N chunks */
+	int rank, nranks, keep_all, fill, have;
+	uint32_t *w;
+	uint64_t *o, nw, n, cap_w, cap_o, ord_base, ord_stride;
 } push_state;
 
 /* millisecond phase timer on stderr (the reference's own lines on stdout have 1 s resolution) */
@@ -48,8 +57,10 @@ static double now_ms(void)
 	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 static double g_t_last;
+static int g_quiet;                 /* --gpus N: ranks > 0 */
 static void phase(const char *name)
 {
+	if (g_quiet) return;
 	const double t = now_ms();
 	fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", name, t - g_t_last);
 	g_t_last = t;
@@ -68,6 +79,58 @@ static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_
 		return -1;
 	}
 	return 0;
+}
+
+static int flush_group(push_state *st)
+{
+	static const uint32_t none[4] = {0, 0, 0, 0};
+	static const uint64_t zero[1] = {0};
+	if (st->have) sdt_gpu_set_read_ordinal(st->gpu, st->ord_base, st->ord_stride);
+	const int rc = sdt_gpu_push_reads_sharded(st->gpu, st->have ? st->w : none, st->have ? st->nw : 4, st->have ? st->o : zero, st->have ? st->n : 0);
+	if (rc != SDT_OK) fprintf(stderr, "[rank %d] sdt_gpu_push_reads_sharded: %s\n", st->rank, sdt_gpu_last_error());
+	st->have = 0;
+	st->fill = 0;
+	return rc == SDT_OK ? 0 : -1;
+}
+
+static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
+{
+	push_state *st = (push_state *)user;
+	unsigned long long before = st->reads / 1000000ULL;
+	st->reads += b->nreads;
+	if (st->reads / 1000000ULL != before)
+		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);
+	if (st->keep_all && !b->counted_only && b->nreads) {         /* rank 0: every read stays resident for the second pass */
+		sdt_gpu_set_read_ordinal(st->gpu, ord_base, ord_stride);
+		if (sdt_gpu_keep_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
+			fprintf(stderr, "sdt_gpu_keep_reads: %s\n", sdt_gpu_last_error());
+			return -1;
+		}
+	}
+	if (b->owner == st->rank && b->nreads) {                      /* mine: it waits for the end of its group */
+		if (b->nwords > st->cap_w) { st->cap_w = b->nwords * 5 / 4; st->w = (uint32_t *)realloc(st->w, st->cap_w * 4); }
+		if (b->nreads + 1 > st->cap_o) { st->cap_o = (b->nreads + 1) * 5 / 4; st->o = (uint64_t *)realloc(st->o, st->cap_o * 8); }
+		memcpy(st->w, b->words, b->nwords * 4);
+		memcpy(st->o, b->offsets, (b->nreads + 1) * 8);
+		st->nw = b->nwords; st->n = b->nreads; st->ord_base = ord_base; st->ord_stride = ord_stride;
+		st->have = 1;
+	}
+	if (++st->fill == st->nranks)
+		return flush_group(st);
+	return 0;
+}
+
+/* --gpus N: the shard of every other rank comes to rank 0 through POSIX shared memory */
+typedef struct { volatile int ready; sdt_comm_id id; char name[64]; } boot_t;
+
+static void *shm_region(const char *name, size_t bytes, int create)
+{
+	int fd = create ? shm_open(name, O_CREAT | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+	if (fd < 0) return NULL;
+	if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return NULL; }
+	void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	return p == MAP_FAILED ? NULL : p;
 }
 
 /* second pass (prlRead2edge): unpack each read and thread it through the edge graph */
@@ -242,10 +305,12 @@ int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", prefix[4096] = "";
 	int K = 23, threads = 8, d = 0, max_k = 0, device = 0, dd = 5, hash_only = 0, host_map = 0, host_walks = 0;
+	int gpus = 1, share_device = 0, rank = 0;
 	int have_s = 0, have_o = 0, c;
 	unsigned long long est = 0;
 	static struct option longopts[] = {{"max-k", required_argument, 0, 1000}, {"device", required_argument, 0, 1001},
 	                                   {"est-distinct", required_argument, 0, 1002}, {"hash-only", no_argument, 0, 1003}, {"host-map", no_argument, 0, 1004}, {"host-walks", no_argument, 0, 1005},
+	                                   {"gpus", required_argument, 0, 1006}, {"share-device", no_argument, 0, 1007},
 	                                   {0, 0, 0, 0}};
 	/* accept an optional leading "pregraph" sub-command like the reference's dispatcher (main.c:49-106) */
 	if (argc > 1 && strcmp(argv[1], "pregraph") == 0) { argv++; argc--; }
@@ -268,6 +333,8 @@ int main(int argc, char **argv)
 		case 1003: hash_only = 1; break;
 		case 1004: host_map = 1; break;
 		case 1005: host_walks = 1; break;
+		case 1006: gpus = atoi(optarg); break;                /* one process per GPU: devices --device .. --device + N - 1 */
+		case 1007: share_device = 1; break;                   /* validation: all ranks on --device, shared-memory transport */
 		default:
 			if (!have_s || !have_o) { usage(max_k ? max_k : SDT_MAX_K); return 255; }
 		}
@@ -289,20 +356,74 @@ int main(int argc, char **argv)
 	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;                /* prlHashReads.c:361-364 */
 	printf("In %s, %d libs, max seq len %d, max name len %d\n\n", cfgfile, cfg.nlibs, max_read_len, 256);
 
+	/* --gpus N: one process per GPU, forked BEFORE anything touches the HIP runtime.  Rank 0 is this process: it prints,
+	 * writes the files and runs the graph phases; the others count their share of the reads and hand their nodes over. */
+	boot_t *boot = NULL;
+	if (gpus < 1 || gpus > 64) { fprintf(stderr, "--gpus must be 1..64\n"); return 255; }
+	if (gpus > 1) {
+		boot = (boot_t *)mmap(NULL, sizeof(boot_t), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+		if (boot == MAP_FAILED) { perror("mmap"); return 1; }
+		memset(boot, 0, sizeof *boot);
+		snprintf(boot->name, sizeof boot->name, "pg%d", (int)getpid());
+		fflush(stdout);
+		for (int r = 1; r < gpus; r++) {
+			const pid_t pid = fork();
+			if (pid < 0) { perror("fork"); return 1; }
+			if (pid == 0) {
+				rank = r;
+				g_quiet = 1;
+				if (!freopen("/dev/null", "w", stdout)) return 1;       /* one voice: rank 0's */
+				break;
+			}
+		}
+	}
+	const int my_threads = gpus == 1 ? threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
 	sdt_ctx *gpu = NULL;
-	if (sdt_gpu_init(&gpu, device, K, est, hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | (host_map ? 0 : SDT_FLAG_KEEP_READS))) != SDT_OK) {
+	const uint32_t iflags = hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS));
+	if (sdt_gpu_init(&gpu, share_device ? device : device + rank, K, est / (unsigned long long)gpus, iflags) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
+	if (gpus > 1) {
+		int rcc;
+		if (share_device) {
+			rcc = sdt_gpu_comm_init_shm(gpu, boot->name, rank, gpus);
+		} else {
+			if (rank == 0) {
+				rcc = sdt_gpu_comm_id(&boot->id);
+				__sync_synchronize();
+				boot->ready = rcc == SDT_OK ? 1 : -1;
+			}
+			while (!boot->ready) usleep(1000);
+			rcc = boot->ready == 1 ? sdt_gpu_comm_init(gpu, &boot->id, rank, gpus) : SDT_EHIP;
+		}
+		if (rcc != SDT_OK) { fprintf(stderr, "[rank %d] communicator: %s\n", rank, sdt_gpu_last_error()); return 1; }
+	}
 	phase("config + gpu init");
-	push_state st = {gpu, 0};
-	const size_t chunk = 32u << 20;
-	int rc = sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, push_batch, &st, NULL);
+	push_state st;
+	memset(&st, 0, sizeof st);
+	st.gpu = gpu; st.rank = rank; st.nranks = gpus; st.keep_all = gpus > 1 && rank == 0 && !hash_only && !host_map;
+	const size_t chunk = getenv("SDT_CHUNK_BYTES") ? (size_t)strtoull(getenv("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
+	int rc;
+	if (gpus == 1) {
+		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch, &st, NULL);
+	} else {
+		sdt_read_shard_begin(rank, gpus, st.keep_all);
+		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch_sharded, &st, NULL);
+		if (rc == 0 && st.fill) rc = flush_group(&st);
+		sdt_read_shard_begin(0, 1, 0);
+	}
 	if (rc != 0) { sdt_gpu_destroy(gpu); return 1; }
 	uint64_t kmers = 0, nodes = 0, removed = 0, linear = 0;
 	if (sdt_gpu_finish_count(gpu, &kmers, &nodes) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_finish_count: %s\n", sdt_gpu_last_error());
 		return 1;
+	}
+	const uint64_t my_nodes = nodes;
+	if (gpus > 1) {                                              /* the counters the reference prints are sums over its sets */
+		int64_t v[2] = {(int64_t)kmers, (int64_t)nodes};
+		if (sdt_gpu_allreduce_i64(gpu, v, 2) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		kmers = (uint64_t)v[0]; nodes = (uint64_t)v[1];
 	}
 	phase("parse + hash (GPU)");
 	printf("time spent on hash reads: %ds, %llu reads processed\n", (int)(time(NULL) - t_start), st.reads);
@@ -310,21 +431,31 @@ int main(int argc, char **argv)
 	       (unsigned long long)kmers, (unsigned long long)kmers);
 	if (d) {
 		if (sdt_gpu_delow(gpu, d, &removed) != SDT_OK) { fprintf(stderr, "sdt_gpu_delow: %s\n", sdt_gpu_last_error()); return 1; }
-		printf("%llu kmer removed\n", (unsigned long long)removed);
 	}
 	int64_t hist[257];
 	if (sdt_gpu_mark_and_hist(gpu, hist, &linear) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_mark_and_hist: %s\n", sdt_gpu_last_error());
 		return 1;
 	}
+	if (gpus > 1) {
+		int64_t v[259];
+		memcpy(v, hist, sizeof hist);
+		v[257] = (int64_t)linear; v[258] = (int64_t)removed;
+		if (sdt_gpu_allreduce_i64(gpu, v, 259) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		memcpy(hist, v, sizeof hist);
+		linear = (uint64_t)v[257]; removed = (uint64_t)v[258];
+	}
+	if (d) printf("%llu kmer removed\n", (unsigned long long)removed);
 	printf("%llu linear nodes\n", (unsigned long long)linear);
 	char name[4200];
 	snprintf(name, sizeof name, "%s.kmerFreq", prefix);
-	FILE *fo = fopen(name, "w");
-	if (!fo) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
-	for (int i = 1; i < 256; i++)
-		fprintf(fo, "%lld\n", (long long)hist[i]);
-	fclose(fo);
+	if (rank == 0) {
+		FILE *fo = fopen(name, "w");
+		if (!fo) { printf("Cannot open %s. Now exit to system...\n", name); return 255; }
+		for (int i = 1; i < 256; i++)
+			fprintf(fo, "%lld\n", (long long)hist[i]);
+		fclose(fo);
+	}
 	phase("delow/mark/kmerFreq (GPU)");
 	printf("time spent on pre-graph construction: %ds\n\n", (int)(time(NULL) - t_start));
 	printf("deLowKmer %d, deLowEdge %d\n", d, 1);
@@ -333,9 +464,63 @@ int main(int argc, char **argv)
 		uint64_t n = 0;
 		const int nwk = sdt_gpu_key_words(gpu), nwv = max_k <= 31 ? 1 : (max_k <= 63 ? 2 : 4);
 		if (sdt_gpu_export_nodes(gpu, NULL, NULL, NULL, NULL, NULL, 0, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
-		uint64_t *keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8), *first = (uint64_t *)malloc((n + 1) * 8);
-		uint32_t *ll = (uint32_t *)malloc((n + 1) * 4), *rf = (uint32_t *)malloc((n + 1) * 4), *cnt = (uint32_t *)malloc((n + 1) * 4);
-		if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		uint64_t *keys, *first;
+		uint32_t *ll, *rf, *cnt;
+		if (gpus > 1) {
+			/* shards -> rank 0.  Every rank learns all shard sizes; ranks > 0 export into a shared-memory segment each and
+			 * leave once rank 0 has taken their nodes (host arrays + its own device table: sdt_gpu_import_nodes) */
+			int64_t sizes[64];
+			memset(sizes, 0, sizeof sizes);
+			sizes[rank] = (int64_t)my_nodes;
+			if (sdt_gpu_allreduce_i64(gpu, sizes, gpus) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+			const size_t per_node = (size_t)nwk * 8 + 8 + 12;
+			char seg[128];
+			int64_t token = 0;
+			if (rank > 0) {
+				snprintf(seg, sizeof seg, "/sdt_%s_n%d", boot->name, rank);
+				uint8_t *m = (uint8_t *)shm_region(seg, (size_t)(my_nodes + 1) * per_node, 1);
+				if (!m) { fprintf(stderr, "[rank %d] shared memory for %llu nodes failed\n", rank, (unsigned long long)my_nodes); return 1; }
+				uint64_t *k2 = (uint64_t *)m, *f2 = k2 + (my_nodes + 1) * (size_t)nwk;
+				uint32_t *l2 = (uint32_t *)(f2 + my_nodes + 1), *r2 = l2 + my_nodes + 1, *c2 = r2 + my_nodes + 1;
+				if (sdt_gpu_export_nodes(gpu, k2, l2, r2, c2, f2, my_nodes, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+				sdt_gpu_allreduce_i64(gpu, &token, 1);            /* "my shard is in shared memory" */
+				sdt_gpu_allreduce_i64(gpu, &token, 1);            /* "rank 0 has it" */
+				munmap(m, (size_t)(my_nodes + 1) * per_node);
+				shm_unlink(seg);
+				sdt_gpu_destroy(gpu);
+				return 0;
+			}
+			n = nodes;                                            /* all shards */
+			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
+			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
+			uint64_t got = 0;
+			if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, my_nodes, &got) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+			sdt_gpu_allreduce_i64(gpu, &token, 1);
+			uint64_t at = my_nodes;
+			for (int r = 1; r < gpus; r++) {
+				const uint64_t m_n = (uint64_t)sizes[r];
+				snprintf(seg, sizeof seg, "/sdt_%s_n%d", boot->name, r);
+				uint8_t *m = (uint8_t *)shm_region(seg, (size_t)(m_n + 1) * per_node, 0);
+				if (!m) { fprintf(stderr, "cannot map the shard of rank %d\n", r); return 1; }
+				const uint64_t *k2 = (const uint64_t *)m, *f2 = k2 + (m_n + 1) * (size_t)nwk;
+				const uint32_t *l2 = (const uint32_t *)(f2 + m_n + 1), *r2 = l2 + m_n + 1, *c2 = r2 + m_n + 1;
+				memcpy(keys + at * nwk, k2, m_n * (size_t)nwk * 8); memcpy(first + at, f2, m_n * 8);
+				memcpy(ll + at, l2, m_n * 4); memcpy(rf + at, r2, m_n * 4); memcpy(cnt + at, c2, m_n * 4);
+				at += m_n;
+				munmap(m, (size_t)(m_n + 1) * per_node);
+			}
+			sdt_gpu_allreduce_i64(gpu, &token, 1);                /* the other ranks may go */
+			if (at != n) { fprintf(stderr, "shards hold %llu nodes, the counters say %llu\n", (unsigned long long)at, (unsigned long long)n); return 1; }
+			if (!host_map && sdt_gpu_import_nodes(gpu, keys + my_nodes * nwk, ll + my_nodes, rf + my_nodes, cnt + my_nodes, first + my_nodes, n - my_nodes) != SDT_OK) {
+				fprintf(stderr, "sdt_gpu_import_nodes: %s\n", sdt_gpu_last_error());
+				return 1;
+			}
+			while (waitpid(-1, NULL, WNOHANG) > 0) { }
+		} else {
+			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
+			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
+			if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		}
 		if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
 		phase("export nodes (D2H)");
 		dev_state D = {gpu, nwk, 0};
@@ -411,5 +596,7 @@ int main(int argc, char **argv)
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
 	sdt_cfg_free(&cfg);
+	if (gpus > 1 && rank == 0)
+		while (wait(NULL) > 0) { }
 	return 0;
 }

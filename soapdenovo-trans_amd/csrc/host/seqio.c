@@ -14,7 +14,19 @@ typedef struct {
 	const char *beg, *end;      /* [beg, end) holds whole records */
 	sdt_batch out;
 	int done;
+	int owner, encode;          /* sdt_read_shard_begin */
 } chunk_t;
+
+static int g_shard_rank = 0, g_shard_n = 1, g_shard_keep_all = 0;
+static uint64_t g_shard_chunk = 0;
+
+void sdt_read_shard_begin(int rank, int nranks, int keep_all)
+{
+	g_shard_rank = rank;
+	g_shard_n = nranks > 0 ? nranks : 1;
+	g_shard_keep_all = keep_all;
+	g_shard_chunk = 0;
+}
 
 typedef struct {
 	chunk_t *chunks;
@@ -172,7 +184,7 @@ static void parse_chunk(job_t *J, chunk_t *c)
 			const char *se = line_end(seq, end);
 			int sl = (int)(se - seq);
 			if (sl > 0 && seq[sl - 1] == '\r') sl--;
-			len = encode_line(&pk, seq, sl, J->max_read_len, J->reverse);
+			if (c->encode) len = encode_line(&pk, seq, sl, J->max_read_len, J->reverse);
 			const char *plus = se < end ? se + 1 : end;
 			const char *pe = line_end(plus, end);
 			const char *qual = pe < end ? pe + 1 : end;
@@ -189,6 +201,7 @@ static void parse_chunk(job_t *J, chunk_t *c)
 				const char *se = line_end(q, end);
 				size_t sl = (size_t)(se - q);
 				if (sl > 0 && q[sl - 1] == '\r') sl--;
+				if (!c->encode) sl = 0;
 				if (bl + sl > bcap) {
 					bcap = (bl + sl) * 2;
 					char *nb = (char *)malloc(bcap);
@@ -200,7 +213,7 @@ static void parse_chunk(job_t *J, chunk_t *c)
 				bl += sl;
 				q = se < end ? se + 1 : end;
 			}
-			len = encode_line(&pk, buf, (int)bl, J->max_read_len, J->reverse);
+			if (c->encode) len = encode_line(&pk, buf, (int)bl, J->max_read_len, J->reverse);
 			if (buf != stackbuf) free(buf);
 			p = q;
 		}
@@ -215,6 +228,15 @@ static void parse_chunk(job_t *J, chunk_t *c)
 	c->out.nwords = ((pk.nbases + 15) >> 4) + 4;          /* pk_reserve keeps >= 8 zero words of slack */
 	c->out.offsets = offs;
 	c->out.nreads = n;
+	c->out.owner = c->owner;
+	c->out.counted_only = !c->encode;
+	if (!c->encode) {                                      /* a foreign chunk: only the number of records matters */
+		free(pk.w);
+		free(offs);
+		c->out.words = NULL;
+		c->out.offsets = NULL;
+		c->out.nwords = 0;
+	}
 }
 
 static void *worker(void *arg)
@@ -289,6 +311,9 @@ int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int 
 		if (cut > prev) {
 			J.chunks[nc].beg = prev;
 			J.chunks[nc].end = cut;
+			J.chunks[nc].owner = (int)(g_shard_chunk % (uint64_t)g_shard_n);
+			J.chunks[nc].encode = g_shard_keep_all || J.chunks[nc].owner == g_shard_rank;
+			g_shard_chunk++;
 			nc++;
 			prev = cut;
 		}

@@ -16,7 +16,15 @@ typedef struct {
 	uint64_t nwords;
 	uint64_t *offsets;      /* nreads + 1, in bases */
 	uint64_t nreads;        /* every record of the chunk, also reads shorter than K+1 (the device skips them) */
+	int owner;              /* multi-process runs (sdt_read_shard): the rank that counts this chunk in pass 1 */
+	int counted_only;       /* 1: the chunk belongs to another rank and was only counted (words == offsets == NULL) */
 } sdt_batch;
+
+/* Multi-process runs (`sdt-pregraph --gpus N`): every rank walks the same chunks in the same order, chunk i (counted
+ * over all files of a pass) belongs to rank i % nranks.  A rank only COUNTS the records of foreign chunks (the read
+ * ordinals of everything after them depend on it) unless keep_all is set (rank 0 keeps every read for the second
+ * pass).  sdt_read_shard_begin resets the chunk counter: call it before each pass over the reads. */
+void sdt_read_shard_begin(int rank, int nranks, int keep_all);
 
 typedef int (*sdt_batch_fn)(void *user, const sdt_batch *b);
 

@@ -447,6 +447,34 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+// nodes counted elsewhere (another rank's shard, sdt_gpu_export_nodes layout) become nodes of this table
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_import(Table<NW> tbl, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ l_links,
+                                                const uint32_t *__restrict__ r_flags, const uint32_t *__restrict__ count,
+                                                const uint64_t *__restrict__ first, uint64_t n, Stats *stats)
+{
+	uint32_t claimed = 0, failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> key;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			key.w[w] = keys[i * NW + w];
+		uint64_t slot, seen;
+		const uint32_t before = claimed;
+		if (!table_locate<NW>(tbl, key, claimed, slot, seen) || claimed == before) {
+			failed++;                                // no room, or the key is already there: shards are disjoint
+			continue;
+		}
+		const uint32_t rf = r_flags[i], cnt = count[i];
+		tbl.ent[slot].val = ((uint64_t)(cnt & 0xFFFFu) << 48) | ((uint64_t)(rf & 0xFFFFFFu) << 24) | (uint64_t)(l_links[i] & 0xFFFFFFu);
+		tbl.aux[slot] = (cnt >> 16) | ((rf >> 24) & 1u ? AUX_LINEAR : 0u) | ((rf >> 25) & 1u ? AUX_DELETED : 0u);
+		if (tbl.first)
+			tbl.first[slot] = first ? first[i] : ORD_NONE;
+	}
+	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
 #include "sdt_superkmer_kernels.cuh"
 #include "sdt_comm.cuh"
 #include "sdt_map_kernels.cuh"
@@ -721,7 +749,7 @@ static int tile_words_for(uint64_t max_read_len)
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << 33;      // k-mers per batch at most (pools: ~11 B per k-mer)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
-static const uint32_t SK_COUNT_ITEM_CHUNKS = 512;           // level-2 chunks per k_sk_count work item (4096 records)
+static const uint32_t SK_COUNT_ITEM_CHUNKS = 2048;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 static void sk_free(sdt_ctx *c)
@@ -1935,8 +1963,8 @@ int sdt_gpu_map_reads(sdt_ctx *c, uint64_t *reads_processed, uint64_t *arcs)
 		return fail(SDT_EINVAL, "ctx is NULL");
 	if (!c->paths_loaded)
 		return fail(SDT_ESTATE, "call sdt_gpu_load_paths first");
-	if (!(c->flags & SDT_FLAG_KEEP_READS))
-		return fail(SDT_ESTATE, "the reads were not kept: init with SDT_FLAG_KEEP_READS");
+	if (!(c->flags & SDT_FLAG_KEEP_READS) && c->kept.empty())
+		return fail(SDT_ESTATE, "the reads were not kept: init with SDT_FLAG_KEEP_READS (or hand them over with sdt_gpu_keep_reads)");
 	HIPCHK(hipSetDevice(c->device));
 	for (int attempt = 0; attempt < 8; attempt++) {
 		// ArcEnt.first starts at ~0 (atomicMin), key/mult at 0
@@ -2598,6 +2626,73 @@ int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
 		if (hv < best) best = hv;
 	}
 	return sk_owner_of_bucket(sk_l1_bucket(sk_bucket_hash(best)), nranks);
+}
+
+int sdt_gpu_keep_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads)
+{
+	if (!c || !packed_words || !offsets)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (nreads == 0)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t maxlen = 0;
+	for (uint64_t i = 0; i < nreads; i++)
+		if (offsets[i + 1] - offsets[i] > maxlen) maxlen = offsets[i + 1] - offsets[i];
+	if (((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
+		return fail(SDT_EINVAL, "packed_words too short");
+	sdt_ctx::KeptBatch kb;
+	kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->ord_base; kb.ord_stride = c->ord_stride; kb.maxlen = maxlen;
+	kb.d_words = nullptr; kb.d_offs = nullptr;
+	HIPCHK(hipMalloc((void **)&kb.d_words, nwords * sizeof(uint32_t)));
+	hipError_t e2 = hipMalloc((void **)&kb.d_offs, (nreads + 1) * sizeof(uint64_t));
+	if (e2 != hipSuccess) { (void)hipFree(kb.d_words); return fail(SDT_ENOMEM, "kept reads: %s", hipGetErrorString(e2)); }
+	c->kept.push_back(kb);
+	HIPCHK(hipMemcpyAsync(kb.d_words, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+	HIPCHK(hipMemcpyAsync(kb.d_offs, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+	HIPCHK(hipStreamSynchronize(c->copy_stream));
+	return SDT_OK;
+}
+
+int sdt_gpu_import_nodes(sdt_ctx *c, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count,
+                         const uint64_t *first, uint64_t n)
+{
+	if (!c || (n && (!keys || !l_links || !r_flags || !count)))
+		return fail(SDT_EINVAL, "NULL argument");
+	if (n == 0)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK) return rc;
+	if ((double)(c->distinct_known + n) > (double)c->slots * MAX_LOAD) {
+		rc = grow_table(c, c->distinct_known + n);
+		if (rc != SDT_OK) return rc;
+	}
+	uint64_t *d_k = nullptr, *d_f = nullptr;
+	uint32_t *d_l = nullptr, *d_r = nullptr, *d_c = nullptr;
+	const uint64_t STEP = 1ULL << 26;                // nodes per upload: bounded staging memory
+	const uint64_t m = n < STEP ? n : STEP;
+	HIPCHK(hipMalloc((void **)&d_k, m * c->nw * 8));
+	HIPCHK(hipMalloc((void **)&d_l, m * 4));
+	HIPCHK(hipMalloc((void **)&d_r, m * 4));
+	HIPCHK(hipMalloc((void **)&d_c, m * 4));
+	if (first && c->d_first) HIPCHK(hipMalloc((void **)&d_f, m * 8));
+	for (uint64_t i0 = 0; i0 < n && rc == SDT_OK; i0 += STEP) {
+		const uint64_t k = n - i0 < STEP ? n - i0 : STEP;
+		HIPCHK(hipMemcpyAsync(d_k, keys + i0 * c->nw, k * c->nw * 8, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_l, l_links + i0, k * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_r, r_flags + i0, k * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_c, count + i0, k * 4, hipMemcpyHostToDevice, c->stream));
+		if (d_f) HIPCHK(hipMemcpyAsync(d_f, first + i0, k * 8, hipMemcpyHostToDevice, c->stream));
+		const int g = scan_grid(c, k);
+		if (c->nw == 1) hipLaunchKernelGGL(k_import<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_import<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		else hipLaunchKernelGGL(k_import<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	(void)hipFree(d_k); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_c);
+	if (d_f) (void)hipFree(d_f);
+	return sync_stats(c);                            // a key that was already there shows up as SDT_EFULL
 }
 
 int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets, uint64_t nreads,

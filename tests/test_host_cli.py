@@ -106,6 +106,32 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("name", ["se100_k23_p8_d1", "pe150_k31_p8", "se250_k63_p8_127mer", "dirty_ragged_k25_cut80"])
+def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus):
+    """`sdt-pregraph --gpus N`: one process per rank (forked before HIP is touched; here all on the one GPU of the box over
+    the shared-memory transport), the read stream cut into small chunks that alternate between the ranks, pass 1 bucket
+    sharded, shards gathered on rank 0 for the graph phases: all five files as the reference wrote them"""
+    info = gu.load_case(name)
+    cfg = materialise(info, tmp_path)
+    cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
+           str(tmp_path / "out"), "--max-k", str(gu.VARIANT_MAXK[info["variant"]]), "--gpus", str(gpus), "--share-device"]
+    if info["d"]:
+        cmd += ["-d", str(info["d"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SDT_CHUNK_BYTES="30000"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")
+    assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
+    assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
+    assert open(tmp_path / "out.preGraphBasic").read() == gu.golden_text(info, "preGraphBasic")
+    assert open(tmp_path / "out.preArc").read() == gu.golden_text(info, "preArc")
+    m = re.search(r"(\d+) nodes allocated, (\d+) kmer in reads, (\d+) kmer processed", r.stdout)
+    assert (int(m.group(1)), int(m.group(2))) == (info["nodes_allocated"], info["kmer_in_reads"])
+    if info["d"]:
+        assert int(re.search(r"(\d+) kmer removed", r.stdout).group(1)) == info["kmer_removed"]
+
+
+@pytest.mark.gpu
 def test_cli_usage_and_errors(pkg, tmp_path):
     exe = bin_path(pkg, "sdt-pregraph")
     r = subprocess.run([exe, "pregraph"], capture_output=True, text=True)

@@ -35,6 +35,7 @@ ap.add_argument("--layout", choices=["se", "pe", "mixed"], default="se", help="l
 ap.add_argument("--d", type=int, default=0, help="-d: delete k-mer links of frequency <= d")
 ap.add_argument("--i", type=int, default=None, help="-i: minor-branch threshold in percent (reference default 5)")
 ap.add_argument("--variant", type=int, default=0, choices=[0, 31, 63, 127], help="reference binary to compare with (default: 31 for K <= 31, else 127)")
+ap.add_argument("--ref-p2", type=int, default=0, help="time the reference a second time with this -p (same FASTQ): kmerFreq must agree")
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 args = ap.parse_args()
 
@@ -178,6 +179,19 @@ try:
                                  os.path.join(tmp, "hm"), "--host-map"] + extra, capture_output=True, text=True, timeout=args.timeout)
             res["host_map_preArc_same_as_ref"] = open(os.path.join(tmp, "hm.preArc")).read() == open(os.path.join(tmp, "ref.preArc")).read()
         res["speedup_full"] = round(res["ref_wall_s"] / res["ours_wall_s"], 2)
+        hr = [l for l in rr.stdout.splitlines() if l.startswith("time spent on hash reads")]
+        if hr:                                       # the reference's own line (prlHashReads.c:623): parse + chop + insert
+            res["ref_hash_reads_s"] = int(hr[0].split(":")[1].split("s")[0])
+            res["ref_hash_reads_kmers_per_s"] = round(res["kmers"] / max(res["ref_hash_reads_s"], 1))
+        if args.ref_p2:
+            t0 = time.time()
+            rr2 = subprocess.run([ref, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.ref_p2), "-o",
+                                  os.path.join(tmp, "ref2")] + common, capture_output=True, text=True, timeout=max(args.timeout, 1800))
+            res["ref_p2"] = args.ref_p2
+            res["ref_p2_wall_s"] = round(time.time() - t0, 2)
+            res["ref_p2_phase_lines"] = [l for l in rr2.stdout.splitlines() if l.startswith("time spent")]
+            res["ref_p2_kmerFreq_same"] = open(os.path.join(tmp, "ref2.kmerFreq"), "rb").read() == open(os.path.join(tmp, "ref.kmerFreq"), "rb").read()
+            res["speedup_full_vs_p2"] = round(res["ref_p2_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
     res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]"))]
     print(json.dumps(res, indent=1))
