@@ -749,7 +749,7 @@ static int tile_words_for(uint64_t max_read_len)
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << 33;      // k-mers per batch at most (pools: ~11 B per k-mer)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
-static const uint32_t SK_COUNT_ITEM_CHUNKS = 2048;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
+static const uint32_t SK_COUNT_ITEM_CHUNKS = 1024;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 static void sk_free(sdt_ctx *c)
@@ -916,7 +916,7 @@ static int sk_list1(sdt_ctx *c)
 	const int g = c->cu_count * 8;
 	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.blk, k.wgs, k.p1, (uint32_t)SK_CAP1);
 	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
-	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1);
+	hipLaunchKernelGGL(k_sk_chunk_place_few, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1, (int)SK_NB1);
 	SK_CHK(hipGetLastError());
 	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
 	SK_CHK(hipStreamSynchronize(c->stream));

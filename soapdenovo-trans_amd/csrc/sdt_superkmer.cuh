@@ -39,7 +39,7 @@ constexpr int SK_NB1 = 1 << SK_L1BITS;
 constexpr int SK_NB2 = 1 << SK_L2BITS;
 constexpr int SK_NBF = SK_NB1 * SK_NB2;          // final buckets
 constexpr int SK_CAP1 = 32;                      // records per level-1 chunk
-constexpr int SK_CAP2 = 8;                       // records per level-2 chunk
+constexpr int SK_CAP2 = 16;                      // records per level-2 chunk
 constexpr uint32_t SK_NOCHUNK = 0xFFFFFFFFu;
 constexpr int SK_MAX_RUN = 64;                   // k-mers per record (6-bit field holds n - 1)
 
