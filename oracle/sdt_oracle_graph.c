@@ -155,10 +155,17 @@ uint64_t sdto_remove_minor_out(sdto_sets *S, int dd, uint64_t *more_linear)
 }
 
 /* ---- clipTipFromNode (cutTipPreGraph.c:43-337) ---- */
-static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin, uint64_t *tip_c)
+
+/* its read-only first half (:43-281): from a dead end n1 along linear nodes to the node `o` the chain runs into.
+ * Returns 0 when there is nothing to decide (n1 linear / deleted / not a dead end / thin and not single / chain longer
+ * than cut_len).  pre_word = the oriented k-mer the walk arrived from, smaller = strand on which `o` was reached,
+ * thin_stop = the walk ended at a linear node that is not single (:163-166). */
+static int tip_walk(sdto_sets *S, const sdto_node *n1, int cut_len, int thin, sdto_node **end, sdto_kmer *pre_out, int *smaller_out,
+                    int *thin_stop)
 {
 	int K = S->K, smaller, ch1, ch;
 	sdto_kmer pre_word, word;
+	*thin_stop = 0;
 	if (n1->linear || n1->deleted) return 0;
 	if (thin && !n1->single) return 0;
 	int in_num = branch2prev(n1), out_num = branch2next(n1);
@@ -179,7 +186,7 @@ static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin
 	/* from here `word` is the canonical form and `bal` its reverse complement, as in the reference */
 	while (o->linear) {
 		count++;
-		if (thin && !o->single) break;
+		if (thin && !o->single) { *thin_stop = 1; break; }
 		if (count > cut_len) return 0;
 		if (smaller) {
 			pre_word = canon;                                         /* oriented = canonical */
@@ -192,6 +199,19 @@ static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin
 		}
 		o = find_oriented(S, word, &smaller, &canon);
 	}
+	*end = o;
+	*pre_out = pre_word;
+	*smaller_out = smaller;
+	return 1;
+}
+
+static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin, uint64_t *tip_c)
+{
+	int K = S->K, smaller, ch, thin_stop;
+	sdto_kmer pre_word;
+	sdto_node *o;
+	if (!tip_walk(S, n1, cut_len, thin, &o, &pre_word, &smaller, &thin_stop))
+		return 0;
 	if (branch2next(o) + branch2prev(o) == 1) {                        /* :282-288 isolated path */
 		(*tip_c)++;
 		n1->deleted = 1;
@@ -221,6 +241,86 @@ static int clip_tip_from_node(sdto_sets *S, sdto_node *n1, int cut_len, int thin
 		return 1;
 	}
 	return 0;
+}
+
+/* ---- read-only probes of the passes above, for pinning the device dry runs (tests/test_gpu_parity.py) ---------------
+ * The same code paths the ordered passes take (tip_walk is literally clipTipFromNode's first half), minus the writes. */
+static sdto_node *node_of(sdto_sets *S, const uint64_t key4[4])
+{
+	sdto_kmer k;
+	memcpy(k.w, key4, sizeof k.w);
+	int sm;
+	return find_oriented(S, k, &sm, NULL);           /* keys handed in are canonical: sm == 1 */
+}
+
+/* overwrite a node's links and flags (bit 0 linear, bit 1 deleted): what a host "write" does to the graph */
+void sdto_node_set(sdto_sets *S, const uint64_t key4[4], uint32_t l_links, uint32_t r_links, int linear, int deleted)
+{
+	sdto_node *n = node_of(S, key4);
+	n->l_links = l_links & 0xFFFFFFu;
+	n->r_links = r_links & 0xFFFFFFu;
+	n->linear = linear != 0;
+	n->deleted = deleted != 0;
+}
+
+/* clipTipFromNode's walk from one node: 1 = there is a decision to take at end_key4, info = ch | sm << 2 | thin_stop << 3 */
+int sdto_tip_walk(sdto_sets *S, const uint64_t key4[4], int cut_len, int thin, uint64_t end_key4[4], int *info)
+{
+	sdto_node *o;
+	sdto_kmer pre;
+	int sm, ts;
+	if (!tip_walk(S, node_of(S, key4), cut_len, thin, &o, &pre, &sm, &ts))
+		return 0;
+	memcpy(end_key4, o->seq.w, sizeof o->seq.w);
+	*info = sdto_first_char(pre, S->K) | (sm << 2) | (ts << 3);
+	return 1;
+}
+
+/* the eight neighbours of a node (left links 0..3, then right links 0..3): state[i] = -1 no link, else the strand flag
+ * `smaller` of the look-up; nb_key4[i] = the neighbour's canonical k-mer */
+void sdto_neighbours(sdto_sets *S, const uint64_t key4[4], uint64_t nb_key4[8][4], int state[8])
+{
+	const sdto_node *n1 = node_of(S, key4);
+	for (int i = 0; i < 8; i++) {
+		const int c = i & 3, left = i < 4;
+		state[i] = -1;
+		if (!(left ? lcov(n1, c) : rcov(n1, c))) continue;
+		int sm;
+		sdto_node *p = find_oriented(S, left ? sdto_prev_kmer(n1->seq, c, S->K) : sdto_next_kmer(n1->seq, c, S->K), &sm, NULL);
+		memcpy(nb_key4[i], p->seq.w, sizeof p->seq.w);
+		state[i] = sm;
+	}
+}
+
+/* clipKmerFromNode's tests (:591-1010) on the graph as it is: cut[i] = 1 when neighbour i (order as above) would be
+ * cut by the ratio test of this junction; returns how many */
+int sdto_minor_out_probe(sdto_sets *S, const uint64_t key4[4], double threshold, int cut[8])
+{
+	const sdto_node *n1 = node_of(S, key4);
+	int K = S->K, smaller, ncut = 0;
+	for (int i = 0; i < 8; i++) cut[i] = 0;
+	if (n1->linear || n1->deleted) return 0;
+	const int in_num = branch2prev(n1), out_num = branch2next(n1);
+	for (int side = 0; side < 2; side++) {
+		if ((side == 0 ? in_num : out_num) <= 1) continue;
+		int mx = 0;
+		for (int c = 0; c < 4; c++)
+			if (side == 0 ? lcov(n1, c) : rcov(n1, c)) {
+				sdto_node *p = find_oriented(S, side == 0 ? sdto_prev_kmer(n1->seq, c, K) : sdto_next_kmer(n1->seq, c, K), &smaller, NULL);
+				if ((int)p->count > mx) mx = (int)p->count;
+			}
+		if (!mx) continue;
+		for (int c = 0; c < 4; c++) {
+			if (!(side == 0 ? lcov(n1, c) : rcov(n1, c))) continue;
+			sdto_node *p = find_oriented(S, side == 0 ? sdto_prev_kmer(n1->seq, c, K) : sdto_next_kmer(n1->seq, c, K), &smaller, NULL);
+			const int temp = (int)p->count;
+			if (temp && (double)temp / mx < threshold) {
+				cut[side * 4 + c] = 1;
+				ncut++;
+			}
+		}
+	}
+	return ncut;
 }
 
 uint64_t sdto_remove_single_tips(sdto_sets *S, uint64_t *more_linear)

@@ -781,7 +781,7 @@ static SkGeo sk_geo(int K, uint64_t max_read_len)
 
 template <int NW, bool TRACK> static size_t sk_count_smem()
 {
-	constexpr int SLOTS = SkCnt<NW>::SLOTS, BW = SkFmt<NW>::BW, TR = SkCntGeo<NW, TRACK>::TILE;
+	constexpr int SLOTS = SkCntGeo<NW, TRACK>::SLOTS, BW = SkFmt<NW>::BW, TR = SkCntGeo<NW, TRACK>::TILE;
 	return (size_t)(NW + (TRACK ? 1 : 0)) * SLOTS * 8 + (size_t)TR * 8 + (size_t)SLOTS * 20 + (size_t)(TR + 2) * 4 +
 	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4;
 }

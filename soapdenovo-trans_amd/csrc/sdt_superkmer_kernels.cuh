@@ -3,23 +3,21 @@
 #pragma once
 
 // k_sk_count geometry: two workgroups per CU wherever the LDS table allows it (their fill / count / merge phases overlap)
+#ifndef SDT_SK_TRACK_GEO
+#define SDT_SK_TRACK_GEO 0
+#endif
 template <int NW, bool TRACK> struct SkCntGeo {
-	static constexpr bool SMALL = TRACK && NW == 1;                       // + 8 B ordinal per slot: halve the workgroup instead of the table
+	// + 8 B ordinal per slot (TRACK, 1-word keys): variant 0 halves the workgroup, variant 1 halves the table
+	static constexpr bool SMALL = TRACK && NW == 1 && SDT_SK_TRACK_GEO == 0;
 	static constexpr int TPB = SMALL ? 512 : 1024;
 	static constexpr int TILE = SMALL ? 256 : 512;                        // records per tile
 	static constexpr int TILE_LOG2 = SMALL ? 8 : 9;
+	static constexpr int SLOTS = (TRACK && NW == 1 && SDT_SK_TRACK_GEO == 1) ? 1024 : 2048;   // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
+	static constexpr int FLUSH_AT = SLOTS / 2;                            // flush + clear between rounds past this load ...
+	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
 };
 constexpr int SK_L2_TPB = 256;
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
-template <int NW> struct SkCnt {
-	static constexpr int SLOTS = 2048;                           // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
-#ifndef SDT_SK_FLUSH_AT
-#define SDT_SK_FLUSH_AT 1024
-#define SDT_SK_MAXFILL 2040
-#endif
-	static constexpr int FLUSH_AT = SDT_SK_FLUSH_AT;             // flush + clear between rounds past this load ...
-	static constexpr int MAXFILL = SDT_SK_MAXFILL;               // ... a round counts as many k-mers as there are slots left below this one
-};
 
 // Chunk ids come from the pool in blocks of SK_BLK per workgroup (s_blk = next id | end of block << 32): one global
 // atomic per SK_BLK chunks.  (One atomicAdd per chunk on the single pool counter was measured to cap BOTH scatter
@@ -119,64 +117,81 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 #define SK_TICK(i) do { } while (0)
 #endif
 	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		for (int i = tid; i < bits_words; i += TPB)  // the run-start bitmap (the barriers inside stage_tile order this)
+			s_bits[i] = 0;
 		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * SK_TILE_READS, nreads, K, SK_TILE_READS);
 		const int npos = (int)tv.rb[tv.nr];
 		SK_TICK(0);
-		const bool strips = w <= 49;                 // a wave's 64 lanes hold at least 16 whole windows
+		const bool strips = w <= 49;                 // a wave's 64 lanes hold at least 15 whole windows
+		const uint32_t nk = tv.nk, nkr = (nk + 63u) & ~63u;
 		if (strips) {
-			// bucket hash of the window of w m-mers that starts at every base position: lane l of a strip hashes the
-			// m-mer at its position, a doubling min over shuffles gives min[l, l + P), two of those cover [l, l + w)
-			const int valid = 64 - (w - 1), nstrips = (npos + valid - 1) / valid, lane = tid & 63;
+			// One wave per read, strips of 64 - w k-mers.  Lane l of a strip hashes the canonical m-mer at its position; a
+			// doubling min over shuffles gives min[l, l + P), two of those cover the window [l, l + w) of the k-mer that
+			// starts there; its bucket hash goes to LDS (the emission reads it back) and is compared with the lane before:
+			// a k-mer starts a run when it is the first of its read, when its bucket differs from its predecessor's, or
+			// when the record is full.  Lane 0 carries the predecessor of the strip's first k-mer.  The run starts are
+			// OR-ed into the tile's bitmap (zeroed below, before the barriers of stage_tile of the NEXT tile).
+			const int valid = 64 - w, lane = tid & 63;
 			int P = 1;
 			while (2 * P <= w)
 				P *= 2;
-			for (int st = tid >> 6; st < nstrips; st += TPB / 64) {
-				const int p = st * valid + lane;
-				uint32_t x = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
-				for (int d = 1; d < P; d <<= 1) {
-					const uint32_t y = __shfl_down(x, d);
+			for (int r = tid >> 6; r < tv.nr; r += TPB / 64) {
+				const int nk_r = (int)(tv.pre[r + 1] - tv.pre[r]);
+				const int rb_r = (int)tv.rb[r], len_r = (int)tv.rb[r + 1] - rb_r;
+				for (int j0 = 0; j0 < nk_r; j0 += valid) {
+					const int j = j0 + lane - 1, p = rb_r + j;
+					uint32_t x = (j >= 0 && j + m <= len_r) ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+					for (int d = 1; d < P; d <<= 1) {
+						const uint32_t y = __shfl_down(x, d);
+						x = y < x ? y : x;
+					}
+					const uint32_t y = __shfl_down(x, w - P);
 					x = y < x ? y : x;
+					const uint32_t bh = sk_bucket_hash(x), pbh = __shfl_up(bh, 1);
+					const bool kv = lane >= 1 && lane <= valid && j < nk_r;
+					if (kv)
+						s_hv[p] = bh;
+					const bool start = kv && (j == 0 || (j & (ncap - 1)) == 0 || sk_final_bucket(bh) != sk_final_bucket(pbh));
+					const unsigned long long mask = __ballot(start) >> 1;         // bit i: k-mer j0 + i of the read
+					if (lane == 0 && mask) {
+						const uint32_t q0 = tv.pre[r] + (uint32_t)j0, sh = q0 & 63u;
+						atomicOr(&s_bits[q0 >> 6], mask << sh);
+						if (sh && (mask >> (64u - sh)))
+							atomicOr(&s_bits[(q0 >> 6) + 1], mask >> (64u - sh));
+					}
 				}
-				const uint32_t y = __shfl_down(x, w - P);
-				x = y < x ? y : x;
-				if (lane < valid && p < npos)
-					s_hv[p] = sk_bucket_hash(x);
 			}
 		} else {
-			// hash of the canonical m-mer at every base position of the tile
+			// long windows (K > 59): hash of the canonical m-mer at every base position of the tile, windows scanned per k-mer
 			for (int p = tid; p < npos; p += TPB)
 				s_hv[p] = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
+			__syncthreads();
+			for (uint32_t q = tid; q < nkr; q += TPB) {
+				bool start = false;
+				if (q < nk) {
+					const int r = tile_find_read(tv.pre, q);
+					const int j = (int)(q - tv.pre[r]);
+					const int p = (int)tv.rb[r] + j;
+					if (j == 0 || (j & (ncap - 1)) == 0) {    // ncap is a power of two
+						start = true;
+					} else {
+						uint32_t sh = s_hv[p];                              // m-mers this k-mer shares with its predecessor
+						for (int i = 1; i <= w - 2; i++) {
+							const uint32_t v = s_hv[p + i];
+							sh = v < sh ? v : sh;
+						}
+						const uint32_t a = s_hv[p + w - 1], b = s_hv[p - 1];
+						const uint32_t mine = a < sh ? a : sh, prevm = b < sh ? b : sh;
+						start = sk_final_bucket(sk_bucket_hash(mine)) != sk_final_bucket(sk_bucket_hash(prevm));
+					}
+				}
+				const unsigned long long mask = __ballot(start);
+				if ((tid & 63) == 0)
+					s_bits[q >> 6] = mask;
+			}
 		}
 		__syncthreads();
 		SK_TICK(1);
-		// which k-mers start a run: first of a read, bucket differs from the k-mer before it, or the record is full
-		const uint32_t nk = tv.nk, nkr = (nk + 63u) & ~63u;
-		for (uint32_t q = tid; q < nkr; q += TPB) {
-			bool start = false;
-			if (q < nk) {
-				const int r = tile_find_read(tv.pre, q);
-				const int j = (int)(q - tv.pre[r]);
-				const int p = (int)tv.rb[r] + j;
-				if (j == 0 || (j & (ncap - 1)) == 0) {    // ncap is a power of two
-					start = true;
-				} else if (strips) {
-					start = sk_final_bucket(s_hv[p]) != sk_final_bucket(s_hv[p - 1]);
-				} else {
-					uint32_t sh = s_hv[p];                              // m-mers this k-mer shares with its predecessor
-					for (int i = 1; i <= w - 2; i++) {
-						const uint32_t v = s_hv[p + i];
-						sh = v < sh ? v : sh;
-					}
-					const uint32_t a = s_hv[p + w - 1], b = s_hv[p - 1];
-					const uint32_t mine = a < sh ? a : sh, prevm = b < sh ? b : sh;
-					start = sk_final_bucket(sk_bucket_hash(mine)) != sk_final_bucket(sk_bucket_hash(prevm));
-				}
-			}
-			const unsigned long long mask = __ballot(start);
-			if ((tid & 63) == 0)
-				s_bits[q >> 6] = mask;
-		}
-		__syncthreads();
 		// exclusive prefix of the popcounts: s_pc[i] = run starts before word i
 		const int nw64 = (int)(nkr >> 6);
 		if (tid < 64) {
@@ -513,13 +528,13 @@ template <int NW> __device__ inline uint32_t sk_lds_hash(const Key<NW> &k)
 
 // find-or-claim in the LDS table; -1: no room (full table or too many probes)
 template <int NW, int SLOTS>
-__device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key)
+__device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
 {
 	uint32_t s = sk_lds_hash<NW>(key) & (SLOTS - 1);
 	for (int probe = 0; probe < 96;) {
 		uint64_t k0 = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (k0 == KEY_EMPTY) {
-			if (__hip_atomic_load(s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)SkCnt<NW>::MAXFILL)
+			if (__hip_atomic_load(s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= maxfill)
 				return -1;
 			const uint64_t old = atomicCAS(&s_key[s], (unsigned long long)KEY_EMPTY, (unsigned long long)(NW == 1 ? key.w[0] : KEY_LOCKED));
 			if (old == KEY_EMPTY) {
@@ -589,7 +604,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
                                                          Table<NW> tbl, Stats *stats)
 {
-	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCnt<NW>::SLOTS;
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCntGeo<NW, TRACK>::SLOTS;
+	constexpr uint32_t FLUSH_AT = SkCntGeo<NW, TRACK>::FLUSH_AT, MAXFILL = SkCntGeo<NW, TRACK>::MAXFILL;
 	constexpr int SK_CNT_TPB = SkCntGeo<NW, TRACK>::TPB, SK_CNT_TILE_LOG2 = SkCntGeo<NW, TRACK>::TILE_LOG2;
 	constexpr int TR = SkCntGeo<NW, TRACK>::TILE;    // records per tile: the first TR lanes bring one each
 	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
@@ -717,7 +733,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 			// rounds of 4 k-mers per free slot: barriers are what this loop pays for, and even error-rich data brings fewer
 			// than one new key per four occurrences (a k-mer that does find the table full takes the direct path)
 			for (uint32_t qb = 0, qe; qb < total; qb = qe) {
-				const uint32_t room = 4u * ((uint32_t)SkCnt<NW>::MAXFILL - s_fill);   // s_fill < FLUSH_AT here (uniform: read after a barrier)
+				const uint32_t room = 4u * (MAXFILL - s_fill);                        // s_fill < FLUSH_AT here (uniform: read after a barrier)
 				qe = qb + room < total ? qb + room : total;
 				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
 					int lo = 0, hi = TR;
@@ -732,7 +748,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 					const int len = hp + nr + K - 1 + sk_hdr_next(h0);
 					uint32_t prev, next;
 					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-					const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key);
+					const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key, MAXFILL);
 					if (s >= 0) {
 						sk_lds_update(s_cnt, s_lk, s, prev, next);
 						if (TRACK) {
@@ -750,7 +766,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 				}
 				__syncthreads();
 				const bool last = qe == total && cb + CPT >= c1;
-				if (last || s_fill >= (uint32_t)SkCnt<NW>::FLUSH_AT) {
+				if (last || s_fill >= FLUSH_AT) {
 					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
 					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise
 					const bool owned = whole && s_spilled == 0;

@@ -97,6 +97,14 @@ def lib():
     L.sdto_remove_minor_out.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.sdto_write_vertex.restype = C.c_uint64
     L.sdto_write_vertex.argtypes = [C.c_void_p, C.c_char_p]
+    L.sdto_node_set.restype = None
+    L.sdto_node_set.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    L.sdto_tip_walk.restype = C.c_int
+    L.sdto_tip_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    L.sdto_neighbours.restype = None
+    L.sdto_neighbours.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sdto_minor_out_probe.restype = C.c_int
+    L.sdto_minor_out_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     _lib = L
     return L
 
@@ -166,6 +174,50 @@ class Oracle:
 
     def write_vertex(self, path):
         return self.L.sdto_write_vertex(self.h, path.encode())
+
+    # read-only probes of the cleaning passes (oracle/sdt_oracle_graph.c): the device dry runs are compared with them.
+    # Keys are rows of 4 uint64, most significant first (the export layout).
+    @staticmethod
+    def _key4(key_row):
+        a = np.zeros(4, dtype=np.uint64)
+        kr = np.asarray(key_row, dtype=np.uint64).reshape(-1)
+        a[4 - kr.size:] = kr
+        return a
+
+    def node_set(self, key_row, l_links, r_links, linear, deleted):
+        k = self._key4(key_row)
+        self.L.sdto_node_set(self.h, k.ctypes.data, int(l_links), int(r_links), int(linear), int(deleted))
+
+    def tip_walk(self, key_row, cut_len, thin):
+        """None, or (end key as a Python int, info = ch | sm << 2 | thin_stop << 3)"""
+        k, e, info = self._key4(key_row), np.zeros(4, dtype=np.uint64), C.c_int()
+        if not self.L.sdto_tip_walk(self.h, k.ctypes.data, cut_len, int(thin), e.ctypes.data, C.byref(info)):
+            return None
+        v = 0
+        for x in e:
+            v = (v << 64) | int(x)
+        return v, info.value
+
+    def neighbours(self, key_row):
+        """8 entries (left links 0..3, right links 0..3): None, or (neighbour key as int, smaller)"""
+        k, nb, st = self._key4(key_row), np.zeros((8, 4), dtype=np.uint64), np.zeros(8, dtype=np.int32)
+        self.L.sdto_neighbours(self.h, k.ctypes.data, nb.ctypes.data, st.ctypes.data)
+        out = []
+        for i in range(8):
+            if st[i] < 0:
+                out.append(None)
+            else:
+                v = 0
+                for x in nb[i]:
+                    v = (v << 64) | int(x)
+                out.append((v, int(st[i])))
+        return out
+
+    def minor_out_probe(self, key_row, threshold):
+        """cut flags of the 8 neighbours under clipKmerFromNode's ratio test on the graph as it is"""
+        k, cut = self._key4(key_row), np.zeros(8, dtype=np.int32)
+        n = self.L.sdto_minor_out_probe(self.h, k.ctypes.data, float(threshold), cut.ctypes.data)
+        return n, [int(x) for x in cut]
 
     def export(self):
         n = self.node_count()

@@ -474,6 +474,11 @@ def test_tip_walks_equal_reference_walk(pkg, synth, K, L):
     tx = synth.make_transcriptome(20, seed=K)
     codes, offs = synth.sample_reads(*tx, n_reads=3000, read_len=L, seed=K + 3, err=0.004, ragged=True)
     rng = np.random.default_rng(K)
+    # the pinned C oracle holds the same graph (its tip_walk IS the first half of its clipTipFromNode, which the
+    # reference's *.vertex goldens pin): the Python restatement below is a second opinion
+    orc = ob.Oracle(K, nsets=3)
+    orc.add_reads(codes, offs)
+    orc.mark()
     with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
         g.push_reads(synth.pack_2bit(codes), offs)
         g.finish_count()
@@ -482,11 +487,18 @@ def test_tip_walks_equal_reference_walk(pkg, synth, K, L):
         perm = rng.permutation(len(keys))
         keys, l, rf, cnt = keys[perm], l[perm].copy(), rf[perm].copy(), cnt[perm]
         ki = keys_to_int(keys)
+        index_of = {k: i for i, k in enumerate(ki)}
         g.set_node_index(keys)
         for round_ in range(2):
             for thin in (0, 1):
                 end, info = g.tip_walks(bool(thin), 2 * K)
                 want = py_tip_walks(ki, l, rf, cnt, K, thin, 2 * K)
+                for i in range(len(keys)):
+                    w = orc.tip_walk(keys[i], 2 * K, thin)
+                    if w is None:
+                        assert end[i] == np.uint64(0xFFFFFFFFFFFFFFFF), (i, thin, "oracle: no walk")
+                    else:
+                        assert (int(end[i]), int(info[i])) == (index_of[w[0]], w[1]), (i, thin, "oracle walk")
                 n_walks = 0
                 for i, w in enumerate(want):
                     if w is None:
@@ -515,6 +527,8 @@ def test_tip_walks_equal_reference_walk(pkg, synth, K, L):
                         if b < 4:
                             l[j] &= np.uint32(~(63 << (6 * b)) & 0xFFFFFFFF)
                 g.update_nodes(keys[pick], l[pick], rf[pick])
+                for j in pick:
+                    orc.node_set(keys[j], int(l[j]) & 0xFFFFFF, int(rf[j]) & 0xFFFFFF, (int(rf[j]) >> 24) & 1, (int(rf[j]) >> 25) & 1)
         # the mirror now equals what we sent: export agrees (flags and links), counts untouched
         k2, l2, rf2, c2 = g.export_nodes()
         got = {k: (int(a), int(b) & 0x3FFFFFF, int(c)) for k, a, b, c in zip(keys_to_int(k2), l2, rf2, c2)}
@@ -746,6 +760,10 @@ def test_minor_out_dry_run_equals_reference_rule(pkg, synth, K, L):
     tx = synth.make_transcriptome(15, seed=K + 1)
     codes, offs = synth.sample_reads(*tx, n_reads=4000, read_len=L, seed=K + 5, err=0.006)
     rng = np.random.default_rng(K)
+    orc = ob.Oracle(K, nsets=3)                       # the pinned C oracle on the same graph (clipKmerFromNode's own tests)
+    orc.add_reads(codes, offs)
+    orc.mark()
+    NONE = (1 << 64) - 1
     with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
         g.push_reads(synth.pack_2bit(codes), offs)
         g.finish_count()
@@ -754,11 +772,25 @@ def test_minor_out_dry_run_equals_reference_rule(pkg, synth, K, L):
         perm = rng.permutation(len(keys))
         keys, l, rf, cnt = keys[perm], l[perm], rf[perm], cnt[perm]
         ki = keys_to_int(keys)
+        index_of = {k: i for i, k in enumerate(ki)}
         g.set_node_index(keys)
         for thr in (0.05, 0.3):
             rec, nj = g.minor_out_dry(thr)
             junc, need, nbrs = py_minor_out_dry(ki, l, rf, cnt, K, thr)
             got_j = {int(r[0]): [int(x) for x in r[1:]] for r in rec[:nj]}
+            # C oracle: which nodes cut at all, whom, and every reported neighbour table
+            o_junc, o_need = set(), set()
+            for i in range(len(keys)):
+                ncut, cut = orc.minor_out_probe(keys[i], thr)
+                if ncut:
+                    o_junc.add(i)
+                    nb = orc.neighbours(keys[i])
+                    o_need |= {index_of[nb[t][0]] for t in range(8) if cut[t]}
+            assert set(got_j) == o_junc
+            assert {int(r[0]) for r in rec[nj:]} == o_need - o_junc
+            for r in rec:
+                nb = orc.neighbours(keys[int(r[0])])
+                assert [int(x) for x in r[1:]] == [NONE if e is None else (index_of[e[0]] << 1) | e[1] for e in nb]
             assert got_j == junc and len(junc) > 0
             got_c = {int(r[0]): [int(x) for x in r[1:]] for r in rec[nj:]}
             assert set(got_c) == need - set(junc)
