@@ -324,7 +324,7 @@ def main():
     stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
     log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms],
-        {k: v for k, v in sk_counters.items() if "ticks" not in k})
+        {k: v for k, v in sk_counters.items() if "ticks" not in k or v})
     ms_per_step = dt / args.steps * 1e3
     value = kmers_total * args.steps / dt
     B = algorithmic_bytes_per_kmer(L, K)
