@@ -783,7 +783,7 @@ template <int NW, bool TRACK> static size_t sk_count_smem()
 {
 	constexpr int SLOTS = SkCntGeo<NW, TRACK>::SLOTS, BW = SkFmt<NW>::BW, TR = SkCntGeo<NW, TRACK>::TILE;
 	return (size_t)(NW + (TRACK ? 1 : 0)) * SLOTS * 8 + (size_t)TR * 8 + (size_t)SLOTS * 20 + (size_t)(TR + 2) * 4 +
-	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4;
+	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4 + (SkCntGeo<NW, TRACK>::COARSE_INDEX ? (size_t)TR * 4 * 2 : 0);
 }
 
 static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)

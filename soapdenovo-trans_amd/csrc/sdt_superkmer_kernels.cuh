@@ -12,6 +12,7 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TPB = SMALL ? 512 : 1024;
 	static constexpr int TILE = SMALL ? 256 : 512;                        // records per tile
 	static constexpr int TILE_LOG2 = SMALL ? 8 : 9;
+	static constexpr bool COARSE_INDEX = !SMALL;                           // (the small geometry has no LDS to spare for it)
 	static constexpr int SLOTS = (TRACK && NW == 1 && SDT_SK_TRACK_GEO == 1) ? 1024 : 2048;   // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
 	static constexpr int FLUSH_AT = SLOTS / 2;                            // flush + clear between rounds past this load ...
 	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
@@ -607,6 +608,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCntGeo<NW, TRACK>::SLOTS;
 	constexpr uint32_t FLUSH_AT = SkCntGeo<NW, TRACK>::FLUSH_AT, MAXFILL = SkCntGeo<NW, TRACK>::MAXFILL;
 	constexpr int SK_CNT_TPB = SkCntGeo<NW, TRACK>::TPB, SK_CNT_TILE_LOG2 = SkCntGeo<NW, TRACK>::TILE_LOG2;
+	constexpr bool COARSE = SkCntGeo<NW, TRACK>::COARSE_INDEX;
 	constexpr int TR = SkCntGeo<NW, TRACK>::TILE;    // records per tile: the first TR lanes bring one each
 	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
 	constexpr int NWAVES = TR / 64;
@@ -618,6 +620,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 	uint32_t *s_lk = s_cnt + SLOTS;                                      // 4 x SLOTS
 	uint32_t *s_pre = s_lk + 4 * SLOTS;                                  // TR + 2
 	uint32_t *s_words = s_pre + TR + 2;                                  // LDS_LEAD + TR * BW * 2 + TAIL_PAD
+	unsigned short *s_idx = (unsigned short *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);   // TR * 4: record of every 16th k-mer
 	__shared__ uint32_t s_fill, s_item, s_spilled, s_wsum[NWAVES];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
@@ -701,6 +704,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 			if (cb + CPT < c1)
 				fetch(cb + CPT);
 			// exclusive prefix sum of the k-mers per record
+			const uint32_t n_mine = n;
 			if (tid < TR) {
 				uint32_t x = n;
 #pragma unroll
@@ -723,8 +727,14 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 					if (wv < (tid >> 6)) wbase += v;
 					total += v;
 				}
-				if (tid < TR)
+				if (tid < TR) {
 					s_pre[tid] = wbase + n;
+					// coarse index: every 16th k-mer of the tile lies in exactly one record, which writes itself there
+					// (the look-up below starts from it instead of searching the whole prefix array)
+					const uint32_t lo = wbase + n, hi = lo + n_mine;
+					for (uint32_t m16 = (lo + 15u) & ~15u; COARSE && m16 < hi; m16 += 16u)
+						s_idx[m16 >> 4] = (unsigned short)tid;
+				}
 				if (tid == 0)
 					s_pre[TR] = total;
 			}
@@ -736,13 +746,21 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 				const uint32_t room = 4u * (MAXFILL - s_fill);                        // s_fill < FLUSH_AT here (uniform: read after a barrier)
 				qe = qb + room < total ? qb + room : total;
 				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
-					int lo = 0, hi = TR;
+					int r;
+					if (COARSE) {
+						r = s_idx[q >> 4];                   // the record of k-mer q & ~15; q's own is at most a few records on
+						while (s_pre[r + 1] <= q)
+							r++;
+					} else {
+						int lo = 0, hi = TR;
 #pragma unroll
-					for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
-						const int mid = (lo + hi) >> 1;
-						if (s_pre[mid] <= q) lo = mid; else hi = mid;
+						for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
+							const int mid = (lo + hi) >> 1;
+							if (s_pre[mid] <= q) lo = mid; else hi = mid;
+						}
+						r = lo;
 					}
-					const int r = lo, j = (int)(q - s_pre[r]);
+					const int j = (int)(q - s_pre[r]);
 					const uint64_t h0 = s_h0[r];
 					const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
 					const int len = hp + nr + K - 1 + sk_hdr_next(h0);
