@@ -121,7 +121,10 @@ int sdt_gpu_finish_count(sdt_ctx *ctx, uint64_t *kmers_processed, uint64_t *node
  *   allreduce_i64            COLLECTIVE sum, for counters and the 257 kmerFreq bins (freqStat sums per-thread bins,
  *                            prlHashReads.c:1004-1014)
  *   comm_stats               bytes this rank sent / received in exchanges and the time they took on the exchange stream
- *   sdt_kmer_owner           host copy of the owner function (tests, host graph phases): rank of a canonical k-mer */
+ *   shard_ranges / sdt_kmer_bucket   who owns what: rank r owns the level-1 buckets [first_bucket[r], first_bucket[r + 1])
+ *                            (nranks + 1 entries), cut on the FIRST sharded call so that the ranks' bucket weights -- taken
+ *                            from a sample of every rank's reads -- are equal; sdt_kmer_bucket is the host copy of the device's
+ *                            bucket function (canonical k-mer -> 0..255).  sdt_kmer_owner: the owner under EQUAL ranges. */
 typedef struct { unsigned char bytes[128]; } sdt_comm_id;
 int sdt_gpu_comm_id(sdt_comm_id *id);
 int sdt_gpu_comm_init(sdt_ctx *ctx, const sdt_comm_id *id, int rank, int nranks);
@@ -132,6 +135,8 @@ int sdt_gpu_push_reads_sharded(sdt_ctx *ctx, const uint32_t *packed_words, uint6
                                uint64_t nreads);
 int sdt_gpu_allreduce_i64(sdt_ctx *ctx, int64_t *vals, int n);
 int sdt_gpu_comm_stats(sdt_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_recv, double *exchange_ms, uint64_t *exchanges);
+int sdt_gpu_shard_ranges(const sdt_ctx *ctx, uint32_t *first_bucket);
+int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K);
 int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks);
 /* After pass 1 the order-dependent graph phases (cutTipPreGraph.c, node2edge.c) run on ONE host over ALL nodes: rank 0
  * takes the other ranks' exported shards (sdt_gpu_export_nodes arrays; keys are disjoint by construction) into its own

@@ -85,6 +85,8 @@ _ABI = [
     ("sdt_gpu_comm_stats", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_double),
                                       _c.POINTER(_c.c_uint64)]),
     ("sdt_kmer_owner", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
+    ("sdt_kmer_bucket", _c.c_int, [_c.c_void_p, _c.c_int]),
+    ("sdt_gpu_shard_ranges", _c.c_int, [_c.c_void_p, _c.c_void_p]),
     ("sdt_comm_selftest_shm", _c.c_int, [_c.c_char_p, _c.c_int, _c.c_int, _c.c_int]),
     ("sdt_gpu_import_nodes", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_keep_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64]),
@@ -243,6 +245,12 @@ class PregraphGPU:
         v = np.ascontiguousarray(values, dtype=np.int64).copy()
         self._check(self.lib.sdt_gpu_allreduce_i64(self._ctx, _ptr(v), v.size))
         return v
+
+    def shard_ranges(self, nranks: int) -> np.ndarray:
+        """first level-1 bucket of every rank (+ the end): cut on the first sharded call"""
+        a = np.zeros(nranks + 1, dtype=np.uint32)
+        self._check(self.lib.sdt_gpu_shard_ranges(self._ctx, _ptr(a)))
+        return a
 
     def comm_stats(self):
         """(bytes sent, bytes received, milliseconds on the exchange stream, exchanges) of this rank"""
@@ -422,6 +430,12 @@ def kmer_owner(key_words_msw_first, K: int, nranks: int) -> int:
     """rank that owns a canonical k-mer under bucket sharding (host copy of the device function)"""
     a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
     return load_library().sdt_kmer_owner(a.ctypes.data, K, nranks)
+
+
+def kmer_bucket(key_words_msw_first, K: int) -> int:
+    """level-1 minimizer bucket (0..255) of a canonical k-mer (host copy of the device function)"""
+    a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
+    return load_library().sdt_kmer_bucket(a.ctypes.data, K)
 
 
 def write_kmerfreq(path: str, hist) -> None:

@@ -560,10 +560,18 @@ struct sdt_ctx {
 		uint32_t pending_items = 0;
 		std::vector<SkItem> items;
 		uint64_t kmers_scattered = 0;
+		// which rank owns which level-1 buckets: contiguous ranges [ranges[r], ranges[r + 1]), balanced by the bucket
+		// weights of a sample of the first call's reads (the same on every rank: the weights are all-gathered)
+		bool have_ranges = false;
+		uint32_t ranges[65] = {0};
 	} sh;
 	// second pass (prlRead2edge): reads kept from pass 1, path words, patch table, arcs
 	struct KeptBatch { uint32_t *d_words; uint64_t *d_offs; uint64_t nwords, nreads, ord_base, ord_stride, maxlen; };
 	std::vector<KeptBatch> kept;
+	// kept batches live in a few large slabs (two hipMallocs per 32 MiB batch were thousands of synchronous calls on
+	// the ingest path): bump allocation, everything is released together
+	struct KeepSlab { uint8_t *p; size_t size, used; };
+	std::vector<KeepSlab> keep_slabs;
 	void *d_patch = nullptr;
 	uint64_t patch_slots = 0;
 	ArcEnt *d_arcs = nullptr;
@@ -587,6 +595,34 @@ struct sdt_ctx {
 };
 
 static const double MAX_LOAD = 0.70;
+
+static void *keep_alloc(sdt_ctx *c, size_t bytes)
+{
+	bytes = (bytes + 255) & ~(size_t)255;
+	if (c->keep_slabs.empty() || c->keep_slabs.back().size - c->keep_slabs.back().used < bytes) {
+		sdt_ctx::KeepSlab sl;
+		sl.size = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+		sl.used = 0;
+		sl.p = nullptr;
+		if (hipMalloc((void **)&sl.p, sl.size) != hipSuccess) {
+			sl.size = bytes;                             // a full slab does not fit any more: exactly what is needed
+			if (hipMalloc((void **)&sl.p, sl.size) != hipSuccess)
+				return nullptr;
+		}
+		c->keep_slabs.push_back(sl);
+	}
+	sdt_ctx::KeepSlab &b = c->keep_slabs.back();
+	void *r = b.p + b.used;
+	b.used += bytes;
+	return r;
+}
+
+static void keep_release(sdt_ctx *c)
+{
+	for (auto &sl : c->keep_slabs) (void)hipFree(sl.p);
+	c->keep_slabs.clear();
+	c->kept.clear();
+}
 
 template <int NW> static Table<NW> table_of(const sdt_ctx *c)
 {
@@ -850,6 +886,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 		break;
 	}
 	k.wgs = wgs;
+	const double t_alloc0 = comm_now();
 	HIPCHK(hipMalloc((void **)&k.p1.recs, (size_t)k.p1.chunks * SK_CAP1 * rw * 8));
 	HIPCHK(hipMalloc((void **)&k.p1.meta, (size_t)k.p1.chunks * 4));
 	HIPCHK(hipMalloc((void **)&k.p1.next, 64));
@@ -879,6 +916,9 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	HIPCHK(hipMalloc((void **)&k.next_item, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t)));
 	k.cap_kmers = cap;
 	k.ready = true;
+	if (getenv("SDT_TIMING"))
+		fprintf(stderr, "[libsdt_gpu] super-k-mer pools for %llu k-mers per batch: %.1f GiB in %.0f ms\n", (unsigned long long)cap,
+		        ((double)k.p1.chunks * SK_CAP1 + (double)k.p2.chunks * SK_CAP2) * rw * 8 / (1 << 30), (comm_now() - t_alloc0) * 1e3);
 	return sk_reset_pool1(c);
 }
 
@@ -1112,8 +1152,9 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 	for (uint64_t r0 = 0; r0 < nreads;) {
 		if (k.pending_kmers + per_read * SK_TILE_READS > k.cap_kmers) {
 			rc = sk_flush(c);
-			// a stream that keeps filling the pools gets larger ones: fewer batches = fewer merges per distinct key
-			if (rc == SDT_OK && !k.cap_is_max)
+			// a stream that keeps filling SMALL pools gets larger ones: fewer batches = fewer merges per distinct key.  Past 2^31
+			// k-mers they stay: replacing tens of GiB was seen to stall for seconds in hipFree / hipMalloc now and then.
+			if (rc == SDT_OK && !k.cap_is_max && k.cap_kmers < (1ULL << 31))
 				rc = sk_alloc(c, k.cap_kmers * 2);
 			if (rc != SDT_OK)
 				return rc;
@@ -1221,9 +1262,7 @@ static int sk_flush_sharded(sdt_ctx *c)
 	rc = cm.allgather_host(k.h_off1, mat.data(), (SK_NB1 + 1) * sizeof(uint32_t));
 	if (rc != SDT_OK) return rc;
 	auto M = [&](int r, uint32_t b) { return mat[(size_t)r * (SK_NB1 + 1) + b]; };
-	std::vector<uint32_t> blo(n + 1);
-	for (int r = 0; r < n; r++) blo[r] = sk_first_bucket(r, n);
-	blo[n] = SK_NB1;
+	std::vector<uint32_t> blo(h.ranges, h.ranges + n + 1);
 	// sub-rounds: every rank can see every rank's inflow, so all agree without another message
 	uint32_t S = 1;
 	for (int d = 0; d < n; d++) {
@@ -1474,7 +1513,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
 	if (c->d_cursors) (void)hipFree(c->d_cursors);
-	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
+	keep_release(c);
 	if (c->d_patch) (void)hipFree(c->d_patch);
 	if (c->d_arcs) (void)hipFree(c->d_arcs);
 	if (c->d_idx) (void)hipFree(c->d_idx);
@@ -1513,8 +1552,7 @@ int sdt_gpu_reset(sdt_ctx *c)
 		if (rcr != SDT_OK)
 			return rcr;
 	}
-	for (auto &kb : c->kept) { (void)hipFree(kb.d_words); (void)hipFree(kb.d_offs); }
-	c->kept.clear();
+	keep_release(c);
 	c->ctg_ord = 0;
 	c->index_final = false;
 	c->paths_loaded = false;
@@ -1657,10 +1695,10 @@ int sdt_gpu_push_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords
 		// the batch stays resident for the second pass: own buffers instead of the recycled staging pair
 		sdt_ctx::KeptBatch kb;
 		kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->ord_base; kb.ord_stride = c->ord_stride; kb.maxlen = maxlen;
-		kb.d_words = nullptr; kb.d_offs = nullptr;
-		HIPCHK(hipMalloc((void **)&kb.d_words, nwords * sizeof(uint32_t)));
-		hipError_t e2 = hipMalloc((void **)&kb.d_offs, (nreads + 1) * sizeof(uint64_t));
-		if (e2 != hipSuccess) { (void)hipFree(kb.d_words); return fail(SDT_ENOMEM, "kept reads: %s", hipGetErrorString(e2)); }
+		kb.d_words = (uint32_t *)keep_alloc(c, nwords * sizeof(uint32_t));
+		kb.d_offs = (uint64_t *)keep_alloc(c, (nreads + 1) * sizeof(uint64_t));
+		if (!kb.d_words || !kb.d_offs)
+			return fail(SDT_ENOMEM, "kept reads: no device memory for another batch (%zu slabs held); run with --host-map", c->keep_slabs.size());
 		c->kept.push_back(kb);
 		HIPCHK(hipMemcpyAsync(kb.d_words, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
 		HIPCHK(hipMemcpyAsync(kb.d_offs, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
@@ -2608,10 +2646,21 @@ int sdt_gpu_comm_stats(sdt_ctx *c, uint64_t *bytes_sent, uint64_t *bytes_recv, d
 	return SDT_OK;
 }
 
-int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
+int sdt_gpu_shard_ranges(const sdt_ctx *c, uint32_t *first_bucket)
 {
-	// the rank whose table holds a canonical k-mer under bucket sharding: minimizer -> bucket -> owner, as on the device
-	if (!key_words_msw_first || K < 13 || K > 127 || nranks < 1)
+	if (!c || !first_bucket)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->sh.have_ranges)
+		return fail(SDT_ESTATE, "no sharded call yet: the bucket ranges are cut on the first one");
+	for (int r = 0; r <= c->comm.nranks; r++)
+		first_bucket[r] = c->sh.ranges[r];
+	return SDT_OK;
+}
+
+int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K)
+{
+	// the level-1 minimizer bucket (0..255) of a canonical k-mer, as on the device
+	if (!key_words_msw_first || K < 13 || K > 127)
 		return -1;
 	const int nw = K <= 31 ? 1 : (K <= 63 ? 2 : 4), m = sk_minimizer_len(K);
 	uint32_t best = 0xFFFFFFFFu;
@@ -2625,7 +2674,16 @@ int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
 		const uint32_t hv = sk_mmer_hash(sk_canon_mmer(fw, m));
 		if (hv < best) best = hv;
 	}
-	return sk_owner_of_bucket(sk_l1_bucket(sk_bucket_hash(best)), nranks);
+	return (int)sk_l1_bucket(sk_bucket_hash(best));
+}
+
+int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
+{
+	// owner under EQUAL bucket ranges (what a context uses before its first sharded call has weighed the buckets)
+	const int b = sdt_kmer_bucket(key_words_msw_first, K);
+	if (b < 0 || nranks < 1)
+		return -1;
+	return sk_owner_of_bucket((uint32_t)b, nranks);
 }
 
 int sdt_gpu_keep_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads)
@@ -2642,10 +2700,10 @@ int sdt_gpu_keep_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords
 		return fail(SDT_EINVAL, "packed_words too short");
 	sdt_ctx::KeptBatch kb;
 	kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->ord_base; kb.ord_stride = c->ord_stride; kb.maxlen = maxlen;
-	kb.d_words = nullptr; kb.d_offs = nullptr;
-	HIPCHK(hipMalloc((void **)&kb.d_words, nwords * sizeof(uint32_t)));
-	hipError_t e2 = hipMalloc((void **)&kb.d_offs, (nreads + 1) * sizeof(uint64_t));
-	if (e2 != hipSuccess) { (void)hipFree(kb.d_words); return fail(SDT_ENOMEM, "kept reads: %s", hipGetErrorString(e2)); }
+	kb.d_words = (uint32_t *)keep_alloc(c, nwords * sizeof(uint32_t));
+	kb.d_offs = (uint64_t *)keep_alloc(c, (nreads + 1) * sizeof(uint64_t));
+	if (!kb.d_words || !kb.d_offs)
+		return fail(SDT_ENOMEM, "kept reads: no device memory for another batch (%zu slabs held); run with --host-map", c->keep_slabs.size());
 	c->kept.push_back(kb);
 	HIPCHK(hipMemcpyAsync(kb.d_words, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
 	HIPCHK(hipMemcpyAsync(kb.d_offs, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
@@ -2737,6 +2795,42 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 	}
 	rc = shard_alloc(c);
 	if (rc != SDT_OK) return rc;
+	if (!c->sh.have_ranges) {
+		// Ownership.  Minimizer buckets are far from equal (a highly expressed transcript's minimizers are giants), so
+		// equal ranges of buckets would leave the ranks unequal work.  Weigh the buckets on a sample -- the first 2^18
+		// reads of every rank's slice through the level-1 scatter -- and cut the 256 buckets into contiguous ranges of
+		// equal weight.  Every rank computes the same cut from the all-gathered counts; the sample's records are dropped.
+		const uint64_t sample = nreads < (1ULL << 18) ? nreads : (1ULL << 18);
+		if (sample) {
+			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, sample, maxlen, c->ord_base);
+			if (rc != SDT_OK) return rc;
+		}
+		rc = sk_list1(c);
+		if (rc != SDT_OK) return rc;
+		std::vector<uint32_t> mat((size_t)cm.nranks * (SK_NB1 + 1));
+		rc = cm.allgather_host(k.h_off1, mat.data(), (SK_NB1 + 1) * sizeof(uint32_t));
+		if (rc != SDT_OK) return rc;
+		uint64_t wsum[SK_NB1 + 1];
+		wsum[0] = 0;
+		for (uint32_t b = 0; b < (uint32_t)SK_NB1; b++) {
+			uint64_t wgt = 1;                            // (+1: an empty sample still gives every bucket a weight)
+			for (int r = 0; r < cm.nranks; r++)
+				wgt += mat[(size_t)r * (SK_NB1 + 1) + b + 1] - mat[(size_t)r * (SK_NB1 + 1) + b];
+			wsum[b + 1] = wsum[b] + wgt;
+		}
+		c->sh.ranges[0] = 0;
+		for (int r = 1; r < cm.nranks; r++) {
+			const uint64_t want_w = wsum[SK_NB1] * (uint64_t)r / (uint64_t)cm.nranks;
+			uint32_t b = c->sh.ranges[r - 1] + 1;        // every rank owns at least one bucket
+			while (b < (uint32_t)SK_NB1 - (uint32_t)(cm.nranks - r) && wsum[b] < want_w)
+				b++;
+			c->sh.ranges[r] = b;
+		}
+		c->sh.ranges[cm.nranks] = SK_NB1;
+		c->sh.have_ranges = true;
+		rc = sk_reset_pool1(c);
+		if (rc != SDT_OK) return rc;
+	}
 	// every rank must cut its reads into the same number of rounds
 	uint64_t capmine = k.cap_kmers;
 	std::vector<uint64_t> caps(cm.nranks);

@@ -84,7 +84,8 @@ def _shard_worker(name, rank, n, K, nreads, L, out, env):
         tot = g.allreduce(np.concatenate([hist, [kmers, nodes, linear]]))
         keys, l, rf, cnt, first = g.export_nodes(with_first=True)
         sent, recv, ms, nx = g.comm_stats()
-        np.savez(out, keys=keys, l=l, rf=rf, cnt=cnt, first=first, tot=tot, local=np.array([kmers, nodes]), comm=np.array([sent, recv, nx]))
+        np.savez(out, keys=keys, l=l, rf=rf, cnt=cnt, first=first, tot=tot, local=np.array([kmers, nodes]), comm=np.array([sent, recv, nx]),
+                 ranges=g.shard_ranges(n))
 
 
 @pytest.mark.gpu
@@ -123,8 +124,13 @@ def test_sharded_ranks_sharing_one_gpu(tmp_path, n, K, env):
         return v
     want = {kint(k): (int(a), int(b), int(c), int(f)) for k, a, b, c, f in zip(okeys, ol, orr, ocnt, ofirst)}
     got = {}
+    ranges = np.load(outs[0])["ranges"]
+    assert ranges[0] == 0 and ranges[n] == 256 and (np.diff(ranges.astype(np.int64)) >= 1).all()
+    sizes = []
     for r in range(n):
         z = np.load(outs[r])
+        assert (z["ranges"] == ranges).all(), "the ranks disagree about who owns what"
+        sizes.append(int(z["local"][0]))
         assert int(z["tot"][257]) == o.kmers_in_reads() and int(z["tot"][258]) == o.node_count() and int(z["tot"][259]) == olinear
         assert (z["tot"][:257] == ohist).all()
         assert len(z["keys"]) == int(z["local"][1])
@@ -132,10 +138,12 @@ def test_sharded_ranks_sharing_one_gpu(tmp_path, n, K, env):
             ki = kint(k)
             assert ki not in got, "a k-mer sits on two ranks"
             got[ki] = (int(a), int(b) & 0xFFFFFF, int(c), int(f))
-            assert pkg.kmer_owner([int(x) for x in k], K, n) == r
+            assert ranges[r] <= pkg.kmer_bucket([int(x) for x in k], K) < ranges[r + 1]
         if n > 1:
             assert int(z["comm"][0]) > 0 and int(z["comm"][2]) >= 2
     assert got == want
+    # the ranges were cut by weight: no rank counts more than 1.6x the mean (equal ranges of these buckets: up to 2x)
+    assert max(sizes) <= 1.6 * sum(sizes) / n, sizes
 
 
 @pytest.mark.gpu
