@@ -513,7 +513,8 @@ struct sdt_ctx {
 	// bookkeeping for growth: upper bound of distinct nodes without syncing
 	uint64_t distinct_known = 0;       // as of the last sync
 	uint64_t kmers_known = 0;          // occurrences counted as of the last sync (new nodes per occurrence: bound of the next launch)
-	uint64_t kmers_since_sync = 0;     // launched since then
+	uint64_t kmers_since_sync = 0;     // launched since then (an upper bound of the new nodes they may bring)
+	uint64_t hard_since_sync = 0;      // k-mers launched since then by the locality pipeline, whatever its own bound said
 	uint64_t kmers_total_host = 0;
 	uint64_t kmers_offered = 0;        // upper bound of the k-mers handed to pass 1 since the last reset (picks the kernel family)
 	// route scratch
@@ -695,6 +696,7 @@ static int sync_stats(sdt_ctx *c)
 	c->distinct_known = c->h_stats->distinct;
 	c->kmers_known = c->h_stats->kmers;
 	c->kmers_since_sync = 0;
+	c->hard_since_sync = 0;
 	return SDT_OK;
 }
 
@@ -1005,8 +1007,8 @@ static int sk_count_all(sdt_ctx *c)
 	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
 	// A launch must find room for every node it may create.  "Every occurrence is a new node" is hopeless for a batch of
 	// 2^33 k-mers, so: a first launch of at most 2^26 k-mers under that bound, then launches bounded by twice the rate of
-	// new nodes per occurrence seen so far (later data brings fewer new nodes, not more; a wrong guess ends in SDT_EFULL,
-	// never in a silent loss: table_merge reports a full table).
+	// new nodes per occurrence seen so far (later data usually brings fewer new nodes, not more; should it bring more, the load
+	// factor suffers until the next look but the table cannot fill: see the 95 % rule below).
 	std::vector<uint32_t> first_item;                // first item of every launch
 	std::vector<uint64_t> launch_kmers;
 	uint64_t acc = 0;
@@ -1045,9 +1047,17 @@ static int sk_count_all(sdt_ctx *c)
 			if (guess < bound) bound = guess;
 		}
 		rc = ensure_room(c, bound);
+		// the guess keeps the load factor; this keeps the table from FILLING should the guess be wrong: whatever the data,
+		// the nodes known + every k-mer launched since + this launch must fit 95 % of the slots
+		if (rc == SDT_OK && (double)(c->distinct_known + c->hard_since_sync + launch_kmers[l]) > 0.95 * (double)c->slots) {
+			rc = sync_stats(c);
+			if (rc == SDT_OK && (double)(c->distinct_known + launch_kmers[l]) > 0.95 * (double)c->slots)
+				rc = grow_table(c, c->distinct_known + launch_kmers[l]);
+		}
 		if (rc == SDT_OK)
 			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
 		c->kmers_since_sync += bound;
+		c->hard_since_sync += launch_kmers[l];
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
 	return rc;
@@ -1543,6 +1553,7 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->distinct_known = 0;
 	c->kmers_known = 0;
 	c->kmers_since_sync = 0;
+	c->hard_since_sync = 0;
 	c->kmers_total_host = 0;
 	c->kmers_offered = 0;
 	c->ord_base = 0;
@@ -1556,6 +1567,8 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->ctg_ord = 0;
 	c->index_final = false;
 	c->paths_loaded = false;
+	c->sh.pending = false;                           // (a sharded call that failed half-way leaves nothing behind)
+	c->sh.items.clear();
 	if (c->d_idx) (void)hipFree(c->d_idx);
 	c->d_idx = nullptr;
 	c->idx_slots = c->idx_n = 0;

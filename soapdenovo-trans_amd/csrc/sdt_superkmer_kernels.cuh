@@ -13,7 +13,10 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TILE = SMALL ? 256 : 512;                        // records per tile
 	static constexpr int TILE_LOG2 = SMALL ? 8 : 9;
 	static constexpr bool COARSE_INDEX = !SMALL;                           // (the small geometry has no LDS to spare for it)
-	static constexpr int SLOTS = (TRACK && NW == 1 && SDT_SK_TRACK_GEO == 1) ? 1024 : 2048;   // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
+#ifndef SDT_SK_SLOTS_NW2
+#define SDT_SK_SLOTS_NW2 2048
+#endif
+	static constexpr int SLOTS = (TRACK && NW == 1 && SDT_SK_TRACK_GEO == 1) ? 1024 : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);   // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
 	static constexpr int FLUSH_AT = SLOTS / 2;                            // flush + clear between rounds past this load ...
 	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
 };
