@@ -828,7 +828,7 @@ static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
 {
 	if (c->nranks > 1 || (c->flags & SDT_FLAG_CONTIG_INDEX))
 		return false;
-	if (max_read_len < (uint64_t)c->K + 1 || max_read_len > 65535)
+	if (max_read_len < (uint64_t)c->K + 1 || max_read_len > (uint64_t)SK_MAX_READ_LEN)
 		return false;
 	return sk_geo(c->K, max_read_len).smem <= 160 * 1024;
 }
@@ -1357,9 +1357,9 @@ static int sk_flush_sharded(sdt_ctx *c)
 			HIPCHK(hipStreamWaitEvent(c->stream, h.ev_xdone[slot], 0));
 		if (plan.pre[n]) {
 			const unsigned g = (unsigned)c->cu_count * 8;
-			if (c->nw == 1) hipLaunchKernelGGL(k_sk_gather<4>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
-			else if (c->nw == 2) hipLaunchKernelGGL(k_sk_gather<6>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
-			else hipLaunchKernelGGL(k_sk_gather<8>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			if (c->nw == 1) hipLaunchKernelGGL(k_sk_gather<SkFmt<1>::REC_WORDS>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_sk_gather<SkFmt<2>::REC_WORDS>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
+			else hipLaunchKernelGGL(k_sk_gather<SkFmt<4>::REC_WORDS>, dim3(g), dim3(256), 0, c->stream, k.p1, k.list1, plan, h.send[slot], h.send_meta[slot], h.recv[slot], h.recv_meta[slot]);
 			HIPCHK(hipGetLastError());
 		}
 		HIPCHK(hipEventRecord(h.ev_gather[slot], c->stream));
@@ -1644,7 +1644,8 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	// (a small job is not worth the pipeline's fixed cost -- two host syncs and scans over 2^18 buckets, ~3 ms -- unless asked for)
 	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && c->kmers_offered + nreads * per_read < (1ULL << 27);
 	c->kmers_offered += nreads * per_read;
-	if (!(c->flags & SDT_FLAG_DIRECT) && !sk_small && sk_applicable(c, max_read_len)) {
+	const bool sk_ord_ok = c->ord_base + nreads * c->ord_stride < SK_MAX_READ_ORDINAL;      // what a record header can number
+	if (!(c->flags & SDT_FLAG_DIRECT) && !sk_small && sk_ord_ok && sk_applicable(c, max_read_len)) {
 		const int rcs = sk_scatter(c, d_words, d_offs, nreads, max_read_len);
 		if (rcs == SDT_OK)
 			c->ord_base += nreads * c->ord_stride;     // the next batch continues the read stream
@@ -2794,8 +2795,10 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		c->ord_base += nreads * c->ord_stride;
 		return SDT_OK;
 	}
-	if (maxlen > 65535 || sk_geo(c->K, maxlen).smem > 160 * 1024)
+	if (maxlen > (uint64_t)SK_MAX_READ_LEN || sk_geo(c->K, maxlen).smem > 160 * 1024)
 		return fail(SDT_EINVAL, "reads of %llu bases do not fit the LDS tile of the sharded path", (unsigned long long)maxlen);
+	if (c->ord_base + nreads * c->ord_stride >= SK_MAX_READ_ORDINAL)
+		return fail(SDT_EINVAL, "read ordinals past 2^34 do not fit a super-k-mer record");
 	const uint64_t per_read = maxlen - c->K + 1;
 	uint64_t want = maxreads * per_read;
 	if (want > (1ULL << 31)) want = 1ULL << 31;       // rounds of at most 2 G k-mers per rank: the exchange overlaps the next round

@@ -12,7 +12,8 @@
 // Consecutive k-mers of a read mostly share their minimizer; a maximal run with one bucket is cut out of the
 // read as ONE record (a "super-k-mer"): 8 B of header + the run's bases with one base of context either side
 // (the prev / next neighbour codes of chopKmer4read, prlHashReads.c:215-230,275-308, are read off them).  That
-// is ~3 B per k-mer occurrence instead of the 16-B (key, meta) record of the per-k-mer exchange.
+// is ~3 B per k-mer occurrence (24-byte records of ~8 k-mers at K = 31) instead of the 16-B (key, meta) record of the
+// per-k-mer exchange.
 //
 //   k_sk_scatter_reads   chop + minimizers per tile of 64 reads in LDS, cut the runs, append each record to
 //                        its level-1 bucket (256 of them).  Space comes from a pool of fixed-size chunks; every
@@ -44,17 +45,20 @@ constexpr uint32_t SK_NOCHUNK = 0xFFFFFFFFu;
 constexpr int SK_MAX_RUN = 64;                   // k-mers per record (6-bit field holds n - 1)
 
 // record: REC_WORDS 64-bit words
-//   [0] read ordinal << 24 | position of the run's first k-mer in its read << 8 | (n - 1) << 2 | has_prev << 1 | has_next
-//   [1] bucket hash (low 32 bits)
-//   [2..] the bases [first k-mer - has_prev, last k-mer + K + has_next), 2 bits each, first base in the MOST
-//         significant pair of word 2 (the packed-read convention of include/sdt_gpu.h), zero padded
+//   [0] read ordinal (34 bits) << 30 | position of the run's first k-mer in its read (12 bits) << 18 |
+//       level-2 bucket (10 bits) << 8 | (n - 1) << 2 | has_prev << 1 | has_next
+//   [1..] the bases [first k-mer - has_prev, last k-mer + K + has_next), 2 bits each, first base in the MOST
+//         significant pair of word 1 (the packed-read convention of include/sdt_gpu.h), zero padded
+// (the level-1 bucket of a record is where it lies; the level-2 bucket rides in the header: 24 / 40 / 56 bytes per record)
 template <int NW> struct SkFmt {
 	static constexpr int BW = NW == 1 ? 2 : (NW == 2 ? 4 : 6);     // base words: 64 / 128 / 192 bases
-	static constexpr int REC_WORDS = 2 + BW;                       // 32 / 48 / 64 bytes
+	static constexpr int REC_WORDS = 1 + BW;                       // 24 / 40 / 56 bytes
 	static constexpr int CAP_BASES = 32 * BW;
 };
+constexpr uint64_t SK_MAX_READ_ORDINAL = 1ULL << 34;             // reads of one run the header can number
+constexpr int SK_MAX_READ_LEN = 4095;                            // positions the header can hold
 
-__host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 4 : (nw == 2 ? 6 : 8); }
+__host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 3 : (nw == 2 ? 5 : 7); }
 
 // minimizer length for a k-mer size (window w = K - m + 1 m-mers)
 __host__ __device__ inline int sk_minimizer_len(int K) { return K >= 23 ? 11 : (K >= 17 ? 9 : 7); }
@@ -125,15 +129,18 @@ __host__ __device__ inline uint64_t sk_stream_word(const uint32_t *words, int p)
 	return sh ? ((hi << sh) | ((uint64_t)words[wi + 2] >> (32 - sh))) : hi;
 }
 
-__host__ __device__ inline uint64_t sk_header(uint64_t read_ord, uint32_t pos, int n, int has_prev, int has_next)
+__host__ __device__ inline uint64_t sk_header(uint64_t read_ord, uint32_t pos, uint32_t l2, int n, int has_prev, int has_next)
 {
-	return (read_ord << 24) | ((uint64_t)(pos & 0xFFFFu) << 8) | ((uint64_t)(n - 1) << 2) | ((uint64_t)has_prev << 1) | (uint64_t)has_next;
+	return (read_ord << 30) | ((uint64_t)(pos & 0xFFFu) << 18) | ((uint64_t)(l2 & 0x3FFu) << 8) | ((uint64_t)(n - 1) << 2) |
+	       ((uint64_t)has_prev << 1) | (uint64_t)has_next;
 }
 __host__ __device__ inline int sk_hdr_n(uint64_t h) { return (int)((h >> 2) & 63u) + 1; }
 __host__ __device__ inline int sk_hdr_prev(uint64_t h) { return (int)((h >> 1) & 1u); }
 __host__ __device__ inline int sk_hdr_next(uint64_t h) { return (int)(h & 1u); }
-__host__ __device__ inline uint32_t sk_hdr_pos(uint64_t h) { return (uint32_t)((h >> 8) & 0xFFFFu); }
-__host__ __device__ inline uint64_t sk_hdr_read(uint64_t h) { return h >> 24; }
+__host__ __device__ inline uint32_t sk_hdr_l2(uint64_t h) { return (uint32_t)((h >> 8) & 0x3FFu); }
+__host__ __device__ inline uint32_t sk_hdr_pos(uint64_t h) { return (uint32_t)((h >> 18) & 0xFFFu); }
+__host__ __device__ inline uint64_t sk_hdr_read(uint64_t h) { return h >> 30; }
+static_assert(SK_L2BITS == 10, "the record header holds a 10-bit level-2 bucket");
 
 // device state of the pipeline (all device pointers)
 struct SkPool {

@@ -82,12 +82,18 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 	}
 }
 
+// records are 8-byte aligned (24 / 40 / 56 bytes): 8-byte accesses, consecutive lanes still cover consecutive bytes
 template <int RW> __device__ inline void sk_store_record(uint64_t *dst, const uint64_t (&rec)[RW])
 {
-	ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst);
 #pragma unroll
-	for (int i = 0; i < RW / 2; i++)
-		d[i] = make_ulonglong2(rec[2 * i], rec[2 * i + 1]);
+	for (int i = 0; i < RW; i++)
+		dst[i] = rec[i];
+}
+template <int RW> __device__ inline void sk_load_record(const uint64_t *src, uint64_t (&rec)[RW])
+{
+#pragma unroll
+	for (int i = 0; i < RW; i++)
+		rec[i] = src[i];
 }
 
 // ---- level 1: reads -> super-k-mer records in 256 buckets ----------------------------------------------------
@@ -260,8 +266,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 			if (sk_reserve(s_cur, &s_blk, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, g_cnt, chunk, pos)) {
 				const int len = hp + n + K - 1 + hn, ps = p0 - hp;
 				uint64_t rec[RW];
-				rec[0] = sk_header(read_ord, (uint32_t)j, n, hp, hn);
-				rec[1] = bh;
+				rec[0] = sk_header(read_ord, (uint32_t)j, sk_l2_bucket(bh), n, hp, hn);
 #pragma unroll
 				for (int k = 0; k < BW; k++) {
 					uint64_t wv = 0;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 						if (keep < 32)
 							wv &= ~0ULL << (64 - 2 * keep);
 					}
-					rec[2 + k] = wv;
+					rec[1 + k] = wv;
 				}
 				sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
 			} else {
@@ -446,14 +451,8 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		if (slot >= (src.meta[chunk] >> 24))
 			continue;
 		uint64_t rec[RW];
-		const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(src.recs + ((size_t)chunk * SK_CAP1 + slot) * RW);
-#pragma unroll
-		for (int i = 0; i < RW / 2; i++) {
-			const ulonglong2 v = s[i];
-			rec[2 * i] = v.x;
-			rec[2 * i + 1] = v.y;
-		}
-		const uint32_t b2 = sk_l2_bucket((uint32_t)rec[1]);
+		sk_load_record<RW>(src.recs + ((size_t)chunk * SK_CAP1 + slot) * RW, rec);
+		const uint32_t b2 = sk_hdr_l2(rec[0]);
 		atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
 		uint32_t dchunk, pos;
 		if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, g_cnt, dchunk, pos))
@@ -673,13 +672,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 				if (ci < c1) {
 					const uint32_t chunk = list2[ci];
 					if (slot < (pool.meta[chunk] >> 24)) {
-						const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW);
-#pragma unroll
-						for (int i = 0; i < RW / 2; i++) {
-							const ulonglong2 v = s[i];
-							nx[2 * i] = v.x;
-							nx[2 * i + 1] = v.y;
-						}
+						sk_load_record<RW>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW, nx);
 						nx_ok = true;
 					}
 				}
@@ -698,8 +691,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 					n = (uint32_t)sk_hdr_n(h0);
 #pragma unroll
 					for (int i = 0; i < BW; i++) {
-						words[tid * BW * 2 + 2 * i] = (uint32_t)(nx[2 + i] >> 32);
-						words[tid * BW * 2 + 2 * i + 1] = (uint32_t)nx[2 + i];
+						words[tid * BW * 2 + 2 * i] = (uint32_t)(nx[1 + i] >> 32);
+						words[tid * BW * 2 + 2 * i + 1] = (uint32_t)nx[1 + i];
 					}
 				}
 				s_h0[tid] = h0;

@@ -112,6 +112,31 @@ def test_saturation_and_hot_keys(pkg, synth, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+def test_growth_when_later_data_is_all_new(pkg, synth, mode):
+    """the pipeline sizes a count launch by the rate of new nodes seen so far; here the history lies: 40 000 copies of one
+    read first (one new node per 40 000 occurrences), then random reads (every k-mer a new node) into a table that starts
+    far too small -- the table must grow in time, nothing may be lost"""
+    K, L = 31, 100
+    rng = np.random.default_rng(9)
+    one = rng.integers(0, 4, size=L, dtype=np.uint8)
+    first = np.tile(one, 40_000)
+    second = rng.integers(0, 4, size=60_000 * L, dtype=np.uint8)
+    o = ob.Oracle(K, nsets=4)
+    with pkg.PregraphGPU(K, est_distinct=1 << 12, flags=mode) as g:
+        for codes in (first, second):
+            offs = (np.arange(len(codes) // L + 1, dtype=np.uint64) * L)
+            o.add_reads(codes, offs)
+            g.push_reads(synth.pack_2bit(codes), offs)
+            g.finish_count()                        # the second push meets a table sized for the first
+        kmers, nodes = g.finish_count()
+        assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+        hist, linear = g.mark_and_hist()
+        ohist, olinear = o.mark()
+        assert linear == olinear and (hist == ohist).all()
+        assert node_dict_gpu(g) == node_dict_oracle(o)
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_edge_cases(pkg, synth, mode):
     """empty batch, reads shorter than K+1 (skipped, prlHashReads.c:592), a read of exactly K+1, reset"""
     K = 25
