@@ -544,6 +544,8 @@ struct sdt_ctx {
 		bool flushing = false;
 		// statistics of the last flush (sdt_gpu_pipeline_stats)
 		uint64_t st_records = 0, st_chunks1 = 0, st_chunks2 = 0, st_flushes = 0;
+		uint64_t l2_in_total = 0;      // k-mers that entered the count stage (sum of the level-2 bucket sizes): Stats.sk_counted must match
+		bool exchanged = false;        // records left for / came from other ranks: Stats.sk_emitted is not this rank's input
 	} sk;
 	// multi-GPU (sdt_comm.cuh): communicator + double-buffered send / receive chunk buffers of the exchange
 	Comm comm;
@@ -693,6 +695,16 @@ static int sync_stats(sdt_ctx *c)
 	if (c->h_stats->probe_fail)
 		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full or route bucket overflow)",
 		            (unsigned long long)c->h_stats->probe_fail);
+	// conservation in the locality pipeline: every k-mer cut into a record must come out of the count stage.  (A
+	// workgroup geometry that lost a chunk now and then was found with exactly this comparison; it costs two counters.)
+	if (!c->sk.flushing) {
+		if (c->h_stats->sk_counted != c->sk.l2_in_total)
+			return fail(SDT_ESTATE, "locality pipeline lost k-mers: %llu entered the count stage, %llu were counted",
+			            (unsigned long long)c->sk.l2_in_total, (unsigned long long)c->h_stats->sk_counted);
+		if (!c->sk.exchanged && c->h_stats->sk_emitted != c->sk.l2_in_total)
+			return fail(SDT_ESTATE, "locality pipeline lost k-mers: %llu were cut into records, %llu reached the count stage",
+			            (unsigned long long)c->h_stats->sk_emitted, (unsigned long long)c->sk.l2_in_total);
+	}
 	c->distinct_known = c->h_stats->distinct;
 	c->kmers_known = c->h_stats->kmers;
 	c->kmers_since_sync = 0;
@@ -800,7 +812,11 @@ static void sk_free(sdt_ctx *c)
 	void *host[] = {k.h_off1, k.h_off2, k.h_kpre2, k.h_items, k.h_citems};
 	for (void *p : host)
 		if (p) (void)hipHostFree(p);
+	const uint64_t in_total = k.l2_in_total;         // (the conservation totals belong to the run, not to the pools)
+	const bool exchanged = k.exchanged;
 	k = sdt_ctx::SkState();
+	k.l2_in_total = in_total;
+	k.exchanged = exchanged;
 }
 
 // LDS bytes of the level-1 scatter for a maximum read length
@@ -978,9 +994,18 @@ static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_
 	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
 	if (nitems) {
 		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
-		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), 0, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		// ONE workgroup (512 lanes) per CU -- the unused dynamic LDS is there to keep a second one away.  Every workgroup has
+		// 1024 chunks open and a record is 24..56 bytes of a 128-byte line: with 8 x 256 lanes per CU the lines being
+		// filled (2 M of them, 270 MB) did not live in L2 until they were full and reached HBM as partial writes
+		// (22.3 ms per 6 G k-mers); 256 K open lines do (17.8 ms).  SDT_SK_L2_PAD_KB: A/B switch.  (1024 lanes per
+		// workgroup were 1 ms faster still and lost a chunk of records in half of the runs of the hot-bucket test --
+		// 512 and 256 never did in the same stress; sync_stats' conservation check is the net under this.)
+		static const size_t l2pad = (size_t)(getenv("SDT_SK_L2_PAD_KB") ? atoi(getenv("SDT_SK_L2_PAD_KB")) : SK_L2_LDS_PAD_KB) * 1024;
+		const void *l2fn = c->nw == 1 ? (const void *)k_sk_scatter_records<1> : (c->nw == 2 ? (const void *)k_sk_scatter_records<2> : (const void *)k_sk_scatter_records<4>);
+		SK_CHK(hipFuncSetAttribute(l2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2pad));
+		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
 		SK_CHK(hipGetLastError());
 	}
 	if (after_l2)
@@ -1000,6 +1025,7 @@ static int sk_count_all(sdt_ctx *c)
 	SK_CHK(hipStreamSynchronize(c->stream));
 	k.st_chunks2 = k.h_off2[SK_NBF];
 	k.st_flushes++;
+	k.l2_in_total += k.h_kpre2[SK_NBF];
 	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
 	// k-mers (every one might be a new node: ensure_room)
 	int rc = SDT_OK;
@@ -1131,7 +1157,29 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 		hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, \
 		                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
 	} while (0)
-	if (c->nw == 1) SK_SCATTER(1);
+	// one lane per read where the window length has an instantiation and the run list can hold a read
+	const int w = c->K - m + 1;
+	static const bool no_seq = getenv("SDT_SK_STRIPS") != NULL;          // A/B switch (tools/)
+	if (c->nw == 1 && (w == 13 || w == 21) && per_read <= (uint64_t)SK_SEQ_MAX_KMERS && !no_seq) {
+		const int mtw = (int)(((uint64_t)SK_SEQ_TILE * max_read_len + 16 + 15) / 16) + TAIL_PAD + 1;
+		const size_t smem = (size_t)SK_NB1 * 8 + (size_t)(SK_SEQ_TILE + 2) * 4 + (size_t)SK_SEQ_TILE * SK_SEQ_RUNCAP * 4 + (size_t)(LDS_LEAD + mtw) * 4;
+		const uint64_t nt = (nr + SK_SEQ_TILE - 1) / SK_SEQ_TILE;
+		unsigned g2;
+#define SK_SEQ(W)                                                                                                                  \
+		do {                                                                                                                       \
+			HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads_seq<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+			int per_cu = 0;                          /* persistent workgroups: exactly the resident ones (a second wave of them would run half empty) */ \
+			HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sk_scatter_reads_seq<W>, SK_SEQ_TILE, smem));              \
+			uint64_t res = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)c->cu_count;                                                    \
+			if (res > k.wgs) res = k.wgs;                                                                                             \
+			g2 = (unsigned)(nt < res ? nt : res);                                                                                     \
+			hipLaunchKernelGGL(k_sk_scatter_reads_seq<W>, dim3(g2), dim3(SK_SEQ_TILE), smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, mtw, \
+			                   k.p1, k.cursors, k.blk, k.cnt1, table_of<1>(c), c->d_stats, ob, c->ord_stride);                        \
+		} while (0)
+		if (w == 13) SK_SEQ(13);
+		else SK_SEQ(21);
+#undef SK_SEQ
+	} else if (c->nw == 1) SK_SCATTER(1);
 	else if (c->nw == 2) SK_SCATTER(2);
 	else SK_SCATTER(4);
 #undef SK_SCATTER
@@ -1265,6 +1313,7 @@ static int sk_flush_sharded(sdt_ctx *c)
 	sdt_ctx::SkState &k = c->sk;
 	Comm &cm = c->comm;
 	const int n = cm.nranks, me = cm.rank;
+	k.exchanged = true;
 	int rc = sk_list1(c);
 	if (rc != SDT_OK) return rc;
 	// everybody's chunk counts per bucket
@@ -1550,6 +1599,8 @@ int sdt_gpu_reset(sdt_ctx *c)
 	if (rc != SDT_OK)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
+	c->sk.l2_in_total = 0;
+	c->sk.exchanged = false;
 	c->distinct_known = 0;
 	c->kmers_known = 0;
 	c->kmers_since_sync = 0;

@@ -20,7 +20,14 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int FLUSH_AT = SLOTS / 2;                            // flush + clear between rounds past this load ...
 	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
 };
-constexpr int SK_L2_TPB = 256;
+#ifndef SDT_SK_L2_TPB
+#define SDT_SK_L2_TPB 512
+#endif
+constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one large workgroup per CU (see sk_split)
+#ifndef SDT_SK_L2_DEPTH
+#define SDT_SK_L2_DEPTH 2
+#endif
+constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 
 // Chunk ids come from the pool in blocks of SK_BLK per workgroup (s_blk = next id | end of block << 32): one global
@@ -55,9 +62,11 @@ __device__ inline void sk_retire_block(unsigned long long blk, const SkPool &poo
 
 // Reserve one record slot in the open chunk of local bucket `lb` (s_cur[lb] = chunk << 32 | records used).  The lane
 // that takes the slot one past the end opens a new chunk (and counts it for its bucket: the counting sort of the
-// chunk ids by bucket needs no pass of its own).  false: the pool is exhausted (the caller takes its slow path).
+// chunk ids by bucket needs no pass of its own).  The counters s_cnt[lb] are the WORKGROUP's (LDS), added to the
+// global ones once at its end: one global atomic per chunk on 256 counters (8 cache lines) ran at ~0.8 G/s and
+// was what bounded the level-1 scatter.  false: the pool is exhausted (the caller takes its slow path).
 __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long *s_blk, uint32_t lb, uint32_t meta_bucket,
-                                  uint32_t cap, const SkPool &pool, uint32_t *__restrict__ g_cnt, uint32_t &chunk, uint32_t &pos)
+                                  uint32_t cap, const SkPool &pool, uint32_t *s_cnt, uint32_t &chunk, uint32_t &pos)
 {
 	for (;;) {
 		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
@@ -71,7 +80,7 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 				id = SK_NOCHUNK;
 			} else {
 				pool.meta[id] = meta_bucket | (cap << 24);
-				atomicAdd(&g_cnt[meta_bucket], 1u);
+				atomicAdd(&s_cnt[lb], 1u);
 			}
 			atomicExch(&s_cur[lb], ((unsigned long long)id << 32) | 1ULL);
 			chunk = id;
@@ -112,14 +121,17 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 	unsigned long long *s_bits = (unsigned long long *)(s_hv + hv_words);                 // bits_words
 	uint32_t *s_pc = (uint32_t *)(s_bits + bits_words);                                   // bits_words + 1
 	__shared__ unsigned long long s_blk;
-	const int tid = threadIdx.x;
-	for (int i = tid; i < SK_NB1; i += TPB)
+	__shared__ uint32_t s_cnt[SK_NB1];               // chunks opened per bucket (added to g_cnt once, at the end: 256 counters
+	const int tid = threadIdx.x;                     //  in 8 cache lines take ~1 G same-line atomics/s, measured)
+	for (int i = tid; i < SK_NB1; i += TPB) {
 		s_cur[i] = g_cursors[(size_t)blockIdx.x * SK_NB1 + i];
+		s_cnt[i] = 0;
+	}
 	if (tid == 0)
 		s_blk = g_blk[blockIdx.x];
 	const int w = K - m + 1;                         // m-mers per k-mer
 	const uint64_t ntiles = (nreads + SK_TILE_READS - 1) / SK_TILE_READS;
-	uint32_t claimed = 0, failed = 0, done = 0;
+	uint32_t claimed = 0, failed = 0, done = 0, emitted = 0;
 #ifdef SDT_SK_TICKS
 	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
 #define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 			}
 			const uint64_t read_ord = ord_base + (tile * SK_TILE_READS + (uint64_t)r) * ord_stride;
 			uint32_t chunk, pos;
-			if (sk_reserve(s_cur, &s_blk, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, g_cnt, chunk, pos)) {
+			if (sk_reserve(s_cur, &s_blk, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, s_cnt, chunk, pos)) {
 				const int len = hp + n + K - 1 + hn, ps = p0 - hp;
 				uint64_t rec[RW];
 				rec[0] = sk_header(read_ord, (uint32_t)j, sk_l2_bucket(bh), n, hp, hn);
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 					rec[1 + k] = wv;
 				}
 				sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
+				emitted += (uint32_t)n;
 			} else {
 				// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
 				const int len_r = (int)(tv.rb[r + 1] - tv.rb[r]);
@@ -296,8 +309,11 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 		SK_TICK(3);
 	}
 #undef SK_TICK
-	for (int i = tid; i < SK_NB1; i += TPB)
+	for (int i = tid; i < SK_NB1; i += TPB) {
 		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
+		if (s_cnt[i])
+			atomicAdd(&g_cnt[i], s_cnt[i]);
+	}
 	if (tid == 0) {
 		g_blk[blockIdx.x] = s_blk;
 #ifdef SDT_SK_TICKS
@@ -311,6 +327,219 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 	}
 	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
 	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1)
+		emitted += __shfl_down(emitted, d);
+	if ((tid & 63) == 0 && emitted)
+		atomicAdd(&stats->sk_emitted, (unsigned long long)emitted);
+}
+
+// ---- level 1, one lane per read (1-word keys, the common window lengths, reads up to ~150 bases) ------------------
+// The strip kernel above spends two thirds of its time in the window minima: 64 lanes hash 64 m-mers and five
+// shuffles later hold 64 - w window minima.  Here a lane walks ONE read base by base: the canonical m-mer rolls
+// (one shift per strand), and the sliding minimum over W m-mers is the block decomposition of van Herk / Gil-Werman
+// -- suffix minima of the block of W hashes behind, a running prefix minimum of the block ahead, min of the two --
+// with both blocks in registers (W is a template parameter so that every index is static).  ~3 compares per window
+// instead of a shuffle tree, every hash computed once, all 64 lanes on their own read.  Runs are noted in a
+// per-lane LDS list (bucket << 14 | n - 1 << 9 | first k-mer) and cut out of the tile when the read is done.
+constexpr int SK_SEQ_TILE = 256;                 // reads per tile = lanes per workgroup
+constexpr int SK_SEQ_RUNCAP = 24;                // runs per read the list holds (more: emitted on the spot)
+constexpr int SK_SEQ_MAX_KMERS = 128;            // k-mers per read (the list entry has 9 bits for the position)
+
+// cut run [j0, j0 + n) of a read out of the tile and append the record to its level-1 bucket
+template <int NW>
+__device__ inline void sk_emit_run(const uint32_t *words, int rb_r, int len_r, int nk_r, int K, uint64_t read_ord, int j0, int n,
+                                   uint32_t fb, unsigned long long *s_cur, unsigned long long *s_blk, const SkPool &pool,
+                                   uint32_t *s_cnt, const Table<NW> &tbl, uint32_t &claimed, uint32_t &failed, uint32_t &done,
+                                   uint32_t &emitted)
+{
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS;
+	const int hp = j0 > 0, hn = j0 + n < nk_r;
+	const uint32_t l1 = fb >> SK_L2BITS, l2 = fb & (SK_NB2 - 1);
+	uint32_t chunk, pos;
+	if (sk_reserve(s_cur, s_blk, l1, l1, SK_CAP1, pool, s_cnt, chunk, pos)) {
+		const int len = hp + n + K - 1 + hn, ps = rb_r + j0 - hp;
+		uint64_t rec[RW];
+		rec[0] = sk_header(read_ord, (uint32_t)j0, l2, n, hp, hn);
+#pragma unroll
+		for (int k = 0; k < BW; k++) {
+			uint64_t wv = 0;
+			if (32 * k < len) {
+				wv = sk_stream_word(words, ps + 32 * k);
+				const int keep = len - 32 * k;
+				if (keep < 32)
+					wv &= ~0ULL << (64 - 2 * keep);
+			}
+			rec[1 + k] = wv;
+		}
+		sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
+		emitted += (uint32_t)n;
+	} else {
+		// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
+		for (int jj = j0; jj < j0 + n; jj++) {
+			uint32_t prev, next;
+			const Key<NW> key = chop_record<NW>(words, rb_r, len_r, jj, K, prev, next);
+			const uint64_t ord = tbl.first ? (read_ord << 16) | (uint64_t)jj : ORD_NONE;
+			if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
+				failed++;
+			done++;
+		}
+	}
+}
+
+template <int W>
+__global__ __launch_bounds__(SK_SEQ_TILE) void k_sk_scatter_reads_seq(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offs,
+                                                                      uint64_t nreads, int K, int m, int ncap, int max_tile_words, SkPool pool,
+                                                                      unsigned long long *__restrict__ g_cursors, unsigned long long *__restrict__ g_blk,
+                                                                      uint32_t *__restrict__ g_cnt, Table<1> tbl, Stats *stats,
+                                                                      uint64_t ord_base, uint64_t ord_stride)
+{
+	constexpr int TR = SK_SEQ_TILE;
+	extern __shared__ uint32_t smem[];
+	unsigned long long *s_cur = (unsigned long long *)smem;                               // SK_NB1
+	uint32_t *s_rb = (uint32_t *)(s_cur + SK_NB1);                                        // TR + 2
+	uint32_t *s_runs = s_rb + TR + 2;                                                     // TR * SK_SEQ_RUNCAP
+	uint32_t *s_words = s_runs + TR * SK_SEQ_RUNCAP;                                      // LDS_LEAD + max_tile_words
+	__shared__ unsigned long long s_blk;
+	__shared__ uint32_t s_cnt[SK_NB1];               // chunks opened per bucket (see k_sk_scatter_reads)
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SK_NB1; i += TR) {
+		s_cur[i] = g_cursors[(size_t)blockIdx.x * SK_NB1 + i];
+		s_cnt[i] = 0;
+	}
+	if (tid == 0)
+		s_blk = g_blk[blockIdx.x];
+	const uint64_t ntiles = (nreads + TR - 1) / TR;
+	const uint32_t mmask = (1u << (2 * m)) - 1u;
+	const int topsh = 2 * (m - 1);
+	uint32_t claimed = 0, failed = 0, done = 0, emitted = 0;
+#ifdef SDT_SK_TICKS
+	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define SK_TICK(i) do { } while (0)
+#endif
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const uint64_t r0 = tile * TR;
+		const int nr = (int)((nreads - r0) < (uint64_t)TR ? (nreads - r0) : (uint64_t)TR);
+		const uint64_t word0 = offs[r0] >> 4;
+		int nwords = (int)(((offs[r0 + nr] + 15) >> 4) - word0) + TAIL_PAD;
+		if (nwords > max_tile_words)
+			nwords = max_tile_words;                     // cannot happen when max_read_len was honoured
+		s_rb[tid] = (uint32_t)(offs[r0 + (tid < nr ? tid : nr)] - (word0 << 4));
+		if (tid == 0)
+			s_rb[TR] = (uint32_t)(offs[r0 + nr] - (word0 << 4));
+		if (tid < LDS_LEAD)
+			s_words[tid] = 0;
+		for (int i = tid; i < nwords; i += TR)
+			s_words[LDS_LEAD + i] = packed[word0 + i];
+		__syncthreads();
+		SK_TICK(0);
+		const uint32_t *words = s_words + LDS_LEAD;
+		const int rb_r = (int)s_rb[tid];
+		const int len_r = tid < nr ? (int)s_rb[tid + 1] - rb_r : 0;
+		const int nk_r = len_r >= K + 1 ? len_r - K + 1 : 0;                // prlHashReads.c:592
+		const uint64_t read_ord = ord_base + (r0 + (uint64_t)tid) * ord_stride;
+		uint32_t *runs = s_runs + tid * SK_SEQ_RUNCAP;
+		int nrun = 0;
+		if (nk_r > 0) {
+			const int nhv = len_r - m + 1;               // m-mers of the read; window j covers m-mers [j, j + W)
+			// rolling canonical m-mer: fw holds the last m - 1 bases, rc their reverse complement one base up
+			uint32_t fw = sk_stream_mmer(words, rb_r, m) >> 2;
+			uint32_t rc = (sk_rev2bit32(fw ^ 0xAAAAAAAAu) >> (32 - 2 * (m - 1))) << 2;
+			int pb = rb_r + m - 1;                       // stream index of the next base to enter
+			auto next_hv = [&]() -> uint32_t {
+				const uint32_t b = (words[pb >> 4] >> (30 - 2 * (pb & 15))) & 3u;
+				pb++;
+				fw = ((fw << 2) | b) & mmask;
+				rc = (rc >> 2) | ((b ^ 2u) << topsh);
+				return sk_mmer_hash(fw < rc ? fw : rc);
+			};
+			int j0 = 0;
+			uint32_t fb0 = 0, pfb = 0;
+			auto window = [&](int j, uint32_t mn) {
+				const uint32_t fb = sk_final_bucket(sk_bucket_hash(mn));
+				if (j == 0) {
+					fb0 = fb;
+				} else if ((j & (ncap - 1)) == 0 || fb != pfb) {
+					if (nrun < SK_SEQ_RUNCAP)
+						runs[nrun] = (fb0 << 14) | ((uint32_t)(j - j0 - 1) << 9) | (uint32_t)j0;
+					else
+						sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, j0, j - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
+					nrun++;
+					j0 = j;
+					fb0 = fb;
+				}
+				pfb = fb;
+			};
+			uint32_t h[W], nh[W];
+#pragma unroll
+			for (int i = 0; i < W; i++)
+				h[i] = next_hv();                        // nhv >= W: the read has at least one k-mer
+#pragma unroll
+			for (int i = W - 2; i >= 0; i--)
+				h[i] = h[i] < h[i + 1] ? h[i] : h[i + 1];
+			int p = W;                                   // next m-mer position
+			for (int jb = 0; jb < nk_r; jb += W) {
+				window(jb, h[0]);
+				uint32_t pre = 0xFFFFFFFFu;
+#pragma unroll
+				for (int i = 1; i < W; i++) {
+					const uint32_t x = p < nhv ? next_hv() : 0xFFFFFFFFu;
+					p++;
+					nh[i - 1] = x;
+					pre = x < pre ? x : pre;
+					if (jb + i < nk_r)
+						window(jb + i, h[i] < pre ? h[i] : pre);
+				}
+				nh[W - 1] = p < nhv ? next_hv() : 0xFFFFFFFFu;
+				p++;
+				h[W - 1] = nh[W - 1];
+#pragma unroll
+				for (int i = W - 2; i >= 0; i--)
+					h[i] = nh[i] < h[i + 1] ? nh[i] : h[i + 1];
+			}
+			// the last run of the read
+			if (nrun < SK_SEQ_RUNCAP)
+				runs[nrun] = (fb0 << 14) | ((uint32_t)(nk_r - j0 - 1) << 9) | (uint32_t)j0;
+			else
+				sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, j0, nk_r - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
+			nrun++;
+		}
+		SK_TICK(1);
+		const int nlist = nrun < SK_SEQ_RUNCAP ? nrun : SK_SEQ_RUNCAP;
+		for (int k = 0; k < nlist; k++) {
+			const uint32_t e = runs[k];
+			sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, (int)(e & 511u), (int)((e >> 9) & 31u) + 1, e >> 14, s_cur, &s_blk, pool,
+			               s_cnt, tbl, claimed, failed, done, emitted);
+		}
+		__syncthreads();                             // the tile buffers are reused
+		SK_TICK(3);
+	}
+#undef SK_TICK
+	for (int i = tid; i < SK_NB1; i += TR) {
+		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
+		if (s_cnt[i])
+			atomicAdd(&g_cnt[i], s_cnt[i]);
+	}
+	if (tid == 0) {
+		g_blk[blockIdx.x] = s_blk;
+#ifdef SDT_SK_TICKS
+		for (int i = 0; i < 4; i++)
+			atomicAdd(&stats->sk_cyc1[i], cyc[i]);
+#endif
+	}
+	if (done) {
+		atomicAdd(&stats->kmers, (unsigned long long)done);
+		atomicAdd(&stats->sk_direct, (unsigned long long)done);
+	}
+	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1)
+		emitted += __shfl_down(emitted, d);
+	if ((tid & 63) == 0 && emitted)
+		atomicAdd(&stats->sk_emitted, (unsigned long long)emitted);
 }
 
 // every workgroup's open chunks: write the number of records they hold; retire the rest of its block of chunk ids
@@ -431,34 +660,69 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 	constexpr int RW = SkFmt<NW>::REC_WORDS;
 	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
 	__shared__ unsigned long long s_cur[SK_NB2];
-	__shared__ uint32_t s_kc[SK_NB2];
+	__shared__ uint32_t s_kc[SK_NB2], s_cc[SK_NB2];  // k-mers and chunks per level-2 bucket of this item
 	__shared__ unsigned long long s_blk;
 	const SkItem it = items[blockIdx.x];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
 		s_cur[i] = ((unsigned long long)SK_NOCHUNK << 32) | (unsigned)SK_CAP2;
 		s_kc[i] = 0;
+		s_cc[i] = 0;
 	}
 	if (tid == 0)
 		s_blk = 0;
 	__syncthreads();
 	uint32_t failed = 0;
-	for (uint32_t cb = it.c0; cb < it.c1; cb += CPT) {
-		const uint32_t ci = cb + (uint32_t)tid / SK_CAP1, slot = (uint32_t)tid % SK_CAP1;
-		if (ci >= it.c1)
-			continue;
-		const uint32_t chunk = list1[ci];
-		if (slot >= (src.meta[chunk] >> 24))
-			continue;
-		uint64_t rec[RW];
-		sk_load_record<RW>(src.recs + ((size_t)chunk * SK_CAP1 + slot) * RW, rec);
-		const uint32_t b2 = sk_hdr_l2(rec[0]);
-		atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
-		uint32_t dchunk, pos;
-		if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, g_cnt, dchunk, pos))
-			sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
-		else
-			failed++;                                // the pool is sized for the worst case: never expected
+	// chunk id -> fill + record -> LDS cursor -> store is three memory latencies in a row, and one workgroup per CU has
+	// only 8 waves to hide them: a lane keeps the records of its next D sweeps in registers and the chunk ids of the D
+	// after those (a slot past a chunk's fill is loaded and dropped)
+	constexpr int D = SDT_SK_L2_DEPTH;
+	const uint32_t slot = (uint32_t)tid % SK_CAP1, cfirst = it.c0 + (uint32_t)tid / SK_CAP1;
+	uint32_t id_a[D], id_b[D], fill_a[D];
+	uint64_t rec_a[D][RW];
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		const uint32_t ca = cfirst + (uint32_t)d * CPT, cb = ca + (uint32_t)D * CPT;
+		id_a[d] = ca < it.c1 ? list1[ca] : SK_NOCHUNK;
+		id_b[d] = cb < it.c1 ? list1[cb] : SK_NOCHUNK;
+	}
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		fill_a[d] = 0;
+#pragma unroll
+		for (int i = 0; i < RW; i++)
+			rec_a[d][i] = 0;
+		if (id_a[d] != SK_NOCHUNK) {
+			fill_a[d] = src.meta[id_a[d]] >> 24;
+			sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
+		}
+	}
+	for (uint32_t cg = cfirst; cg < it.c1; cg += (uint32_t)D * CPT) {
+#pragma unroll
+		for (int d = 0; d < D; d++) {
+			const uint32_t ci = cg + (uint32_t)d * CPT;
+			uint64_t rec[RW];
+#pragma unroll
+			for (int i = 0; i < RW; i++)
+				rec[i] = rec_a[d][i];
+			const uint32_t fill = ci < it.c1 ? fill_a[d] : 0u;
+			id_a[d] = id_b[d];
+			const uint32_t cn = ci + 2u * (uint32_t)D * CPT;
+			id_b[d] = cn < it.c1 ? list1[cn] : SK_NOCHUNK;
+			if (id_a[d] != SK_NOCHUNK) {
+				fill_a[d] = src.meta[id_a[d]] >> 24;
+				sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
+			}
+			if (slot >= fill)
+				continue;
+			const uint32_t b2 = sk_hdr_l2(rec[0]);
+			atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
+			uint32_t dchunk, pos;
+			if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, s_cc, dchunk, pos))
+				sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
+			else
+				failed++;                            // the pool is sized for the worst case: never expected
+		}
 	}
 	__syncthreads();
 	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
@@ -468,6 +732,8 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 			dst.meta[chunk] = (it.b1 * SK_NB2 + (uint32_t)i) | ((pos < (uint32_t)SK_CAP2 ? pos : (uint32_t)SK_CAP2) << 24);
 		if (s_kc[i])
 			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], s_kc[i]);
+		if (s_cc[i])
+			atomicAdd(&g_cnt[it.b1 * SK_NB2 + i], s_cc[i]);
 	}
 	if (tid == 0)
 		sk_retire_block(s_blk, dst);
@@ -833,6 +1099,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 	}
 	if (tid == 0) {
 		atomicAdd(&stats->kmers, done);
+		atomicAdd(&stats->sk_counted, done);
 		if (gens) atomicAdd(&stats->sk_gens, (unsigned long long)gens);
 #ifdef SDT_SK_TICKS
 		for (int i = 0; i < 4; i++)

@@ -81,6 +81,8 @@ struct Stats {             // device counters, one cache line each would be nice
 	unsigned long long sk_spills;  // k-mers that found no LDS slot and took the direct path
 	unsigned long long sk_direct;  // k-mers whose record found no chunk and took the direct path
 	unsigned long long sk_gens;    // flushes of a full LDS table before its bucket was done
+	unsigned long long sk_emitted; // k-mers the level-1 scatter put into records     } conservation: what goes into the pools
+	unsigned long long sk_counted; // k-mers k_sk_count took out of level-2 records   } must come out (checked by sync_stats)
 	unsigned long long sk_cyc1[4]; // k_sk_scatter_reads, thread 0 of every workgroup: clock ticks in tile staging / window minima / run starts / emission
 	unsigned long long sk_cyc[4];  // k_sk_count, wave 0 of every workgroup: clock ticks in set-up / tile fill + scan / counting / merging
 };
