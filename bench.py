@@ -346,7 +346,7 @@ def main():
                 "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes of this workload, this build)",
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(B * per_launch_kmers),
-                "kernel": ("pass 1 = k_sk_scatter_reads + chunk lists + k_sk_scatter_records + k_sk_count (every k-mer goes through "
+                "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records + k_sk_count (every k-mer goes through "
                            "all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
                 "bytes_per_kmer": round(B, 3), "launches": int(batches * args.steps),
                 "avg_launch_ms": round(kms / (batches * args.steps), 4), "kernel_ms_per_step": round(kms / args.steps, 3),

@@ -22,7 +22,7 @@ for f in glob.glob(f"{d}/pass_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-PASS1 = ("k_sk_scatter_reads", "k_sk_scatter_records", "k_sk_count", "k_sk_chunk_place", "k_sk_scan", "k_sk_seal", "k_sk_init_cursors", "k_count_reads")
+PASS1 = ("k_sk_scatter_reads", "k_sk_scatter_reads_seq", "k_sk_scatter_records", "k_sk_count", "k_sk_chunk_place", "k_sk_scan", "k_sk_seal", "k_sk_init_cursors", "k_count_reads")
 DOUBLE = ("k_sk_scatter_records", "k_sk_count")
 res = {"reads": reads, "read_len": L, "K": K, "steps_profiled": steps, "kmers": kmers, "kernels": {}}
 tot_f = tot_w = tot_a = 0.0
