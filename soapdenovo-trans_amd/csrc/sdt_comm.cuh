@@ -193,10 +193,16 @@ struct Comm {
 		if (kind == 1) {
 			HIPCHK(hipEventRecord(ev_a, xstream));
 			NCCLCHK(g_rccl.GroupStart());
+			// pieces of at most 256 MiB, the same on both sides (a rank's send_bytes[p] is p's recv_bytes[rank]): collectives of
+			// this RCCL past 1 GiB per call were seen to deliver garbage (soapdenovo-trans_amd/sharding.py), and nothing is
+			// lost by staying far below
+			const size_t PIECE = (size_t)256 << 20;
 			for (int p = 0; p < nranks; p++) {
 				if (p == rank) continue;
-				if (send_bytes[p]) NCCLCHK(g_rccl.Send(send_ptr[p], send_bytes[p], NCCL_UINT8, p, nccl, xstream));
-				if (recv_bytes[p]) NCCLCHK(g_rccl.Recv(recv_ptr[p], recv_bytes[p], NCCL_UINT8, p, nccl, xstream));
+				for (size_t o = 0; o < send_bytes[p]; o += PIECE)
+					NCCLCHK(g_rccl.Send((const char *)send_ptr[p] + o, send_bytes[p] - o < PIECE ? send_bytes[p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
+				for (size_t o = 0; o < recv_bytes[p]; o += PIECE)
+					NCCLCHK(g_rccl.Recv((char *)recv_ptr[p] + o, recv_bytes[p] - o < PIECE ? recv_bytes[p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
 			}
 			NCCLCHK(g_rccl.GroupEnd());
 			HIPCHK(hipEventRecord(ev_b, xstream));

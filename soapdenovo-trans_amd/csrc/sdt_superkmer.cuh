@@ -15,10 +15,11 @@
 // is ~3 B per k-mer occurrence (24-byte records of ~8 k-mers at K = 31) instead of the 16-B (key, meta) record of the
 // per-k-mer exchange.
 //
-//   k_sk_scatter_reads   chop + minimizers per tile of 64 reads in LDS, cut the runs, append each record to
+//   k_sk_scatter_reads(_seq)  chop + minimizers per tile of reads in LDS (_seq: one lane walks one read, rolling m-mers and a
+//                        block sliding minimum; otherwise strips of 64 positions per wave), cut the runs, append each record to
 //                        its level-1 bucket (256 of them).  Space comes from a pool of fixed-size chunks; every
 //                        workgroup owns one open chunk per bucket and reserves slots with LDS atomics, so the
-//                        only global atomic is the pool bump once per 32 records.
+//                        only global atomic is the pool bump once per 128 chunks.
 //   k_sk_scatter_records level 2: every level-1 bucket is split 1024 ways the same way (records only move).
 //   k_sk_count           one workgroup per final bucket (2^18): records -> LDS -> k-mers -> an LDS hash table
 //                        whose entries have the layout of the node table's (key, val); LDS atomics do the
