@@ -38,7 +38,8 @@ enum {
 	SDT_ENOMEM   = -3,   /* device or host allocation failed */
 	SDT_EHIP     = -4,   /* HIP runtime error (message in sdt_gpu_last_error) */
 	SDT_EFULL    = -5,   /* node table cannot grow any further */
-	SDT_ESTATE   = -6    /* call out of order (e.g. export before finish) */
+	SDT_ESTATE   = -6    /* call out of order (e.g. export before finish); also: the pipeline's conservation check failed
+	                      * (k-mers cut into records != k-mers counted, sdt_gpu_finish_count) -- never a silent loss */
 };
 
 typedef struct sdt_ctx sdt_ctx;
@@ -101,7 +102,8 @@ int sdt_gpu_count_reads_device(sdt_ctx *ctx, const void *d_packed_words, uint64_
 
 /* Drain: all pushed batches are in the table on return (end of the read loop, prlHashReads.c:615-623).
  * Outputs (may be NULL): k-mer occurrences processed ("kmer in reads", :662) and distinct nodes
- * ("nodes allocated" = sum of count_kmerset, :655-662). */
+ * ("nodes allocated" = sum of count_kmerset, :655-662).  SDT_EFULL if an insert ever found no slot; SDT_ESTATE if the
+ * k-mers that went into the locality pipeline's records are not the k-mers that came out of its count stage. */
 int sdt_gpu_finish_count(sdt_ctx *ctx, uint64_t *kmers_processed, uint64_t *nodes);
 
 /* ---- multi-GPU, bucket sharding (the product path) ---------------------------------------------------------
