@@ -57,7 +57,6 @@ static int fail(int code, const char *fmt, ...)
 // ------------------------------------------------------------------------------------------------
 constexpr int TPB = 256;           // 4 waves
 constexpr int TILE_READS = 64;     // reads staged per workgroup tile
-constexpr int TAIL_PAD = 4;        // readable words past the last base of a tile
 
 // Stage reads [r0, r1) of the batch in LDS.  Returns the tile's k-mer count; fills
 //   s_words : LDS_LEAD lead words, then the packed words that hold bases [off[r0], off[r1])
@@ -1160,25 +1159,17 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 	// one lane per read where the window length has an instantiation and the run list can hold a read
 	const int w = c->K - m + 1;
 	static const bool no_seq = getenv("SDT_SK_STRIPS") != NULL;          // A/B switch (tools/)
-	if (c->nw == 1 && (w == 13 || w == 21) && per_read <= (uint64_t)SK_SEQ_MAX_KMERS && !no_seq) {
-		const int mtw = (int)(((uint64_t)SK_SEQ_TILE * max_read_len + 16 + 15) / 16) + TAIL_PAD + 1;
-		const size_t smem = (size_t)SK_NB1 * 8 + (size_t)(SK_SEQ_TILE + 2) * 4 + (size_t)SK_SEQ_TILE * SK_SEQ_RUNCAP * 4 + (size_t)(LDS_LEAD + mtw) * 4;
-		const uint64_t nt = (nr + SK_SEQ_TILE - 1) / SK_SEQ_TILE;
-		unsigned g2;
-#define SK_SEQ(W)                                                                                                                  \
-		do {                                                                                                                       \
-			HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads_seq<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-			int per_cu = 0;                          /* persistent workgroups: exactly the resident ones (a second wave of them would run half empty) */ \
-			HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sk_scatter_reads_seq<W>, SK_SEQ_TILE, smem));              \
-			uint64_t res = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)c->cu_count;                                                    \
-			if (res > k.wgs) res = k.wgs;                                                                                             \
-			g2 = (unsigned)(nt < res ? nt : res);                                                                                     \
-			hipLaunchKernelGGL(k_sk_scatter_reads_seq<W>, dim3(g2), dim3(SK_SEQ_TILE), smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, mtw, \
-			                   k.p1, k.cursors, k.blk, k.cnt1, table_of<1>(c), c->d_stats, ob, c->ord_stride);                        \
-		} while (0)
-		if (w == 13) SK_SEQ(13);
-		else SK_SEQ(21);
-#undef SK_SEQ
+	// (instantiated: every odd window of 1-word keys with K >= 17 and of 2-word keys, i.e. every odd K from 17 to 63)
+	const bool seq1 = c->nw == 1 && (w & 1) && w >= 9 && w <= 21 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS_NW1;
+	const bool seq2 = c->nw == 2 && (w & 1) && w >= 23 && w <= 53 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS;
+	if ((seq1 || seq2) && !no_seq) {
+		SkSeqLaunch a;
+		a.words = d_words; a.offs = d_offs; a.nreads = nr; a.K = c->K; a.m = m; a.ncap = ncap;
+		a.mtw = (int)(((uint64_t)SK_SEQ_TILE * max_read_len + 16 + 15) / 16) + TAIL_PAD + 1;
+		a.pool = k.p1; a.cursors = k.cursors; a.blk = k.blk; a.cnt = k.cnt1; a.stats = c->d_stats;
+		a.ord_base = ob; a.ord_stride = c->ord_stride; a.max_wgs = k.wgs; a.cu_count = c->cu_count; a.stream = c->stream;
+		HIPCHK(seq1 ? sk_seq_launch_nw1(w, a, table_of<1>(c)) : (w <= 33 ? sk_seq_launch_nw2_lo(w, a, table_of<2>(c))
+		            : (w <= 43 ? sk_seq_launch_nw2_mid(w, a, table_of<2>(c)) : sk_seq_launch_nw2_hi(w, a, table_of<2>(c)))));
 	} else if (c->nw == 1) SK_SCATTER(1);
 	else if (c->nw == 2) SK_SCATTER(2);
 	else SK_SCATTER(4);

@@ -104,6 +104,7 @@ template <int NW> __device__ inline Key<NW> key_revcomp(const Key<NW> &k, int K)
 // word holding stream bit 0 of the tile and is preceded by LDS_LEAD readable words (their content is
 // masked off), so windows that start "before" the tile need no branch.
 constexpr int LDS_LEAD = 8;
+constexpr int TAIL_PAD = 4;        // readable words past the last base of a tile
 
 __device__ inline uint32_t stream_base(const uint32_t *lds, int p)
 {

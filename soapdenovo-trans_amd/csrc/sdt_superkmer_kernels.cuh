@@ -30,80 +30,8 @@ constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one la
 constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 
-// Chunk ids come from the pool in blocks of SK_BLK per workgroup (s_blk = next id | end of block << 32): one global
-// atomic per SK_BLK chunks.  (One atomicAdd per chunk on the single pool counter was measured to cap BOTH scatter
-// kernels: same-address device atomics run at well under 1 G/s on MI355X.)
-constexpr uint32_t SK_BLK = 128;
-constexpr uint32_t SK_DEAD = 0xFFFFFFFFu;        // meta of a chunk id that was handed to a workgroup but never used
-
-__device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool)
-{
-	for (;;) {
-		const unsigned long long v = atomicAdd(s_blk, 1ULL);
-		const uint32_t id = (uint32_t)v, end = (uint32_t)(v >> 32);
-		if (id < end)
-			return id;
-		if (id == end) {
-			const uint32_t base = atomicAdd(pool.next, SK_BLK);
-			atomicExch(s_blk, ((unsigned long long)(base + SK_BLK) << 32) | (unsigned long long)(base + 1u));
-			return base;
-		}
-		// id > end: another lane of this workgroup is fetching the next block -- look again
-	}
-}
-
-// the ids of a block that were never handed out must not look like chunks of an earlier batch
-__device__ inline void sk_retire_block(unsigned long long blk, const SkPool &pool)
-{
-	const uint32_t next = (uint32_t)blk, end = (uint32_t)(blk >> 32);
-	for (uint32_t id = next; id < end && id < pool.chunks; id++)
-		pool.meta[id] = SK_DEAD;
-}
-
-// Reserve one record slot in the open chunk of local bucket `lb` (s_cur[lb] = chunk << 32 | records used).  The lane
-// that takes the slot one past the end opens a new chunk (and counts it for its bucket: the counting sort of the
-// chunk ids by bucket needs no pass of its own).  The counters s_cnt[lb] are the WORKGROUP's (LDS), added to the
-// global ones once at its end: one global atomic per chunk on 256 counters (8 cache lines) ran at ~0.8 G/s and
-// was what bounded the level-1 scatter.  false: the pool is exhausted (the caller takes its slow path).
-__device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long *s_blk, uint32_t lb, uint32_t meta_bucket,
-                                  uint32_t cap, const SkPool &pool, uint32_t *s_cnt, uint32_t &chunk, uint32_t &pos)
-{
-	for (;;) {
-		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
-		pos = (uint32_t)cur;
-		chunk = (uint32_t)(cur >> 32);
-		if (pos < cap)
-			return chunk != SK_NOCHUNK;
-		if (pos == cap) {
-			uint32_t id = sk_alloc_chunk(s_blk, pool);
-			if (id >= pool.chunks) {
-				id = SK_NOCHUNK;
-			} else {
-				pool.meta[id] = meta_bucket | (cap << 24);
-				atomicAdd(&s_cnt[lb], 1u);
-			}
-			atomicExch(&s_cur[lb], ((unsigned long long)id << 32) | 1ULL);
-			chunk = id;
-			pos = 0;
-			return id != SK_NOCHUNK;
-		}
-		// pos > cap: another lane of this workgroup is replacing the chunk -- look again
-	}
-}
-
-// records are 8-byte aligned (24 / 40 / 56 bytes): 8-byte accesses, consecutive lanes still cover consecutive bytes
-template <int RW> __device__ inline void sk_store_record(uint64_t *dst, const uint64_t (&rec)[RW])
-{
-#pragma unroll
-	for (int i = 0; i < RW; i++)
-		dst[i] = rec[i];
-}
-template <int RW> __device__ inline void sk_load_record(const uint64_t *src, uint64_t (&rec)[RW])
-{
-#pragma unroll
-	for (int i = 0; i < RW; i++)
-		rec[i] = src[i];
-}
+#include "sdt_sk_scatter_seq.cuh"      // chunk reservation helpers + the one-lane-per-read level-1 scatter (own header: its
+                                        // many instantiations are compiled in translation units of their own)
 
 // ---- level 1: reads -> super-k-mer records in 256 buckets ----------------------------------------------------
 template <int NW>
@@ -310,214 +238,6 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 	}
 #undef SK_TICK
 	for (int i = tid; i < SK_NB1; i += TPB) {
-		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
-		if (s_cnt[i])
-			atomicAdd(&g_cnt[i], s_cnt[i]);
-	}
-	if (tid == 0) {
-		g_blk[blockIdx.x] = s_blk;
-#ifdef SDT_SK_TICKS
-		for (int i = 0; i < 4; i++)
-			atomicAdd(&stats->sk_cyc1[i], cyc[i]);
-#endif
-	}
-	if (done) {
-		atomicAdd(&stats->kmers, (unsigned long long)done);
-		atomicAdd(&stats->sk_direct, (unsigned long long)done);
-	}
-	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
-	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1)
-		emitted += __shfl_down(emitted, d);
-	if ((tid & 63) == 0 && emitted)
-		atomicAdd(&stats->sk_emitted, (unsigned long long)emitted);
-}
-
-// ---- level 1, one lane per read (1-word keys, the common window lengths, reads up to ~150 bases) ------------------
-// The strip kernel above spends two thirds of its time in the window minima: 64 lanes hash 64 m-mers and five
-// shuffles later hold 64 - w window minima.  Here a lane walks ONE read base by base: the canonical m-mer rolls
-// (one shift per strand), and the sliding minimum over W m-mers is the block decomposition of van Herk / Gil-Werman
-// -- suffix minima of the block of W hashes behind, a running prefix minimum of the block ahead, min of the two --
-// with both blocks in registers (W is a template parameter so that every index is static).  ~3 compares per window
-// instead of a shuffle tree, every hash computed once, all 64 lanes on their own read.  Runs are noted in a
-// per-lane LDS list (bucket << 14 | n - 1 << 9 | first k-mer) and cut out of the tile when the read is done.
-constexpr int SK_SEQ_TILE = 256;                 // reads per tile = lanes per workgroup
-constexpr int SK_SEQ_RUNCAP = 24;                // runs per read the list holds (more: emitted on the spot)
-constexpr int SK_SEQ_MAX_KMERS = 128;            // k-mers per read (the list entry has 9 bits for the position)
-
-// cut run [j0, j0 + n) of a read out of the tile and append the record to its level-1 bucket
-template <int NW>
-__device__ inline void sk_emit_run(const uint32_t *words, int rb_r, int len_r, int nk_r, int K, uint64_t read_ord, int j0, int n,
-                                   uint32_t fb, unsigned long long *s_cur, unsigned long long *s_blk, const SkPool &pool,
-                                   uint32_t *s_cnt, const Table<NW> &tbl, uint32_t &claimed, uint32_t &failed, uint32_t &done,
-                                   uint32_t &emitted)
-{
-	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS;
-	const int hp = j0 > 0, hn = j0 + n < nk_r;
-	const uint32_t l1 = fb >> SK_L2BITS, l2 = fb & (SK_NB2 - 1);
-	uint32_t chunk, pos;
-	if (sk_reserve(s_cur, s_blk, l1, l1, SK_CAP1, pool, s_cnt, chunk, pos)) {
-		const int len = hp + n + K - 1 + hn, ps = rb_r + j0 - hp;
-		uint64_t rec[RW];
-		rec[0] = sk_header(read_ord, (uint32_t)j0, l2, n, hp, hn);
-#pragma unroll
-		for (int k = 0; k < BW; k++) {
-			uint64_t wv = 0;
-			if (32 * k < len) {
-				wv = sk_stream_word(words, ps + 32 * k);
-				const int keep = len - 32 * k;
-				if (keep < 32)
-					wv &= ~0ULL << (64 - 2 * keep);
-			}
-			rec[1 + k] = wv;
-		}
-		sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
-		emitted += (uint32_t)n;
-	} else {
-		// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
-		for (int jj = j0; jj < j0 + n; jj++) {
-			uint32_t prev, next;
-			const Key<NW> key = chop_record<NW>(words, rb_r, len_r, jj, K, prev, next);
-			const uint64_t ord = tbl.first ? (read_ord << 16) | (uint64_t)jj : ORD_NONE;
-			if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
-				failed++;
-			done++;
-		}
-	}
-}
-
-template <int W>
-__global__ __launch_bounds__(SK_SEQ_TILE) void k_sk_scatter_reads_seq(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offs,
-                                                                      uint64_t nreads, int K, int m, int ncap, int max_tile_words, SkPool pool,
-                                                                      unsigned long long *__restrict__ g_cursors, unsigned long long *__restrict__ g_blk,
-                                                                      uint32_t *__restrict__ g_cnt, Table<1> tbl, Stats *stats,
-                                                                      uint64_t ord_base, uint64_t ord_stride)
-{
-	constexpr int TR = SK_SEQ_TILE;
-	extern __shared__ uint32_t smem[];
-	unsigned long long *s_cur = (unsigned long long *)smem;                               // SK_NB1
-	uint32_t *s_rb = (uint32_t *)(s_cur + SK_NB1);                                        // TR + 2
-	uint32_t *s_runs = s_rb + TR + 2;                                                     // TR * SK_SEQ_RUNCAP
-	uint32_t *s_words = s_runs + TR * SK_SEQ_RUNCAP;                                      // LDS_LEAD + max_tile_words
-	__shared__ unsigned long long s_blk;
-	__shared__ uint32_t s_cnt[SK_NB1];               // chunks opened per bucket (see k_sk_scatter_reads)
-	const int tid = threadIdx.x;
-	for (int i = tid; i < SK_NB1; i += TR) {
-		s_cur[i] = g_cursors[(size_t)blockIdx.x * SK_NB1 + i];
-		s_cnt[i] = 0;
-	}
-	if (tid == 0)
-		s_blk = g_blk[blockIdx.x];
-	const uint64_t ntiles = (nreads + TR - 1) / TR;
-	const uint32_t mmask = (1u << (2 * m)) - 1u;
-	const int topsh = 2 * (m - 1);
-	uint32_t claimed = 0, failed = 0, done = 0, emitted = 0;
-#ifdef SDT_SK_TICKS
-	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
-#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
-#else
-#define SK_TICK(i) do { } while (0)
-#endif
-	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const uint64_t r0 = tile * TR;
-		const int nr = (int)((nreads - r0) < (uint64_t)TR ? (nreads - r0) : (uint64_t)TR);
-		const uint64_t word0 = offs[r0] >> 4;
-		int nwords = (int)(((offs[r0 + nr] + 15) >> 4) - word0) + TAIL_PAD;
-		if (nwords > max_tile_words)
-			nwords = max_tile_words;                     // cannot happen when max_read_len was honoured
-		s_rb[tid] = (uint32_t)(offs[r0 + (tid < nr ? tid : nr)] - (word0 << 4));
-		if (tid == 0)
-			s_rb[TR] = (uint32_t)(offs[r0 + nr] - (word0 << 4));
-		if (tid < LDS_LEAD)
-			s_words[tid] = 0;
-		for (int i = tid; i < nwords; i += TR)
-			s_words[LDS_LEAD + i] = packed[word0 + i];
-		__syncthreads();
-		SK_TICK(0);
-		const uint32_t *words = s_words + LDS_LEAD;
-		const int rb_r = (int)s_rb[tid];
-		const int len_r = tid < nr ? (int)s_rb[tid + 1] - rb_r : 0;
-		const int nk_r = len_r >= K + 1 ? len_r - K + 1 : 0;                // prlHashReads.c:592
-		const uint64_t read_ord = ord_base + (r0 + (uint64_t)tid) * ord_stride;
-		uint32_t *runs = s_runs + tid * SK_SEQ_RUNCAP;
-		int nrun = 0;
-		if (nk_r > 0) {
-			const int nhv = len_r - m + 1;               // m-mers of the read; window j covers m-mers [j, j + W)
-			// rolling canonical m-mer: fw holds the last m - 1 bases, rc their reverse complement one base up
-			uint32_t fw = sk_stream_mmer(words, rb_r, m) >> 2;
-			uint32_t rc = (sk_rev2bit32(fw ^ 0xAAAAAAAAu) >> (32 - 2 * (m - 1))) << 2;
-			int pb = rb_r + m - 1;                       // stream index of the next base to enter
-			auto next_hv = [&]() -> uint32_t {
-				const uint32_t b = (words[pb >> 4] >> (30 - 2 * (pb & 15))) & 3u;
-				pb++;
-				fw = ((fw << 2) | b) & mmask;
-				rc = (rc >> 2) | ((b ^ 2u) << topsh);
-				return sk_mmer_hash(fw < rc ? fw : rc);
-			};
-			int j0 = 0;
-			uint32_t fb0 = 0, pfb = 0;
-			auto window = [&](int j, uint32_t mn) {
-				const uint32_t fb = sk_final_bucket(sk_bucket_hash(mn));
-				if (j == 0) {
-					fb0 = fb;
-				} else if ((j & (ncap - 1)) == 0 || fb != pfb) {
-					if (nrun < SK_SEQ_RUNCAP)
-						runs[nrun] = (fb0 << 14) | ((uint32_t)(j - j0 - 1) << 9) | (uint32_t)j0;
-					else
-						sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, j0, j - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
-					nrun++;
-					j0 = j;
-					fb0 = fb;
-				}
-				pfb = fb;
-			};
-			uint32_t h[W], nh[W];
-#pragma unroll
-			for (int i = 0; i < W; i++)
-				h[i] = next_hv();                        // nhv >= W: the read has at least one k-mer
-#pragma unroll
-			for (int i = W - 2; i >= 0; i--)
-				h[i] = h[i] < h[i + 1] ? h[i] : h[i + 1];
-			int p = W;                                   // next m-mer position
-			for (int jb = 0; jb < nk_r; jb += W) {
-				window(jb, h[0]);
-				uint32_t pre = 0xFFFFFFFFu;
-#pragma unroll
-				for (int i = 1; i < W; i++) {
-					const uint32_t x = p < nhv ? next_hv() : 0xFFFFFFFFu;
-					p++;
-					nh[i - 1] = x;
-					pre = x < pre ? x : pre;
-					if (jb + i < nk_r)
-						window(jb + i, h[i] < pre ? h[i] : pre);
-				}
-				nh[W - 1] = p < nhv ? next_hv() : 0xFFFFFFFFu;
-				p++;
-				h[W - 1] = nh[W - 1];
-#pragma unroll
-				for (int i = W - 2; i >= 0; i--)
-					h[i] = nh[i] < h[i + 1] ? nh[i] : h[i + 1];
-			}
-			// the last run of the read
-			if (nrun < SK_SEQ_RUNCAP)
-				runs[nrun] = (fb0 << 14) | ((uint32_t)(nk_r - j0 - 1) << 9) | (uint32_t)j0;
-			else
-				sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, j0, nk_r - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
-			nrun++;
-		}
-		SK_TICK(1);
-		const int nlist = nrun < SK_SEQ_RUNCAP ? nrun : SK_SEQ_RUNCAP;
-		for (int k = 0; k < nlist; k++) {
-			const uint32_t e = runs[k];
-			sk_emit_run<1>(words, rb_r, len_r, nk_r, K, read_ord, (int)(e & 511u), (int)((e >> 9) & 31u) + 1, e >> 14, s_cur, &s_blk, pool,
-			               s_cnt, tbl, claimed, failed, done, emitted);
-		}
-		__syncthreads();                             // the tile buffers are reused
-		SK_TICK(3);
-	}
-#undef SK_TICK
-	for (int i = tid; i < SK_NB1; i += TR) {
 		g_cursors[(size_t)blockIdx.x * SK_NB1 + i] = s_cur[i];
 		if (s_cnt[i])
 			atomicAdd(&g_cnt[i], s_cnt[i]);

@@ -111,6 +111,25 @@ def test_saturation_and_hot_keys(pkg, synth, mode):
         assert max(v[3] for v in gd.values()) > 65536
 
 
+@pytest.mark.parametrize("K", list(range(17, 64, 2)))
+def test_seq_scatter_every_window(pkg, synth, K):
+    """the one-lane-per-read level-1 scatter has one instantiation per window length (every odd K from 17 to 63, 1- and
+    2-word keys): each against the oracle -- ragged reads (some shorter than K), reads with more runs than the
+    per-lane list holds, every node compared"""
+    L = 100 if K <= 31 else 200
+    tx = synth.make_transcriptome(12, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=2500, read_len=L, seed=K + 11, err=0.004, ragged=True)
+    o = ob.Oracle(K, nsets=3)
+    o.add_reads(codes, offs)
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=MODES[-1]) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        assert g.finish_count() == (o.kmers_in_reads(), o.node_count())
+        hist, linear = g.mark_and_hist()
+        ohist, olinear = o.mark()
+        assert linear == olinear and (hist == ohist).all()
+        assert node_dict_gpu(g) == node_dict_oracle(o)
+
+
 def test_hot_bucket_repeated(pkg, synth):
     """the hot-bucket input ten times through the locality pipeline: every lane of every workgroup appends to ONE
     level-2 cursor.  (A 1024-lane geometry of the level-2 scatter lost a chunk of 16 records in half of such runs;

@@ -12,3 +12,5 @@ find $O/pmc200 -name "pass_*" -type d | xargs rm -rf
 mkdir -p profiles/r2 && cp $O/pmc_pass1_200M_k31.json profiles/r2/pmc_pass1_200M_k31.json      # bench.py reads the traffic from here
 timeout 1800 python bench.py > $O/bench_default_200M_k31.json 2> $O/bench_default_200M_k31.err
 tail -1 $O/bench_default_200M_k31.json | cut -c1-400
+timeout 900 python bench.py --reads 50000000 --read-len 250 --K 63 --steps 3 --warmup 1 --cpu-sample 0 > $O/bench_C4_50M_250bp_k63.json 2> $O/bench_C4.err
+tail -1 $O/bench_C4_50M_250bp_k63.json | cut -c1-200
