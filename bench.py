@@ -60,7 +60,8 @@ def pmc_traffic_per_kmer(K, L, reads):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_pass1_*.json")), reverse=True):
         try:
             j = json.load(open(f))
-            if (j["K"], j["read_len"], j["reads"]) == (K, L, reads) and j.get("kernel_source_id") == kernel_source_id():
+            if ((j["K"], j["read_len"], j["reads"]) == (K, L, reads) and j.get("kernel_source_id") == kernel_source_id()
+                    and j.get("complete", True)):
                 return j["hbm_bytes_per_kmer"], os.path.relpath(f, ROOT)
         except Exception:
             pass

@@ -1160,7 +1160,7 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 	const int w = c->K - m + 1;
 	static const bool no_seq = getenv("SDT_SK_STRIPS") != NULL;          // A/B switch (tools/)
 	// (instantiated: every odd window of 1-word keys with K >= 17 and of 2-word keys, i.e. every odd K from 17 to 63)
-	const bool seq1 = c->nw == 1 && (w & 1) && w >= 9 && w <= 21 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS_NW1;
+	const bool seq1 = c->nw == 1 && (w & 1) && w >= 9 && w <= 21 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS;
 	const bool seq2 = c->nw == 2 && (w & 1) && w >= 23 && w <= 53 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS;
 	if ((seq1 || seq2) && !no_seq) {
 		SkSeqLaunch a;

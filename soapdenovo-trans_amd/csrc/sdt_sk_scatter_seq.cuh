@@ -96,9 +96,10 @@ template <int RW> __device__ inline void sk_load_record(const uint64_t *src, uin
 // instead of a shuffle tree, every hash computed once, all 64 lanes on their own read.  Runs are noted in a
 // per-lane LDS list (bucket << 14 | n - 1 << 8 | first k-mer) and cut out of the tile when the read is done.
 constexpr int SK_SEQ_TILE = 256;                 // reads per tile = lanes per workgroup
-constexpr int SK_SEQ_RUNCAP = 24;                // runs per read the list holds (more: emitted on the spot)
+constexpr int SK_SEQ_RUNCAP = 24;                // runs per read the list holds (more: emitted on the spot -- K=31 on 250 bp does that
+                                                 //  for most reads and is still 3x the strip kernel: 50 -> 17 ms per 6.6 G k-mers)
 constexpr int SK_SEQ_MAX_KMERS = 256;            // k-mers per read (the list entry has 8 bits for the position, 6 for n - 1)
-constexpr int SK_SEQ_MAX_KMERS_NW1 = 128;        // (1-word keys: what the 24-entry run list holds without overflowing all the time)
+
 
 // cut run [j0, j0 + n) of a read out of the tile and append the record to its level-1 bucket
 template <int NW>

@@ -60,7 +60,7 @@ def test_golden_case_kmerfreq_bit_identical(pkg, name, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (23, 150, True), (31, 150, True), (31, 158, False), (33, 150, True),
+@pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (23, 150, True), (31, 150, True), (31, 158, False), (31, 250, True), (21, 250, True), (33, 150, True),
                                         (63, 250, False), (65, 200, True), (127, 250, True)])
 def test_node_table_equals_oracle(pkg, synth, K, L, ragged, mode):
     """every node: key, 8 saturating link counters, count, single/linear/deleted flags"""

@@ -11,9 +11,9 @@ ARGS="--steps 1 --warmup 0 --cpu-sample 0 --extras 0 $*"
 find $O/trace -name "*kernel_stats*" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 rm -rf $O/trace
 for pmc in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  for attempt in 1 2; do          # (a pass has been seen to stall once: bounded, retried once)
+  for attempt in 1 2 3; do          # (a pass has been seen to stall once: bounded, retried once)
     rm -rf $O/pass_$pmc
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $ROOT/$O/pass_$pmc -o p -- python3 $ROOT/bench.py $ARGS > $ROOT/$O/pass_$pmc.log 2>&1)
+    (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $ROOT/$O/pass_$pmc -o p -- python3 $ROOT/bench.py $ARGS > $ROOT/$O/pass_$pmc.log 2>&1)
     if find $O/pass_$pmc -name "*counter_collection.csv" | grep -q .; then break; fi
   done
 done

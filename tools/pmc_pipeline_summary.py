@@ -35,6 +35,7 @@ for k, c in sorted(agg.items()):
                          "bytes_per_kmer": (fetch + write) / kmers, "atomics_per_kmer": atom / kmers}
     if base in PASS1:
         tot_f += fetch; tot_w += write; tot_a += atom
+res["complete"] = tot_f > 0 and tot_w > 0          # a pass that never finished (rocprofv3 stalls now and then) must not pass for a measurement
 res["hbm_bytes_per_kmer"] = (tot_f + tot_w) / kmers
 res["fetch_bytes_per_kmer"] = tot_f / kmers
 res["write_bytes_per_kmer"] = tot_w / kmers
