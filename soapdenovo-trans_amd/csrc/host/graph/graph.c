@@ -5,6 +5,8 @@
 #include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
+#include "par.h"
+#include "big.h"        /* every large block (replay tables, node arrays) asks for transparent huge pages */
 
 /* ---- hash_kmer: table-driven CRC-32 with a SIGNED 32-bit state (arithmetic >> 8), hashFunction.c:83-122 ---- */
 static int32_t crc_tab[256];
@@ -285,8 +287,6 @@ static void *job_thread(void *a)
 	return NULL;
 }
 
-#include "par.h"
-#include "big.h"
 static void run_parallel(build_job *J, job_fn fn)
 {
 	J->fn = fn;

@@ -19,6 +19,8 @@
 #include "graph.h"
 #include <stdlib.h>
 #include <string.h>
+#include "par.h"
+#include "big.h"
 
 typedef struct { uint64_t key; uint64_t first; uint32_t mult; } arc_t;      /* key = from << 32 | to, 0 = empty */
 
