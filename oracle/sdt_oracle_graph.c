@@ -6,7 +6,8 @@
  * These passes are ORDER DEPENDENT (survey 7.3-1): they visit set 0..p-1, slot 0..size-1 of the reference's
  * table layout and mutate neighbours as they go.  The oracle's sets have that exact layout (sdto_set_put is a
  * bit-exact put_kmerset), so running the passes here reproduces the reference's result for the same -p.
- * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files.
+ * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files and, for the read-only
+ * walk of kmer2edges (sdto_edge_port), ::test_case_edges_from_port_walks against its *.edge.gz files.
  */
 #include "sdt_oracle.h"
 #include <stdio.h>
@@ -290,6 +291,57 @@ void sdto_neighbours(sdto_sets *S, const uint64_t key4[4], uint64_t nb_key4[8][4
 		memcpy(nb_key4[i], p->seq.w, sizeof p->seq.w);
 		state[i] = sm;
 	}
+}
+
+/* kmer2edges' walk from one port of a node that is neither linear nor deleted (startEdgeFromNode + stringBeads +
+ * check_iden_kmerList, node2edge.c:58-191,193-310,563-588): port 0..3 = right link ch on the stored strand, port 4..7 =
+ * left link ch - 4, walked on the reverse strand with int_comp(ch).  Returns -1 for a node that starts no edge, 0 for a
+ * port without a link, 1 otherwise with far_key4 = the first non-linear node, info[0] = the port of the far node the
+ * chain arrives through, info[1] = edges' length in k-mer steps (node_c - 1), info[2] = bal_edge (0: the list of
+ * oriented k-mers equals the list of their reverse complements read backwards, i.e. the edge is its own twin). */
+int sdto_edge_port(sdto_sets *S, const uint64_t key4[4], int port, uint64_t far_key4[4], int info[3])
+{
+	const sdto_node *n1 = node_of(S, key4);
+	const int K = S->K;
+	if (n1->linear || n1->deleted) return -1;                      /* :201-204 */
+	const int ch1 = port & 3, right = port < 4;
+	if (!(right ? rcov(n1, ch1) : lcov(n1, ch1))) return 0;        /* :213-219 / :262-268 */
+	size_t cap = 64, n = 0;
+	sdto_kmer *list = (sdto_kmer *)malloc(cap * sizeof *list);     /* nodeStack: the oriented k-mer of every bead */
+	sdto_kmer oriented = right ? n1->seq : sdto_reverse_complement(n1->seq, K);
+	list[n++] = oriented;
+	/* stringBeads :58-191 */
+	sdto_kmer word = sdto_next_kmer(oriented, right ? ch1 : (ch1 ^ 2), K), canon;
+	int smaller, ch;
+	sdto_node *o = find_oriented(S, word, &smaller, &canon);
+	while (o->linear) {
+		if (n + 2 > cap) { cap *= 2; list = (sdto_kmer *)realloc(list, cap * sizeof *list); }
+		oriented = smaller ? canon : sdto_reverse_complement(canon, K);
+		list[n++] = oriented;
+		if (smaller) {
+			for (ch = 0; ch < 4; ch++) if (rcov(o, ch)) break;
+			word = sdto_next_kmer(oriented, ch, K);
+		} else {
+			for (ch = 0; ch < 4; ch++) if (lcov(o, ch)) break;
+			word = sdto_next_kmer(oriented, ch ^ 2, K);
+		}
+		o = find_oriented(S, word, &smaller, &canon);
+	}
+	if (n + 1 > cap) { cap += 1; list = (sdto_kmer *)realloc(list, cap * sizeof *list); }
+	list[n++] = smaller ? canon : sdto_reverse_complement(canon, K);
+	/* check_iden_kmerList :563-588 on nodeStack and its reverse-complemented copy popped in step */
+	int palindrome = 1;
+	for (size_t j = 0; j < n && palindrome; j++) {
+		const sdto_kmer a = list[n - 1 - j], b = sdto_reverse_complement(list[j], K);
+		if (memcmp(a.w, b.w, sizeof a.w) != 0) palindrome = 0;
+	}
+	const int fc = sdto_first_char(list[n - 2], K);                /* the base the chain leaves behind when it enters the far node */
+	memcpy(far_key4, o->seq.w, sizeof o->seq.w);
+	info[0] = smaller ? 4 + fc : (fc ^ 2);
+	info[1] = (int)(n - 1);
+	info[2] = palindrome ? 0 : 1;
+	free(list);
+	return 1;
 }
 
 /* clipKmerFromNode's tests (:591-1010) on the graph as it is: cut[i] = 1 when neighbour i (order as above) would be

@@ -105,6 +105,8 @@ def lib():
     L.sdto_neighbours.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sdto_minor_out_probe.restype = C.c_int
     L.sdto_minor_out_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    L.sdto_edge_port.restype = C.c_int
+    L.sdto_edge_port.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -212,6 +214,20 @@ class Oracle:
                     v = (v << 64) | int(x)
                 out.append((v, int(st[i])))
         return out
+
+    def edge_port(self, key_row, port):
+        """kmer2edges' walk from one port: -1 (the node starts no edge), None (no link), or
+        (far node key as int, arrival port, length, bal_edge)"""
+        k, e, info = self._key4(key_row), np.zeros(4, dtype=np.uint64), np.zeros(3, dtype=np.int32)
+        rc = self.L.sdto_edge_port(self.h, k.ctypes.data, int(port), e.ctypes.data, info.ctypes.data)
+        if rc < 0:
+            return -1
+        if rc == 0:
+            return None
+        v = 0
+        for x in e:
+            v = (v << 64) | int(x)
+        return v, int(info[0]), int(info[1]), int(info[2])
 
     def minor_out_probe(self, key_row, threshold):
         """cut flags of the 8 neighbours under clipKmerFromNode's ratio test on the graph as it is"""

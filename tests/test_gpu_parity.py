@@ -907,6 +907,11 @@ def test_edge_port_walks_equal_reference_rule(pkg, synth, K, L):
         extra += [hp] * 5
     codes = np.concatenate([codes] + extra)
     offs = np.concatenate([offs, offs[-1] + np.cumsum([len(e) for e in extra]).astype(np.uint64)])
+    # the C oracle holds the same graph (its walk restates startEdgeFromNode / stringBeads / check_iden_kmerList from the
+    # reference's sources); the Python restatement above is a second opinion
+    orc = ob.Oracle(K, nsets=3)
+    orc.add_reads(codes, offs)
+    orc.mark()
     with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
         g.push_reads(synth.pack_2bit(codes), offs)
         g.finish_count()
@@ -919,6 +924,14 @@ def test_edge_port_walks_equal_reference_rule(pkg, synth, K, L):
         rec = g.edge_ports()
         want = py_edge_ports(ki, l, rf, K)
         assert len(rec) == len(want) > 0
+        for i, ports in want.items():                         # restatement in C == restatement in Python
+            for p in range(8):
+                c = orc.edge_port(keys[i], p)
+                assert c != -1
+                assert c == (None if ports[p] is None else (ki[ports[p][0]],) + tuple(ports[p][1:])), (i, p)
+        for i in range(len(keys)):                            # linear / deleted nodes start no edge
+            if i not in want:
+                assert orc.edge_port(keys[i], 0) == -1
         NONE = (1 << 64) - 1
         palins = 0
         for r in rec:

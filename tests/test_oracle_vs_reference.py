@@ -168,6 +168,62 @@ def test_case_vertex(name, tmp_path, pkg):
     assert open(out).read() == gu.golden_text(info, "vertex")
 
 
+def _rc_int(v, K):
+    out = 0
+    for _ in range(K):
+        out = (out << 2) | ((v & 3) ^ 2)
+        v >>= 2
+    return out
+
+
+@pytest.mark.parametrize("name", gu.case_names())
+def test_case_edges_from_port_walks(name, pkg):
+    """kmer2edges' walks restated (sdto_edge_port = startEdgeFromNode + stringBeads + check_iden_kmerList,
+    node2edge.c:58-310,563-588) on the graph the three cleaning passes leave: the reference's *.edge.gz lists every edge
+    once (its twin is implied, bal_edge = 1) with its first and last oriented k-mer and its length -- walking every port of
+    every node that starts edges must find exactly those, each non-palindromic one from both ends"""
+    import collections
+    import gzip
+    info = gu.load_case(name)
+    o, _ = run_oracle_pregraph(info, pkg)
+    K = o.K
+
+    def rep(frm, to):
+        return min((frm, to), (_rc_int(to, K), _rc_int(frm, K)))
+
+    want = collections.Counter()
+    with gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt") as fh:
+        for line in fh:
+            if not line.startswith(">"):
+                continue
+            f = line[1:].split(",")                        # length N,<from words>,<to words>,cvg C, bal
+            length, bal = int(f[0].split()[1]), int(f[4])
+            frm = to = 0
+            for w in f[1].split():
+                frm = (frm << 64) | int(w, 16)
+            for w in f[2].split():
+                to = (to << 64) | int(w, 16)
+            want[(rep(frm, to), length, bal)] += 2 if bal else 1
+    keys = o.export()[0]
+    got = collections.Counter()
+    for row in keys:
+        k = 0
+        for x in row:
+            k = (k << 64) | int(x)
+        for p in range(8):
+            w = o.edge_port(row, p)
+            if w == -1:
+                break
+            if w is None:
+                continue
+            far, aport, length, bal = w
+            frm = k if p < 4 else _rc_int(k, K)
+            to = far if aport >= 4 else _rc_int(far, K)
+            got[(rep(frm, to), length, bal)] += 1
+    assert sum(want.values()) > 0
+    assert got == want
+
+
 def test_chop_matches_definition():
     """chopKmer4read restatement vs. the closed form of SURVEY 9.1 (independent of the rolling update)"""
     rng = np.random.default_rng(3)
