@@ -18,18 +18,27 @@ constexpr uint32_t SK_DEAD = 0xFFFFFFFFu;        // meta of a chunk id that was 
 
 __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool)
 {
-	for (;;) {
+	// Flag form on purpose: a lane that finds the block exhausted (id > end) spins until the lane that took id == end has
+	// fetched the next block -- possibly a lane of ITS OWN wave.  With `for (;;) { ... return ...; }` the compiler is free
+	// to move the fetch behind the loop (it sits on an exit path), and then the spinning lanes wait for ever for a lane that
+	// waits for them to leave the loop (tools/lds_cursor_stress.hip hung exactly so).  The work below is inside the loop body.
+	uint32_t got = 0;
+	bool done = false;
+	while (!done) {
 		const unsigned long long v = atomicAdd(s_blk, 1ULL);
 		const uint32_t id = (uint32_t)v, end = (uint32_t)(v >> 32);
-		if (id < end)
-			return id;
-		if (id == end) {
+		if (id < end) {
+			got = id;
+			done = true;
+		} else if (id == end) {
 			const uint32_t base = atomicAdd(pool.next, SK_BLK);
 			atomicExch(s_blk, ((unsigned long long)(base + SK_BLK) << 32) | (unsigned long long)(base + 1u));
-			return base;
+			got = base;
+			done = true;
 		}
 		// id > end: another lane of this workgroup is fetching the next block -- look again
 	}
+	return got;
 }
 
 // the ids of a block that were never handed out must not look like chunks of an earlier batch
@@ -48,13 +57,15 @@ __device__ inline void sk_retire_block(unsigned long long blk, const SkPool &poo
 __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long *s_blk, uint32_t lb, uint32_t meta_bucket,
                                   uint32_t cap, const SkPool &pool, uint32_t *s_cnt, uint32_t &chunk, uint32_t &pos)
 {
-	for (;;) {
+	bool done = false, ok = false;                   // (flag form: see sk_alloc_chunk)
+	while (!done) {
 		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
 		pos = (uint32_t)cur;
 		chunk = (uint32_t)(cur >> 32);
-		if (pos < cap)
-			return chunk != SK_NOCHUNK;
-		if (pos == cap) {
+		if (pos < cap) {
+			ok = chunk != SK_NOCHUNK;
+			done = true;
+		} else if (pos == cap) {
 			uint32_t id = sk_alloc_chunk(s_blk, pool);
 			if (id >= pool.chunks) {
 				id = SK_NOCHUNK;
@@ -65,10 +76,12 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 			atomicExch(&s_cur[lb], ((unsigned long long)id << 32) | 1ULL);
 			chunk = id;
 			pos = 0;
-			return id != SK_NOCHUNK;
+			ok = id != SK_NOCHUNK;
+			done = true;
 		}
 		// pos > cap: another lane of this workgroup is replacing the chunk -- look again
 	}
+	return ok;
 }
 
 // records are 8-byte aligned (24 / 40 / 56 bytes): 8-byte accesses, consecutive lanes still cover consecutive bytes
