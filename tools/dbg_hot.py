@@ -1,4 +1,5 @@
-"""scratch: repeat the hot-key input through the pipeline and print the k-mers counted each time"""
+"""repeat the hot-bucket input through the locality pipeline and print the k-mers counted and the pipeline counters each time
+(N=<runs> in the environment; tools/README.md)"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
