@@ -520,7 +520,8 @@ template <int NW, int SLOTS>
 __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
 {
 	uint32_t s = sk_lds_hash<NW>(key) & (SLOTS - 1);
-	for (int probe = 0; probe < 96;) {
+	int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
+	for (int probe = 0; probe < 96 && found == -2;) {
 		uint64_t k0 = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (k0 == KEY_EMPTY) {
 			if (__hip_atomic_load(s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= maxfill)
@@ -533,6 +534,8 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 					for (int i = 1; i < NW; i++)
 						s_key[i * SLOTS + s] = key.w[i];
 					__hip_atomic_store(&s_key[s], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					found = (int)s;
+					continue;
 				}
 				return (int)s;
 			}
@@ -552,7 +555,7 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 		s = (s + 1) & (SLOTS - 1);
 		probe++;
 	}
-	return -1;
+	return found == -2 ? -1 : found;
 }
 
 // one occurrence: s_lk[4 * slot + side * 2 + (code >> 1)] holds the counters of codes (code & ~1) and (code | 1)

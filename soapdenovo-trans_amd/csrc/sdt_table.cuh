@@ -152,7 +152,12 @@ __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint
 {
 	uint64_t slot = key_hash<NW>(key) & t.mask;
 	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
-	for (uint64_t probe = 0; probe < max_probe;) {
+	// Multi-word keys: a lane that reads KEY_LOCKED looks again until the claimer -- possibly a lane of its own wave -- has
+	// published the low words, so the claimer's stores must stay INSIDE the loop body: its branch ends in `hit = true;
+	// continue;` and the loop condition lets it out, not a `return` (an exit path, which the compiler may move behind the
+	// loop; tools/lds_cursor_stress.hip hung exactly so with the chunk cursors).  1-word keys have no such wait.
+	bool hit = false;
+	for (uint64_t probe = 0; probe < max_probe && !hit;) {
 		Entry<NW> *e = t.ent + slot;
 		uint64_t k0, seen = 0;
 		if constexpr (NW == 1) {
@@ -215,7 +220,10 @@ __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint
 				}
 				slot_out = slot;
 				seen_out = 0;
-				return true;
+				if constexpr (NW == 1)
+					return true;
+				hit = true;
+				continue;
 			}
 			k0 = old;        // somebody else got it first: fall through and look at what they put
 			seen = 0;
@@ -242,7 +250,7 @@ __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint
 		slot = (slot + 1) & t.mask;
 		probe++;
 	}
-	return false;
+	return hit;
 }
 
 // put_kmerset (newhash.c:411-462) for one record.  Returns false when the probe budget ran out.
