@@ -1,13 +1,14 @@
 /*
  * sdt_oracle_graph.c -- CPU restatement of the k-mer-graph cleaning passes of `pregraph`
  * (cutTipPreGraph.c: removeMinorOut / clipKmerFromNode, removeSingleTips / removeMinorTips / clipTipFromNode,
- * Mark1in1outNode) and of output_vertex.  TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).
+ * Mark1in1outNode), of kmer2edges (node2edge.c) and of output_vertex.  TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).
  *
  * These passes are ORDER DEPENDENT (survey 7.3-1): they visit set 0..p-1, slot 0..size-1 of the reference's
  * table layout and mutate neighbours as they go.  The oracle's sets have that exact layout (sdto_set_put is a
  * bit-exact put_kmerset), so running the passes here reproduces the reference's result for the same -p.
- * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files and, for the read-only
- * walk of kmer2edges (sdto_edge_port), ::test_case_edges_from_port_walks against its *.edge.gz files.
+ * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files; kmer2edges
+ * (node2edge.c) is restated here too: ::test_case_edge_file (sdto_write_edges: the reference's *.edge.gz byte for byte) and
+ * ::test_case_edges_from_port_walks (its read-only walk, sdto_edge_port, which the device dry run is compared with).
  */
 #include "sdt_oracle.h"
 #include <stdio.h>
@@ -412,6 +413,139 @@ uint64_t sdto_remove_minor_tips(sdto_sets *S, uint64_t *more_linear)
 /* output_vertex (output_pregraph.c:29-81): every !linear && !deleted node in table order, 8 per line,
  * print_kmer format of the variant (kmer.c:499-516): MER31 "%llx" with 0 printed as "0x0"; MER63 two words;
  * MER127 four words */
+/* ---- kmer2edges (node2edge.c:46-588, output_pregraph.c:83-100): the whole pass, in the reference's order, MUTATING the
+ * graph as the reference does (end links zeroed so that the twin walk does not emit the edge again, interior nodes' l_links
+ * overwritten with the edge id -- which the coverage of a self-complementary chain then reads back, :497-507) and
+ * writing the text of <prefix>.edge.gz (uncompressed).  Pinned byte for byte by tests/test_oracle_vs_reference.py::
+ * test_case_edge_file.  The (K+1)-mer patch table of length-1 edges (:404-463) is only counted ("extra nodes"). */
+typedef struct { sdto_node *node; sdto_kmer kmer; int smaller; } sdto_bead;
+
+static uint32_t left_covs(const sdto_node *n) { return lcov(n, 0) + lcov(n, 1) + lcov(n, 2) + lcov(n, 3); }
+
+static void print_kmer_sep(FILE *fp, const sdto_sets *S, sdto_kmer k, char c)       /* kmer.c:517-535 */
+{
+	const uint64_t *w = k.w;
+	if (S->nw == 4)
+		fprintf(fp, "%llx %llx %llx %llx", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
+	else if (S->nw == 2)
+		fprintf(fp, "%llx %llx", (unsigned long long)w[2], (unsigned long long)w[3]);
+	else if (w[3])
+		fprintf(fp, "%llx", (unsigned long long)w[3]);
+	else
+		fprintf(fp, "0x0");
+	fputc(c, fp);
+}
+
+/* merge_linearV2 :352-560 on the beads b[0..n) of one chain */
+static void merge_linear(sdto_sets *S, FILE *fp, sdto_bead *b, int n, int bal_edge, long long *edge_c, uint64_t *edge_counter,
+                         uint64_t *extra_nodes, char **seqbuf, size_t *seqcap)
+{
+	const int K = S->K, length = n - 1;
+	if ((size_t)length + 1 > *seqcap) { *seqcap = (size_t)length * 2 + 64; *seqbuf = (char *)realloc(*seqbuf, *seqcap); }
+	char *seq = *seqbuf;
+	int ci = length - 1;
+	sdto_bead *last = &b[n - 1], *second_last = &b[n - 2], *first = &b[0], *second = &b[1];
+	seq[ci--] = (char)sdto_last_char(last->kmer);
+	dislink2prev(last->node, sdto_first_char(second_last->kmer, K), last->smaller);           /* :382 */
+	dislink2next(first->node, sdto_last_char(second->kmer), first->smaller);                  /* :392 */
+	long long symbol = 0;
+	if (length == 1) {
+		(*extra_nodes)++;                                                                 /* the (K+1)-mer goes to KmerSetsPatch */
+		(*edge_c)++;
+		(*edge_counter)++;
+		symbol = first->node->count;                                                      /* :470-473 */
+	} else {
+		(*edge_c)++;
+		(*edge_counter)++;
+	}
+	for (int i = n - 2; i >= 1; i--) {                                                    /* :488-513: the interior, last to first */
+		sdto_node *d = b[i].node;
+		symbol += length == 1 ? (long long)d->count : (long long)left_covs(d);            /* (reads a link word that may hold an edge id) */
+		d->l_links = (uint32_t)(b[i].smaller ? *edge_c : *edge_c + bal_edge);
+		seq[ci--] = (char)sdto_last_char(b[i].kmer);
+	}
+	long long cvg;
+	if (length > 1) cvg = symbol / (length - 1) * 10;
+	else cvg = symbol / length * 10;
+	if (cvg > 16000) cvg = 16000;                                                         /* MaxEdgeCov, inc/def.h:37 */
+	/* output_1edge, output_pregraph.c:83-100 */
+	fprintf(fp, ">length %d,", length);
+	print_kmer_sep(fp, S, first->kmer, ',');
+	print_kmer_sep(fp, S, last->kmer, ',');
+	fprintf(fp, "cvg %d, %d\n", (int)cvg, bal_edge);
+	for (int i = 0; i < length; i++) {
+		fputc("ACTG"[(int)seq[i]], fp);
+		if ((i + 1) % 100 == 0) fputc('\n', fp);
+	}
+	fputc('\n', fp);
+	*edge_c += bal_edge;
+}
+
+/* startEdgeFromNode :193-310 for one side of one node; returns the number of beads */
+static int string_beads(sdto_sets *S, sdto_node *n1, int right, int ch1, sdto_bead **beads, size_t *cap)
+{
+	const int K = S->K;
+	size_t n = 0;
+	sdto_bead *b = *beads;
+	sdto_kmer oriented = right ? n1->seq : sdto_reverse_complement(n1->seq, K);
+	b[n].node = n1; b[n].kmer = oriented; b[n].smaller = right; n++;
+	sdto_kmer word = sdto_next_kmer(oriented, right ? ch1 : (ch1 ^ 2), K), canon;
+	int smaller, ch;
+	sdto_node *o = find_oriented(S, word, &smaller, &canon);
+	while (o->linear) {
+		if (n + 2 > *cap) { *cap *= 2; b = *beads = (sdto_bead *)realloc(b, *cap * sizeof *b); }
+		oriented = smaller ? canon : sdto_reverse_complement(canon, K);
+		b[n].node = o; b[n].kmer = oriented; b[n].smaller = smaller; n++;
+		if (smaller) {
+			for (ch = 0; ch < 4; ch++) if (rcov(o, ch)) break;
+			word = sdto_next_kmer(oriented, ch, K);
+		} else {
+			for (ch = 0; ch < 4; ch++) if (lcov(o, ch)) break;
+			word = sdto_next_kmer(oriented, ch ^ 2, K);
+		}
+		o = find_oriented(S, word, &smaller, &canon);
+	}
+	b[n].node = o; b[n].kmer = smaller ? canon : sdto_reverse_complement(canon, K); b[n].smaller = smaller; n++;
+	return (int)n;
+}
+
+uint64_t sdto_write_edges(sdto_sets *S, const char *path, uint64_t *edge_counter_out, uint64_t *extra_nodes_out)
+{
+	FILE *fp = fopen(path, "w");
+	if (!fp) return 0;
+	const int K = S->K;
+	long long edge_c = 0;
+	uint64_t edge_counter = 0, extra = 0;
+	size_t cap = 1024, seqcap = 1024;
+	sdto_bead *beads = (sdto_bead *)malloc(cap * sizeof *beads);
+	char *seqbuf = (char *)malloc(seqcap);
+	for (int t = 0; t < S->nsets; t++) {                                                  /* make_edge :312-349 */
+		sdto_set *s = S->sets[t];
+		for (uint64_t i = 0; i < s->size; i++) {
+			if (FL_NULL(s->flags, i)) continue;
+			sdto_node *n1 = s->array + i;
+			if (n1->linear || n1->deleted) continue;                                      /* :201-204 */
+			for (int side = 0; side < 2; side++)                                          /* outgoing list, then incoming list */
+				for (int ch1 = 0; ch1 < 4; ch1++) {
+					if (!(side == 0 ? rcov(n1, ch1) : lcov(n1, ch1))) continue;            /* live: earlier edges have zeroed links */
+					const int n = string_beads(S, n1, side == 0, ch1, &beads, &cap);
+					int palindrome = 1;                                                   /* check_iden_kmerList :563-588 */
+					for (int j = 0; j < n && palindrome; j++) {
+						const sdto_kmer a = beads[n - 1 - j].kmer, bb = sdto_reverse_complement(beads[j].kmer, K);
+						if (memcmp(a.w, bb.w, sizeof a.w) != 0) palindrome = 0;
+					}
+					merge_linear(S, fp, beads, n, palindrome ? 0 : 1, &edge_c, &edge_counter, &extra, &seqbuf, &seqcap);
+				}
+		}
+	}
+	fclose(fp);
+	free(beads);
+	free(seqbuf);
+	if (edge_counter_out) *edge_counter_out = edge_counter;
+	if (extra_nodes_out) *extra_nodes_out = extra;
+	return (uint64_t)edge_c;
+}
+
 uint64_t sdto_write_vertex(const sdto_sets *S, const char *path)
 {
 	FILE *fp = fopen(path, "w");

@@ -105,6 +105,8 @@ def lib():
     L.sdto_neighbours.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sdto_minor_out_probe.restype = C.c_int
     L.sdto_minor_out_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    L.sdto_write_edges.restype = C.c_uint64
+    L.sdto_write_edges.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sdto_edge_port.restype = C.c_int
     L.sdto_edge_port.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
@@ -173,6 +175,12 @@ class Oracle:
     def remove_minor_tips(self):
         ml = C.c_uint64()
         return self.L.sdto_remove_minor_tips(self.h, C.byref(ml)), ml.value
+
+    def write_edges(self, path):
+        """kmer2edges (mutates the graph as the reference does) -> (num_ed, edges emitted, extra (K+1)-mer nodes)"""
+        ec, ex = C.c_uint64(), C.c_uint64()
+        n = self.L.sdto_write_edges(self.h, path.encode(), C.byref(ec), C.byref(ex))
+        return n, ec.value, ex.value
 
     def write_vertex(self, path):
         return self.L.sdto_write_vertex(self.h, path.encode())

@@ -168,6 +168,26 @@ def test_case_vertex(name, tmp_path, pkg):
     assert open(out).read() == gu.golden_text(info, "vertex")
 
 
+@pytest.mark.parametrize("name", gu.case_names())
+def test_case_edge_file(name, tmp_path, pkg):
+    """kmer2edges restated in full (node2edge.c: startEdgeFromNode, stringBeads, check_iden_kmerList, merge_linearV2;
+    output_1edge): after the three cleaning passes the oracle writes the text of *.edge.gz -- every edge in the reference's
+    order with its first / last k-mer, length, coverage (including the self-complementary chains whose coverage reads a
+    link word already overwritten with the edge id), twin flag and sequence -- byte for byte what the reference binary
+    wrote at the same -p, and the counts of its closing line"""
+    import gzip
+    import re
+    info = gu.load_case(name)
+    o, _ = run_oracle_pregraph(info, pkg)
+    out = str(tmp_path / "out.edge")
+    num_ed, emitted, extra = o.write_edges(out)
+    with gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt") as fh:
+        want = fh.read()
+    assert open(out).read() == want
+    m = re.search(r"(\d+) \((\d+)\) edges (\d+) extra nodes", open(os.path.join(info["dir"], "stdout.log")).read())
+    assert m and (num_ed, emitted, extra) == tuple(int(x) for x in m.groups())
+
+
 def _rc_int(v, K):
     out = 0
     for _ in range(K):
