@@ -146,12 +146,34 @@ static uint64_t rev2bit(uint64_t x)
 
 /* kmer.c:548-656 fastReverseComp/reverseComplement: complement every base (^0b10), reverse the order
  * of the 2-bit groups over the whole register, then right-align the 2K significant bits. */
+/* KmerPlus (kmer.c:191-207): append a base WITHOUT masking -- the (K+1)-mer of a length-1 edge */
+sdto_kmer sdto_kmer_plus(sdto_kmer prev, int ch)
+{
+	sdto_kmer w = k_shl2(prev);
+	w.w[3] |= (uint64_t)(ch & 3);
+	return w;
+}
+
 sdto_kmer sdto_reverse_complement(sdto_kmer k, int K)
 {
 	sdto_kmer r;
 	for (int i = 0; i < 4; i++)
 		r.w[i] = rev2bit(k.w[3 - i] ^ 0xAAAAAAAAAAAAAAAAULL);
 	return k_shr(r, 256 - 2 * K);
+}
+
+/* reverseComplement(wordplus, overlaplen + 1) as the reference computes it.  fastReverseComp takes the length as a `char`
+ * (kmer.c:548): with the 127mer binary and K = 127 the 128 bases arrive as -128, take the "shorter than 32 bases" branch
+ * (:553-557) and only the LAST word is complemented and reversed (the shift count 64 - (-256) is 0 mod 64 on x86); every
+ * other length is the ordinary reverse complement. */
+sdto_kmer sdto_rc_kplus1(sdto_kmer wordplus, int K, int nw)
+{
+	if (nw == 4 && K + 1 == 128) {
+		sdto_kmer r = wordplus;
+		r.w[3] = rev2bit(wordplus.w[3] ^ 0xAAAAAAAAAAAAAAAAULL);
+		return r;
+	}
+	return sdto_reverse_complement(wordplus, K + 1);
 }
 
 /* ------------------------------------------------------------------ owner hash */
@@ -443,6 +465,7 @@ void sdto_sets_free(sdto_sets *S)
 	for (int i = 0; i < S->nsets; i++)
 		sdto_set_free(S->sets[i]);
 	free(S->sets);
+	free(S->patch);
 	free(S);
 }
 

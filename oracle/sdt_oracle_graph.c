@@ -1,14 +1,15 @@
 /*
  * sdt_oracle_graph.c -- CPU restatement of the k-mer-graph cleaning passes of `pregraph`
  * (cutTipPreGraph.c: removeMinorOut / clipKmerFromNode, removeSingleTips / removeMinorTips / clipTipFromNode,
- * Mark1in1outNode), of kmer2edges (node2edge.c) and of output_vertex.  TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).
+ * Mark1in1outNode), of kmer2edges (node2edge.c), of prlRead2edge (prlRead2path.c) and of output_vertex.  TEST INFRASTRUCTURE ONLY (see sdt_oracle.h).
  *
  * These passes are ORDER DEPENDENT (survey 7.3-1): they visit set 0..p-1, slot 0..size-1 of the reference's
  * table layout and mutate neighbours as they go.  The oracle's sets have that exact layout (sdto_set_put is a
  * bit-exact put_kmerset), so running the passes here reproduces the reference's result for the same -p.
  * Pinned by tests/test_oracle_vs_reference.py::test_case_vertex against the reference's *.vertex files; kmer2edges
  * (node2edge.c) is restated here too: ::test_case_edge_file (sdto_write_edges: the reference's *.edge.gz byte for byte) and
- * ::test_case_edges_from_port_walks (its read-only walk, sdto_edge_port, which the device dry run is compared with).
+ * ::test_case_edges_from_port_walks (its read-only walk, sdto_edge_port, which the device dry run is compared with); and so is
+ * the second read pass, prlRead2edge (prlRead2path.c): ::test_case_prearc (sdto_read2edge: *.preArc byte for byte).
  */
 #include "sdt_oracle.h"
 #include <stdio.h>
@@ -420,6 +421,51 @@ uint64_t sdto_remove_minor_tips(sdto_sets *S, uint64_t *more_linear)
  * test_case_edge_file.  The (K+1)-mer patch table of length-1 edges (:404-463) is only counted ("extra nodes"). */
 typedef struct { sdto_node *node; sdto_kmer kmer; int smaller; } sdto_bead;
 
+/* what kmer2edges leaves in a node for the second read pass: kmer_t.twin (2 bits) and .inEdge, kept in sdto_node.pad */
+#define ND_TWIN(n) ((n)->pad & 3)
+#define ND_INEDGE(n) (((n)->pad >> 2) & 1)
+static void nd_set_edge(sdto_node *n, uint32_t l_links, int twin) { n->l_links = l_links; n->pad = (uint8_t)((twin & 3) | 4); }
+
+/* KmerSetsPatch as one open-addressing table over the 4-word (K+1)-mer (the reference's per-thread sets only decide who looks) */
+typedef struct { sdto_kmer key; uint32_t edge; uint8_t twin, used; } sdto_patch;
+static uint64_t patch_hash(const sdto_kmer *k)
+{
+	uint64_t h = 0x9E3779B97F4A7C15ULL;
+	for (int i = 0; i < 4; i++) { h ^= k->w[i]; h *= 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+	return h;
+}
+static sdto_patch *patch_find(const sdto_sets *S, const sdto_kmer *k)
+{
+	sdto_patch *t = (sdto_patch *)S->patch;
+	if (!t) return NULL;
+	for (uint64_t h = patch_hash(k) & (S->patch_cap - 1);; h = (h + 1) & (S->patch_cap - 1)) {
+		if (!t[h].used) return NULL;
+		if (memcmp(t[h].key.w, k->w, sizeof k->w) == 0) return &t[h];
+	}
+}
+static void patch_put(sdto_sets *S, const sdto_kmer *k, uint32_t edge, int twin)
+{
+	if (!S->patch || (S->patch_n + 1) * 2 > S->patch_cap) {
+		const uint64_t ncap = S->patch_cap ? S->patch_cap * 2 : 1024;
+		sdto_patch *old = (sdto_patch *)S->patch, *nt = (sdto_patch *)calloc(ncap, sizeof *nt);
+		const uint64_t ocap = S->patch_cap;
+		S->patch = nt;
+		S->patch_cap = ncap;
+		for (uint64_t i = 0; i < ocap; i++)
+			if (old[i].used) {
+				uint64_t h = patch_hash(&old[i].key) & (ncap - 1);
+				while (nt[h].used) h = (h + 1) & (ncap - 1);
+				nt[h] = old[i];
+			}
+		free(old);
+	}
+	sdto_patch *t = (sdto_patch *)S->patch;
+	uint64_t h = patch_hash(k) & (S->patch_cap - 1);
+	while (t[h].used && memcmp(t[h].key.w, k->w, sizeof k->w) != 0) h = (h + 1) & (S->patch_cap - 1);
+	if (!t[h].used) S->patch_n++;                                                         /* (an existing node is overwritten, :426-443) */
+	t[h].key = *k; t[h].edge = edge; t[h].twin = (uint8_t)twin; t[h].used = 1;
+}
+
 static uint32_t left_covs(const sdto_node *n) { return lcov(n, 0) + lcov(n, 1) + lcov(n, 2) + lcov(n, 3); }
 
 static void print_kmer_sep(FILE *fp, const sdto_sets *S, sdto_kmer k, char c)       /* kmer.c:517-535 */
@@ -450,9 +496,15 @@ static void merge_linear(sdto_sets *S, FILE *fp, sdto_bead *b, int n, int bal_ed
 	dislink2next(first->node, sdto_last_char(second->kmer), first->smaller);                  /* :392 */
 	long long symbol = 0;
 	if (length == 1) {
-		(*extra_nodes)++;                                                                 /* the (K+1)-mer goes to KmerSetsPatch */
+		(*extra_nodes)++;                                                                 /* the (K+1)-mer goes to KmerSetsPatch, :404-463 */
 		(*edge_c)++;
 		(*edge_counter)++;
+		const sdto_kmer wordplus = sdto_kmer_plus(first->kmer, sdto_last_char(last->kmer));
+		const sdto_kmer bal_wordplus = sdto_rc_kplus1(wordplus, K, S->nw);
+		if (sdto_kmer_smaller(wordplus, bal_wordplus))
+			patch_put(S, &wordplus, (uint32_t)*edge_c, bal_edge + 1);
+		else
+			patch_put(S, &bal_wordplus, (uint32_t)(*edge_c + bal_edge), -bal_edge + 1);
 		symbol = first->node->count;                                                      /* :470-473 */
 	} else {
 		(*edge_c)++;
@@ -461,7 +513,8 @@ static void merge_linear(sdto_sets *S, FILE *fp, sdto_bead *b, int n, int bal_ed
 	for (int i = n - 2; i >= 1; i--) {                                                    /* :488-513: the interior, last to first */
 		sdto_node *d = b[i].node;
 		symbol += length == 1 ? (long long)d->count : (long long)left_covs(d);            /* (reads a link word that may hold an edge id) */
-		d->l_links = (uint32_t)(b[i].smaller ? *edge_c : *edge_c + bal_edge);
+		if (b[i].smaller) nd_set_edge(d, (uint32_t)*edge_c, bal_edge + 1);                 /* :497-507: inEdge, l_links = id, twin */
+		else nd_set_edge(d, (uint32_t)(*edge_c + bal_edge), -bal_edge + 1);
 		seq[ci--] = (char)sdto_last_char(b[i].kmer);
 	}
 	long long cvg;
@@ -543,7 +596,113 @@ uint64_t sdto_write_edges(sdto_sets *S, const char *path, uint64_t *edge_counter
 	free(seqbuf);
 	if (edge_counter_out) *edge_counter_out = edge_counter;
 	if (extra_nodes_out) *extra_nodes_out = extra;
+	S->num_ed = (uint64_t)edge_c;
 	return (uint64_t)edge_c;
+}
+
+/* ---- prlRead2edge (prlRead2path.c:817-1335; per read: chopKmer4read :253-371, searchKmer, parse1read :617-789,
+ * search1kmerPlus :575-615, thread_add1preArc :413-428; output_arcs :454-505) after sdto_write_edges: every read -> its path
+ * of edge ids -> one arc per adjacent pair; <prefix>.preArc lists, per from-edge in id order, its arcs with the one seen
+ * first LAST (new arcs are pushed at the head of the list).  -n (N_kmer) is off, as everywhere in this build. */
+typedef struct sdto_arc { uint32_t to, mult; struct sdto_arc *next; } sdto_arc;
+
+uint64_t sdto_read2edge(sdto_sets *S, const uint8_t *codes, const uint64_t *offs, uint64_t nreads, const char *path)
+{
+	const int K = S->K;
+	sdto_arc **heads = (sdto_arc **)calloc(S->num_ed + 2, sizeof *heads);
+	uint64_t narcs = 0;
+	size_t cap = 1024;
+	uint64_t *mix = (uint64_t *)malloc(cap * sizeof *mix);
+	sdto_kmer *plus = (sdto_kmer *)malloc(cap * sizeof *plus);
+	uint8_t *flag = (uint8_t *)malloc(cap), *psm = (uint8_t *)malloc(cap);
+	for (uint64_t t = 0; t < nreads; t++) {
+		const uint8_t *seq = codes + offs[t];
+		const int len = (int)(offs[t + 1] - offs[t]);
+		if (len < K + 1) continue;                                                        /* :969 */
+		const int n = len - K + 1;
+		if ((size_t)n + 1 > cap) {
+			cap = (size_t)n * 2;
+			mix = (uint64_t *)realloc(mix, cap * sizeof *mix);
+			plus = (sdto_kmer *)realloc(plus, cap * sizeof *plus);
+			flag = (uint8_t *)realloc(flag, cap);
+			psm = (uint8_t *)realloc(psm, cap);
+		}
+		/* parse1read :617-789 over the read's k-mers (chopped and looked up on the fly) */
+		sdto_kmer word;
+		memset(&word, 0, sizeof word);
+		for (int i = 0; i < K - 1; i++) word = sdto_next_kmer(word, seq[i], K);
+		unsigned retain = 0, pos = 0;
+		int is_prev = 0;
+		sdto_kmer prev_kmer;
+		memset(&prev_kmer, 0, sizeof prev_kmer);
+		for (int j = 0; j < n; j++) {
+			word = sdto_next_kmer(word, seq[j + K - 1], K);
+			int smaller;
+			sdto_node *node = find_oriented(S, word, &smaller, NULL);
+			if (node->deleted || (node->linear && !ND_INEDGE(node))) {                    /* deleted, or in a floating loop */
+				if (retain < 2) { retain = 0; pos = 0; } else break;
+				continue;                                                                 /* (is_prev is NOT reset: upstream) */
+			}
+			if (node->linear) {
+				const uint64_t edge_index = smaller ? node->l_links : node->l_links + ND_TWIN(node) - 1;
+				if (retain == 0 || is_prev) {
+					retain++; mix[pos] = edge_index; flag[pos++] = 0; is_prev = 0;
+				} else if (edge_index != mix[pos - 1]) {
+					retain++; mix[pos] = edge_index; flag[pos++] = 0;
+				}
+			} else {
+				const sdto_kmer cur = smaller ? node->seq : sdto_reverse_complement(node->seq, K);
+				if (is_prev) {
+					retain++;
+					const sdto_kmer wp = sdto_kmer_plus(prev_kmer, sdto_last_char(cur)), bwp = sdto_rc_kplus1(wp, K, S->nw);
+					if (sdto_kmer_smaller(wp, bwp)) { psm[pos] = 1; plus[pos] = wp; }
+					else { psm[pos] = 0; plus[pos] = bwp; }
+					mix[pos] = 1;                                                         /* (non-zero: resolved below) */
+					flag[pos++] = 1;
+				}
+				is_prev = 1;
+				prev_kmer = cur;
+			}
+		}
+		if (retain < 2) continue;                                                         /* :771-776: no path */
+		if (pos < (unsigned)n) { flag[pos] = 0; mix[pos] = 0; }
+		const unsigned end = pos < (unsigned)n ? pos + 1 : pos;
+		/* search1kmerPlus :575-615 for the (K+1)-mers, up to the terminator */
+		for (unsigned j = 0; j < end; j++) {
+			if (!flag[j]) { if (mix[j] == 0) break; continue; }
+			const sdto_patch *pn = patch_find(S, &plus[j]);
+			mix[j] = pn ? (psm[j] ? pn->edge : pn->edge + pn->twin - 1) : 0;
+		}
+		/* arcs :190-241 */
+		for (unsigned j = 0; j + 1 < end; j++) {
+			if (mix[j] == 0 || mix[j + 1] == 0) break;
+			const uint32_t from = (uint32_t)mix[j], to = (uint32_t)mix[j + 1];
+			sdto_arc *a = heads[from];
+			while (a && a->to != to) a = a->next;
+			if (a) {
+				a->mult++;
+			} else {
+				a = (sdto_arc *)malloc(sizeof *a);
+				a->to = to; a->mult = 1; a->next = heads[from];                           /* prlAllocatePreArc: multiplicity 1, pushed at the head */
+				heads[from] = a;
+				narcs++;
+			}
+		}
+	}
+	FILE *fp = fopen(path, "w");                                                         /* output_arcs :454-505 */
+	if (fp) {
+		for (uint64_t i = 1; i <= S->num_ed; i++) {
+			if (!heads[i]) continue;
+			fprintf(fp, "%u", (unsigned)i);
+			for (sdto_arc *a = heads[i]; a; a = a->next) fprintf(fp, " %u %u", a->to, a->mult);
+			fputc('\n', fp);
+		}
+		fclose(fp);
+	}
+	for (uint64_t i = 0; i <= S->num_ed + 1; i++)
+		for (sdto_arc *a = heads[i]; a;) { sdto_arc *nx = a->next; free(a); a = nx; }
+	free(heads); free(mix); free(plus); free(flag); free(psm);
+	return narcs;
 }
 
 uint64_t sdto_write_vertex(const sdto_sets *S, const char *path)

@@ -107,6 +107,8 @@ def lib():
     L.sdto_minor_out_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     L.sdto_write_edges.restype = C.c_uint64
     L.sdto_write_edges.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sdto_read2edge.restype = C.c_uint64
+    L.sdto_read2edge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
     L.sdto_edge_port.restype = C.c_int
     L.sdto_edge_port.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
@@ -181,6 +183,12 @@ class Oracle:
         ec, ex = C.c_uint64(), C.c_uint64()
         n = self.L.sdto_write_edges(self.h, path.encode(), C.byref(ec), C.byref(ex))
         return n, ec.value, ex.value
+
+    def read2edge(self, codes, offs, path):
+        """prlRead2edge after write_edges: text of *.preArc; returns the number of arcs"""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        return self.L.sdto_read2edge(self.h, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, path.encode())
 
     def write_vertex(self, path):
         return self.L.sdto_write_vertex(self.h, path.encode())

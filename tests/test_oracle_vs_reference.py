@@ -188,6 +188,24 @@ def test_case_edge_file(name, tmp_path, pkg):
     assert m and (num_ed, emitted, extra) == tuple(int(x) for x in m.groups())
 
 
+@pytest.mark.parametrize("name", gu.case_names())
+def test_case_prearc(name, tmp_path, pkg):
+    """the second read pass restated (prlRead2path.c: parse1read, search1kmerPlus, thread_add1preArc, output_arcs) on top of
+    the restated kmer2edges: read -> path of edge ids (linear nodes by their edge id and strand, pairs of vertex nodes through the
+    (K+1)-mer patch table -- with the 127mer binary's K = 127 reverse complement) -> arcs; *.preArc byte for byte as the
+    reference binary wrote it, list order (most recent first) included"""
+    import re
+    info = gu.load_case(name)
+    o, _ = run_oracle_pregraph(info, pkg)
+    o.write_edges(str(tmp_path / "out.edge"))
+    codes, offs = gu.case_reads(info)
+    out = str(tmp_path / "out.preArc")
+    narcs = o.read2edge(codes, offs, out)
+    assert open(out).read() == gu.golden_text(info, "preArc")
+    m = re.search(r"done mapping reads, \d+ reads deleted, (\d+) arcs created", open(os.path.join(info["dir"], "stdout.log")).read())
+    assert m and narcs == int(m.group(1))
+
+
 def _rc_int(v, K):
     out = 0
     for _ in range(K):
