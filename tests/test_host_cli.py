@@ -132,6 +132,58 @@ def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,p,d,L,variant,seed", [(25, 3, 0, 90, 31, 1), (31, 5, 1, 120, 31, 2), (45, 2, 0, 150, 63, 3),
+                                                  (63, 7, 0, 200, 63, 4), (71, 4, 0, 200, 127, 5), (21, 1, 2, 100, 31, 6)])
+def test_cli_against_oracle_on_fresh_inputs(pkg, synth, tmp_path, K, p, d, L, variant, seed):
+    """beyond the 12 fixtures: seeded synthetic reads (ragged, with errors, a few hairpins) through `sdt-pregraph` on the GPU
+    and through the C oracle's restatement of the WHOLE of pregraph (pass 1, -d, the three cleaning passes, kmer2edges, the
+    second read pass) -- the oracle is pinned file by file against the reference on the fixtures
+    (tests/test_oracle_vs_reference.py), so agreement here is agreement with the reference on inputs it never saw"""
+    import oracle_binding as ob
+    tx = synth.make_transcriptome(14, seed=seed)
+    codes, offs = synth.sample_reads(*tx, n_reads=3000, read_len=L, seed=seed + 100, err=0.004, ragged=True)
+    extra = []
+    for j in range(4):                                    # hairpins: X + rc(X) -> self-complementary chains
+        x = tx[0][150 * j + 11: 150 * j + 11 + L // 2]
+        extra += [np.concatenate([x, (x[::-1] ^ 2)]).astype(np.uint8)] * 4
+    codes = np.concatenate([codes] + extra)
+    offs = np.concatenate([offs, offs[-1] + np.cumsum([len(e) for e in extra]).astype(np.uint64)])
+    letters = np.frombuffer(b"ACTG", dtype=np.uint8)[codes].tobytes().decode()
+    o64 = offs.astype(np.int64)
+    with open(tmp_path / "reads.fq", "w") as fq:
+        for i in range(len(o64) - 1):
+            r = letters[o64[i]:o64[i + 1]]
+            fq.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+    cfg = tmp_path / "lib.cfg"
+    cfg.write_text(f"max_rd_len={L}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq={tmp_path}/reads.fq\n")
+    cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", str(cfg), "-K", str(K), "-p", str(p), "-o", str(tmp_path / "out"),
+           "--max-k", str(gu.VARIANT_MAXK[variant])]
+    if d:
+        cmd += ["-d", str(d)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # the reference's pipeline in the oracle (call_pregraph's order, pregraph.c:63-89)
+    o = ob.Oracle(K, nsets=p, nw=gu.VARIANT_WORDS[variant])
+    o.add_reads(codes, offs)
+    if d:
+        o.delow(d)
+    hist, _ = o.mark()
+    o.remove_minor_out(5)
+    if not d:
+        o.remove_single_tips()
+    o.remove_minor_tips()
+    nvert = o.write_vertex(str(tmp_path / "o.vertex"))
+    num_ed, _, _ = o.write_edges(str(tmp_path / "o.edge"))
+    o.read2edge(codes, offs, str(tmp_path / "o.preArc"))
+    assert nvert > 0 and num_ed > 0
+    assert open(tmp_path / "out.kmerFreq").read() == ob.kmerfreq_text(hist)
+    assert open(tmp_path / "out.vertex").read() == open(tmp_path / "o.vertex").read()
+    assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == open(tmp_path / "o.edge").read()
+    assert open(tmp_path / "out.preArc").read() == open(tmp_path / "o.preArc").read()
+    assert f"EDGEs {num_ed}" in open(tmp_path / "out.preGraphBasic").read()
+
+
+@pytest.mark.gpu
 def test_cli_usage_and_errors(pkg, tmp_path):
     exe = bin_path(pkg, "sdt-pregraph")
     r = subprocess.run([exe, "pregraph"], capture_output=True, text=True)
