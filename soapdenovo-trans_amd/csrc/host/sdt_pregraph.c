@@ -379,7 +379,9 @@ int main(int argc, char **argv)
 	}
 	const int my_threads = gpus == 1 ? threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
 	sdt_ctx *gpu = NULL;
-	const uint32_t iflags = hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS));
+	/* SDT_PIPELINE=1 (tests): the locality pipeline also for jobs below its 2^27 k-mer threshold */
+	const uint32_t iflags = (hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS))) |
+	                        (getenv("SDT_PIPELINE") ? SDT_FLAG_PARTITION : 0);
 	if (sdt_gpu_init(&gpu, share_device ? device : device + rank, K, est / (unsigned long long)gpus, iflags) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;

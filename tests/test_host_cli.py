@@ -134,10 +134,11 @@ def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus):
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,p,d,L,variant,seed,gpus", [(25, 3, 0, 90, 31, 1, 1), (31, 5, 1, 120, 31, 2, 1), (45, 2, 0, 150, 63, 3, 1),
                                                        (63, 7, 0, 200, 63, 4, 1), (71, 4, 0, 200, 127, 5, 1), (21, 1, 2, 100, 31, 6, 1),
-                                                       (31, 4, 0, 150, 31, 7, 2), (47, 3, 1, 150, 63, 8, 3)])
+                                                       (31, 4, 0, 150, 31, 7, 2), (47, 3, 1, 150, 63, 8, 3),
+                                                       (31, 6, 0, 150, 31, 9, 0), (55, 2, 0, 250, 63, 10, 0), (95, 3, 0, 250, 127, 11, 0)])
 def test_cli_against_oracle_on_fresh_inputs(pkg, synth, tmp_path, K, p, d, L, variant, seed, gpus):
     """beyond the 12 fixtures: seeded synthetic reads (ragged, with errors, a few hairpins) through `sdt-pregraph` on the GPU
-    (the last two configurations with 2 and 3 ranks, bucket sharded) and through the C oracle's restatement of the WHOLE of pregraph (pass 1, -d, the three cleaning passes, kmer2edges, the
+    (two configurations with 2 and 3 ranks, bucket sharded; gpus = 0: one GPU with the locality pipeline forced) and through the C oracle's restatement of the WHOLE of pregraph (pass 1, -d, the three cleaning passes, kmer2edges, the
     second read pass) -- the oracle is pinned file by file against the reference on the fixtures
     (tests/test_oracle_vs_reference.py), so agreement here is agreement with the reference on inputs it never saw"""
     import oracle_binding as ob
@@ -162,6 +163,8 @@ def test_cli_against_oracle_on_fresh_inputs(pkg, synth, tmp_path, K, p, d, L, va
     if d:
         cmd += ["-d", str(d)]
     env = dict(os.environ)
+    if gpus == 0:                                         # one GPU, the locality pipeline forced (it starts at 2^27 k-mers otherwise)
+        env["SDT_PIPELINE"] = "1"
     if gpus > 1:                                          # one process per rank, all on the one GPU of the box (shared-memory transport)
         cmd += ["--gpus", str(gpus), "--share-device"]
         env["SDT_CHUNK_BYTES"] = "30000"
