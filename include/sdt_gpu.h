@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 3
+#define SDT_ABI_VERSION 4
 
 enum {
 	SDT_OK       = 0,
@@ -313,7 +313,7 @@ int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches,
 #define SDT_STAGE_SK_SPLIT    2   /* chunk lists + k_sk_scatter_records (level 2) */
 #define SDT_STAGE_SK_COUNT    3   /* k_sk_count: LDS counting + merges */
 #define SDT_NSTAGES           4
-#define SDT_NCOUNTERS         16
+#define SDT_NCOUNTERS         20   /* [16] distinct records of the count stage's tiles, [17] records (level-2), [18] k-mers of the distinct records, [19] reserved */
 int sdt_gpu_stage_times(sdt_ctx *ctx, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS]);
 /* the hash used for sharding (host-callable, identical to the device function):
  * owner rank = ((sdt_owner_hash(key) >> 32) * nranks) >> 32 */

@@ -114,6 +114,8 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("SDT_GPU_LIB", LIB_PATH)      # (A/B builds of the library: tools/, profiles/)
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -410,11 +412,11 @@ class PregraphGPU:
     def stage_times(self):
         """(ms per stage [direct, sk scatter, sk split, sk count], pipeline counters) since the last kernel_time(reset=True)"""
         ms = (ctypes.c_double * 4)()
-        cnt = (ctypes.c_uint64 * 16)()
+        cnt = (ctypes.c_uint64 * 20)()
         self._check(self.lib.sdt_gpu_stage_times(self._ctx, ms, cnt))
         names = ("merges", "lds_spills", "pool_direct", "early_flushes", "chunks_l1", "chunks_l2", "batches", "batch_kmers", "cnt_ticks_setup",
                  "cnt_ticks_fill", "cnt_ticks_count", "cnt_ticks_merge", "sc_ticks_stage", "sc_ticks_minima", "sc_ticks_starts",
-                 "sc_ticks_emit")
+                 "sc_ticks_emit", "distinct_records", "records", "distinct_record_kmers", "reserved1")
         return [float(x) for x in ms], dict(zip(names, (int(x) for x in cnt)))
 
 

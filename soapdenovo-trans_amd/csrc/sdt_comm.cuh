@@ -17,6 +17,8 @@
 #include <unistd.h>
 #include <time.h>
 #include <atomic>
+#include <utility>
+#include <vector>
 
 namespace sdt {
 
@@ -106,7 +108,9 @@ struct Comm {
 	// accounting (sdt_gpu_comm_stats)
 	uint64_t bytes_sent = 0, bytes_recv = 0, exchanges = 0;
 	double exchange_ms = 0;
-	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	// RCCL: one event pair per exchange() call; harvest_time() adds the pairs that have completed, each exactly once
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	size_t ev_used = 0, ev_harvested = 0;
 
 	ShmHeader *hdr() const { return (ShmHeader *)shm; }
 	uint8_t *ctrl(int r) const { return shm + SHM_HEADER_BYTES + (size_t)r * SHM_CTRL_BYTES; }
@@ -177,35 +181,44 @@ struct Comm {
 	}
 
 	// Move bytes between device buffers: send_ptr[p] / send_bytes[p] go to rank p, recv_ptr[p] / recv_bytes[p] come from
-	// rank p (p == rank is skipped: the caller places its own share itself).  `after` (may be NULL) is an event the
-	// exchange waits for; the call returns once the exchange is enqueued on xstream (RCCL) or done (SHM).
-	int exchange(void *const *send_ptr, const size_t *send_bytes, void *const *recv_ptr, const size_t *recv_bytes,
-	             const size_t *peer_outbox_off /* [src * nranks + dst]: SHM layout, computed by the caller from the count matrix */)
+	// rank p (p == rank is skipped: the caller places its own share itself) -- for `nsets` sets of buffers at once (the chunk
+	// payloads and their meta words travel in ONE group).  The call returns once the exchange is enqueued on xstream (RCCL) or
+	// done (SHM).  peer_outbox_off[set][src * nranks + dst]: SHM layout, computed by the caller from the count matrix.
+	int exchange(int nsets, void *const *const *send_ptr, const size_t *const *send_bytes, void *const *const *recv_ptr,
+	             const size_t *const *recv_bytes, const size_t *const *peer_outbox_off)
 	{
 		if (nranks == 1 || kind == 0)
 			return SDT_OK;
 		size_t sb = 0, rb = 0;
-		for (int p = 0; p < nranks; p++)
-			if (p != rank) { sb += send_bytes[p]; rb += recv_bytes[p]; }
+		for (int s = 0; s < nsets; s++)
+			for (int p = 0; p < nranks; p++)
+				if (p != rank) { sb += send_bytes[s][p]; rb += recv_bytes[s][p]; }
 		bytes_sent += sb;
 		bytes_recv += rb;
 		exchanges++;
 		if (kind == 1) {
-			HIPCHK(hipEventRecord(ev_a, xstream));
+			if (ev_used == ev.size()) {
+				std::pair<hipEvent_t, hipEvent_t> e;
+				HIPCHK(hipEventCreate(&e.first));
+				HIPCHK(hipEventCreate(&e.second));
+				ev.push_back(e);
+			}
+			HIPCHK(hipEventRecord(ev[ev_used].first, xstream));
 			NCCLCHK(g_rccl.GroupStart());
 			// pieces of at most 256 MiB, the same on both sides (a rank's send_bytes[p] is p's recv_bytes[rank]): collectives of
-			// this RCCL past 1 GiB per call were seen to deliver garbage (soapdenovo-trans_amd/sharding.py), and nothing is
-			// lost by staying far below
+			// this RCCL past 1 GiB per call were seen to deliver garbage in round 1, and nothing is lost by staying far below
 			const size_t PIECE = (size_t)256 << 20;
-			for (int p = 0; p < nranks; p++) {
-				if (p == rank) continue;
-				for (size_t o = 0; o < send_bytes[p]; o += PIECE)
-					NCCLCHK(g_rccl.Send((const char *)send_ptr[p] + o, send_bytes[p] - o < PIECE ? send_bytes[p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
-				for (size_t o = 0; o < recv_bytes[p]; o += PIECE)
-					NCCLCHK(g_rccl.Recv((char *)recv_ptr[p] + o, recv_bytes[p] - o < PIECE ? recv_bytes[p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
-			}
+			for (int s = 0; s < nsets; s++)
+				for (int p = 0; p < nranks; p++) {
+					if (p == rank) continue;
+					for (size_t o = 0; o < send_bytes[s][p]; o += PIECE)
+						NCCLCHK(g_rccl.Send((const char *)send_ptr[s][p] + o, send_bytes[s][p] - o < PIECE ? send_bytes[s][p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
+					for (size_t o = 0; o < recv_bytes[s][p]; o += PIECE)
+						NCCLCHK(g_rccl.Recv((char *)recv_ptr[s][p] + o, recv_bytes[s][p] - o < PIECE ? recv_bytes[s][p] - o : PIECE, NCCL_UINT8, p, nccl, xstream));
+				}
 			NCCLCHK(g_rccl.GroupEnd());
-			HIPCHK(hipEventRecord(ev_b, xstream));
+			HIPCHK(hipEventRecord(ev[ev_used].second, xstream));
+			ev_used++;
 			return SDT_OK;
 		}
 		// SHM: device -> my outbox, barrier, peers' outboxes -> device, barrier
@@ -213,33 +226,37 @@ struct Comm {
 			return fail(SDT_ESTATE, "shared-memory transport opened without a device");
 		HIPCHK(hipStreamSynchronize(xstream));
 		const double t0 = comm_now();
-		for (int p = 0; p < nranks; p++) {
-			if (p == rank || !send_bytes[p]) continue;
-			const size_t off = peer_outbox_off[(size_t)rank * nranks + p];
-			if (off + send_bytes[p] > outbox_bytes)
-				return fail(SDT_ENOMEM, "shared-memory transport: outbox of %zu MiB too small (set SDT_SHM_OUTBOX_MB)", outbox_bytes >> 20);
-			HIPCHK(hipMemcpy(outbox(rank) + off, send_ptr[p], send_bytes[p], hipMemcpyDeviceToHost));
-		}
+		for (int s = 0; s < nsets; s++)
+			for (int p = 0; p < nranks; p++) {
+				if (p == rank || !send_bytes[s][p]) continue;
+				const size_t off = peer_outbox_off[s][(size_t)rank * nranks + p];
+				if (off + send_bytes[s][p] > outbox_bytes)
+					return fail(SDT_ENOMEM, "shared-memory transport: outbox of %zu MiB too small (set SDT_SHM_OUTBOX_MB)", outbox_bytes >> 20);
+				HIPCHK(hipMemcpy(outbox(rank) + off, send_ptr[s][p], send_bytes[s][p], hipMemcpyDeviceToHost));
+			}
 		int rc = shm_barrier();
 		if (rc != SDT_OK) return rc;
-		for (int p = 0; p < nranks; p++) {
-			if (p == rank || !recv_bytes[p]) continue;
-			const size_t off = peer_outbox_off[(size_t)p * nranks + rank];
-			HIPCHK(hipMemcpy(recv_ptr[p], outbox(p) + off, recv_bytes[p], hipMemcpyHostToDevice));
-		}
+		for (int s = 0; s < nsets; s++)
+			for (int p = 0; p < nranks; p++) {
+				if (p == rank || !recv_bytes[s][p]) continue;
+				const size_t off = peer_outbox_off[s][(size_t)p * nranks + rank];
+				HIPCHK(hipMemcpy(recv_ptr[s][p], outbox(p) + off, recv_bytes[s][p], hipMemcpyHostToDevice));
+			}
 		rc = shm_barrier();
 		exchange_ms += (comm_now() - t0) * 1e3;
 		return rc;
 	}
 
-	// RCCL: add the time of the exchanges that have completed (call after a sync of xstream)
+	// RCCL: add the time of the exchanges enqueued since the last call (call after a sync of xstream: all have completed)
 	int harvest_time()
 	{
-		if (kind == 1 && exchanges) {
+		for (; kind == 1 && ev_harvested < ev_used; ev_harvested++) {
 			float t = 0;
-			if (hipEventElapsedTime(&t, ev_a, ev_b) == hipSuccess)
+			if (hipEventElapsedTime(&t, ev[ev_harvested].first, ev[ev_harvested].second) == hipSuccess)
 				exchange_ms += t;
 		}
+		if (ev_harvested == ev_used)
+			ev_harvested = ev_used = 0;                  // every pair is free again
 		return SDT_OK;
 	}
 
@@ -255,8 +272,6 @@ struct Comm {
 		if (rc != SDT_OK) return rc;
 		rank = r; nranks = n;
 		HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
-		HIPCHK(hipEventCreate(&ev_a));
-		HIPCHK(hipEventCreate(&ev_b));
 		NCCLCHK(g_rccl.CommInitRank(&nccl, n, *id, r));
 		HIPCHK(hipMalloc(&d_ctrl, SHM_CTRL_BYTES * (size_t)(n + 1)));
 		HIPCHK(hipHostMalloc(&h_ctrl, SHM_CTRL_BYTES * (size_t)(n + 1), hipHostMallocDefault));
@@ -322,8 +337,7 @@ struct Comm {
 		}
 		if (d_ctrl) (void)hipFree(d_ctrl);
 		if (h_ctrl) (void)hipHostFree(h_ctrl);
-		if (ev_a) (void)hipEventDestroy(ev_a);
-		if (ev_b) (void)hipEventDestroy(ev_b);
+		for (auto &e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 		if (xstream) (void)hipStreamDestroy(xstream);
 		*this = Comm();
 	}

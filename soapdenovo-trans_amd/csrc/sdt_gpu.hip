@@ -530,8 +530,8 @@ struct sdt_ctx {
 		unsigned long long *blk = nullptr;       // [wgs] block of chunk ids each workgroup is handing out
 		uint32_t wgs = 0;
 		uint32_t *cnt1 = nullptr, *off1 = nullptr, *fill1 = nullptr, *list1 = nullptr;
-		uint32_t *cnt2 = nullptr, *off2 = nullptr, *fill2 = nullptr, *list2 = nullptr, *kmers2 = nullptr;
-		unsigned long long *kpre2 = nullptr;
+		uint32_t *cnt2 = nullptr, *off2 = nullptr, *fill2 = nullptr, *list2 = nullptr;
+		unsigned long long *kmers2 = nullptr, *kpre2 = nullptr;
 		SkItem *items = nullptr;
 		uint32_t items_cap = 0;
 		uint2 *citems = nullptr, *h_citems = nullptr;       // work items of k_sk_count: [c0, c1) in list2 (device / pinned)
@@ -834,9 +834,11 @@ static SkGeo sk_geo(int K, uint64_t max_read_len)
 
 template <int NW, bool TRACK> static size_t sk_count_smem()
 {
-	constexpr int SLOTS = SkCntGeo<NW, TRACK>::SLOTS, BW = SkFmt<NW>::BW, TR = SkCntGeo<NW, TRACK>::TILE;
-	return (size_t)(NW + (TRACK ? 1 : 0)) * SLOTS * 8 + (size_t)TR * 8 + (size_t)SLOTS * 20 + (size_t)(TR + 2) * 4 +
-	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4 + (SkCntGeo<NW, TRACK>::COARSE_INDEX ? (size_t)TR * 4 * 2 : 0);
+	using G = SkCntGeo<NW, TRACK>;
+	constexpr int SLOTS = G::SLOTS, BW = SkFmt<NW>::BW, TR = G::TILE;
+	// keys (+ ordinals), headers, 5 field words per slot, weights, the prefix / map / index region (= dedupe table), the tile's bases
+	return (size_t)(NW + (TRACK ? 1 : 0)) * SLOTS * 8 + (size_t)TR * 8 + (size_t)SLOTS * 20 + (size_t)TR * 4 + G::REGION +
+	       (size_t)(LDS_LEAD + TR * BW * 2 + TAIL_PAD) * 4;
 }
 
 static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
@@ -890,7 +892,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;
 		// (a sharded context adds two send and two receive buffers of pool-1 size: shard_alloc)
 		const uint64_t all = c->comm.nranks > 1 ? bytes + chunks1 * SK_CAP1 * rw * 8 * 9 / 2 : bytes;
-		if (chunks2 >= 0xFFFFFF00ULL || all > free_b / 2) {
+		if (chunks2 >= (1ULL << SK_LIST2_FILL_SHIFT) || all > free_b / 2) {      // (a list2 entry has 27 bits for the chunk id)
 			k.cap_is_max = true;
 			if (cap <= (1ULL << 24))
 				return fail(SDT_ENOMEM, "super-k-mer pools: %llu MiB needed for the smallest batch, %zu MiB free",
@@ -920,7 +922,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	HIPCHK(hipMalloc((void **)&k.off2, (SK_NBF + 1) * 4));
 	HIPCHK(hipMalloc((void **)&k.fill2, SK_NBF * 4));
 	HIPCHK(hipMalloc((void **)&k.list2, (size_t)k.p2.chunks * 4));
-	HIPCHK(hipMalloc((void **)&k.kmers2, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&k.kmers2, SK_NBF * 8));
 	HIPCHK(hipMalloc((void **)&k.kpre2, (SK_NBF + 1) * 8));
 	HIPCHK(hipMalloc((void **)&k.items, (size_t)k.items_cap * sizeof(SkItem)));
 	HIPCHK(hipHostMalloc((void **)&k.h_off1, (SK_NB1 + 1) * 4, hipHostMallocDefault));
@@ -972,7 +974,7 @@ static int sk_list1(sdt_ctx *c)
 	sdt_ctx::SkState &k = c->sk;
 	const int g = c->cu_count * 8;
 	hipLaunchKernelGGL(k_sk_seal, dim3(256), dim3(256), 0, c->stream, k.cursors, k.wgs * (uint32_t)SK_NB1, k.blk, k.wgs, k.p1, (uint32_t)SK_CAP1);
-	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt1, k.off1, k.fill1, (int)SK_NB1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
 	hipLaunchKernelGGL(k_sk_chunk_place_few, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1, (int)SK_NB1);
 	SK_CHK(hipGetLastError());
 	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -989,7 +991,7 @@ static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_
 	sdt_ctx::SkState &k = c->sk;
 	const int g = c->cu_count * 8;
 	SK_CHK(hipMemsetAsync(k.p2.next, 0, 4, c->stream));
-	SK_CHK(hipMemsetAsync(k.kmers2, 0, SK_NBF * 4, c->stream));
+	SK_CHK(hipMemsetAsync(k.kmers2, 0, SK_NBF * 8, c->stream));
 	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
 	if (nitems) {
 		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
@@ -1009,7 +1011,7 @@ static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_
 	}
 	if (after_l2)
 		SK_CHK(hipEventRecord(after_l2, c->stream));
-	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const uint32_t *)k.kmers2, k.kpre2);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, k.cnt2, k.off2, k.fill2, (int)SK_NBF, (const unsigned long long *)k.kmers2, k.kpre2);
 	hipLaunchKernelGGL(k_sk_chunk_place, dim3(g), dim3(256), 0, c->stream, k.p2, k.off2, k.fill2, k.list2);
 	SK_CHK(hipGetLastError());
 	SK_CHK(hipMemcpyAsync(k.h_kpre2, k.kpre2, (SK_NBF + 1) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1081,8 +1083,10 @@ static int sk_count_all(sdt_ctx *c)
 		}
 		if (rc == SDT_OK)
 			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
-		c->kmers_since_sync += bound;
-		c->hard_since_sync += launch_kmers[l];
+		if (rc == SDT_OK) {                              // (only what was launched counts)
+			c->kmers_since_sync += bound;
+			c->hard_since_sync += launch_kmers[l];
+		}
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
 	return rc;
@@ -1127,16 +1131,29 @@ static int sk_flush(sdt_ctx *c)
 	if (rc == SDT_OK) rc = sk_reset_pool1(c);
 	if (rc == SDT_OK && (hipEventRecord(ev->b, c->stream) != hipSuccess || hipEventRecord(ev2->a, c->stream) != hipSuccess))
 		rc = fail(SDT_EHIP, "hipEventRecord failed");
-	k.pending_kmers = 0;
-	if (rc == SDT_OK) rc = sk_count_all(c);
+	if (rc == SDT_OK) {
+		k.pending_kmers = 0;
+		rc = sk_count_all(c);
+	}
 	if (hipEventRecord(ev2->b, c->stream) != hipSuccess && rc == SDT_OK)
 		rc = fail(SDT_EHIP, "hipEventRecord failed");
 	k.flushing = false;
 	return rc;
 }
 
+template <int NW> static Table<NW> sk_tbl(const sdt_ctx *c, bool allow_direct)
+{
+	Table<NW> t = table_of<NW>(c);
+	if (!allow_direct)
+		t.ent = nullptr;
+	return t;
+}
+
 // one launch of the level-1 scatter over reads [0, nr) of a device-resident batch (ordinals from `ob`)
-static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nr, uint64_t max_read_len, uint64_t ob)
+// (allow_direct = false: a record that finds no chunk is an error, not a put into the local table -- sharded contexts, where
+// the local table owns only some buckets, and the range-weighing sample, whose reads are scattered a second time)
+static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nr, uint64_t max_read_len, uint64_t ob,
+                             bool allow_direct = true)
 {
 	sdt_ctx::SkState &k = c->sk;
 	const uint64_t per_read = max_read_len - c->K + 1;
@@ -1154,7 +1171,7 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 	do {                                                                                                                       \
 		HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
 		hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, \
-		                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, table_of<NW>(c), c->d_stats, ob, c->ord_stride); \
+		                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, sk_tbl<NW>(c, allow_direct), c->d_stats, ob, c->ord_stride); \
 	} while (0)
 	// one lane per read where the window length has an instantiation and the run list can hold a read
 	const int w = c->K - m + 1;
@@ -1168,8 +1185,8 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 		a.mtw = (int)(((uint64_t)SK_SEQ_TILE * max_read_len + 16 + 15) / 16) + TAIL_PAD + 1;
 		a.pool = k.p1; a.cursors = k.cursors; a.blk = k.blk; a.cnt = k.cnt1; a.stats = c->d_stats;
 		a.ord_base = ob; a.ord_stride = c->ord_stride; a.max_wgs = k.wgs; a.cu_count = c->cu_count; a.stream = c->stream;
-		HIPCHK(seq1 ? sk_seq_launch_nw1(w, a, table_of<1>(c)) : (w <= 33 ? sk_seq_launch_nw2_lo(w, a, table_of<2>(c))
-		            : (w <= 43 ? sk_seq_launch_nw2_mid(w, a, table_of<2>(c)) : sk_seq_launch_nw2_hi(w, a, table_of<2>(c)))));
+		HIPCHK(seq1 ? sk_seq_launch_nw1(w, a, sk_tbl<1>(c, allow_direct)) : (w <= 33 ? sk_seq_launch_nw2_lo(w, a, sk_tbl<2>(c, allow_direct))
+		            : (w <= 43 ? sk_seq_launch_nw2_mid(w, a, sk_tbl<2>(c, allow_direct)) : sk_seq_launch_nw2_hi(w, a, sk_tbl<2>(c, allow_direct)))));
 	} else if (c->nw == 1) SK_SCATTER(1);
 	else if (c->nw == 2) SK_SCATTER(2);
 	else SK_SCATTER(4);
@@ -1287,8 +1304,8 @@ static int shard_finish_pending(sdt_ctx *c)
 	memcpy(k.h_items, h.items.data(), h.items.size() * sizeof(SkItem));
 	SkPool src = {h.recv[slot], h.recv_meta[slot], nullptr, h.recv_chunks};
 	int rc = sk_split(c, src, h.iota, (uint32_t)h.items.size(), h.ev_l2[slot]);
-	h.l2_recorded[slot] = true;
 	if (rc != SDT_OK) return rc;
+	h.l2_recorded[slot] = true;                      // (only an event that was recorded may be waited for)
 	HIPCHK(hipEventRecord(ev->b, c->stream));
 	HIPCHK(hipEventRecord(ev2->a, c->stream));
 	rc = sk_count_all(c);
@@ -1411,9 +1428,12 @@ static int sk_flush_sharded(sdt_ctx *c)
 		HIPCHK(hipStreamWaitEvent(cm.xstream, h.ev_gather[slot], 0));
 		if (h.l2_recorded[slot])
 			HIPCHK(hipStreamWaitEvent(cm.xstream, h.ev_l2[slot], 0));
-		rc = cm.exchange(sp.data(), sb.data(), rp.data(), rb.data(), oboff.data());
-		if (rc == SDT_OK)
-			rc = cm.exchange(smp.data(), smb.data(), rmp.data(), rmb.data(), obmoff.data());
+		{
+			// payloads and metas in ONE grouped exchange (one event pair: the time sdt_gpu_comm_stats reports covers both)
+			void *const *const sps[2] = {sp.data(), smp.data()}, *const *const rps[2] = {rp.data(), rmp.data()};
+			const size_t *const sbs[2] = {sb.data(), smb.data()}, *const rbs[2] = {rb.data(), rmb.data()}, *const obs[2] = {oboff.data(), obmoff.data()};
+			rc = cm.exchange(2, sps, sbs, rps, rbs, obs);
+		}
 		if (rc != SDT_OK) return rc;
 		HIPCHK(hipEventRecord(h.ev_xdone[slot], cm.xstream));
 		h.x_recorded[slot] = true;
@@ -2860,7 +2880,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		// equal weight.  Every rank computes the same cut from the all-gathered counts; the sample's records are dropped.
 		const uint64_t sample = nreads < (1ULL << 18) ? nreads : (1ULL << 18);
 		if (sample) {
-			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, sample, maxlen, c->ord_base);
+			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, sample, maxlen, c->ord_base, false);
 			if (rc != SDT_OK) return rc;
 		}
 		rc = sk_list1(c);
@@ -2904,7 +2924,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		const uint64_t r0 = i * per_round;
 		const uint64_t nr = r0 < nreads ? (nreads - r0 < per_round ? nreads - r0 : per_round) : 0;
 		if (nr) {
-			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets + r0, nr, maxlen, c->ord_base + r0 * c->ord_stride);
+			rc = sk_scatter_launch(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets + r0, nr, maxlen, c->ord_base + r0 * c->ord_stride, false);
 			if (rc != SDT_OK) return rc;
 			c->sh.kmers_scattered += nr * per_read;
 		}
@@ -2988,6 +3008,10 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 			counters[8 + i] = c->h_stats->sk_cyc[i];
 		for (int i = 0; i < 4; i++)
 			counters[12 + i] = c->h_stats->sk_cyc1[i];
+		counters[16] = c->h_stats->sk_distinct_recs;
+		counters[17] = c->h_stats->sk_records;
+		counters[18] = c->h_stats->sk_distinct_kmers;
+		counters[19] = 0;
 	}
 	return SDT_OK;
 }

@@ -123,7 +123,7 @@ template <int NW> __device__ inline Key<NW> stream_kmer(const uint32_t *lds, int
 	for (int i = 0; i < NW; i++) {
 		const uint64_t a = lds[wi + 2 * i], b = lds[wi + 2 * i + 1], c = lds[wi + 2 * i + 2];
 		const uint64_t hi = (a << 32) | b;
-		k.w[i] = sh ? ((hi << sh) | (c >> (32 - sh))) : hi;
+		k.w[i] = (hi << sh) | (c >> (32 - sh));     // (c holds 32 bits in a 64-bit word: sh == 0 shifts all of them out, no branch)
 	}
 	// createFilter (kmer.c:313-355): keep the low 2K bits.  With 4-word keys K may be as small as 65, so
 	// more than one leading word can be (partly) outside the k-mer.
@@ -147,8 +147,10 @@ __device__ inline Key<NW> chop_record(const uint32_t *lds, int rb, int len, int 
 	const Key<NW> fw = stream_kmer<NW>(lds, p, K);
 	const Key<NW> rc = key_revcomp<NW>(fw, K);
 	const bool has_l = j > 0, has_r = j < len - K;
-	const uint32_t lb = has_l ? stream_base(lds, p - 1) : 0u;
-	const uint32_t rbse = has_r ? stream_base(lds, p + K) : 0u;
+	// (both neighbours are read whether they exist or not: the lead / tail words of the tile make that legal, and two
+	// conditional LDS reads were two exec-mask branches per k-mer)
+	const uint32_t lb = stream_base(lds, p - 1);
+	const uint32_t rbse = stream_base(lds, p + K);
 	if (key_less<NW>(fw, rc)) {
 		prev = has_l ? lb : 4u;
 		next = has_r ? rbse : 4u;

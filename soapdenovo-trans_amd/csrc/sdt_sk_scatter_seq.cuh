@@ -142,6 +142,9 @@ __device__ inline void sk_emit_run(const uint32_t *words, int rb_r, int len_r, i
 		}
 		sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
 		emitted += (uint32_t)n;
+	} else if (!tbl.ent) {
+		// no chunk left and no table to fall back on (a sharded context: this rank does not own every key; the caller gets SDT_EFULL)
+		failed += (uint32_t)n;
 	} else {
 		// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
 		for (int jj = j0; jj < j0 + n; jj++) {
@@ -229,7 +232,9 @@ __global__ __launch_bounds__(SK_SEQ_TILE, NW == 1 ? 4 : 2) void k_sk_scatter_rea
 				const uint32_t fb = sk_final_bucket(sk_bucket_hash(mn));
 				if (j == 0) {
 					fb0 = fb;
-				} else if ((j & (ncap - 1)) == 0 || fb != pfb) {
+				} else if (j - j0 >= ncap || fb != pfb) {        // (a full record ends ncap k-mers after ITS start, not at a multiple of
+					                                         //  ncap in the read: reads that cover the same stretch then cut the same
+					                                         //  records out of it, and k_sk_count's dedupe folds them into one)
 					if (nrun < SK_SEQ_RUNCAP)
 						runs[nrun] = (fb0 << 14) | ((uint32_t)(j - j0 - 1) << 8) | (uint32_t)j0;
 					else

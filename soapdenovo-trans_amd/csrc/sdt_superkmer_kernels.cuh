@@ -2,23 +2,43 @@
 // Included by sdt_gpu.hip after stage_tile / TileView / tile_find_read / chop_record are defined.
 #pragma once
 
-// k_sk_count geometry: two workgroups per CU wherever the LDS table allows it (their fill / count / merge phases overlap)
-#ifndef SDT_SK_TRACK_GEO
-#define SDT_SK_TRACK_GEO 0
+// k_sk_count geometry: 1024 lanes, tiles of 512 records; two workgroups per CU wherever the LDS table allows it (their fill /
+// dedupe / count / merge phases overlap)
+#ifndef SDT_SK_PREFETCH
+#define SDT_SK_PREFETCH 1      // one dword of every record of the next tile is loaded (and dropped) during phases A-C: L2 warm-up (0: off)
 #endif
-template <int NW, bool TRACK> struct SkCntGeo {
-	// + 8 B ordinal per slot (TRACK, 1-word keys): variant 0 halves the workgroup, variant 1 halves the table
-	static constexpr bool SMALL = TRACK && NW == 1 && SDT_SK_TRACK_GEO == 0;
-	static constexpr int TPB = SMALL ? 512 : 1024;
-	static constexpr int TILE = SMALL ? 256 : 512;                        // records per tile
-	static constexpr int TILE_LOG2 = SMALL ? 8 : 9;
-	static constexpr bool COARSE_INDEX = !SMALL;                           // (the small geometry has no LDS to spare for it)
+#ifndef SDT_SK_CLAIM_BELOW
+#define SDT_SK_CLAIM_BELOW 0      // flush: keys counted at most this often send their slot claim along with the loads (0: never; 2 measured 5 % slower: profiles/r3)
+#endif
+#ifndef SDT_SK_FLUSH_NUM
+#define SDT_SK_FLUSH_NUM 4        // the LDS table is flushed between rounds once it is FLUSH_NUM / 8 full
+#endif
+#ifndef SDT_SK_CNT_TPB
+#define SDT_SK_CNT_TPB 1024
+#endif
+#ifndef SDT_SK_SLOTS_TRACK
+#define SDT_SK_SLOTS_TRACK 1536
+#endif
 #ifndef SDT_SK_SLOTS_NW2
 #define SDT_SK_SLOTS_NW2 2048
 #endif
-	static constexpr int SLOTS = (TRACK && NW == 1 && SDT_SK_TRACK_GEO == 1) ? 1024 : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);   // LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal)
-	static constexpr int FLUSH_AT = SLOTS / 2;                            // flush + clear between rounds past this load ...
+template <int NW, bool TRACK> struct SkCntGeo {
+	static constexpr int TPB = SDT_SK_CNT_TPB;
+	static constexpr int WAVES_PER_SIMD = NW == 1 ? 2 * (TPB / 256) : TPB / 256;      // 1-word keys: two workgroups per CU
+	static constexpr int TILE = 512;                                       // records per tile
+	// LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal).  1-word keys: 2048 slots = 75 KB with the tile, two
+	// workgroups per CU; with ordinals half the table keeps it at two
+	static constexpr int SLOTS = NW == 1 ? (TRACK ? SDT_SK_SLOTS_TRACK : 2048) : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);
+	// (any size: 1-word keys with ordinals take 1536 slots, 36 B each -- the most that leaves two workgroups per CU)
+	static constexpr int FLUSH_AT = SLOTS * SDT_SK_FLUSH_NUM / 8;                            // flush + clear between rounds past this load ...
 	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
+	static constexpr int MAXN = NW == 1 ? 32 : 64;                        // k-mers per record at most (sk_max_run)
+	static constexpr int IDXN = TILE * MAXN / 16;                         // coarse index: one entry per 16 k-mers of a tile
+	static constexpr int REP = 2 * TILE;                                  // slots of the tile's record-dedupe table
+	// region shared by the dedupe table (phase B) and prefix / map / coarse index (phases C, D)
+	static constexpr size_t REGION = (((size_t)(TILE + 2) * 4 + (size_t)TILE * 2 + (size_t)IDXN * 2) + 7) & ~(size_t)7;
+	static_assert(((LDS_LEAD + TAIL_PAD) & 1) == 0, "the LDS table behind the tile's words is 8-byte aligned");
+	static_assert(REGION >= (size_t)REP * 4, "the dedupe table aliases prefix + map + index");
 };
 #ifndef SDT_SK_L2_TPB
 #define SDT_SK_L2_TPB 512
@@ -27,6 +47,7 @@ constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one la
 #ifndef SDT_SK_L2_DEPTH
 #define SDT_SK_L2_DEPTH 2
 #endif
+constexpr int SK_LIST2_FILL_SHIFT = 27;           // list2 entry = chunk id (27 bits) | (records in use - 1) << 27
 constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 
@@ -220,6 +241,8 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 				}
 				sk_store_record<RW>(pool.recs + ((size_t)chunk * SK_CAP1 + pos) * RW, rec);
 				emitted += (uint32_t)n;
+			} else if (!tbl.ent) {
+				failed += (uint32_t)n;                   // (a sharded context has no table to fall back on: sk_emit_run)
 			} else {
 				// no chunk left: these k-mers take the direct path (put_kmerset, one atomic per occurrence)
 				const int len_r = (int)(tv.rb[r + 1] - tv.rb[r]);
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cur
 // ---- chunk lists per bucket (counting sort of chunk ids by bucket) ---------------------------------------------
 // exclusive scans over nb buckets by ONE workgroup of 1024: off[0..nb] of cnt, and (kmers != NULL) kpre[0..nb] of kmers
 __global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
-                                                  int nb, const uint32_t *__restrict__ kmers, unsigned long long *__restrict__ kpre)
+                                                  int nb, const unsigned long long *__restrict__ kmers, unsigned long long *__restrict__ kpre)
 {
 	__shared__ unsigned long long s_a[1024], s_b[1024];
 	const int t = threadIdx.x, per = (nb + 1023) / 1024;
@@ -333,7 +356,9 @@ __global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint3
 		if (mt == SK_DEAD)
 			continue;
 		const uint32_t b = mt & 0xFFFFFFu;
-		list[off[b] + atomicAdd(&fillcur[b], 1u)] = c;
+		// level 2 only: the entry carries the chunk's fill (1..16) above the 27-bit chunk id, so that k_sk_count needs no
+		// look at pool.meta between the chunk id and the record (one memory round trip and one live register less)
+		list[off[b] + atomicAdd(&fillcur[b], 1u)] = c | (((mt >> 24) - 1u) << SK_LIST2_FILL_SHIFT);
 	}
 }
 
@@ -375,7 +400,7 @@ struct SkItem { uint32_t b1, c0, c1, pad; };
 template <int NW>
 __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, const uint32_t *__restrict__ list1,
                                                                   const SkItem *__restrict__ items, SkPool dst,
-                                                                  uint32_t *__restrict__ g_cnt, uint32_t *__restrict__ g_kmers, Stats *stats)
+                                                                  uint32_t *__restrict__ g_cnt, unsigned long long *__restrict__ g_kmers, Stats *stats)
 {
 	constexpr int RW = SkFmt<NW>::REC_WORDS;
 	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
@@ -451,7 +476,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		if (chunk != SK_NOCHUNK)
 			dst.meta[chunk] = (it.b1 * SK_NB2 + (uint32_t)i) | ((pos < (uint32_t)SK_CAP2 ? pos : (uint32_t)SK_CAP2) << 24);
 		if (s_kc[i])
-			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], s_kc[i]);
+			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], (unsigned long long)s_kc[i]);     // (64 bits: a hot bucket of a 2^33-k-mer batch)
 		if (s_cc[i])
 			atomicAdd(&g_cnt[it.b1 * SK_NB2 + i], s_cc[i]);
 	}
@@ -498,28 +523,46 @@ __global__ __launch_bounds__(256) void k_sk_iota(uint32_t *p, uint32_t n)
 }
 
 // ---- count: persistent workgroups, one final bucket at a time ---------------------------------------------------
-// LDS node = key word(s) + 32-bit count + 8 link counters of 16 bits (two per 32-bit word), not the node table's
-// packed val: LDS adds must not need a CAS loop -- the records of a bucket are windows around ONE minimizer, so
-// the lanes of a wave keep hitting the same few keys.  A link counter is only incremented while the value read
-// just before is < 63, so it ends at min(63, n) + at most one increment per thread of the workgroup: 16 bits never
-// overflow, and clamping at 63 when the node is merged into the table is exactly the reference's saturating ++
-// (newhash.c:77-94).
-template <int NW> __device__ inline uint32_t sk_lds_hash(const Key<NW> &k)
+// Per tile of 512 records the work is done in four phases (SQ counter passes of the round-2 kernel, profiles/r3/: 222 vector +
+// 131 scalar instructions per k-mer occurrence, vector issue 70 % busy, the LDS array 33 % -- instructions, not LDS, were the
+// wall, so the way down is to do the per-k-mer work less often):
+//   A  records -> LDS
+//   B  DEDUPE: a bucket holds windows around a handful of minimizers, and reads that cover the same stretch of a transcript cut
+//      IDENTICAL records out of it (same bases, same length, same context flags).  Every record looks itself up in a small hash
+//      table of record indices (one CAS; on a hit, a 16..48-byte compare against the representative's words in LDS): duplicates
+//      add 1 to the representative's weight (and, with ordinals, atomicMin their header into the representative's: the low 18
+//      header bits of identical records are identical) and drop out.
+//   C  exclusive prefix of the k-mers of the DISTINCT records, compact map, coarse index
+//   D  one lane per k-mer of a distinct record: cut, canonical, LDS table probe, and TWO LDS atomic adds of the record's weight.
+// LDS node = key word(s) + ten 16-bit counters in five words: {L0,L1} {L2,L3} {Lnone,Rnone} {R3,R2} {R1,R0} -- an occurrence adds
+// its weight to ONE left field (its prev code, or "none") and ONE right field, so count = sum of the left fields and nothing
+// is read before it is added to.  The fields cannot overflow: the table is merged into the node table and cleared before the
+// k-mers counted into it since the last clear pass 65535 (`since`), whatever the keys are.  Clamping at 63 when a node is merged
+// is exactly the reference's saturating ++ (newhash.c:77-94).
+template <int NW> __device__ inline uint32_t sk_fold_key(const Key<NW> &k)
 {
-	uint32_t h = 0;
+	uint32_t x = 0;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
-		h = (h ^ (uint32_t)k.w[i]) * 0x9E3779B1u;
-		h = (h ^ (uint32_t)(k.w[i] >> 32)) * 0x85EBCA77u;
+		x = __builtin_rotateleft32(x, 7) ^ (uint32_t)k.w[i];
+		x = __builtin_rotateleft32(x, 9) ^ (uint32_t)(k.w[i] >> 32);
 	}
-	return h ^ (h >> 15);
+	return x;
+}
+// slot of a key in a table of SLOTS slots (any number): multiplicative hash, then the high word of hash x SLOTS
+template <int NW, int SLOTS> __device__ inline uint32_t sk_lds_hash(const Key<NW> &k)
+{
+	const uint32_t h = sk_fold_key<NW>(k) * 0x9E3779B1u;
+	if ((SLOTS & (SLOTS - 1)) == 0)
+		return h >> (32 - __builtin_ctz(SLOTS));
+	return __umulhi(h, (uint32_t)SLOTS);
 }
 
 // find-or-claim in the LDS table; -1: no room (full table or too many probes)
 template <int NW, int SLOTS>
 __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
 {
-	uint32_t s = sk_lds_hash<NW>(key) & (SLOTS - 1);
+	uint32_t s = sk_lds_hash<NW, SLOTS>(key);
 	int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
 	for (int probe = 0; probe < 96 && found == -2;) {
 		uint64_t k0 = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -552,83 +595,94 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 		}
 		if (same)
 			return (int)s;
-		s = (s + 1) & (SLOTS - 1);
+		s = s + 1 == (uint32_t)SLOTS ? 0u : s + 1;
 		probe++;
 	}
 	return found == -2 ? -1 : found;
 }
 
-// one occurrence: s_lk[4 * slot + side * 2 + (code >> 1)] holds the counters of codes (code & ~1) and (code | 1)
-__device__ inline void sk_lds_update(uint32_t *s_cnt, uint32_t *s_lk, int s, uint32_t prev, uint32_t next)
+// `w` occurrences with neighbour codes prev / next (0..3, 4 = none) into the five field words of slot s
+__device__ inline void sk_lds_update(uint32_t *s_f, int s, uint32_t prev, uint32_t next, uint32_t w)
 {
-	atomicAdd(&s_cnt[s], 1u);
-	if (prev < 4u) {
-		uint32_t *w = &s_lk[4 * s + (prev >> 1)];
-		const uint32_t sh = (prev & 1u) * 16u;
-		if (((*(volatile uint32_t *)w >> sh) & 0xFFFFu) < 63u)
-			atomicAdd(w, 1u << sh);
-	}
-	if (next < 4u) {
-		uint32_t *w = &s_lk[4 * s + 2 + (next >> 1)];
-		const uint32_t sh = (next & 1u) * 16u;
-		if (((*(volatile uint32_t *)w >> sh) & 0xFFFFu) < 63u)
-			atomicAdd(w, 1u << sh);
-	}
+	atomicAdd(&s_f[5 * s + (prev >> 1)], w << ((prev & 1u) << 4));              // {L0,L1} {L2,L3} {Lnone,..}
+	atomicAdd(&s_f[5 * s + 4 - (next >> 1)], w << (16u - ((next & 1u) << 4)));  // {R1,R0} {R3,R2} {..,Rnone}
 }
 
-// the node table's val layout (count low 16 | r_links | l_links, 6-bit fields clamped) and the high count of an LDS node
-__device__ inline uint64_t sk_lds_val(uint32_t cnt, const uint32_t *lk, uint32_t &hi)
+// the node table's val layout (count low 16 | r_links | l_links, 6-bit fields clamped) of an LDS node
+__device__ inline uint64_t sk_lds_val(const uint32_t *f)
 {
-	uint64_t v = (uint64_t)(cnt & 0xFFFFu) << 48;
+	uint64_t v = 0;
+	uint32_t cnt = f[2] & 0xFFFFu;
 #pragma unroll
 	for (int b = 0; b < 4; b++) {
-		const uint32_t l = (lk[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu, r = (lk[2 + (b >> 1)] >> ((b & 1) * 16)) & 0xFFFFu;
+		const uint32_t l = (f[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu, r = (f[4 - (b >> 1)] >> (16 - (b & 1) * 16)) & 0xFFFFu;
+		cnt += l;
 		v |= (uint64_t)(l > 63u ? 63u : l) << (6 * b);
 		v |= (uint64_t)(r > 63u ? 63u : r) << (24 + 6 * b);
 	}
-	hi = cnt >> 16;
+	return v | ((uint64_t)cnt << 48);      // (cnt <= SK_CNT_MAX_SINCE: 16 bits)
+}
+
+// `w` occurrences of one (key, prev, next) as a table_merge operand
+__device__ inline uint64_t sk_weighted_val(uint32_t w, uint32_t prev, uint32_t next)
+{
+	const uint64_t c = w > 63u ? 63u : w;
+	uint64_t v = (uint64_t)(w & 0xFFFFu) << 48;
+	if (prev < 4u) v |= c << (6 * prev);
+	if (next < 4u) v |= c << (24 + 6 * next);
 	return v;
 }
 
+constexpr uint32_t SK_CNT_MAX_SINCE = 65535;     // k-mers counted into the LDS table between two clears at most (16-bit fields)
+
 // (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU)
 template <int NW, bool TRACK>
-__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8 : 4) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
+__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
                                                          Table<NW> tbl, Stats *stats)
 {
-	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = SkCntGeo<NW, TRACK>::SLOTS;
-	constexpr uint32_t FLUSH_AT = SkCntGeo<NW, TRACK>::FLUSH_AT, MAXFILL = SkCntGeo<NW, TRACK>::MAXFILL;
-	constexpr int SK_CNT_TPB = SkCntGeo<NW, TRACK>::TPB, SK_CNT_TILE_LOG2 = SkCntGeo<NW, TRACK>::TILE_LOG2;
-	constexpr bool COARSE = SkCntGeo<NW, TRACK>::COARSE_INDEX;
-	constexpr int TR = SkCntGeo<NW, TRACK>::TILE;    // records per tile: the first TR lanes bring one each
+	using G = SkCntGeo<NW, TRACK>;
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = G::SLOTS;
+	constexpr uint32_t FLUSH_AT = G::FLUSH_AT, MAXFILL = G::MAXFILL;
+	constexpr int SK_CNT_TPB = G::TPB;
+	constexpr int TR = G::TILE;                      // records per tile: the first TR lanes bring one each
 	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
 	constexpr int NWAVES = TR / 64;
+	constexpr uint32_t REP = G::REP, REP_EMPTY = 0xFFFFFFFFu;
 	extern __shared__ unsigned long long sm64[];
-	unsigned long long *s_key = sm64;                                    // NW x SLOTS, word-major
+	// (the tile's small arrays first: every base below 64 KB is an immediate offset of a ds instruction, not a register)
+	unsigned long long *s_h0 = sm64;                                     // TR: headers (TRACK: the smallest among a record's duplicates)
+	uint32_t *s_w = (uint32_t *)(s_h0 + TR);                             // TR: weight of a distinct record
+	uint32_t *s_pre = s_w + TR;                                          // TR + 2   } this region is the dedupe table s_rep
+	unsigned short *s_map = (unsigned short *)(s_pre + TR + 2);          // TR       } (REP words) during phase B
+	unsigned short *s_idx = s_map + TR;                                  // IDXN: distinct record of every 16th k-mer
+	uint32_t *s_rep = s_pre;
+	uint32_t *s_words = (uint32_t *)((char *)s_pre + G::REGION);         // LDS_LEAD + TR * BW * 2 + TAIL_PAD (an even number of words)
+	unsigned long long *s_key = (unsigned long long *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);     // NW x SLOTS, word-major
 	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
-	unsigned long long *s_h0 = s_ord + (TRACK ? SLOTS : 0);              // TR
-	uint32_t *s_cnt = (uint32_t *)(s_h0 + TR);                           // SLOTS
-	uint32_t *s_lk = s_cnt + SLOTS;                                      // 4 x SLOTS
-	uint32_t *s_pre = s_lk + 4 * SLOTS;                                  // TR + 2
-	uint32_t *s_words = s_pre + TR + 2;                                  // LDS_LEAD + TR * BW * 2 + TAIL_PAD
-	unsigned short *s_idx = (unsigned short *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);   // TR * 4: record of every 16th k-mer
-	__shared__ uint32_t s_fill, s_item, s_spilled, s_wsum[NWAVES];
+	uint32_t *s_f = (uint32_t *)(s_ord + (TRACK ? SLOTS : 0));           // 5 x SLOTS
+	__shared__ uint32_t s_fill, s_item, s_spilled;
+	// statistics of the workgroup (claimed, failed, merges, spills, gens, k-mers, records, distinct records, their k-mers): in LDS, not
+	// in nine registers per lane that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
+	enum { ST_CLAIMED, ST_FAILED, ST_MERGES, ST_SPILLS, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
+	__shared__ uint32_t s_stat[ST_N];
+	__shared__ uint32_t s_ent[3 * (G::TILE / SK_CAP2)];      // ring of list entries: the tiles t, t + 1, t + 2 (see below)
+	__shared__ unsigned long long s_wsum[NWAVES];
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 		s_key[i] = KEY_EMPTY;
-		s_cnt[i] = 0;
 		if (TRACK) s_ord[i] = ORD_NONE;
 	}
-	for (int i = tid; i < 4 * SLOTS; i += SK_CNT_TPB)
-		s_lk[i] = 0;
+	for (int i = tid; i < 5 * SLOTS; i += SK_CNT_TPB)
+		s_f[i] = 0;
 	if (tid < LDS_LEAD)
 		s_words[tid] = 0;
 	if (tid < TAIL_PAD)
 		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
 	if (tid == 0)
 		s_fill = 0;
-	uint32_t claimed = 0, failed = 0, merges = 0, spills = 0, gens = 0;
-	unsigned long long done = 0;
+	if (tid < ST_N)
+		s_stat[tid] = 0;
 	uint32_t *words = s_words + LDS_LEAD;
 #ifdef SDT_SK_TICKS
 	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
@@ -644,186 +698,317 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (NW == 1 && !TRACK) ? 8
 			s_spilled = 0;
 		}
 		__syncthreads();
-		const uint32_t item = s_item;
+		const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);     // (uniform values belong in scalar registers)
 		__syncthreads();
 		if (item >= item1)
 			break;
 		const uint2 it = items[item];
-		const uint32_t c0 = it.x, c1 = it.y & 0x7FFFFFFFu;
-		const bool whole = (it.y >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
-		// a lane's record of the NEXT tile waits in registers while the current tile is counted
-		uint64_t nx[RW];
-		bool nx_ok = false;
-		auto fetch = [&](uint32_t cb) {
-			nx_ok = false;
-			if (tid < TR) {
-				const uint32_t ci = cb + (uint32_t)tid / SK_CAP2, slot = (uint32_t)tid % SK_CAP2;
-				if (ci < c1) {
-					const uint32_t chunk = list2[ci];
-					if (slot < (pool.meta[chunk] >> 24)) {
-						sk_load_record<RW>(pool.recs + ((size_t)chunk * SK_CAP2 + slot) * RW, nx);
-						nx_ok = true;
-					}
-				}
-			}
+		const uint32_t ity = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+		const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), c1 = ity & 0x7FFFFFFFu;
+		const bool whole = (ity >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
+		// Chunk id -> record are two dependent memory round trips per tile, and on this kernel's 64-register budget nothing can
+		// wait in registers across the counting loop: the compiler spilled every such value (the next record, its chunk id, even
+		// one prefetch dword), i.e. waited for the load at once -- with both trips in the open phases A-C were a third of the
+		// kernel's time (tick counters, profiles/r3).  So the prefetches live across phases A-C only, where registers are free:
+		// at the top of tile t wave 0 asks for the list entries of tile t + 2 and every record lane for ONE dword of its record
+		// of tile t + 1 (which pulls the record's line into L2); at the end of phase C the entries go into a ring of three rows
+		// in LDS and the dword is dropped.  The real record load at the top of a tile is then an L2 hit behind a known address.
+		// A list entry carries the chunk's fill (k_sk_chunk_place): pool.meta is not read here.  (LDS-DMA -- global_load_lds_dword,
+		// no destination register at all -- was tried for both and ran 10..50x slower than no prefetch: profiles/r3.)
+		auto rec_ptr = [&](uint32_t e, uint32_t t) -> const uint64_t * {
+			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * RW;
 		};
-		fetch(c0);
-		__syncthreads();                             // the table is clear (start of the kernel / end of the last bucket)
+		auto rec_ok = [&](uint32_t e, uint32_t t) -> bool { return e != SK_NOCHUNK && t % SK_CAP2 <= (e >> SK_LIST2_FILL_SHIFT); };
+		auto ent_row = [&](uint32_t t) -> uint32_t * { return s_ent + (t % 3u) * CPT; };
+		if (tid < CPT) {
+			ent_row(0)[tid] = c0 + (uint32_t)tid < c1 ? list2[c0 + tid] : SK_NOCHUNK;
+			ent_row(1)[tid] = c0 + CPT + (uint32_t)tid < c1 ? list2[c0 + CPT + tid] : SK_NOCHUNK;
+		}
+		__syncthreads();
+		uint32_t tile_no = 0;
+		uint32_t since = 0;                          // k-mers counted into the LDS table since its last clear (uniform)
+		bool stores_pending = false;                 // plain stores of an owned flush may still be in flight (uniform)
 		SK_TICK(0);
 		for (uint32_t cb = c0; cb < c1; cb += CPT) {
-			// the first TR lanes put their record into LDS and start the loads of the next one
+			// ---- A: the first TR lanes put their record into LDS
+			// (phases A-C address everything from an opaque copy of the lane id: hoisted out of the tile loop, lane-dependent
+			// addresses would sit in -- spilled -- registers, and every reload of a spilled register waits for ALL loads in
+			// flight, the prefetches included)
+			uint32_t ot_ = (uint32_t)tid;
+			asm volatile("" : "+v"(ot_));
+			const int ot = (int)ot_;
 			uint32_t n = 0;
-			if (tid < TR) {
-				uint64_t h0 = 0;
-				if (nx_ok) {
+			uint64_t h0 = 0;
+			uint64_t nx[RW];
+			uint32_t ring_e = SK_NOCHUNK, pf = 0;        // prefetches: in flight during phases A-C
+			const uint32_t e = ot < TR ? ent_row(tile_no)[ot / SK_CAP2] : SK_NOCHUNK;
+			const uint32_t e1 = ot < TR ? ent_row(tile_no + 1)[ot / SK_CAP2] : SK_NOCHUNK;
+			const bool ok = rec_ok(e, ot);
+			// (every lane loads, from a harmless address when it has nothing to load: behind a branch the compiler cannot count
+			// the loads in flight and waits for all of them; and the prefetches are issued BEHIND the loads this phase waits
+			// for, because vector memory returns in order)
+			sk_load_record<RW>(ok ? rec_ptr(e, ot) : pool.recs, nx);
+			const bool ring_ok = ot < CPT && cb + 2 * CPT + (uint32_t)ot < c1;
+			ring_e = (list2 + cb)[ring_ok ? 2 * CPT + ot : 0];
+			if (!ring_ok)
+				ring_e = SK_NOCHUNK;
+			if (SDT_SK_PREFETCH)
+				pf = *(const uint32_t *)(rec_ok(e1, ot) ? rec_ptr(e1, ot) : pool.recs);
+			if (ot < TR) {
+				if (ok) {
 					h0 = nx[0];
 					n = (uint32_t)sk_hdr_n(h0);
 #pragma unroll
 					for (int i = 0; i < BW; i++) {
-						words[tid * BW * 2 + 2 * i] = (uint32_t)(nx[1 + i] >> 32);
-						words[tid * BW * 2 + 2 * i + 1] = (uint32_t)nx[1 + i];
+						words[ot * BW * 2 + 2 * i] = (uint32_t)(nx[1 + i] >> 32);
+						words[ot * BW * 2 + 2 * i + 1] = (uint32_t)nx[1 + i];
 					}
 				}
-				s_h0[tid] = h0;
+				s_h0[ot] = h0;
+				s_w[ot] = 1;
 			}
-			if (cb + CPT < c1)
-				fetch(cb + CPT);
-			// exclusive prefix sum of the k-mers per record
-			const uint32_t n_mine = n;
-			if (tid < TR) {
-				uint32_t x = n;
+			for (uint32_t i = ot; i < REP; i += SK_CNT_TPB)
+				s_rep[i] = REP_EMPTY;
+			__syncthreads();                             // (also: the rounds of the last tile are over, the table is quiet)
+			// ---- B: dedupe
+			bool distinct = false;
+			if (n) {
+				distinct = true;
+				uint32_t x = (uint32_t)h0 & 0x3FFFFu;
+#pragma unroll
+				for (int i = 0; i < BW; i++) {
+					x = __builtin_rotateleft32(x, 5) ^ (uint32_t)nx[1 + i];
+					x = __builtin_rotateleft32(x, 11) ^ (uint32_t)(nx[1 + i] >> 32);
+				}
+				uint32_t slot = (x * 0x85EBCA77u) >> (32 - 10);
+				static_assert(REP == 1024, "the dedupe slot is 10 bits of the hash");
+				for (;;) {
+					const uint32_t cur = atomicCAS(&s_rep[slot], REP_EMPTY, (uint32_t)ot);
+					if (cur == REP_EMPTY)
+						break;                           // this record represents its kind
+					// identical records: same bases, and the same low 18 header bits (bucket, n, context flags)
+					bool same = (((uint32_t)s_h0[cur] ^ (uint32_t)h0) & 0x3FFFFu) == 0;
+#pragma unroll
+					for (int i = 0; i < BW; i++)
+						same = same && (((uint64_t)words[cur * BW * 2 + 2 * i] << 32) | words[cur * BW * 2 + 2 * i + 1]) == nx[1 + i];
+					if (same) {
+						atomicAdd(&s_w[cur], 1u);
+						if (TRACK)
+							atomicMin(&s_h0[cur], (unsigned long long)h0);
+						distinct = false;
+						break;
+					}
+					slot = (slot + 1) & (REP - 1);
+				}
+			}
+			// exclusive prefix sums over the distinct records: k-mers [15:0], records [31:16]; all k-mers of the tile [47:32], all its records [63:48]
+			const uint32_t n_mine = distinct ? n : 0u;
+			unsigned long long xs = ((unsigned long long)(n ? (n | 0x10000u) : 0u) << 32) | (distinct ? (n | 0x10000u) : 0u);
+			const unsigned long long xs_mine = xs;
+			if (ot < TR) {
 #pragma unroll
 				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t y = __shfl_up(x, d);
-					if ((tid & 63) >= d)
-						x += y;
+					const unsigned long long y = __shfl_up(xs, d);
+					if ((ot & 63) >= d)
+						xs += y;
 				}
-				if ((tid & 63) == 63)
-					s_wsum[tid >> 6] = x;
-				n = x - n;                           // exclusive within the wave
+				if ((ot & 63) == 63)
+					s_wsum[ot >> 6] = xs;
 			}
 			__syncthreads();
-			uint32_t total = 0;
-			{
-				uint32_t wbase = 0;
+			// ---- C: compact map of the distinct records
+			unsigned long long wbase = 0, tot = 0;
 #pragma unroll
-				for (int wv = 0; wv < NWAVES; wv++) {
-					const uint32_t v = s_wsum[wv];
-					if (wv < (tid >> 6)) wbase += v;
-					total += v;
-				}
-				if (tid < TR) {
-					s_pre[tid] = wbase + n;
-					// coarse index: every 16th k-mer of the tile lies in exactly one record, which writes itself there
-					// (the look-up below starts from it instead of searching the whole prefix array)
-					const uint32_t lo = wbase + n, hi = lo + n_mine;
-					for (uint32_t m16 = (lo + 15u) & ~15u; COARSE && m16 < hi; m16 += 16u)
-						s_idx[m16 >> 4] = (unsigned short)tid;
-				}
-				if (tid == 0)
-					s_pre[TR] = total;
+			for (int wv = 0; wv < NWAVES; wv++) {
+				const unsigned long long v = s_wsum[wv];
+				if (wv < (ot >> 6)) wbase += v;
+				tot += v;
+			}
+			const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tot), thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tot >> 32));
+			const uint32_t total = tlo & 0xFFFFu, ndist = tlo >> 16, tile_kmers = thi & 0xFFFFu;
+			// the 16-bit fields hold what this tile can add only if the table is young enough (uniform decision)
+			bool want_flush = since + tile_kmers > SK_CNT_MAX_SINCE;
+			since += tile_kmers;
+			if (distinct) {
+				const uint32_t ex = (uint32_t)(wbase + xs - xs_mine);
+				const uint32_t lo = ex & 0xFFFFu, ci = (ex >> 16) & 0xFFFFu, hi = lo + n_mine;
+				s_pre[ci] = lo;
+				s_map[ci] = (unsigned short)ot;
+				// coarse index: every 16th k-mer of the tile lies in exactly one record, which writes itself there
+				// (the look-up below starts from it instead of searching the whole prefix array)
+				for (uint32_t m16 = (lo + 15u) & ~15u; m16 < hi; m16 += 16u)
+					s_idx[m16 >> 4] = (unsigned short)ci;
+			}
+			if (ot < CPT)
+				ent_row(tile_no + 2)[ot] = ring_e;
+			asm volatile("" :: "v"(pf));                 // (the warm-up dword dies here)
+			if (ot == 0) {
+				s_pre[ndist] = total;
+				s_stat[ST_KMERS] += tile_kmers;
+				s_stat[ST_RECS] += thi >> 16;
+				s_stat[ST_DRECS] += ndist;
+				s_stat[ST_DKMERS] += total;
 			}
 			__syncthreads();
 			SK_TICK(1);
-			// rounds of 4 k-mers per free slot: barriers are what this loop pays for, and even error-rich data brings fewer
+			// ---- D: rounds of 4 k-mers per free slot: barriers are what this loop pays for, and even error-rich data brings fewer
 			// than one new key per four occurrences (a k-mer that does find the table full takes the direct path)
-			for (uint32_t qb = 0, qe; qb < total; qb = qe) {
-				const uint32_t room = 4u * (MAXFILL - s_fill);                        // s_fill < FLUSH_AT here (uniform: read after a barrier)
-				qe = qb + room < total ? qb + room : total;
-				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
-					int r;
-					if (COARSE) {
-						r = s_idx[q >> 4];                   // the record of k-mer q & ~15; q's own is at most a few records on
-						while (s_pre[r + 1] <= q)
-							r++;
-					} else {
-						int lo = 0, hi = TR;
-#pragma unroll
-						for (int st = 0; st < SK_CNT_TILE_LOG2; st++) {
-							const int mid = (lo + hi) >> 1;
-							if (s_pre[mid] <= q) lo = mid; else hi = mid;
-						}
-						r = lo;
+			const bool last_tile = cb + CPT >= c1;
+			tile_no++;
+			for (uint32_t qb = 0;;) {
+				if (want_flush) {
+					SK_TICK(2);
+					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
+					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise.  (The ONE place where it is
+					// done -- before a tile that could overflow the fields, between rounds when the table is half full, after the
+					// item's last round: three copies of the merge code cost the hot loop its registers.)
+					const bool owned = whole && __builtin_amdgcn_readfirstlane((int)s_spilled) == 0;
+					uint32_t claimed = 0, failed = 0, merges = 0;
+					// (the stores of this item's previous flush were left in flight: they must have landed before this one reads)
+					if (stores_pending) {
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						__syncthreads();
+						stores_pending = false;
 					}
-					const int j = (int)(q - s_pre[r]);
-					const uint64_t h0 = s_h0[r];
-					const int hp = sk_hdr_prev(h0), nr = sk_hdr_n(h0);
-					const int len = hp + nr + K - 1 + sk_hdr_next(h0);
+					if (owned) {
+						// this lane's PER slots: everything out of LDS, all global loads issued, then the merges
+						constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
+						Key<NW> mk[PER];
+						uint64_t madd[PER], mord[TRACK ? PER : 1], mslot[PER];
+						bool have[PER];
+						EntSnap<NW, TRACK> sn[PER];
+#pragma unroll
+						for (int p = 0; p < PER; p++) {
+							const int i = tid + p * SK_CNT_TPB;
+							have[p] = i < SLOTS && s_key[i] != KEY_EMPTY;
+							if (have[p]) {
+								mk[p].w[0] = s_key[i];
+#pragma unroll
+								for (int wv = 1; wv < NW; wv++)
+									mk[p].w[wv] = s_key[wv * SLOTS + i];
+								madd[p] = sk_lds_val(&s_f[5 * i]);
+								if (TRACK) mord[p] = (uint64_t)s_ord[i];
+								mslot[p] = key_hash<NW>(mk[p]) & tbl.mask;
+								s_key[i] = KEY_EMPTY;
+#pragma unroll
+								for (int f = 0; f < 5; f++)
+									s_f[5 * i + f] = 0;
+								if (TRACK) s_ord[i] = ORD_NONE;
+							}
+						}
+						__builtin_amdgcn_sched_barrier(0);       // (hashes first, then all loads, then the merges: interleaved by the
+#pragma unroll                                                 //  scheduler the snapshots were spilled, i.e. waited for one by one)
+						for (int p = 0; p < PER; p++)
+							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
+								sn[p] = ent_load<NW, TRACK>(tbl, mslot[p], mk[p], (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int p = 0; p < PER; p++)
+							if (have[p]) {
+								merges++;
+								if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], mslot[p], sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
+									failed++;
+							}
+						stores_pending = true;
+					} else {
+						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+							const uint64_t k0 = s_key[i];
+							if (k0 == KEY_EMPTY)
+								continue;
+							Key<NW> key;
+							key.w[0] = k0;
+#pragma unroll
+							for (int wv = 1; wv < NW; wv++)
+								key.w[wv] = s_key[wv * SLOTS + i];
+							merges++;
+							const uint64_t add = sk_lds_val(&s_f[5 * i]);
+							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
+							if (!table_merge<NW>(tbl, key, add, 0u, claimed, ord))
+								failed++;
+							s_key[i] = KEY_EMPTY;
+#pragma unroll
+							for (int f = 0; f < 5; f++)
+								s_f[5 * i + f] = 0;
+							if (TRACK) s_ord[i] = ORD_NONE;
+						}
+					}
+#pragma unroll
+					for (int d = 32; d > 0; d >>= 1) {
+						claimed += __shfl_down(claimed, d);
+						failed += __shfl_down(failed, d);
+						merges += __shfl_down(merges, d);
+					}
+					if ((tid & 63) == 0) {
+						if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+						if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+						if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+					}
+					__syncthreads();
+					if (tid == 0) {
+						s_fill = 0;
+						if (!(last_tile && qb >= total)) s_stat[ST_GENS]++;
+					}
+					__syncthreads();
+					since = tile_kmers;                  // (what is left of this tile is at most the tile)
+					SK_TICK(3);
+				}
+				if (qb >= total)
+					break;
+				const uint32_t room = 4u * (MAXFILL - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill));                        // s_fill < FLUSH_AT here (uniform: read after a barrier)
+				const uint32_t qe = qb + room < total ? qb + room : total;
+				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
+					uint32_t ci = s_idx[q >> 4];             // the record of k-mer q & ~15; q's own is at most a few records on
+					while (s_pre[ci + 1] <= q)
+						ci++;
+					const int r = s_map[ci];
+					const int j = (int)(q - s_pre[ci]);
+					const uint64_t hr = s_h0[r];
+					const uint32_t wgt = s_w[r];
+					const int hp = sk_hdr_prev(hr), nr = sk_hdr_n(hr);
+					const int len = hp + nr + K - 1 + sk_hdr_next(hr);
 					uint32_t prev, next;
 					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
 					const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key, MAXFILL);
 					if (s >= 0) {
-						sk_lds_update(s_cnt, s_lk, s, prev, next);
+						sk_lds_update(s_f, s, prev, next, wgt);
 						if (TRACK) {
-							const uint64_t ord = (sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j);
+							const uint64_t ord = (sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j);
 							if (ord < *(volatile unsigned long long *)&s_ord[s])
 								atomicMin(&s_ord[s], (unsigned long long)ord);
 						}
 					} else {
-						spills++;
 						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
-						const uint64_t ord = TRACK ? ((sk_hdr_read(h0) << 16) | (uint64_t)(sk_hdr_pos(h0) + (uint32_t)j)) : ORD_NONE;
-						if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
-							failed++;
+						const uint64_t ord = TRACK ? ((sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j)) : ORD_NONE;
+						uint32_t cl = 0;
+						atomicAdd(&s_stat[ST_SPILLS], 1u);
+						if (!table_merge<NW>(tbl, key, sk_weighted_val(wgt, prev, next), 0u, cl, ord))
+							atomicAdd(&s_stat[ST_FAILED], 1u);
+						if (cl)
+							atomicAdd(&s_stat[ST_CLAIMED], cl);
 					}
 				}
 				__syncthreads();
-				const bool last = qe == total && cb + CPT >= c1;
-				if (last || s_fill >= FLUSH_AT) {
-					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
-					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise
-					const bool owned = whole && s_spilled == 0;
-					for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-						const uint64_t k0 = s_key[i];
-						if (k0 == KEY_EMPTY)
-							continue;
-						Key<NW> key;
-						key.w[0] = k0;
-#pragma unroll
-						for (int wv = 1; wv < NW; wv++)
-							key.w[wv] = s_key[wv * SLOTS + i];
-						merges++;
-						uint32_t hi;
-						const uint64_t add = sk_lds_val(s_cnt[i], &s_lk[4 * i], hi);
-						const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
-						if (!(owned ? table_merge_owned<NW>(tbl, key, add, hi, claimed, ord) : table_merge<NW>(tbl, key, add, hi, claimed, ord)))
-							failed++;
-						s_key[i] = KEY_EMPTY;
-						s_cnt[i] = 0;
-						s_lk[4 * i] = 0; s_lk[4 * i + 1] = 0; s_lk[4 * i + 2] = 0; s_lk[4 * i + 3] = 0;
-						if (TRACK) s_ord[i] = ORD_NONE;
-					}
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a later generation of this item reads what was stored here
-					__syncthreads();
-					if (tid == 0) {
-						s_fill = 0;
-						if (!last) gens++;
-					}
-					__syncthreads();
-				}
+				qb = qe;
+				want_flush = (qb >= total && last_tile) || (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill) >= FLUSH_AT;     // the item is done: the table must be clear for the next one
 			}
-			done += tid == 0 ? total : 0;
 			SK_TICK(2);
 		}
 	}
 #undef SK_TICK
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) {
-		claimed += __shfl_down(claimed, d);
-		failed += __shfl_down(failed, d);
-		merges += __shfl_down(merges, d);
-		spills += __shfl_down(spills, d);
-	}
-	if ((tid & 63) == 0) {
-		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
-		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
-		if (merges) atomicAdd(&stats->sk_merges, (unsigned long long)merges);
-		if (spills) atomicAdd(&stats->sk_spills, (unsigned long long)spills);
-	}
+	__syncthreads();
 	if (tid == 0) {
-		atomicAdd(&stats->kmers, done);
-		atomicAdd(&stats->sk_counted, done);
-		if (gens) atomicAdd(&stats->sk_gens, (unsigned long long)gens);
+		if (s_stat[ST_CLAIMED]) atomicAdd(&stats->distinct, (unsigned long long)s_stat[ST_CLAIMED]);
+		if (s_stat[ST_FAILED]) atomicAdd(&stats->probe_fail, (unsigned long long)s_stat[ST_FAILED]);
+		if (s_stat[ST_MERGES]) atomicAdd(&stats->sk_merges, (unsigned long long)s_stat[ST_MERGES]);
+		if (s_stat[ST_SPILLS]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_SPILLS]);
+		if (s_stat[ST_GENS]) atomicAdd(&stats->sk_gens, (unsigned long long)s_stat[ST_GENS]);
+		if (s_stat[ST_KMERS]) {
+			atomicAdd(&stats->kmers, (unsigned long long)s_stat[ST_KMERS]);
+			atomicAdd(&stats->sk_counted, (unsigned long long)s_stat[ST_KMERS]);
+		}
+		if (s_stat[ST_RECS]) atomicAdd(&stats->sk_records, (unsigned long long)s_stat[ST_RECS]);
+		if (s_stat[ST_DRECS]) atomicAdd(&stats->sk_distinct_recs, (unsigned long long)s_stat[ST_DRECS]);
+		if (s_stat[ST_DKMERS]) atomicAdd(&stats->sk_distinct_kmers, (unsigned long long)s_stat[ST_DKMERS]);
 #ifdef SDT_SK_TICKS
 		for (int i = 0; i < 4; i++)
 			atomicAdd(&stats->sk_cyc[i], cyc[i]);

@@ -83,6 +83,9 @@ struct Stats {             // device counters, one cache line each would be nice
 	unsigned long long sk_gens;    // flushes of a full LDS table before its bucket was done
 	unsigned long long sk_emitted; // k-mers the level-1 scatter put into records     } conservation: what goes into the pools
 	unsigned long long sk_counted; // k-mers k_sk_count took out of level-2 records   } must come out (checked by sync_stats)
+	unsigned long long sk_distinct_recs; // records left after k_sk_count's per-tile dedupe (their k-mers are the ones cut, hashed and probed)
+	unsigned long long sk_records;  // records that entered the count stage
+	unsigned long long sk_distinct_kmers; // k-mers of the distinct records
 	unsigned long long sk_cyc1[4]; // k_sk_scatter_reads, thread 0 of every workgroup: clock ticks in tile staging / window minima / run starts / emission
 	unsigned long long sk_cyc[4];  // k_sk_count, wave 0 of every workgroup: clock ticks in set-up / tile fill + scan / counting / merging
 };
@@ -326,6 +329,111 @@ __device__ inline bool table_merge_owned(const Table<NW> &t, const Key<NW> &key,
 			__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	return true;
+}
+
+// ---- owned merges with the loads of several keys in flight ----------------------------------------------------
+// table_merge_owned pays three dependent memory round trips per key (probe, re-read of val, store) and k_sk_count's flush
+// did them for one slot of the LDS table after the other: ~15 us per flush, a third of the kernel (tick counters, profiles/r3).
+// Split in two: ent_load() issues agent-scope loads of everything a merge can need (key words, val, first-occurrence word) --
+// the caller issues them for ALL its keys before it looks at any -- and table_merge_owned_at() finishes from the snapshot.
+// An owned key has no other writer in this launch, so there is nothing to wait for: a slot that holds another key -- or
+// KEY_LOCKED, another workgroup publishing ITS key -- is simply not ours, and the next one is looked at.
+// first-occurrence ordinal: a memory-side min that nobody waits for (k_clear leaves ORD_NONE = ~0, so it also serves a new key).
+// The load + compare + store it replaces was a second cache line per merge ON the critical path of k_sk_count's flush.
+__device__ inline void ord_min_noret(uint64_t *p, uint64_t ord)
+{
+	(void)__hip_atomic_fetch_min(p, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NW, bool FIRST> struct EntSnap { uint64_t k[NW]; uint64_t v; bool won; };
+
+// `claim` (1-word keys): the key is probably new -- its slot claim, a compare-and-swap on the key word, travels TOGETHER with
+// the loads instead of after them (the CAS returns the key word either way; on a slot that holds a key it changes nothing).
+// A new key then costs one memory round trip, not two; an existing key pays for an atomic it did not need.
+template <int NW, bool FIRST> __device__ inline EntSnap<NW, FIRST> ent_load(const Table<NW> &t, uint64_t slot, const Key<NW> &key, bool claim)
+{
+	EntSnap<NW, FIRST> sn;
+	Entry<NW> *e = t.ent + slot;
+	sn.won = false;
+	if (NW == 1 && claim) {
+		sn.k[0] = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY, (unsigned long long)key.w[0]);
+		sn.won = sn.k[0] == KEY_EMPTY;
+	} else {
+#pragma unroll
+		for (int i = 0; i < NW; i++)
+			sn.k[i] = ld_relaxed(&e->key[i]);
+	}
+	sn.v = ld_relaxed(&e->val);
+	return sn;
+}
+
+template <int NW, bool FIRST>
+__device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &key, uint64_t slot, EntSnap<NW, FIRST> sn, uint64_t add, uint32_t hi,
+                                            uint32_t &claimed, uint64_t ord)
+{
+	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
+	for (uint64_t probe = 0; probe < max_probe; probe++) {
+		Entry<NW> *e = t.ent + slot;
+		if (NW == 1 && sn.won) {
+			// the claim that travelled with the loads won the slot: k_clear left val = 0, aux = 0, first = none
+			claimed++;
+			__hip_atomic_store(&e->val, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (hi)
+				__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (FIRST && ord != ORD_NONE)
+				ord_min_noret(t.first + slot, ord);
+			return true;
+		}
+		bool same = true;
+#pragma unroll
+		for (int i = 0; i < NW; i++)
+			same = same && sn.k[i] == key.w[i];
+		if (same) {
+			uint64_t nv = 0;
+#pragma unroll
+			for (int f = 0; f < 8; f++) {
+				const uint32_t a = (uint32_t)(sn.v >> (6 * f)) & 63u, b = (uint32_t)(add >> (6 * f)) & 63u;
+				const uint32_t sum = a + b > 63u ? 63u : a + b;
+				nv |= (uint64_t)sum << (6 * f);
+			}
+			const uint32_t cs = (uint32_t)(sn.v >> 48) + (uint32_t)(add >> 48);
+			nv |= (uint64_t)(cs & 0xFFFFu) << 48;
+			__hip_atomic_store(&e->val, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t up = hi + (cs >> 16);
+			if (up) {
+				const uint32_t a = __hip_atomic_load(t.aux + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(t.aux + slot, a + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (FIRST && ord != ORD_NONE)
+				ord_min_noret(t.first + slot, ord);
+			return true;
+		}
+		if (sn.k[0] == KEY_EMPTY) {
+			const uint64_t old = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY,
+			                               (unsigned long long)(NW == 1 ? key.w[0] : KEY_LOCKED));
+			if (old == KEY_EMPTY) {
+				claimed++;
+				if (NW > 1) {
+#pragma unroll
+					for (int i = 1; i < NW; i++)
+						__hip_atomic_store(&e->key[i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (as in table_locate: low words before key[0])
+					__hip_atomic_store(&e->key[0], key.w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				// the slot was empty a moment ago: k_clear left val = 0, aux = 0, first = none
+				__hip_atomic_store(&e->val, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (hi)
+					__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (FIRST && ord != ORD_NONE)
+					ord_min_noret(t.first + slot, ord);
+				return true;
+			}
+			// somebody else's key (or its KEY_LOCKED) got there first: not ours
+		}
+		slot = (slot + 1) & t.mask;
+		sn = ent_load<NW, FIRST>(t, slot, key, false);
+	}
+	return false;
 }
 
 } // namespace sdt
