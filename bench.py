@@ -171,10 +171,6 @@ def main():
     ap.add_argument("--track-first", action="store_true", help="SDT_FLAG_TRACK_FIRST: what the five-file pipeline runs with")
     ap.add_argument("--extras", type=int, default=1, help="N=1: also time the TRACK_FIRST configuration and the PCIe-inclusive "
                                                           "rate through sdt_gpu_push_reads (0 = skip)")
-    ap.add_argument("--shard-mode", choices=["bucket", "filter", "route"], default="bucket",
-                    help="N>1: 'bucket' = the C-level product path (reads split, super-k-mer chunks to the owners of their "
-                         "minimizer buckets over RCCL); 'filter' / 'route' = round 1's Python plumbing (A/B only)")
-    ap.add_argument("--route-batch", type=int, default=2_000_000, help="reads per all-to-all round (--shard-mode route)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank")
     ap.add_argument("--slice-of-whole", action="store_true",
                     help="validation: every rank generates the WHOLE single-rank workload and keeps its slice, so that N ranks "
@@ -205,10 +201,7 @@ def main():
         if share:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        if args.shard_mode == "bucket" or share:
-            dist.init_process_group("gloo")          # control plane only (communicator id, barrier, max time): the data path is the library's own RCCL
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")              # control plane only (communicator id, barrier, max time): the data path is the library's own RCCL
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -218,14 +211,11 @@ def main():
 
     K, L = pkg.clamp_K(args.K), args.read_len
     n_total = args.reads
-    mode = args.shard_mode if sharded_path else "single"
-    if mode == "filter":
-        n_local = n_total                     # owner-filter sharding: the reads are replicated, the TABLE is sharded
-    else:
-        n_local = n_total // world + (1 if rank < n_total % world else 0)
+    mode = "bucket" if sharded_path else "single"
+    n_local = n_total // world + (1 if rank < n_total % world else 0)
     kmers_total = n_total * (L - K + 1)
     t0 = time.time()
-    if args.slice_of_whole and mode in ("route", "bucket"):
+    if args.slice_of_whole and mode == "bucket":
         wf, _, _ = synth.torch_workload(n_total, L, args.T, dev, err=args.err, sigma=args.sigma, seed=42)
         lo = (rank * n_total // world) // 16 * 16        # slices start on a word boundary (16 reads x L bases)
         hi = ((rank + 1) * n_total // world) // 16 * 16 if rank + 1 < world else n_total
@@ -237,7 +227,7 @@ def main():
         del wf
     else:
         words, offsets, nwords = synth.torch_workload(n_local, L, args.T, dev, err=args.err, sigma=args.sigma,
-                                                      seed=42 + (1000 * rank if mode in ("route", "bucket") else 0))
+                                                      seed=42 + (1000 * rank if mode == "bucket" else 0))
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
 
@@ -251,7 +241,6 @@ def main():
     g.set_stream(stream.cuda_stream)
     log(f"node table: {g.table_slots()} slots")
 
-    sharded = None
     if mode == "bucket":
         if share:
             name = [os.environ.get("MASTER_PORT", "0") + "_" + str(os.getppid())]
@@ -261,31 +250,19 @@ def main():
             cid = [pkg.new_comm_id() if rank == 0 else None]
             dist.broadcast_object_list(cid, src=0)
             g.comm_init(cid[0], rank, world)
-    elif mode == "route":
-        from soapdenovo_trans_amd.sharding import ShardedCounter
-        sharded = ShardedCounter(g, world, L, min(args.route_batch, n_local), dev)
-    elif mode == "filter":
-        g.set_owner_filter(rank, world)
 
     def allsum(hist, kmers, nodes, linear):
         v = np.concatenate([np.asarray(hist, dtype=np.int64), np.array([kmers, nodes, linear], dtype=np.int64)])
         if mode == "bucket":
             v = g.allreduce(v)
-        elif sharded_path:
-            t = torch.from_numpy(v).to(dev)
-            dist.all_reduce(t)
-            v = t.cpu().numpy()
         return v[:257], int(v[257]), int(v[258]), int(v[259])
 
     local_inserted = [0]
 
-    def one_step(ctx, verify=False):
+    def one_step(ctx):
         ctx.reset()
         if mode == "bucket":
             ctx.count_reads_sharded(words, nwords, offsets, n_local, L)
-        elif mode == "route":
-            with torch.cuda.stream(stream):
-                sharded.count_reads(words, nwords, offsets, n_local, verify=verify)
         else:
             ctx.count_reads_device(words, nwords, offsets, n_local, L)
         kmers, nodes = ctx.finish_count()
@@ -305,7 +282,7 @@ def main():
     def timed(ctx, steps, warmup):
         res = None
         for _ in range(warmup):
-            res = one_step(ctx, verify=True)   # (route: checksum the exchange once, outside the timed region)
+            res = one_step(ctx)
         ctx.kernel_time(reset=True)
         barrier()
         t0 = time.perf_counter()
@@ -330,10 +307,7 @@ def main():
     value = kmers_total * args.steps / dt
     B = algorithmic_bytes_per_kmer(L, K)
     # kernel level: the k-mers this rank chopped over the time of this rank's pass-1 kernels (N = 1: the whole job)
-    if mode == "filter":
-        local_kmers = local_inserted[0]         # its launches walk ALL reads and insert the k-mers it owns
-    else:
-        local_kmers = n_local * (L - K + 1)
+    local_kmers = n_local * (L - K + 1)
     roof = None
     if local_kmers and kms > 0:
         ach = B * local_kmers * args.steps / (kms * 1e-3) / 1e9
@@ -344,7 +318,7 @@ def main():
         roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": None if tpk is None else round(tpk * per_launch_kmers),
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes of this workload, this build)",
+                "traffic_unit": "HBM bytes per launch, a LOWER bound (FETCH_SIZE x2 for the record-streaming kernels + WRITE_SIZE PMC passes of this workload, this build; FETCH_SIZE under-reports wide coalesced reads on gfx950)",
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(B * per_launch_kmers),
                 "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records + k_sk_count (every k-mer goes through "
@@ -368,19 +342,27 @@ def main():
                    "parallelism": {"single": "single-GPU table",
                                    "bucket": f"reads split x{world}; tables sharded by minimizer bucket; super-k-mer chunks by grouped "
                                              f"ncclSend/ncclRecv (C ABI: sdt_gpu_count_reads_sharded)" + (" [shared-memory transport: ranks share one GPU]" if share else ""),
-                                   "route": f"owner-sharded table x{world}, 16-B records by torch all-to-all (round-1 path)",
-                                   "filter": f"owner-sharded table x{world}, reads replicated, owner filter (round-1 path)"}[mode]},
+                                   }[mode],
+                   "kmerfreq_sha1": __import__("hashlib").sha1(np.asarray(hist, dtype=np.int64).tobytes()).hexdigest()},
         "roofline": roof,
     }
     if mode == "bucket":
         sent, recv, xms, nx = g.comm_stats()
         tot = g.allreduce([sent, recv])
+        # skew: the k-mers every rank counted into ITS shard in the last step (the owners' load, after the exchange)
+        per_rank = [0] * world
+        per_rank[rank] = int(local_inserted[0])
+        per_rank = [int(x) for x in g.allreduce(per_rank)]
+        out["per_rank_kmers_counted"] = per_rank
+        out["skew_max_over_mean"] = round(max(per_rank) / max(sum(per_rank) / world, 1), 4)
         out["exchange"] = {"bytes_sent_rank0": sent, "bytes_sent_all_ranks": int(tot[0]), "exchanges_rank0": nx,
                            "bytes_per_kmer": round(int(tot[0]) / max(kmers_total * (args.steps + args.warmup), 1), 3),
                            "ms_on_exchange_stream_rank0": round(xms, 2),
                            "GBps_out_rank0": round(sent / max(xms, 1e-9) / 1e6, 2),
                            "GBps_per_link_rank0": round(sent / max(world - 1, 1) / max(xms, 1e-9) / 1e6, 2),
-                           "note": "per link = bytes to one peer / time of the grouped send/recv; xGMI peak ~153 GB/s per link and direction"}
+                           "note": "ms = sum over this rank's exchanges of the time between the two events around each grouped send/recv "
+                                   "(payload + metas in one group); per link = bytes to one peer / that time; xGMI peak ~153 GB/s per "
+                                   "link and direction"}
     # ---- extras (N = 1): the configuration the five-file pipeline runs with, and the rate from host buffers ----
     out["track_first"] = None
     out["pcie_inclusive"] = None

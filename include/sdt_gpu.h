@@ -59,13 +59,6 @@ typedef struct sdt_ctx sdt_ctx;
 /* map stage: the table indexes the k-mers of the contigs (sdt_gpu_index_contigs; implies TRACK_FIRST) */
 #define SDT_FLAG_CONTIG_INDEX 16u
 
-/* record routed between GPUs / inserted by sdt_gpu_insert_records: key_words() uint64 key words, MOST
- * significant first (the reference Kmer struct order), then one uint64 meta = prev | next << 3 | (ordinal + 1) << 6
- * with prev/next the neighbour base codes 0..3 or SDT_REC_NB_NONE (prlHashReads.c:215-230,275-308) and, when the
- * extracting context tracks first occurrences, the occurrence's ordinal (read ordinal << 16 | position; 0 = none), so
- * that a table filled through the exchange orders its nodes exactly like one filled directly. */
-#define SDT_REC_NB_NONE 4
-
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 
 /* Replaces the allocation half of prlRead2HashTable (prlHashReads.c:355,402-423: createFilter +
@@ -152,26 +145,19 @@ int sdt_gpu_keep_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwor
  * several processes) */
 int sdt_comm_selftest_shm(const char *name, int rank, int nranks, int rounds);
 
-/* ---- multi-GPU, per-k-mer routing (building blocks kept from round 1; the per-k-mer exchange of
- * soapdenovo-trans_amd/sharding.py) -------------------------------------------------------------
- * Here the owner of a canonical k-mer is sdt_owner_of(key) % nranks (a mixed hash: canonical prefixes
- * are skewed).  extract_route chops the batch and writes 16-byte records grouped by owner rank into
- * d_records (capacity max_records, split in nranks equal slices), with counts[r] / displs[r] (device
- * uint64[nranks], in records) describing each rank's slice: the send buffer of an all-to-all(v).
- * A slice overflow is reported by the next sdt_gpu_finish_count as SDT_EFULL.
- * insert_records consumes received records. */
-int sdt_gpu_extract_route(sdt_ctx *ctx, const void *d_packed_words, uint64_t nwords,
-                          const void *d_offsets, uint64_t nreads, uint64_t max_read_len, int nranks,
-                          void *d_records, uint64_t max_records,
-                          void *d_counts, void *d_displs);
-int sdt_gpu_insert_records(sdt_ctx *ctx, const void *d_records, uint64_t nrecords);
-/* Alternative without any exchange (the reference's own scheme across threads, prlHashReads.c:79-88): every
- * rank is given ALL reads and sdt_gpu_push_reads / sdt_gpu_count_reads_device insert only the k-mers whose
- * owner is `rank`.  Chopping is ~10x cheaper than inserting, so this beats the all-to-all whenever the reads
- * can be replicated (7.5 GB packed for 200 M x 150 bp).  rank 0 / nranks 1 switches the filter off. */
-int sdt_gpu_set_owner_filter(sdt_ctx *ctx, int rank, int nranks);
-/* bytes per routed record for this context's key width */
-int sdt_gpu_record_bytes(const sdt_ctx *ctx);
+/* The exchange plan as pure host functions of the count matrix (csrc/sdt_shard_plan.h; no device, no communicator): what
+ * sdt_gpu_count_reads_sharded computes after its all-gather, exported so that the protocol can be driven -- and checked --
+ * with any transport (tests/test_multirank_gloo.py: two gloo ranks on CPU).
+ *   mat[r * 257 + b]   first position of level-1 bucket b in rank r's chunk list (b = 256: the list's length)
+ *   cut_ranges         ranges[0..nranks]: rank d owns buckets [ranges[d], ranges[d + 1]), equal weights
+ *   plan               sub-round t of the exchange as rank `me` sees it (*subrounds: how many there are -- the same on every
+ *                      rank): for every peer p the piece [send_begin[p], + send_count[p]) of my chunk list, its place
+ *                      send_at[p] in my send buffer (p == me: in my receive buffer), and the run recv_count[s] at recv_at[s]
+ *                      of my receive buffer that arrives from rank s.  Arrays of nranks entries. */
+int sdt_shard_cut_ranges(const uint32_t *mat, int nranks, uint32_t *ranges);
+int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *ranges, uint32_t recv_chunks, uint32_t t,
+                   uint32_t *subrounds, uint32_t *send_begin, uint32_t *send_count, uint32_t *send_at, uint32_t *recv_count,
+                   uint32_t *recv_at);
 
 /* ---- table scans ------------------------------------------------------------------------------ */
 
@@ -315,8 +301,7 @@ int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches,
 #define SDT_NSTAGES           4
 #define SDT_NCOUNTERS         20   /* [16] distinct records of the count stage's tiles, [17] records (level-2), [18] k-mers of the distinct records, [19] reserved */
 int sdt_gpu_stage_times(sdt_ctx *ctx, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS]);
-/* the hash used for sharding (host-callable, identical to the device function):
- * owner rank = ((sdt_owner_hash(key) >> 32) * nranks) >> 32 */
+/* the device table's slot hash of a canonical key (host-callable, identical to the device function) */
 uint64_t sdt_owner_hash(const uint64_t *key_words_msw_first, int nwords);
 
 #ifdef __cplusplus

@@ -37,12 +37,8 @@ _ABI = [
     ("sdt_gpu_count_reads_device", _c.c_int,
      [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
-    ("sdt_gpu_extract_route", _c.c_int,
-     [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_int, _c.c_void_p,
-      _c.c_uint64, _c.c_void_p, _c.c_void_p]),
-    ("sdt_gpu_insert_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
-    ("sdt_gpu_record_bytes", _c.c_int, [_c.c_void_p]),
-    ("sdt_gpu_set_owner_filter", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
+    ("sdt_shard_cut_ranges", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
+    ("sdt_shard_plan", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32] + [_c.c_void_p] * 6),
     ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_mark_and_hist", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_nodes", _c.c_int,
@@ -214,16 +210,6 @@ class PregraphGPU:
         self._check(self.lib.sdt_gpu_finish_count(self._ctx, ctypes.byref(k), ctypes.byref(n)))
         return k.value, n.value
 
-    # -- sharding
-    def record_bytes(self) -> int:
-        return self.lib.sdt_gpu_record_bytes(self._ctx)
-
-    def extract_route(self, d_words, nwords, d_offsets, nreads, max_read_len, nranks, d_records, max_records,
-                      d_counts, d_displs):
-        self._check(self.lib.sdt_gpu_extract_route(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets), nreads,
-                                                   max_read_len, nranks, _ptr(d_records), max_records,
-                                                   _ptr(d_counts), _ptr(d_displs)))
-
     # -- multi-GPU, bucket sharding (include/sdt_gpu.h): every method below except kmer_owner is COLLECTIVE
     def comm_init(self, comm_id: bytes, rank: int, nranks: int):
         """RCCL communicator; comm_id = new_comm_id() of rank 0, handed to every rank"""
@@ -259,12 +245,6 @@ class PregraphGPU:
         a, b, n, ms = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
         self._check(self.lib.sdt_gpu_comm_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms), ctypes.byref(n)))
         return a.value, b.value, ms.value, n.value
-
-    def set_owner_filter(self, rank: int, nranks: int):
-        self._check(self.lib.sdt_gpu_set_owner_filter(self._ctx, rank, nranks))
-
-    def insert_records(self, d_records, nrecords: int):
-        self._check(self.lib.sdt_gpu_insert_records(self._ctx, _ptr(d_records), nrecords))
 
     # -- scans
     def delow(self, d: int) -> int:
@@ -424,8 +404,31 @@ def new_comm_id() -> bytes:
     """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to every rank)"""
     buf = ctypes.create_string_buffer(128)
     if load_library().sdt_gpu_comm_id(buf) != SDT_OK:
-        raise SdtError(load_library().sdt_gpu_last_error().decode())
+        raise SdtError(SDT_EHIP, load_library().sdt_gpu_last_error().decode())
     return buf.raw
+
+
+def shard_cut_ranges(mat: np.ndarray, nranks: int) -> np.ndarray:
+    """bucket ranges of equal weight from the all-gathered chunk-list offsets (nranks x 257 uint32); host only"""
+    m = np.ascontiguousarray(mat, dtype=np.uint32).reshape(nranks, 257)
+    r = np.zeros(nranks + 1, dtype=np.uint32)
+    rc = load_library().sdt_shard_cut_ranges(m.ctypes.data, nranks, r.ctypes.data)
+    if rc != SDT_OK:
+        raise SdtError(rc, load_library().sdt_gpu_last_error().decode())
+    return r
+
+
+def shard_plan(mat: np.ndarray, nranks: int, me: int, ranges: np.ndarray, recv_chunks: int, t: int):
+    """sub-round t of the exchange as rank `me` sees it: (subrounds, send_begin, send_count, send_at, recv_count, recv_at)"""
+    m = np.ascontiguousarray(mat, dtype=np.uint32).reshape(nranks, 257)
+    rg = np.ascontiguousarray(ranges, dtype=np.uint32)
+    S = ctypes.c_uint32()
+    out = [np.zeros(nranks, dtype=np.uint32) for _ in range(5)]
+    rc = load_library().sdt_shard_plan(m.ctypes.data, nranks, me, rg.ctypes.data, recv_chunks, t, ctypes.addressof(S),
+                                       *[o.ctypes.data for o in out])
+    if rc != SDT_OK:
+        raise SdtError(rc, load_library().sdt_gpu_last_error().decode())
+    return (S.value, *out)
 
 
 def kmer_owner(key_words_msw_first, K: int, nranks: int) -> int:

@@ -15,6 +15,8 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 
@@ -110,6 +112,7 @@ static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base,
 	if (b->owner == st->rank && b->nreads) {                      /* mine: it waits for the end of its group */
 		if (b->nwords > st->cap_w) { st->cap_w = b->nwords * 5 / 4; st->w = (uint32_t *)realloc(st->w, st->cap_w * 4); }
 		if (b->nreads + 1 > st->cap_o) { st->cap_o = (b->nreads + 1) * 5 / 4; st->o = (uint64_t *)realloc(st->o, st->cap_o * 8); }
+		if (!st->w || !st->o) { fprintf(stderr, "[rank %d] out of host memory for a batch of %llu reads\n", st->rank, (unsigned long long)b->nreads); return -1; }
 		memcpy(st->w, b->words, b->nwords * 4);
 		memcpy(st->o, b->offsets, (b->nreads + 1) * 8);
 		st->nw = b->nwords; st->n = b->nreads; st->ord_base = ord_base; st->ord_stride = ord_stride;
@@ -122,6 +125,37 @@ static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base,
 
 /* --gpus N: the shard of every other rank comes to rank 0 through POSIX shared memory */
 typedef struct { volatile int ready; sdt_comm_id id; char name[64]; } boot_t;
+
+/* Failure propagation between the forked ranks.  RCCL collectives have no timeout: a rank that leaves early would keep its
+ * peers blocked for ever, holding their GPUs.  So: every child dies with its parent (PR_SET_PDEATHSIG); rank 0 -- the parent --
+ * reaps children in a SIGCHLD handler and, when one of them failed, kills the rest and exits; and whenever rank 0 itself
+ * leaves (any `return`, atexit) it takes the children that are still alive with it. */
+static volatile pid_t g_child[64];
+static volatile int g_nchild;
+
+static void kill_children(void)
+{
+	for (int i = 0; i < g_nchild; i++)
+		if (g_child[i] > 0) { kill(g_child[i], SIGKILL); (void)waitpid(g_child[i], NULL, 0); g_child[i] = 0; }
+}
+
+static void on_sigchld(int sig)
+{
+	(void)sig;
+	int st;
+	pid_t p;
+	while ((p = waitpid(-1, &st, WNOHANG)) > 0) {
+		for (int i = 0; i < g_nchild; i++)
+			if (g_child[i] == p) g_child[i] = 0;
+		if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+			static const char msg[] = "sdt-pregraph: a rank failed; stopping the others\n";
+			if (write(2, msg, sizeof msg - 1) < 0) { }
+			for (int i = 0; i < g_nchild; i++)
+				if (g_child[i] > 0) kill(g_child[i], SIGKILL);
+			_exit(1);
+		}
+	}
+}
 
 static void *shm_region(const char *name, size_t bytes, int create)
 {
@@ -366,15 +400,27 @@ int main(int argc, char **argv)
 		memset(boot, 0, sizeof *boot);
 		snprintf(boot->name, sizeof boot->name, "pg%d", (int)getpid());
 		fflush(stdout);
+		struct sigaction sa;
+		memset(&sa, 0, sizeof sa);
+		sa.sa_handler = on_sigchld;
+		sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+		sigaction(SIGCHLD, &sa, NULL);
+		atexit(kill_children);
 		for (int r = 1; r < gpus; r++) {
 			const pid_t pid = fork();
 			if (pid < 0) { perror("fork"); return 1; }
 			if (pid == 0) {
 				rank = r;
 				g_quiet = 1;
+				g_nchild = 0;                                         /* (a child has no children to take along) */
+				signal(SIGCHLD, SIG_DFL);
+				prctl(PR_SET_PDEATHSIG, SIGKILL);
+				if (getppid() == 1) return 1;                         /* the parent is gone already */
 				if (!freopen("/dev/null", "w", stdout)) return 1;       /* one voice: rank 0's */
 				break;
 			}
+			g_child[g_nchild] = pid;
+			g_nchild = g_nchild + 1;
 		}
 	}
 	const int my_threads = gpus == 1 ? threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
@@ -485,8 +531,11 @@ int main(int argc, char **argv)
 				uint64_t *k2 = (uint64_t *)m, *f2 = k2 + (my_nodes + 1) * (size_t)nwk;
 				uint32_t *l2 = (uint32_t *)(f2 + my_nodes + 1), *r2 = l2 + my_nodes + 1, *c2 = r2 + my_nodes + 1;
 				if (sdt_gpu_export_nodes(gpu, k2, l2, r2, c2, f2, my_nodes, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
-				sdt_gpu_allreduce_i64(gpu, &token, 1);            /* "my shard is in shared memory" */
-				sdt_gpu_allreduce_i64(gpu, &token, 1);            /* "rank 0 has it" */
+				if (sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK ||          /* "my shard is in shared memory" */
+				    sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK) {          /* "rank 0 has it" */
+					fprintf(stderr, "[rank %d] %s\n", rank, sdt_gpu_last_error());
+					return 1;
+				}
 				munmap(m, (size_t)(my_nodes + 1) * per_node);
 				shm_unlink(seg);
 				sdt_gpu_destroy(gpu);
@@ -495,9 +544,10 @@ int main(int argc, char **argv)
 			n = nodes;                                            /* all shards */
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
+			if (!keys || !first || !ll || !rf || !cnt) { fprintf(stderr, "out of host memory for %llu nodes\n", (unsigned long long)n); return 1; }
 			uint64_t got = 0;
 			if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, my_nodes, &got) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
-			sdt_gpu_allreduce_i64(gpu, &token, 1);
+			if (sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 			uint64_t at = my_nodes;
 			for (int r = 1; r < gpus; r++) {
 				const uint64_t m_n = (uint64_t)sizes[r];
@@ -511,13 +561,12 @@ int main(int argc, char **argv)
 				at += m_n;
 				munmap(m, (size_t)(m_n + 1) * per_node);
 			}
-			sdt_gpu_allreduce_i64(gpu, &token, 1);                /* the other ranks may go */
+			if (sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }   /* the other ranks may go */
 			if (at != n) { fprintf(stderr, "shards hold %llu nodes, the counters say %llu\n", (unsigned long long)at, (unsigned long long)n); return 1; }
 			if (!host_map && sdt_gpu_import_nodes(gpu, keys + my_nodes * nwk, ll + my_nodes, rf + my_nodes, cnt + my_nodes, first + my_nodes, n - my_nodes) != SDT_OK) {
 				fprintf(stderr, "sdt_gpu_import_nodes: %s\n", sdt_gpu_last_error());
 				return 1;
 			}
-			while (waitpid(-1, NULL, WNOHANG) > 0) { }
 		} else {
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
@@ -598,7 +647,13 @@ int main(int argc, char **argv)
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
 	sdt_cfg_free(&cfg);
-	if (gpus > 1 && rank == 0)
-		while (wait(NULL) > 0) { }
+	if (gpus > 1 && rank == 0) {                                 /* the ranks that are still leaving (the handler reaps them) */
+		for (int tries = 0; tries < 30000; tries++) {
+			int alive = 0;
+			for (int i = 0; i < g_nchild; i++) alive += g_child[i] > 0;
+			if (!alive) break;
+			usleep(1000);
+		}
+	}
 	return 0;
 }

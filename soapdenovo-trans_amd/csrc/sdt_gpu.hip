@@ -7,9 +7,7 @@
 //                         (newhash.c:411-462): a workgroup stages a tile of packed reads in LDS with
 //                         coalesced loads, every lane cuts its k-mers out of LDS by funnel shift and
 //                         updates the node table with one 64-bit atomic per occurrence.
-//   k_extract_route<NW>   same chop, but records go to per-owner-rank slices (send side of the
-//                         all-to-all that replaces `hash_kmer % thrd_num`, prlHashReads.c:81)
-//   k_insert_records<NW>  put_kmerset for received records
+//   k_sk_*                the locality pipeline (sdt_superkmer.cuh): minimizer buckets of super-k-mer records counted in LDS
 //   k_delow<NW>           thread_delow   (prlHashReads.c:844-887)
 //   k_mark_hist<NW>       thread_mark    (prlHashReads.c:911-967) + per-thread kmerFreq bins
 //   k_export<NW>          compaction of the table into kmer_t-shaped arrays (inc/newhash.h:65-77)
@@ -146,11 +144,8 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict__ packed,
                                                      const uint64_t *__restrict__ offs, uint64_t nreads, int K,
                                                      int max_tile_words, Table<NW> tbl, Stats *stats,
-                                                     uint64_t ord_base, uint64_t ord_stride, int my_rank, int nranks)
+                                                     uint64_t ord_base, uint64_t ord_stride)
 {
-	// nranks > 1: owner-filter sharding.  Every rank chops ALL reads (the chop runs at > 200 G k-mers/s) and
-	// inserts only the k-mers it owns -- the reference's own scheme across threads (prlHashReads.c:79-88),
-	// without any record exchange.
 	extern __shared__ uint32_t smem[];
 	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
 	uint32_t claimed = 0, failed = 0, done = 0;
@@ -163,8 +158,6 @@ __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict_
 			uint32_t prev, next;
 			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
 			// ordinal of this occurrence in the reference's stream order: (read ordinal, position in read)
-			if (nranks > 1 && (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32) != my_rank)
-				continue;
 			const uint64_t ord = tbl.first ? ((ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride) << 16) | (uint64_t)j : ORD_NONE;
 			if (!table_put<NW>(tbl, key, prev, next, claimed, ord))
 				failed++;
@@ -173,110 +166,6 @@ __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict_
 		__syncthreads();                             // tile buffer is reused
 	}
 	// per-wave reduction of the counters, one atomic per wave
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) {
-		claimed += __shfl_down(claimed, d);
-		failed += __shfl_down(failed, d);
-		done += __shfl_down(done, d);
-	}
-	if ((threadIdx.x & 63) == 0) {
-		if (done) atomicAdd(&stats->kmers, (unsigned long long)done);
-		if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
-		if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
-	}
-}
-
-// routed record: NW key words (most significant first) + one meta word (prev | next << 3)
-template <int NW> struct Record {
-	uint64_t key[NW];
-	uint64_t meta;
-};
-
-template <int NW>
-__global__ __launch_bounds__(TPB) void k_extract_route(const uint32_t *__restrict__ packed,
-                                                       const uint64_t *__restrict__ offs, uint64_t nreads, int K,
-                                                       int max_tile_words, int tile_smem_words, int nranks,
-                                                       Record<NW> *__restrict__ out,
-                                                       const unsigned long long *__restrict__ displs,
-                                                       unsigned long long *__restrict__ cursors,
-                                                       unsigned long long cap_per_rank, Stats *stats,
-                                                       uint64_t ord_base, uint64_t ord_stride, int with_ord)
-{
-	// Per tile: count the records per owner rank in LDS, reserve each owner's run with ONE global atomic, then chop
-	// again and write.  (One atomic per wave and owner was measured to serialise on the nranks cursor words:
-	// ~88 same-address atomics/us = 5.6 G records/s; the chop itself runs at > 200 G k-mers/s, so doing it twice
-	// is the cheap side of the trade.)
-	extern __shared__ uint32_t smem[];
-	uint32_t *s_cnt = smem + tile_smem_words;                           // 64
-	uint32_t *s_fill = s_cnt + 64;                                      // 64
-	unsigned long long *s_base = (unsigned long long *)(s_fill + 64);   // 64 (8-byte aligned: tile_smem_words is even)
-	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
-	uint32_t failed = 0;
-	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const TileView tv = stage_tile(smem, max_tile_words, packed, offs, tile * TILE_READS, nreads, K);
-		if (threadIdx.x < 64) {
-			s_cnt[threadIdx.x] = 0;
-			s_fill[threadIdx.x] = 0;
-		}
-		__syncthreads();
-		for (uint32_t q = threadIdx.x; q < tv.nk; q += TPB) {
-			const int r = tile_find_read(tv.pre, q);
-			const int j = (int)(q - tv.pre[r]);
-			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
-			uint32_t prev, next;
-			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
-			const int owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
-			atomicAdd(&s_cnt[owner], 1u);
-		}
-		__syncthreads();
-		if (threadIdx.x < (unsigned)nranks) {
-			const uint32_t n = s_cnt[threadIdx.x];
-			s_base[threadIdx.x] = n ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)n) : 0ULL;
-		}
-		__syncthreads();
-		for (uint32_t q = threadIdx.x; q < tv.nk; q += TPB) {
-			const int r = tile_find_read(tv.pre, q);
-			const int j = (int)(q - tv.pre[r]);
-			const int len = (int)(tv.rb[r + 1] - tv.rb[r]);
-			uint32_t prev, next;
-			const Key<NW> key = chop_record<NW>(tv.words, (int)tv.rb[r], len, j, K, prev, next);
-			const int owner = (int)(((key_hash<NW>(key) >> 32) * (uint64_t)nranks) >> 32);
-			const unsigned long long pos = s_base[owner] + atomicAdd(&s_fill[owner], 1u);
-			if (pos < cap_per_rank) {
-				Record<NW> rec;
-#pragma unroll
-				for (int i = 0; i < NW; i++)
-					rec.key[i] = key.w[i];
-				// first-occurrence tracking travels with the record: ordinal + 1 above the two neighbour codes
-				const uint64_t ord = ((ord_base + (tile * TILE_READS + (uint64_t)r) * ord_stride) << 16) | (uint64_t)j;
-				rec.meta = (uint64_t)prev | ((uint64_t)next << 3) | (with_ord ? (ord + 1) << 6 : 0ULL);
-				out[displs[owner] + pos] = rec;
-			} else {
-				failed++;
-			}
-		}
-		__syncthreads();
-	}
-	if (failed)
-		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
-}
-
-template <int NW>
-__global__ __launch_bounds__(TPB) void k_insert_records(const Record<NW> *__restrict__ recs, uint64_t n,
-                                                        Table<NW> tbl, Stats *stats)
-{
-	uint32_t claimed = 0, failed = 0, done = 0;
-	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
-		const Record<NW> rec = recs[i];
-		Key<NW> key;
-#pragma unroll
-		for (int w = 0; w < NW; w++)
-			key.w[w] = rec.key[w];
-		const uint64_t ordp1 = rec.meta >> 6;
-		if (!table_put<NW>(tbl, key, (uint32_t)(rec.meta & 7u), (uint32_t)((rec.meta >> 3) & 7u), claimed, ordp1 ? ordp1 - 1 : ORD_NONE))
-			failed++;
-		done++;
-	}
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) {
 		claimed += __shfl_down(claimed, d);
@@ -476,6 +365,8 @@ __global__ __launch_bounds__(TPB) void k_import(Table<NW> tbl, const uint64_t *_
 
 #include "sdt_superkmer_kernels.cuh"
 #include "sdt_comm.cuh"
+#include "sdt_shard_plan.h"
+static_assert(SHARD_NB1 == SK_NB1, "the exchange plan and the pipeline agree about the level-1 buckets");
 #include "sdt_map_kernels.cuh"
 #include "sdt_ctg_kernels.cuh"
 
@@ -497,7 +388,6 @@ struct sdt_ctx {
 	uint32_t *d_aux = nullptr;
 	uint64_t *d_first = nullptr;       // SDT_FLAG_TRACK_FIRST
 	uint64_t ord_base = 0, ord_stride = 1;
-	int my_rank = 0, nranks = 1;       // owner-filter sharding (sdt_gpu_set_owner_filter)
 	Stats *d_stats = nullptr;
 	Stats *h_stats = nullptr;          // pinned
 	unsigned long long *d_hist = nullptr;
@@ -516,8 +406,6 @@ struct sdt_ctx {
 	uint64_t hard_since_sync = 0;      // k-mers launched since then by the locality pipeline, whatever its own bound said
 	uint64_t kmers_total_host = 0;
 	uint64_t kmers_offered = 0;        // upper bound of the k-mers handed to pass 1 since the last reset (picks the kernel family)
-	// route scratch
-	unsigned long long *d_cursors = nullptr;
 	uint32_t flags = 0;
 	// locality pipeline (sdt_superkmer.cuh): chunk pools of the two scatter levels, chunk lists, pending work
 	struct SkState {
@@ -843,7 +731,7 @@ template <int NW, bool TRACK> static size_t sk_count_smem()
 
 static bool sk_applicable(const sdt_ctx *c, uint64_t max_read_len)
 {
-	if (c->nranks > 1 || (c->flags & SDT_FLAG_CONTIG_INDEX))
+	if (c->flags & SDT_FLAG_CONTIG_INDEX)
 		return false;
 	if (max_read_len < (uint64_t)c->K + 1 || max_read_len > (uint64_t)SK_MAX_READ_LEN)
 		return false;
@@ -1328,65 +1216,52 @@ static int sk_flush_sharded(sdt_ctx *c)
 	std::vector<uint32_t> mat((size_t)n * (SK_NB1 + 1));
 	rc = cm.allgather_host(k.h_off1, mat.data(), (SK_NB1 + 1) * sizeof(uint32_t));
 	if (rc != SDT_OK) return rc;
-	auto M = [&](int r, uint32_t b) { return mat[(size_t)r * (SK_NB1 + 1) + b]; };
-	std::vector<uint32_t> blo(h.ranges, h.ranges + n + 1);
-	// sub-rounds: every rank can see every rank's inflow, so all agree without another message
-	uint32_t S = 1;
-	for (int d = 0; d < n; d++) {
-		uint64_t in = 0;
-		for (int s2 = 0; s2 < n; s2++) in += M(s2, blo[d + 1]) - M(s2, blo[d]);
-		const uint32_t need = (uint32_t)((in + h.recv_chunks - 1) / h.recv_chunks);
-		if (need > S) S = need;
-	}
-	if (S > 1) S += 1;                               // pieces are cut by source, not by size: leave slack
+	auto M = [&](int r, uint32_t b) { return shard_mat(mat.data(), r, b); };
+	const uint32_t *blo = h.ranges;
+	// sub-rounds, pieces and buffer layouts: pure functions of the matrix (sdt_shard_plan.h) -- every rank computes every
+	// rank's layout from it, so all agree without another message
+	const uint32_t S = shard_subrounds(mat.data(), n, blo, h.recv_chunks);
 	const size_t cw = (size_t)SK_CAP1 * sk_rec_words(c->nw) * 8;
 	for (uint32_t t = 0; t < S; t++) {
 		const int slot = (int)(h.round & 1);
-		// piece of (source s -> destination d) in sub-round t, as a range of s's chunk list
-		auto piece = [&](int s2, int d, uint32_t &lo, uint32_t &hi) {
-			const uint64_t a = M(s2, blo[d]), b = M(s2, blo[d + 1]);
-			lo = (uint32_t)(a + (b - a) * t / S);
-			hi = (uint32_t)(a + (b - a) * (t + 1) / S);
-		};
+		ShardRound sr;
+		shard_round(mat.data(), n, me, blo, t, S, sr);
+		auto piece = [&](int s2, int d, uint32_t &lo, uint32_t &hi) { shard_piece(mat.data(), blo, s2, d, t, S, lo, hi); };
 		SkGatherPlan plan;
 		memset(&plan, 0, sizeof plan);
 		plan.n = n;
 		plan.self = me;
 		std::vector<void *> sp(n), rp(n), smp(n), rmp(n);
 		std::vector<size_t> sb(n, 0), rb(n, 0), smb(n, 0), rmb(n, 0), oboff((size_t)n * n, 0), obmoff((size_t)n * n, 0);
-		uint32_t send_at = 0, recv_at = 0;
+		const uint32_t send_at = sr.send_total, recv_at = sr.recv_total;
 		std::vector<SkItem> cur;                     // level-2 work items of THIS exchange (h.items still describes the last one)
 		for (int p = 0; p < n; p++) {
-			uint32_t lo, hi;
-			piece(me, p, lo, hi);
-			plan.begin[p] = lo;
-			plan.pre[p + 1] = plan.pre[p] + (hi - lo);
+			plan.begin[p] = sr.send_begin[p];
+			plan.pre[p + 1] = plan.pre[p] + sr.send_count[p];
+			plan.dst0[p] = sr.send_at[p];
 			if (p != me) {
-				plan.dst0[p] = send_at;
-				sp[p] = (uint8_t *)h.send[slot] + (size_t)send_at * cw;
-				smp[p] = h.send_meta[slot] + send_at;
-				sb[p] = (size_t)(hi - lo) * cw;
-				smb[p] = (size_t)(hi - lo) * 4;
-				send_at += hi - lo;
+				sp[p] = (uint8_t *)h.send[slot] + (size_t)sr.send_at[p] * cw;
+				smp[p] = h.send_meta[slot] + sr.send_at[p];
+				sb[p] = (size_t)sr.send_count[p] * cw;
+				smb[p] = (size_t)sr.send_count[p] * 4;
 			}
 		}
 		for (int s2 = 0; s2 < n; s2++) {             // receive buffer: one run per source, rank order (mine included)
 			uint32_t lo, hi;
 			piece(s2, me, lo, hi);
-			if (s2 == me) plan.dst0[me] = recv_at;
-			rp[s2] = (uint8_t *)h.recv[slot] + (size_t)recv_at * cw;
-			rmp[s2] = h.recv_meta[slot] + recv_at;
+			const uint32_t at = sr.recv_at[s2];
+			rp[s2] = (uint8_t *)h.recv[slot] + (size_t)at * cw;
+			rmp[s2] = h.recv_meta[slot] + at;
 			rb[s2] = (size_t)(hi - lo) * cw;
 			rmb[s2] = (size_t)(hi - lo) * 4;
 			// level-2 work items over this run: its chunks are in bucket order
 			for (uint32_t b = blo[me]; b < blo[me + 1] && rc == SDT_OK; b++) {
 				const uint32_t x0 = M(s2, b) > lo ? M(s2, b) : lo, x1 = M(s2, b + 1) < hi ? M(s2, b + 1) : hi;
-				for (uint32_t c0 = recv_at + (x0 - lo); x1 > x0 && c0 < recv_at + (x1 - lo); c0 += SK_ITEM_CHUNKS) {
-					const uint32_t c1 = c0 + SK_ITEM_CHUNKS < recv_at + (x1 - lo) ? c0 + SK_ITEM_CHUNKS : recv_at + (x1 - lo);
+				for (uint32_t c0 = at + (x0 - lo); x1 > x0 && c0 < at + (x1 - lo); c0 += SK_ITEM_CHUNKS) {
+					const uint32_t c1 = c0 + SK_ITEM_CHUNKS < at + (x1 - lo) ? c0 + SK_ITEM_CHUNKS : at + (x1 - lo);
 					cur.push_back(SkItem{b, c0, c1, 0});
 				}
 			}
-			recv_at += hi - lo;
 		}
 		if (send_at > h.send_chunks || recv_at > h.recv_chunks)
 			return fail(SDT_EFULL, "exchange buffers too small: %u / %u chunks to send, %u / %u to receive", send_at, h.send_chunks, recv_at, h.recv_chunks);
@@ -1547,7 +1422,6 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	INIT_CHK(hipMalloc((void **)&c->d_stats, sizeof(Stats)));
 	INIT_CHK(hipHostMalloc((void **)&c->h_stats, sizeof(Stats), hipHostMallocDefault));
 	INIT_CHK(hipMalloc((void **)&c->d_hist, 257 * sizeof(unsigned long long)));
-	INIT_CHK(hipMalloc((void **)&c->d_cursors, 64 * sizeof(unsigned long long)));
 	int rc = alloc_table(c, c->slots, &c->d_ent, &c->d_aux, &c->d_first);
 	if (rc != SDT_OK) {
 		sdt_gpu_destroy(c);
@@ -1582,7 +1456,6 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_stats) (void)hipFree(c->d_stats);
 	if (c->h_stats) (void)hipHostFree(c->h_stats);
 	if (c->d_hist) (void)hipFree(c->d_hist);
-	if (c->d_cursors) (void)hipFree(c->d_cursors);
 	keep_release(c);
 	if (c->d_patch) (void)hipFree(c->d_patch);
 	if (c->d_arcs) (void)hipFree(c->d_arcs);
@@ -1640,17 +1513,6 @@ int sdt_gpu_reset(sdt_ctx *c)
 int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
 uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
-int sdt_gpu_record_bytes(const sdt_ctx *c) { return c ? (c->nw + 1) * 8 : 0; }
-
-int sdt_gpu_set_owner_filter(sdt_ctx *c, int rank, int nranks)
-{
-	if (!c || nranks < 1 || rank < 0 || rank >= nranks)
-		return fail(SDT_EINVAL, "bad rank/nranks");
-	c->my_rank = rank;
-	c->nranks = nranks;
-	return SDT_OK;
-}
-
 int sdt_gpu_set_read_ordinal(sdt_ctx *c, uint64_t base, uint64_t stride)
 {
 	if (!c || stride == 0)
@@ -1734,11 +1596,11 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 		HIPCHK(hipEventRecord(ev->a, c->stream));
 		// offsets are absolute base indices into d_words, so a sub-range of reads is just a shifted pointer
 		if (c->nw == 1)
-			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
+			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else if (c->nw == 2)
-			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
+			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else
-			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride, c->my_rank, c->nranks);
+			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev->b, c->stream));
 		c->kmers_since_sync += upper;
@@ -1841,78 +1703,6 @@ int sdt_gpu_finish_count(sdt_ctx *c, uint64_t *kmers_processed, uint64_t *nodes)
 		return rc;
 	if (kmers_processed) *kmers_processed = c->h_stats->kmers;
 	if (nodes) *nodes = c->h_stats->distinct;
-	return SDT_OK;
-}
-
-int sdt_gpu_extract_route(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets,
-                          uint64_t nreads, uint64_t max_read_len, int nranks, void *d_records, uint64_t max_records,
-                          void *d_counts, void *d_displs)
-{
-	(void)nwords;
-	if (!c || !d_packed_words || !d_offsets || !d_records || !d_counts || !d_displs)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (nranks < 1 || nranks > 64)
-		return fail(SDT_EINVAL, "nranks must be 1..64");
-	HIPCHK(hipSetDevice(c->device));
-	// fixed-capacity slices: rank r owns [r * cap, (r+1) * cap)
-	const unsigned long long cap = max_records / (uint64_t)nranks;
-	std::vector<unsigned long long> displs(nranks);
-	for (int r = 0; r < nranks; r++)
-		displs[r] = cap * (unsigned long long)r;
-	HIPCHK(hipMemcpyAsync(d_displs, displs.data(), nranks * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemsetAsync(d_counts, 0, nranks * sizeof(unsigned long long), c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));   // displs lives on our stack
-	if (nreads == 0)
-		return SDT_OK;
-	if (max_read_len == 0)
-		return fail(SDT_EINVAL, "max_read_len must be > 0");
-	const int mtw = tile_words_for(max_read_len);
-	const size_t tile_bytes = tile_smem_bytes(mtw);
-	const int tile_words = (int)((tile_bytes / sizeof(uint32_t) + 1) & ~(size_t)1);
-	const size_t smem = (size_t)tile_words * 4 + 128 * sizeof(uint32_t) + 64 * sizeof(unsigned long long);
-	if (smem > 64 * 1024)
-		return fail(SDT_EINVAL, "max read length %llu needs %zu B of LDS per tile (limit 64 KiB)",
-		            (unsigned long long)max_read_len, smem);
-	const uint64_t ntiles = (nreads + TILE_READS - 1) / TILE_READS;
-	uint64_t grid = ntiles;
-	const uint64_t gcap = (uint64_t)c->cu_count * 4;
-	if (grid > gcap) grid = gcap;
-	if (c->nw == 1)
-		hipLaunchKernelGGL(k_extract_route<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<1> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
-	else if (c->nw == 2)
-		hipLaunchKernelGGL(k_extract_route<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<2> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
-	else
-		hipLaunchKernelGGL(k_extract_route<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, c->K, mtw, tile_words, nranks, (Record<4> *)d_records, (const unsigned long long *)d_displs, (unsigned long long *)d_counts, cap, c->d_stats, c->ord_base, c->ord_stride, (c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0);
-	HIPCHK(hipGetLastError());
-	c->ord_base += nreads * c->ord_stride;         // the next batch continues the read stream
-	return SDT_OK;
-}
-
-int sdt_gpu_insert_records(sdt_ctx *c, const void *d_records, uint64_t nrecords)
-{
-	if (!c || (!d_records && nrecords))
-		return fail(SDT_EINVAL, "NULL argument");
-	if (nrecords == 0)
-		return SDT_OK;
-	HIPCHK(hipSetDevice(c->device));
-	int rc = ensure_room(c, nrecords);
-	if (rc != SDT_OK)
-		return rc;
-	const int g = scan_grid(c, nrecords);
-	EventPair *ev = next_event(c);
-	if (!ev)
-		return fail(SDT_EHIP, "hipEventCreate failed");
-	ev->kmers = nrecords;
-	HIPCHK(hipEventRecord(ev->a, c->stream));
-	if (c->nw == 1)
-		hipLaunchKernelGGL(k_insert_records<1>, dim3(g), dim3(TPB), 0, c->stream, (const Record<1> *)d_records, nrecords, table_of<1>(c), c->d_stats);
-	else if (c->nw == 2)
-		hipLaunchKernelGGL(k_insert_records<2>, dim3(g), dim3(TPB), 0, c->stream, (const Record<2> *)d_records, nrecords, table_of<2>(c), c->d_stats);
-	else
-		hipLaunchKernelGGL(k_insert_records<4>, dim3(g), dim3(TPB), 0, c->stream, (const Record<4> *)d_records, nrecords, table_of<4>(c), c->d_stats);
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(ev->b, c->stream));
-	c->kmers_since_sync += nrecords;
 	return SDT_OK;
 }
 
@@ -2733,6 +2523,35 @@ int sdt_gpu_shard_ranges(const sdt_ctx *c, uint32_t *first_bucket)
 	return SDT_OK;
 }
 
+int sdt_shard_cut_ranges(const uint32_t *mat, int nranks, uint32_t *ranges)
+{
+	if (!mat || !ranges || nranks < 1 || nranks > SHARD_MAX_RANKS)
+		return fail(SDT_EINVAL, "bad argument (1..64 ranks)");
+	shard_cut_ranges(mat, nranks, ranges);
+	return SDT_OK;
+}
+
+int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *ranges, uint32_t recv_chunks, uint32_t t,
+                   uint32_t *subrounds, uint32_t *send_begin, uint32_t *send_count, uint32_t *send_at, uint32_t *recv_count,
+                   uint32_t *recv_at)
+{
+	if (!mat || !ranges || !subrounds || !send_begin || !send_count || !send_at || !recv_count || !recv_at)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (nranks < 1 || nranks > SHARD_MAX_RANKS || me < 0 || me >= nranks || recv_chunks == 0)
+		return fail(SDT_EINVAL, "bad argument (1..64 ranks, a receive buffer of at least one chunk)");
+	const uint32_t S = shard_subrounds(mat, nranks, ranges, recv_chunks);
+	*subrounds = S;
+	if (t >= S)
+		return fail(SDT_EINVAL, "sub-round %u of %u", t, S);
+	ShardRound r;
+	shard_round(mat, nranks, me, ranges, t, S, r);
+	for (int p = 0; p < nranks; p++) {
+		send_begin[p] = r.send_begin[p]; send_count[p] = r.send_count[p]; send_at[p] = r.send_at[p];
+		recv_count[p] = r.recv_count[p]; recv_at[p] = r.recv_at[p];
+	}
+	return SDT_OK;
+}
+
 int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K)
 {
 	// the level-1 minimizer bucket (0..255) of a canonical k-mer, as on the device
@@ -2888,23 +2707,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		std::vector<uint32_t> mat((size_t)cm.nranks * (SK_NB1 + 1));
 		rc = cm.allgather_host(k.h_off1, mat.data(), (SK_NB1 + 1) * sizeof(uint32_t));
 		if (rc != SDT_OK) return rc;
-		uint64_t wsum[SK_NB1 + 1];
-		wsum[0] = 0;
-		for (uint32_t b = 0; b < (uint32_t)SK_NB1; b++) {
-			uint64_t wgt = 1;                            // (+1: an empty sample still gives every bucket a weight)
-			for (int r = 0; r < cm.nranks; r++)
-				wgt += mat[(size_t)r * (SK_NB1 + 1) + b + 1] - mat[(size_t)r * (SK_NB1 + 1) + b];
-			wsum[b + 1] = wsum[b] + wgt;
-		}
-		c->sh.ranges[0] = 0;
-		for (int r = 1; r < cm.nranks; r++) {
-			const uint64_t want_w = wsum[SK_NB1] * (uint64_t)r / (uint64_t)cm.nranks;
-			uint32_t b = c->sh.ranges[r - 1] + 1;        // every rank owns at least one bucket
-			while (b < (uint32_t)SK_NB1 - (uint32_t)(cm.nranks - r) && wsum[b] < want_w)
-				b++;
-			c->sh.ranges[r] = b;
-		}
-		c->sh.ranges[cm.nranks] = SK_NB1;
+		shard_cut_ranges(mat.data(), cm.nranks, c->sh.ranges);
 		c->sh.have_ranges = true;
 		rc = sk_reset_pool1(c);
 		if (rc != SDT_OK) return rc;

@@ -3,7 +3,12 @@ k-mers in seconds): the two pass-1 kernel families -- one device atomic per occu
 in LDS -- must agree on every number the path reports (k-mers, nodes, `-d 1` removals, linear nodes, all 257 kmerFreq
 bins: a checksum of checksums), the bins must add up to the nodes, the scan must be idempotent, and the oracle checks the
 first 3 000 reads of the very same device buffers bit for bit.
-  C2: 50 M x 150 bp, K = 31 (1-word keys)      C4: 50 M x 250 bp, K = 63 (2-word keys, the 127mer build's layout)"""
+  C2: 50 M x 150 bp, K = 31 (1-word keys)      C4: 50 M x 250 bp, K = 63 (2-word keys, the 127mer build's layout)
+  C3: 200 M x 150 bp, K = 31 -- the workload of the headline metric (as far as one GPU goes: the 8-GPU exchange is hardware)
+  C5: 400 M x 150 bp, K = 31, expression skew sigma = 2.5, -d 1
+and the multi-rank PRODUCT path (sdt_gpu_count_reads_sharded behind bench.py --gpus N) at C2 size with 2 and 4 ranks sharing
+the box's one GPU over the shared-memory transport, sub-rounds forced: every reported number and the checksum of all 257
+kmerFreq bins must be the single rank's."""
 import numpy as np
 import pytest
 
@@ -12,11 +17,12 @@ import oracle_binding as ob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,n,L,K,est", [("C2", 50_000_000, 150, 31, 300_000_000), ("C4", 50_000_000, 250, 63, 750_000_000)])
-def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est):
+@pytest.mark.parametrize("name,n,L,K,est,sigma", [("C2", 50_000_000, 150, 31, 300_000_000, 2.0), ("C4", 50_000_000, 250, 63, 750_000_000, 2.0),
+                                                  ("C3", 200_000_000, 150, 31, 700_000_000, 2.0), ("C5", 400_000_000, 150, 31, 800_000_000, 2.5)])
+def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est, sigma):
     import torch
     dev = torch.device("cuda:0")
-    words, offsets, nwords = synth.torch_workload(n, L, T=20000, device=dev, seed=42)
+    words, offsets, nwords = synth.torch_workload(n, L, T=20000, device=dev, seed=42, sigma=sigma)
     torch.cuda.synchronize()
     seen = {}
     for mode in (pkg.SDT_FLAG_DIRECT, pkg.SDT_FLAG_PARTITION):
@@ -49,3 +55,31 @@ def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est):
                 gh, gl = g.mark_and_hist()
                 assert (gh == oh).all() and gl == ol
     assert seen[pkg.SDT_FLAG_DIRECT] == seen[pkg.SDT_FLAG_PARTITION], f"{name}: the two kernel families disagree"
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_product_path_multi_rank_at_c2_size(pkg, ranks):
+    """bench.py --gpus N (C-level bucket sharding: chop -> level-1 chunks to the owners of their buckets -> split + count) with N
+    processes on cuda:0 (SDT_BENCH_SHARE_DEVICE=1: shared-memory transport instead of RCCL, which refuses two ranks per
+    device), every exchange cut into sub-rounds by a small receive buffer, on slices of the single-rank C2 workload"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--reads", "50000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--extras", "0", "--slice-of-whole"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, SDT_BENCH_SHARE_DEVICE="1", SDT_SHM_OUTBOX_MB="1500", SDT_SHARD_RECV_CHUNKS="1500000")
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                           "--master-port", str(29620 + ranks), os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common,
+                          capture_output=True, text=True, timeout=1500, env=env)
+    assert many.returncode == 0, many.stderr[-3000:]
+    b = json.loads(many.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == ranks
+    assert b["exchange"]["exchanges_rank0"] >= 3, "the small receive buffer must force sub-rounds"
+    for k in ("kmers", "distinct_nodes", "linear_nodes", "kmerfreq_sha1"):
+        assert a["config"][k] == b["config"][k], k
+    assert sum(b["per_rank_kmers_counted"]) == a["config"]["kmers"] and len(b["per_rank_kmers_counted"]) == ranks
+    assert b["skew_max_over_mean"] < 1.6                 # ranges are cut by weight; a giant minimizer cannot be split

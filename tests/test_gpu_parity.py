@@ -233,71 +233,6 @@ def test_device_resident_batch_and_properties(pkg, synth, mode):
         assert (g.mark_and_hist()[0] == o.mark()[0]).all()
 
 
-def test_route_then_insert_equals_direct(pkg, synth):
-    """owner-computes sharding on one GPU: extract_route into N virtual ranks, insert every slice into
-    one table == counting directly; and slices are disjoint by owner hash"""
-    import torch
-    dev = torch.device("cuda:0")
-    K, L, n, nranks = 31, 100, 20000, 4
-    tx = synth.make_transcriptome(40, seed=5)
-    codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=L, seed=6)
-    words = torch.from_numpy(synth.pack_2bit(codes).view(np.int32)).to(dev)
-    offsets = torch.from_numpy(offs.astype(np.int64)).to(dev)
-    o = ob.Oracle(K, nsets=4)
-    o.add_reads(codes, offs)
-    ohist, _ = o.mark()
-    with pkg.PregraphGPU(K, est_distinct=1 << 20) as g:
-        rb = g.record_bytes()
-        assert rb == 16
-        total = n * (L - K + 1)
-        cap = int(total / nranks * 1.5) * nranks
-        recs = torch.zeros(cap * rb // 8, dtype=torch.int64, device=dev)
-        counts = torch.zeros(nranks, dtype=torch.int64, device=dev)
-        displs = torch.zeros(nranks, dtype=torch.int64, device=dev)
-        g.extract_route(words, words.numel(), offsets, n, L, nranks, recs, cap, counts, displs)
-        g.finish_count()
-        torch.cuda.synchronize()
-        c = counts.cpu().numpy()
-        d = displs.cpu().numpy()
-        assert c.sum() == total
-        lib = pkg.load_library()
-        r2 = recs.view(-1, 2)
-        for r in range(nranks):
-            sl = r2[d[r]: d[r] + c[r]]
-            kk = sl[:200, 0].cpu().numpy().view(np.uint64)
-            for k in kk:                                            # owner function agrees host/device
-                a = np.array([k], dtype=np.uint64)
-                assert ((lib.sdt_owner_hash(a.ctypes.data, 1) >> 32) * nranks) >> 32 == r
-            g.insert_records(sl.contiguous(), int(c[r]))
-        kmers, nodes = g.finish_count()
-        assert (kmers, nodes) == (total, o.node_count())
-        assert (g.mark_and_hist()[0] == ohist).all()
-    # first-occurrence ordinals travel with the records: routed + inserted == counted directly (two extract calls:
-    # the ordinal base carries over like between pushes)
-    with pkg.PregraphGPU(K, est_distinct=1 << 20, flags=pkg.SDT_FLAG_TRACK_FIRST) as g, \
-            pkg.PregraphGPU(K, est_distinct=1 << 20, flags=pkg.SDT_FLAG_TRACK_FIRST) as d:
-        d.push_reads(synth.pack_2bit(codes), offs)
-        d.finish_count()
-        half = n // 2
-        w2 = torch.from_numpy(synth.pack_2bit(codes[int(offs[half]):]).view(np.int32)).to(dev)
-        o2 = torch.from_numpy((offs[half:] - offs[half]).astype(np.int64)).to(dev)
-        for wv, ov, nr in ((words, offsets, half), (w2, o2, n - half)):
-            counts.zero_()
-            torch.cuda.synchronize()
-            g.extract_route(wv, wv.numel(), ov, nr, L, nranks, recs, cap, counts, displs)
-            g.finish_count()
-            torch.cuda.synchronize()
-            c, dd = counts.cpu().numpy(), displs.cpu().numpy()
-            for r in range(nranks):
-                g.insert_records(recs.view(-1, 2)[dd[r]: dd[r] + c[r]].contiguous(), int(c[r]))
-            g.finish_count()
-        ka, la, ra, ca, fa = g.export_nodes(with_first=True)
-        kb, lb, rb_, cb, fb = d.export_nodes(with_first=True)
-        A = {int(k[0]): (int(x), int(y), int(z), int(f)) for k, x, y, z, f in zip(ka, la, ra, ca, fa)}
-        B = {int(k[0]): (int(x), int(y), int(z), int(f)) for k, x, y, z, f in zip(kb, lb, rb_, cb, fb)}
-        assert A == B
-
-
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("K,stride,base", [(21, 1, 0), (35, 2, 1), (71, 2, 0)])
 def test_first_occurrence_ordinals(pkg, synth, K, stride, base, mode):
@@ -389,81 +324,6 @@ def test_wide_key_poly_g_tails(pkg, synth, K, mode):
                 assert node_dict_gpu(g) == node_dict_oracle(o)
 
 
-def test_sharded_counter_world1_equals_direct(pkg, synth):
-    """the N>1 driver path (sharding.ShardedCounter: extract_route -> RCCL all-to-all(v) -> insert_records ->
-    all-reduce) with a one-rank process group on the GPU: same table as the direct kernel, several rounds,
-    exchange checksum on.  (RCCL silently corrupts all-to-alls above 2^27 words -- sharding.MAX_CALL_WORDS.)"""
-    import os
-    import torch
-    import torch.distributed as dist
-    from soapdenovo_trans_amd import sharding
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        K, L, n = 31, 150, 600_000
-        words, offsets, nwords = synth.torch_workload(n, L, T=500, device=dev, seed=9)
-        torch.cuda.synchronize()
-        with pkg.PregraphGPU(K, est_distinct=1 << 24) as g:
-            g.count_reads_device(words, nwords, offsets, n, L)
-            want = g.finish_count()
-            whist, wlin = g.mark_and_hist()
-        with pkg.PregraphGPU(K, est_distinct=1 << 24) as g:
-            stream = torch.cuda.Stream(device=dev)
-            g.set_stream(stream.cuda_stream)
-            sc = sharding.ShardedCounter(g, 1, L, 250_000, dev)          # 3 rounds
-            torch.cuda.synchronize()
-            with torch.cuda.stream(stream):
-                sc.count_reads(words, nwords, offsets, n, verify=True)
-            got = g.finish_count()
-            hist, lin = g.mark_and_hist()
-            hist, k, nodes, lin = sharding.allreduce_stats(hist, got[0], got[1], lin, dev)
-            assert (k, nodes) == want and lin == wlin and (hist == whist).all()
-        # the size guard fails loudly instead of exchanging garbage
-        big = sharding.MAX_CALL_WORDS // 2 + 8
-        send = torch.empty(16, dtype=torch.int64, device=dev)
-        counts = torch.tensor([big], dtype=torch.int64, device=dev)
-        with pytest.raises(RuntimeError):
-            sharding.exchange_records(send, counts, big, 2, send)
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("K,nranks", [(31, 4), (47, 3)])
-def test_owner_filter_shards_add_up(pkg, synth, K, nranks):
-    """owner-filter sharding (sdt_gpu_set_owner_filter): every virtual rank sees all reads and keeps its own
-    k-mers; the shards are disjoint and their histograms / counters add up to the single-table result"""
-    tx = synth.make_transcriptome(30, seed=K)
-    codes, offs = synth.sample_reads(*tx, n_reads=8000, read_len=120, seed=3, ragged=True)
-    words = synth.pack_2bit(codes)
-    with pkg.PregraphGPU(K, est_distinct=1 << 18) as g:
-        g.push_reads(words, offs)
-        want = g.finish_count()
-        whist, wlin = g.mark_and_hist()
-        wkeys = set(keys_to_int(g.export_nodes()[0]))
-    tot_k = tot_n = tot_l = 0
-    hist = np.zeros(257, dtype=np.int64)
-    seen = set()
-    for r in range(nranks):
-        with pkg.PregraphGPU(K, est_distinct=1 << 16) as g:
-            g.set_owner_filter(r, nranks)
-            g.push_reads(words, offs)
-            k, n = g.finish_count()
-            h, lin = g.mark_and_hist()
-            keys = set(keys_to_int(g.export_nodes()[0]))
-            assert not (keys & seen)
-            seen |= keys
-            tot_k += k; tot_n += n; tot_l += lin
-            hist += h
-    assert (tot_k, tot_n) == want and tot_l == wlin and (hist == whist).all() and seen == wkeys
-
-
-# ---- graph-cleaning dry runs on the device mirror (sdt_gpu_set_node_index / update_nodes / tip_walks) --------
 def _rc_int(v, K):
     out = 0
     for _ in range(K):
