@@ -82,6 +82,21 @@ int sdt_gpu_reset(sdt_ctx *ctx);
 int sdt_gpu_push_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords,
                        const uint64_t *offsets, uint64_t nreads);
 
+/* The same without the wait: the call returns as soon as the copies and kernels are enqueued (a ring of 4 device staging
+ * buffers; the host blocks only when the ring is full of batches whose kernels have not run yet).  The caller's buffers must
+ * stay untouched until sdt_gpu_push_wait(ctx, *ticket) has returned -- a host that parses into a ring of its own waits for
+ * the ticket of the buffer it is about to refill, not for every push (prlHashReads.c:493-620 double-buffers the same way:
+ * one buffer is parsed while the threads work on the other).  Pinned host memory keeps the copy asynchronous.
+ * hint_total_kmers: the caller expects this many k-mers in all, so the first small batch already takes the locality pipeline
+ * (cleared by sdt_gpu_reset). */
+int sdt_gpu_push_reads_async(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads,
+                             uint64_t *ticket);
+/* a batch whose reads all have read_len bases (read i starts at base i * read_len): no offsets cross PCIe, the device makes them */
+int sdt_gpu_push_reads_fixed_async(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, uint64_t nreads, uint64_t read_len,
+                                   uint64_t *ticket);
+int sdt_gpu_push_wait(sdt_ctx *ctx, uint64_t ticket);
+int sdt_gpu_hint_total_kmers(sdt_ctx *ctx, uint64_t kmers);
+
 /* Read ordinals of the NEXT batch: read i of it gets ordinal base + i*stride; afterwards the base advances by
  * nreads*stride.  Only needed with SDT_FLAG_TRACK_FIRST when the stream is not consumed file after file: the
  * reference interleaves paired files read1, read2, read1, ... (prlHashReads.c:493-567) = stride 2, base 0 / 1. */

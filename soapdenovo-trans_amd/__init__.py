@@ -34,6 +34,10 @@ _ABI = [
     ("sdt_gpu_abi_version", _c.c_int, []),
     ("sdt_gpu_reset", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_push_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_push_reads_async", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_push_reads_fixed_async", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_push_wait", _c.c_int, [_c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_hint_total_kmers", _c.c_int, [_c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_count_reads_device", _c.c_int,
      [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
@@ -200,6 +204,27 @@ class PregraphGPU:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._check(self.lib.sdt_gpu_push_reads(self._ctx, _ptr(packed_words), packed_words.size,
                                                 _ptr(offsets), offsets.size - 1))
+
+    def push_reads_async(self, packed_words: np.ndarray, offsets: np.ndarray) -> int:
+        """enqueue only; the arrays must stay alive and untouched until push_wait(ticket) (pinned memory keeps the copy asynchronous)"""
+        assert packed_words.dtype == np.uint32 and offsets.dtype == np.uint64 and packed_words.flags.c_contiguous and offsets.flags.c_contiguous
+        t = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_push_reads_async(self._ctx, _ptr(packed_words), packed_words.size, _ptr(offsets), offsets.size - 1,
+                                                      ctypes.byref(t)))
+        return t.value
+
+    def push_reads_fixed_async(self, packed_words: np.ndarray, nreads: int, read_len: int) -> int:
+        """a batch of equal-length reads: the offsets are made on the device"""
+        assert packed_words.dtype == np.uint32 and packed_words.flags.c_contiguous
+        t = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_push_reads_fixed_async(self._ctx, _ptr(packed_words), packed_words.size, nreads, read_len, ctypes.byref(t)))
+        return t.value
+
+    def push_wait(self, ticket: int):
+        self._check(self.lib.sdt_gpu_push_wait(self._ctx, ticket))
+
+    def hint_total_kmers(self, kmers: int):
+        self._check(self.lib.sdt_gpu_hint_total_kmers(self._ctx, kmers))
 
     def count_reads_device(self, d_words, nwords: int, d_offsets, nreads: int, max_read_len: int):
         self._check(self.lib.sdt_gpu_count_reads_device(self._ctx, _ptr(d_words), nwords, _ptr(d_offsets),

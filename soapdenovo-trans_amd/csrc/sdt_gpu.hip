@@ -394,11 +394,24 @@ struct sdt_ctx {
 	hipStream_t stream = nullptr, copy_stream = nullptr;
 	bool own_stream = true;
 	// host-batch staging (double buffered)
-	uint32_t *d_words[2] = {nullptr, nullptr};
-	uint64_t *d_offs[2] = {nullptr, nullptr};
-	uint64_t cap_words[2] = {0, 0}, cap_offs[2] = {0, 0};
-	hipEvent_t buf_free[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+	// A ring of NSTAGE device buffers.  A pushed batch is COPIED at once (copy stream) and queued; its kernels are launched
+	// from the queue.  The one thing that blocks the host for long is a flush of the locality pipeline (two host syncs for
+	// the chunk lists: ~30 ms per 2^31 k-mers), and while the host is blocked nobody feeds the copy engine -- so a launch
+	// that needs a flush is put off until STAGE_AHEAD copies are queued behind it: the copies then run while the host waits
+	// (without this the PCIe-inclusive rate was compute + copy, not max(compute, copy): 50 vs 76 G k-mers/s resident).
+	static constexpr int NSTAGE = 48, STAGE_AHEAD = 32;
+	uint32_t *d_words[NSTAGE] = {};
+	uint64_t *d_offs[NSTAGE] = {};
+	uint64_t cap_words[NSTAGE] = {}, cap_offs[NSTAGE] = {};
+	hipEvent_t buf_free[NSTAGE] = {}, copied[NSTAGE] = {};
 	int next_buf = 0;
+	struct Staged { const uint32_t *dw; uint64_t *dof; uint64_t nreads, maxlen, ord_base, ord_stride; int slot; uint64_t fixed_len; };
+	std::vector<Staged> staged;        // copied (or being copied), not yet launched: [staged_head, size)
+	size_t staged_head = 0;
+	bool draining = false;
+	uint64_t push_ord_base = 0, push_ord_stride = 1;      // ordinals of the next PUSHED batch (ord_base / ord_stride: of the next LAUNCHED one)
+	uint64_t push_ticket = 0;          // pushes issued so far: ticket t's host buffers are free once copied[(t - 1) % NSTAGE] has passed
+	uint64_t expect_kmers = 0;         // sdt_gpu_hint_total_kmers
 	// bookkeeping for growth: upper bound of distinct nodes without syncing
 	uint64_t distinct_known = 0;       // as of the last sync
 	uint64_t kmers_known = 0;          // occurrences counted as of the last sync (new nodes per occurrence: bound of the next launch)
@@ -569,9 +582,17 @@ static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, u
 static int sk_flush(sdt_ctx *c);
 static void sk_free(sdt_ctx *c);
 
+static int drain_staged(sdt_ctx *c, bool force);
+
 static int sync_stats(sdt_ctx *c)
 {
-	// work parked in the locality pipeline belongs to the table before anybody looks at it
+	// batches that were pushed but not launched yet, and work parked in the locality pipeline, belong to the table before
+	// anybody looks at it
+	if (!c->draining) {
+		const int rcd = drain_staged(c, true);
+		if (rcd != SDT_OK)
+			return rcd;
+	}
 	if (c->sk.pending_kmers && !c->sk.flushing) {
 		const int rcf = sk_flush(c);
 		if (rcf != SDT_OK)
@@ -1415,7 +1436,7 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	} while (0)
 	INIT_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	INIT_CHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < sdt_ctx::NSTAGE; i++) {
 		INIT_CHK(hipEventCreateWithFlags(&c->buf_free[i], hipEventDisableTiming));
 		INIT_CHK(hipEventCreateWithFlags(&c->copied[i], hipEventDisableTiming));
 	}
@@ -1444,7 +1465,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
 	for (auto &p : c->ev) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < sdt_ctx::NSTAGE; i++) {
 		if (c->d_words[i]) (void)hipFree(c->d_words[i]);
 		if (c->d_offs[i]) (void)hipFree(c->d_offs[i]);
 		if (c->buf_free[i]) (void)hipEventDestroy(c->buf_free[i]);
@@ -1491,7 +1512,12 @@ int sdt_gpu_reset(sdt_ctx *c)
 	c->hard_since_sync = 0;
 	c->kmers_total_host = 0;
 	c->kmers_offered = 0;
+	c->expect_kmers = 0;
 	c->ord_base = 0;
+	c->push_ord_base = 0;
+	c->push_ord_stride = 1;
+	c->staged.clear();
+	c->staged_head = 0;
 	c->ord_stride = 1;
 	if (c->sk.ready) {                               // records scattered but not counted belong to the run being forgotten
 		const int rcr = sk_reset_pool1(c);
@@ -1517,8 +1543,12 @@ int sdt_gpu_set_read_ordinal(sdt_ctx *c, uint64_t base, uint64_t stride)
 {
 	if (!c || stride == 0)
 		return fail(SDT_EINVAL, "bad argument");
-	c->ord_base = base;
-	c->ord_stride = stride;
+	c->push_ord_base = base;
+	c->push_ord_stride = stride;
+	if (c->staged_head == c->staged.size()) {            // nothing queued: the launch cursor follows at once
+		c->ord_base = base;
+		c->ord_stride = stride;
+	}
 	return SDT_OK;
 }
 
@@ -1566,7 +1596,8 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	// default: the locality pipeline wherever it applies (2.2x the direct kernel on 200 M x 150 bp, K = 31); SDT_FLAG_DIRECT /
 	// SDT_FLAG_PARTITION force one family (the latter still needs a geometry the pipeline can take)
 	// (a small job is not worth the pipeline's fixed cost -- two host syncs and scans over 2^18 buckets, ~3 ms -- unless asked for)
-	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && c->kmers_offered + nreads * per_read < (1ULL << 27);
+	const bool sk_small = !(c->flags & SDT_FLAG_PARTITION) && !c->sk.pending_kmers && c->kmers_offered + nreads * per_read < (1ULL << 27) &&
+	                      c->expect_kmers < (1ULL << 27);      // (a caller that knows more is coming says so: sdt_gpu_hint_total_kmers)
 	c->kmers_offered += nreads * per_read;
 	const bool sk_ord_ok = c->ord_base + nreads * c->ord_stride < SK_MAX_READ_ORDINAL;      // what a record header can number
 	if (!(c->flags & SDT_FLAG_DIRECT) && !sk_small && sk_ord_ok && sk_applicable(c, max_read_len)) {
@@ -1609,76 +1640,188 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	return SDT_OK;
 }
 
-int sdt_gpu_push_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
-                       uint64_t nreads)
+// enqueue one host batch: H2D on the copy stream into the next buffer of the ring, kernels behind it.  Returns without waiting
+// for the copy; *ticket (may be NULL) names it for sdt_gpu_push_wait.
+// offsets of a batch of equal-length reads, made where they are used (8 B per read that need not cross PCIe: 21 % of a 150-bp batch)
+__global__ __launch_bounds__(256) void k_fixed_offsets(uint64_t *offs, uint64_t nreads, uint64_t len)
 {
-	if (!c || (!packed_words && nwords) || !offsets)
+	for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i <= nreads; i += (uint64_t)gridDim.x * 256ull)
+		offs[i] = i * len;
+}
+
+static int push_reads_enqueue(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads,
+                              uint64_t *ticket, uint64_t fixed_len = 0)
+{
+	if (!c || (!packed_words && nwords) || (!offsets && !fixed_len))
 		return fail(SDT_EINVAL, "NULL argument");
+	if (ticket) *ticket = c->push_ticket;
 	if (nreads == 0)
 		return SDT_OK;
 	HIPCHK(hipSetDevice(c->device));
 	// batch geometry from the host copy of the offsets
-	uint64_t kmers = 0, maxlen = 0;
-	for (uint64_t i = 0; i < nreads; i++) {
-		if (offsets[i + 1] < offsets[i])
-			return fail(SDT_EINVAL, "offsets not monotonic at read %llu", (unsigned long long)i);
-		const uint64_t len = offsets[i + 1] - offsets[i];
-		if (len > maxlen) maxlen = len;
-		if (len >= (uint64_t)c->K + 1) kmers += len - c->K + 1;
+	uint64_t kmers = 0, maxlen = 0, bad = 0;
+	const uint64_t Kp1 = (uint64_t)c->K + 1;
+	if (fixed_len) {
+		maxlen = fixed_len;
+		kmers = fixed_len >= Kp1 ? nreads * (fixed_len - Kp1 + 2) : 0;
+	} else {
+		for (uint64_t i = 0; i < nreads; i++) {          // (branch-free: one pass over a million offsets per batch, vectorised)
+			const uint64_t len = offsets[i + 1] - offsets[i];
+			bad |= len >> 63;                            // offsets[i + 1] < offsets[i]
+			maxlen = len > maxlen ? len : maxlen;
+			kmers += len >= Kp1 ? len - Kp1 + 2 : 0;
+		}
 	}
-	if (((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
+	if (bad)
+		return fail(SDT_EINVAL, "offsets not monotonic");
+	const uint64_t total_bases = fixed_len ? nreads * fixed_len : offsets[nreads];
+	if (((total_bases + 15) >> 4) + TAIL_PAD > nwords)
 		return fail(SDT_EINVAL, "packed_words too short: need %llu words incl. %d pad words, got %llu",
-		            (unsigned long long)(((offsets[nreads] + 15) >> 4) + TAIL_PAD), TAIL_PAD, (unsigned long long)nwords);
+		            (unsigned long long)(((total_bases + 15) >> 4) + TAIL_PAD), TAIL_PAD, (unsigned long long)nwords);
+	const int b = c->next_buf;
+	uint32_t *dw;
+	uint64_t *dof;
 	if (c->flags & SDT_FLAG_KEEP_READS) {
-		// the batch stays resident for the second pass: own buffers instead of the recycled staging pair
+		// the batch stays resident for the second pass: own buffers instead of the recycled staging ring
 		sdt_ctx::KeptBatch kb;
-		kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->ord_base; kb.ord_stride = c->ord_stride; kb.maxlen = maxlen;
+		kb.nwords = nwords; kb.nreads = nreads; kb.ord_base = c->push_ord_base; kb.ord_stride = c->push_ord_stride; kb.maxlen = maxlen;
 		kb.d_words = (uint32_t *)keep_alloc(c, nwords * sizeof(uint32_t));
 		kb.d_offs = (uint64_t *)keep_alloc(c, (nreads + 1) * sizeof(uint64_t));
 		if (!kb.d_words || !kb.d_offs)
 			return fail(SDT_ENOMEM, "kept reads: no device memory for another batch (%zu slabs held); run with --host-map", c->keep_slabs.size());
 		c->kept.push_back(kb);
-		HIPCHK(hipMemcpyAsync(kb.d_words, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
-		HIPCHK(hipMemcpyAsync(kb.d_offs, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
-		HIPCHK(hipEventRecord(c->copied[0], c->copy_stream));
-		HIPCHK(hipStreamWaitEvent(c->stream, c->copied[0], 0));
-		int rck = launch_count(c, kb.d_words, kb.d_offs, nreads, maxlen);
-		if (rck != SDT_OK)
-			return rck;
-		c->kmers_total_host += kmers;
-		HIPCHK(hipStreamSynchronize(c->copy_stream));
-		return SDT_OK;
+		dw = kb.d_words;
+		dof = kb.d_offs;
+	} else {
+		// the kernels that last read this staging buffer must be done before it is overwritten (NSTAGE batches ago): its batch
+		// has left the queue (drain_staged never lets the queue grow to NSTAGE) and its buf_free event is the newest one
+		if (c->staged.size() - c->staged_head + 1 >= (size_t)sdt_ctx::NSTAGE) {
+			const int rcd = drain_staged(c, true);
+			if (rcd != SDT_OK) return rcd;
+		}
+		HIPCHK(hipEventSynchronize(c->buf_free[b]));
+		if (c->cap_words[b] < nwords) {
+			if (c->d_words[b]) HIPCHK(hipFree(c->d_words[b]));
+			c->d_words[b] = nullptr;
+			c->cap_words[b] = 0;
+			HIPCHK(hipMalloc((void **)&c->d_words[b], nwords * sizeof(uint32_t)));
+			c->cap_words[b] = nwords;
+		}
+		if (c->cap_offs[b] < nreads + 1) {
+			if (c->d_offs[b]) HIPCHK(hipFree(c->d_offs[b]));
+			c->d_offs[b] = nullptr;
+			c->cap_offs[b] = 0;
+			HIPCHK(hipMalloc((void **)&c->d_offs[b], (nreads + 1) * sizeof(uint64_t)));
+			c->cap_offs[b] = nreads + 1;
+		}
+		dw = c->d_words[b];
+		dof = c->d_offs[b];
 	}
-	const int b = c->next_buf;
-	c->next_buf ^= 1;
-	// the kernel that last read this staging buffer must be done before we overwrite it
-	HIPCHK(hipEventSynchronize(c->buf_free[b]));
-	if (c->cap_words[b] < nwords) {
-		if (c->d_words[b]) HIPCHK(hipFree(c->d_words[b]));
-		c->d_words[b] = nullptr;
-		c->cap_words[b] = 0;
-		HIPCHK(hipMalloc((void **)&c->d_words[b], nwords * sizeof(uint32_t)));
-		c->cap_words[b] = nwords;
-	}
-	if (c->cap_offs[b] < nreads + 1) {
-		if (c->d_offs[b]) HIPCHK(hipFree(c->d_offs[b]));
-		c->d_offs[b] = nullptr;
-		c->cap_offs[b] = 0;
-		HIPCHK(hipMalloc((void **)&c->d_offs[b], (nreads + 1) * sizeof(uint64_t)));
-		c->cap_offs[b] = nreads + 1;
-	}
-	HIPCHK(hipMemcpyAsync(c->d_words[b], packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
-	HIPCHK(hipMemcpyAsync(c->d_offs[b], offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+	HIPCHK(hipMemcpyAsync(dw, packed_words, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+	if (!fixed_len)
+		HIPCHK(hipMemcpyAsync(dof, offsets, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
 	HIPCHK(hipEventRecord(c->copied[b], c->copy_stream));
-	HIPCHK(hipStreamWaitEvent(c->stream, c->copied[b], 0));
-	int rc = launch_count(c, c->d_words[b], c->d_offs[b], nreads, maxlen);
-	if (rc != SDT_OK)
-		return rc;
-	HIPCHK(hipEventRecord(c->buf_free[b], c->stream));
+	if (c->staged_head == c->staged.size()) {
+		c->staged.clear();
+		c->staged_head = 0;
+	}
+	c->staged.push_back(sdt_ctx::Staged{dw, dof, nreads, maxlen, c->push_ord_base, c->push_ord_stride, b, fixed_len});
+	c->push_ord_base += nreads * c->push_ord_stride;     // the next batch continues the read stream
 	c->kmers_total_host += kmers;
-	// the caller may reuse its buffers once the H2D copies have left them
-	HIPCHK(hipStreamSynchronize(c->copy_stream));
+	c->next_buf = (b + 1) % sdt_ctx::NSTAGE;
+	c->push_ticket++;
+	if (ticket) *ticket = c->push_ticket;
+	return drain_staged(c, false);
+}
+
+// would launching this batch make the locality pipeline flush (= block the host)?  (an estimate: sk_scatter decides)
+static bool launch_would_flush(const sdt_ctx *c, const sdt_ctx::Staged &b)
+{
+	const sdt_ctx::SkState &k = c->sk;
+	if (!k.ready || (c->flags & SDT_FLAG_DIRECT) || b.maxlen < (uint64_t)c->K + 1)
+		return false;
+	const uint64_t per_read = b.maxlen - c->K + 1;
+	return k.pending_kmers + (b.nreads + SK_TILE_READS) * per_read > k.cap_kmers;
+}
+
+// launch the kernels of queued batches, oldest first; a launch that would flush waits for STAGE_AHEAD queued copies unless
+// `force` (a sync point) or the ring is about to run out of slots
+static int drain_staged(sdt_ctx *c, bool force)
+{
+	if (c->draining)
+		return SDT_OK;
+	c->draining = true;
+	int rc = SDT_OK;
+	while (rc == SDT_OK && c->staged_head < c->staged.size()) {
+		const sdt_ctx::Staged b = c->staged[c->staged_head];
+		const size_t queued = c->staged.size() - c->staged_head;
+		if (!force && queued < (size_t)sdt_ctx::STAGE_AHEAD && queued + 2 < (size_t)sdt_ctx::NSTAGE && launch_would_flush(c, b))
+			break;
+		c->staged_head++;
+		hipError_t e = hipStreamWaitEvent(c->stream, c->copied[b.slot], 0);
+		if (e != hipSuccess) { rc = fail(SDT_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
+		c->ord_base = b.ord_base;
+		c->ord_stride = b.ord_stride;
+		if (b.fixed_len) {
+			hipLaunchKernelGGL(k_fixed_offsets, dim3(scan_grid(c, b.nreads + 1)), dim3(256), 0, c->stream, b.dof, b.nreads, b.fixed_len);
+			e = hipGetLastError();
+			if (e != hipSuccess) { rc = fail(SDT_EHIP, "k_fixed_offsets: %s", hipGetErrorString(e)); break; }
+		}
+		rc = launch_count(c, b.dw, b.dof, b.nreads, b.maxlen);
+		if (rc != SDT_OK) break;
+		e = hipEventRecord(c->buf_free[b.slot], c->stream);
+		if (e != hipSuccess) { rc = fail(SDT_EHIP, "hipEventRecord: %s", hipGetErrorString(e)); break; }
+	}
+	if (c->staged_head == c->staged.size()) {            // the launch cursor has caught up with the push cursor
+		c->ord_base = c->push_ord_base;
+		c->ord_stride = c->push_ord_stride;
+	}
+	c->draining = false;
+	return rc;
+}
+
+int sdt_gpu_push_reads_async(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets, uint64_t nreads,
+                             uint64_t *ticket)
+{
+	return push_reads_enqueue(c, packed_words, nwords, offsets, nreads, ticket);
+}
+
+int sdt_gpu_push_reads_fixed_async(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, uint64_t nreads, uint64_t read_len,
+                                   uint64_t *ticket)
+{
+	if (read_len == 0)
+		return fail(SDT_EINVAL, "read_len must be > 0");
+	return push_reads_enqueue(c, packed_words, nwords, nullptr, nreads, ticket, read_len);
+}
+
+int sdt_gpu_push_wait(sdt_ctx *c, uint64_t ticket)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	if (ticket == 0 || ticket > c->push_ticket)
+		return ticket == 0 ? SDT_OK : fail(SDT_EINVAL, "ticket %llu was never issued", (unsigned long long)ticket);
+	HIPCHK(hipSetDevice(c->device));
+	// (copies run in order on one stream: should the ring slot have been reused since, its event stands for a LATER copy)
+	HIPCHK(hipEventSynchronize(c->copied[(ticket - 1) % sdt_ctx::NSTAGE]));
 	return SDT_OK;
+}
+
+int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	c->expect_kmers = kmers;
+	return SDT_OK;
+}
+
+int sdt_gpu_push_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nwords, const uint64_t *offsets,
+                       uint64_t nreads)
+{
+	uint64_t t = 0;
+	const int rc = push_reads_enqueue(c, packed_words, nwords, offsets, nreads, &t);
+	if (rc != SDT_OK || nreads == 0)
+		return rc;
+	return sdt_gpu_push_wait(c, t);                  // the caller may reuse its buffers once the H2D copies have left them
 }
 
 int sdt_gpu_count_reads_device(sdt_ctx *c, const void *d_packed_words, uint64_t nwords, const void *d_offsets,
@@ -1690,6 +1833,8 @@ int sdt_gpu_count_reads_device(sdt_ctx *c, const void *d_packed_words, uint64_t 
 	if (max_read_len == 0)
 		return fail(SDT_EINVAL, "max_read_len must be > 0");
 	HIPCHK(hipSetDevice(c->device));
+	const int rcd = drain_staged(c, true);               // (batches pushed earlier come first)
+	if (rcd != SDT_OK) return rcd;
 	return launch_count(c, (const uint32_t *)d_packed_words, (const uint64_t *)d_offsets, nreads, max_read_len);
 }
 
@@ -1713,6 +1858,7 @@ int sdt_gpu_delow(sdt_ctx *c, int d, uint64_t *removed)
 	if (d < 0)
 		d = 0;       // pregraph.c:159: negative -d becomes 0
 	HIPCHK(hipSetDevice(c->device));
+	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 	const int g = scan_grid(c, c->slots);
 	if (c->nw == 1) hipLaunchKernelGGL(k_delow<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), (uint32_t)d, c->d_stats);
@@ -1731,6 +1877,7 @@ int sdt_gpu_mark_and_hist(sdt_ctx *c, int64_t hist[257], uint64_t *linear)
 	if (!c || !hist)
 		return fail(SDT_EINVAL, "NULL argument");
 	HIPCHK(hipSetDevice(c->device));
+	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 	HIPCHK(hipMemsetAsync(c->d_hist, 0, 257 * sizeof(unsigned long long), c->stream));
 	const int g = scan_grid(c, c->slots);
@@ -2660,6 +2807,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		return sdt_gpu_count_reads_device(c, d_packed_words, nwords, d_offsets, nreads, max_read_len);
 	}
 	HIPCHK(hipSetDevice(c->device));
+	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	Comm &cm = c->comm;
 	sdt_ctx::SkState &k = c->sk;
 	// agree on the geometry of the call: the longest read anywhere, the rank with the most reads

@@ -263,6 +263,42 @@ def test_first_occurrence_ordinals(pkg, synth, K, stride, base, mode):
             g.export_nodes(with_first=True)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("K,L", [(31, 100), (63, 160)])
+def test_async_and_fixed_length_pushes_equal_one_push(pkg, synth, K, L, mode):
+    """sdt_gpu_push_reads_async / _fixed_async: many small batches that are copied at once and launched from a queue (with
+    read ordinals set once, stride 2) must leave exactly the table of one synchronous push -- keys, links, counts, flags and
+    first-occurrence ordinals -- whether the offsets cross PCIe or are made on the device"""
+    tx = synth.make_transcriptome(30, seed=11)
+    codes, offs = synth.sample_reads(*tx, n_reads=6400, read_len=L, seed=12)          # fixed length
+    assert (np.diff(offs.astype(np.int64)) == L).all()
+
+    def table(g):
+        keys, l, rf, cnt, first = g.export_nodes(with_first=True)
+        order = np.lexsort(keys.T[::-1])
+        return keys[order].tolist(), l[order].tolist(), rf[order].tolist(), cnt[order].tolist(), first[order].tolist()
+
+    flags = pkg.SDT_FLAG_TRACK_FIRST | mode
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=flags) as g:
+        g.set_read_ordinal(1, 2)
+        g.push_reads(synth.pack_2bit(codes), offs)
+        want_counts = g.finish_count()
+        want = table(g)
+    per = 640                                            # 10 batches; 640 * L bases is a multiple of 16: batches start on a word
+    assert (per * L) % 16 == 0
+    batches = [(np.ascontiguousarray(synth.pack_2bit(codes[r0 * L: (r0 + per) * L])), np.ascontiguousarray((np.arange(per + 1) * L).astype(np.uint64)))
+               for r0 in range(0, 6400, per)]
+    for fixed in (False, True):
+        with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=flags) as g:
+            g.set_read_ordinal(1, 2)
+            g.hint_total_kmers(6400 * (L - K + 1))
+            tickets = [g.push_reads_fixed_async(w, per, L) if fixed else g.push_reads_async(w, o) for w, o in batches]
+            assert tickets == list(range(1, len(batches) + 1))
+            g.push_wait(tickets[-1])
+            assert g.finish_count() == want_counts
+            assert table(g) == want, f"fixed={fixed}"
+
+
 @pytest.mark.parametrize("K", [63, 127])
 def test_wide_key_publication_stress(pkg, synth, K):
     """multi-word keys are claimed with a CAS on the first word and published without a release fence
