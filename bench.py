@@ -80,7 +80,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
+def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=False):
     """Rank 0, N=1 only.  Time the reference binary (oracle/_ref, kind 'reference') on the first
     `sample_reads` reads of the same workload, from process start until <prefix>.kmerFreq is complete
     (= parse + chop + hash + mark, the part of pregraph this repo replaces); fall back to the oracle port."""
@@ -113,28 +113,47 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log):
                 with open(fq, "ab") as fo:
                     fo.write(b"\n")
             synth.write_config(os.path.join(tmp, "lib.cfg"), L, fastq=[fq])
+            def run_ref(p_threads):
+                """one run of the reference: (seconds from process start until *.kmerFreq is complete, the reference's own
+                'time spent on hash reads' in whole seconds or None)"""
+                out = os.path.join(tmp, f"out_p{p_threads}")
+                log_path = out + ".stdout"
+                t0 = time.time()
+                with open(log_path, "wb") as lo:
+                    proc = subprocess.Popen([exe, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(K), "-p",
+                                             str(p_threads), "-o", out], stdout=lo, stderr=subprocess.DEVNULL)
+                    kf = out + ".kmerFreq"
+                    t1 = None
+                    while proc.poll() is None and time.time() - t0 < 1200:
+                        if os.path.exists(kf) and os.path.getsize(kf) > 0:
+                            with open(kf, "rb") as fi:
+                                if fi.read().count(b"\n") >= 255:
+                                    t1 = time.time()
+                                    break
+                        time.sleep(0.02)
+                    if proc.poll() is None:
+                        proc.kill()           # exact child we started; the later phases are out of scope here
+                    proc.wait()
+                hash_s = None
+                for line in open(log_path, errors="replace"):
+                    if line.startswith("time spent on hash reads:"):       # prlHashReads.c:623 (whole seconds)
+                        hash_s = int(line.split(":")[1].split("s")[0])
+                return (None if t1 is None else t1 - t0), hash_s
+
             p_threads = min(cores, 64)
-            out = os.path.join(tmp, "out")
-            t0 = time.time()
-            proc = subprocess.Popen([exe, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(K), "-p",
-                                     str(p_threads), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            kf = out + ".kmerFreq"
-            t1 = None
-            while proc.poll() is None and time.time() - t0 < 600:
-                if os.path.exists(kf) and os.path.getsize(kf) > 0:
-                    with open(kf, "rb") as fi:
-                        if fi.read().count(b"\n") >= 255:
-                            t1 = time.time()
-                            break
-                time.sleep(0.02)
-            if proc.poll() is None:
-                proc.kill()           # exact child we started; the later phases are out of scope here
-            proc.wait()
-            if t1 is not None:
-                return {"value": kmers / (t1 - t0), "unit": "kmers/s", "cores": p_threads, "kind": "reference",
-                        "sample": f"first {n} reads ({kmers} k-mers) of the workload as FASTQ; reference "
-                                  f"SOAPdenovo-Trans pregraph -K {K} -p {p_threads}, process start until "
-                                  f"*.kmerFreq written ({t1 - t0:.2f} s)"}
+            wall, hash_s = run_ref(p_threads)
+            if wall is not None:
+                res = {"value": kmers / wall, "unit": "kmers/s", "cores": p_threads, "kind": "reference",
+                       "sample": f"first {n} reads ({kmers} k-mers, 1/{max(n_reads_total // max(n, 1), 1)} of the workload) as FASTQ; reference "
+                                 f"SOAPdenovo-Trans pregraph -K {K} -p {p_threads}, process start until "
+                                 f"*.kmerFreq written ({wall:.2f} s)",
+                       "hash_reads_s": hash_s,
+                       "hash_reads_kmers_per_s": None if not hash_s else kmers / hash_s}
+                if also_p8 and p_threads != 8:
+                    w8, h8 = run_ref(8)
+                    res["p8"] = {"value": None if w8 is None else kmers / w8, "cores": 8, "wall_s": w8, "hash_reads_s": h8,
+                                 "hash_reads_kmers_per_s": None if not h8 else kmers / h8}
+                return res
             log("reference binary did not produce kmerFreq; falling back to the oracle port")
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -164,6 +183,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=2.0, help="log-normal sigma of the expression weights (SURVEY C5: 2.5)")
     ap.add_argument("--d", type=int, default=0, help="-d: also run the low-coverage filter (k_delow) in every step")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-p8", action="store_true", help="cpu_baseline: also time the reference with its default -p 8")
     ap.add_argument("--est-distinct", type=int, default=0)
     ap.add_argument("--pipeline", choices=["auto", "direct", "superkmer"], default="auto",
                     help="pass-1 kernel family: 'direct' = one device atomic per occurrence (k_count_reads); 'superkmer' = "
@@ -231,9 +251,22 @@ def main():
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
 
-    # distinct k-mers ~ true k-mers + a share of errors * K; table sized so that MAX_LOAD is not hit
-    # (measured: 0.68 G nodes for 200 M x 150 bp at err 0.002 -- most erroneous k-mers of a highly expressed transcript recur)
-    est = args.est_distinct or int(args.T * 2250 + n_total * L * args.err * K * 0.35) // world + (1 << 20)
+    # Table size from the data, not from the answer: count the nodes of the first c and the first 2c reads of this rank (two small
+    # passes outside the timed region) and extend the last slope to all reads -- new true k-mers dry up as coverage grows, new
+    # erroneous ones keep coming at a constant rate, so the straight line is an upper bound that is tight once the sample covers
+    # the transcriptome (200 M x 150 bp: estimate vs 0.68 G measured in config.distinct_nodes / est_distinct).
+    def estimate_distinct():
+        c = min(max(n_local // 64, 1 << 18), 1 << 21, n_local // 2)
+        if c < 1024:
+            return n_local * (L - K + 1)
+        got = []
+        for m in (c, 2 * c):
+            with pkg.PregraphGPU(K, est_distinct=1 << 24, device=dev.index or 0) as ge_:
+                ge_.count_reads_device(words, nwords, offsets, m, L)
+                got.append(ge_.finish_count()[1])
+        slope = max(got[1] - got[0], 0) / c
+        return int(got[1] + slope * (n_local - 2 * c))
+    est = args.est_distinct or estimate_distinct() + (1 << 20)
     base_flags = {"auto": 0, "direct": pkg.SDT_FLAG_DIRECT, "superkmer": pkg.SDT_FLAG_PARTITION}[args.pipeline]
     flags = base_flags | (pkg.SDT_FLAG_TRACK_FIRST if args.track_first else 0)
     g = pkg.PregraphGPU(K, est_distinct=est, device=dev.index or 0, flags=flags)
@@ -338,7 +371,7 @@ def main():
                                f"K={K}, pass-1 chop+hash+count" + (f"+delow(-d {args.d})" if args.d else "") + "+kmerFreq"
                                + (f", sigma={args.sigma}" if args.sigma != 2.0 else "")
                                + (", first-occurrence tracking" if args.track_first else ""), "reads": n_total, "read_len": L, "K": K,
-                   "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear,
+                   "kmers": kmers_total, "distinct_nodes": nodes, "linear_nodes": linear, "est_distinct_per_rank": est,
                    "parallelism": {"single": "single-GPU table",
                                    "bucket": f"reads split x{world}; tables sharded by minimizer bucket; super-k-mer chunks by grouped "
                                              f"ncclSend/ncclRecv (C ABI: sdt_gpu_count_reads_sharded)" + (" [shared-memory transport: ranks share one GPU]" if share else ""),
@@ -424,7 +457,7 @@ def main():
             log("pcie extra failed:", repr(e))
     if rank == 0 and world == 1 and not sharded_path and args.cpu_sample > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log)
+            out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log, also_p8=args.cpu_p8)
         except Exception as e:     # the baseline is reported, never required
             log("cpu baseline failed:", repr(e))
             out["cpu_baseline"] = None

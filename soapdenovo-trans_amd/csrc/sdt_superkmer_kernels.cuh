@@ -13,6 +13,9 @@
 #ifndef SDT_SK_FLUSH_NUM
 #define SDT_SK_FLUSH_NUM 4        // the LDS table is flushed between rounds once it is FLUSH_NUM / 8 full
 #endif
+#ifndef SDT_SK_NW2_TWO
+#define SDT_SK_NW2_TWO 1        // 2-word keys: 1 = two workgroups per CU (64 registers; needs SDT_SK_SLOTS_NW2 <= 1280)
+#endif
 #ifndef SDT_SK_CNT_TPB
 #define SDT_SK_CNT_TPB 1024
 #endif
@@ -20,11 +23,11 @@
 #define SDT_SK_SLOTS_TRACK 1536
 #endif
 #ifndef SDT_SK_SLOTS_NW2
-#define SDT_SK_SLOTS_NW2 2048
+#define SDT_SK_SLOTS_NW2 1280
 #endif
 template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TPB = SDT_SK_CNT_TPB;
-	static constexpr int WAVES_PER_SIMD = NW == 1 ? 2 * (TPB / 256) : TPB / 256;      // 1-word keys: two workgroups per CU
+	static constexpr int WAVES_PER_SIMD = (NW == 1 || (NW == 2 && SDT_SK_NW2_TWO)) ? 2 * (TPB / 256) : TPB / 256;      // two workgroups per CU where the table allows
 	static constexpr int TILE = 512;                                       // records per tile
 	// LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal).  1-word keys: 2048 slots = 75 KB with the tile, two
 	// workgroups per CU; with ordinals half the table keeps it at two
