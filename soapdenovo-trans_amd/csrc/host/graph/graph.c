@@ -215,7 +215,7 @@ gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller)
 	}
 	uint64_t h = mix_key(canon) & g->index_mask;
 	for (;;) {
-		const uint64_t v = g->index[h];
+		const uint64_t v = g->index64 ? g->index64[h] : g->index[h];
 		if (!v) break;
 		if (kw_eq(&g->nodes[v - 1].seq, canon)) return &g->nodes[v - 1];
 		h = (h + 1) & g->index_mask;
@@ -374,8 +374,13 @@ static void job_index(build_job *J, int tid)
 	const uint64_t lo = g->n * (uint64_t)tid / J->nthreads, hi = g->n * (uint64_t)(tid + 1) / J->nthreads;
 	for (uint64_t i = lo; i < hi; i++) {
 		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
-		while (!__sync_bool_compare_and_swap(&g->index[h], 0u, (uint32_t)(i + 1)))
-			h = (h + 1) & g->index_mask;
+		if (g->index64) {
+			while (!__sync_bool_compare_and_swap(&g->index64[h], 0ULL, i + 1))
+				h = (h + 1) & g->index_mask;
+		} else {
+			while (!__sync_bool_compare_and_swap(&g->index[h], 0u, (uint32_t)(i + 1)))
+				h = (h + 1) & g->index_mask;
+		}
 	}
 }
 
@@ -465,15 +470,24 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	/* gigabytes of scratch: returning them to the kernel takes a fraction of a second, off the critical path */
 	graph_free_later(J.ord, J.per_set, J.set_of, J.tmp);
 	/* index */
-	if (n >= 0xFFFFFFFEULL) { printf("%llu nodes: the host index holds 32-bit node ids\n", (unsigned long long)n); exit(1); }
+	/* node ids past 32 bits: 64-bit index entries, built here (the device-built index is the 32-bit one; the hook still
+	 * brings the device mirror of the graph up, then declines) */
+	const int wide = n >= 0xFFFFFFFEULL || getenv("SDT_WIDE_INDEX") != NULL;
+	uint64_t cap = 1024;
+	while (cap < 2 * n + 2) cap <<= 1;
+	if (wide) {
+		g->index64 = (uint64_t *)calloc(cap, sizeof(uint64_t));
+		if (!g->index64) { printf("out of memory for the node index (%llu entries)\n", (unsigned long long)cap); exit(1); }
+		g->index_mask = cap - 1;
+	}
 	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {
 		GB_PHASE("index (device)");
 		return g;
 	}
-	uint64_t cap = 1024;
-	while (cap < 2 * n + 2) cap <<= 1;
-	g->index = (uint32_t *)calloc(cap, sizeof(uint32_t));
-	g->index_mask = cap - 1;
+	if (!wide) {
+		g->index = (uint32_t *)calloc(cap, sizeof(uint32_t));
+		g->index_mask = cap - 1;
+	}
 	run_parallel(&J, job_index);
 	GB_PHASE("index");
 	return g;
@@ -482,5 +496,5 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 void graph_free(graph_t *g)
 {
 	if (!g) return;
-	free(g->nodes); free(g->set_start); free(g->index); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g->vbits); free(g);
+	free(g->nodes); free(g->set_start); free(g->index); free(g->index64); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g->vbits); free(g);
 }

@@ -35,7 +35,9 @@ typedef struct graph_s {
 	uint64_t n;
 	gnode_t *nodes;                    /* visiting order */
 	uint64_t *set_start;               /* p + 1 offsets into nodes[] */
-	uint32_t *index;                   /* open addressing: node id + 1, 0 = empty (n < 2^32 - 1) */
+	uint32_t *index;                   /* open addressing: node id + 1, 0 = empty (n < 2^32 - 2) ... */
+	uint64_t *index64;                 /* ... or, for larger graphs (and SDT_WIDE_INDEX=1: tests), the same with 64-bit entries;
+	                                    * exactly one of the two is set (the reference's sets have ubyte8 sizes, inc/newhash.h:79-88) */
 	uint64_t index_mask;
 	gpatch_t *patch;                   /* open addressing over canonical (K+1)-mers */
 	uint64_t patch_mask, patch_n;

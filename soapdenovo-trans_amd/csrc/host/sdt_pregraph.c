@@ -272,6 +272,8 @@ static int dev_index_hook(graph_t *g, void *user)
 	const double t0 = now_ms();
 	if (dev_mirror_sync(g) != 0) exit(1);
 	const double t1 = now_ms();
+	if (g->index64)
+		return 1;                                                        /* a graph past 2^32 nodes: the host builds its 64-bit index */
 	uint64_t cap = 1024;
 	while (cap < 2 * g->n + 2) cap <<= 1;
 	g->index = (uint32_t *)malloc(cap * sizeof(uint32_t));

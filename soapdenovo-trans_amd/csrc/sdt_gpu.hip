@@ -20,6 +20,7 @@
 #include <stdarg.h>
 #include <vector>
 #include <new>
+#include <thread>
 
 #include "../../include/sdt_gpu.h"
 #include "sdt_kmer.cuh"
@@ -1347,6 +1348,8 @@ static int sk_flush_sharded(sdt_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static int h2d_big(sdt_ctx *c, void *dst, const void *src, size_t bytes);
+
 template <int NW>
 static int build_patch_table(sdt_ctx *c, const uint64_t *pkeys, const uint64_t *pinfo, uint64_t np)
 {
@@ -1752,12 +1755,14 @@ static int drain_staged(sdt_ctx *c, bool force)
 		return SDT_OK;
 	c->draining = true;
 	int rc = SDT_OK;
+	bool launched = false;
 	while (rc == SDT_OK && c->staged_head < c->staged.size()) {
 		const sdt_ctx::Staged b = c->staged[c->staged_head];
 		const size_t queued = c->staged.size() - c->staged_head;
 		if (!force && queued < (size_t)sdt_ctx::STAGE_AHEAD && queued + 2 < (size_t)sdt_ctx::NSTAGE && launch_would_flush(c, b))
 			break;
 		c->staged_head++;
+		launched = true;
 		hipError_t e = hipStreamWaitEvent(c->stream, c->copied[b.slot], 0);
 		if (e != hipSuccess) { rc = fail(SDT_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
 		c->ord_base = b.ord_base;
@@ -1772,9 +1777,13 @@ static int drain_staged(sdt_ctx *c, bool force)
 		e = hipEventRecord(c->buf_free[b.slot], c->stream);
 		if (e != hipSuccess) { rc = fail(SDT_EHIP, "hipEventRecord: %s", hipGetErrorString(e)); break; }
 	}
-	if (c->staged_head == c->staged.size()) {            // the launch cursor has caught up with the push cursor
+	if (launched && c->staged_head == c->staged.size()) {     // the launch cursor has caught up with the push cursor
 		c->ord_base = c->push_ord_base;
 		c->ord_stride = c->push_ord_stride;
+	}
+	if (!launched && c->staged_head == c->staged.size()) {    // nothing was queued: calls that count device-resident reads move the
+		c->push_ord_base = c->ord_base;                       // launch cursor on their own, and the push cursor follows it
+		c->push_ord_stride = c->ord_stride;
 	}
 	c->draining = false;
 	return rc;
@@ -1968,8 +1977,9 @@ int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_wo
 		if (!by_index) HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
 		hipError_t e = hipMalloc((void **)&d_i, n * sizeof(uint64_t));
 		if (e != hipSuccess) { if (d_k) (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
-		if (!by_index) HIPCHK(hipMemcpyAsync(d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipMemcpyAsync(d_i, path_words, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		int rcu = by_index ? SDT_OK : h2d_big(c, d_k, keys, n * c->nw * sizeof(uint64_t));
+		if (rcu == SDT_OK) rcu = h2d_big(c, d_i, path_words, n * sizeof(uint64_t));
+		if (rcu != SDT_OK) { if (d_k) (void)hipFree(d_k); (void)hipFree(d_i); return rcu; }
 		if (by_index) {
 			const int g = scan_grid(c, c->slots);
 			if (c->nw == 1) hipLaunchKernelGGL(k_set_paths_by_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_i, n, c->d_stats);
@@ -2101,13 +2111,54 @@ done:
 	return ret;
 }
 
+// Gigabytes from PAGEABLE host memory (the host graph's arrays: 5.4 GB of keys, as much again of path words at 200 M reads): the
+// runtime stages such a copy through one small pinned buffer on one thread, ~2.2 GB/s (2.4 s per array).  Here: two pinned
+// buffers of 64 MiB, filled by four threads while the other one is on the wire.  Synchronous: the source may be freed on return.
+static int h2d_big(sdt_ctx *c, void *dst, const void *src, size_t bytes)
+{
+	const size_t CH = (size_t)64 << 20;
+	if (bytes < 2 * CH) {
+		HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		return SDT_OK;
+	}
+	void *pin[2] = {nullptr, nullptr};
+	hipEvent_t done[2] = {nullptr, nullptr};
+	int rc = SDT_OK;
+	for (int i = 0; i < 2 && rc == SDT_OK; i++)
+		if (hipHostMalloc(&pin[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+			rc = fail(SDT_ENOMEM, "pinned staging for a %zu-byte upload", bytes);
+	int b = 0;
+	bool used[2] = {false, false};
+	for (size_t off = 0; off < bytes && rc == SDT_OK; off += CH, b ^= 1) {
+		const size_t n = bytes - off < CH ? bytes - off : CH;
+		if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "upload: event wait failed"); break; }
+		const int T = 4;
+		std::thread th[T];
+		for (int t = 0; t < T; t++) {
+			const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
+			th[t] = std::thread([=] { memcpy((char *)pin[b] + a0, (const char *)src + off + a0, a1 - a0); });
+		}
+		for (int t = 0; t < T; t++) th[t].join();
+		if (hipMemcpyAsync((char *)dst + off, pin[b], n, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+		    hipEventRecord(done[b], c->copy_stream) != hipSuccess) { rc = fail(SDT_EHIP, "upload: copy failed"); break; }
+		used[b] = true;
+	}
+	if (hipStreamSynchronize(c->copy_stream) != hipSuccess && rc == SDT_OK) rc = fail(SDT_EHIP, "upload: sync failed");
+	for (int i = 0; i < 2; i++) {
+		if (pin[i]) (void)hipHostFree(pin[i]);
+		if (done[i]) (void)hipEventDestroy(done[i]);
+	}
+	return rc;
+}
+
 // ---- graph-cleaning dry runs on the device mirror of the host graph ---------------------------------------
 static int upload_keys(sdt_ctx *c, const uint64_t *keys, uint64_t n, uint64_t **d_k)
 {
 	HIPCHK(hipMalloc((void **)d_k, (n ? n : 1) * c->nw * sizeof(uint64_t)));
-	hipError_t e = hipMemcpyAsync(*d_k, keys, n * c->nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
-	if (e != hipSuccess) { (void)hipFree(*d_k); *d_k = nullptr; return fail(SDT_EHIP, "key upload: %s", hipGetErrorString(e)); }
-	return SDT_OK;
+	const int rc = h2d_big(c, *d_k, keys, n * c->nw * sizeof(uint64_t));
+	if (rc != SDT_OK) { (void)hipFree(*d_k); *d_k = nullptr; }
+	return rc;
 }
 
 int sdt_gpu_set_node_index(sdt_ctx *c, const uint64_t *keys, uint64_t n)
@@ -2930,6 +2981,18 @@ int sdt_gpu_push_reads_sharded(sdt_ctx *c, const uint32_t *packed_words, uint64_
 		HIPCHK(hipStreamSynchronize(c->stream));     // the staging buffers may be overwritten by the next call
 	return rc;
 }
+
+#ifdef SDT_SK_L2_LOG
+// debug builds only (not declared in include/sdt_gpu.h): point the level-2 scatter's slot log at a device buffer of `cap` words
+extern "C" int sdt_gpu_debug_l2_log(sdt_ctx *c, void *d_buf, uint64_t cap)
+{
+	unsigned long long *p = (unsigned long long *)d_buf, cp = cap;
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_l2_log), &p, sizeof p));
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_l2_log_cap), &cp, sizeof cp));
+	return SDT_OK;
+}
+#endif
 
 int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS])
 {

@@ -16,6 +16,36 @@ using namespace sdt;
 constexpr uint32_t SK_BLK = 128;
 constexpr uint32_t SK_DEAD = 0xFFFFFFFFu;        // meta of a chunk id that was handed to a workgroup but never used
 
+#ifdef SDT_SK_L2_LOG
+extern __device__ unsigned long long *g_l2_log;
+extern __device__ unsigned long long g_l2_log_cap;
+// (debug build: every id sk_alloc_chunk hands out -- bit 63 | path << 61 | lane << 48 | end of block << 24 | id)
+__device__ inline void sk_log_alloc(uint32_t path, uint32_t end, uint32_t id)
+{
+	if (g_l2_log) {
+		const unsigned long long at = atomicAdd(g_l2_log, 1ULL);
+		if (at + 1 < g_l2_log_cap)
+			g_l2_log[1 + at] = (1ULL << 63) | ((unsigned long long)path << 61) | ((unsigned long long)(threadIdx.x & 0x1FFF) << 48) |
+			                   ((unsigned long long)(end & 0xFFFFFFu) << 24) | (unsigned long long)(id & 0xFFFFFFu);
+	}
+}
+// every value a lane reads from a chunk cursor: bit 63 | 3 << 61 | kind << 59 (0 slot granted, 1 this lane opens the next chunk,
+// 2 look again, 3 the exchange it then wrote) | workgroup & 15 << 55 | lane << 45 | bucket << 35 | min(pos, 31) << 30 | chunk & 2^30 - 1
+__device__ inline void sk_log_cursor(uint32_t kind, uint32_t lb, uint32_t chunk, uint32_t pos)
+{
+	if (g_l2_log) {
+		const unsigned long long at = atomicAdd(g_l2_log, 1ULL);
+		if (at + 1 < g_l2_log_cap)
+			g_l2_log[1 + at] = (1ULL << 63) | (3ULL << 61) | ((unsigned long long)kind << 59) | ((unsigned long long)(blockIdx.x & 15u) << 55) |
+			                   ((unsigned long long)(threadIdx.x & 1023u) << 45) | ((unsigned long long)(lb & 1023u) << 35) |
+			                   ((unsigned long long)(pos > 31u ? 31u : pos) << 30) | (unsigned long long)(chunk & 0x3FFFFFFFu);
+	}
+}
+#else
+__device__ inline void sk_log_alloc(uint32_t, uint32_t, uint32_t) {}
+__device__ inline void sk_log_cursor(uint32_t, uint32_t, uint32_t, uint32_t) {}
+#endif
+
 __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool)
 {
 	// Flag form on purpose: a lane that finds the block exhausted (id > end) spins until the lane that took id == end has
@@ -30,11 +60,13 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 		if (id < end) {
 			got = id;
 			done = true;
+			sk_log_alloc(0, end, id);
 		} else if (id == end) {
 			const uint32_t base = atomicAdd(pool.next, SK_BLK);
 			atomicExch(s_blk, ((unsigned long long)(base + SK_BLK) << 32) | (unsigned long long)(base + 1u));
 			got = base;
 			done = true;
+			sk_log_alloc(1, end, base);
 		}
 		// id > end: another lane of this workgroup is fetching the next block -- look again
 	}
@@ -65,7 +97,9 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 		if (pos < cap) {
 			ok = chunk != SK_NOCHUNK;
 			done = true;
+			sk_log_cursor(0, lb, chunk, pos);            // (debug build)
 		} else if (pos == cap) {
+			sk_log_cursor(1, lb, chunk, pos);
 			uint32_t id = sk_alloc_chunk(s_blk, pool);
 			if (id >= pool.chunks) {
 				id = SK_NOCHUNK;
@@ -78,6 +112,11 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 			pos = 0;
 			ok = id != SK_NOCHUNK;
 			done = true;
+			sk_log_cursor(3, lb, id, 1);
+		} else {
+#if SDT_SK_L2_LOG >= 2
+			sk_log_cursor(2, lb, chunk, pos);            // (every look-again too: slows the spinning lanes enough to hide the failure)
+#endif
 		}
 		// pos > cap: another lane of this workgroup is replacing the chunk -- look again
 	}

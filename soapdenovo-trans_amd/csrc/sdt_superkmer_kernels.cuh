@@ -400,6 +400,13 @@ __global__ __launch_bounds__(256) void k_sk_chunk_place_few(SkPool pool, const u
 // ---- level 2: one item = a run of chunks of ONE level-1 bucket, split into its 1024 sub-buckets ---------------
 struct SkItem { uint32_t b1, c0, c1, pad; };
 
+#ifdef SDT_SK_L2_LOG
+// debug build (tools/l2_lost_chunk.py): every slot the level-2 scatter hands out goes into a side buffer
+//   word 0: entries written; then per entry  chunk << 32 | pos << 16 | lane
+__device__ unsigned long long *g_l2_log = nullptr;
+__device__ unsigned long long g_l2_log_cap = 0;
+#endif
+
 template <int NW>
 __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, const uint32_t *__restrict__ list1,
                                                                   const SkItem *__restrict__ items, SkPool dst,
@@ -466,9 +473,16 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 			const uint32_t b2 = sk_hdr_l2(rec[0]);
 			atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
 			uint32_t dchunk, pos;
-			if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, s_cc, dchunk, pos))
+			if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, s_cc, dchunk, pos)) {
 				sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
-			else
+#ifdef SDT_SK_L2_LOG
+				if (g_l2_log) {
+					const unsigned long long at = atomicAdd(g_l2_log, 1ULL);
+					if (at + 1 < g_l2_log_cap)
+						g_l2_log[1 + at] = ((unsigned long long)dchunk << 32) | ((unsigned long long)pos << 16) | (unsigned long long)tid;
+				}
+#endif
+			} else
 				failed++;                            // the pool is sized for the worst case: never expected
 		}
 	}
