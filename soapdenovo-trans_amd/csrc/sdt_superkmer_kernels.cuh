@@ -16,6 +16,9 @@
 #ifndef SDT_SK_NW2_TWO
 #define SDT_SK_NW2_TWO 1        // 2-word keys: 1 = two workgroups per CU (64 registers; needs SDT_SK_SLOTS_NW2 <= 1280)
 #endif
+#ifndef SDT_SK_DEFER_FLUSH
+#define SDT_SK_DEFER_FLUSH 0       // EXPERIMENT, off: an owned flush at a tile boundary issues its loads and is finished before the NEXT tile's phase D (1 = always, 2 = within an item only, 3 = across items only); hangs at >= 5 M reads, see profiles/r3/README.md
+#endif
 #ifndef SDT_SK_CNT_TPB
 #define SDT_SK_CNT_TPB 1024
 #endif
@@ -707,6 +710,40 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #else
 #define SK_TICK(i) do { } while (0)
 #endif
+	// A flush that is waiting for its loads (SDT_SK_DEFER_FLUSH): an owned flush at a tile boundary takes its slots out of LDS,
+	// clears them and issues the node-table loads, and the merges are done just before the NEXT tile's phase D -- the round
+	// trip to the node table (a third of the kernel's time was spent inside flushes, most of it waiting: tick counters,
+	// profiles/r3) then runs beside that tile's phases A-C (or the next item's start).  The registers below are the buffer.
+	constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
+	Key<NW> mk[PER];
+	uint64_t madd[PER], mord[TRACK ? PER : 1];       // (the slot of a key is hashed again when the flush is finished: two registers
+	bool have[PER];                                  //  per key less to carry across a tile)
+	EntSnap<NW, TRACK> sn[PER];
+	bool flush_open = false;                         // (uniform) the registers above hold a flush whose merges are still to do
+	bool stores_pending = false;                     // (uniform) plain stores of an owned flush may still be in flight
+	auto flush_finish = [&]() {
+		uint32_t claimed = 0, failed = 0, merges = 0;
+#pragma unroll
+		for (int p = 0; p < PER; p++)
+			if (have[p]) {
+				merges++;
+				if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], key_hash<NW>(mk[p]) & tbl.mask, sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
+					failed++;
+			}
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) {
+			claimed += __shfl_down(claimed, d);
+			failed += __shfl_down(failed, d);
+			merges += __shfl_down(merges, d);
+		}
+		if ((tid & 63) == 0) {
+			if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+			if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+			if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+		}
+		flush_open = false;
+		stores_pending = true;
+	};
 	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
 	// its own), handed out first come first served
 	for (;;) {
@@ -744,7 +781,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		__syncthreads();
 		uint32_t tile_no = 0;
 		uint32_t since = 0;                          // k-mers counted into the LDS table since its last clear (uniform)
-		bool stores_pending = false;                 // plain stores of an owned flush may still be in flight (uniform)
 		SK_TICK(0);
 		for (uint32_t cb = c0; cb < c1; cb += CPT) {
 			// ---- A: the first TR lanes put their record into LDS
@@ -872,6 +908,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			// than one new key per four occurrences (a k-mer that does find the table full takes the direct path)
 			const bool last_tile = cb + CPT >= c1;
 			tile_no++;
+			if (flush_open)
+				flush_finish();                              // (its loads were issued a tile ago)
 			for (uint32_t qb = 0;;) {
 				if (want_flush) {
 					SK_TICK(2);
@@ -881,19 +919,16 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					// item's last round: three copies of the merge code cost the hot loop its registers.)
 					const bool owned = whole && __builtin_amdgcn_readfirstlane((int)s_spilled) == 0;
 					uint32_t claimed = 0, failed = 0, merges = 0;
-					// (the stores of this item's previous flush were left in flight: they must have landed before this one reads)
+					if (flush_open)
+						flush_finish();                          // (one flush in the registers at a time)
+					// (the stores of the previous flush were left in flight: they must have landed before this one reads)
 					if (stores_pending) {
 						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 						__syncthreads();
 						stores_pending = false;
 					}
 					if (owned) {
-						// this lane's PER slots: everything out of LDS, all global loads issued, then the merges
-						constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
-						Key<NW> mk[PER];
-						uint64_t madd[PER], mord[TRACK ? PER : 1], mslot[PER];
-						bool have[PER];
-						EntSnap<NW, TRACK> sn[PER];
+						// this lane's PER slots: everything out of LDS, all global loads issued, then (now or a tile later) the merges
 #pragma unroll
 						for (int p = 0; p < PER; p++) {
 							const int i = tid + p * SK_CNT_TPB;
@@ -905,7 +940,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 									mk[p].w[wv] = s_key[wv * SLOTS + i];
 								madd[p] = sk_lds_val(&s_f[5 * i]);
 								if (TRACK) mord[p] = (uint64_t)s_ord[i];
-								mslot[p] = key_hash<NW>(mk[p]) & tbl.mask;
 								s_key[i] = KEY_EMPTY;
 #pragma unroll
 								for (int f = 0; f < 5; f++)
@@ -917,16 +951,11 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #pragma unroll                                                 //  scheduler the snapshots were spilled, i.e. waited for one by one)
 						for (int p = 0; p < PER; p++)
 							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
-								sn[p] = ent_load<NW, TRACK>(tbl, mslot[p], mk[p], (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
 						__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-						for (int p = 0; p < PER; p++)
-							if (have[p]) {
-								merges++;
-								if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], mslot[p], sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
-									failed++;
-							}
-						stores_pending = true;
+						flush_open = true;
+						if (!(SDT_SK_DEFER_FLUSH && NW == 1 && qb >= total && (SDT_SK_DEFER_FLUSH == 1 || (SDT_SK_DEFER_FLUSH == 2 && !last_tile) || (SDT_SK_DEFER_FLUSH == 3 && last_tile))))      // (wider keys: a deferred flush lost nodes in one golden case -- not understood, not used)
+							flush_finish();                          // (in the middle of a tile: nothing to hide behind)
 					} else {
 						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 							const uint64_t k0 = s_key[i];
@@ -948,17 +977,17 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 								s_f[5 * i + f] = 0;
 							if (TRACK) s_ord[i] = ORD_NONE;
 						}
-					}
 #pragma unroll
-					for (int d = 32; d > 0; d >>= 1) {
-						claimed += __shfl_down(claimed, d);
-						failed += __shfl_down(failed, d);
-						merges += __shfl_down(merges, d);
-					}
-					if ((tid & 63) == 0) {
-						if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
-						if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
-						if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+						for (int d = 32; d > 0; d >>= 1) {
+							claimed += __shfl_down(claimed, d);
+							failed += __shfl_down(failed, d);
+							merges += __shfl_down(merges, d);
+						}
+						if ((tid & 63) == 0) {
+							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+						}
 					}
 					__syncthreads();
 					if (tid == 0) {
@@ -1012,6 +1041,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		}
 	}
 #undef SK_TICK
+	if (flush_open)
+		flush_finish();
 	__syncthreads();
 	if (tid == 0) {
 		if (s_stat[ST_CLAIMED]) atomicAdd(&stats->distinct, (unsigned long long)s_stat[ST_CLAIMED]);
