@@ -705,7 +705,8 @@ static int tile_words_for(uint64_t max_read_len)
 // ------------------------------------------------------------------------------------------------
 // locality pipeline (sdt_superkmer.cuh): scatter super-k-mers -> split -> count in LDS -> merge
 // ------------------------------------------------------------------------------------------------
-static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << 33;      // k-mers per batch at most (pools: ~11 B per k-mer)
+static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << env_int("SDT_SK_BATCH_LOG2", 34);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
 static const uint32_t SK_COUNT_ITEM_CHUNKS = 1024;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
@@ -772,7 +773,7 @@ static int sk_reset_pool1(sdt_ctx *c)
 	return SDT_OK;
 }
 
-static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
+static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 {
 	sdt_ctx::SkState &k = c->sk;
 	if (want_kmers > SK_BATCH_MAX_KMERS)
@@ -785,10 +786,14 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 	}
 	const int rw = sk_rec_words(c->nw);
 	const int w = c->K - sk_minimizer_len(c->K) + 1;
-	// records: a run is (w + 1) / 2 k-mers long on average; leave room for twice as many
-	uint64_t div = (uint64_t)(w + 1) / 4;
+	// records: a run is (w + 1) / 2 k-mers long on average (and never longer than a record or a read); room for 4/3 as many -- a record
+	// that finds no chunk takes the direct path (`pool_direct` in the pipeline statistics), nothing is lost
+	int run = (w + 1) / 2 < sk_max_run(c->K, c->nw) ? (w + 1) / 2 : sk_max_run(c->K, c->nw);
+	if ((uint64_t)run > per_read) run = (int)per_read;               // (a read is at least one record)
+	uint64_t div = (uint64_t)run * 3 / 4;
 	if (div < 2) div = 2;
-	if (div > 6) div = 6;
+	div = (uint64_t)env_int("SDT_SK_POOL_DIV", (int)div);
+	const int mem_pct = env_int("SDT_SK_POOL_MEM_PCT", 60);
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	uint64_t cap = want_kmers < (1ULL << 24) ? (1ULL << 24) : want_kmers;
@@ -802,7 +807,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers)
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;
 		// (a sharded context adds two send and two receive buffers of pool-1 size: shard_alloc)
 		const uint64_t all = c->comm.nranks > 1 ? bytes + chunks1 * SK_CAP1 * rw * 8 * 9 / 2 : bytes;
-		if (chunks2 >= (1ULL << SK_LIST2_FILL_SHIFT) || all > free_b / 2) {      // (a list2 entry has 27 bits for the chunk id)
+		if (chunks2 >= (1ULL << SK_LIST2_FILL_SHIFT) - 1 || all > free_b / 100 * (uint64_t)mem_pct) {      // (a list2 entry has 28 bits for the chunk id; all ones = no chunk)
 			k.cap_is_max = true;
 			if (cap <= (1ULL << 24))
 				return fail(SDT_ENOMEM, "super-k-mer pools: %llu MiB needed for the smallest batch, %zu MiB free",
@@ -1121,7 +1126,7 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		uint64_t want = k.pending_kmers + nreads * per_read;
 		if (!(c->flags & SDT_FLAG_PARTITION) && want < (1ULL << 31))
 			want = 1ULL << 31;
-		rc = sk_alloc(c, want);
+		rc = sk_alloc(c, want, per_read);
 	}
 	if (rc != SDT_OK)
 		return rc;
@@ -1131,7 +1136,7 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 			// a stream that keeps filling SMALL pools gets larger ones: fewer batches = fewer merges per distinct key.  Past 2^31
 			// k-mers they stay: replacing tens of GiB was seen to stall for seconds in hipFree / hipMalloc now and then.
 			if (rc == SDT_OK && !k.cap_is_max && k.cap_kmers < (1ULL << 31))
-				rc = sk_alloc(c, k.cap_kmers * 2);
+				rc = sk_alloc(c, k.cap_kmers * 2, per_read);
 			if (rc != SDT_OK)
 				return rc;
 		}
@@ -2886,7 +2891,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 		want = strtoull(getenv("SDT_SHARD_ROUND_KMERS"), nullptr, 10);
 	if (!k.ready || k.cap_kmers < want) {
 		if (k.ready && !k.cap_is_max) { HIPCHK(hipStreamSynchronize(c->stream)); sk_free(c); }
-		rc = sk_alloc(c, want);
+		rc = sk_alloc(c, want, per_read);
 		if (rc != SDT_OK) return rc;
 	}
 	rc = shard_alloc(c);

@@ -53,7 +53,7 @@ constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one la
 #ifndef SDT_SK_L2_DEPTH
 #define SDT_SK_L2_DEPTH 2
 #endif
-constexpr int SK_LIST2_FILL_SHIFT = 27;           // list2 entry = chunk id (27 bits) | (records in use - 1) << 27
+constexpr int SK_LIST2_FILL_SHIFT = 28;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
 constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
 constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 
@@ -655,7 +655,11 @@ __device__ inline uint64_t sk_weighted_val(uint32_t w, uint32_t prev, uint32_t n
 
 constexpr uint32_t SK_CNT_MAX_SINCE = 65535;     // k-mers counted into the LDS table between two clears at most (16-bit fields)
 
-// (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU)
+// (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU.  8 waves per SIMD also
+// means 78 usable SCALAR registers -- 800 per SIMD in granules of 16, 16 of every wave's reserved -- and this kernel keeps
+// about ninety uniform values: the overflow lives in lanes of vector registers.  Raising the scalar budget by hand
+// (amdgpu_waves_per_eu(4, 8) + amdgpu_num_vgpr(32) + amdgpu_num_sgpr(96)) removed every spill and cost the second workgroup
+// per CU: 172 -> 251 ms per step on the 200 M-read workload.)
 template <int NW, bool TRACK>
 __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
@@ -681,7 +685,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	unsigned long long *s_key = (unsigned long long *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);     // NW x SLOTS, word-major
 	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
 	uint32_t *s_f = (uint32_t *)(s_ord + (TRACK ? SLOTS : 0));           // 5 x SLOTS
-	__shared__ uint32_t s_fill, s_item, s_spilled;
+	__shared__ uint32_t s_fillc[2], s_item, s_spilled;       // s_fillc: keys in the LDS table = the sum of two counters, see phase D
 	// statistics of the workgroup (claimed, failed, merges, spills, gens, k-mers, records, distinct records, their k-mers): in LDS, not
 	// in nine registers per lane that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
 	enum { ST_CLAIMED, ST_FAILED, ST_MERGES, ST_SPILLS, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
@@ -700,7 +704,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	if (tid < TAIL_PAD)
 		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
 	if (tid == 0)
-		s_fill = 0;
+		s_fillc[0] = s_fillc[1] = 0;
 	if (tid < ST_N)
 		s_stat[tid] = 0;
 	uint32_t *words = s_words + LDS_LEAD;
@@ -719,6 +723,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	uint64_t madd[PER], mord[TRACK ? PER : 1];       // (the slot of a key is hashed again when the flush is finished: two registers
 	bool have[PER];                                  //  per key less to carry across a tile)
 	EntSnap<NW, TRACK> sn[PER];
+	uint32_t ko = 0, km = 0;                         // (uniform) the two key counters as of the last barrier: the one that stands still in the coming round; the one the round adds to (bit 31: which)
+	uint32_t room_shift = NW == 1 ? 2u : 1u;          // (uniform) a round of phase D takes 1, 2 or 4 k-mers per free slot of the LDS table
 	bool flush_open = false;                         // (uniform) the registers above hold a flush whose merges are still to do
 	bool stores_pending = false;                     // (uniform) plain stores of an owned flush may still be in flight
 	auto flush_finish = [&]() {
@@ -904,8 +910,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			}
 			__syncthreads();
 			SK_TICK(1);
-			// ---- D: rounds of 4 k-mers per free slot: barriers are what this loop pays for, and even error-rich data brings fewer
-			// than one new key per four occurrences (a k-mer that does find the table full takes the direct path)
+			// ---- D: rounds of up to 4 k-mers per free slot: barriers are what this loop pays for (a k-mer that does find the table
+			// full takes the direct path)
 			const bool last_tile = cb + CPT >= c1;
 			tile_no++;
 			if (flush_open)
@@ -951,7 +957,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #pragma unroll                                                 //  scheduler the snapshots were spilled, i.e. waited for one by one)
 						for (int p = 0; p < PER; p++)
 							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
-								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
 						__builtin_amdgcn_sched_barrier(0);
 						flush_open = true;
 						if (!(SDT_SK_DEFER_FLUSH && NW == 1 && qb >= total && (SDT_SK_DEFER_FLUSH == 1 || (SDT_SK_DEFER_FLUSH == 2 && !last_tile) || (SDT_SK_DEFER_FLUSH == 3 && last_tile))))      // (wider keys: a deferred flush lost nodes in one golden case -- not understood, not used)
@@ -991,16 +997,26 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					}
 					__syncthreads();
 					if (tid == 0) {
-						s_fill = 0;
+						s_fillc[0] = s_fillc[1] = 0;
 						if (!(last_tile && qb >= total)) s_stat[ST_GENS]++;
 					}
 					__syncthreads();
+					ko = 0;
+					km &= 0x80000000u;
 					since = tile_kmers;                  // (what is left of this tile is at most the tile)
 					SK_TICK(3);
 				}
 				if (qb >= total)
 					break;
-				const uint32_t room = 4u * (MAXFILL - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill));                        // s_fill < FLUSH_AT here (uniform: read after a barrier)
+				// The number of keys in the table decides how long a round is and when to flush, so every wave must see the SAME number:
+				// a wave that read one live counter a little late -- after a faster wave had claimed the next round's first slots --
+				// would take another branch than its workgroup and meet it at the wrong barrier (seen as hangs and lost k-mers once
+				// merges ran between the barrier and the read).  Hence two counters: round r adds to counter r & 1 only, so the
+				// other one stands still for the whole round and can be read at leisure; ko / km are the values all waves agree on.
+				const uint32_t fill0 = ko + (km & 0x7FFFFFFFu);  // < FLUSH_AT here
+				const uint32_t room = (MAXFILL - fill0) << room_shift;
+				uint32_t *const fillc = &s_fillc[km >> 31];
+				const uint32_t maxfill = MAXFILL - ko;
 				const uint32_t qe = qb + room < total ? qb + room : total;
 				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
 					uint32_t ci = s_idx[q >> 4];             // the record of k-mer q & ~15; q's own is at most a few records on
@@ -1014,7 +1030,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					const int len = hp + nr + K - 1 + sk_hdr_next(hr);
 					uint32_t prev, next;
 					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-					const int s = sk_lds_locate<NW, SLOTS>(s_key, &s_fill, key, MAXFILL);
+					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill);
 					if (s >= 0) {
 						sk_lds_update(s_f, s, prev, next, wgt);
 						if (TRACK) {
@@ -1034,8 +1050,21 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					}
 				}
 				__syncthreads();
+				const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)*fillc);     // (nobody adds to it before the round after next)
+				const uint32_t fill1 = cur + ko;
+				km = ko | (~km & 0x80000000u);               // the next round adds to the other counter
+				ko = cur;
+				// k-mers per free slot in a round follow the data: a round that used more than half of the free slots halves them (the
+				// next one might have run out: its k-mers would take the direct path and cost the item its plain merges), a full
+				// round that used less than an eighth doubles them
+				if (NW > 1) {                                // (1-word keys, K <= 31: 4 per slot has always been enough, and the bookkeeping costs 5 %)
+					if ((fill1 - fill0) * 2u > MAXFILL - fill0)
+						room_shift = room_shift ? room_shift - 1u : 0u;
+					else if (qe - qb == room && (fill1 - fill0) * 8u < MAXFILL - fill0 && room_shift < 2u)
+						room_shift++;
+				}
 				qb = qe;
-				want_flush = (qb >= total && last_tile) || (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fill) >= FLUSH_AT;     // the item is done: the table must be clear for the next one
+				want_flush = (qb >= total && last_tile) || fill1 >= FLUSH_AT;     // the item is done: the table must be clear for the next one
 			}
 			SK_TICK(2);
 		}
