@@ -146,7 +146,7 @@ template <int RW> __device__ inline void sk_load_record(const uint64_t *src, uin
 // -- suffix minima of the block of W hashes behind, a running prefix minimum of the block ahead, min of the two --
 // with both blocks in registers (W is a template parameter so that every index is static).  ~3 compares per window
 // instead of a shuffle tree, every hash computed once, all 64 lanes on their own read.  Runs are noted in a
-// per-lane LDS list (bucket << 14 | n - 1 << 8 | first k-mer) and cut out of the tile when the read is done.
+// per-lane LDS list (bucket << 6 | n - 1; the runs of a read follow one another) and cut out of the tile when the read is done.
 constexpr int SK_SEQ_TILE = 256;                 // reads per tile = lanes per workgroup
 constexpr int SK_SEQ_RUNCAP = 24;                // runs per read the list holds (more: emitted on the spot -- K=31 on 250 bp does that
                                                  //  for most reads and is still 3x the strip kernel: 50 -> 17 ms per 6.6 G k-mers)
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(SK_SEQ_TILE, NW == 1 ? 4 : 2) void k_sk_scatter_rea
 					                                         //  ncap in the read: reads that cover the same stretch then cut the same
 					                                         //  records out of it, and k_sk_count's dedupe folds them into one)
 					if (nrun < SK_SEQ_RUNCAP)
-						runs[nrun] = (fb0 << 14) | ((uint32_t)(j - j0 - 1) << 8) | (uint32_t)j0;
+						runs[nrun] = (fb0 << 6) | (uint32_t)(j - j0 - 1);
 					else
 						sk_emit_run<NW>(words, rb_r, len_r, nk_r, K, read_ord, j0, j - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
 					nrun++;
@@ -313,17 +313,18 @@ __global__ __launch_bounds__(SK_SEQ_TILE, NW == 1 ? 4 : 2) void k_sk_scatter_rea
 			}
 			// the last run of the read
 			if (nrun < SK_SEQ_RUNCAP)
-				runs[nrun] = (fb0 << 14) | ((uint32_t)(nk_r - j0 - 1) << 8) | (uint32_t)j0;
+				runs[nrun] = (fb0 << 6) | (uint32_t)(nk_r - j0 - 1);
 			else
 				sk_emit_run<NW>(words, rb_r, len_r, nk_r, K, read_ord, j0, nk_r - j0, fb0, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
 			nrun++;
 		}
 		SK_TICK(1);
 		const int nlist = nrun < SK_SEQ_RUNCAP ? nrun : SK_SEQ_RUNCAP;
-		for (int k = 0; k < nlist; k++) {
+		for (int k = 0, jr = 0; k < nlist; k++) {        // (the listed runs are the read's first ones, back to back from k-mer 0)
 			const uint32_t e = runs[k];
-			sk_emit_run<NW>(words, rb_r, len_r, nk_r, K, read_ord, (int)(e & 255u), (int)((e >> 8) & 63u) + 1, e >> 14, s_cur, &s_blk, pool,
-			               s_cnt, tbl, claimed, failed, done, emitted);
+			const int nr = (int)(e & 63u) + 1;
+			sk_emit_run<NW>(words, rb_r, len_r, nk_r, K, read_ord, jr, nr, e >> 6, s_cur, &s_blk, pool, s_cnt, tbl, claimed, failed, done, emitted);
+			jr += nr;
 		}
 		__syncthreads();                             // the tile buffers are reused
 		SK_TICK(3);

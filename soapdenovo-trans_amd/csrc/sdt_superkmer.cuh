@@ -36,7 +36,11 @@
 namespace sdt {
 
 constexpr int SK_L1BITS = 8;
-constexpr int SK_L2BITS = 10;
+#ifndef SDT_SK_L2BITS
+#define SDT_SK_L2BITS 10
+#endif
+constexpr int SK_L2BITS = SDT_SK_L2BITS;
+constexpr int SK_POSBITS = 22 - SK_L2BITS;          // header: level-2 bucket and position share 22 bits
 constexpr int SK_NB1 = 1 << SK_L1BITS;
 constexpr int SK_NB2 = 1 << SK_L2BITS;
 constexpr int SK_NBF = SK_NB1 * SK_NB2;          // final buckets
@@ -57,7 +61,7 @@ template <int NW> struct SkFmt {
 	static constexpr int CAP_BASES = 32 * BW;
 };
 constexpr uint64_t SK_MAX_READ_ORDINAL = 1ULL << 34;             // reads of one run the header can number
-constexpr int SK_MAX_READ_LEN = 4095;                            // positions the header can hold
+constexpr int SK_MAX_READ_LEN = (1 << SK_POSBITS) - 1;                            // positions the header can hold
 
 __host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 3 : (nw == 2 ? 5 : 7); }
 
@@ -132,16 +136,17 @@ __host__ __device__ inline uint64_t sk_stream_word(const uint32_t *words, int p)
 
 __host__ __device__ inline uint64_t sk_header(uint64_t read_ord, uint32_t pos, uint32_t l2, int n, int has_prev, int has_next)
 {
-	return (read_ord << 30) | ((uint64_t)(pos & 0xFFFu) << 18) | ((uint64_t)(l2 & 0x3FFu) << 8) | ((uint64_t)(n - 1) << 2) |
+	return (read_ord << 30) | ((uint64_t)(pos & (uint32_t)SK_MAX_READ_LEN) << (8 + SK_L2BITS)) | ((uint64_t)(l2 & (uint32_t)(SK_NB2 - 1)) << 8) | ((uint64_t)(n - 1) << 2) |
 	       ((uint64_t)has_prev << 1) | (uint64_t)has_next;
 }
 __host__ __device__ inline int sk_hdr_n(uint64_t h) { return (int)((h >> 2) & 63u) + 1; }
 __host__ __device__ inline int sk_hdr_prev(uint64_t h) { return (int)((h >> 1) & 1u); }
 __host__ __device__ inline int sk_hdr_next(uint64_t h) { return (int)(h & 1u); }
-__host__ __device__ inline uint32_t sk_hdr_l2(uint64_t h) { return (uint32_t)((h >> 8) & 0x3FFu); }
-__host__ __device__ inline uint32_t sk_hdr_pos(uint64_t h) { return (uint32_t)((h >> 18) & 0xFFFu); }
+__host__ __device__ inline uint32_t sk_hdr_l2(uint64_t h) { return (uint32_t)((h >> 8) & (uint32_t)(SK_NB2 - 1)); }
+__host__ __device__ inline uint32_t sk_hdr_pos(uint64_t h) { return (uint32_t)((h >> (8 + SK_L2BITS)) & (uint32_t)SK_MAX_READ_LEN); }
 __host__ __device__ inline uint64_t sk_hdr_read(uint64_t h) { return h >> 30; }
-static_assert(SK_L2BITS == 10, "the record header holds a 10-bit level-2 bucket");
+static_assert(SK_L2BITS >= 10 && SK_L2BITS <= 12, "the record header holds a 10..12-bit level-2 bucket");
+constexpr uint32_t SK_HDR_KIND_MASK = (1u << (8 + SK_L2BITS)) - 1u;     // bucket, n, context flags: what identical records share besides their bases
 
 // device state of the pipeline (all device pointers)
 struct SkPool {

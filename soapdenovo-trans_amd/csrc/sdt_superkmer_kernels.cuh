@@ -19,6 +19,9 @@
 #ifndef SDT_SK_DEFER_FLUSH
 #define SDT_SK_DEFER_FLUSH 0       // EXPERIMENT, off: an owned flush at a tile boundary issues its loads and is finished before the NEXT tile's phase D (1 = always, 2 = within an item only, 3 = across items only); hangs at >= 5 M reads, see profiles/r3/README.md
 #endif
+#ifndef SDT_SK_SEQ_FLUSH
+#define SDT_SK_SEQ_FLUSH 1         // multi-word keys: owned merges one slot at a time (registers)
+#endif
 #ifndef SDT_SK_CNT_TPB
 #define SDT_SK_CNT_TPB 1024
 #endif
@@ -833,7 +836,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			bool distinct = false;
 			if (n) {
 				distinct = true;
-				uint32_t x = (uint32_t)h0 & 0x3FFFFu;
+				uint32_t x = (uint32_t)h0 & SK_HDR_KIND_MASK;
 #pragma unroll
 				for (int i = 0; i < BW; i++) {
 					x = __builtin_rotateleft32(x, 5) ^ (uint32_t)nx[1 + i];
@@ -846,7 +849,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					if (cur == REP_EMPTY)
 						break;                           // this record represents its kind
 					// identical records: same bases, and the same low 18 header bits (bucket, n, context flags)
-					bool same = (((uint32_t)s_h0[cur] ^ (uint32_t)h0) & 0x3FFFFu) == 0;
+					bool same = (((uint32_t)s_h0[cur] ^ (uint32_t)h0) & SK_HDR_KIND_MASK) == 0;
 #pragma unroll
 					for (int i = 0; i < BW; i++)
 						same = same && (((uint64_t)words[cur * BW * 2 + 2 * i] << 32) | words[cur * BW * 2 + 2 * i + 1]) == nx[1 + i];
@@ -933,7 +936,43 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 						__syncthreads();
 						stores_pending = false;
 					}
-					if (owned) {
+					if (owned && NW > 1 && SDT_SK_SEQ_FLUSH) {
+						// multi-word keys: one slot at a time -- two keys, two snapshots and two addresses in flight did not fit the 64
+						// registers, and a spilled snapshot is a load that is waited for at once (see the 1-word path below)
+#pragma unroll 1
+						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+							if (s_key[i] == KEY_EMPTY)
+								continue;
+							Key<NW> key;
+							key.w[0] = s_key[i];
+#pragma unroll
+							for (int wv = 1; wv < NW; wv++)
+								key.w[wv] = s_key[wv * SLOTS + i];
+							const uint64_t add = sk_lds_val(&s_f[5 * i]);
+							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
+							s_key[i] = KEY_EMPTY;
+#pragma unroll
+							for (int f = 0; f < 5; f++)
+								s_f[5 * i + f] = 0;
+							if (TRACK) s_ord[i] = ORD_NONE;
+							const uint64_t slot = key_hash<NW>(key) & tbl.mask;
+							merges++;
+							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, false), add, 0u, claimed, ord))
+								failed++;
+						}
+#pragma unroll
+						for (int d = 32; d > 0; d >>= 1) {
+							claimed += __shfl_down(claimed, d);
+							failed += __shfl_down(failed, d);
+							merges += __shfl_down(merges, d);
+						}
+						if ((tid & 63) == 0) {
+							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+						}
+						stores_pending = true;
+					} else if (owned) {
 						// this lane's PER slots: everything out of LDS, all global loads issued, then (now or a tile later) the merges
 #pragma unroll
 						for (int p = 0; p < PER; p++) {
