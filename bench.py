@@ -251,21 +251,34 @@ def main():
     torch.cuda.synchronize()
     log(f"workload: {n_local} reads x {L} bp on rank 0 ({nwords * 4 / 1e9:.2f} GB packed), generated in {time.time() - t0:.1f} s")
 
-    # Table size from the data, not from the answer: count the nodes of the first c and the first 2c reads of this rank (two small
-    # passes outside the timed region) and extend the last slope to all reads -- new true k-mers dry up as coverage grows, new
-    # erroneous ones keep coming at a constant rate, so the straight line is an upper bound that is tight once the sample covers
-    # the transcriptome (200 M x 150 bp: estimate vs 0.68 G measured in config.distinct_nodes / est_distinct).
+    # Table size from the data, not from the answer: count the nodes of up to four doubling prefixes of this rank's reads (small
+    # passes outside the timed region) and extrapolate (config.distinct_nodes against config.est_distinct_per_rank shows how well).
     def estimate_distinct():
         c = min(max(n_local // 64, 1 << 18), 1 << 21, n_local // 2)
         if c < 1024:
             return n_local * (L - K + 1)
+        # distinct k-mers follow a power law of the reads seen (Heaps: the transcripts saturate, the error k-mers keep coming,
+        # and under deep coverage even those repeat): fit the exponent on doubling prefixes, let it drift on as it did between
+        # the last two pairs, extrapolate.  (A straight line through the last two points said 1.2 G for the 678 M of the
+        # 200 M-read workload; the table then has four times the slots its scans need.)
+        import math
+        sizes = [c]
+        while len(sizes) < 4 and sizes[-1] * 4 <= n_local:
+            sizes.append(sizes[-1] * 2)
+        if len(sizes) < 2:
+            sizes.append(2 * c)
         got = []
-        for m in (c, 2 * c):
+        for m in sizes:
             with pkg.PregraphGPU(K, est_distinct=1 << 24, device=dev.index or 0) as ge_:
                 ge_.count_reads_device(words, nwords, offsets, m, L)
-                got.append(ge_.finish_count()[1])
-        slope = max(got[1] - got[0], 0) / c
-        return int(got[1] + slope * (n_local - 2 * c))
+                got.append(max(ge_.finish_count()[1], 1))
+        bs = [math.log2(got[i + 1] / got[i]) for i in range(len(got) - 1)]
+        more = math.log2(n_local / sizes[-1])
+        drift = max(bs[-1] - bs[-2], 0.0) if len(bs) > 1 else 0.0
+        b = min(bs[-1] + drift * (more + 1) / 2, 1.0)
+        est_ = int(got[-1] * 2 ** (b * more))
+        log(f"distinct k-mers of the first {sizes} reads: {got}; exponents {[round(x, 3) for x in bs]} -> {b:.3f}: {est_} expected")
+        return est_
     est = args.est_distinct or estimate_distinct() + (1 << 20)
     base_flags = {"auto": 0, "direct": pkg.SDT_FLAG_DIRECT, "superkmer": pkg.SDT_FLAG_PARTITION}[args.pipeline]
     flags = base_flags | (pkg.SDT_FLAG_TRACK_FIRST if args.track_first else 0)

@@ -20,7 +20,7 @@
 #define SDT_SK_DEFER_FLUSH 0       // EXPERIMENT, off: an owned flush at a tile boundary issues its loads and is finished before the NEXT tile's phase D (1 = always, 2 = within an item only, 3 = across items only); hangs at >= 5 M reads, see profiles/r3/README.md
 #endif
 #ifndef SDT_SK_SEQ_FLUSH
-#define SDT_SK_SEQ_FLUSH 1         // multi-word keys: owned merges one slot at a time (registers)
+#define SDT_SK_SEQ_FLUSH 1         // multi-word keys, ordinals: owned merges one slot at a time (registers)
 #endif
 #ifndef SDT_SK_CNT_TPB
 #define SDT_SK_CNT_TPB 1024
@@ -936,8 +936,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 						__syncthreads();
 						stores_pending = false;
 					}
-					if (owned && NW > 1 && SDT_SK_SEQ_FLUSH) {
-						// multi-word keys: one slot at a time -- two keys, two snapshots and two addresses in flight did not fit the 64
+					if (owned && (NW > 1 || TRACK) && SDT_SK_SEQ_FLUSH) {
+						// multi-word keys, keys with ordinals: one slot at a time -- two keys, two snapshots and two addresses in flight did not fit the 64
 						// registers, and a spilled snapshot is a load that is waited for at once (see the 1-word path below)
 #pragma unroll 1
 						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {

@@ -345,7 +345,7 @@ __device__ inline void ord_min_noret(uint64_t *p, uint64_t ord)
 	(void)__hip_atomic_fetch_min(p, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int NW, bool FIRST> struct EntSnap { uint64_t k[NW]; uint64_t v; bool won; };
+template <int NW, bool FIRST> struct EntSnap { uint64_t k[NW]; uint64_t v; uint64_t f; bool won; };      // f: the slot's first-occurrence ordinal (FIRST only)
 
 // `claim` (1-word keys): the key is probably new -- its slot claim, a compare-and-swap on the key word, travels TOGETHER with
 // the loads instead of after them (the CAS returns the key word either way; on a slot that holds a key it changes nothing).
@@ -364,6 +364,7 @@ template <int NW, bool FIRST> __device__ inline EntSnap<NW, FIRST> ent_load(cons
 			sn.k[i] = ld_relaxed(&e->key[i]);
 	}
 	sn.v = ld_relaxed(&e->val);
+	sn.f = FIRST ? ld_relaxed(t.first + slot) : ORD_NONE;      // (the only writer of a key needs no atomic min: load, compare, store)
 	return sn;
 }
 
@@ -381,7 +382,7 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 			if (hi)
 				__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (FIRST && ord != ORD_NONE)
-				ord_min_noret(t.first + slot, ord);
+				__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return true;
 		}
 		bool same = true;
@@ -404,8 +405,8 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 				const uint32_t a = __hip_atomic_load(t.aux + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(t.aux + slot, a + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (FIRST && ord != ORD_NONE)
-				ord_min_noret(t.first + slot, ord);
+			if (FIRST && ord < sn.f)
+				__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return true;
 		}
 		if (sn.k[0] == KEY_EMPTY) {
@@ -425,7 +426,7 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 				if (hi)
 					__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (FIRST && ord != ORD_NONE)
-					ord_min_noret(t.first + slot, ord);
+					__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				return true;
 			}
 			// somebody else's key (or its KEY_LOCKED) got there first: not ours
