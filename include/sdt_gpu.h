@@ -82,8 +82,8 @@ int sdt_gpu_reset(sdt_ctx *ctx);
 int sdt_gpu_push_reads(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords,
                        const uint64_t *offsets, uint64_t nreads);
 
-/* The same without the wait: the call returns as soon as the copies and kernels are enqueued (a ring of 4 device staging
- * buffers; the host blocks only when the ring is full of batches whose kernels have not run yet).  The caller's buffers must
+/* The same without the wait: the call returns as soon as the copies and kernels are enqueued (a ring of 48 device staging
+ * buffers, up to 32 batches staged ahead of their kernels; the host blocks only when the ring is full).  The caller's buffers must
  * stay untouched until sdt_gpu_push_wait(ctx, *ticket) has returned -- a host that parses into a ring of its own waits for
  * the ticket of the buffer it is about to refill, not for every push (prlHashReads.c:493-620 double-buffers the same way:
  * one buffer is parsed while the threads work on the other).  Pinned host memory keeps the copy asynchronous.

@@ -445,6 +445,7 @@ struct sdt_ctx {
 		bool flushing = false;
 		// statistics of the last flush (sdt_gpu_pipeline_stats)
 		uint64_t st_records = 0, st_chunks1 = 0, st_chunks2 = 0, st_flushes = 0;
+		uint32_t stream_flushes = 0;   // flushes since the last reset (sk_batch_limit)
 		uint64_t l2_in_total = 0;      // k-mers that entered the count stage (sum of the level-2 bucket sizes): Stats.sk_counted must match
 		bool exchanged = false;        // records left for / came from other ranks: Stats.sk_emitted is not this rank's input
 	} sk;
@@ -709,6 +710,7 @@ static int env_int(const char *name, int dflt) { const char *v = getenv(name); r
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << env_int("SDT_SK_BATCH_LOG2", 34);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
+static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
 static const uint32_t SK_COUNT_ITEM_CHUNKS = 1024;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
@@ -724,9 +726,11 @@ static void sk_free(sdt_ctx *c)
 		if (p) (void)hipHostFree(p);
 	const uint64_t in_total = k.l2_in_total;         // (the conservation totals belong to the run, not to the pools)
 	const bool exchanged = k.exchanged;
+	const uint32_t stream_flushes = k.stream_flushes;
 	k = sdt_ctx::SkState();
 	k.l2_in_total = in_total;
 	k.exchanged = exchanged;
+	k.stream_flushes = stream_flushes;
 }
 
 // LDS bytes of the level-1 scatter for a maximum read length
@@ -941,6 +945,7 @@ static int sk_count_all(sdt_ctx *c)
 	SK_CHK(hipStreamSynchronize(c->stream));
 	k.st_chunks2 = k.h_off2[SK_NBF];
 	k.st_flushes++;
+	k.stream_flushes++;
 	k.l2_in_total += k.h_kpre2[SK_NBF];
 	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
 	// k-mers (every one might be a new node: ensure_room)
@@ -954,6 +959,8 @@ static int sk_count_all(sdt_ctx *c)
 	std::vector<uint32_t> first_item;                // first item of every launch
 	std::vector<uint64_t> launch_kmers;
 	uint64_t acc = 0;
+	bool pack_open = false;
+	uint32_t pack_c0 = 0;
 	first_item.push_back(0);
 	for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
 		const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
@@ -962,12 +969,29 @@ static int sk_count_all(sdt_ctx *c)
 			launch_kmers.push_back(acc);
 			first_item.push_back(nci);
 			acc = 0;
+			pack_open = false;                           // (an item belongs to one launch)
 		}
 		acc += km;
-		const uint32_t whole = k.h_off2[f + 1] - k.h_off2[f] <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
+		const uint32_t nch = k.h_off2[f + 1] - k.h_off2[f];
+		// small buckets (early, short batches of a stream; sparse minimizers) share an item with their neighbours: their chunks
+		// lie next to each other in the list, the item is still the only writer of all its keys, and the workgroup pays its
+		// per-item costs (item fetch, barriers, a flush of a nearly empty table) once per SK_COUNT_PACK_CHUNKS chunks
+		if (nch <= SK_COUNT_PACK_CHUNKS && pack_open && k.h_off2[f + 1] - pack_c0 <= SK_COUNT_PACK_CHUNKS) {
+			if (nch)
+				k.h_citems[nci - 1] = make_uint2(pack_c0, k.h_off2[f + 1] | 0x80000000u);
+			continue;
+		}
+		pack_open = false;
+		if (!nch)
+			continue;
+		const uint32_t whole = nch <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
 		for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
 			const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
 			k.h_citems[nci++] = make_uint2(c0, c1 | whole);    // top bit: the item is its bucket
+		}
+		if (nch <= SK_COUNT_PACK_CHUNKS) {               // the next small buckets may join this item
+			pack_open = true;
+			pack_c0 = k.h_off2[f];
 		}
 	}
 	launch_kmers.push_back(acc);
@@ -1112,6 +1136,22 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 	return SDT_OK;
 }
 
+// k-mers a batch may hold before it is flushed: the pools' capacity -- except for the first batches of a stream whose length
+// the caller has announced (sdt_gpu_hint_total_kmers): 1/16 of the job, then 1/8, 1/4 ... .  The kernels need about twice the
+// time of the copies, so a batch's copies hide behind the counting of the batches before it as long as it is at most about
+// twice their size; one large batch after a small first one left the GPU waiting for 9 GB of copies (measured: 66 instead
+// of 68 G k-mers/s from host memory), equal quarters of the job merge more often than they must.
+static uint64_t sk_batch_limit(const sdt_ctx *c)
+{
+	const sdt_ctx::SkState &k = c->sk;
+	if (c->expect_kmers && c->expect_kmers / 16 >= (1ULL << 27) && k.stream_flushes < 4) {
+		const uint64_t lim = (c->expect_kmers / 16) << k.stream_flushes;
+		if (lim < k.cap_kmers)
+			return lim;
+	}
+	return k.cap_kmers;
+}
+
 // chop + scatter a device-resident batch into the level-1 buckets (flushing whenever the pools are full)
 static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint64_t nreads, uint64_t max_read_len)
 {
@@ -1126,12 +1166,17 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		uint64_t want = k.pending_kmers + nreads * per_read;
 		if (!(c->flags & SDT_FLAG_PARTITION) && want < (1ULL << 31))
 			want = 1ULL << 31;
+		// a caller that streams its reads in and has said how much is coming (sdt_gpu_hint_total_kmers): pools for the whole job
+		// (sk_alloc caps them) -- the kernels, not the link, are the limit, so the copies only have to be hidden at the START
+		// (sk_batch_limit cuts the first batch short), and fewer, larger batches merge less (quarters of the job measured 3 % slower)
+		if (c->expect_kmers > want)
+			want = c->expect_kmers;
 		rc = sk_alloc(c, want, per_read);
 	}
 	if (rc != SDT_OK)
 		return rc;
 	for (uint64_t r0 = 0; r0 < nreads;) {
-		if (k.pending_kmers + per_read * SK_TILE_READS > k.cap_kmers) {
+		if (k.pending_kmers + per_read * SK_TILE_READS > sk_batch_limit(c)) {
 			rc = sk_flush(c);
 			// a stream that keeps filling SMALL pools gets larger ones: fewer batches = fewer merges per distinct key.  Past 2^31
 			// k-mers they stay: replacing tens of GiB was seen to stall for seconds in hipFree / hipMalloc now and then.
@@ -1140,7 +1185,7 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 			if (rc != SDT_OK)
 				return rc;
 		}
-		uint64_t nr = (k.cap_kmers - k.pending_kmers) / per_read / SK_TILE_READS * SK_TILE_READS;
+		uint64_t nr = (sk_batch_limit(c) - k.pending_kmers) / per_read / SK_TILE_READS * SK_TILE_READS;
 		if (nr > nreads - r0) nr = nreads - r0;
 		rc = sk_scatter_launch(c, d_words, d_offs + r0, nr, max_read_len, c->ord_base + r0 * c->ord_stride);
 		if (rc != SDT_OK)
@@ -1513,6 +1558,7 @@ int sdt_gpu_reset(sdt_ctx *c)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
 	c->sk.l2_in_total = 0;
+	c->sk.stream_flushes = 0;
 	c->sk.exchanged = false;
 	c->distinct_known = 0;
 	c->kmers_known = 0;
@@ -1749,7 +1795,7 @@ static bool launch_would_flush(const sdt_ctx *c, const sdt_ctx::Staged &b)
 	if (!k.ready || (c->flags & SDT_FLAG_DIRECT) || b.maxlen < (uint64_t)c->K + 1)
 		return false;
 	const uint64_t per_read = b.maxlen - c->K + 1;
-	return k.pending_kmers + (b.nreads + SK_TILE_READS) * per_read > k.cap_kmers;
+	return k.pending_kmers + (b.nreads + SK_TILE_READS) * per_read > sk_batch_limit(c);
 }
 
 // launch the kernels of queued batches, oldest first; a launch that would flush waits for STAGE_AHEAD queued copies unless

@@ -364,7 +364,7 @@ template <int NW, bool FIRST> __device__ inline EntSnap<NW, FIRST> ent_load(cons
 			sn.k[i] = ld_relaxed(&e->key[i]);
 	}
 	sn.v = ld_relaxed(&e->val);
-	sn.f = FIRST ? ld_relaxed(t.first + slot) : ORD_NONE;      // (the only writer of a key needs no atomic min: load, compare, store)
+	sn.f = ORD_NONE;                                 // (read on demand: see table_merge_owned_at)
 	return sn;
 }
 
@@ -405,7 +405,9 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 				const uint32_t a = __hip_atomic_load(t.aux + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(t.aux + slot, a + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (FIRST && ord < sn.f)
+			// the only writer of a key needs no atomic min: load, compare, store -- and the load only for a key that was there
+			// already (a third of the merges claim a new slot: they store without ever fetching the ordinal's line)
+			if (FIRST && ord != ORD_NONE && ord < ld_relaxed(t.first + slot))
 				__hip_atomic_store(t.first + slot, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return true;
 		}
