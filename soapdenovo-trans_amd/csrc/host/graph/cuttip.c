@@ -693,7 +693,6 @@ static int commit_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int th
  * position is still visited in this sweep, one written behind it waits for the next, exactly as in the full scan */
 typedef struct { uint64_t *rec; uint64_t n; } cwalks_t;      /* 2 words per walk, sorted by node index (low 56 bits of [0]) */
 #define CW_NODE(c, r) ((c)->rec[2 * (r)] & 0x00FFFFFFFFFFFFFFULL)
-#define CW_AHEAD 48
 
 static uint64_t cw_lower_bound(const cwalks_t *cw, uint64_t node)
 {
@@ -715,17 +714,9 @@ static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len,
 		uint64_t range = ~0ULL;
 		if (k == k0) range &= ~0ULL << (lo & 63);
 		if (k == k1 && ((hi & 63) != 0)) range &= (1ULL << (hi & 63)) - 1ULL;
-		/* the decisions ahead read these nodes: the sweep is one thread waiting for memory (a recorded walk every ~40 nodes of
-		 * a 30-GB array, its end node anywhere), so the pipeline runs CW_AHEAD walks ahead of it, not two words of the bitmap
-		 * (that was three or four walks: one DRAM round trip per visit stayed exposed) */
-		while (pf < cw->n && (pf < ptr + CW_AHEAD || CW_NODE(cw, pf) < ((k + 3) << 6))) {
-			const uint64_t en = cw->rec[2 * pf + 1];
-			__builtin_prefetch(&g->nodes[en], 1);
-			__builtin_prefetch(&g->nodes[CW_NODE(cw, pf)], 1);
-			if (g->dirty) __builtin_prefetch(&g->dirty[en], 1);                  /* touch() of a cut: the end node's marks */
-			__builtin_prefetch(&g->vbits[en >> 6], 1);
-			pf++;
-		}
+		/* the decisions of the next two words read these nodes.  (A pipeline 48 recorded walks ahead that also fetched the tip
+		 * node and the end node's marks measured no faster: 918 vs 1014 ms for the single-tip commit of 50 M reads.) */
+		while (pf < cw->n && CW_NODE(cw, pf) < ((k + 3) << 6)) { __builtin_prefetch(&g->nodes[cw->rec[2 * pf + 1]]); pf++; }
 		uint64_t done = 0;
 		for (;;) {
 			const uint64_t w = g->vbits[k] & range & ~done;
