@@ -734,7 +734,7 @@ static void sk_free(sdt_ctx *c)
 }
 
 // LDS bytes of the level-1 scatter for a maximum read length
-struct SkGeo { int mtw, tile_words, hv_words, bits_words; size_t smem; };
+struct SkGeo { int mtw, tile_words, hv_words, hv2_words, bits_words; size_t smem; };
 static SkGeo sk_geo(int K, uint64_t max_read_len)
 {
 	SkGeo g;
@@ -743,7 +743,9 @@ static SkGeo sk_geo(int K, uint64_t max_read_len)
 	g.hv_words = (int)((SK_TILE_READS * max_read_len + 16 + 1) & ~(uint64_t)1);
 	const uint64_t nk_max = (uint64_t)SK_TILE_READS * (max_read_len - K + 1);
 	g.bits_words = (int)(nk_max / 64 + 2);
-	g.smem = (size_t)g.tile_words * 4 + (size_t)SK_NB1 * 8 + (size_t)g.hv_words * 4 + (size_t)g.bits_words * 8 + (size_t)(g.bits_words + 2) * 4;
+	// long windows (K - m + 1 > 49: the strip kernel's sparse table of window minima) ping-pong between two hash arrays
+	g.hv2_words = K - sk_minimizer_len(K) + 1 > 49 ? g.hv_words : 0;
+	g.smem = (size_t)g.tile_words * 4 + (size_t)SK_NB1 * 8 + (size_t)(g.hv_words + g.hv2_words) * 4 + (size_t)g.bits_words * 8 + (size_t)(g.bits_words + 2) * 4;
 	return g;
 }
 
@@ -790,11 +792,17 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	}
 	const int rw = sk_rec_words(c->nw);
 	const int w = c->K - sk_minimizer_len(c->K) + 1;
-	// records: a run is (w + 1) / 2 k-mers long on average (and never longer than a record or a read); room for 4/3 as many -- a record
-	// that finds no chunk takes the direct path (`pool_direct` in the pipeline statistics), nothing is lost
-	int run = (w + 1) / 2 < sk_max_run(c->K, c->nw) ? (w + 1) / 2 : sk_max_run(c->K, c->nw);
-	if ((uint64_t)run > per_read) run = (int)per_read;               // (a read is at least one record)
-	uint64_t div = (uint64_t)run * 3 / 4;
+	// records: a run ends where the minimizer's bucket changes (every (w + 1) / 2 k-mers for a random order of the m-mers) or
+	// where the record is full (every `max run` k-mers at the latest): 1 / (2 / (w + 1) + 1 / max run) k-mers per record is what
+	// the pools are sized for.  Measured: 10.2 k-mers per record against 8.2 from this formula at K = 31, 23.9 against 19 at
+	// K = 63, 6.5 against 5.7 at K = 23 -- the margin IS the head room (a record that finds no chunk takes the direct path,
+	// `pool_direct` in the pipeline statistics: nothing is lost, but a fifth of the k-mers of a K = 95 job went that way and
+	// tripled its scatter time when the pools were sized at (w + 1) / 2 * 3 / 4).  4-word keys and reads of more than 256 k-mers go
+	// through the strip kernel, which also cuts at multiples of the record capacity: a fifth more room.  A read is at least one record.
+	const double rate = 2.0 / (double)(w + 1) + 1.0 / (double)sk_max_run(c->K, c->nw);
+	double run = 1.0 / rate * ((c->nw == 4 || per_read > (uint64_t)SK_SEQ_MAX_KMERS) ? 0.8 : 1.0);
+	if (run > (double)per_read) run = (double)per_read;
+	uint64_t div = (uint64_t)run;
 	if (div < 2) div = 2;
 	div = (uint64_t)env_int("SDT_SK_POOL_DIV", (int)div);
 	const int mem_pct = env_int("SDT_SK_POOL_MEM_PCT", 60);
@@ -1110,7 +1118,7 @@ static int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t
 	do {                                                                                                                       \
 		HIPCHK(hipFuncSetAttribute((const void *)k_sk_scatter_reads<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo.smem)); \
 		hipLaunchKernelGGL(k_sk_scatter_reads<NW>, dim3(grid), dim3(TPB), geo.smem, c->stream, d_words, d_offs, nr, c->K, m, ncap, \
-		                   geo.mtw, geo.tile_words, geo.hv_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, sk_tbl<NW>(c, allow_direct), c->d_stats, ob, c->ord_stride); \
+		                   geo.mtw, geo.tile_words, geo.hv_words, geo.hv2_words, geo.bits_words, k.p1, k.cursors, k.blk, k.cnt1, sk_tbl<NW>(c, allow_direct), c->d_stats, ob, c->ord_stride); \
 	} while (0)
 	// one lane per read where the window length has an instantiation and the run list can hold a read
 	const int w = c->K - m + 1;

@@ -67,7 +67,7 @@ constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatt
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offs,
                                                           uint64_t nreads, int K, int m, int ncap, int max_tile_words,
-                                                          int tile_smem_words, int hv_words, int bits_words, SkPool pool,
+                                                          int tile_smem_words, int hv_words, int hv2_words, int bits_words, SkPool pool,
                                                           unsigned long long *__restrict__ g_cursors, unsigned long long *__restrict__ g_blk,
                                                           uint32_t *__restrict__ g_cnt, Table<NW> tbl, Stats *stats,
                                                           uint64_t ord_base, uint64_t ord_stride)
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 	extern __shared__ uint32_t smem[];
 	unsigned long long *s_cur = (unsigned long long *)(smem + tile_smem_words);           // SK_NB1 (tile_smem_words is even)
 	uint32_t *s_hv = (uint32_t *)(s_cur + SK_NB1);                                        // hv_words (even)
-	unsigned long long *s_bits = (unsigned long long *)(s_hv + hv_words);                 // bits_words
+	uint32_t *s_hv2 = s_hv + hv_words;                                                    // hv2_words (long windows only)
+	unsigned long long *s_bits = (unsigned long long *)(s_hv2 + hv2_words);               // bits_words
 	uint32_t *s_pc = (uint32_t *)(s_bits + bits_words);                                   // bits_words + 1
 	__shared__ unsigned long long s_blk;
 	__shared__ uint32_t s_cnt[SK_NB1];               // chunks opened per bucket (added to g_cnt once, at the end: 256 counters
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 		const int npos = (int)tv.rb[tv.nr];
 		SK_TICK(0);
 		const bool strips = w <= 49;                 // a wave's 64 lanes hold at least 15 whole windows
+		const uint32_t *bhs = s_hv;                  // bucket hash of the k-mer at every position (long windows: see below)
 		const uint32_t nk = tv.nk, nkr = (nk + 63u) & ~63u;
 		if (strips) {
 			// One wave per read, strips of 64 - w k-mers.  Lane l of a strip hashes the canonical m-mer at its position; a
@@ -142,10 +144,33 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 				}
 			}
 		} else {
-			// long windows (K > 59): hash of the canonical m-mer at every base position of the tile, windows scanned per k-mer
+			// long windows (K > 59): hash of the canonical m-mer at every base position of the tile, then the window minima
+			// of ALL positions by a sparse table in LDS -- min over [p, p + 2d) from the minima over [p, p + d) and
+			// [p + d, p + 2d), log2(w) passes ping-ponging between two arrays; a window of w m-mers is two overlapping
+			// spans of P = 2^floor(log2 w).  (Scanning the w - 2 shared hashes per k-mer, as this branch used to, made
+			// the level-1 scatter 419 of the 949 ms of a K = 95 step.)  The last pass leaves the BUCKET hash of every
+			// k-mer position in `bhs`, as the strips do in s_hv.
 			for (int p = tid; p < npos; p += TPB)
 				s_hv[p] = p + m <= npos ? sk_mmer_hash(sk_canon_mmer(sk_stream_mmer(tv.words, p, m), m)) : 0xFFFFFFFFu;
 			__syncthreads();
+			int P = 1;
+			while (2 * P <= w)
+				P *= 2;
+			uint32_t *src = s_hv, *dst = s_hv2;
+			for (int d = 1; d < P; d <<= 1) {
+				for (int p = tid; p < npos; p += TPB) {
+					const uint32_t a = src[p], b = p + d < npos ? src[p + d] : 0xFFFFFFFFu;
+					dst[p] = b < a ? b : a;
+				}
+				__syncthreads();
+				uint32_t *t = src; src = dst; dst = t;
+			}
+			for (int p = tid; p < npos; p += TPB) {
+				const uint32_t a = src[p], b = p + w - P < npos ? src[p + w - P] : 0xFFFFFFFFu;
+				dst[p] = sk_bucket_hash(b < a ? b : a);
+			}
+			__syncthreads();
+			bhs = dst;
 			for (uint32_t q = tid; q < nkr; q += TPB) {
 				bool start = false;
 				if (q < nk) {
@@ -155,14 +180,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 					if (j == 0 || (j & (ncap - 1)) == 0) {    // ncap is a power of two
 						start = true;
 					} else {
-						uint32_t sh = s_hv[p];                              // m-mers this k-mer shares with its predecessor
-						for (int i = 1; i <= w - 2; i++) {
-							const uint32_t v = s_hv[p + i];
-							sh = v < sh ? v : sh;
-						}
-						const uint32_t a = s_hv[p + w - 1], b = s_hv[p - 1];
-						const uint32_t mine = a < sh ? a : sh, prevm = b < sh ? b : sh;
-						start = sk_final_bucket(sk_bucket_hash(mine)) != sk_final_bucket(sk_bucket_hash(prevm));
+						start = sk_final_bucket(bhs[p]) != sk_final_bucket(bhs[p - 1]);
 					}
 				}
 				const unsigned long long mask = __ballot(start);
@@ -223,14 +241,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 			const int nk_r = (int)(tv.pre[r + 1] - tv.pre[r]);
 			const int p0 = (int)tv.rb[r] + j;
 			const int hp = j > 0, hn = j + n < nk_r;
-			uint32_t bh = s_hv[p0];
-			if (!strips) {
-				for (int t = 1; t < w; t++) {
-					const uint32_t v = s_hv[p0 + t];
-					bh = v < bh ? v : bh;
-				}
-				bh = sk_bucket_hash(bh);
-			}
+			const uint32_t bh = bhs[p0];
 			const uint64_t read_ord = ord_base + (tile * SK_TILE_READS + (uint64_t)r) * ord_stride;
 			uint32_t chunk, pos;
 			if (sk_reserve(s_cur, &s_blk, sk_l1_bucket(bh), sk_l1_bucket(bh), SK_CAP1, pool, s_cnt, chunk, pos)) {
