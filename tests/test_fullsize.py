@@ -5,7 +5,7 @@ bins: a checksum of checksums), the bins must add up to the nodes, the scan must
 first 3 000 reads of the very same device buffers bit for bit.
   C2: 50 M x 150 bp, K = 31 (1-word keys)      C4: 50 M x 250 bp, K = 63 (2-word keys, the 127mer build's layout)
   C3: 200 M x 150 bp, K = 31 -- the workload of the headline metric (as far as one GPU goes: the 8-GPU exchange is hardware)
-  C5: 400 M x 150 bp, K = 31, expression skew sigma = 2.5, -d 1
+  C5: 400 M x 150 bp, K = 31, expression skew sigma = 2.5, -d 1        K95: 30 M x 250 bp, K = 95 (4-word keys, the strip scatter)
 and the multi-rank PRODUCT path (sdt_gpu_count_reads_sharded behind bench.py --gpus N) at C2 size with 2 and 4 ranks sharing
 the box's one GPU over the shared-memory transport, sub-rounds forced: every reported number and the checksum of all 257
 kmerFreq bins must be the single rank's."""
@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,n,L,K,est,sigma", [("C2", 50_000_000, 150, 31, 300_000_000, 2.0), ("C4", 50_000_000, 250, 63, 750_000_000, 2.0),
-                                                  ("C3", 200_000_000, 150, 31, 700_000_000, 2.0), ("C5", 400_000_000, 150, 31, 800_000_000, 2.5)])
+                                                  ("C3", 200_000_000, 150, 31, 700_000_000, 2.0), ("C5", 400_000_000, 150, 31, 800_000_000, 2.5),
+                                                  ("K95", 30_000_000, 250, 95, 700_000_000, 2.0)])
 def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est, sigma):
     import torch
     dev = torch.device("cuda:0")
@@ -39,6 +40,10 @@ def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est, sigma):
             assert int(hist1.sum()) == nodes and 0 < removed < nodes
             seen[mode] = (kmers, nodes, removed, linear0, linear1, hist0.tolist(), hist1.tolist())
             if mode == pkg.SDT_FLAG_PARTITION:
+                # the pools are sized by a model of the record rate, not for the worst case: at these sizes every record must
+                # still have found a chunk (the direct path is correct but an order of magnitude slower: a pool sized for
+                # K = 31 sent a fifth of a K = 95 job that way in round 3 and nothing but a timing showed it)
+                assert g.stage_times()[1]["pool_direct"] == 0, f"{name}: records overflowed the pools into the direct path"
                 # the oracle on a slice of the same device buffers
                 sub = 3000
                 hw = words[: (sub * L + 15) // 16 + 1].cpu().numpy().view(np.uint32)
