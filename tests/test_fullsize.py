@@ -88,3 +88,48 @@ def test_product_path_multi_rank_at_c2_size(pkg, ranks):
         assert a["config"][k] == b["config"][k], k
     assert sum(b["per_rank_kmers_counted"]) == a["config"]["kmers"] and len(b["per_rank_kmers_counted"]) == ranks
     assert b["skew_max_over_mean"] < 1.6                 # ranges are cut by weight; a giant minimizer cannot be split
+
+
+@pytest.mark.parametrize("K,L,track", [(31, 150, False), (31, 150, True), (63, 250, False)])
+def test_announced_stream_in_short_batches_equals_one_count(pkg, synth, K, L, track):
+    """an announced stream (sdt_gpu_hint_total_kmers) is cut into batches of 1/16, 1/8, 1/4 ... of the job so that counting starts
+    under the copies, and the small buckets of such batches share work items: 4 M reads pushed from host memory with a hint of 2^31
+    k-mers (cuts at 2^27, 2^28 ... k-mers) must leave the table of ONE count of the same reads resident on the device -- k-mers,
+    nodes, -d 1 removals, linear nodes, all 257 bins, and with ordinals a checksum of every node's first occurrence"""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 4_000_000
+    words, offsets, nwords = synth.torch_workload(n, L, T=5000, device=dev, seed=7, sigma=2.0)
+    torch.cuda.synchronize()
+    flags = pkg.SDT_FLAG_PARTITION | (pkg.SDT_FLAG_TRACK_FIRST if track else 0)
+
+    def summary(g):
+        kmers, nodes = g.finish_count()
+        h0, l0 = g.mark_and_hist()
+        first = None
+        if track:
+            keys, _, _, cnt, fo = g.export_nodes(with_first=True)
+            # order-free checksum over (key, count, first occurrence)
+            first = int(np.bitwise_xor.reduce((keys[:, -1] * np.uint64(0x9E3779B97F4A7C15) + fo.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+                                               + cnt.astype(np.uint64)).astype(np.uint64)))
+        removed = g.delow(1)
+        h1, l1 = g.mark_and_hist()
+        return kmers, nodes, removed, l0, l1, h0.tolist(), h1.tolist(), first
+
+    with pkg.PregraphGPU(K, est_distinct=300_000_000, flags=flags) as g:
+        g.count_reads_device(words, nwords, offsets, n, L)
+        want = summary(g)
+        assert want[0] == n * (L - K + 1)
+    batch = 1 << 17
+    assert (batch * L) % 16 == 0
+    hw = words[: (n * L + 15) // 16 + 4].cpu().numpy().view(np.uint32)
+    with pkg.PregraphGPU(K, est_distinct=300_000_000, flags=flags) as g:
+        g.hint_total_kmers(1 << 31)
+        for r0 in range(0, n, batch):
+            nr = min(batch, n - r0)
+            w0 = r0 * L // 16
+            g.push_reads_fixed_async(np.ascontiguousarray(hw[w0: w0 + (nr * L + 15) // 16 + 4]), nr, L)
+        got = summary(g)
+        assert g.stage_times()[1]["batches"] >= 3, "the hint must have cut the stream into several batches"
+    assert got == want
+
