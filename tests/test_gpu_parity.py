@@ -61,7 +61,10 @@ def test_golden_case_kmerfreq_bit_identical(pkg, name, mode):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("K,L,ragged", [(13, 60, True), (23, 100, False), (23, 150, True), (31, 150, True), (31, 158, False), (31, 250, True), (21, 250, True), (33, 150, True),
-                                        (63, 250, False), (65, 200, True), (127, 250, True)])
+                                        (63, 250, False), (65, 200, True), (127, 250, True),
+                                        # reads of more than 256 k-mers leave the one-lane-per-read scatter for the strip kernel: its strips
+                                        # (window <= 49 m-mers) with 1-word keys, its sparse table of window minima (longer windows) with 2- and 4-word keys
+                                        (31, 330, True), (63, 400, True), (95, 420, False)])
 def test_node_table_equals_oracle(pkg, synth, K, L, ragged, mode):
     """every node: key, 8 saturating link counters, count, single/linear/deleted flags"""
     tx = synth.make_transcriptome(25, seed=K)
