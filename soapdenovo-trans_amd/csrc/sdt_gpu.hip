@@ -813,7 +813,9 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	const uint32_t wgs = (uint32_t)c->cu_count * 6;
 	for (;; cap /= 2) {
 		const uint64_t recs = cap / div;
-		const uint64_t chunks1 = recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
+		// (SDT_SK_POOL_CHUNKS1: test hook -- a level-1 pool of that many chunks, so that small inputs overflow it: tests/test_gpu_parity.py,
+		// tests/test_sharded.py)
+		const uint64_t chunks1 = env_int("SDT_SK_POOL_CHUNKS1", 0) > 0 ? (uint64_t)env_int("SDT_SK_POOL_CHUNKS1", 0) : recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
 		const uint64_t items = chunks1 / SK_ITEM_CHUNKS + SK_NB1 + 1;
 		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw * 8 + (chunks1 + chunks2) * 8;

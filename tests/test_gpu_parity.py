@@ -133,6 +133,29 @@ def test_seq_scatter_every_window(pkg, synth, K):
         assert node_dict_gpu(g) == node_dict_oracle(o)
 
 
+@pytest.mark.parametrize("K,L", [(31, 150), (63, 250), (95, 250)])
+def test_pool_overflow_takes_the_direct_path(pkg, synth, monkeypatch, K, L):
+    """the pools of the locality pipeline are sized by a model, never for the worst case: a record that finds no chunk must go
+    through put_kmerset directly and change nothing but the speed.  A level-1 pool of 48 chunks (test hook) overflows at once:
+    most k-mers take the direct path, every node must still be the oracle's"""
+    monkeypatch.setenv("SDT_SK_POOL_CHUNKS1", "48")
+    tx = synth.make_transcriptome(20, seed=K + 3)
+    codes, offs = synth.sample_reads(*tx, n_reads=5000, read_len=L, seed=K + 4, err=0.003, ragged=True)
+    o = ob.Oracle(K, nsets=4)
+    o.add_reads(codes, offs)
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=MODES[-1] | pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        assert g.finish_count() == (o.kmers_in_reads(), o.node_count())
+        direct = g.stage_times()[1]["pool_direct"]
+        assert 0 < direct <= o.kmers_in_reads() and direct > o.kmers_in_reads() // 2
+        hist, linear = g.mark_and_hist()
+        ohist, olinear = o.mark()
+        assert linear == olinear and (hist == ohist).all()
+        assert node_dict_gpu(g) == node_dict_oracle(o)
+        _, _, _, _, first = g.export_nodes(with_first=True)
+        assert sorted(first.tolist()) == sorted(o.export_first().tolist())
+
+
 def test_hot_bucket_repeated(pkg, synth):
     """the hot-bucket input ten times through the locality pipeline: every lane of every workgroup appends to ONE
     level-2 cursor.  (A 1024-lane geometry of the level-2 scatter lost a chunk of 16 records in half of such runs;

@@ -146,6 +146,43 @@ def test_sharded_ranks_sharing_one_gpu(tmp_path, n, K, env):
     assert max(sizes) <= 1.6 * sum(sizes) / n, sizes
 
 
+def _overflow_worker(name, rank, n, K, nreads, L, q):
+    os.environ["SDT_SK_POOL_CHUNKS1"] = "48"
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from soapdenovo_trans_amd import synth
+    tx = synth.make_transcriptome(30, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=nreads, read_len=L, seed=K + 1, err=0.003)
+    lo, hi = rank * nreads // n, (rank + 1) * nreads // n
+    try:
+        with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+            g.comm_init_shm(name, rank, n)
+            g.set_read_ordinal(lo, 1)
+            c = codes[int(offs[lo]):int(offs[hi])]
+            g.push_reads_sharded(synth.pack_2bit(c), offs[lo:hi + 1] - offs[lo])
+            g.finish_count()
+        q.put((rank, "no error"))
+    except pkg.SdtError as e:
+        q.put((rank, int(e.code)))
+
+
+@pytest.mark.gpu
+def test_sharded_pool_overflow_is_an_error_not_a_local_insert(pkg):
+    """a rank whose level-1 pool overflows must NOT fall back on its local table (the key may belong to another rank: the same
+    k-mer would become a node twice): with a pool of 48 chunks (test hook) every rank reports SDT_EFULL"""
+    n, K, nreads, L = 2, 31, 6000, 120
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "o" + uuid.uuid4().hex[:12]
+    ps = [ctx.Process(target=_overflow_worker, args=(name, r, n, K, nreads, L, q)) for r in range(n)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(r, pkg.SDT_EFULL) for r in range(n)], res
+
+
 @pytest.mark.gpu
 def test_rccl_single_rank_control_plane(pkg, synth):
     """one rank: librccl is loaded, a communicator made, the control-plane collectives run through ncclAllGather"""
