@@ -174,6 +174,19 @@ int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *rang
                    uint32_t *subrounds, uint32_t *send_begin, uint32_t *send_count, uint32_t *send_at, uint32_t *recv_count,
                    uint32_t *recv_at);
 
+/* The work items and launches of the count stage as a pure host function of the level-2 chunk lists (csrc/sdt_count_plan.h; no
+ * device): what the library computes between the level-2 scatter and k_sk_count, callable so that it can be tested on a CPU.
+ *   off2[f], kpre2[f]   first chunk / first k-mer of final bucket f in the chunk list (f = nbuckets: the totals)
+ *   items               2 words per work item: the run [c0, c1) of the list, top bit of c1 = the item holds whole buckets only
+ *                       (its workgroup is the only writer of their keys: merges without atomics).  Buckets of <= 64 chunks share an
+ *                       item with their neighbours, buckets of > 1024 chunks are cut into pieces.
+ *   first_item[l], launch_kmers[l]   first item and k-mers of launch l (first_item[*nlaunches] = *nitems); a launch is cut
+ *                       between buckets at `limit` k-mers (`first_limit` for the first).
+ * Stands where the reference hands a batch of k-mers to its threads (prlHashReads.c:312-336, sendWorkSignal). */
+int sdt_sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uint32_t nbuckets, uint64_t first_limit, uint64_t limit,
+                            uint32_t max_launches, uint32_t *items, uint32_t items_cap, uint32_t *first_item, uint64_t *launch_kmers,
+                            uint32_t launches_cap, uint32_t *nitems, uint32_t *nlaunches);
+
 /* ---- table scans ------------------------------------------------------------------------------ */
 
 /* deLowCov / thread_delow (prlHashReads.c:844-909), `-d d`: zero links with 0 < v <= d, mark nodes

@@ -43,6 +43,8 @@ _ABI = [
     ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_shard_cut_ranges", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
     ("sdt_shard_plan", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32] + [_c.c_void_p] * 6),
+    ("sdt_sk_plan_count_items", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint64, _c.c_uint64, _c.c_uint32, _c.c_void_p, _c.c_uint32,
+                                           _c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
     ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_mark_and_hist", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_nodes", _c.c_int,
@@ -431,6 +433,24 @@ def new_comm_id() -> bytes:
     if load_library().sdt_gpu_comm_id(buf) != SDT_OK:
         raise SdtError(SDT_EHIP, load_library().sdt_gpu_last_error().decode())
     return buf.raw
+
+
+def count_plan(off2, kpre2, first_limit, limit, max_launches=4096):
+    """the count stage's work items and launches for chunk lists off2 / kpre2 (csrc/sdt_count_plan.h): (items [n, 2], first_item, launch_kmers)"""
+    o = np.ascontiguousarray(off2, dtype=np.uint32)
+    kp = np.ascontiguousarray(kpre2, dtype=np.uint64)
+    nb = len(o) - 1
+    assert len(kp) == nb + 1
+    cap = nb + int(o[-1]) // 1024 + 2
+    items = np.zeros((cap, 2), dtype=np.uint32)
+    first = np.zeros(max_launches + 2, dtype=np.uint32)
+    lk = np.zeros(max_launches + 2, dtype=np.uint64)
+    ni, nl = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = load_library().sdt_sk_plan_count_items(o.ctypes.data, kp.ctypes.data, nb, first_limit, limit, max_launches, items.ctypes.data, cap,
+                                                first.ctypes.data, lk.ctypes.data, len(first), ctypes.addressof(ni), ctypes.addressof(nl))
+    if rc != 0:
+        raise SdtError(rc, load_library().sdt_gpu_last_error().decode())
+    return items[: ni.value].copy(), first[: nl.value + 1].copy(), lk[: nl.value].copy()
 
 
 def shard_cut_ranges(mat: np.ndarray, nranks: int) -> np.ndarray:

@@ -1,0 +1,78 @@
+// sdt_count_plan.h -- the work items and launches of the count stage as a PURE host function of the level-2 chunk lists.
+//
+// After the level-2 scatter the host knows, per final bucket f, where its chunks lie in the chunk list (off2[f] .. off2[f + 1])
+// and how many k-mers they hold (kpre2[f + 1] - kpre2[f]).  k_sk_count's workgroups take work items first come first served;
+// an item is a run [c0, c1) of the list:
+//   * a bucket of at most `item_chunks` chunks is one item, flagged WHOLE (top bit of c1): its workgroup is the only writer of
+//     the bucket's keys in the launch and may merge without atomics;
+//   * a larger bucket is cut into pieces of `item_chunks` chunks, not flagged;
+//   * buckets of at most `pack_chunks` chunks share an item with their neighbours (their chunks are adjacent in the list, empty
+//     buckets in between do not matter) as long as the item stays within `pack_chunks` chunks: per-item costs are paid once;
+//   * launches are cut between buckets: a launch holds at most `limit` k-mers (`first_limit` for the first one, whose rate of
+//     new nodes sizes the others) unless a single bucket is larger, and an item never spans two launches.
+// sk_count_all (sdt_gpu.hip) calls this; tests/test_count_plan.py checks it on the CPU through sdt_sk_plan_count_items.
+#pragma once
+#include <stdint.h>
+
+namespace sdt {
+
+constexpr uint32_t SK_ITEM_WHOLE = 0x80000000u;
+
+// items: 2 words per item (c0, c1 | SK_ITEM_WHOLE); first_item[l] = first item of launch l (first_item[*nlaunches] = *nitems);
+// launch_kmers[l] = its k-mers.  Returns false when an output array is too small.
+inline bool sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uint32_t nbuckets, uint64_t first_limit, uint64_t limit,
+                                uint32_t max_launches, uint32_t pack_chunks, uint32_t item_chunks, uint32_t *items, uint32_t items_cap,
+                                uint32_t *first_item, uint64_t *launch_kmers, uint32_t launches_cap, uint32_t *nitems, uint32_t *nlaunches)
+{
+	uint32_t nci = 0, nl = 0;
+	uint64_t acc = 0;
+	bool pack_open = false;
+	uint32_t pack_c0 = 0;
+	if (launches_cap < 1)
+		return false;
+	first_item[0] = 0;
+	for (uint32_t f = 0; f < nbuckets; f++) {
+		const uint64_t km = kpre2[f + 1] - kpre2[f];
+		const uint64_t lim = nl == 0 ? first_limit : limit;
+		if (acc && acc + km > lim && nl + 1 < max_launches) {
+			if (nl + 2 > launches_cap)
+				return false;
+			launch_kmers[nl++] = acc;
+			first_item[nl] = nci;
+			acc = 0;
+			pack_open = false;                           // (an item belongs to one launch)
+		}
+		acc += km;
+		const uint32_t nch = off2[f + 1] - off2[f];
+		if (nch <= pack_chunks && pack_open && off2[f + 1] - pack_c0 <= pack_chunks) {
+			if (nch)
+				items[2 * (nci - 1) + 1] = off2[f + 1] | SK_ITEM_WHOLE;
+			continue;
+		}
+		pack_open = false;
+		if (!nch)
+			continue;
+		const uint32_t whole = nch <= item_chunks ? SK_ITEM_WHOLE : 0u;
+		for (uint32_t c0 = off2[f]; c0 < off2[f + 1]; c0 += item_chunks) {
+			const uint32_t c1 = c0 + item_chunks < off2[f + 1] ? c0 + item_chunks : off2[f + 1];
+			if (nci >= items_cap)
+				return false;
+			items[2 * nci] = c0;
+			items[2 * nci + 1] = c1 | whole;
+			nci++;
+		}
+		if (nch <= pack_chunks) {                        // the next small buckets may join this item
+			pack_open = true;
+			pack_c0 = off2[f];
+		}
+	}
+	if (nl + 2 > launches_cap)
+		return false;
+	launch_kmers[nl++] = acc;
+	first_item[nl] = nci;
+	*nitems = nci;
+	*nlaunches = nl;
+	return true;
+}
+
+} // namespace sdt

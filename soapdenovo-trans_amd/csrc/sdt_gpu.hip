@@ -367,6 +367,7 @@ __global__ __launch_bounds__(TPB) void k_import(Table<NW> tbl, const uint64_t *_
 #include "sdt_superkmer_kernels.cuh"
 #include "sdt_comm.cuh"
 #include "sdt_shard_plan.h"
+#include "sdt_count_plan.h"
 static_assert(SHARD_NB1 == SK_NB1, "the exchange plan and the pipeline agree about the level-1 buckets");
 #include "sdt_map_kernels.cuh"
 #include "sdt_ctg_kernels.cuh"
@@ -966,46 +967,17 @@ static int sk_count_all(sdt_ctx *c)
 	// 2^33 k-mers, so: a first launch of at most 2^26 k-mers under that bound, then launches bounded by twice the rate of
 	// new nodes per occurrence seen so far (later data usually brings fewer new nodes, not more; should it bring more, the load
 	// factor suffers until the next look but the table cannot fill: see the 95 % rule below).
-	std::vector<uint32_t> first_item;                // first item of every launch
-	std::vector<uint64_t> launch_kmers;
-	uint64_t acc = 0;
-	bool pack_open = false;
-	uint32_t pack_c0 = 0;
-	first_item.push_back(0);
-	for (uint32_t f = 0; f < (uint32_t)SK_NBF; f++) {
-		const uint64_t km = k.h_kpre2[f + 1] - k.h_kpre2[f];
-		const uint64_t limit = (c->kmers_known == 0 && launch_kmers.empty()) ? (1ULL << 26) : SK_COUNT_KMERS;
-		if (acc && acc + km > limit && first_item.size() < SK_MAX_COUNT_LAUNCHES) {
-			launch_kmers.push_back(acc);
-			first_item.push_back(nci);
-			acc = 0;
-			pack_open = false;                           // (an item belongs to one launch)
-		}
-		acc += km;
-		const uint32_t nch = k.h_off2[f + 1] - k.h_off2[f];
-		// small buckets (early, short batches of a stream; sparse minimizers) share an item with their neighbours: their chunks
-		// lie next to each other in the list, the item is still the only writer of all its keys, and the workgroup pays its
-		// per-item costs (item fetch, barriers, a flush of a nearly empty table) once per SK_COUNT_PACK_CHUNKS chunks
-		if (nch <= SK_COUNT_PACK_CHUNKS && pack_open && k.h_off2[f + 1] - pack_c0 <= SK_COUNT_PACK_CHUNKS) {
-			if (nch)
-				k.h_citems[nci - 1] = make_uint2(pack_c0, k.h_off2[f + 1] | 0x80000000u);
-			continue;
-		}
-		pack_open = false;
-		if (!nch)
-			continue;
-		const uint32_t whole = nch <= SK_COUNT_ITEM_CHUNKS ? 0x80000000u : 0u;
-		for (uint32_t c0 = k.h_off2[f]; c0 < k.h_off2[f + 1]; c0 += SK_COUNT_ITEM_CHUNKS) {
-			const uint32_t c1 = c0 + SK_COUNT_ITEM_CHUNKS < k.h_off2[f + 1] ? c0 + SK_COUNT_ITEM_CHUNKS : k.h_off2[f + 1];
-			k.h_citems[nci++] = make_uint2(c0, c1 | whole);    // top bit: the item is its bucket
-		}
-		if (nch <= SK_COUNT_PACK_CHUNKS) {               // the next small buckets may join this item
-			pack_open = true;
-			pack_c0 = k.h_off2[f];
-		}
-	}
-	launch_kmers.push_back(acc);
-	first_item.push_back(nci);
+	// (the items and launches are a pure function of the chunk lists: sdt_count_plan.h, tested on the CPU)
+	std::vector<uint32_t> first_item(SK_MAX_COUNT_LAUNCHES + 2);   // first item of every launch
+	std::vector<uint64_t> launch_kmers(SK_MAX_COUNT_LAUNCHES + 2);
+	uint32_t nlaunches = 0;
+	static_assert(sizeof(uint2) == 2 * sizeof(uint32_t), "an item is two words");
+	if (!sk_plan_count_items(k.h_off2, (const uint64_t *)k.h_kpre2, (uint32_t)SK_NBF, c->kmers_known == 0 ? (1ULL << 26) : SK_COUNT_KMERS, SK_COUNT_KMERS,
+	                         SK_MAX_COUNT_LAUNCHES, SK_COUNT_PACK_CHUNKS, SK_COUNT_ITEM_CHUNKS, (uint32_t *)k.h_citems, k.citems_cap,
+	                         first_item.data(), launch_kmers.data(), (uint32_t)first_item.size(), &nci, &nlaunches))
+		return fail(SDT_ESTATE, "count stage: work item table overflow");
+	first_item.resize(nlaunches + 1);
+	launch_kmers.resize(nlaunches);
 	if (nci)
 		SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
 	for (size_t l = 0; l + 1 < first_item.size() && rc == SDT_OK; l++) {
@@ -2808,6 +2780,20 @@ int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *rang
 		send_begin[p] = r.send_begin[p]; send_count[p] = r.send_count[p]; send_at[p] = r.send_at[p];
 		recv_count[p] = r.recv_count[p]; recv_at[p] = r.recv_at[p];
 	}
+	return SDT_OK;
+}
+
+int sdt_sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uint32_t nbuckets, uint64_t first_limit, uint64_t limit,
+                            uint32_t max_launches, uint32_t *items, uint32_t items_cap, uint32_t *first_item, uint64_t *launch_kmers,
+                            uint32_t launches_cap, uint32_t *nitems, uint32_t *nlaunches)
+{
+	if (!off2 || !kpre2 || !items || !first_item || !launch_kmers || !nitems || !nlaunches)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (max_launches < 1 || limit == 0 || first_limit == 0)
+		return fail(SDT_EINVAL, "bad argument (at least one launch, limits of at least one k-mer)");
+	if (!sk_plan_count_items(off2, kpre2, nbuckets, first_limit, limit, max_launches, SK_COUNT_PACK_CHUNKS, SK_COUNT_ITEM_CHUNKS, items, items_cap,
+	                         first_item, launch_kmers, launches_cap, nitems, nlaunches))
+		return fail(SDT_ENOMEM, "output arrays too small");
 	return SDT_OK;
 }
 
