@@ -38,6 +38,9 @@ typedef struct { int would_write; uint64_t end; } dry_t;
 /* parallel commits (removeMinorOut by components): a thread only ever touches nodes of its own component, so the
  * per-node marks need no synchronisation; the shared list is replaced by one list per thread, merged afterwards */
 static __thread struct { uint64_t *v; size_t n, cap; int on; } tl_dirty;
+struct tip_comp;
+static __thread struct tip_comp *tl_comp;          /* the component of walks this thread is committing (tip passes) */
+static void comp_first_touch(struct tip_comp *C, uint64_t i);
 
 static inline void touch(graph_t *g, const gnode_t *n)
 {
@@ -50,6 +53,7 @@ static inline void touch(graph_t *g, const gnode_t *n)
 				tl_dirty.v = (uint64_t *)realloc(tl_dirty.v, tl_dirty.cap * sizeof(uint64_t));
 			}
 			tl_dirty.v[tl_dirty.n++] = i;
+			if (tl_comp) comp_first_touch(tl_comp, i);
 		}
 		return;
 	}
@@ -60,7 +64,6 @@ static inline void touch(graph_t *g, const gnode_t *n)
 			g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
 		}
 		g->dlist[g->dn++] = i;
-		if (g->vbits) g->vbits[i >> 6] |= 1ULL << (i & 63);
 	}
 	if (!g->touched || g->touched[i]) return;
 	g->touched[i] = 1;
@@ -441,7 +444,6 @@ static int commit_minor_out_by_components(graph_t *g, const uint64_t *ex, uint64
 				g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
 			}
 			g->dlist[g->dn++] = i;
-			if (g->vbits) g->vbits[i >> 6] |= 1ULL << (i & 63);
 		}
 		free(C.tl[t]);
 	}
@@ -451,20 +453,93 @@ static int commit_minor_out_by_components(graph_t *g, const uint64_t *ex, uint64
 	return 0;
 }
 
+/* ---- the device's labelled records (sdt_gpu_minor_out_dry): 10 words = node, 8 neighbours, component label; the junction
+ * records come sorted by (label, node), so a component is a run of records and its visits are in the reference's order ---- */
 static void mo_scatter_records(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
 	void **a = (void **)vc;
 	graph_t *g = (graph_t *)a[0];
 	const uint64_t *rec = (const uint64_t *)a[1];
-	uint8_t *writes = (uint8_t *)a[2];
-	const uint64_t nj = *(const uint64_t *)a[3];
 	for (uint64_t r = lo; r < hi; r++) {
-		const uint64_t i = rec[r * 9];
-		memcpy(&g->nb_pool[r * 8], &rec[r * 9 + 1], 8 * sizeof(uint64_t));
-		g->nb_slot[i] = (uint32_t)(r + 1);
-		if (r < nj) writes[i] = 1;
+		memcpy(&g->nb_pool[r * 8], &rec[r * 10 + 1], 8 * sizeof(uint64_t));
+		g->nb_slot[rec[r * 10]] = (uint32_t)(r + 1);
 	}
+}
+
+typedef struct {
+	graph_t *g;
+	const uint64_t *rec;
+	const uint64_t *cstart;
+	const uint32_t *corder;
+	double threshold;
+	volatile uint64_t off;
+	uint64_t **tl;
+	size_t *tln;
+	volatile int ntl;
+} ml_run_ctx;
+
+static void mo_run_labelled(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	ml_run_ctx *C = (ml_run_ctx *)vc;
+	uint64_t off = 0;
+	tl_dirty.on = 1;
+	tl_dirty.v = NULL;
+	tl_dirty.n = tl_dirty.cap = 0;
+	for (uint64_t k = lo; k < hi; k++) {
+		const uint64_t c = C->corder[k];
+		for (uint64_t r = C->cstart[c]; r < C->cstart[c + 1]; r++)
+			visit_minor_out(C->g, &C->g->nodes[C->rec[r * 10]], C->threshold, &off, NULL);
+	}
+	tl_dirty.on = 0;
+	const int slot = __sync_fetch_and_add(&C->ntl, 1);
+	C->tl[slot] = tl_dirty.v;
+	C->tln[slot] = tl_dirty.n;
+	__sync_fetch_and_add(&C->off, off);
+}
+
+static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t nj, double threshold, uint64_t *off)
+{
+	if (!nj) return;
+	uint64_t ncomp = 1;
+	for (uint64_t r = 1; r < nj; r++) ncomp += rec[r * 10 + 9] != rec[r * 10 - 1];
+	if (ncomp > 0xFFFFFFF0ULL) { printf("too many components of junctions\n"); exit(1); }
+	uint64_t *cstart = (uint64_t *)malloc((ncomp + 1) * sizeof(uint64_t));
+	ncomp = 0;
+	cstart[0] = 0;
+	for (uint64_t r = 1; r < nj; r++)
+		if (rec[r * 10 + 9] != rec[r * 10 - 1]) cstart[++ncomp] = r;
+	cstart[++ncomp] = nj;
+	uint32_t *corder = (uint32_t *)malloc((ncomp + 1) * sizeof(uint32_t));          /* largest first */
+	uint64_t bucket[66] = {0}, biggest = 0;
+	for (uint64_t c = 0; c < ncomp; c++) {
+		const uint64_t sz = cstart[c + 1] - cstart[c];
+		bucket[64 - __builtin_clzll(sz)]++;
+		if (sz > biggest) biggest = sz;
+	}
+	{
+		uint64_t acc = 0;
+		for (int b = 65; b >= 0; b--) { const uint64_t t = bucket[b]; bucket[b] = acc; acc += t; }
+	}
+	for (uint64_t c = 0; c < ncomp; c++) corder[bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++] = (uint32_t)c;
+	const uint64_t per = 16;
+	const uint64_t nchunks = (ncomp + per - 1) / per;
+	ml_run_ctx C = {g, rec, cstart, corder, threshold, 0, (uint64_t **)calloc(nchunks + 1, sizeof(uint64_t *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
+	par_for(0, ncomp, per, mo_run_labelled, &C);
+	for (int t = 0; t < C.ntl; t++) {
+		for (size_t k = 0; k < C.tln[t]; k++) {
+			if (g->dn == g->dcap) {
+				g->dcap = g->dcap ? g->dcap * 2 : 4096;
+				g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
+			}
+			g->dlist[g->dn++] = C.tl[t][k];
+		}
+		free(C.tl[t]);
+	}
+	if (getenv("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nj, (unsigned long long)ncomp, (unsigned long long)biggest);
+	free(C.tl); free(C.tln); free(cstart); free(corder);
+	*off += C.off;
 }
 
 uint64_t graph_remove_minor_out(graph_t *g, int dd)
@@ -473,9 +548,11 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
 	double t_sub = cut_now_ms();
-	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
 	if (g->dev_minor_out) {
-		/* junction dry run + neighbour look-ups answered by the device mirror of the graph (sdt_gpu_minor_out_dry) */
+		/* junction dry run + neighbour look-ups + components answered by the device mirror of the graph (sdt_gpu_minor_out_dry).
+		 * Only the junctions the dry run flagged are visited: links only disappear during the pass, so on any junction the live
+		 * largest count per side is <= the dry run's and every live ratio >= the dry run's -- a junction with nothing under the
+		 * threshold then has nothing under it now, whatever was written around it. */
 		uint64_t *rec = NULL, nj = 0, nr = 0;
 		if (g->dev_minor_out(g, threshold, &rec, &nj, &nr) != 0) {
 			printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
@@ -487,12 +564,21 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 		if (nr > 0xFFFFFFF0ULL) { printf("too many junction records\n"); exit(1); }
 		g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
 		g->nb_pool = (uint64_t *)malloc((nr + 1) * 8 * sizeof(uint64_t));
-		void *sa[4] = {g, rec, c.writes, &nj};
+		void *sa[2] = {g, rec};
 		par_for(0, nr, 4096, mo_scatter_records, sa);
-		free(rec);
-		c.cap = (uint32_t)nr;
 		SUBPHASE("scatter records");
-	} else {
+		commit_minor_out_labelled(g, rec, nj, threshold, &off);
+		SUBPHASE("ordered commit");
+		graph_free_later(g->nb_slot, g->nb_pool, rec, NULL);
+		g->nb_slot = NULL;
+		g->nb_pool = NULL;
+		printf("%llu kmers off\n", (unsigned long long)off);
+		mark_linear(g);
+		SUBPHASE("free + mark linear");
+		return off;
+	}
+	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
+	{
 	par_for(0, g->n, 16384, count_junctions, &c);
 	SUBPHASE("count junctions");
 	const uint64_t njunc = c.cursor;
@@ -688,63 +774,6 @@ static int commit_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int th
 	return clipped;
 }
 
-/* the same sweep driven by g->vbits (device-walk passes): only nodes with a recorded walk or written since the walks
- * were taken can do anything, and touch() adds the latter while the sweep runs -- a node written AHEAD of the sweep
- * position is still visited in this sweep, one written behind it waits for the next, exactly as in the full scan */
-typedef struct { uint64_t *rec; uint64_t n; } cwalks_t;      /* 2 words per walk, sorted by node index (low 56 bits of [0]) */
-#define CW_NODE(c, r) ((c)->rec[2 * (r)] & 0x00FFFFFFFFFFFFFFULL)
-
-static uint64_t cw_lower_bound(const cwalks_t *cw, uint64_t node)
-{
-	uint64_t lo = 0, hi = cw->n;
-	while (lo < hi) {
-		const uint64_t mid = (lo + hi) >> 1;
-		if (CW_NODE(cw, mid) < node) lo = mid + 1; else hi = mid;
-	}
-	return lo;
-}
-
-static int commit_tips_sparse(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thin, uint64_t *tips, const cwalks_t *cw)
-{
-	int clipped = 0;
-	if (hi <= lo) return 0;
-	const uint64_t k0 = lo >> 6, k1 = (hi - 1) >> 6;
-	uint64_t ptr = cw_lower_bound(cw, lo), pf = ptr;               /* next recorded walk at or after the sweep position */
-	for (uint64_t k = k0; k <= k1; k++) {
-		uint64_t range = ~0ULL;
-		if (k == k0) range &= ~0ULL << (lo & 63);
-		if (k == k1 && ((hi & 63) != 0)) range &= (1ULL << (hi & 63)) - 1ULL;
-		/* the decisions of the next two words read these nodes.  (A pipeline 48 recorded walks ahead that also fetched the tip
-		 * node and the end node's marks measured no faster: 918 vs 1014 ms for the single-tip commit of 50 M reads.) */
-		while (pf < cw->n && CW_NODE(cw, pf) < ((k + 3) << 6)) { __builtin_prefetch(&g->nodes[cw->rec[2 * pf + 1]]); pf++; }
-		uint64_t done = 0;
-		for (;;) {
-			const uint64_t w = g->vbits[k] & range & ~done;
-			if (!w) break;
-			const int b = __builtin_ctzll(w);
-			done |= (b == 63) ? ~0ULL : ((2ULL << b) - 1ULL);
-			const uint64_t i = (k << 6) + (uint64_t)b;
-			gnode_t *tip = &g->nodes[i];
-			while (ptr < cw->n && CW_NODE(cw, ptr) < i) ptr++;
-			if (g->dirty[i]) {
-				clipped += clip_tip(g, tip, cut_len, thin, tips);
-			} else if (ptr < cw->n && CW_NODE(cw, ptr) == i) {
-				const unsigned inf = (unsigned)(cw->rec[2 * ptr] >> 56);
-				walk_t wk;
-				wk.end = cw->rec[2 * ptr + 1];
-				wk.ch = (uint8_t)(inf & 3u);
-				wk.sm = (uint8_t)((inf >> 2) & 1u);
-				wk.thin_stop = (uint8_t)((inf >> 3) & 1u);
-				if (!wk.thin_stop && g->nodes[wk.end].linear)
-					clipped += clip_tip(g, tip, cut_len, thin, tips);
-				else
-					clipped += decide_tip(g, tip, &wk, thin, tips, 0);
-			}
-		}
-	}
-	return clipped;
-}
-
 /* One sweep over nodes [lo, hi) with the reference's semantics; returns the number of clips.
  * Dry run: every walk, in parallel, on the graph as the sweep finds it.  Commit, in order:
  *   - a node written since the dry run is visited for real (it may have become a dead end, or stopped being one);
@@ -769,86 +798,291 @@ static int sweep_tips(graph_t *g, uint64_t lo, uint64_t hi, int cut_len, int thi
 	return clipped;
 }
 
-/* The walks of ALL nodes from the device mirror of the graph (sdt_gpu_tip_walks), taken once per pass.  They stay
- * valid across the sweeps of the pass under the same three rules as above with "since the dry run" read as
- * "since the device answered" (g->dirty): chains are made of nodes that were linear then and nothing writes a
- * linear node in these passes (THIN turns a linear non-single node non-linear, but every THIN walk stops there
- * either way), so no host dry run is needed for any later sweep either. */
-static void cw_mark(void *vc, uint64_t lo, uint64_t hi, int tid)
+/* ---- tip passes on the walks of the device: commit by components ------------------------------------------------
+ * A visit of a dead end reads and writes its tip and the node its walk ends at; a cut there may turn the end node
+ * into a dead end of its own (it then walks on to ITS neighbours along chains of at most cut_len nodes) or make it
+ * linear (walks that stopped at it now run on to the next junction).  Whatever a pass does therefore stays inside
+ * one connected component of the graph whose vertices are the non-linear nodes and whose edges are the chains of
+ * linear nodes no longer than cut_len between them (removeSingleTips: the walks themselves are enough -- a single
+ * k-mer has at most one link per side, so an end node that is written never starts a THIN walk that was not recorded).
+ * The dry run labels every recorded walk with its component (union-find on the device) and returns the records sorted
+ * by (label, node): a component is a run of records, components run side by side, each one in the reference's order
+ * -- "set 0 until nothing changes, then set 1, ..." restricted to the component is exactly what the full sweeps do to
+ * it, because a sweep that clips nothing in a component leaves it untouched.
+ *
+ * Inside a component the sweep visits, ascending: the recorded walks (static), plus every node written during the pass
+ * (touch(): the first write makes it a member) -- one written AHEAD of the sweep position is still visited in this
+ * sweep (min-heap), one written behind it waits for the next sweep of its set, one in an earlier set is never
+ * visited again (the reference does not return to a finished set). */
+#define CW_NODE(rec, r) ((rec)[3 * (r)] & 0x00FFFFFFFFFFFFFFULL)
+typedef struct { uint64_t *v; size_t n, cap; } u64vec;
+static inline void vec_push(u64vec *a, uint64_t x)
+{
+	if (a->n == a->cap) {
+		a->cap = a->cap ? a->cap * 2 : 64;
+		a->v = (uint64_t *)realloc(a->v, a->cap * sizeof(uint64_t));
+	}
+	a->v[a->n++] = x;
+}
+
+typedef struct tip_comp {
+	graph_t *g;
+	const uint64_t *rec;       /* this component's walks: 3 words each, ascending node index */
+	uint64_t n;
+	uint64_t pos, lo, hi;      /* node being visited; range of the current sweep */
+	int sweeping;
+	u64vec heap;               /* written ahead of pos (this set or a later one): min-heap */
+	u64vec behind;             /* written behind pos inside [lo, hi) */
+	u64vec dyn;                /* written nodes of the current set that have been visited once, ascending */
+	u64vec vis;                /* popped from the heap during this sweep, ascending */
+} tip_comp;
+
+static void heap_push(u64vec *h, uint64_t x)
+{
+	vec_push(h, x);
+	size_t i = h->n - 1;
+	while (i) {
+		const size_t p = (i - 1) >> 1;
+		if (h->v[p] <= h->v[i]) break;
+		const uint64_t t = h->v[p]; h->v[p] = h->v[i]; h->v[i] = t;
+		i = p;
+	}
+}
+static uint64_t heap_pop(u64vec *h)
+{
+	const uint64_t top = h->v[0];
+	h->v[0] = h->v[--h->n];
+	size_t i = 0;
+	for (;;) {
+		size_t l = 2 * i + 1, r = l + 1, m = i;
+		if (l < h->n && h->v[l] < h->v[m]) m = l;
+		if (r < h->n && h->v[r] < h->v[m]) m = r;
+		if (m == i) break;
+		const uint64_t t = h->v[m]; h->v[m] = h->v[i]; h->v[i] = t;
+		i = m;
+	}
+	return top;
+}
+
+static int comp_is_static(const tip_comp *C, uint64_t node)
+{
+	uint64_t lo = 0, hi = C->n;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (CW_NODE(C->rec, mid) < node) lo = mid + 1; else hi = mid;
+	}
+	return lo < C->n && CW_NODE(C->rec, lo) == node;
+}
+
+/* touch() calls this the first time a node is written in the pass */
+static void comp_first_touch(tip_comp *C, uint64_t i)
+{
+	if (comp_is_static(C, i)) return;                     /* a recorded walk: visited anyway, live once it is dirty */
+	if (i > C->pos) heap_push(&C->heap, i);
+	else if (i < C->pos && i >= C->lo && C->sweeping) vec_push(&C->behind, i);
+}
+
+static int cmp_u64(const void *a, const void *b)
+{
+	const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+	return x < y ? -1 : x > y;
+}
+
+/* one sweep of [lo, hi) over the component; kc = first static record at or after lo */
+static int comp_sweep(tip_comp *C, uint64_t kc, int cut_len, int thin, uint64_t *tips)
+{
+	graph_t *g = C->g;
+	int clipped = 0;
+	size_t kd = 0;
+	C->sweeping = 1;
+	for (;;) {
+		const uint64_t a = kc < C->n && CW_NODE(C->rec, kc) < C->hi ? CW_NODE(C->rec, kc) : NO_NODE;
+		const uint64_t b = kd < C->dyn.n ? C->dyn.v[kd] : NO_NODE;
+		const uint64_t h = C->heap.n && C->heap.v[0] < C->hi ? C->heap.v[0] : NO_NODE;
+		uint64_t m = a < b ? a : b;
+		if (h < m) m = h;
+		if (m == NO_NODE) break;
+		C->pos = m;
+		gnode_t *tip = &g->nodes[m];
+		if (m == h) {
+			heap_pop(&C->heap);
+			vec_push(&C->vis, m);
+			clipped += clip_tip(g, tip, cut_len, thin, tips);
+		} else if (m == b) {
+			kd++;
+			clipped += clip_tip(g, tip, cut_len, thin, tips);
+		} else {
+			if (kc + 4 < C->n) __builtin_prefetch(&g->nodes[C->rec[3 * (kc + 4) + 1]]);       /* the decision reads the end node */
+			if (g->dirty[m]) {
+				clipped += clip_tip(g, tip, cut_len, thin, tips);
+			} else {
+				const unsigned inf = (unsigned)(C->rec[3 * kc] >> 56);
+				walk_t wk;
+				wk.end = C->rec[3 * kc + 1];
+				wk.ch = (uint8_t)(inf & 3u);
+				wk.sm = (uint8_t)((inf >> 2) & 1u);
+				wk.thin_stop = (uint8_t)((inf >> 3) & 1u);
+				if (!wk.thin_stop && g->nodes[wk.end].linear)
+					clipped += clip_tip(g, tip, cut_len, thin, tips);            /* the end node has become linear: the walk runs on */
+				else
+					clipped += decide_tip(g, tip, &wk, thin, tips, 0);
+			}
+			kc++;
+		}
+	}
+	C->sweeping = 0;
+	/* the written nodes of this range, for the next sweep of it: dyn + vis (both ascending) + behind */
+	if (C->vis.n || C->behind.n) {
+		for (size_t k = 0; k < C->vis.n; k++) vec_push(&C->dyn, C->vis.v[k]);
+		for (size_t k = 0; k < C->behind.n; k++) vec_push(&C->dyn, C->behind.v[k]);
+		qsort(C->dyn.v, C->dyn.n, sizeof(uint64_t), cmp_u64);
+		C->vis.n = C->behind.n = 0;
+	}
+	return clipped;
+}
+
+typedef struct {
+	graph_t *g;
+	const uint64_t *rec;
+	const uint64_t *cstart;
+	const uint32_t *corder;
+	uint64_t ncomp;
+	int thin, cut_len;
+	volatile uint64_t tips;
+	uint64_t **tl;
+	size_t *tln;
+	volatile int ntl;
+} tc_ctx;
+
+static void tc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
-	void **a = (void **)vc;
-	const cwalks_t *cw = (const cwalks_t *)a[0];
-	uint64_t *vbits = (uint64_t *)a[1];
-	for (uint64_t r = lo; r < hi; r++) {
-		const uint64_t i = CW_NODE(cw, r);
-		__sync_fetch_and_or(&vbits[i >> 6], 1ULL << (i & 63));
-	}
-}
-
-/* LSD radix sort of the 2-word records by node index */
-static void cw_sort(cwalks_t *cw)
-{
-	const uint64_t n = cw->n;
-	if (n < 2) return;
-	uint64_t *tmp = (uint64_t *)malloc(2 * n * sizeof(uint64_t));
-	uint64_t all_or = 0, all_and = ~0ULL;
-	for (uint64_t r = 0; r < n; r++) { const uint64_t k = CW_NODE(cw, r); all_or |= k; all_and &= k; }
-	const uint64_t varying = all_or ^ all_and;
-	uint64_t *src = cw->rec, *dst = tmp;
-	for (int shift = 0; shift < 56; shift += 8) {
-		if (!((varying >> shift) & 0xFF)) continue;
-		uint64_t cnt[257] = {0};
-		for (uint64_t r = 0; r < n; r++) cnt[((src[2 * r] >> shift) & 0xFF) + 1]++;
-		for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
-		for (uint64_t r = 0; r < n; r++) {
-			const uint64_t d = cnt[(src[2 * r] >> shift) & 0xFF]++;
-			dst[2 * d] = src[2 * r];
-			dst[2 * d + 1] = src[2 * r + 1];
+	tc_ctx *T = (tc_ctx *)vc;
+	graph_t *g = T->g;
+	uint64_t tips = 0;
+	tip_comp C;
+	memset(&C, 0, sizeof C);
+	C.g = g;
+	tl_dirty.on = 1;
+	tl_dirty.v = NULL;
+	tl_dirty.n = tl_dirty.cap = 0;
+	tl_comp = &C;
+	for (uint64_t k = lo; k < hi; k++) {
+		const uint64_t c = T->corder[k];
+		C.rec = T->rec + 3 * T->cstart[c];
+		C.n = T->cstart[c + 1] - T->cstart[c];
+		C.heap.n = C.behind.n = C.dyn.n = C.vis.n = 0;
+		if (T->thin) {                                         /* removeSingleTips: one sweep over everything */
+			C.lo = 0; C.hi = g->n; C.pos = 0;
+			comp_sweep(&C, 0, T->cut_len, 1, &tips);
+			continue;
 		}
-		uint64_t *t = src; src = dst; dst = t;
+		uint64_t kc = 0;
+		int s = 0;
+		while (s < g->p) {
+			/* the next set this component has anything in */
+			const uint64_t a = kc < C.n ? CW_NODE(C.rec, kc) : NO_NODE;
+			const uint64_t h = C.heap.n ? C.heap.v[0] : NO_NODE;
+			const uint64_t m = a < h ? a : h;
+			if (m == NO_NODE) break;
+			while (g->set_start[s + 1] <= m) s++;
+			C.lo = g->set_start[s]; C.hi = g->set_start[s + 1];
+			C.dyn.n = 0;
+			int changed = 1;
+			while (changed) {                                  /* fixed point per set before the next set (:385-408) */
+				C.pos = C.lo;
+				changed = comp_sweep(&C, kc, T->cut_len, 0, &tips);
+			}
+			while (kc < C.n && CW_NODE(C.rec, kc) < C.hi) kc++;
+			s++;
+		}
 	}
-	if (src != cw->rec) memcpy(cw->rec, src, 2 * n * sizeof(uint64_t));
-	free(tmp);
+	tl_comp = NULL;
+	tl_dirty.on = 0;
+	free(C.heap.v); free(C.behind.v); free(C.dyn.v); free(C.vis.v);
+	const int slot = __sync_fetch_and_add(&T->ntl, 1);
+	T->tl[slot] = tl_dirty.v;
+	T->tln[slot] = tl_dirty.n;
+	__sync_fetch_and_add(&T->tips, tips);
 }
 
-static void device_walks(graph_t *g, int thin, int cut_len, cwalks_t *cw)
+/* the walks of every dead end from the device mirror of the graph, labelled and sorted by (component, node) */
+static void device_walks(graph_t *g, int thin, int cut_len, uint64_t **rec, uint64_t *nrec)
 {
-	free(cw->rec);
-	cw->rec = NULL;
-	cw->n = 0;
-	if (g->dev_walks(g, thin, cut_len, &cw->rec, &cw->n) != 0) {
+	*rec = NULL;
+	*nrec = 0;
+	if (g->dev_walks(g, thin, cut_len, rec, nrec) != 0) {
 		printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
 		exit(1);
 	}
 	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the mirror is current as of now */
 	g->dn = 0;
-	cw_sort(cw);
-	if (!g->vbits) g->vbits = (uint64_t *)malloc(((g->n >> 6) + 2) * sizeof(uint64_t));
-	memset(g->vbits, 0, ((g->n >> 6) + 2) * sizeof(uint64_t));
-	void *a[2] = {cw, g->vbits};
-	par_for(0, cw->n, 1 << 14, cw_mark, a);
+}
+
+static uint64_t commit_tips_by_components(graph_t *g, const uint64_t *rec, uint64_t nrec, int thin, int cut_len)
+{
+	if (!nrec) return 0;
+	/* components = runs of equal labels */
+	uint64_t ncomp = 1;
+	for (uint64_t r = 1; r < nrec; r++) ncomp += rec[3 * r + 2] != rec[3 * r - 1];
+	if (ncomp > 0xFFFFFFF0ULL) { printf("too many components of tips\n"); exit(1); }
+	uint64_t *cstart = (uint64_t *)malloc((ncomp + 1) * sizeof(uint64_t));
+	ncomp = 0;
+	cstart[0] = 0;
+	for (uint64_t r = 1; r < nrec; r++)
+		if (rec[3 * r + 2] != rec[3 * r - 1]) cstart[++ncomp] = r;
+	cstart[++ncomp] = nrec;
+	/* largest first (counting sort by the bit length of the size): the giant components must not start last */
+	uint32_t *corder = (uint32_t *)malloc((ncomp + 1) * sizeof(uint32_t));
+	uint64_t bucket[66] = {0};
+	for (uint64_t c = 0; c < ncomp; c++) bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++;
+	{
+		uint64_t acc = 0;
+		for (int b = 65; b >= 0; b--) { const uint64_t t = bucket[b]; bucket[b] = acc; acc += t; }
+	}
+	for (uint64_t c = 0; c < ncomp; c++) corder[bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++] = (uint32_t)c;
+	const uint64_t per = 64;
+	const uint64_t nchunks = (ncomp + per - 1) / per;
+	tc_ctx T = {g, rec, cstart, corder, ncomp, thin, cut_len, 0, (uint64_t **)calloc(nchunks + 1, sizeof(uint64_t *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
+	par_for(0, ncomp, per, tc_run, &T);
+	for (int t = 0; t < T.ntl; t++) {
+		for (size_t k = 0; k < T.tln[t]; k++) {
+			if (g->dn == g->dcap) {
+				g->dcap = g->dcap ? g->dcap * 2 : 4096;
+				g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
+			}
+			g->dlist[g->dn++] = T.tl[t][k];
+		}
+		free(T.tl[t]);
+	}
+	if (getenv("SDT_TIMING")) {
+		uint64_t biggest = 0;
+		for (uint64_t c = 0; c < ncomp; c++) if (cstart[c + 1] - cstart[c] > biggest) biggest = cstart[c + 1] - cstart[c];
+		fprintf(stderr, "[cuttip]     %llu walks in %llu components, largest %llu\n", (unsigned long long)nrec, (unsigned long long)ncomp, (unsigned long long)biggest);
+	}
+	free(T.tl); free(T.tln); free(cstart); free(corder);
+	return T.tips;
 }
 
 uint64_t graph_remove_single_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips of single frequency kmers short than %d\n", 2 * g->K);
-	tips_ctx c = {g, 0, 0, g->dev_walks ? NULL : (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
-	uint8_t *marks = g->dev_walks ? NULL : (uint8_t *)calloc(g->n + 1, 1);
-	cwalks_t cw = {NULL, 0};
 	double t_sub = cut_now_ms();
 	if (g->dev_walks) {
-		device_walks(g, 1, 2 * g->K, &cw);
+		uint64_t *rec, nrec;
+		device_walks(g, 1, 2 * g->K, &rec, &nrec);
 		SUBPHASE("single tips: device walks");
-		commit_tips_sparse(g, 0, g->n, 2 * g->K, 1, &tips, &cw);
-		free(cw.rec);
+		tips = commit_tips_by_components(g, rec, nrec, 1, 2 * g->K);
+		free(rec);
 		SUBPHASE("single tips: commit");
 	} else {
+		tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
+		uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
 		sweep_tips(g, 0, g->n, 2 * g->K, 1, &tips, &c, marks);
+		free(marks);
+		free(c.walks);
 	}
-	free(marks);
-	free(c.walks);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	return tips;
@@ -858,25 +1092,27 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 {
 	uint64_t tips = 0;
 	printf("Start to remove tips which don't contribute the most links\n");
-	tips_ctx c = {g, 0, 0, g->dev_walks ? NULL : (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
-	uint8_t *marks = g->dev_walks ? NULL : (uint8_t *)calloc(g->n + 1, 1);
-	cwalks_t cw = {NULL, 0};
 	double t_sub = cut_now_ms();
 	if (g->dev_walks) {
-		device_walks(g, 0, 2 * g->K, &cw);
+		uint64_t *rec, nrec;
+		device_walks(g, 0, 2 * g->K, &rec, &nrec);
 		SUBPHASE("minor tips: device walks");
-	}
-	for (int s = 0; s < g->p; s++) {
-		int changed = 1;
-		while (changed)                                /* fixed point PER SET before the next set (:385-408) */
-			changed = g->dev_walks ? commit_tips_sparse(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &cw)
-			                       : sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
-		printf("kmer set %d done\n", s);
+		tips = commit_tips_by_components(g, rec, nrec, 0, 2 * g->K);
+		free(rec);
+		for (int s = 0; s < g->p; s++) printf("kmer set %d done\n", s);
+	} else {
+		tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
+		uint8_t *marks = (uint8_t *)calloc(g->n + 1, 1);
+		for (int s = 0; s < g->p; s++) {
+			int changed = 1;
+			while (changed)                                /* fixed point PER SET before the next set (:385-408) */
+				changed = sweep_tips(g, g->set_start[s], g->set_start[s + 1], 2 * g->K, 0, &tips, &c, marks);
+			printf("kmer set %d done\n", s);
+		}
+		free(marks);
+		free(c.walks);
 	}
 	SUBPHASE("minor tips: sweeps");
-	free(marks);
-	free(c.walks);
-	free(cw.rec);
 	printf("%llu tips off\n", (unsigned long long)tips);
 	mark_linear(g);
 	SUBPHASE("minor tips: mark linear");
@@ -976,4 +1212,154 @@ int graph_write_basic(const char *prefix, uint64_t vertices, int K, uint64_t num
 	fprintf(fp, "\nMaxReadLen %d MinReadLen %d MaxNameLen %d\n", max_read_len, 0, 256);
 	fclose(fp);
 	return 0;
+}
+
+/* ---- host stand-ins for the device hooks (sdt-graphcheck, the CPU tests) ------------------------------------------
+ * The commits above are driven by what sdt_gpu_minor_out_dry / sdt_gpu_tip_walks_labelled return.  Without a device the
+ * same records are made here from the host's own dry runs (walk_from_tip, mo_junctions / mo_candidates) and a host
+ * union-find, so that every line of the device-path commits runs -- and is compared with the reference's files -- in
+ * the CPU suite.  Never used by sdt-pregraph. */
+typedef struct { graph_t *g; int thin, cut_len; u64vec out[64]; uint32_t *parent; } emu_ctx;
+
+static void emu_walk_part(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	emu_ctx *E = (emu_ctx *)vc;
+	graph_t *g = E->g;
+	for (uint64_t i = lo; i < hi; i++) {
+		walk_t w;
+		if (!walk_from_tip(g, &g->nodes[i], E->cut_len, E->thin, &w)) continue;
+		vec_push(&E->out[tid], i | ((uint64_t)(w.ch | (w.sm << 2) | (w.thin_stop << 3)) << 56));
+		vec_push(&E->out[tid], w.end);
+		vec_push(&E->out[tid], 0);
+		if (E->thin) cc_union(E->parent, (uint32_t)i, (uint32_t)w.end);
+	}
+}
+
+/* the first non-linear node behind port p of n (right links 0..3 on the stored strand, left links 0..3 on the other),
+ * NO_NODE when more than max_linear linear nodes lie in between */
+static uint64_t emu_port_far(graph_t *g, const gnode_t *n, int p, int max_linear)
+{
+	const int K = g->K;
+	kw_t word = p < 4 ? kw_next(n->seq, (unsigned)p, K) : kw_next(kw_rc(n->seq, K), (unsigned)(p - 4) ^ 2u, K);
+	int sm, passed = 0;
+	gnode_t *o = graph_find_oriented(g, word, &sm);
+	while (o->linear) {
+		if (++passed > max_linear) return NO_NODE;
+		unsigned b;
+		if (sm) { for (b = 0; b < 4 && !link_of(o, RIGHT, b); b++) ; }
+		else { for (b = 0; b < 4 && !link_of(o, LEFT, b); b++) ; b ^= 2u; }
+		word = kw_next(word, b, K);
+		o = graph_find_oriented(g, word, &sm);
+	}
+	return (uint64_t)(o - g->nodes);
+}
+
+static void emu_port_union(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	emu_ctx *E = (emu_ctx *)vc;
+	graph_t *g = E->g;
+	for (uint64_t i = lo; i < hi; i++) {
+		const gnode_t *n = &g->nodes[i];
+		if (n->linear || n->deleted) continue;
+		for (int p = 0; p < 8; p++) {
+			if (!(p < 4 ? link_of(n, RIGHT, (unsigned)p) : link_of(n, LEFT, (unsigned)(p - 4)))) continue;
+			const uint64_t far = emu_port_far(g, n, p, E->cut_len);
+			if (far != NO_NODE) cc_union(E->parent, (uint32_t)i, (uint32_t)far);
+		}
+	}
+}
+
+static int cmp_rec3(const void *a, const void *b)
+{
+	const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
+	if (x[2] != y[2]) return x[2] < y[2] ? -1 : 1;
+	const uint64_t nx = x[0] & 0x00FFFFFFFFFFFFFFULL, ny = y[0] & 0x00FFFFFFFFFFFFFFULL;
+	return nx < ny ? -1 : nx > ny;
+}
+
+static int emu_walks(graph_t *g, int thin, int cut_len, uint64_t **records, uint64_t *nr)
+{
+	if (g->n > 0xFFFFFFF0ULL) return 1;
+	emu_ctx E;
+	memset(&E, 0, sizeof E);
+	E.g = g; E.thin = thin; E.cut_len = cut_len;
+	E.parent = (uint32_t *)malloc((g->n + 1) * sizeof(uint32_t));
+	for (uint64_t i = 0; i <= g->n; i++) E.parent[i] = (uint32_t)i;
+	par_for(0, g->n, 4096, emu_walk_part, &E);
+	if (!thin) par_for(0, g->n, 4096, emu_port_union, &E);
+	uint64_t n = 0;
+	for (int t = 0; t < 64; t++) n += E.out[t].n / 3;
+	uint64_t *rec = (uint64_t *)malloc((n + 1) * 3 * sizeof(uint64_t));
+	uint64_t at = 0;
+	for (int t = 63; t >= 0; t--) {                           /* any order: the sort below is what the contract asks for */
+		memcpy(rec + 3 * at, E.out[t].v, E.out[t].n * sizeof(uint64_t));
+		at += E.out[t].n / 3;
+		free(E.out[t].v);
+	}
+	for (uint64_t r = 0; r < n; r++) rec[3 * r + 2] = cc_find(E.parent, (uint32_t)(rec[3 * r] & 0x00FFFFFFFFFFFFFFULL));
+	qsort(rec, n, 3 * sizeof(uint64_t), cmp_rec3);
+	free(E.parent);
+	for (size_t k = 0; k < g->dn; k++) { }                     /* (the caller clears the dirty marks) */
+	*records = rec;
+	*nr = n;
+	return 0;
+}
+
+static int cmp_rec10(const void *a, const void *b)
+{
+	const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
+	if (x[9] != y[9]) return x[9] < y[9] ? -1 : 1;
+	return x[0] < y[0] ? -1 : x[0] > y[0];
+}
+
+static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint64_t *nj_out, uint64_t *nr_out)
+{
+	if (g->n > 0xFFFFFFF0ULL) return 1;
+	mo_ctx c = {g, threshold, (uint8_t *)calloc(g->n + 1, 1), (uint8_t *)calloc(g->n + 1, 1), 0, 0};
+	par_for(0, g->n, 16384, count_junctions, &c);
+	uint64_t cap = (uint64_t)c.cursor * 9 + 1024;
+	if (cap > 0xFFFFFFF0ULL) cap = 0xFFFFFFF0ULL;
+	g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
+	g->nb_pool = (uint64_t *)malloc(cap * 8 * sizeof(uint64_t));
+	c.cursor = 0;
+	c.cap = (uint32_t)cap;
+	par_for(0, g->n, 8192, mo_junctions, &c);
+	par_for(0, g->n, 16384, mo_candidates, &c);
+	if (c.cursor > c.cap) return 1;
+	uint32_t *parent = (uint32_t *)malloc((g->n + 1) * sizeof(uint32_t));
+	for (uint64_t i = 0; i <= g->n; i++) parent[i] = (uint32_t)i;
+	uint64_t nj = 0, nc = 0;
+	for (uint64_t i = 0; i < g->n; i++) {
+		if (c.writes[i]) nj++;
+		else if (g->nb_slot[i]) nc++;
+	}
+	uint64_t *rec = (uint64_t *)malloc((nj + nc + 1) * 10 * sizeof(uint64_t));
+	uint64_t aj = 0, ac = nj;
+	for (uint64_t i = 0; i < g->n; i++) {
+		if (!g->nb_slot[i]) continue;
+		uint64_t *r = &rec[(c.writes[i] ? aj++ : ac++) * 10];
+		r[0] = i;
+		memcpy(r + 1, &g->nb_pool[(uint64_t)(g->nb_slot[i] - 1) * 8], 8 * sizeof(uint64_t));
+		r[9] = 0;
+		for (int k = 0; k < 8; k++)
+			if (r[1 + k] != NO_NODE) cc_union(parent, (uint32_t)i, (uint32_t)(r[1 + k] >> 1));
+	}
+	for (uint64_t r = 0; r < nj; r++) rec[r * 10 + 9] = cc_find(parent, (uint32_t)rec[r * 10]);
+	qsort(rec, nj, 10 * sizeof(uint64_t), cmp_rec10);
+	free(parent);
+	free(g->nb_slot); free(g->nb_pool); free(c.need); free(c.writes);
+	g->nb_slot = NULL;
+	g->nb_pool = NULL;
+	*records = rec;
+	*nj_out = nj;
+	*nr_out = nj + nc;
+	return 0;
+}
+
+void graph_emulate_device_cuts(graph_t *g)
+{
+	if (!g->dirty) g->dirty = (uint8_t *)calloc(g->n + 1, 1);
+	g->dev_walks = emu_walks;
+	g->dev_minor_out = emu_minor_out;
 }

@@ -533,3 +533,38 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	free(emit); free(E.ports); free(E.starts);
 	return num_ed;
 }
+
+/* ---- host stand-in for sdt_gpu_edge_ports (sdt-graphcheck, the CPU tests): the same 17-word records from dry_ports ---- */
+void graph_emulate_device_cuts(graph_t *g);
+
+static int emu_edge_ports(graph_t *g, uint64_t **records, uint64_t *n_records)
+{
+	edges_ctx E;
+	E.g = g;
+	E.starts = (uint64_t *)malloc((g->n + 1) * sizeof(uint64_t));
+	E.nstarts = 0;
+	for (uint64_t i = 0; i < g->n; i++)
+		if (!g->nodes[i].linear && !g->nodes[i].deleted) E.starts[E.nstarts++] = i;
+	E.ports = (port_t *)calloc(E.nstarts * 8 + 8, sizeof(port_t));
+	par_for(0, E.nstarts, 256, dry_ports, &E);
+	uint64_t *rec = (uint64_t *)malloc((E.nstarts + 1) * 17 * sizeof(uint64_t));
+	for (uint64_t s = 0; s < E.nstarts; s++) {
+		uint64_t *r = &rec[(E.nstarts - 1 - s) * 17];                      /* any order */
+		r[0] = E.starts[s];
+		for (int p = 0; p < 8; p++) {
+			const port_t *P = &E.ports[s * 8 + p];
+			r[1 + 2 * p] = P->far_node;
+			r[2 + 2 * p] = P->far_node == NO_WALK ? 0 : ((uint64_t)P->length | ((uint64_t)P->far_port << 32) | ((uint64_t)P->bal_edge << 40));
+		}
+	}
+	*records = rec;
+	*n_records = E.nstarts;
+	free(E.ports); free(E.starts);
+	return 0;
+}
+
+void graph_emulate_device(graph_t *g)
+{
+	graph_emulate_device_cuts(g);
+	g->dev_edge_ports = emu_edge_ports;
+}

@@ -496,5 +496,5 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 void graph_free(graph_t *g)
 {
 	if (!g) return;
-	free(g->nodes); free(g->set_start); free(g->index); free(g->index64); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g->vbits); free(g);
+	free(g->nodes); free(g->set_start); free(g->index); free(g->index64); free(g->patch); free(g->tlist); free(g->dirty); free(g->dlist); free(g);
 }

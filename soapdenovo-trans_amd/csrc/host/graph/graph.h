@@ -50,14 +50,15 @@ typedef struct graph_s {
 	 * sends them over, and the commit uses the same marks to tell which recorded walks are still what the
 	 * reference would walk. */
 	uint8_t *dirty;
-	uint64_t *vbits;                   /* 1 bit per node: a sweep has to look at it (recorded walk, or written since) */
 	uint64_t *dlist;
 	size_t dn, dcap;
-	/* malloc'ed records of 2 words (node index | info << 56, end index) for the nodes that have a walk, any order */
+	/* malloc'ed records of 3 words (node index | info << 56, end index, component label) for the nodes that have a walk,
+	 * sorted by (label, node index): a component of the commit is a run of records (cuttip.c) */
 	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t **records, uint64_t *n_records);   /* 0 = ok */
 	/* kmer2edges' port walks from the device: malloc'ed records (17 words each, sdt_gpu_edge_ports) */
 	int (*dev_edge_ports)(struct graph_s *g, uint64_t **records, uint64_t *n_records);
-	/* removeMinorOut's dry run from the device: malloc'ed records (9 words each, sdt_gpu_minor_out_dry) */
+	/* removeMinorOut's dry run from the device: malloc'ed records of 10 words (node index, 8 neighbours, component label);
+	 * the junction records [0, n_junctions) sorted by (label, node index), then the neighbours to cut in any order */
 	int (*dev_minor_out)(struct graph_s *g, double threshold, uint64_t **records, uint64_t *n_junctions, uint64_t *n_records);
 	void *dev_user;
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
@@ -104,6 +105,10 @@ void arcs_add_read(graph_t *g, struct arcs *A, const uint8_t *codes, int len, ui
 int arcs_write(struct arcs *A, const char *prefix);
 int arcs_write_arrays(const char *prefix, const uint32_t *from, const uint32_t *to, const uint32_t *mult,
                       const uint64_t *first, uint64_t n);
+
+/* CPU stand-ins for the three device hooks above, made from the host's own dry runs (sdt-graphcheck with
+ * SDT_GRAPHCHECK_EMULATE=1, the CPU tests): the commits that sdt-pregraph runs on the device's records run on these */
+void graph_emulate_device(graph_t *g);
 
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);

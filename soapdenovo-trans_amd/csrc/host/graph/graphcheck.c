@@ -47,6 +47,7 @@ int main(int argc, char **argv)
 	if (getenv("SDT_GRAPHCHECK_A")) graph_init_kmerset_size = atoi(getenv("SDT_GRAPHCHECK_A"));      /* -a of the CLI */
 	graph_t *G = graph_build(K, nwv, nwk, p, n, keys, ll, rf, cnt, first);
 	phase("build");
+	if (getenv("SDT_GRAPHCHECK_EMULATE")) graph_emulate_device(G);       /* the device-path commits on host-made records */
 	graph_remove_minor_out(G, dd);
 	phase("minor-out");
 	if (!d) graph_remove_single_tips(G);
