@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 4
+#define SDT_ABI_VERSION 5
 
 enum {
 	SDT_OK       = 0,
@@ -265,6 +265,35 @@ int sdt_gpu_build_host_index(sdt_ctx *ctx, uint32_t *index, uint64_t index_slots
  *                   the chain arrives through; bal_edge = 0 when the chain is its own reverse complement,
  *                   check_iden_kmerList :563-588).  SDT_EFULL when records[] is too small (*n_records = needed). */
 int sdt_gpu_edge_ports(sdt_ctx *ctx, uint64_t *records, uint64_t max_records, uint64_t *n_records);
+
+/* ---- the reference's visiting order, and the dry runs labelled for commits that run side by side ----------------------
+ * Every phase after kmerFreq walks the reference's tables "set 0..p-1, slot 0..size-1" (cutTipPreGraph.c:351-366,385-408,
+ * 1049-1072, node2edge.c:46-56), and a node's place there is a function of hash_kmer(key) % p and of the order in which the
+ * distinct keys of its set first occurred (put_kmerset / encap_kmerset, newhash.c:293-462).  The device knows both:
+ *   layout_sorted_keys: sorts the nodes by (set, first-occurrence ordinal) -- set = hash_kmer (hashFunction.c:83-122) over the
+ *                   bytes of the nw_variant-word Kmer of the emulated binary, % p -- and returns the KEYS in that order
+ *                   (key_words() words each) with set_start[0..p]; keys == NULL: only *n.  Ends pass 1 (its pools are freed).
+ *   layout_apply:   order[v] = rank (index into that key array) of the node at visiting position v, from the host's replay of
+ *                   the probing (csrc/host/graph/graph.c: graph_replay_order).  Numbers the nodes: everything below that
+ *                   speaks of a node index means v.  Replaces sdt_gpu_set_node_index (no keys cross the link).
+ *   export_ordered: the nodes in visiting order, arrays as sdt_gpu_export_nodes (any may be NULL).
+ *   update_nodes_by_index: sdt_gpu_update_nodes with node indices instead of keys.
+ *   tip_walks_labelled / minor_out_labelled: the dry runs of sdt_gpu_tip_walks_compact / sdt_gpu_minor_out_dry with one more
+ *                   word per record, the COMPONENT of the record's node: a visit of the ordered commit reads and writes only
+ *                   its own node and nodes of the same component, so components commit side by side, each in the reference's
+ *                   order (csrc/host/graph/cuttip.c).  Components = union-find over node indices on the device --
+ *                   removeSingleTips (thin): tip + end node of every walk; removeMinorTips: non-linear nodes joined by chains
+ *                   of <= cut_len linear nodes; removeMinorOut: every record's node + its eight neighbours.  Records:
+ *                   walks 3 words (node | info << 56, end, label), all sorted by (label, node); junctions 10 words (node,
+ *                   8 neighbours, label), the first *n_junctions sorted by (label, node), then the neighbours to cut.
+ *                   The records stay on the device until fetch_records copies them (nwords = records x words, exactly). */
+int sdt_gpu_layout_sorted_keys(sdt_ctx *ctx, int p, int nw_variant, uint64_t *keys, uint64_t max_nodes, uint64_t *set_start, uint64_t *n);
+int sdt_gpu_layout_apply(sdt_ctx *ctx, const uint64_t *order, uint64_t n);
+int sdt_gpu_export_ordered(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count, uint64_t n);
+int sdt_gpu_update_nodes_by_index(sdt_ctx *ctx, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
+int sdt_gpu_tip_walks_labelled(sdt_ctx *ctx, int thin, int cut_len, uint64_t *n_records);
+int sdt_gpu_minor_out_labelled(sdt_ctx *ctx, double threshold, uint64_t *n_junctions, uint64_t *n_records);
+int sdt_gpu_fetch_records(sdt_ctx *ctx, uint64_t *dst, uint64_t nwords);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

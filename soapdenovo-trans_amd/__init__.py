@@ -64,6 +64,13 @@ _ABI = [
                                          _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_edge_ports", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_build_host_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_layout_sorted_keys", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_layout_apply", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_export_ordered", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_update_nodes_by_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_tip_walks_labelled", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_minor_out_labelled", _c.c_int, [_c.c_void_p, _c.c_double, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_fetch_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_set_contig_table", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_align_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_int,
@@ -396,6 +403,52 @@ class PregraphGPU:
                 continue
             self._check(rc)
             return rec[: nr.value]
+
+    # -- the reference's visiting order on the device, labelled dry runs (include/sdt_gpu.h)
+    def layout_sorted_keys(self, p: int, nw_variant: int):
+        """-> (keys uint64[n, nw] sorted by (set, first occurrence), set_start uint64[p + 1])"""
+        n = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_layout_sorted_keys(self._ctx, p, nw_variant, None, 0, None, ctypes.byref(n)))
+        keys = np.zeros((max(n.value, 1), self.nw), dtype=np.uint64)
+        ss = np.zeros(p + 1, dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_layout_sorted_keys(self._ctx, p, nw_variant, _ptr(keys), n.value, _ptr(ss), ctypes.byref(n)))
+        return keys[: n.value], ss
+
+    def layout_apply(self, order: np.ndarray):
+        order = np.ascontiguousarray(order, dtype=np.uint64)
+        self._nidx = len(order)
+        self._check(self.lib.sdt_gpu_layout_apply(self._ctx, _ptr(order), len(order)))
+
+    def export_ordered(self):
+        n = self._nidx
+        keys = np.zeros((max(n, 1), self.nw), dtype=np.uint64)
+        l, r, cnt = (np.zeros(max(n, 1), dtype=np.uint32) for _ in range(3))
+        self._check(self.lib.sdt_gpu_export_ordered(self._ctx, _ptr(keys), _ptr(l), _ptr(r), _ptr(cnt), n))
+        return keys[:n], l[:n], r[:n], cnt[:n]
+
+    def update_nodes_by_index(self, node, l_links, r_flags):
+        node = np.ascontiguousarray(node, dtype=np.uint64)
+        l_links = np.ascontiguousarray(l_links, dtype=np.uint32)
+        r_flags = np.ascontiguousarray(r_flags, dtype=np.uint32)
+        assert len(l_links) == len(node) == len(r_flags)
+        self._check(self.lib.sdt_gpu_update_nodes_by_index(self._ctx, _ptr(node), _ptr(l_links), _ptr(r_flags), len(node)))
+
+    def _fetch(self, n: int, words: int):
+        rec = np.zeros((max(n, 1), words), dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_fetch_records(self._ctx, _ptr(rec), n * words))
+        return rec[:n]
+
+    def tip_walks_labelled(self, thin: bool, cut_len: int):
+        """-> records uint64[n, 3]: node index | info << 56, end index, component label; sorted by (label, node)"""
+        nr = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_tip_walks_labelled(self._ctx, int(thin), cut_len, ctypes.byref(nr)))
+        return self._fetch(nr.value, 3)
+
+    def minor_out_labelled(self, threshold: float):
+        """-> (records uint64[n, 10], n_junctions): node, 8 neighbours, label; the junction records sorted by (label, node)"""
+        nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_minor_out_labelled(self._ctx, ctypes.c_double(threshold), ctypes.byref(nj), ctypes.byref(nr)))
+        return self._fetch(nr.value, 10), nj.value
 
     def set_read_ordinal(self, base: int, stride: int = 1):
         self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))

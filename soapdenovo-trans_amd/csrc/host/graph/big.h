@@ -17,7 +17,9 @@ static inline void *big_malloc(size_t bytes)
 	const size_t huge = (size_t)2 << 20, sz = (bytes + huge - 1) & ~(huge - 1);
 	void *p = NULL;
 	if (posix_memalign(&p, huge, sz) != 0) return NULL;
-	madvise(p, sz, MADV_HUGEPAGE);
+	static int thp = -1;                                /* SDT_NO_THP=1: plain pages (some sandboxes fault huge pages in very slowly) */
+	if (thp < 0) thp = getenv("SDT_NO_THP") == NULL;
+	if (thp) madvise(p, sz, MADV_HUGEPAGE);
 	return p;
 }
 

@@ -7,6 +7,8 @@
 #include <string.h>
 #include "par.h"
 #include "big.h"        /* every large block (replay tables, node arrays) asks for transparent huge pages */
+#include <time.h>
+static double gb_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 /* ---- hash_kmer: table-driven CRC-32 with a SIGNED 32-bit state (arithmetic >> 8), hashFunction.c:83-122 ---- */
 static int32_t crc_tab[256];
@@ -58,139 +60,200 @@ static uint64_t next_prime_kh(uint64_t n)
 	return n;
 }
 
-typedef struct {
-	int64_t *slot;         /* node id or -1 */
-	uint8_t *moved;        /* scratch for the rehash */
-	uint64_t size, count, max;
-	double lf;
-} replay_t;
+/* One table for the whole replay of a set, as the reference has one array that it reallocs: an entry is (key, id, tag) with
+ * tag 0 = empty, tag == gen = placed in the current geometry, tag == gen - 1 (during a rehash) = still where the previous
+ * geometry left it -- "empty" for the probing of the new geometry, evicted and carried onward when something lands on it.  A
+ * step of the rehash then touches ONE random cache line (the landing slot holds flags, key and id together), the scan over the
+ * old slots is sequential, and the homes of the entries a few steps ahead are prefetched.  The table is allocated once at its
+ * final size (the sequence of sizes depends only on the number of keys). */
+typedef struct { uint64_t key; uint32_t id, tag; } rent_t;         /* 1-word keys: the key travels with the entry */
+typedef struct { uint32_t id, tag; } rent_w;                       /* wider keys: looked up through the id */
 
-static uint64_t home_slot(const kw_t *k, int nw, uint64_t size)
+static uint64_t replay_next_size(uint64_t size, double lf, uint64_t count)
 {
-	if (nw == 1) return k->w[3] % size;                                  /* newhash.c:428 */
-	if (nw == 2) {                                                       /* :423-425 */
-		unsigned __int128 v = ((unsigned __int128)k->w[2] << 64) | k->w[3];
+	uint64_t n = size;
+	do {
+		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
+		n = next_prime_kh(n);
+	} while (n * lf < (double)(count + 1));
+	return n;
+}
+
+static uint64_t replay_final_size(uint64_t init, uint64_t m)
+{
+	uint64_t size = init, max = (uint64_t)(size * 0.77f);
+	const double lf = (double)0.77f;
+	while (m > max) {                                       /* a put grows the table when count + 1 > max */
+		size = replay_next_size(size, lf, max);             /* ... and that happens at count == max */
+		max = (uint64_t)(size * lf);
+	}
+	return size;
+}
+
+#define RP_AHEAD 16
+
+/* keys[i] (i = 0..m-1, first-occurrence order) -> ids in slot order */
+static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_t base, uint64_t *out)
+{
+	if (m > 0xFFFFFFF0ULL) { printf("a set of %llu nodes does not fit the replay's 32-bit ids\n", (unsigned long long)m); exit(1); }
+	const uint64_t fin = replay_final_size(init, m);
+	rent_t *t = (rent_t *)malloc(fin * sizeof(rent_t));
+	if (!t) { printf("out of memory for a replay table of %llu slots\n", (unsigned long long)fin); exit(1); }
+	memset(t, 0, fin * sizeof(rent_t));
+	uint64_t size = init, count = 0, max = (uint64_t)(size * 0.77f);
+	const double lf = (double)0.77f;
+	uint32_t gen = 1;
+	for (uint64_t i = 0; i < m; i++) {
+		if (count + 1 > max) {
+			/* encap_kmerset (newhash.c:293-409) */
+			const uint64_t old = size, n = replay_next_size(size, lf, count);
+			const uint32_t was = gen++;
+			uint64_t ring[RP_AHEAD];
+			for (uint64_t j = 0; j < RP_AHEAD && j < old; j++) {
+				ring[j] = t[j].tag == was ? t[j].key % n : 0;
+				__builtin_prefetch(&t[ring[j]], 1);
+			}
+			for (uint64_t j = 0; j < old; j++) {
+				const uint64_t home = ring[j % RP_AHEAD];
+				if (j + RP_AHEAD < old) {
+					const uint64_t hp = t[j + RP_AHEAD].tag == was ? t[j + RP_AHEAD].key % n : 0;
+					ring[j % RP_AHEAD] = hp;
+					__builtin_prefetch(&t[hp], 1);
+				}
+				if (t[j].tag != was) continue;               /* empty, or evicted earlier in this rehash */
+				rent_t carry = t[j];
+				t[j].tag = 0;
+				uint64_t h = home;
+				for (;;) {
+					while (t[h].tag == gen) h = h + 1 == n ? 0 : h + 1;
+					if (h < old && t[h].tag == was) {        /* an entry that has not moved yet: it gives way and is carried on */
+						const rent_t evicted = t[h];
+						t[h] = carry;
+						t[h].tag = gen;
+						carry = evicted;
+						h = carry.key % n;
+						continue;
+					}
+					t[h] = carry;
+					t[h].tag = gen;
+					break;
+				}
+			}
+			size = n;
+			max = (uint64_t)(n * lf);
+		}
+		if (i + RP_AHEAD < m) __builtin_prefetch(&t[keys[i + RP_AHEAD] % size], 1);    /* its home, unless the table grows first */
+		uint64_t h = keys[i] % size;
+		while (t[h].tag) h = h + 1 == size ? 0 : h + 1;
+		t[h].key = keys[i];
+		t[h].id = (uint32_t)i;
+		t[h].tag = gen;
+		count++;
+	}
+	uint64_t k = 0;
+	for (uint64_t s = 0; s < size; s++)
+		if (t[s].tag) out[k++] = base + t[s].id;
+	free(t);
+}
+
+static uint64_t home_words(const uint64_t *k, int nwk, uint64_t size)
+{
+	if (nwk == 1) return k[0] % size;                                    /* newhash.c:428 (and :423-425, :43-55 with zero high words) */
+	if (nwk == 2) {                                                      /* :423-425 */
+		unsigned __int128 v = ((unsigned __int128)k[0] << 64) | k[1];
 		return (uint64_t)(v % size);
 	}
-	uint64_t t = k->w[0] % size;                                         /* :43-55, 32 bits at a time */
-	const uint64_t part[6] = {k->w[1] >> 32, k->w[1] & 0xffffffffu, k->w[2] >> 32, k->w[2] & 0xffffffffu,
-	                          k->w[3] >> 32, k->w[3] & 0xffffffffu};
+	uint64_t t = k[0] % size;                                            /* :43-55, 32 bits at a time */
+	const uint64_t part[6] = {k[1] >> 32, k[1] & 0xffffffffu, k[2] >> 32, k[2] & 0xffffffffu, k[3] >> 32, k[3] & 0xffffffffu};
 	for (int i = 0; i < 6; i++)
 		t = ((t << 32) | part[i]) % size;
 	return t;
 }
 
-static void replay_grow(replay_t *r, const gnode_t *nodes, int nw)
+static void replay_setw(const uint64_t *keys, int nwk, uint64_t m, uint64_t init, uint64_t base, uint64_t *out)
 {
-	uint64_t n = r->size;
-	do {
-		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
-		n = next_prime_kh(n);
-	} while (n * r->lf < (double)(r->count + 1));
-	const uint64_t old = r->size;
-	int64_t *ns = (int64_t *)malloc(n * sizeof(int64_t));
-	/* the reference reallocs in place and tells old from new by two flag arrays; here: ns = new geometry,
-	 * r->slot = old geometry, moved[i] = old entry i has left its old slot */
-	for (uint64_t i = 0; i < n; i++) ns[i] = -1;
-	r->moved = (uint8_t *)realloc(r->moved, old);
-	memset(r->moved, 0, old);
-	for (uint64_t i = 0; i < old; i++) {
-		if (r->slot[i] < 0 || r->moved[i]) continue;
-		int64_t carry = r->slot[i];
-		r->moved[i] = 1;
-		for (;;) {
-			uint64_t h = home_slot(&nodes[carry].seq, nw, n);
-			while (ns[h] >= 0) h = h + 1 == n ? 0 : h + 1;
-			/* the new array aliases the old one below `old`: a slot h < old that still holds an unmoved old
-			 * entry is "empty" in the new flags, and its occupant gets evicted and carried on */
-			if (h < old && r->slot[h] >= 0 && !r->moved[h]) {
-				const int64_t evicted = r->slot[h];
-				r->moved[h] = 1;
-				ns[h] = carry;
-				carry = evicted;
-				continue;
+	if (m > 0xFFFFFFF0ULL) { printf("a set of %llu nodes does not fit the replay's 32-bit ids\n", (unsigned long long)m); exit(1); }
+	const uint64_t fin = replay_final_size(init, m);
+	rent_w *t = (rent_w *)malloc(fin * sizeof(rent_w));
+	if (!t) { printf("out of memory for a replay table of %llu slots\n", (unsigned long long)fin); exit(1); }
+	memset(t, 0, fin * sizeof(rent_w));
+	uint64_t size = init, count = 0, max = (uint64_t)(size * 0.77f);
+	const double lf = (double)0.77f;
+	uint32_t gen = 1;
+	for (uint64_t i = 0; i < m; i++) {
+		if (count + 1 > max) {
+			const uint64_t old = size, n = replay_next_size(size, lf, count);
+			const uint32_t was = gen++;
+			for (uint64_t j = 0; j < old; j++) {
+				if (j + 8 < old && t[j + 8].tag == was) __builtin_prefetch(&keys[(uint64_t)t[j + 8].id * nwk]);
+				if (t[j].tag != was) continue;
+				uint32_t carry = t[j].id;
+				t[j].tag = 0;
+				for (;;) {
+					uint64_t h = home_words(keys + (uint64_t)carry * nwk, nwk, n);
+					while (t[h].tag == gen) h = h + 1 == n ? 0 : h + 1;
+					if (h < old && t[h].tag == was) {
+						const uint32_t evicted = t[h].id;
+						t[h].id = carry;
+						t[h].tag = gen;
+						carry = evicted;
+						continue;
+					}
+					t[h].id = carry;
+					t[h].tag = gen;
+					break;
+				}
 			}
-			ns[h] = carry;
-			break;
+			size = n;
+			max = (uint64_t)(n * lf);
 		}
+		uint64_t h = home_words(keys + i * nwk, nwk, size);
+		while (t[h].tag) h = h + 1 == size ? 0 : h + 1;
+		t[h].id = (uint32_t)i;
+		t[h].tag = gen;
+		count++;
 	}
-	free(r->slot);
-	r->slot = ns;
-	r->size = n;
-	r->max = (uint64_t)(n * r->lf);
+	uint64_t k = 0;
+	for (uint64_t s = 0; s < size; s++)
+		if (t[s].tag) out[k++] = base + t[s].id;
+	free(t);
 }
 
-static void replay_put(replay_t *r, const gnode_t *nodes, int64_t id, int nw)
+/* init_kmerset(1024, 0.77f), prlHashReads.c:402-423; with -a <n != 0> the 63mer / 127mer binaries ask for k * 0xFFFFFF slots
+ * with k == 0 (:404-413), and init_kmerset turns anything below 3 into 3 (newhash.c:163-166) */
+static uint64_t replay_init_size(int nw_variant)
 {
-	if (r->count + 1 > r->max)
-		replay_grow(r, nodes, nw);
-	uint64_t h = home_slot(&nodes[id].seq, nw, r->size);
-	while (r->slot[h] >= 0) h = h + 1 == r->size ? 0 : h + 1;
-	r->slot[h] = id;
-	r->count++;
+	return nw_variant != 1 && graph_init_kmerset_size ? 3 : next_prime_kh(1024);
 }
 
-/* ---- the same replay for 1-word keys with the key kept next to the node id: a rehash then walks the old slots
- * in order and touches one random cache line per entry (its new slot) instead of two (plus the 48-byte node) ---- */
-typedef struct { int64_t id; uint64_t key; } rslot1;
-typedef struct {
-	rslot1 *slot;
-	uint8_t *moved;
-	uint64_t size, count, max;
-	double lf;
-} replay1_t;
+typedef struct { int nw_variant, nwk, p; const uint64_t *keys, *set_start; uint64_t *order; volatile int next_set; } rp_job;
 
-static void replay1_grow(replay1_t *r)
+static void *rp_thread(void *v)
 {
-	uint64_t n = r->size;
-	do {
-		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
-		n = next_prime_kh(n);
-	} while (n * r->lf < (double)(r->count + 1));
-	const uint64_t old = r->size;
-	rslot1 *ns = (rslot1 *)malloc(n * sizeof(rslot1));
-	for (uint64_t i = 0; i < n; i++) ns[i].id = -1;
-	r->moved = (uint8_t *)realloc(r->moved, old);
-	memset(r->moved, 0, old);
-	for (uint64_t i = 0; i < old; i++) {
-		/* the old slots are walked in order, so the new home of the entry a few steps ahead is known: have it in cache */
-		if (i + 12 < old && r->slot[i + 12].id >= 0) {
-			const uint64_t hp = r->slot[i + 12].key % n;
-			__builtin_prefetch(&ns[hp], 1);
-			if (hp < old) { __builtin_prefetch(&r->slot[hp]); __builtin_prefetch(&r->moved[hp], 1); }   /* the eviction test reads both */
-		}
-		if (r->slot[i].id < 0 || r->moved[i]) continue;
-		rslot1 carry = r->slot[i];
-		r->moved[i] = 1;
-		for (;;) {
-			uint64_t h = carry.key % n;
-			while (ns[h].id >= 0) h = h + 1 == n ? 0 : h + 1;
-			if (h < old && r->slot[h].id >= 0 && !r->moved[h]) {        /* see replay_grow */
-				const rslot1 evicted = r->slot[h];
-				r->moved[h] = 1;
-				ns[h] = carry;
-				carry = evicted;
-				continue;
-			}
-			ns[h] = carry;
-			break;
-		}
+	rp_job *J = (rp_job *)v;
+	for (;;) {
+		const int s = __sync_fetch_and_add(&J->next_set, 1);
+		if (s >= J->p) break;
+		const uint64_t b = J->set_start[s], m = J->set_start[s + 1] - b;
+		const double t0 = getenv("SDT_TIMING") && s == 0 ? gb_now() : 0;
+		if (J->nwk == 1) replay_set1(J->keys + b, m, replay_init_size(J->nw_variant), b, J->order + b);
+		else replay_setw(J->keys + b * J->nwk, J->nwk, m, replay_init_size(J->nw_variant), b, J->order + b);
+		if (t0 > 0) fprintf(stderr, "[graph]      set 0: replay %9.1f ms (%llu nodes)\n", gb_now() - t0, (unsigned long long)m);
 	}
-	free(r->slot);
-	r->slot = ns;
-	r->size = n;
-	r->max = (uint64_t)(n * r->lf);
+	return NULL;
 }
 
-static inline void replay1_put(replay1_t *r, int64_t id, uint64_t key)
+/* keys grouped by set ([set_start[s], set_start[s + 1])) and, inside a set, in first-occurrence order (nwk words each, most
+ * significant first): order[v] = index into keys[] of the node at visiting position v.  Sets are replayed side by side. */
+void graph_replay_order(int nw_variant, int nwk, int p, const uint64_t *keys, const uint64_t *set_start, uint64_t *order)
 {
-	if (r->count + 1 > r->max)
-		replay1_grow(r);
-	uint64_t h = key % r->size;
-	while (r->slot[h].id >= 0) h = h + 1 == r->size ? 0 : h + 1;
-	r->slot[h].id = id;
-	r->slot[h].key = key;
-	r->count++;
+	rp_job J = {nw_variant, nwk, p, keys, set_start, order, 0};
+	int nt = par_threads();
+	if (nt > p) nt = p;
+	pthread_t th[64];
+	for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, rp_thread, &J);
+	rp_thread(&J);
+	for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
 }
 
 /* ---- our own lookup index ---- */
@@ -225,8 +288,6 @@ gnode_t *graph_find_oriented(graph_t *g, kw_t word, int *smaller)
 	exit(1);
 }
 
-#include <time.h>
-static double gb_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 typedef struct { uint64_t first; uint64_t id; } ord_t;
 static int cmp_ord(const void *a, const void *b)
 {
@@ -275,6 +336,7 @@ struct build_job {
 	uint32_t *set_of;
 	uint64_t *per_set;       /* p + 1 prefix */
 	ord_t *ord;
+	uint64_t *skeys, *order; /* keys grouped by set in first-occurrence order; visiting position -> index into them */
 	uint64_t *hist;          /* nthreads x p */
 	volatile int next_set;
 };
@@ -316,55 +378,28 @@ static void job_unpack(build_job *J, int tid)
 	}
 }
 
-static void job_replay(build_job *J, int tid)
+/* per set: sort by first occurrence, then the keys in that order (what the device hands over ready-made) */
+static void job_sort_sets(build_job *J, int tid)
 {
 	(void)tid;
 	graph_t *g = J->g;
+	const int nwk = J->nw_keys;
 	for (;;) {
 		const int s = __sync_fetch_and_add(&J->next_set, 1);
 		if (s >= g->p) break;
 		const uint64_t b = J->per_set[s], e = J->per_set[s + 1];
-		const double t_s0 = getenv("SDT_TIMING") ? gb_now() : 0;
 		sort_ord(J->ord + b, e - b);
-		if (t_s0 > 0 && s == 0) fprintf(stderr, "[graph]      set 0: sort %9.1f ms (%llu nodes)\n", gb_now() - t_s0, (unsigned long long)(e - b));
-		uint64_t out = b;                                  /* every node of the set is placed: the set fills [b, e) */
-		if (g->nw == 1) {
-			replay1_t r;
-			memset(&r, 0, sizeof r);
-			r.size = next_prime_kh(1024);                 /* init_kmerset(1024, 0.77f), prlHashReads.c:402-423 */
-			r.max = (uint64_t)(r.size * 0.77f);
-			r.lf = (double)0.77f;
-			r.slot = (rslot1 *)malloc(r.size * sizeof(rslot1));
-			for (uint64_t i = 0; i < r.size; i++) r.slot[i].id = -1;
-			for (uint64_t i = b; i < e; i++) {
-				if (i + 24 < e) __builtin_prefetch(&J->tmp[J->ord[i + 24].id].seq.w[3]);
-				if (i + 8 < e) __builtin_prefetch(&r.slot[J->tmp[J->ord[i + 8].id].seq.w[3] % r.size], 1);   /* its home slot, if the table does not grow first */
-				replay1_put(&r, (int64_t)J->ord[i].id, J->tmp[J->ord[i].id].seq.w[3]);
-			}
-			if (t_s0 > 0 && s == 0) fprintf(stderr, "[graph]      set 0: sort + puts %9.1f ms\n", gb_now() - t_s0);
-			for (uint64_t i = 0; i < r.size; i++) {
-				if (i + 8 < r.size && r.slot[i + 8].id >= 0) __builtin_prefetch(&J->tmp[r.slot[i + 8].id]);
-				if (r.slot[i].id >= 0) g->nodes[out++] = J->tmp[r.slot[i].id];
-			}
-			free(r.slot);
-			free(r.moved);
-			continue;
-		}
-		replay_t r;
-		memset(&r, 0, sizeof r);
-		/* init_kmerset(1024, 0.77f), prlHashReads.c:402-423; with -a <n != 0> the 63mer / 127mer binaries ask for
-		 * k * 0xFFFFFF slots with k == 0 (:404-413), and init_kmerset turns anything below 3 into 3 (newhash.c:163-166) */
-		r.size = graph_init_kmerset_size ? 3 : next_prime_kh(1024);
-		r.max = (uint64_t)(r.size * 0.77f);
-		r.lf = (double)0.77f;
-		r.slot = (int64_t *)malloc(r.size * sizeof(int64_t));
-		for (uint64_t i = 0; i < r.size; i++) r.slot[i] = -1;
 		for (uint64_t i = b; i < e; i++)
-			replay_put(&r, J->tmp, (int64_t)J->ord[i].id, g->nw);
-		for (uint64_t i = 0; i < r.size; i++)
-			if (r.slot[i] >= 0) g->nodes[out++] = J->tmp[r.slot[i]];
-		free(r.slot);
-		free(r.moved);
+			for (int w = 0; w < nwk; w++) J->skeys[i * nwk + w] = J->keys[J->ord[i].id * nwk + w];
+	}
+}
+
+static void job_place(build_job *J, int tid)
+{
+	const uint64_t lo = J->n * (uint64_t)tid / J->nthreads, hi = J->n * (uint64_t)(tid + 1) / J->nthreads;
+	for (uint64_t v = lo; v < hi; v++) {
+		if (v + 8 < hi) __builtin_prefetch(&J->tmp[J->ord[J->order[v + 8]].id]);
+		J->g->nodes[v] = J->tmp[J->ord[J->order[v]].id];
 	}
 }
 
@@ -465,8 +500,15 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
 	memcpy(g->set_start, J.per_set, ((size_t)p + 1) * sizeof(uint64_t));
 	J.next_set = 0;
-	run_parallel(&J, job_replay);
-	GB_PHASE("sort + replay per set");
+	J.skeys = (uint64_t *)malloc((n ? n : 1) * (size_t)nw_keys * sizeof(uint64_t));
+	J.order = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+	run_parallel(&J, job_sort_sets);
+	GB_PHASE("sort per set");
+	graph_replay_order(nw_variant, nw_keys, p, J.skeys, J.per_set, J.order);
+	GB_PHASE("replay per set");
+	run_parallel(&J, job_place);
+	GB_PHASE("nodes into visiting order");
+	free(J.skeys); free(J.order);
 	/* gigabytes of scratch: returning them to the kernel takes a fraction of a second, off the critical path */
 	graph_free_later(J.ord, J.per_set, J.set_of, J.tmp);
 	/* index */
@@ -489,6 +531,70 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 		g->index_mask = cap - 1;
 	}
 	run_parallel(&J, job_index);
+	GB_PHASE("index");
+	return g;
+}
+
+/* the graph from nodes that are in visiting order already (sdt_gpu_export_ordered after graph_replay_order); the look-up index
+ * comes from graph_index_hook (the device builds it) or is built here */
+typedef struct { graph_t *g; int nwk; const uint64_t *keys; const uint32_t *l_links, *r_flags, *count; } fo_ctx;
+
+static void fo_unpack(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	fo_ctx *F = (fo_ctx *)vc;
+	const int nwk = F->nwk;
+	for (uint64_t i = lo; i < hi; i++) {
+		gnode_t *nd = &F->g->nodes[i];
+		memset(nd, 0, sizeof *nd);
+		for (int w = 0; w < nwk; w++) nd->seq.w[4 - nwk + w] = F->keys[i * nwk + w];
+		nd->l_links = F->l_links[i];
+		nd->r_links = F->r_flags[i] & 0xFFFFFFu;
+		nd->linear = (F->r_flags[i] >> 24) & 1; nd->deleted = (F->r_flags[i] >> 25) & 1; nd->single = (F->r_flags[i] >> 27) & 1;
+		nd->count = F->count[i];
+	}
+}
+
+static void fo_index(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	graph_t *g = ((fo_ctx *)vc)->g;
+	for (uint64_t i = lo; i < hi; i++) {
+		uint64_t h = mix_key(&g->nodes[i].seq) & g->index_mask;
+		if (g->index64) { while (!__sync_bool_compare_and_swap(&g->index64[h], 0ULL, i + 1)) h = (h + 1) & g->index_mask; }
+		else { while (!__sync_bool_compare_and_swap(&g->index[h], 0u, (uint32_t)(i + 1))) h = (h + 1) & g->index_mask; }
+	}
+}
+
+graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys, const uint32_t *l_links,
+                            const uint32_t *r_flags, const uint32_t *count, const uint64_t *set_start)
+{
+	double t_sub = gb_now();
+	graph_t *g = (graph_t *)calloc(1, sizeof *g);
+	g->K = K; g->nw = nw_variant; g->p = p; g->n = n;
+	g->nodes = (gnode_t *)malloc((n ? n : 1) * sizeof(gnode_t));
+	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
+	memcpy(g->set_start, set_start, ((size_t)p + 1) * sizeof(uint64_t));
+	fo_ctx F = {g, nw_keys, keys, l_links, r_flags, count};
+	par_for(0, n, 1 << 16, fo_unpack, &F);
+	GB_PHASE("unpack");
+	const int wide = n >= 0xFFFFFFFEULL || getenv("SDT_WIDE_INDEX") != NULL;
+	uint64_t cap = 1024;
+	while (cap < 2 * n + 2) cap <<= 1;
+	if (wide) {
+		g->index64 = (uint64_t *)calloc(cap, sizeof(uint64_t));
+		if (!g->index64) { printf("out of memory for the node index (%llu entries)\n", (unsigned long long)cap); exit(1); }
+		g->index_mask = cap - 1;
+	}
+	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {
+		GB_PHASE("index (device)");
+		return g;
+	}
+	if (!wide) {
+		g->index = (uint32_t *)calloc(cap, sizeof(uint32_t));
+		g->index_mask = cap - 1;
+	}
+	par_for(0, n, 1 << 14, fo_index, &F);
 	GB_PHASE("index");
 	return g;
 }

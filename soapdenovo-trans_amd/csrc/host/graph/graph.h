@@ -71,6 +71,12 @@ typedef struct graph_s {
 extern int graph_init_kmerset_size;
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first);
+/* the same in two steps when the nodes come grouped by set and ordered by first occurrence (sdt_gpu_layout_sorted_keys): the
+ * replay alone -- order[v] = index into keys[] of the node at visiting position v -- and, once the device has handed the
+ * nodes over in that order (sdt_gpu_layout_apply, sdt_gpu_export_ordered), the graph around them */
+void graph_replay_order(int nw_variant, int nw_keys, int p, const uint64_t *keys, const uint64_t *set_start, uint64_t *order);
+graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys, const uint32_t *l_links,
+                            const uint32_t *r_flags, const uint32_t *count, const uint64_t *set_start);
 void graph_free(graph_t *g);
 /* free() of up to four large blocks on a detached thread (munmap of gigabytes is not free) */
 void graph_free_later(void *a, void *b, void *c, void *d);

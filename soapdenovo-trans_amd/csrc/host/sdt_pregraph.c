@@ -193,7 +193,7 @@ static int arc_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t
 
 /* graph.h dev_walks: bring the device mirror up to date with what the host wrote, then take the walks of every
  * node from it (sdt_gpu_tip_walks) */
-typedef struct { sdt_ctx *gpu; int nwk, indexed; } dev_state;
+typedef struct { sdt_ctx *gpu; int nwk, indexed, by_index; } dev_state;     /* by_index: the device numbered the nodes itself (sdt_gpu_layout_apply) */
 
 static void gather_keys(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
@@ -232,7 +232,7 @@ static void gather_dirty(void *vc, uint64_t lo, uint64_t hi, int tid)
 	const int nwk = (int)(intptr_t)a[4];
 	for (uint64_t j = lo; j < hi; j++) {
 		const gnode_t *nd = &g->nodes[g->dlist[j]];
-		for (int w = 0; w < nwk; w++) k[j * nwk + w] = nd->seq.w[4 - nwk + w];
+		if (k) for (int w = 0; w < nwk; w++) k[j * nwk + w] = nd->seq.w[4 - nwk + w];
 		l[j] = nd->l_links;
 		r[j] = nd->r_links | ((uint32_t)nd->linear << 24) | ((uint32_t)nd->deleted << 25);
 	}
@@ -252,7 +252,14 @@ static int dev_mirror_sync(graph_t *g)
 		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_set_node_index: %s\n", sdt_gpu_last_error()); return 1; }
 		D->indexed = 1;
 	}
-	if (g->dn) {
+	if (g->dn && D->by_index) {                                /* what the host wrote goes over by node index: no keys, no look-ups */
+		uint32_t *l = (uint32_t *)malloc(g->dn * 4), *r = (uint32_t *)malloc(g->dn * 4);
+		void *da[5] = {g, NULL, l, r, (void *)(intptr_t)nwk};
+		par_for(0, g->dn, 1 << 14, gather_dirty, da);
+		const int rc = sdt_gpu_update_nodes_by_index(D->gpu, g->dlist, l, r, g->dn);
+		free(l); free(r);
+		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_update_nodes_by_index: %s\n", sdt_gpu_last_error()); return 1; }
+	} else if (g->dn) {
 		uint64_t *k = (uint64_t *)malloc(g->dn * (size_t)nwk * 8);
 		uint32_t *l = (uint32_t *)malloc(g->dn * 4), *r = (uint32_t *)malloc(g->dn * 4);
 		void *da[5] = {g, k, l, r, (void *)(intptr_t)nwk};
@@ -307,34 +314,24 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
-	uint64_t cap = g->n / 6 + 4096;                        /* junction + candidate records: ~5-10 % of the nodes */
-	for (;;) {
-		uint64_t *rec = (uint64_t *)malloc(cap * 9 * sizeof(uint64_t));
-		if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)cap); return 1; }
-		const int rc = sdt_gpu_minor_out_dry(D->gpu, threshold, rec, cap, nj, nr);
-		if (rc == SDT_OK) { *records = rec; return 0; }
-		free(rec);
-		if (rc == SDT_EFULL && *nr > cap) { cap = *nr; continue; }
-		fprintf(stderr, "sdt_gpu_minor_out_dry: %s\n", sdt_gpu_last_error());
-		return 1;
-	}
+	if (sdt_gpu_minor_out_labelled(D->gpu, threshold, nj, nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_labelled: %s\n", sdt_gpu_last_error()); return 1; }
+	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * 10 * sizeof(uint64_t));
+	if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)*nr); return 1; }
+	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * 10) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
+	*records = rec;
+	return 0;
 }
 
 static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records, uint64_t *nr)
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
-	uint64_t cap = g->n / 8 + 4096;
-	for (;;) {
-		uint64_t *rec = (uint64_t *)malloc(cap * 2 * sizeof(uint64_t));
-		if (!rec) { fprintf(stderr, "out of memory for %llu walk records\n", (unsigned long long)cap); return 1; }
-		const int rc = sdt_gpu_tip_walks_compact(D->gpu, thin, cut_len, rec, cap, nr);
-		if (rc == SDT_OK) { *records = rec; return 0; }
-		free(rec);
-		if (rc == SDT_EFULL && *nr > cap) { cap = *nr; continue; }
-		fprintf(stderr, "sdt_gpu_tip_walks_compact: %s\n", sdt_gpu_last_error());
-		return 1;
-	}
+	if (sdt_gpu_tip_walks_labelled(D->gpu, thin, cut_len, nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_tip_walks_labelled: %s\n", sdt_gpu_last_error()); return 1; }
+	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * 3 * sizeof(uint64_t));
+	if (!rec) { fprintf(stderr, "out of memory for %llu walk records\n", (unsigned long long)*nr); return 1; }
+	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * 3) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
+	*records = rec;
+	return 0;
 }
 
 int main(int argc, char **argv)
@@ -514,8 +511,11 @@ int main(int argc, char **argv)
 		uint64_t n = 0;
 		const int nwk = sdt_gpu_key_words(gpu), nwv = max_k <= 31 ? 1 : (max_k <= 63 ? 2 : 4);
 		if (sdt_gpu_export_nodes(gpu, NULL, NULL, NULL, NULL, NULL, 0, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
-		uint64_t *keys, *first;
+		uint64_t *keys, *first = NULL;
 		uint32_t *ll, *rf, *cnt;
+		graph_t *G = NULL;
+		dev_state *Dp = (dev_state *)calloc(1, sizeof(dev_state));
+		Dp->nwk = nwk;
 		if (gpus > 1) {
 			/* shards -> rank 0.  Every rank learns all shard sizes; ranks > 0 export into a shared-memory segment each and
 			 * leave once rank 0 has taken their nodes (host arrays + its own device table: sdt_gpu_import_nodes) */
@@ -569,28 +569,52 @@ int main(int argc, char **argv)
 				fprintf(stderr, "sdt_gpu_import_nodes: %s\n", sdt_gpu_last_error());
 				return 1;
 			}
+		} else if (!host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT")) {
+			/* the visiting order with the device: it sorts the nodes by (set, first occurrence) and sends the keys, the host
+			 * replays the probing of every set (graph_replay_order), the device numbers the nodes and sends them in that order */
+			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);
+			uint64_t *set_start = (uint64_t *)calloc((size_t)threads + 1, sizeof(uint64_t));
+			if (sdt_gpu_layout_sorted_keys(gpu, threads, nwv, keys, n, set_start, &n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_sorted_keys: %s\n", sdt_gpu_last_error()); return 1; }
+			phase("layout: sort (GPU) + keys D2H");
+			uint64_t *order = (uint64_t *)malloc((n + 1) * 8);
+			graph_replay_order(nwv, nwk, threads, keys, set_start, order);
+			phase("layout: replay (host)");
+			if (sdt_gpu_layout_apply(gpu, order, n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_apply: %s\n", sdt_gpu_last_error()); return 1; }
+			free(order);
+			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
+			if (sdt_gpu_export_ordered(gpu, keys, ll, rf, cnt, n) != SDT_OK) { fprintf(stderr, "sdt_gpu_export_ordered: %s\n", sdt_gpu_last_error()); return 1; }
+			phase("layout: number + export (D2H)");
+			Dp->gpu = gpu; Dp->indexed = 1; Dp->by_index = 1;
+			graph_index_hook = dev_index_hook;
+			graph_index_hook_user = Dp;
+			G = graph_from_ordered(K, nwv, nwk, threads, n, keys, ll, rf, cnt, set_start);
+			graph_free_later(keys, ll, rf, cnt);
+			free(set_start);
+			phase("graph + index");
 		} else {
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
 			if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 		}
-		if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
-		phase("export nodes (D2H)");
-		dev_state D = {gpu, nwk, 0};
-		if (gpu && !host_walks) {
-			graph_index_hook = dev_index_hook;
-			graph_index_hook_user = &D;
+		if (!G) {
+			if (host_map) { sdt_gpu_destroy(gpu); gpu = NULL; }
+			phase("export nodes (D2H)");
+			Dp->gpu = gpu;
+			if (gpu && !host_walks) {
+				graph_index_hook = dev_index_hook;
+				graph_index_hook_user = Dp;
+			}
+			G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
+			graph_free_later(keys, first, ll, rf);
+			free(cnt);
+			phase("layout replay + index (host)");
 		}
-		graph_t *G = graph_build(K, nwv, nwk, threads, n, keys, ll, rf, cnt, first);
-		graph_free_later(keys, first, ll, rf);
-		free(cnt);
-		phase("layout replay + index (host)");
 		if (gpu && !host_walks) {                                          /* dry runs from the device mirror of the graph */
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
 			G->dev_walks = dev_walks_hook;
 			G->dev_minor_out = dev_minor_out_hook;
 			G->dev_edge_ports = dev_edge_ports_hook;
-			G->dev_user = &D;
+			G->dev_user = Dp;
 		}
 		time_t t0 = time(NULL);
 		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
@@ -616,7 +640,7 @@ int main(int argc, char **argv)
 		} else {
 			/* second pass on the GPU over the reads kept in HBM: send the cleaned graph back as path words */
 			/* with the device mirror in place the path words go over by node index; otherwise with their keys */
-			const int by_index = G->dev_walks != NULL && D.indexed;
+			const int by_index = G->dev_walks != NULL && Dp->indexed;
 			uint64_t *pk = by_index ? NULL : (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8), *pw = (uint64_t *)malloc((G->n + 1) * 8);
 			void *pa[4] = {G, pk, pw, (void *)(intptr_t)nwk};
 			par_for(0, G->n, 1 << 16, gather_paths, pa);

@@ -22,9 +22,7 @@
 #include <new>
 #include <thread>
 
-#include "../../include/sdt_gpu.h"
-#include "sdt_kmer.cuh"
-#include "sdt_table.cuh"
+#include "sdt_internal.hpp"
 #include "sdt_superkmer.cuh"
 
 using namespace sdt;
@@ -34,7 +32,7 @@ using namespace sdt;
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int sdti::fail(int code, const char *fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);
@@ -42,19 +40,11 @@ static int fail(int code, const char *fmt, ...)
 	va_end(ap);
 	return code;
 }
-
-#define HIPCHK(expr)                                                                                  \
-	do {                                                                                              \
-		hipError_t e_ = (expr);                                                                       \
-		if (e_ != hipSuccess)                                                                         \
-			return fail(e_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)",   \
-			            #expr, hipGetErrorString(e_), __FILE__, __LINE__);                            \
-	} while (0)
+using sdti::fail;
 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int TPB = 256;           // 4 waves
 constexpr int TILE_READS = 64;     // reads staged per workgroup tile
 
 // Stage reads [r0, r1) of the batch in LDS.  Returns the tile's k-mer count; fills
@@ -483,7 +473,8 @@ struct sdt_ctx {
 	ArcEnt *d_arcs = nullptr;
 	uint64_t arc_slots = 0;
 	bool paths_loaded = false;
-	uint64_t *d_idx = nullptr;         // slot -> index of the node in the host's visiting order (sdt_gpu_set_node_index)
+	uint64_t *d_idx = nullptr;         // slot -> index of the node in the host's visiting order (sdt_gpu_layout_apply / sdt_gpu_set_node_index)
+	sdti::GraphExt *gx = nullptr;      // graph phases (sdt_gpu_graph.hip)
 	uint64_t idx_slots = 0, idx_n = 0;
 	// map stage (SDT_FLAG_CONTIG_INDEX): contig ordinal -> id, contig_array, staging for sdt_gpu_align_reads
 	uint32_t *d_ctg_ids = nullptr;
@@ -1380,7 +1371,6 @@ static int sk_flush_sharded(sdt_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-static int h2d_big(sdt_ctx *c, void *dst, const void *src, size_t bytes);
 
 template <int NW>
 static int build_patch_table(sdt_ctx *c, const uint64_t *pkeys, const uint64_t *pinfo, uint64_t np)
@@ -1516,6 +1506,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_patch) (void)hipFree(c->d_patch);
 	if (c->d_arcs) (void)hipFree(c->d_arcs);
 	if (c->d_idx) (void)hipFree(c->d_idx);
+	if (c->gx) sdti::graph_ext_free(c->gx);
 	if (c->d_ctg_ids) (void)hipFree(c->d_ctg_ids);
 	if (c->d_ctg_len) (void)hipFree(c->d_ctg_len);
 	if (c->d_ctg_twin) (void)hipFree(c->d_ctg_twin);
@@ -2010,8 +2001,8 @@ int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_wo
 		if (!by_index) HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
 		hipError_t e = hipMalloc((void **)&d_i, n * sizeof(uint64_t));
 		if (e != hipSuccess) { if (d_k) (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
-		int rcu = by_index ? SDT_OK : h2d_big(c, d_k, keys, n * c->nw * sizeof(uint64_t));
-		if (rcu == SDT_OK) rcu = h2d_big(c, d_i, path_words, n * sizeof(uint64_t));
+		int rcu = by_index ? SDT_OK : sdti::h2d_big(c->copy_stream, d_k, keys, n * c->nw * sizeof(uint64_t));
+		if (rcu == SDT_OK) rcu = sdti::h2d_big(c->copy_stream, d_i, path_words, n * sizeof(uint64_t));
 		if (rcu != SDT_OK) { if (d_k) (void)hipFree(d_k); (void)hipFree(d_i); return rcu; }
 		if (by_index) {
 			const int g = scan_grid(c, c->slots);
@@ -2147,143 +2138,6 @@ done:
 // Gigabytes from PAGEABLE host memory (the host graph's arrays: 5.4 GB of keys, as much again of path words at 200 M reads): the
 // runtime stages such a copy through one small pinned buffer on one thread, ~2.2 GB/s (2.4 s per array).  Here: two pinned
 // buffers of 64 MiB, filled by four threads while the other one is on the wire.  Synchronous: the source may be freed on return.
-static int h2d_big(sdt_ctx *c, void *dst, const void *src, size_t bytes)
-{
-	const size_t CH = (size_t)64 << 20;
-	if (bytes < 2 * CH) {
-		HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipStreamSynchronize(c->stream));
-		return SDT_OK;
-	}
-	void *pin[2] = {nullptr, nullptr};
-	hipEvent_t done[2] = {nullptr, nullptr};
-	int rc = SDT_OK;
-	for (int i = 0; i < 2 && rc == SDT_OK; i++)
-		if (hipHostMalloc(&pin[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
-			rc = fail(SDT_ENOMEM, "pinned staging for a %zu-byte upload", bytes);
-	int b = 0;
-	bool used[2] = {false, false};
-	for (size_t off = 0; off < bytes && rc == SDT_OK; off += CH, b ^= 1) {
-		const size_t n = bytes - off < CH ? bytes - off : CH;
-		if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "upload: event wait failed"); break; }
-		const int T = 4;
-		std::thread th[T];
-		for (int t = 0; t < T; t++) {
-			const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
-			th[t] = std::thread([=] { memcpy((char *)pin[b] + a0, (const char *)src + off + a0, a1 - a0); });
-		}
-		for (int t = 0; t < T; t++) th[t].join();
-		if (hipMemcpyAsync((char *)dst + off, pin[b], n, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
-		    hipEventRecord(done[b], c->copy_stream) != hipSuccess) { rc = fail(SDT_EHIP, "upload: copy failed"); break; }
-		used[b] = true;
-	}
-	if (hipStreamSynchronize(c->copy_stream) != hipSuccess && rc == SDT_OK) rc = fail(SDT_EHIP, "upload: sync failed");
-	for (int i = 0; i < 2; i++) {
-		if (pin[i]) (void)hipHostFree(pin[i]);
-		if (done[i]) (void)hipEventDestroy(done[i]);
-	}
-	return rc;
-}
-
-// ---- graph-cleaning dry runs on the device mirror of the host graph ---------------------------------------
-static int upload_keys(sdt_ctx *c, const uint64_t *keys, uint64_t n, uint64_t **d_k)
-{
-	HIPCHK(hipMalloc((void **)d_k, (n ? n : 1) * c->nw * sizeof(uint64_t)));
-	const int rc = h2d_big(c, *d_k, keys, n * c->nw * sizeof(uint64_t));
-	if (rc != SDT_OK) { (void)hipFree(*d_k); *d_k = nullptr; }
-	return rc;
-}
-
-int sdt_gpu_set_node_index(sdt_ctx *c, const uint64_t *keys, uint64_t n)
-{
-	if (!c || (n && !keys))
-		return fail(SDT_EINVAL, "NULL argument");
-	HIPCHK(hipSetDevice(c->device));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	if (c->d_idx) HIPCHK(hipFree(c->d_idx));
-	c->d_idx = nullptr;
-	c->idx_slots = c->idx_n = 0;
-	HIPCHK(hipMalloc((void **)&c->d_idx, c->slots * sizeof(uint64_t)));
-	HIPCHK(hipMemsetAsync(c->d_idx, 0xFF, c->slots * sizeof(uint64_t), c->stream));
-	uint64_t *d_k = nullptr;
-	int rc = upload_keys(c, keys, n, &d_k);
-	if (rc != SDT_OK) return rc;
-	const int g = scan_grid(c, n ? n : 1);
-	if (c->nw == 1) hipLaunchKernelGGL(k_set_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, n, c->d_idx, c->d_stats);
-	else if (c->nw == 2) hipLaunchKernelGGL(k_set_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, n, c->d_idx, c->d_stats);
-	else hipLaunchKernelGGL(k_set_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, n, c->d_idx, c->d_stats);
-	hipError_t le = hipGetLastError();
-	rc = le == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "k_set_index: %s", hipGetErrorString(le));
-	(void)hipFree(d_k);
-	if (rc != SDT_OK)
-		return fail(SDT_ESTATE, "sdt_gpu_set_node_index: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
-	c->idx_slots = c->slots;
-	c->idx_n = n;
-	return SDT_OK;
-}
-
-int sdt_gpu_update_nodes(sdt_ctx *c, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n)
-{
-	if (!c || (n && (!keys || !l_links || !r_flags)))
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!n)
-		return SDT_OK;
-	HIPCHK(hipSetDevice(c->device));
-	uint64_t *d_k = nullptr;
-	uint32_t *d_l = nullptr, *d_r = nullptr;
-	int rc = upload_keys(c, keys, n, &d_k);
-	if (rc != SDT_OK) return rc;
-	hipError_t e = hipMalloc((void **)&d_l, n * 4);
-	if (e == hipSuccess) e = hipMalloc((void **)&d_r, n * 4);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_l, l_links, n * 4, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_r, r_flags, n * 4, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess) {
-		const int g = scan_grid(c, n);
-		if (c->nw == 1) hipLaunchKernelGGL(k_update_nodes<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_l, d_r, n, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_update_nodes<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_l, d_r, n, c->d_stats);
-		else hipLaunchKernelGGL(k_update_nodes<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_l, d_r, n, c->d_stats);
-		e = hipGetLastError();
-	}
-	rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_update_nodes: %s", hipGetErrorString(e));
-	(void)hipFree(d_k);
-	if (d_l) (void)hipFree(d_l);
-	if (d_r) (void)hipFree(d_r);
-	if (rc != SDT_OK && e == hipSuccess)
-		return fail(SDT_ESTATE, "sdt_gpu_update_nodes: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
-	return rc;
-}
-
-int sdt_gpu_tip_walks(sdt_ctx *c, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n)
-{
-	if (!c || !end_idx || !info)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!c->d_idx || c->idx_slots != c->slots)
-		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
-	if (n != c->idx_n)
-		return fail(SDT_EINVAL, "the node index holds %llu nodes, the output arrays %llu", (unsigned long long)c->idx_n, (unsigned long long)n);
-	HIPCHK(hipSetDevice(c->device));
-	uint64_t *d_e = nullptr;
-	uint8_t *d_i = nullptr;
-	HIPCHK(hipMalloc((void **)&d_e, (n ? n : 1) * sizeof(uint64_t)));
-	hipError_t e = hipMalloc((void **)&d_i, n ? n : 1);
-	if (e == hipSuccess) {
-		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
-		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, d_e, d_i, c->d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr);
-		e = hipGetLastError();
-	}
-	if (e == hipSuccess) e = hipMemcpyAsync(end_idx, d_e, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(info, d_i, n, hipMemcpyDeviceToHost, c->stream);
-	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks: %s", hipGetErrorString(e));
-	(void)hipFree(d_e);
-	if (d_i) (void)hipFree(d_i);
-	if (rc != SDT_OK && e == hipSuccess)
-		return fail(SDT_ESTATE, "sdt_gpu_tip_walks: %llu walks left the graph (a link points at a k-mer that is not a node)",
-		            (unsigned long long)c->h_stats->probe_fail);
-	return rc;
-}
-
 // ---- map stage: prlContig2nodes / prlRead2Ctg ----------------------------------------------------------------
 static int ab_reserve(sdt_ctx *c, int i, size_t bytes)
 {
@@ -2484,160 +2338,6 @@ int sdt_gpu_align_reads(sdt_ctx *c, const uint32_t *packed_words, uint64_t nword
 	if (got) HIPCHK(hipMemcpyAsync(hits, c->ab[4], got * sizeof(Hit), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return SDT_OK;
-}
-
-int sdt_gpu_minor_out_dry(sdt_ctx *c, double threshold, uint64_t *records, uint64_t max_records, uint64_t *n_junctions, uint64_t *n_records)
-{
-	if (!c || (!records && max_records) || !n_junctions || !n_records)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!c->d_idx || c->idx_slots != c->slots)
-		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
-	HIPCHK(hipSetDevice(c->device));
-	uint8_t *d_need = nullptr, *d_flag = nullptr;
-	uint64_t *d_rec = nullptr;
-	unsigned long long *d_cur = nullptr;
-	unsigned long long h1 = 0, h2 = 0;
-	int ret = SDT_OK;
-	const uint64_t n = c->idx_n ? c->idx_n : 1, m = max_records ? max_records : 1;
-#define MO_CHK(expr) do { hipError_t e5_ = (expr); if (e5_ != hipSuccess) { ret = fail(e5_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e5_)); goto done; } } while (0)
-	MO_CHK(hipMalloc((void **)&d_need, n));
-	MO_CHK(hipMalloc((void **)&d_flag, n));
-	MO_CHK(hipMalloc((void **)&d_rec, m * 9 * sizeof(uint64_t)));
-	MO_CHK(hipMalloc((void **)&d_cur, sizeof(unsigned long long)));
-	MO_CHK(hipMemsetAsync(d_need, 0, n, c->stream));
-	MO_CHK(hipMemsetAsync(d_flag, 0, n, c->stream));
-	MO_CHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream));
-	{
-		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_minor_out_junctions<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_minor_out_junctions<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else hipLaunchKernelGGL(k_minor_out_junctions<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		MO_CHK(hipGetLastError());
-		MO_CHK(hipMemcpyAsync(&h1, d_cur, sizeof h1, hipMemcpyDeviceToHost, c->stream));
-		if (c->nw == 1) hipLaunchKernelGGL(k_minor_out_candidates<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_minor_out_candidates<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else hipLaunchKernelGGL(k_minor_out_candidates<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		MO_CHK(hipGetLastError());
-		MO_CHK(hipMemcpyAsync(&h2, d_cur, sizeof h2, hipMemcpyDeviceToHost, c->stream));
-	}
-	ret = sync_stats(c);
-	if (ret != SDT_OK) {
-		ret = fail(SDT_ESTATE, "sdt_gpu_minor_out_dry: %llu links point at k-mers that are not nodes", (unsigned long long)c->h_stats->probe_fail);
-		goto done;
-	}
-	*n_junctions = h1;
-	*n_records = h2;
-	if (h2 > max_records) {
-		ret = fail(SDT_EFULL, "record array holds %llu, the pass needs %llu", (unsigned long long)max_records, h2);
-		goto done;
-	}
-	if (h2) MO_CHK(hipMemcpy(records, d_rec, h2 * 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-done:
-#undef MO_CHK
-	if (d_need) (void)hipFree(d_need);
-	if (d_flag) (void)hipFree(d_flag);
-	if (d_rec) (void)hipFree(d_rec);
-	if (d_cur) (void)hipFree(d_cur);
-	return ret;
-}
-
-int sdt_gpu_build_host_index(sdt_ctx *c, uint32_t *index, uint64_t index_slots)
-{
-	if (!c || !index)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!c->d_idx || c->idx_slots != c->slots)
-		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
-	if (index_slots < 2 * c->idx_n || (index_slots & (index_slots - 1)))
-		return fail(SDT_EINVAL, "index_slots must be a power of two >= 2 x nodes");
-	if (c->idx_n >= 0xFFFFFFFEULL)
-		return fail(SDT_EINVAL, "%llu nodes do not fit 32-bit index entries", (unsigned long long)c->idx_n);
-	HIPCHK(hipSetDevice(c->device));
-	unsigned int *d_index = nullptr;
-	HIPCHK(hipMalloc((void **)&d_index, index_slots * sizeof(unsigned int)));
-	hipError_t e = hipMemsetAsync(d_index, 0, index_slots * sizeof(unsigned int), c->stream);
-	if (e == hipSuccess) {
-		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_build_host_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_index, index_slots - 1);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_build_host_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, d_index, index_slots - 1);
-		else hipLaunchKernelGGL(k_build_host_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, d_index, index_slots - 1);
-		e = hipGetLastError();
-	}
-	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	(void)hipFree(d_index);
-	if (e != hipSuccess)
-		return fail(SDT_EHIP, "sdt_gpu_build_host_index: %s", hipGetErrorString(e));
-	return SDT_OK;
-}
-
-int sdt_gpu_edge_ports(sdt_ctx *c, uint64_t *records, uint64_t max_records, uint64_t *n_records)
-{
-	if (!c || (!records && max_records) || !n_records)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!c->d_idx || c->idx_slots != c->slots)
-		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
-	HIPCHK(hipSetDevice(c->device));
-	uint64_t *d_rec = nullptr;
-	unsigned long long *d_cur = nullptr, h = 0;
-	const uint64_t m = max_records ? max_records : 1;
-	HIPCHK(hipMalloc((void **)&d_rec, m * 17 * sizeof(uint64_t)));
-	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream);
-	if (e == hipSuccess) {
-		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_edge_ports<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_edge_ports<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		else hipLaunchKernelGGL(k_edge_ports<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, c->idx_n + 1, d_rec, (unsigned long long)max_records, d_cur, c->d_stats);
-		e = hipGetLastError();
-	}
-	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, c->stream);
-	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_edge_ports: %s", hipGetErrorString(e));
-	if (rc != SDT_OK && e == hipSuccess)
-		rc = fail(SDT_ESTATE, "sdt_gpu_edge_ports: %llu chains leave the graph or never end", (unsigned long long)c->h_stats->probe_fail);
-	if (rc == SDT_OK) {
-		*n_records = h;
-		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, the graph has %llu non-linear nodes", (unsigned long long)max_records, h);
-		else if (h && hipMemcpy(records, d_rec, h * 17 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "edge port records: copy failed");
-	}
-	(void)hipFree(d_rec);
-	if (d_cur) (void)hipFree(d_cur);
-	return rc;
-}
-
-int sdt_gpu_tip_walks_compact(sdt_ctx *c, int thin, int cut_len, uint64_t *records, uint64_t max_records, uint64_t *n_records)
-{
-	if (!c || (!records && max_records) || !n_records)
-		return fail(SDT_EINVAL, "NULL argument");
-	if (!c->d_idx || c->idx_slots != c->slots)
-		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
-	if (c->idx_n >= (1ULL << 56))
-		return fail(SDT_EINVAL, "node indices do not fit 56 bits");
-	HIPCHK(hipSetDevice(c->device));
-	uint64_t *d_rec = nullptr;
-	unsigned long long *d_cur = nullptr, h = 0;
-	const uint64_t m = max_records ? max_records : 1;
-	HIPCHK(hipMalloc((void **)&d_rec, m * 2 * sizeof(uint64_t)));
-	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), c->stream);
-	if (e == hipSuccess) {
-		const int g = scan_grid(c, c->slots);
-		if (c->nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
-		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, c->K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, c->d_stats, d_rec, (unsigned long long)max_records, d_cur);
-		e = hipGetLastError();
-	}
-	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, c->stream);
-	int rc = e == hipSuccess ? sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks_compact: %s", hipGetErrorString(e));
-	if (rc != SDT_OK && e == hipSuccess)
-		rc = fail(SDT_ESTATE, "sdt_gpu_tip_walks_compact: %llu walks left the graph", (unsigned long long)c->h_stats->probe_fail);
-	if (rc == SDT_OK) {
-		*n_records = h;
-		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, %llu nodes have a walk", (unsigned long long)max_records, h);
-		else if (h && hipMemcpy(records, d_rec, h * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "tip walk records: copy failed");
-	}
-	(void)hipFree(d_rec);
-	if (d_cur) (void)hipFree(d_cur);
-	return rc;
 }
 
 int sdt_gpu_kernel_time(sdt_ctx *c, int reset, double *ms, uint64_t *launches, uint64_t *kmers)
@@ -3078,3 +2778,95 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 }
 
 } // extern "C"
+
+// ---- what the graph unit (sdt_gpu_graph.hip) sees of a context ----------------------------------------------------
+sdti::GraphView sdti::graph_view(sdt_ctx *c)
+{
+	GraphView v;
+	v.device = c->device; v.K = c->K; v.nw = c->nw; v.cu_count = c->cu_count;
+	v.slots = c->slots;
+	v.d_ent = c->d_ent; v.d_aux = c->d_aux; v.d_first = c->d_first;
+	v.d_stats = c->d_stats; v.h_stats = c->h_stats;
+	v.stream = c->stream; v.copy_stream = c->copy_stream;
+	v.d_idx = &c->d_idx; v.idx_slots = &c->idx_slots; v.idx_n = &c->idx_n;
+	v.gx = &c->gx;
+	return v;
+}
+
+int sdti::sync_stats(sdt_ctx *c) { return ::sync_stats(c); }
+
+int sdti::release_pass1(sdt_ctx *c)
+{
+	const int rc = ::sync_stats(c);
+	if (rc != SDT_OK) return rc;
+	sk_free(c);
+	return SDT_OK;
+}
+
+// pageable host memory <-> device in 64-MiB pieces through pinned staging buffers: a few threads copy between the caller's
+// memory and the staging buffers while the copy engine moves the previous piece (a plain hipMemcpy of pageable memory
+// runs at a third of the link)
+static int big_copy(hipStream_t copy_stream, void *dst, const void *src, size_t bytes, bool to_device)
+{
+	const size_t CH = (size_t)64 << 20;
+	if (bytes < 2 * CH) {
+		if (hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+		    hipStreamSynchronize(copy_stream) != hipSuccess)
+			return fail(SDT_EHIP, "copy of %zu bytes failed", bytes);
+		return SDT_OK;
+	}
+	constexpr int NB = 3, T = 6;
+	void *pin[NB] = {};
+	hipEvent_t done[NB] = {};
+	int rc = SDT_OK;
+	for (int i = 0; i < NB && rc == SDT_OK; i++)
+		if (hipHostMalloc(&pin[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+			rc = fail(SDT_ENOMEM, "pinned staging for a %zu-byte transfer", bytes);
+	auto host_copy = [&](void *d, const void *s, size_t n) {
+		std::thread th[T];
+		for (int t = 0; t < T; t++) {
+			const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
+			th[t] = std::thread([=] { memcpy((char *)d + a0, (const char *)s + a0, a1 - a0); });
+		}
+		for (int t = 0; t < T; t++) th[t].join();
+	};
+	const size_t npieces = (bytes + CH - 1) / CH;
+	if (to_device) {
+		bool used[NB] = {};
+		for (size_t k = 0; k < npieces && rc == SDT_OK; k++) {
+			const int b = (int)(k % NB);
+			const size_t off = k * CH, n = bytes - off < CH ? bytes - off : CH;
+			if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "upload: event wait failed"); break; }
+			host_copy(pin[b], (const char *)src + off, n);
+			if (hipMemcpyAsync((char *)dst + off, pin[b], n, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+			    hipEventRecord(done[b], copy_stream) != hipSuccess) { rc = fail(SDT_EHIP, "upload: copy failed"); break; }
+			used[b] = true;
+		}
+	} else {
+		// piece k + NB - 1 is on the link while the threads drain piece k
+		for (size_t k = 0; k < npieces + NB - 1 && rc == SDT_OK; k++) {
+			if (k >= (size_t)(NB - 1)) {
+				const size_t j = k - (NB - 1);
+				const int b = (int)(j % NB);
+				const size_t off = j * CH, n = bytes - off < CH ? bytes - off : CH;
+				if (hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "download: event wait failed"); break; }
+				host_copy((char *)dst + off, pin[b], n);
+			}
+			if (k < npieces) {
+				const int b = (int)(k % NB);
+				const size_t off = k * CH, n = bytes - off < CH ? bytes - off : CH;
+				if (hipMemcpyAsync(pin[b], (const char *)src + off, n, hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+				    hipEventRecord(done[b], copy_stream) != hipSuccess) { rc = fail(SDT_EHIP, "download: copy failed"); break; }
+			}
+		}
+	}
+	if (hipStreamSynchronize(copy_stream) != hipSuccess && rc == SDT_OK) rc = fail(SDT_EHIP, "transfer: sync failed");
+	for (int i = 0; i < NB; i++) {
+		if (pin[i]) (void)hipHostFree(pin[i]);
+		if (done[i]) (void)hipEventDestroy(done[i]);
+	}
+	return rc;
+}
+
+int sdti::h2d_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes) { return big_copy(copy_stream, dst, src, bytes, true); }
+int sdti::d2h_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes) { return big_copy(copy_stream, dst, src, bytes, false); }

@@ -1,0 +1,650 @@
+// sdt_gpu_graph.hip -- the graph phases of pregraph on the device mirror of the graph (part of libsdt_gpu.so).
+//
+//   layout      sdt_gpu_layout_sorted_keys / sdt_gpu_layout_apply / sdt_gpu_export_ordered: the reference's visiting order
+//               (graph.c replays only the probing of each set; sort, gather and numbering happen here)
+//   dry runs    the read-only halves of removeMinorOut / removeSingleTips / removeMinorTips (cutTipPreGraph.c) and of
+//               kmer2edges (node2edge.c), labelled with the connected components the ordered commits may run side by side
+//               (union-find over node indices), sorted by (component, node)
+// gfx950 only; no CPU fallback.  The context is seen through sdti::GraphView (sdt_internal.hpp).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+#include "sdt_internal.hpp"
+
+using namespace sdt;
+
+#include "sdt_graph_kernels.cuh"
+
+using sdti::fail;
+using sdti::GraphView;
+
+struct sdti::GraphExt {
+	uint64_t *d_sval = nullptr;       // rank in (set, first-occurrence) order -> table slot   (layout_sorted_keys .. layout_apply)
+	uint64_t n_sorted = 0;
+	uint64_t *d_slot_of = nullptr;    // node index (visiting order) -> table slot
+	uint64_t n_nodes = 0;
+	uint64_t *d_result = nullptr;     // records of the last labelled dry run, waiting for sdt_gpu_fetch_records
+	uint64_t result_words = 0;
+};
+
+void sdti::graph_ext_free(GraphExt *gx)
+{
+	if (!gx) return;
+	if (gx->d_sval) (void)hipFree(gx->d_sval);
+	if (gx->d_slot_of) (void)hipFree(gx->d_slot_of);
+	if (gx->d_result) (void)hipFree(gx->d_result);
+	delete gx;
+}
+
+static sdti::GraphExt *ext_of(const GraphView &v)
+{
+	if (!*v.gx) *v.gx = new sdti::GraphExt();
+	return *v.gx;
+}
+
+#define LAUNCH_NW(v, kernel, grid, ...)                                                                                      \
+	do {                                                                                                                     \
+		if ((v).nw == 1) hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(TPB), 0, (v).stream, sdti::table_of<1>(v), __VA_ARGS__);      \
+		else if ((v).nw == 2) hipLaunchKernelGGL(kernel<2>, dim3(grid), dim3(TPB), 0, (v).stream, sdti::table_of<2>(v), __VA_ARGS__); \
+		else hipLaunchKernelGGL(kernel<4>, dim3(grid), dim3(TPB), 0, (v).stream, sdti::table_of<4>(v), __VA_ARGS__);                  \
+	} while (0)
+
+// every device buffer of a call in one place: freed when the call returns, whatever the path
+struct Scratch {
+	void *p[16] = {};
+	int n = 0;
+	template <class T> hipError_t alloc(T **out, size_t bytes)
+	{
+		void *q = nullptr;
+		const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+		if (e == hipSuccess) p[n++] = q;
+		*out = (T *)q;
+		return e;
+	}
+	void *release(void *q)                                    // the caller keeps q
+	{
+		for (int i = 0; i < n; i++) if (p[i] == q) p[i] = nullptr;
+		return q;
+	}
+	~Scratch() { for (int i = 0; i < n; i++) if (p[i]) (void)hipFree(p[i]); }
+};
+
+#define GCHK(expr) do { hipError_t e9_ = (expr); if (e9_ != hipSuccess) return fail(e9_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e9_), __FILE__, __LINE__); } while (0)
+
+// device-wide sort of (key, value) pairs by the key bits [0, end_bit): rocPRIM's radix sort (its temporary storage is the
+// only allocation made here; the caller supplies input and output arrays)
+template <class V>
+static int sort_pairs(const GraphView &v, uint64_t *k_in, uint64_t *k_out, V *v_in, V *v_out, uint64_t n, unsigned end_bit)
+{
+	size_t tmp_bytes = 0;
+	GCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, v.stream));
+	void *tmp = nullptr;
+	GCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+	const hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, end_bit, v.stream);
+	const hipError_t e2 = hipStreamSynchronize(v.stream);
+	(void)hipFree(tmp);
+	if (e != hipSuccess || e2 != hipSuccess) return fail(SDT_EHIP, "radix sort of %llu pairs: %s", (unsigned long long)n, hipGetErrorString(e != hipSuccess ? e : e2));
+	return SDT_OK;
+}
+
+extern "C" {
+
+// ---- layout ---------------------------------------------------------------------------------------------------------
+int sdt_gpu_layout_sorted_keys(sdt_ctx *c, int p, int nw_variant, uint64_t *keys, uint64_t max_nodes, uint64_t *set_start, uint64_t *n_out)
+{
+	if (!c || !n_out) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v0 = sdti::graph_view(c);
+	HIPCHK(hipSetDevice(v0.device));
+	int rc = sdti::release_pass1(c);                          // drains pass 1; its pools are not needed any more
+	if (rc != SDT_OK) return rc;
+	const GraphView v = sdti::graph_view(c);                  // (the drain may have grown the table)
+	const uint64_t n = v.h_stats->distinct;
+	*n_out = n;
+	if (!keys && !set_start) return SDT_OK;
+	if (!keys || !set_start) return fail(SDT_EINVAL, "NULL argument");
+	if (!v.d_first) return fail(SDT_ESTATE, "first-occurrence ordinals were not tracked: init with SDT_FLAG_TRACK_FIRST");
+	if (p < 1 || p > 256) return fail(SDT_EINVAL, "layout on the device: 1..256 sets, asked for %d", p);
+	if (nw_variant < v.nw || nw_variant > 4) return fail(SDT_EINVAL, "a %d-word variant cannot hold %d-word keys", nw_variant, v.nw);
+	if (max_nodes < n) return fail(SDT_EINVAL, "key array holds %llu nodes, the table has %llu", (unsigned long long)max_nodes, (unsigned long long)n);
+	sdti::GraphExt *gx = ext_of(v);
+	if (gx->d_sval) { (void)hipFree(gx->d_sval); gx->d_sval = nullptr; gx->n_sorted = 0; }
+	Scratch S;
+	const uint64_t m = n ? n : 1;
+	uint64_t *k0, *k1, *v0s, *v1s, *d_keys, *d_ss;
+	unsigned long long *d_cur;
+	GCHK(S.alloc(&k0, m * 8)); GCHK(S.alloc(&k1, m * 8)); GCHK(S.alloc(&v0s, m * 8)); GCHK(S.alloc(&v1s, m * 8));
+	GCHK(S.alloc(&d_cur, 8)); GCHK(S.alloc(&d_ss, (size_t)(p + 1) * 8));
+	GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
+	const int g = sdti::scan_grid(v.cu_count, v.slots);
+	LAUNCH_NW(v, k_layout_keys, g, (uint32_t)p, nw_variant, k0, v0s, (unsigned long long)n, d_cur, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "layout: %llu nodes without a usable first-occurrence ordinal (>= 2^56, or more nodes than counted)", (unsigned long long)v.h_stats->probe_fail);
+	unsigned end_bit = 56;
+	for (int q = p - 1; q > 0; q >>= 1) end_bit++;
+	rc = sort_pairs<uint64_t>(v, k0, k1, v0s, v1s, n, end_bit);
+	if (rc != SDT_OK) return rc;
+	hipLaunchKernelGGL(k_layout_set_starts, dim3((p + 1 + 63) / 64), dim3(64), 0, v.stream, k1, n, (uint32_t)p, d_ss);
+	GCHK(hipGetLastError());
+	GCHK(hipMemcpyAsync(set_start, d_ss, (size_t)(p + 1) * 8, hipMemcpyDeviceToHost, v.stream));
+	// k0 is free again: the keys in sorted order go there (NW words each: reuse needs NW * n words)
+	if (v.nw == 1) d_keys = k0; else GCHK(S.alloc(&d_keys, m * v.nw * 8));
+	LAUNCH_NW(v, k_layout_gather_keys, sdti::scan_grid(v.cu_count, m), v1s, n, d_keys);
+	GCHK(hipGetLastError());
+	GCHK(hipStreamSynchronize(v.stream));
+	rc = sdti::d2h_big(v.copy_stream, keys, d_keys, n * v.nw * 8);
+	if (rc != SDT_OK) return rc;
+	gx->d_sval = (uint64_t *)S.release(v1s);
+	gx->n_sorted = n;
+	return SDT_OK;
+}
+
+int sdt_gpu_layout_apply(sdt_ctx *c, const uint64_t *order, uint64_t n)
+{
+	if (!c || (n && !order)) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->d_sval || gx->n_sorted != n) return fail(SDT_ESTATE, "call sdt_gpu_layout_sorted_keys first (it sorted %llu nodes, the order has %llu)", (unsigned long long)gx->n_sorted, (unsigned long long)n);
+	HIPCHK(hipSetDevice(v.device));
+	if (*v.d_idx) { (void)hipFree(*v.d_idx); *v.d_idx = nullptr; }
+	*v.idx_slots = *v.idx_n = 0;
+	if (gx->d_slot_of) { (void)hipFree(gx->d_slot_of); gx->d_slot_of = nullptr; gx->n_nodes = 0; }
+	Scratch S;
+	uint64_t *d_order, *d_idx, *d_slot_of;
+	const uint64_t m = n ? n : 1;
+	GCHK(S.alloc(&d_order, m * 8)); GCHK(S.alloc(&d_idx, v.slots * 8)); GCHK(S.alloc(&d_slot_of, m * 8));
+	GCHK(hipMemsetAsync(d_idx, 0xFF, v.slots * 8, v.stream));
+	int rc = sdti::h2d_big(v.copy_stream, d_order, order, n * 8);
+	if (rc != SDT_OK) return rc;
+	hipLaunchKernelGGL(k_layout_apply, dim3(sdti::scan_grid(v.cu_count, m)), dim3(TPB), 0, v.stream, gx->d_sval, d_order, n, d_idx, d_slot_of, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_EINVAL, "layout order: %llu entries are not ranks below %llu", (unsigned long long)v.h_stats->probe_fail, (unsigned long long)n);
+	*v.d_idx = (uint64_t *)S.release(d_idx);
+	*v.idx_slots = v.slots;
+	*v.idx_n = n;
+	gx->d_slot_of = (uint64_t *)S.release(d_slot_of);
+	gx->n_nodes = n;
+	(void)hipFree(gx->d_sval);
+	gx->d_sval = nullptr;
+	gx->n_sorted = 0;
+	return SDT_OK;
+}
+
+int sdt_gpu_export_ordered(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count, uint64_t n)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->d_slot_of || gx->n_nodes != n) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply first (it numbered %llu nodes, the arrays hold %llu)", (unsigned long long)gx->n_nodes, (unsigned long long)n);
+	HIPCHK(hipSetDevice(v.device));
+	// in pieces of 32 M nodes, double buffered: the kernel of piece k + 1 runs while piece k is on the link
+	const uint64_t PIECE = (uint64_t)32 << 20;
+	Scratch S;
+	uint64_t *dk[2] = {};
+	uint32_t *dl[2] = {}, *dr[2] = {}, *dc[2] = {};
+	hipEvent_t ev[2] = {};
+	for (int b = 0; b < 2; b++) {
+		if (keys) GCHK(S.alloc(&dk[b], PIECE * v.nw * 8));
+		if (l_links) GCHK(S.alloc(&dl[b], PIECE * 4));
+		if (r_flags) GCHK(S.alloc(&dr[b], PIECE * 4));
+		if (count) GCHK(S.alloc(&dc[b], PIECE * 4));
+		GCHK(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+	}
+	int rc = SDT_OK;
+	uint64_t prev0 = 0, prevn = 0;
+	int prevb = -1;
+	for (uint64_t v0 = 0, k = 0; rc == SDT_OK && (v0 < n || prevb >= 0); v0 += PIECE, k++) {
+		const int b = (int)(k & 1);
+		const uint64_t cnt = v0 < n ? (n - v0 < PIECE ? n - v0 : PIECE) : 0;
+		if (cnt) {
+			LAUNCH_NW(v, k_export_ordered, sdti::scan_grid(v.cu_count, cnt), gx->d_slot_of, v0, cnt, dk[b], dl[b], dr[b], dc[b]);
+			if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b], v.stream) != hipSuccess) { rc = fail(SDT_EHIP, "export: launch failed"); break; }
+		}
+		if (prevb >= 0) {
+			if (hipEventSynchronize(ev[prevb]) != hipSuccess) { rc = fail(SDT_EHIP, "export: event wait failed"); break; }
+			if (keys && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, keys + prev0 * v.nw, dk[prevb], prevn * v.nw * 8);
+			if (l_links && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, l_links + prev0, dl[prevb], prevn * 4);
+			if (r_flags && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, r_flags + prev0, dr[prevb], prevn * 4);
+			if (count && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, count + prev0, dc[prevb], prevn * 4);
+		}
+		prevb = cnt ? b : -1;
+		prev0 = v0;
+		prevn = cnt;
+	}
+	for (int b = 0; b < 2; b++) if (ev[b]) (void)hipEventDestroy(ev[b]);
+	return rc;
+}
+
+int sdt_gpu_update_nodes_by_index(sdt_ctx *c, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n)
+{
+	if (!c || (n && (!node || !l_links || !r_flags))) return fail(SDT_EINVAL, "NULL argument");
+	if (!n) return SDT_OK;
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->d_slot_of) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply first");
+	HIPCHK(hipSetDevice(v.device));
+	Scratch S;
+	uint64_t *d_n;
+	uint32_t *d_l, *d_r;
+	GCHK(S.alloc(&d_n, n * 8)); GCHK(S.alloc(&d_l, n * 4)); GCHK(S.alloc(&d_r, n * 4));
+	int rc = sdti::h2d_big(v.copy_stream, d_n, node, n * 8);
+	if (rc == SDT_OK) rc = sdti::h2d_big(v.copy_stream, d_l, l_links, n * 4);
+	if (rc == SDT_OK) rc = sdti::h2d_big(v.copy_stream, d_r, r_flags, n * 4);
+	if (rc != SDT_OK) return rc;
+	LAUNCH_NW(v, k_update_by_index, sdti::scan_grid(v.cu_count, n), gx->d_slot_of, gx->n_nodes, d_n, d_l, d_r, n, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_EINVAL, "sdt_gpu_update_nodes_by_index: %llu indices past the last node", (unsigned long long)v.h_stats->probe_fail);
+	return SDT_OK;
+}
+
+// ---- labelled dry runs ------------------------------------------------------------------------------------------------
+// label the first n_label records (stride words each, node in the low 56 bits of word 0, label into word stride - 1) with the
+// roots of `parent`, sort them by (label, node) and leave all n records in gx->d_result
+static int label_sort_keep(sdt_ctx *c, const GraphView &v, uint32_t *parent, uint64_t *d_rec, uint64_t n, uint64_t n_label, int stride)
+{
+	sdti::GraphExt *gx = ext_of(v);
+	if (gx->d_result) { (void)hipFree(gx->d_result); gx->d_result = nullptr; gx->result_words = 0; }
+	Scratch S;
+	uint64_t *k0, *k1, *d_out;
+	uint32_t *p0, *p1;
+	const uint64_t m = n_label ? n_label : 1;
+	GCHK(S.alloc(&k0, m * 8)); GCHK(S.alloc(&k1, m * 8)); GCHK(S.alloc(&p0, m * 4)); GCHK(S.alloc(&p1, m * 4));
+	GCHK(S.alloc(&d_out, (n ? n : 1) * (size_t)stride * 8));
+	if (n_label) {
+		hipLaunchKernelGGL(k_uf_label, dim3(sdti::scan_grid(v.cu_count, n_label)), dim3(TPB), 0, v.stream, parent, d_rec, n_label, stride, stride - 1, k0, p0);
+		GCHK(hipGetLastError());
+		const int rc = sort_pairs<uint32_t>(v, k0, k1, p0, p1, n_label, 64);
+		if (rc != SDT_OK) return rc;
+		hipLaunchKernelGGL(k_gather_records, dim3(sdti::scan_grid(v.cu_count, n_label * stride)), dim3(TPB), 0, v.stream, d_rec, p1, n_label, stride, d_out);
+		GCHK(hipGetLastError());
+	}
+	if (n > n_label)
+		GCHK(hipMemcpyAsync(d_out + n_label * stride, d_rec + n_label * stride, (n - n_label) * (size_t)stride * 8, hipMemcpyDeviceToDevice, v.stream));
+	GCHK(hipStreamSynchronize(v.stream));
+	(void)c;
+	gx->d_result = (uint64_t *)S.release(d_out);
+	gx->result_words = n * (uint64_t)stride;
+	return SDT_OK;
+}
+
+int sdt_gpu_tip_walks_labelled(sdt_ctx *c, int thin, int cut_len, uint64_t *n_records)
+{
+	if (!c || !n_records) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	if (!*v.d_idx || *v.idx_slots != v.slots) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply (or sdt_gpu_set_node_index) first");
+	const uint64_t nn = *v.idx_n;
+	if (nn >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "component labels are 32-bit node indices: %llu nodes", (unsigned long long)nn);
+	HIPCHK(hipSetDevice(v.device));
+	Scratch S;
+	uint32_t *parent;
+	unsigned long long *d_cur, h = 0;
+	GCHK(S.alloc(&parent, (nn + 1) * 4)); GCHK(S.alloc(&d_cur, 8));
+	hipLaunchKernelGGL(k_uf_init, dim3(sdti::scan_grid(v.cu_count, nn + 1)), dim3(TPB), 0, v.stream, parent, nn + 1);
+	const int g = sdti::scan_grid(v.cu_count, v.slots);
+	uint64_t cap = nn / 8 + 4096;
+	uint64_t *d_rec = nullptr;
+	for (int attempt = 0; attempt < 2; attempt++) {
+		GCHK(S.alloc(&d_rec, cap * 3 * 8));
+		GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
+		LAUNCH_NW(v, k_tip_walks, g, *v.d_idx, v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, d_rec, (unsigned long long)cap, d_cur, 3);
+		GCHK(hipGetLastError());
+		GCHK(hipMemcpyAsync(&h, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
+		const int rc = sdti::sync_stats(c);
+		if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: %llu walks left the graph", (unsigned long long)v.h_stats->probe_fail);
+		if (h <= cap) break;
+		if (attempt) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: the number of walks changed between two runs");
+		(void)hipFree(S.release(d_rec));
+		cap = h;
+	}
+	// components: removeSingleTips -- tip and end node of every walk; removeMinorTips -- the chains a walk can cross
+	if (thin) {
+		if (h) hipLaunchKernelGGL(k_uf_records, dim3(sdti::scan_grid(v.cu_count, h)), dim3(TPB), 0, v.stream, parent, d_rec, (uint64_t)h, 3, 1, 2, 0);
+	} else {
+		LAUNCH_NW(v, k_port_union, g, *v.d_idx, v.K, cut_len, parent, v.d_stats);
+	}
+	GCHK(hipGetLastError());
+	int rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: %llu chains left the graph", (unsigned long long)v.h_stats->probe_fail);
+	rc = label_sort_keep(c, v, parent, d_rec, h, h, 3);
+	if (rc != SDT_OK) return rc;
+	*n_records = h;
+	return SDT_OK;
+}
+
+int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctions, uint64_t *n_records)
+{
+	if (!c || !n_junctions || !n_records) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	if (!*v.d_idx || *v.idx_slots != v.slots) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply (or sdt_gpu_set_node_index) first");
+	const uint64_t nn = *v.idx_n;
+	if (nn >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "component labels are 32-bit node indices: %llu nodes", (unsigned long long)nn);
+	HIPCHK(hipSetDevice(v.device));
+	Scratch S;
+	uint32_t *parent;
+	uint8_t *d_need, *d_flag;
+	unsigned long long *d_cur, h1 = 0, h2 = 0;
+	GCHK(S.alloc(&parent, (nn + 1) * 4)); GCHK(S.alloc(&d_cur, 8));
+	GCHK(S.alloc(&d_need, nn + 1)); GCHK(S.alloc(&d_flag, nn + 1));
+	hipLaunchKernelGGL(k_uf_init, dim3(sdti::scan_grid(v.cu_count, nn + 1)), dim3(TPB), 0, v.stream, parent, nn + 1);
+	const int g = sdti::scan_grid(v.cu_count, v.slots);
+	uint64_t cap = nn / 6 + 4096;
+	uint64_t *d_rec = nullptr;
+	for (int attempt = 0; attempt < 2; attempt++) {
+		GCHK(S.alloc(&d_rec, cap * 10 * 8));
+		GCHK(hipMemsetAsync(d_need, 0, nn + 1, v.stream));
+		GCHK(hipMemsetAsync(d_flag, 0, nn + 1, v.stream));
+		GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
+		LAUNCH_NW(v, k_minor_out_junctions, g, *v.d_idx, v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 10);
+		GCHK(hipGetLastError());
+		GCHK(hipMemcpyAsync(&h1, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
+		LAUNCH_NW(v, k_minor_out_candidates, g, *v.d_idx, v.K, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 10);
+		GCHK(hipGetLastError());
+		GCHK(hipMemcpyAsync(&h2, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
+		const int rc = sdti::sync_stats(c);
+		if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_minor_out_labelled: %llu links point at k-mers that are not nodes", (unsigned long long)v.h_stats->probe_fail);
+		if (h2 <= cap) break;
+		if (attempt) return fail(SDT_ESTATE, "sdt_gpu_minor_out_labelled: the number of records changed between two runs");
+		(void)hipFree(S.release(d_rec));
+		cap = h2;
+	}
+	// a visit reads and writes its junction, the junction's neighbours and the neighbours of those it may cut: unite every record's
+	// node with its eight neighbours (junction records and the records of the neighbours to cut alike)
+	if (h2) hipLaunchKernelGGL(k_uf_records, dim3(sdti::scan_grid(v.cu_count, h2)), dim3(TPB), 0, v.stream, parent, d_rec, (uint64_t)h2, 10, 1, 9, 1);
+	GCHK(hipGetLastError());
+	const int rc = label_sort_keep(c, v, parent, d_rec, h2, h1, 10);
+	if (rc != SDT_OK) return rc;
+	*n_junctions = h1;
+	*n_records = h2;
+	return SDT_OK;
+}
+
+int sdt_gpu_fetch_records(sdt_ctx *c, uint64_t *dst, uint64_t nwords)
+{
+	if (!c || (nwords && !dst)) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (nwords != gx->result_words) return fail(SDT_EINVAL, "the last dry run left %llu words, asked for %llu", (unsigned long long)gx->result_words, (unsigned long long)nwords);
+	HIPCHK(hipSetDevice(v.device));
+	int rc = SDT_OK;
+	if (nwords) rc = sdti::d2h_big(v.copy_stream, dst, gx->d_result, nwords * 8);
+	if (gx->d_result) (void)hipFree(gx->d_result);
+	gx->d_result = nullptr;
+	gx->result_words = 0;
+	return rc;
+}
+
+// ---- graph-cleaning dry runs on the device mirror of the host graph ---------------------------------------
+static int upload_keys(sdt_ctx *c, const uint64_t *keys, uint64_t n, uint64_t **d_k)
+{
+	const GraphView v = sdti::graph_view(c);
+	HIPCHK(hipMalloc((void **)d_k, (n ? n : 1) * v.nw * sizeof(uint64_t)));
+	const int rc = sdti::h2d_big(v.copy_stream, *d_k, keys, n * v.nw * sizeof(uint64_t));
+	if (rc != SDT_OK) { (void)hipFree(*d_k); *d_k = nullptr; }
+	return rc;
+}
+
+int sdt_gpu_set_node_index(sdt_ctx *c, const uint64_t *keys, uint64_t n)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || (n && !keys))
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(v.device));
+	HIPCHK(hipStreamSynchronize(v.stream));
+	if ((*v.d_idx)) HIPCHK(hipFree((*v.d_idx)));
+	(*v.d_idx) = nullptr;
+	(*v.idx_slots) = (*v.idx_n) = 0;
+	HIPCHK(hipMalloc((void **)&(*v.d_idx), v.slots * sizeof(uint64_t)));
+	HIPCHK(hipMemsetAsync((*v.d_idx), 0xFF, v.slots * sizeof(uint64_t), v.stream));
+	uint64_t *d_k = nullptr;
+	int rc = upload_keys(c, keys, n, &d_k);
+	if (rc != SDT_OK) return rc;
+	const int g = sdti::scan_grid(v.cu_count, n ? n : 1);
+	if (v.nw == 1) hipLaunchKernelGGL(k_set_index<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), d_k, n, (*v.d_idx), v.d_stats);
+	else if (v.nw == 2) hipLaunchKernelGGL(k_set_index<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), d_k, n, (*v.d_idx), v.d_stats);
+	else hipLaunchKernelGGL(k_set_index<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), d_k, n, (*v.d_idx), v.d_stats);
+	hipError_t le = hipGetLastError();
+	rc = le == hipSuccess ? sdti::sync_stats(c) : fail(SDT_EHIP, "k_set_index: %s", hipGetErrorString(le));
+	(void)hipFree(d_k);
+	if (rc != SDT_OK)
+		return fail(SDT_ESTATE, "sdt_gpu_set_node_index: %llu nodes are not in the table", (unsigned long long)v.h_stats->probe_fail);
+	(*v.idx_slots) = v.slots;
+	(*v.idx_n) = n;
+	return SDT_OK;
+}
+
+int sdt_gpu_update_nodes(sdt_ctx *c, const uint64_t *keys, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || (n && (!keys || !l_links || !r_flags)))
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!n)
+		return SDT_OK;
+	HIPCHK(hipSetDevice(v.device));
+	uint64_t *d_k = nullptr;
+	uint32_t *d_l = nullptr, *d_r = nullptr;
+	int rc = upload_keys(c, keys, n, &d_k);
+	if (rc != SDT_OK) return rc;
+	hipError_t e = hipMalloc((void **)&d_l, n * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&d_r, n * 4);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_l, l_links, n * 4, hipMemcpyHostToDevice, v.stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_r, r_flags, n * 4, hipMemcpyHostToDevice, v.stream);
+	if (e == hipSuccess) {
+		const int g = sdti::scan_grid(v.cu_count, n);
+		if (v.nw == 1) hipLaunchKernelGGL(k_update_nodes<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), d_k, d_l, d_r, n, v.d_stats);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_update_nodes<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), d_k, d_l, d_r, n, v.d_stats);
+		else hipLaunchKernelGGL(k_update_nodes<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), d_k, d_l, d_r, n, v.d_stats);
+		e = hipGetLastError();
+	}
+	rc = e == hipSuccess ? sdti::sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_update_nodes: %s", hipGetErrorString(e));
+	(void)hipFree(d_k);
+	if (d_l) (void)hipFree(d_l);
+	if (d_r) (void)hipFree(d_r);
+	if (rc != SDT_OK && e == hipSuccess)
+		return fail(SDT_ESTATE, "sdt_gpu_update_nodes: %llu nodes are not in the table", (unsigned long long)v.h_stats->probe_fail);
+	return rc;
+}
+
+int sdt_gpu_tip_walks(sdt_ctx *c, int thin, int cut_len, uint64_t *end_idx, uint8_t *info, uint64_t n)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || !end_idx || !info)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!(*v.d_idx) || (*v.idx_slots) != v.slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if (n != (*v.idx_n))
+		return fail(SDT_EINVAL, "the node index holds %llu nodes, the output arrays %llu", (unsigned long long)(*v.idx_n), (unsigned long long)n);
+	HIPCHK(hipSetDevice(v.device));
+	uint64_t *d_e = nullptr;
+	uint8_t *d_i = nullptr;
+	HIPCHK(hipMalloc((void **)&d_e, (n ? n : 1) * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_i, n ? n : 1);
+	if (e == hipSuccess) {
+		const int g = sdti::scan_grid(v.cu_count, v.slots);
+		if (v.nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), v.K, thin, cut_len, d_e, d_i, v.d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr, 2);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), v.K, thin, cut_len, d_e, d_i, v.d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr, 2);
+		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), v.K, thin, cut_len, d_e, d_i, v.d_stats, (uint64_t *)nullptr, 0ULL, (unsigned long long *)nullptr, 2);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(end_idx, d_e, n * sizeof(uint64_t), hipMemcpyDeviceToHost, v.stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(info, d_i, n, hipMemcpyDeviceToHost, v.stream);
+	int rc = e == hipSuccess ? sdti::sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks: %s", hipGetErrorString(e));
+	(void)hipFree(d_e);
+	if (d_i) (void)hipFree(d_i);
+	if (rc != SDT_OK && e == hipSuccess)
+		return fail(SDT_ESTATE, "sdt_gpu_tip_walks: %llu walks left the graph (a link points at a k-mer that is not a node)",
+		            (unsigned long long)v.h_stats->probe_fail);
+	return rc;
+}
+
+
+int sdt_gpu_minor_out_dry(sdt_ctx *c, double threshold, uint64_t *records, uint64_t max_records, uint64_t *n_junctions, uint64_t *n_records)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || (!records && max_records) || !n_junctions || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!(*v.d_idx) || (*v.idx_slots) != v.slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	HIPCHK(hipSetDevice(v.device));
+	uint8_t *d_need = nullptr, *d_flag = nullptr;
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr;
+	unsigned long long h1 = 0, h2 = 0;
+	int ret = SDT_OK;
+	const uint64_t n = (*v.idx_n) ? (*v.idx_n) : 1, m = max_records ? max_records : 1;
+#define MO_CHK(expr) do { hipError_t e5_ = (expr); if (e5_ != hipSuccess) { ret = fail(e5_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s: %s", #expr, hipGetErrorString(e5_)); goto done; } } while (0)
+	MO_CHK(hipMalloc((void **)&d_need, n));
+	MO_CHK(hipMalloc((void **)&d_flag, n));
+	MO_CHK(hipMalloc((void **)&d_rec, m * 9 * sizeof(uint64_t)));
+	MO_CHK(hipMalloc((void **)&d_cur, sizeof(unsigned long long)));
+	MO_CHK(hipMemsetAsync(d_need, 0, n, v.stream));
+	MO_CHK(hipMemsetAsync(d_flag, 0, n, v.stream));
+	MO_CHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), v.stream));
+	{
+		const int g = sdti::scan_grid(v.cu_count, v.slots);
+		if (v.nw == 1) hipLaunchKernelGGL(k_minor_out_junctions<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_minor_out_junctions<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		else hipLaunchKernelGGL(k_minor_out_junctions<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		MO_CHK(hipGetLastError());
+		MO_CHK(hipMemcpyAsync(&h1, d_cur, sizeof h1, hipMemcpyDeviceToHost, v.stream));
+		if (v.nw == 1) hipLaunchKernelGGL(k_minor_out_candidates<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), v.K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_minor_out_candidates<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), v.K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		else hipLaunchKernelGGL(k_minor_out_candidates<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), v.K, d_need, d_flag, d_rec, (unsigned long long)max_records, d_cur, v.d_stats, 9);
+		MO_CHK(hipGetLastError());
+		MO_CHK(hipMemcpyAsync(&h2, d_cur, sizeof h2, hipMemcpyDeviceToHost, v.stream));
+	}
+	ret = sdti::sync_stats(c);
+	if (ret != SDT_OK) {
+		ret = fail(SDT_ESTATE, "sdt_gpu_minor_out_dry: %llu links point at k-mers that are not nodes", (unsigned long long)v.h_stats->probe_fail);
+		goto done;
+	}
+	*n_junctions = h1;
+	*n_records = h2;
+	if (h2 > max_records) {
+		ret = fail(SDT_EFULL, "record array holds %llu, the pass needs %llu", (unsigned long long)max_records, h2);
+		goto done;
+	}
+	if (h2) MO_CHK(hipMemcpy(records, d_rec, h2 * 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+done:
+#undef MO_CHK
+	if (d_need) (void)hipFree(d_need);
+	if (d_flag) (void)hipFree(d_flag);
+	if (d_rec) (void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return ret;
+}
+
+int sdt_gpu_build_host_index(sdt_ctx *c, uint32_t *index, uint64_t index_slots)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || !index)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!(*v.d_idx) || (*v.idx_slots) != v.slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if (index_slots < 2 * (*v.idx_n) || (index_slots & (index_slots - 1)))
+		return fail(SDT_EINVAL, "index_slots must be a power of two >= 2 x nodes");
+	if ((*v.idx_n) >= 0xFFFFFFFEULL)
+		return fail(SDT_EINVAL, "%llu nodes do not fit 32-bit index entries", (unsigned long long)(*v.idx_n));
+	HIPCHK(hipSetDevice(v.device));
+	unsigned int *d_index = nullptr;
+	HIPCHK(hipMalloc((void **)&d_index, index_slots * sizeof(unsigned int)));
+	hipError_t e = hipMemsetAsync(d_index, 0, index_slots * sizeof(unsigned int), v.stream);
+	if (e == hipSuccess) {
+		const int g = sdti::scan_grid(v.cu_count, v.slots);
+		if (v.nw == 1) hipLaunchKernelGGL(k_build_host_index<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), d_index, index_slots - 1);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_build_host_index<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), d_index, index_slots - 1);
+		else hipLaunchKernelGGL(k_build_host_index<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), d_index, index_slots - 1);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned int), hipMemcpyDeviceToHost, v.stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(v.stream);
+	(void)hipFree(d_index);
+	if (e != hipSuccess)
+		return fail(SDT_EHIP, "sdt_gpu_build_host_index: %s", hipGetErrorString(e));
+	return SDT_OK;
+}
+
+int sdt_gpu_edge_ports(sdt_ctx *c, uint64_t *records, uint64_t max_records, uint64_t *n_records)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || (!records && max_records) || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!(*v.d_idx) || (*v.idx_slots) != v.slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	HIPCHK(hipSetDevice(v.device));
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr, h = 0;
+	const uint64_t m = max_records ? max_records : 1;
+	HIPCHK(hipMalloc((void **)&d_rec, m * 17 * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), v.stream);
+	if (e == hipSuccess) {
+		const int g = sdti::scan_grid(v.cu_count, v.slots);
+		if (v.nw == 1) hipLaunchKernelGGL(k_edge_ports<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), v.K, (*v.idx_n) + 1, d_rec, (unsigned long long)max_records, d_cur, v.d_stats);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_edge_ports<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), v.K, (*v.idx_n) + 1, d_rec, (unsigned long long)max_records, d_cur, v.d_stats);
+		else hipLaunchKernelGGL(k_edge_ports<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), v.K, (*v.idx_n) + 1, d_rec, (unsigned long long)max_records, d_cur, v.d_stats);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, v.stream);
+	int rc = e == hipSuccess ? sdti::sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_edge_ports: %s", hipGetErrorString(e));
+	if (rc != SDT_OK && e == hipSuccess)
+		rc = fail(SDT_ESTATE, "sdt_gpu_edge_ports: %llu chains leave the graph or never end", (unsigned long long)v.h_stats->probe_fail);
+	if (rc == SDT_OK) {
+		*n_records = h;
+		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, the graph has %llu non-linear nodes", (unsigned long long)max_records, h);
+		else if (h && hipMemcpy(records, d_rec, h * 17 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "edge port records: copy failed");
+	}
+	(void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return rc;
+}
+
+int sdt_gpu_tip_walks_compact(sdt_ctx *c, int thin, int cut_len, uint64_t *records, uint64_t max_records, uint64_t *n_records)
+{
+	if (!c) return fail(SDT_EINVAL, "ctx is NULL");
+	const GraphView v = sdti::graph_view(c);
+	if (!c || (!records && max_records) || !n_records)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!(*v.d_idx) || (*v.idx_slots) != v.slots)
+		return fail(SDT_ESTATE, "call sdt_gpu_set_node_index first");
+	if ((*v.idx_n) >= (1ULL << 56))
+		return fail(SDT_EINVAL, "node indices do not fit 56 bits");
+	HIPCHK(hipSetDevice(v.device));
+	uint64_t *d_rec = nullptr;
+	unsigned long long *d_cur = nullptr, h = 0;
+	const uint64_t m = max_records ? max_records : 1;
+	HIPCHK(hipMalloc((void **)&d_rec, m * 2 * sizeof(uint64_t)));
+	hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, sizeof(unsigned long long), v.stream);
+	if (e == hipSuccess) {
+		const int g = sdti::scan_grid(v.cu_count, v.slots);
+		if (v.nw == 1) hipLaunchKernelGGL(k_tip_walks<1>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<1>(v), (*v.d_idx), v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, d_rec, (unsigned long long)max_records, d_cur, 2);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_tip_walks<2>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<2>(v), (*v.d_idx), v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, d_rec, (unsigned long long)max_records, d_cur, 2);
+		else hipLaunchKernelGGL(k_tip_walks<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, d_rec, (unsigned long long)max_records, d_cur, 2);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&h, d_cur, sizeof h, hipMemcpyDeviceToHost, v.stream);
+	int rc = e == hipSuccess ? sdti::sync_stats(c) : fail(SDT_EHIP, "sdt_gpu_tip_walks_compact: %s", hipGetErrorString(e));
+	if (rc != SDT_OK && e == hipSuccess)
+		rc = fail(SDT_ESTATE, "sdt_gpu_tip_walks_compact: %llu walks left the graph", (unsigned long long)v.h_stats->probe_fail);
+	if (rc == SDT_OK) {
+		*n_records = h;
+		if (h > max_records) rc = fail(SDT_EFULL, "record array holds %llu, %llu nodes have a walk", (unsigned long long)max_records, h);
+		else if (h && hipMemcpy(records, d_rec, h * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SDT_EHIP, "tip walk records: copy failed");
+	}
+	(void)hipFree(d_rec);
+	if (d_cur) (void)hipFree(d_cur);
+	return rc;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,673 @@
+// sdt_graph_kernels.cuh -- the graph phases of pregraph on the device mirror of the graph (cutTipPreGraph.c, node2edge.c):
+// layout (visiting order of the reference's tables), read-only dry runs of the cutting passes, components of the commits
+// (union-find), port walks of kmer2edges.  Included by sdt_gpu_graph.hip .
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------------------
+// Graph-cleaning dry runs on the device (cutTipPreGraph.c).  The host owns the ORDER (layout replay, ordered commit
+// of the few visits that write); what it needs from a sweep is the read-only part -- the walks -- and those are
+// table look-ups, which this chip does at tens of G/s.  The device table mirrors the host graph: the host sends
+// back the nodes it wrote (k_update_nodes) -- the nodes its own
+// Mark1in1outNode marked included -- and the index each node has in its visiting order (k_set_index).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW> __device__ inline bool find_slot(const Table<NW> &tbl, const Key<NW> &k, uint64_t &slot_out)
+{
+	uint64_t slot = key_hash<NW>(k) & tbl.mask;
+	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
+		const Entry<NW> *e = tbl.ent + slot;
+		if (e->key[0] == KEY_EMPTY)
+			return false;
+		bool same = true;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			same = same && e->key[w] == k.w[w];
+		if (same) {
+			slot_out = slot;
+			return true;
+		}
+	}
+	return false;
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_set_index(Table<NW> tbl, const uint64_t *__restrict__ keys, uint64_t n,
+                                                   uint64_t *__restrict__ idx, Stats *stats)
+{
+	uint32_t failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> k;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			k.w[w] = keys[i * NW + w];
+		uint64_t slot;
+		if (find_slot<NW>(tbl, k, slot)) idx[slot] = i;
+		else failed++;
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+// links + flags of the given nodes as the host has them now (count is never changed by the cleaning passes)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_update_nodes(Table<NW> tbl, const uint64_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ l_links, const uint32_t *__restrict__ r_flags,
+                                                      uint64_t n, Stats *stats)
+{
+	uint32_t failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> k;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			k.w[w] = keys[i * NW + w];
+		uint64_t slot;
+		if (!find_slot<NW>(tbl, k, slot)) { failed++; continue; }
+		const uint64_t v = tbl.ent[slot].val;
+		tbl.ent[slot].val = (v & 0xFFFF000000000000ULL) | ((uint64_t)(r_flags[i] & 0xFFFFFFu) << 24) | (uint64_t)(l_links[i] & 0xFFFFFFu);
+		const uint32_t a = tbl.aux[slot] & 0xFFFFu;
+		tbl.aux[slot] = a | ((r_flags[i] >> 24 & 1u) ? AUX_LINEAR : 0u) | ((r_flags[i] >> 25 & 1u) ? AUX_DELETED : 0u);
+	}
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+__device__ inline uint32_t dev_degree(uint64_t links24)
+{
+	uint32_t d = 0;
+#pragma unroll
+	for (int b = 0; b < 4; b++)
+		d += ((links24 >> (6 * b)) & 63u) != 0;
+	return d;
+}
+__device__ inline uint32_t first_link(uint64_t links24)
+{
+	uint32_t b = 0;
+	while (b < 4 && ((links24 >> (6 * b)) & 63u) == 0) b++;
+	return b;
+}
+
+template <int NW> __device__ inline Key<NW> key_next_masked(const Key<NW> &k, uint32_t b, const Key<NW> &mask)
+{
+	Key<NW> r = key_append<NW>(k, b);
+#pragma unroll
+	for (int i = 0; i < NW; i++)
+		r.w[i] &= mask.w[i];
+	return r;
+}
+
+// the walk of clipTipFromNode (cutTipPreGraph.c:43-281) from every node, read-only.  Output, at the HOST index of
+// the node: end = host index of the node the walk stopped at (~0 = nothing to decide), info = ch | sm << 2 |
+// thin_stop << 3 (the base by which the end node sees the chain, the strand on which it was reached).
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
+                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
+                                                   uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
+                                                   unsigned long long *cursor = nullptr, int rec_stride = 2)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		const uint64_t me = idx[s];
+		if (end_out) {
+			end_out[me] = ~0ULL;
+			info_out[me] = 0;
+		}
+		const uint32_t a = tbl.aux[s];
+		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
+		const bool single = (e.val >> 48) == 1 && (a & 0xFFFFu) == 0;
+		if (thin && !single) continue;
+		const uint64_t ll = e.val & 0xFFFFFFu, rl = (e.val >> 24) & 0xFFFFFFu;
+		const uint32_t in = dev_degree(ll), out = dev_degree(rl);
+		Key<NW> at;
+#pragma unroll
+		for (int w = 0; w < NW; w++) at.w[w] = e.key[w];
+		uint32_t b;
+		if (in == 0 && out == 1) {
+			b = first_link(rl);
+		} else if (in == 1 && out == 0) {
+			at = key_revcomp<NW>(at, K);
+			b = first_link(ll) ^ 2u;
+		} else {
+			continue;
+		}
+		int steps = 1;
+		uint32_t thin_stop = 0;
+		bool give_up = false;
+		Key<NW> step = key_next_masked<NW>(at, b, mask);
+		Key<NW> bal = key_revcomp<NW>(step, K);
+		bool sm = !key_less<NW>(bal, step);               // KmerLarger(word, bal) -> take bal, smaller = 0
+		uint64_t os;
+		if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; continue; }
+		for (;;) {
+			const uint32_t oa = tbl.aux[os];
+			if (!(oa & AUX_LINEAR)) break;
+			steps++;
+			const uint64_t ov = tbl.ent[os].val;
+			if (thin && !((ov >> 48) == 1 && (oa & 0xFFFFu) == 0)) { thin_stop = 1; break; }
+			if (steps > cut_len) { give_up = true; break; }
+			at = step;
+			b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+			step = key_next_masked<NW>(at, b, mask);
+			bal = key_revcomp<NW>(step, K);
+			sm = !key_less<NW>(bal, step);
+			if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; give_up = true; break; }
+		}
+		if (give_up) continue;
+		// first base of `at`: bits 2(K-1)..2(K-1)+1 of the NW-word value
+		const int tb = 2 * (K - 1);
+		uint32_t ch = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			if (w == NW - 1 - (tb >> 6)) ch = (uint32_t)(at.w[w] >> (tb & 63)) & 3u;
+		const uint32_t inf = ch | ((uint32_t)sm << 2) | (thin_stop << 3);
+		if (end_out) {
+			end_out[me] = idx[os];
+			info_out[me] = (uint8_t)inf;
+		} else {                                             // compact: only the nodes that have a walk, in any order
+			const unsigned long long r = atomicAdd(cursor, 1ULL);
+			if (r < max_rec) {
+				rec[rec_stride * r] = me | ((uint64_t)inf << 56);
+				rec[rec_stride * r + 1] = idx[os];
+			}
+		}
+	}
+	if (missing)
+		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// removeMinorOut's read-only part (cutTipPreGraph.c:1012-1076, clipKmerFromNode :591-1010, getmaxofprev/next :439-589)
+// on the device mirror: for every junction (in > 1 or out > 1, not linear, not deleted) look its neighbours up,
+// take the largest occurrence count per branching side and flag the neighbours whose count / max is under the
+// threshold.  Links only disappear during the pass, so the cuts the ordered commit really makes are a subset of
+// these; the host needs, per flagged junction and per flagged neighbour, who their neighbours ARE -- which never
+// changes -- to run that commit without a single hash look-up.
+// Record = 9 words: host index of the node, then (neighbour host index << 1 | smaller) or ~0 for LEFT 0..3, RIGHT 0..3.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW> __device__ inline Key<NW> key_prev_base(const Key<NW> &k, uint32_t b, int K)
+{
+	Key<NW> r = key_shr<NW>(k, 2);
+	const int tb = 2 * (K - 1);
+#pragma unroll
+	for (int w = 0; w < NW; w++)
+		if (w == NW - 1 - (tb >> 6)) r.w[w] |= (uint64_t)b << (tb & 63);
+	return r;
+}
+
+template <int NW>
+__device__ inline void neighbours_of(const Table<NW> &tbl, const uint64_t *__restrict__ idx, const Entry<NW> &e, int K, const Key<NW> &mask,
+                                     uint64_t out[8], uint32_t cnt[8], uint32_t &missing)
+{
+	Key<NW> me;
+#pragma unroll
+	for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+#pragma unroll
+	for (int side = 0; side < 2; side++)
+#pragma unroll
+		for (uint32_t b = 0; b < 4; b++) {
+			const int q = side * 4 + (int)b;
+			out[q] = ~0ULL;
+			cnt[q] = 0;
+			if (!((e.val >> (24 * side + 6 * b)) & 63u)) continue;
+			const Key<NW> word = side == 0 ? key_prev_base<NW>(me, b, K) : key_next_masked<NW>(me, b, mask);
+			const Key<NW> bal = key_revcomp<NW>(word, K);
+			const bool sm = !key_less<NW>(bal, word);
+			uint64_t ns;
+			if (!find_slot<NW>(tbl, sm ? word : bal, ns)) { missing++; continue; }
+			out[q] = (idx[ns] << 1) | (uint64_t)sm;
+			cnt[q] = (uint32_t)(tbl.ent[ns].val >> 48) | ((tbl.aux[ns] & 0xFFFFu) << 16);
+		}
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, double threshold,
+                                                             uint8_t *__restrict__ need, uint8_t *__restrict__ flagged,
+                                                             uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
+                                                             Stats *stats, int rec_stride = 9)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
+		const uint32_t in = dev_degree(e.val & 0xFFFFFFu), out = dev_degree((e.val >> 24) & 0xFFFFFFu);
+		if (in <= 1 && out <= 1) continue;
+		uint64_t nb[8];
+		uint32_t cnt[8];
+		neighbours_of<NW>(tbl, idx, e, K, mask, nb, cnt, missing);
+		bool any = false;
+#pragma unroll
+		for (int side = 0; side < 2; side++) {
+			if ((side == 0 ? in : out) <= 1) continue;
+			int best = 0;
+#pragma unroll
+			for (int b = 0; b < 4; b++)
+				if (nb[side * 4 + b] != ~0ULL && (int)cnt[side * 4 + b] > best) best = (int)cnt[side * 4 + b];
+			if (!best) continue;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int c = (int)cnt[side * 4 + b];
+				if (nb[side * 4 + b] != ~0ULL && c && (double)c / best < threshold) {
+					need[nb[side * 4 + b] >> 1] = 1;
+					any = true;
+				}
+			}
+		}
+		if (!any) continue;
+		const uint64_t me = idx[s];
+		flagged[me] = 1;
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		if (r < max_rec) {
+			rec[r * rec_stride] = me;
+#pragma unroll
+			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+// neighbours of the flagged neighbours (isolate() walks them), unless the node already has a junction record
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, const uint64_t *__restrict__ idx, int K,
+                                                              const uint8_t *__restrict__ need, const uint8_t *__restrict__ flagged,
+                                                              uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
+                                                              Stats *stats, int rec_stride = 9)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		const uint64_t me = idx[s];
+		if (!need[me] || flagged[me]) continue;
+		uint64_t nb[8];
+		uint32_t cnt[8];
+		neighbours_of<NW>(tbl, idx, e, K, mask, nb, cnt, missing);
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		if (r < max_rec) {
+			rec[r * rec_stride] = me;
+#pragma unroll
+			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+
+// the host's own look-up index over its node array (csrc/host/graph/graph.c: open addressing on mix_key of the
+// 4-word k-mer, 32-bit value = node index + 1), built here because the device already knows every node's index
+__device__ inline uint64_t host_mix_key4(const uint64_t w[4])
+{
+	uint64_t h = 0x9E3779B97F4A7C15ULL;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		h ^= w[i];
+		h ^= h >> 32; h *= 0xD6E8FEB86659FD93ULL; h ^= h >> 32;
+	}
+	return h;
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const uint64_t *__restrict__ idx, unsigned int *__restrict__ index,
+                                                          uint64_t index_mask)
+{
+	const uint64_t slots = tbl.mask + 1;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
+		uint64_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int i = 0; i < NW; i++) w[4 - NW + i] = tbl.ent[s].key[i];
+		uint64_t h = host_mix_key4(w) & index_mask;
+		const unsigned int v = (unsigned int)(idx[s] + 1);
+		while (atomicCAS(&index[h], 0u, v) != 0u) h = (h + 1) & index_mask;
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// kmer2edges' read-only part (node2edge.c:46-191, stringBeads): from every node that is neither linear nor deleted,
+// over each of its 8 ports (right links 0..3 on the stored strand, then left links 0..3 on the reverse strand) follow
+// the chain of linear nodes to the first non-linear node.  Per port: the host index of that node, the port the chain
+// arrives through, the chain length and whether the chain is its own reverse complement (bal_edge = 0,
+// check_iden_kmerList :563-588).  The walk is forced after its first step, so the k-mer list equals its own
+// reversed complement list exactly when the last k-mer is the complement of the first AND the second-to-last is the
+// complement of the second -- four k-mers instead of the list.
+// Record = 17 words: node index, then per port (far node index or ~0, length | far_port << 32 | bal_edge << 40).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_edge_ports(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, uint64_t max_steps,
+                                                    uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	const int tb = 2 * (K - 1);
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
+		const unsigned long long r = atomicAdd(cursor, 1ULL);
+		const bool keep = r < max_rec;
+		if (keep) rec[r * 17] = idx[s];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+		const Key<NW> me_rc = key_revcomp<NW>(me, K);
+		for (int p = 0; p < 8; p++) {
+			uint64_t far = ~0ULL, meta = 0;
+			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
+			if (live) {
+				const Key<NW> k0 = p < 4 ? me : me_rc;
+				uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+				Key<NW> prev = k0, word = key_next_masked<NW>(k0, b, mask), k1 = word;
+				uint64_t len = 1;
+				bool ok = true, sm;
+				uint64_t os;
+				for (;;) {
+					const Key<NW> bal = key_revcomp<NW>(word, K);
+					sm = !key_less<NW>(bal, word);
+					if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+					if (!(tbl.aux[os] & AUX_LINEAR)) break;
+					if (++len > max_steps) { missing++; ok = false; break; }
+					const uint64_t ov = tbl.ent[os].val;
+					b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+					prev = word;
+					word = key_next_masked<NW>(word, b, mask);
+				}
+				if (ok) {
+					// word = last k-mer, prev = second to last (== k0 when len == 1), k1 = second (== word when len == 1)
+					uint32_t fc = 0;
+#pragma unroll
+					for (int w = 0; w < NW; w++)
+						if (w == NW - 1 - (tb >> 6)) fc = (uint32_t)(prev.w[w] >> (tb & 63)) & 3u;
+					const uint32_t far_port = sm ? 4u + fc : (fc ^ 2u);
+					const Key<NW> rc0 = key_revcomp<NW>(k0, K), rc1 = key_revcomp<NW>(k1, K);
+					const bool palin = key_eq<NW>(word, rc0) && key_eq<NW>(prev, rc1);
+					far = idx[os];
+					meta = len | ((uint64_t)far_port << 32) | ((uint64_t)(palin ? 0 : 1) << 40);
+				}
+			}
+			if (keep) { rec[r * 17 + 1 + 2 * p] = far; rec[r * 17 + 2 + 2 * p] = meta; }
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+
+// ===============================================================================================================
+// Layout: the reference's visiting order (set 0..p-1, slot 0..size-1 of its per-thread tables)
+// ---------------------------------------------------------------------------------------------------------------
+// A node's set is hash_kmer(key) % p (hashFunction.c:83-122: table-driven CRC-32 over the bytes of the variant's Kmer
+// struct with a SIGNED state, low 24 bits), its place inside the set follows from the order in which the set's distinct
+// keys first occurred (put_kmerset / encap_kmerset, newhash.c:293-462).  The device knows both: it sorts the nodes by
+// (set, first-occurrence ordinal) and hands the host the KEYS in that order; the host replays only the probing of each
+// set (graph.c) and answers with order[v] = rank of the node at visiting position v; k_layout_apply then numbers the
+// nodes (idx[slot] = v) and lays the node arrays out in visiting order for the export.
+// ===============================================================================================================
+__device__ inline void crc_table_to_lds(int32_t *s_crc)
+{
+	for (uint32_t n = threadIdx.x; n < 256; n += blockDim.x) {
+		uint32_t c = n;
+#pragma unroll
+		for (int b = 0; b < 8; b++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+		s_crc[n] = (int32_t)c;
+	}
+	__syncthreads();
+}
+
+// sort key = set << 56 | first-occurrence ordinal (< 2^56), value = table slot
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_layout_keys(Table<NW> tbl, uint32_t p, int nw_variant, uint64_t *__restrict__ skey,
+                                                     uint64_t *__restrict__ sval, unsigned long long max_nodes, unsigned long long *cursor, Stats *stats)
+{
+	__shared__ int32_t s_crc[256];
+	crc_table_to_lds(s_crc);
+	const uint64_t slots = tbl.mask + 1;
+	uint32_t bad = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		int32_t crc = ~0;
+		// raw bytes of the variant's Kmer struct: words most significant first, each little endian; a variant wider than the
+		// device key has zero words in front
+		for (int w = 0; w < nw_variant; w++) {
+			const int kw = w - (nw_variant - NW);
+			const uint64_t word = kw >= 0 ? e.key[kw] : 0ULL;
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				crc = s_crc[(crc ^ (int32_t)((word >> (8 * j)) & 0xFF)) & 0xFF] ^ (crc >> 8);     // >> on a negative int shifts sign bits in
+		}
+		crc = ~crc;
+		const uint64_t set = ((uint64_t)(int64_t)crc & 0xFFFFFFULL) % p;
+		const uint64_t first = tbl.first[s];
+		if (first >> 56) bad++;
+		const unsigned long long pos = atomicAdd(cursor, 1ULL);
+		if (pos >= max_nodes) { bad++; continue; }
+		skey[pos] = (set << 56) | (first & 0x00FFFFFFFFFFFFFFULL);
+		sval[pos] = s;
+	}
+	if (bad) atomicAdd(&stats->probe_fail, (unsigned long long)bad);
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_layout_gather_keys(Table<NW> tbl, const uint64_t *__restrict__ sval, uint64_t n, uint64_t *__restrict__ keys)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> *e = tbl.ent + sval[i];
+#pragma unroll
+		for (int w = 0; w < NW; w++) keys[i * NW + w] = e->key[w];
+	}
+}
+
+// set_start[s] = first rank whose set is >= s (s = 0..p)
+__global__ void k_layout_set_starts(const uint64_t *__restrict__ skey, uint64_t n, uint32_t p, uint64_t *__restrict__ set_start)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > p) return;
+	uint64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if ((skey[mid] >> 56) < s) lo = mid + 1; else hi = mid;
+	}
+	set_start[s] = lo;
+}
+
+// order[v] = rank of the node at visiting position v: number the nodes, remember their slots
+__global__ __launch_bounds__(TPB) void k_layout_apply(const uint64_t *__restrict__ sval, const uint64_t *__restrict__ order, uint64_t n,
+                                                      uint64_t *__restrict__ idx, uint64_t *__restrict__ slot_of, Stats *stats)
+{
+	uint32_t bad = 0;
+	for (uint64_t v = blockIdx.x * (uint64_t)TPB + threadIdx.x; v < n; v += (uint64_t)gridDim.x * TPB) {
+		const uint64_t r = order[v];
+		if (r >= n) { bad++; continue; }
+		const uint64_t s = sval[r];
+		idx[s] = v;
+		slot_of[v] = s;
+	}
+	if (bad) atomicAdd(&stats->probe_fail, (unsigned long long)bad);
+}
+
+// the nodes in visiting order, kmer_t-shaped (as k_export)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_export_ordered(Table<NW> tbl, const uint64_t *__restrict__ slot_of, uint64_t v0, uint64_t n,
+                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ l_links,
+                                                        uint32_t *__restrict__ r_flags, uint32_t *__restrict__ count)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		const uint64_t s = slot_of[v0 + i];
+		const Entry<NW> e = tbl.ent[s];
+		const uint32_t aux = tbl.aux[s];
+		const uint32_t cnt = ((aux & 0xFFFFu) << 16) | (uint32_t)(e.val >> 48);
+		if (keys) {
+#pragma unroll
+			for (int w = 0; w < NW; w++) keys[i * NW + w] = e.key[w];
+		}
+		if (l_links) l_links[i] = (uint32_t)(e.val & 0xFFFFFFu);
+		if (r_flags)
+			r_flags[i] = (uint32_t)((e.val >> 24) & 0xFFFFFFu) | ((aux & AUX_LINEAR) ? 1u << 24 : 0u) |
+			             ((aux & AUX_DELETED) ? 1u << 25 : 0u) | (cnt == 1 ? 1u << 27 : 0u);
+		if (count) count[i] = cnt;
+	}
+}
+
+// links + flags of the nodes the host wrote, addressed by node index (no keys cross the link, no look-ups)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_update_by_index(Table<NW> tbl, const uint64_t *__restrict__ slot_of, uint64_t n_nodes,
+                                                         const uint64_t *__restrict__ node, const uint32_t *__restrict__ l_links,
+                                                         const uint32_t *__restrict__ r_flags, uint64_t n, Stats *stats)
+{
+	uint32_t failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		if (node[i] >= n_nodes) { failed++; continue; }
+		const uint64_t slot = slot_of[node[i]];
+		const uint64_t v = tbl.ent[slot].val;
+		tbl.ent[slot].val = (v & 0xFFFF000000000000ULL) | ((uint64_t)(r_flags[i] & 0xFFFFFFu) << 24) | (uint64_t)(l_links[i] & 0xFFFFFFu);
+		const uint32_t a = tbl.aux[slot] & 0xFFFFu;
+		tbl.aux[slot] = a | ((r_flags[i] >> 24 & 1u) ? AUX_LINEAR : 0u) | ((r_flags[i] >> 25 & 1u) ? AUX_DELETED : 0u);
+	}
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
+
+// ===============================================================================================================
+// Components of the ordered commits (csrc/host/graph/cuttip.c): lock-free union-find over node indices.
+// parent[] only ever changes from "root" to "child of a smaller root" (and by path halving, to an ancestor), so a stale value
+// still leads up the same tree; the per-XCD L2s are not coherent, so parent[] is read with device-scope atomic loads and
+// written with device-scope CAS only -- those resolve at the memory side.
+// ===============================================================================================================
+__device__ inline uint32_t uf_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline uint32_t uf_find(uint32_t *parent, uint32_t x)
+{
+	for (;;) {
+		const uint32_t p = uf_load(parent + x);
+		if (p == x) return x;
+		const uint32_t gp = uf_load(parent + p);
+		if (gp != p) atomicCAS(parent + x, p, gp);          // path halving
+		x = p;
+	}
+}
+
+__device__ inline void uf_union(uint32_t *parent, uint32_t a, uint32_t b)
+{
+	for (;;) {
+		a = uf_find(parent, a);
+		b = uf_find(parent, b);
+		if (a == b) return;
+		if (a < b) { const uint32_t t = a; a = b; b = t; }   // the larger root goes under the smaller
+		if (atomicCAS(parent + a, a, b) == a) return;
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_uf_init(uint32_t *__restrict__ parent, uint64_t n)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) parent[i] = (uint32_t)i;
+}
+
+// records of `stride` words: word 0 = node (low 56 bits); unite the node with the node indices found in words [w0, w1), each
+// shifted right by `shift` (an entry of ~0 is no node)
+__global__ __launch_bounds__(TPB) void k_uf_records(uint32_t *parent, const uint64_t *__restrict__ rec, uint64_t n, int stride, int w0, int w1, int shift)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r < n; r += (uint64_t)gridDim.x * TPB) {
+		const uint32_t me = (uint32_t)(rec[r * stride] & 0x00FFFFFFFFFFFFFFULL);
+		for (int w = w0; w < w1; w++) {
+			const uint64_t x = rec[r * stride + w];
+			if (x != ~0ULL) uf_union(parent, me, (uint32_t)(x >> shift));
+		}
+	}
+}
+
+// label word of every record = root of its node; sort key = label << 32 | node
+__global__ __launch_bounds__(TPB) void k_uf_label(uint32_t *parent, uint64_t *__restrict__ rec, uint64_t n, int stride, int label_word,
+                                                  uint64_t *__restrict__ skey, uint32_t *__restrict__ sval)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r < n; r += (uint64_t)gridDim.x * TPB) {
+		const uint32_t me = (uint32_t)(rec[r * stride] & 0x00FFFFFFFFFFFFFFULL);
+		const uint32_t root = uf_find(parent, me);
+		rec[r * stride + label_word] = root;
+		skey[r] = ((uint64_t)root << 32) | me;
+		sval[r] = (uint32_t)r;
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_gather_records(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ perm, uint64_t n, int stride,
+                                                        uint64_t *__restrict__ out)
+{
+	const uint64_t total = n * (uint64_t)stride;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * TPB) {
+		const uint64_t r = i / (uint64_t)stride, w = i - r * (uint64_t)stride;
+		out[i] = rec[(uint64_t)perm[r] * stride + w];
+	}
+}
+
+// removeMinorTips' components: every node that is neither linear nor deleted is united with the first non-linear node behind
+// each of its live ports when at most max_linear linear nodes lie in between (the chains a walk of <= cut_len steps can cross)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_port_union(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int max_linear, uint32_t *parent, Stats *stats)
+{
+	const uint64_t slots = tbl.mask + 1;
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	uint32_t missing = 0;
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
+		const uint32_t me_idx = (uint32_t)idx[s];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+		const Key<NW> me_rc = key_revcomp<NW>(me, K);
+		for (int p = 0; p < 8; p++) {
+			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
+			if (!live) continue;
+			uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+			Key<NW> word = key_next_masked<NW>(p < 4 ? me : me_rc, b, mask);
+			int passed = 0;
+			bool ok = true;
+			uint64_t os;
+			for (;;) {
+				const Key<NW> bal = key_revcomp<NW>(word, K);
+				const bool sm = !key_less<NW>(bal, word);
+				if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+				if (!(tbl.aux[os] & AUX_LINEAR)) break;
+				if (++passed > max_linear) { ok = false; break; }
+				const uint64_t ov = tbl.ent[os].val;
+				b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+				word = key_next_masked<NW>(word, b, mask);
+			}
+			if (ok) uf_union(parent, me_idx, (uint32_t)idx[os]);
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}

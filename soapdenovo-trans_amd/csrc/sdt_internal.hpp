@@ -1,0 +1,71 @@
+// sdt_internal.hpp -- what the translation units of libsdt_gpu.so share besides the public ABI (include/sdt_gpu.h).
+//   sdt_gpu.hip        pass 1 (direct kernel family, locality pipeline), table scans, second read pass, multi-GPU, map stage
+//   sdt_gpu_graph.hip  graph phases on the device mirror: layout (visiting order), dry runs of the cutting passes with
+//                      the components of their commits, port walks of kmer2edges
+// The context itself (struct sdt_ctx) stays private to sdt_gpu.hip; the graph unit sees it through GraphView.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/sdt_gpu.h"
+#include "sdt_kmer.cuh"
+#include "sdt_table.cuh"
+
+constexpr int TPB = 256;           // 4 waves: block size of every scan-style kernel
+
+namespace sdti {
+
+// error plumbing: sets the message sdt_gpu_last_error() returns (thread local), returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIPCHK(expr)                                                                                         \
+	do {                                                                                                     \
+		hipError_t e_ = (expr);                                                                              \
+		if (e_ != hipSuccess)                                                                                \
+			return sdti::fail(e_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)",    \
+			                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                             \
+	} while (0)
+
+struct GraphExt;                   // state of the graph unit, owned by the context (sdt_gpu_graph.hip)
+void graph_ext_free(GraphExt *gx);
+
+struct GraphView {
+	int device, K, nw, cu_count;
+	uint64_t slots;
+	void *d_ent;
+	uint32_t *d_aux;
+	uint64_t *d_first;
+	sdt::Stats *d_stats, *h_stats;
+	hipStream_t stream, copy_stream;
+	uint64_t **d_idx;              // slot -> node index in the visiting order (fields of the context: load_paths reads them too)
+	uint64_t *idx_slots, *idx_n;
+	GraphExt **gx;
+};
+GraphView graph_view(sdt_ctx *c);
+
+template <int NW> inline sdt::Table<NW> table_of(const GraphView &v)
+{
+	sdt::Table<NW> t;
+	t.ent = (sdt::Entry<NW> *)v.d_ent;
+	t.aux = v.d_aux;
+	t.mask = v.slots - 1;
+	t.first = v.d_first;
+	return t;
+}
+
+inline int scan_grid(int cu_count, uint64_t items)
+{
+	uint64_t blocks = (items + TPB - 1) / TPB;
+	const uint64_t cap = (uint64_t)cu_count * 8;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return (int)blocks;
+}
+
+int sync_stats(sdt_ctx *c);        // drain + copy the device counters to h_stats (SDT_EFULL when a probe failed)
+int release_pass1(sdt_ctx *c);     // pass 1 is over: give the pools of the locality pipeline back to the device
+// large transfers between pageable host memory and the device through pinned staging buffers filled / drained by a few threads
+int h2d_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
+int d2h_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
+
+}  // namespace sdti

@@ -161,4 +161,14 @@ __device__ inline Key<NW> chop_record(const uint32_t *lds, int rb, int len, int 
 	return rc;
 }
 
+// append base b at the low end (the caller masks the result down to K bases where it matters)
+template <int NW> __device__ inline Key<NW> key_append(const Key<NW> &k, uint32_t b)
+{
+	Key<NW> r;
+#pragma unroll
+	for (int i = 0; i < NW; i++)
+		r.w[i] = (k.w[i] << 2) | (i + 1 < NW ? k.w[i + 1] >> 62 : (uint64_t)b);
+	return r;
+}
+
 } // namespace sdt

@@ -991,3 +991,131 @@ def test_kernel_rate_floors(pkg, synth):
         mapped = int((((info >> 40) & 255) > 0).sum().item())
         assert mapped > 0.99 * n
         floor(kmers / (ms * 1e-3), 15e9, "k_align_reads")
+
+
+# ---- round 4: the visiting order on the device, labelled dry runs ----------------------------------------------------
+def _uf_labels(n, edges):
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in edges:
+        a, b = find(a), find(b)
+        if a != b:
+            parent[max(a, b)] = min(a, b)
+    return [find(i) for i in range(n)]
+
+
+@pytest.mark.parametrize("K,L,variant,p", [(23, 100, 1, 8), (31, 150, 1, 3), (31, 150, 2, 16), (47, 150, 2, 5), (75, 200, 4, 8), (25, 100, 4, 1)])
+def test_layout_on_device_sorts_by_set_and_first_occurrence(pkg, synth, K, L, variant, p):
+    """sdt_gpu_layout_sorted_keys: the nodes grouped by hash_kmer % p (the oracle's pinned restatement of hashFunction.c:83-122,
+    over the bytes of the emulated variant's Kmer) and ordered by first occurrence inside a set; layout_apply + export_ordered:
+    the nodes come back in whatever order the host asks for, and the dry runs are indexed by it"""
+    tx = synth.make_transcriptome(10, seed=K)
+    codes, offs = synth.sample_reads(*tx, n_reads=2500, read_len=L, seed=K + 1, err=0.004, ragged=True)
+    rng = np.random.default_rng(K + p)
+    with pkg.PregraphGPU(K, est_distinct=1 << 15, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt, first = g.export_nodes(with_first=True)
+        nwk = keys.shape[1]
+        wide = np.zeros((len(keys), 4), dtype=np.uint64)
+        wide[:, 4 - nwk:] = keys
+        OL = ob.lib()
+        sets = np.array([OL.sdto_hash_kmer(ob.Kmer.of(wide[i]), variant) % p for i in range(len(keys))])
+        want = np.lexsort((first, sets))
+        skeys, ss = g.layout_sorted_keys(p, variant)
+        assert (skeys == keys[want]).all()
+        assert [int(x) for x in ss] == [int((sets < s).sum()) for s in range(p + 1)]
+        order = rng.permutation(len(keys)).astype(np.uint64)
+        g.layout_apply(order)
+        k2, l2, r2, c2 = g.export_ordered()
+        src = want[order]
+        assert (k2 == keys[src]).all() and (l2 == l[src]).all() and (c2 == cnt[src]).all()
+        assert ((r2 & 0x3FFFFFF) == (rf[src] & 0x3FFFFFF)).all()
+        # the node numbering is what every dry run speaks: same walks as with set_node_index on the same order
+        end_a, info_a = g.tip_walks(False, 2 * K)
+        g.set_node_index(k2)
+        end_b, info_b = g.tip_walks(False, 2 * K)
+        assert (end_a == end_b).all() and (info_a == info_b).all()
+        # writes by node index reach the same nodes as writes by key
+        g.layout_sorted_keys(p, variant)
+        g.layout_apply(order)
+        pick = rng.choice(len(keys), size=max(1, len(keys) // 10), replace=False)
+        l3, r3 = l2.copy(), r2.copy()
+        r3[pick] |= np.uint32(1 << 25)
+        l3[pick] &= np.uint32(0xFFFFC0)
+        g.update_nodes_by_index(pick.astype(np.uint64), l3[pick], r3[pick])
+        k4, l4, r4, c4 = g.export_ordered()
+        assert (k4 == k2).all() and (l4 == l3).all() and ((r4 & 0x3FFFFFF) == (r3 & 0x3FFFFFF)).all() and (c4 == c2).all()
+
+
+@pytest.mark.parametrize("K,L", [(21, 100), (31, 150), (63, 150), (75, 200)])
+def test_labelled_walks_and_their_components(pkg, synth, K, L):
+    """sdt_gpu_tip_walks_labelled: the walks of tip_walks_compact, each with the component of its node -- removeSingleTips: the
+    connected components of (tip, end node); removeMinorTips: of the non-linear nodes joined by chains of <= cut_len linear
+    nodes (taken here from the port walks of py_edge_ports) -- and sorted by (label, node)"""
+    tx = synth.make_transcriptome(6, seed=K + 11)
+    codes, offs = synth.sample_reads(*tx, n_reads=4000, read_len=L, seed=K + 12, err=0.01)
+    rng = np.random.default_rng(K)
+    with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        perm = rng.permutation(len(keys))
+        keys, l, rf, cnt = keys[perm], l[perm], rf[perm], cnt[perm]
+        ki = keys_to_int(keys)
+        g.set_node_index(keys)
+        M56 = (1 << 56) - 1
+        for thin, cut_len in ((1, 2 * K), (0, 2 * K), (0, 5)):
+            plain = g.tip_walks_compact(bool(thin), cut_len)
+            rec = g.tip_walks_labelled(bool(thin), cut_len)
+            assert sorted((int(a), int(b)) for a, b in plain) == sorted((int(a), int(b)) for a, b, _ in rec)
+            assert len(rec) > 0
+            nodes = [int(a) & M56 for a, _, _ in rec]
+            labs = [int(c) for _, _, c in rec]
+            assert list(zip(labs, nodes)) == sorted(zip(labs, nodes)), "sorted by (label, node)"
+            if thin:
+                edges = [(int(a) & M56, int(b)) for a, b, _ in rec]
+            else:
+                ports = py_edge_ports(ki, l, rf, K)
+                edges = [(i, pt[0]) for i, pp in ports.items() for pt in pp if pt is not None and pt[2] - 1 <= cut_len]
+            want = _uf_labels(len(keys), edges)
+            assert labs == [want[i] for i in nodes]
+            if not thin and cut_len > 5:
+                assert len(set(labs)) < len(labs), "some component holds more than one walk"
+
+
+@pytest.mark.parametrize("K,L", [(21, 100), (31, 150), (47, 150)])
+def test_labelled_junction_records_and_their_components(pkg, synth, K, L):
+    """sdt_gpu_minor_out_labelled: the records of minor_out_dry with the component of their node (every record's node united
+    with its eight neighbours), the junction records sorted by (label, node)"""
+    tx = synth.make_transcriptome(8, seed=K + 21)
+    codes, offs = synth.sample_reads(*tx, n_reads=4000, read_len=L, seed=K + 22, err=0.008)
+    rng = np.random.default_rng(K)
+    NONE = (1 << 64) - 1
+    with pkg.PregraphGPU(K, est_distinct=1 << 15) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        keys, l, rf, cnt = g.export_nodes()
+        perm = rng.permutation(len(keys))
+        keys = keys[perm]
+        g.set_node_index(keys)
+        for thr in (0.05, 0.3):
+            plain, nj0 = g.minor_out_dry(thr)
+            rec, nj = g.minor_out_labelled(thr)
+            assert nj == nj0 > 0 and len(rec) == len(plain)
+            assert sorted(tuple(int(x) for x in r) for r in plain[:nj0]) == sorted(tuple(int(x) for x in r[:9]) for r in rec[:nj])
+            assert sorted(tuple(int(x) for x in r) for r in plain[nj0:]) == sorted(tuple(int(x) for x in r[:9]) for r in rec[nj:])
+            edges = [(int(r[0]), int(x) >> 1) for r in rec for x in r[1:9] if int(x) != NONE]
+            want = _uf_labels(len(keys), edges)
+            labs = [int(r[9]) for r in rec[:nj]]
+            nodes = [int(r[0]) for r in rec[:nj]]
+            assert labs == [want[i] for i in nodes]
+            assert list(zip(labs, nodes)) == sorted(zip(labs, nodes))
