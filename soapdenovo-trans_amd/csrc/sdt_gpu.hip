@@ -21,6 +21,7 @@
 #include <vector>
 #include <new>
 #include <thread>
+#include <mutex>
 
 #include "sdt_internal.hpp"
 #include "sdt_superkmer.cuh"
@@ -2803,33 +2804,56 @@ int sdti::release_pass1(sdt_ctx *c)
 	return SDT_OK;
 }
 
-// pageable host memory <-> device in 64-MiB pieces through pinned staging buffers: a few threads copy between the caller's
-// memory and the staging buffers while the copy engine moves the previous piece (a plain hipMemcpy of pageable memory
+// pageable host memory <-> device in pieces through pinned staging buffers: a few threads copy between the caller's
+// memory and the staging buffers while the copy engine moves the neighbouring pieces (a plain hipMemcpy of pageable memory
 // runs at a third of the link)
+// the staging buffers live as long as the process (pinning 64 MiB costs milliseconds: a large export makes dozens of transfers)
+struct BigStage {
+	static constexpr int NB = 4;
+	static constexpr size_t CH = (size_t)32 << 20;
+	void *pin[NB] = {};
+	hipEvent_t done[NB] = {};
+	bool ok = false;
+	std::mutex mu;
+	bool init()
+	{
+		if (ok) return true;
+		for (int i = 0; i < NB; i++)
+			if (hipHostMalloc(&pin[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+				return false;
+		ok = true;
+		return true;
+	}
+};
+static BigStage g_stage;
+
+static void host_copy_mt(void *d, const void *s, size_t n)
+{
+	constexpr int T = 8;
+	if (n < ((size_t)4 << 20)) { memcpy(d, s, n); return; }
+	std::thread th[T];
+	for (int t = 0; t < T; t++) {
+		const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
+		th[t] = std::thread([=] { memcpy((char *)d + a0, (const char *)s + a0, a1 - a0); });
+	}
+	for (int t = 0; t < T; t++) th[t].join();
+}
+
 static int big_copy(hipStream_t copy_stream, void *dst, const void *src, size_t bytes, bool to_device)
 {
-	const size_t CH = (size_t)64 << 20;
-	if (bytes < 2 * CH) {
+	constexpr int NB = BigStage::NB;
+	const size_t CH = BigStage::CH;
+	if (bytes < CH) {
 		if (hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
 		    hipStreamSynchronize(copy_stream) != hipSuccess)
 			return fail(SDT_EHIP, "copy of %zu bytes failed", bytes);
 		return SDT_OK;
 	}
-	constexpr int NB = 3, T = 6;
-	void *pin[NB] = {};
-	hipEvent_t done[NB] = {};
+	std::lock_guard<std::mutex> lock(g_stage.mu);
+	if (!g_stage.init()) return fail(SDT_ENOMEM, "pinned staging for a %zu-byte transfer", bytes);
+	void **pin = g_stage.pin;
+	hipEvent_t *done = g_stage.done;
 	int rc = SDT_OK;
-	for (int i = 0; i < NB && rc == SDT_OK; i++)
-		if (hipHostMalloc(&pin[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
-			rc = fail(SDT_ENOMEM, "pinned staging for a %zu-byte transfer", bytes);
-	auto host_copy = [&](void *d, const void *s, size_t n) {
-		std::thread th[T];
-		for (int t = 0; t < T; t++) {
-			const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
-			th[t] = std::thread([=] { memcpy((char *)d + a0, (const char *)s + a0, a1 - a0); });
-		}
-		for (int t = 0; t < T; t++) th[t].join();
-	};
 	const size_t npieces = (bytes + CH - 1) / CH;
 	if (to_device) {
 		bool used[NB] = {};
@@ -2837,20 +2861,20 @@ static int big_copy(hipStream_t copy_stream, void *dst, const void *src, size_t 
 			const int b = (int)(k % NB);
 			const size_t off = k * CH, n = bytes - off < CH ? bytes - off : CH;
 			if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "upload: event wait failed"); break; }
-			host_copy(pin[b], (const char *)src + off, n);
+			host_copy_mt(pin[b], (const char *)src + off, n);
 			if (hipMemcpyAsync((char *)dst + off, pin[b], n, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
 			    hipEventRecord(done[b], copy_stream) != hipSuccess) { rc = fail(SDT_EHIP, "upload: copy failed"); break; }
 			used[b] = true;
 		}
 	} else {
-		// piece k + NB - 1 is on the link while the threads drain piece k
+		// pieces k .. k + NB - 2 are on the link while the threads drain piece k - 1
 		for (size_t k = 0; k < npieces + NB - 1 && rc == SDT_OK; k++) {
 			if (k >= (size_t)(NB - 1)) {
 				const size_t j = k - (NB - 1);
 				const int b = (int)(j % NB);
 				const size_t off = j * CH, n = bytes - off < CH ? bytes - off : CH;
 				if (hipEventSynchronize(done[b]) != hipSuccess) { rc = fail(SDT_EHIP, "download: event wait failed"); break; }
-				host_copy((char *)dst + off, pin[b], n);
+				host_copy_mt((char *)dst + off, pin[b], n);
 			}
 			if (k < npieces) {
 				const int b = (int)(k % NB);
@@ -2861,10 +2885,6 @@ static int big_copy(hipStream_t copy_stream, void *dst, const void *src, size_t 
 		}
 	}
 	if (hipStreamSynchronize(copy_stream) != hipSuccess && rc == SDT_OK) rc = fail(SDT_EHIP, "transfer: sync failed");
-	for (int i = 0; i < NB; i++) {
-		if (pin[i]) (void)hipHostFree(pin[i]);
-		if (done[i]) (void)hipEventDestroy(done[i]);
-	}
 	return rc;
 }
 
