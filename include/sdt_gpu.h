@@ -215,7 +215,8 @@ int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32
  * and the (K+1)-mers of length-1 edges (KmerSetsPatch, node2edge.c:404-463) come as patch_keys (key_words()
  * words each, most significant first) with patch_info = edge id | twin << 32.  load_paths overwrites the
  * nodes' counters with the path words (export the table first); keys == NULL: path_words[i] belongs to node i of
- * sdt_gpu_set_node_index (no keys to send, no look-ups).  map_reads then replays parse1read (:617-789),
+ * sdt_gpu_set_node_index / sdt_gpu_layout_apply (no keys to send, no look-ups); path_words == NULL as well: the path words
+ * sdt_gpu_build_edges left on the device.  map_reads then replays parse1read (:617-789),
  * search1kmerPlus (:575-615) and the arc counting (:190-241,415-430) over the kept reads; export_arcs returns
  * every arc with its multiplicity and the ordinal of its first appearance ((read ordinal << 16) | item index):
  * per from-edge the reference prints arcs most-recent-first-appearance first (:427-428,472-496). */
@@ -294,6 +295,17 @@ int sdt_gpu_update_nodes_by_index(sdt_ctx *ctx, const uint64_t *node, const uint
 int sdt_gpu_tip_walks_labelled(sdt_ctx *ctx, int thin, int cut_len, uint64_t *n_records);
 int sdt_gpu_minor_out_labelled(sdt_ctx *ctx, double threshold, uint64_t *n_junctions, uint64_t *n_records);
 int sdt_gpu_fetch_records(sdt_ctx *ctx, uint64_t *dst, uint64_t nwords);
+/* kmer2edges (node2edge.c:46-561) on the device mirror, after sdt_gpu_layout_apply: every chain of linear nodes between two
+ * nodes that are neither linear nor deleted is one edge; it belongs to the first of its two (node, port) ends in visiting order
+ * (ports: right links 0..3 on the stored strand, then left links 0..3 on the other), ids are handed out in that order (an edge
+ * that is not its own reverse complement takes two), the interior nodes are stamped with id and twin (merge_linearV2, :351-561)
+ * -- as PATH WORDS: sdt_gpu_load_paths(ctx, NULL, NULL, n, ...) then takes them from the device.  *n_edges records wait for
+ * sdt_gpu_fetch_records (4 + 2 * key_words() words each, in id order: length | bal_edge << 32, cvg, id, offset of the edge's
+ * bases, first and last oriented k-mer) and *n_bases letters for sdt_gpu_fetch_edge_bases (the last base of nodes 1..length of
+ * every edge); *num_ed = ids handed out (EDGEs of *.preGraphBasic).  SDT_ESTATE with "does not lead back" in the message: a
+ * chain is not symmetric -- nothing was stamped, build the edges sequentially (node2edge.c's own order). */
+int sdt_gpu_build_edges(sdt_ctx *ctx, uint64_t *n_edges, uint64_t *num_ed, uint64_t *n_bases);
+int sdt_gpu_fetch_edge_bases(sdt_ctx *ctx, char *dst, uint64_t nbytes);
 
 /* ---- `map` stage: prlContig2nodes (prlHashCtg.c:287-425) and prlRead2Ctg (prlRead2Ctg.c:656-894) -------
  * A context created with SDT_FLAG_CONTIG_INDEX holds the k-mers of the contigs:

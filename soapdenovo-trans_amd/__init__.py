@@ -71,6 +71,8 @@ _ABI = [
     ("sdt_gpu_tip_walks_labelled", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_minor_out_labelled", _c.c_int, [_c.c_void_p, _c.c_double, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_fetch_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_build_edges", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_fetch_edge_bases", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_set_contig_table", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_align_reads", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_int,
@@ -449,6 +451,15 @@ class PregraphGPU:
         nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
         self._check(self.lib.sdt_gpu_minor_out_labelled(self._ctx, ctypes.c_double(threshold), ctypes.byref(nj), ctypes.byref(nr)))
         return self._fetch(nr.value, 10), nj.value
+
+    def build_edges(self):
+        """-> (records uint64[n_edges, 4 + 2 nw], bases bytes, num_ed): see sdt_gpu_build_edges"""
+        ne, ids, nb = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_build_edges(self._ctx, ctypes.byref(ne), ctypes.byref(ids), ctypes.byref(nb)))
+        rec = self._fetch(ne.value, 4 + 2 * self.nw)
+        buf = np.zeros(max(nb.value, 1), dtype=np.uint8)
+        self._check(self.lib.sdt_gpu_fetch_edge_bases(self._ctx, _ptr(buf), nb.value))
+        return rec, buf[: nb.value].tobytes(), ids.value
 
     def set_read_ordinal(self, base: int, stride: int = 1):
         self._check(self.lib.sdt_gpu_set_read_ordinal(self._ctx, base, stride))

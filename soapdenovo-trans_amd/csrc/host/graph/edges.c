@@ -311,7 +311,11 @@ static void scatter_ports(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
-typedef struct { graph_t *g; edges_ctx *E; uint64_t *emit; uint64_t nemit; } stamp_ctx;
+/* Edge records -- what the device's sdt_gpu_build_edges hands over, and what the host path below makes itself: RW = 4 + 2 * kw
+ * words per edge, in id order: [0] length | bal_edge << 32, [1] cvg, [2] id, [3] offset of the edge's bases in `bases`
+ * (one letter per base: the last base of nodes 1..length), then the oriented first and last k-mer, kw words each, most
+ * significant first. */
+typedef struct { graph_t *g; edges_ctx *E; uint64_t *emit; uint64_t nemit; uint64_t *rec; const uint64_t *boff; char *bases; } stamp_ctx;
 
 static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
@@ -348,60 +352,97 @@ static void stamp_edges(void *vc, uint64_t lo, uint64_t hi, int tid)
 			if (b->smaller) { nd->l_links = P->id; nd->twin = (unsigned)(bal_edge + 1); }
 			else { nd->l_links = P->id + (uint32_t)bal_edge; nd->twin = (unsigned)(1 - bal_edge); }
 		}
-		/* record text: header + bases with a newline every 100 and at the end (output_pregraph.c:83-100) */
-		const size_t cap = 256 + (size_t)length + (size_t)length / 100 + 8;
-		char *t = (char *)malloc(cap);
-		size_t o = 0;
-		o += (size_t)snprintf(t + o, cap - o, ">length %d,", length);
-		for (int k = 0; k < 2; k++) {
-			const uint64_t *w = (k == 0 ? first : last)->kmer.w;
-			if (g->nw == 4) o += (size_t)snprintf(t + o, cap - o, "%llx %llx %llx %llx,", (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3]);
-			else if (g->nw == 2) o += (size_t)snprintf(t + o, cap - o, "%llx %llx,", (unsigned long long)w[2], (unsigned long long)w[3]);
-			else if (w[3]) o += (size_t)snprintf(t + o, cap - o, "%llx,", (unsigned long long)w[3]);
-			else o += (size_t)snprintf(t + o, cap - o, "0x0,");
-		}
 		long long cvg = length > 1 ? symbol / (length - 1) * 10 : symbol / length * 10;
 		if (cvg > MAX_EDGE_COV) cvg = MAX_EDGE_COV;
-		o += (size_t)snprintf(t + o, cap - o, "cvg %d, %d\n", (int)cvg, bal_edge);
-		for (size_t i = 1; i < cnt; i++) {
-			t[o++] = "ACTG"[kw_last(&c.b[i].kmer)];
-			if (i % 100 == 0) t[o++] = '\n';
-		}
-		t[o++] = '\n';
-		P->text = t;
-		P->text_len = o;
+		uint64_t *R = S->rec + e * 12;
+		R[0] = (uint64_t)length | ((uint64_t)bal_edge << 32);
+		R[1] = (uint64_t)cvg;
+		R[2] = P->id;
+		R[3] = S->boff[e];
+		for (int w = 0; w < 4; w++) { R[4 + w] = first->kmer.w[w]; R[8 + w] = last->kmer.w[w]; }
+		char *q = S->bases + S->boff[e];
+		for (size_t i = 1; i < cnt; i++) q[i - 1] = "ACTG"[kw_last(&c.b[i].kmer)];
 	}
 	free(c.b);
 }
 
 #include <unistd.h>
-typedef struct { edges_ctx *E; const uint64_t *emit, *cut; unsigned char **out; size_t *len; volatile int failed; } gz_ctx;
+/* output_1edge (output_pregraph.c:83-100) for a run of edge records, then one gzip member of it: gzopen / gzgets
+ * (loadPreGraph.c:439-449) read through member boundaries */
+typedef struct { const graph_t *g; const uint64_t *rec; int kw; const char *bases; const uint64_t *cut; unsigned char **out; size_t *len; volatile int failed; } gz_ctx;
+
+static inline size_t fmt_hex(char *p, uint64_t v)
+{
+	char tmp[16];
+	int n = 0;
+	do { tmp[n++] = "0123456789abcdef"[v & 15]; v >>= 4; } while (v);
+	for (int k = 0; k < n; k++) p[k] = tmp[n - 1 - k];
+	return (size_t)n;
+}
+static inline size_t fmt_dec(char *p, uint64_t v)
+{
+	char tmp[24];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	for (int k = 0; k < n; k++) p[k] = tmp[n - 1 - k];
+	return (size_t)n;
+}
 
 static void gz_chunks(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
 	(void)tid;
 	gz_ctx *Z = (gz_ctx *)vc;
+	const int kw = Z->kw, RW = 4 + 2 * kw, nw = Z->g->nw;
 	for (uint64_t k = lo; k < hi; k++) {
-		size_t total = 0;
-		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) total += Z->E->ports[Z->emit[e]].text_len;
+		size_t cap = 64;
+		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) {
+			const uint64_t length = Z->rec[e * RW] & 0xFFFFFFFFULL;
+			cap += 64 + 34 * (size_t)nw + length + length / 100 + 2;
+		}
+		char *t = (char *)malloc(cap);
+		size_t o = 0;
+		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) {
+			const uint64_t *R = Z->rec + e * RW;
+			const uint64_t length = R[0] & 0xFFFFFFFFULL;
+			memcpy(t + o, ">length ", 8); o += 8;
+			o += fmt_dec(t + o, length);
+			t[o++] = ',';
+			for (int end = 0; end < 2; end++) {                             /* print_kmer_gz of the emulated variant (kmer.c:518-545) */
+				const uint64_t *w = R + 4 + end * kw;
+				if (nw == 1 && !w[kw - 1]) { memcpy(t + o, "0x0,", 4); o += 4; continue; }
+				for (int q = 0; q < nw; q++) {
+					const int src = q - (nw - kw);                          /* a variant wider than the keys prints zero words in front */
+					o += fmt_hex(t + o, src >= 0 ? w[src] : 0);
+					t[o++] = q + 1 < nw ? ' ' : ',';
+				}
+			}
+			memcpy(t + o, "cvg ", 4); o += 4;
+			o += fmt_dec(t + o, R[1]);
+			t[o++] = ','; t[o++] = ' ';
+			t[o++] = (char)('0' + ((R[0] >> 32) & 1));
+			t[o++] = '\n';
+			const char *q = Z->bases + R[3];
+			for (uint64_t i = 0; i < length; i += 100) {                     /* a newline after every 100th base and at the end */
+				const uint64_t m = length - i < 100 ? length - i : 100;
+				memcpy(t + o, q + i, m); o += m;
+				if (m == 100) t[o++] = '\n';
+			}
+			t[o++] = '\n';
+		}
 		z_stream zs;
 		memset(&zs, 0, sizeof zs);
-		if (deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { Z->failed = 1; return; }
-		const size_t cap = deflateBound(&zs, (uLong)total) + 64;
-		unsigned char *out = (unsigned char *)malloc(cap);
+		if (deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { Z->failed = 1; free(t); return; }
+		const size_t zcap = deflateBound(&zs, (uLong)o) + 64;
+		unsigned char *out = (unsigned char *)malloc(zcap);
 		zs.next_out = out;
-		zs.avail_out = (uInt)cap;
-		for (uint64_t e = Z->cut[k]; e < Z->cut[k + 1]; e++) {
-			port_t *P = &Z->E->ports[Z->emit[e]];
-			zs.next_in = (Bytef *)P->text;
-			zs.avail_in = (uInt)P->text_len;
-			if (deflate(&zs, e + 1 == Z->cut[k + 1] ? Z_FINISH : Z_NO_FLUSH) == Z_STREAM_ERROR) { Z->failed = 1; break; }
-			free(P->text);
-			P->text = NULL;
-		}
-		Z->len[k] = cap - zs.avail_out;
+		zs.avail_out = (uInt)zcap;
+		zs.next_in = (Bytef *)t;
+		zs.avail_in = (uInt)o;
+		if (deflate(&zs, Z_FINISH) == Z_STREAM_ERROR) Z->failed = 1;
+		Z->len[k] = zcap - zs.avail_out;
 		Z->out[k] = out;
 		deflateEnd(&zs);
+		free(t);
 	}
 }
 
@@ -409,7 +450,9 @@ static void gz_chunks(void *vc, uint64_t lo, uint64_t hi, int tid)
 static double ed_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 #define EPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = ed_now(); fprintf(stderr, "[edges]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
-uint64_t graph_build_edges(graph_t *g, const char *prefix)
+/* the host's own records: port walks (dry run or the device's), ordered ids, parallel stamping.  Returns 0, or 2 when a chain
+ * is not symmetric (nothing has been modified then) */
+static int host_edge_records(graph_t *g, uint64_t **rec_out, uint64_t *nrec_out, uint64_t *num_ed_out, char **bases_out, uint64_t *nb_out)
 {
 	double t_sub = ed_now();
 	edges_ctx E;
@@ -444,7 +487,8 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	/* ordered pass on port flags */
 	uint8_t *zeroed = (uint8_t *)calloc(g->n + 1, 1);
 	uint64_t *emit = (uint64_t *)malloc((E.nstarts * 8 + 8) * sizeof(uint64_t));
-	uint64_t nemit = 0, num_ed = 0;
+	uint64_t *boff = (uint64_t *)malloc((E.nstarts * 8 + 8) * sizeof(uint64_t));
+	uint64_t nemit = 0, num_ed = 0, nb = 0;
 	int symmetric = 1;
 	for (uint64_t s = 0; s < E.nstarts && symmetric; s++) {
 		const uint64_t ni = E.starts[s];
@@ -462,6 +506,8 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 			num_ed += P->bal_edge;
 			zeroed[ni] |= (uint8_t)(1u << p);
 			zeroed[P->far_node] |= (uint8_t)(1u << P->far_port);
+			boff[nemit] = nb;
+			nb += P->length;
 			emit[nemit++] = s * 8 + (uint64_t)p;
 		}
 	}
@@ -469,37 +515,66 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 	free(slot_of);
 	EPHASE("ordered ids");
 	if (!symmetric) {
-		free(emit); free(E.ports); free(E.starts);
-		return build_edges_sequential(g, prefix);
+		free(emit); free(boff); free(E.ports); free(E.starts);
+		return 2;
 	}
+	uint64_t *rec = (uint64_t *)malloc((nemit + 1) * 12 * sizeof(uint64_t));
+	char *bases = (char *)malloc(nb + 16);
+	stamp_ctx S = {g, &E, emit, nemit, rec, boff, bases};
+	par_for(0, nemit, 64, stamp_edges, &S);
+	EPHASE("stamp + records");
+	free(emit); free(boff); free(E.ports); free(E.starts);
+	*rec_out = rec; *nrec_out = nemit; *num_ed_out = num_ed; *bases_out = bases; *nb_out = nb;
+	return 0;
+}
+
+uint64_t graph_build_edges(graph_t *g, const char *prefix)
+{
+	double t_sub = ed_now();
+	uint64_t *rec = NULL, nemit = 0, num_ed = 0, nb = 0;
+	char *bases = NULL;
+	int kw = 4, rc;
+	g->edges_on_device = 0;
+	if (g->dev_build_edges) {
+		/* the whole of kmer2edges from the device mirror (sdt_gpu_build_edges): walks, ordered ids, stamping of the path words
+		 * the second read pass reads -- the host nodes are NOT stamped in this mode; the records come back for the writers */
+		rc = g->dev_build_edges(g, &rec, &kw, &nemit, &num_ed, &bases, &nb);
+		if (rc != 0 && rc != 2) { printf("the device edge builder failed. Now exit to system...\n"); exit(1); }
+		if (rc == 0) {
+			for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;
+			g->dn = 0;
+			g->edges_on_device = 1;
+		}
+		EPHASE("device: walks, ids, stamps");
+	} else {
+		rc = host_edge_records(g, &rec, &nemit, &num_ed, &bases, &nb);
+	}
+	if (rc == 2)
+		return build_edges_sequential(g, prefix);
+	const int RW = 4 + 2 * kw;
 	/* length-1 edges: canonical (K+1)-mer -> edge id, in emission order (node2edge.c:404-463) */
 	g->patch_mask = 1023;
 	g->patch = (gpatch_t *)calloc(1024, sizeof(gpatch_t));
 	g->patch_n = 0;
 	uint64_t extra = 0;
 	for (uint64_t e = 0; e < nemit; e++) {
-		const port_t *P = &E.ports[emit[e]];
-		if (P->length != 1) continue;
+		const uint64_t *R = rec + e * RW;
+		if ((R[0] & 0xFFFFFFFFULL) != 1) continue;
 		extra++;
-		const gnode_t *n = &g->nodes[E.starts[emit[e] / 8]];
-		const int p = (int)(emit[e] % 8);
-		const kw_t from = p < 4 ? n->seq : kw_rc(n->seq, g->K);
-		const unsigned b = p < 4 ? (unsigned)p : (unsigned)(p - 4) ^ 2u;      /* last base of the far k-mer */
+		kw_t from = {{0, 0, 0, 0}}, to = {{0, 0, 0, 0}};
+		for (int w = 0; w < kw; w++) { from.w[4 - kw + w] = R[4 + w]; to.w[4 - kw + w] = R[4 + kw + w]; }
+		const uint32_t id = (uint32_t)R[2], bal_edge = (uint32_t)(R[0] >> 32) & 1u;
 		kw_t plus;
 		plus.w[0] = (from.w[0] << 2) | (from.w[1] >> 62);
 		plus.w[1] = (from.w[1] << 2) | (from.w[2] >> 62);
 		plus.w[2] = (from.w[2] << 2) | (from.w[3] >> 62);
-		plus.w[3] = (from.w[3] << 2) | b;
+		plus.w[3] = (from.w[3] << 2) | kw_last(&to);
 		kw_t bal = kw_rc_kplus1(plus, g->K);
-		if (kw_less(&plus, &bal)) patch_put(g, &plus, P->id, (uint8_t)(P->bal_edge + 1));
-		else patch_put(g, &bal, P->id + (uint32_t)P->bal_edge, (uint8_t)(1 - P->bal_edge));
+		if (kw_less(&plus, &bal)) patch_put(g, &plus, id, (uint8_t)(bal_edge + 1));
+		else patch_put(g, &bal, id + bal_edge, (uint8_t)(1 - bal_edge));
 	}
 	EPHASE("patch table");
-	stamp_ctx S = {g, &E, emit, nemit};
-	par_for(0, nemit, 64, stamp_edges, &S);
-	EPHASE("stamp + text");
-	/* <prefix>.edge.gz as a sequence of gzip members, each deflated by one thread over ~4 MB of records: gzopen /
-	 * gzgets (loadPreGraph.c:439-449) read through member boundaries */
+	/* <prefix>.edge.gz as a sequence of gzip members, each formatted and deflated by one thread over ~4 MB of records */
 	char name[4200];
 	snprintf(name, sizeof name, "%s.edge.gz", prefix);
 	FILE *fz = fopen(name, "wb");
@@ -511,12 +586,12 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		const size_t chunk_bytes = getenv("SDT_GZ_CHUNK") ? (size_t)atol(getenv("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
 		cut[ncut++] = 0;
 		for (uint64_t e = 0; e < nemit; e++) {
-			acc += E.ports[emit[e]].text_len;
+			acc += (size_t)(rec[e * RW] & 0xFFFFFFFFULL) + 60;
 			if (acc >= chunk_bytes) { cut[ncut++] = e + 1; acc = 0; }
 		}
 		if (cut[ncut - 1] != nemit) cut[ncut++] = nemit;
 		const uint64_t nchunks = ncut - 1;
-		gz_ctx Z = {&E, emit, cut, (unsigned char **)calloc(nchunks + 1, sizeof(unsigned char *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
+		gz_ctx Z = {g, rec, kw, bases, cut, (unsigned char **)calloc(nchunks + 1, sizeof(unsigned char *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
 		par_for(0, nchunks, 1, gz_chunks, &Z);
 		if (Z.failed) { printf("deflate failed on %s\n", name); exit(-1); }
 		for (uint64_t k = 0; k < nchunks; k++) { fwrite(Z.out[k], 1, Z.len[k], fz); free(Z.out[k]); }
@@ -527,10 +602,10 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		free(Z.out); free(Z.len); free(cut);
 	}
 	fclose(fz);
-	EPHASE("gzip write");
+	EPHASE("text + gzip write");
 	g->num_ed = num_ed;
 	printf("%llu (%llu) edges %llu extra nodes\n", (unsigned long long)num_ed, (unsigned long long)nemit, (unsigned long long)extra);
-	free(emit); free(E.ports); free(E.starts);
+	free(rec); free(bases);
 	return num_ed;
 }
 

@@ -60,6 +60,13 @@ typedef struct graph_s {
 	/* removeMinorOut's dry run from the device: malloc'ed records of 10 words (node index, 8 neighbours, component label);
 	 * the junction records [0, n_junctions) sorted by (label, node index), then the neighbours to cut in any order */
 	int (*dev_minor_out)(struct graph_s *g, double threshold, uint64_t **records, uint64_t *n_junctions, uint64_t *n_records);
+	/* the whole of kmer2edges from the device (sdt_gpu_build_edges): malloc'ed edge records in id order -- 4 + 2 * *key_words
+	 * words each: length | bal_edge << 32, cvg, id, offset into *bases, first and last oriented k-mer (most significant word
+	 * first) -- and the edges' bases as letters.  Returns 0, or 2 when a chain does not lead back to the port it was entered
+	 * from (the host then builds the edges the sequential way), anything else on failure.  edges_on_device: the interior
+	 * nodes were stamped on the device only (their path words wait there for the second read pass) */
+	int (*dev_build_edges)(struct graph_s *g, uint64_t **records, int *key_words, uint64_t *n_edges, uint64_t *num_ed, char **bases, uint64_t *n_bases);
+	int edges_on_device;
 	void *dev_user;
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
 	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */

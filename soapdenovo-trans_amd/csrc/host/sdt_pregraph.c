@@ -310,6 +310,27 @@ static int dev_edge_ports_hook(graph_t *g, uint64_t **records, uint64_t *nr)
 	}
 }
 
+static int dev_build_edges_hook(graph_t *g, uint64_t **records, int *key_words, uint64_t *n_edges, uint64_t *num_ed, char **bases, uint64_t *n_bases)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	if (dev_mirror_sync(g) != 0) return 1;
+	const int rc = sdt_gpu_build_edges(D->gpu, n_edges, num_ed, n_bases);
+	if (rc == SDT_ESTATE && strstr(sdt_gpu_last_error(), "does not lead back")) return 2;       /* not symmetric: the sequential way */
+	if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_build_edges: %s\n", sdt_gpu_last_error()); return 1; }
+	const int rw = 4 + 2 * D->nwk;
+	uint64_t *rec = (uint64_t *)malloc((*n_edges + 1) * (size_t)rw * sizeof(uint64_t));
+	char *b = (char *)malloc(*n_bases + 16);
+	if (!rec || !b) { fprintf(stderr, "out of memory for %llu edges\n", (unsigned long long)*n_edges); return 1; }
+	if (sdt_gpu_fetch_records(D->gpu, rec, *n_edges * (uint64_t)rw) != SDT_OK || sdt_gpu_fetch_edge_bases(D->gpu, b, *n_bases) != SDT_OK) {
+		fprintf(stderr, "edge records: %s\n", sdt_gpu_last_error());
+		return 1;
+	}
+	*records = rec;
+	*bases = b;
+	*key_words = D->nwk;
+	return 0;
+}
+
 static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, uint64_t *nj, uint64_t *nr)
 {
 	dev_state *D = (dev_state *)g->dev_user;
@@ -614,6 +635,7 @@ int main(int argc, char **argv)
 			G->dev_walks = dev_walks_hook;
 			G->dev_minor_out = dev_minor_out_hook;
 			G->dev_edge_ports = dev_edge_ports_hook;
+			if (Dp->by_index && !getenv("SDT_HOST_EDGES")) G->dev_build_edges = dev_build_edges_hook;
 			G->dev_user = Dp;
 		}
 		time_t t0 = time(NULL);
@@ -641,9 +663,14 @@ int main(int argc, char **argv)
 			/* second pass on the GPU over the reads kept in HBM: send the cleaned graph back as path words */
 			/* with the device mirror in place the path words go over by node index; otherwise with their keys */
 			const int by_index = G->dev_walks != NULL && Dp->indexed;
-			uint64_t *pk = by_index ? NULL : (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8), *pw = (uint64_t *)malloc((G->n + 1) * 8);
-			void *pa[4] = {G, pk, pw, (void *)(intptr_t)nwk};
-			par_for(0, G->n, 1 << 16, gather_paths, pa);
+			/* the edges were built on the device: the path words are there already */
+			uint64_t *pk = NULL, *pw = NULL;
+			if (!G->edges_on_device) {
+				pk = by_index ? NULL : (uint64_t *)malloc((G->n + 1) * (size_t)nwk * 8);
+				pw = (uint64_t *)malloc((G->n + 1) * 8);
+				void *pa[4] = {G, pk, pw, (void *)(intptr_t)nwk};
+				par_for(0, G->n, 1 << 16, gather_paths, pa);
+			}
 			uint64_t np = 0;
 			uint64_t *qk = (uint64_t *)malloc((G->patch_n + 1) * (size_t)nwk * 8), *qi = (uint64_t *)malloc((G->patch_n + 1) * 8);
 			for (uint64_t i = 0; G->patch && i <= G->patch_mask; i++)

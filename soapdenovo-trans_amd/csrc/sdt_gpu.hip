@@ -1990,20 +1990,27 @@ done:
 int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
                        const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed)
 {
-	if (!c || (n && !path_words) || (npatch && (!patch_keys || !patch_info)))
+	if (!c || (npatch && (!patch_keys || !patch_info)))
 		return fail(SDT_EINVAL, "NULL argument");
 	const bool by_index = keys == nullptr;
-	if (by_index && n && (!c->d_idx || c->idx_slots != c->slots || c->idx_n != n))
+	// keys == NULL and path_words == NULL: the path words sdt_gpu_build_edges left on the device
+	uint64_t *d_own = (!keys && !path_words && n) ? sdti::graph_take_path_words(c->gx, n) : nullptr;
+	if (n && !path_words && !d_own)
+		return fail(keys ? SDT_EINVAL : SDT_ESTATE, "no path words: pass them, or build the edges with sdt_gpu_build_edges first");
+	if (by_index && n && (!c->d_idx || c->idx_slots != c->slots || c->idx_n != n)) {
+		if (d_own) (void)hipFree(d_own);
 		return fail(SDT_ESTATE, "keys == NULL needs the node index of sdt_gpu_set_node_index for the same %llu nodes", (unsigned long long)n);
+	}
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	uint64_t *d_k = nullptr, *d_i = nullptr;
 	if (n) {
 		if (!by_index) HIPCHK(hipMalloc((void **)&d_k, n * c->nw * sizeof(uint64_t)));
-		hipError_t e = hipMalloc((void **)&d_i, n * sizeof(uint64_t));
+		hipError_t e = d_own ? hipSuccess : hipMalloc((void **)&d_i, n * sizeof(uint64_t));
 		if (e != hipSuccess) { if (d_k) (void)hipFree(d_k); return fail(SDT_ENOMEM, "path words: %s", hipGetErrorString(e)); }
+		if (d_own) d_i = d_own;
 		int rcu = by_index ? SDT_OK : sdti::h2d_big(c->copy_stream, d_k, keys, n * c->nw * sizeof(uint64_t));
-		if (rcu == SDT_OK) rcu = sdti::h2d_big(c->copy_stream, d_i, path_words, n * sizeof(uint64_t));
+		if (rcu == SDT_OK && !d_own) rcu = sdti::h2d_big(c->copy_stream, d_i, path_words, n * sizeof(uint64_t));
 		if (rcu != SDT_OK) { if (d_k) (void)hipFree(d_k); (void)hipFree(d_i); return rcu; }
 		if (by_index) {
 			const int g = scan_grid(c, c->slots);

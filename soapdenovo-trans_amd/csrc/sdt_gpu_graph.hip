@@ -27,6 +27,10 @@ struct sdti::GraphExt {
 	uint64_t n_nodes = 0;
 	uint64_t *d_result = nullptr;     // records of the last labelled dry run, waiting for sdt_gpu_fetch_records
 	uint64_t result_words = 0;
+	unsigned char *d_seq = nullptr;   // bases of the edges of sdt_gpu_build_edges, waiting for sdt_gpu_fetch_edge_bases
+	uint64_t seq_bytes = 0;
+	uint64_t *d_pw = nullptr;         // path word of every node after sdt_gpu_build_edges (taken by sdt_gpu_load_paths)
+	uint64_t pw_n = 0;
 };
 
 void sdti::graph_ext_free(GraphExt *gx)
@@ -35,7 +39,18 @@ void sdti::graph_ext_free(GraphExt *gx)
 	if (gx->d_sval) (void)hipFree(gx->d_sval);
 	if (gx->d_slot_of) (void)hipFree(gx->d_slot_of);
 	if (gx->d_result) (void)hipFree(gx->d_result);
+	if (gx->d_seq) (void)hipFree(gx->d_seq);
+	if (gx->d_pw) (void)hipFree(gx->d_pw);
 	delete gx;
+}
+
+uint64_t *sdti::graph_take_path_words(GraphExt *gx, uint64_t n)
+{
+	if (!gx || !gx->d_pw || gx->pw_n != n) return nullptr;
+	uint64_t *p = gx->d_pw;
+	gx->d_pw = nullptr;
+	gx->pw_n = 0;
+	return p;
 }
 
 static sdti::GraphExt *ext_of(const GraphView &v)
@@ -88,6 +103,21 @@ static int sort_pairs(const GraphView &v, uint64_t *k_in, uint64_t *k_out, V *v_
 	if (e != hipSuccess || e2 != hipSuccess) return fail(SDT_EHIP, "radix sort of %llu pairs: %s", (unsigned long long)n, hipGetErrorString(e != hipSuccess ? e : e2));
 	return SDT_OK;
 }
+
+template <class T>
+static int exclusive_scan(const GraphView &v, const T *in, T *out, uint64_t n)
+{
+	size_t tmp_bytes = 0;
+	GCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), v.stream));
+	void *tmp = nullptr;
+	GCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+	const hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), v.stream);
+	const hipError_t e2 = hipStreamSynchronize(v.stream);
+	(void)hipFree(tmp);
+	if (e != hipSuccess || e2 != hipSuccess) return fail(SDT_EHIP, "prefix sum over %llu items: %s", (unsigned long long)n, hipGetErrorString(e != hipSuccess ? e : e2));
+	return SDT_OK;
+}
+
 
 extern "C" {
 
@@ -360,6 +390,95 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	*n_junctions = h1;
 	*n_records = h2;
 	return SDT_OK;
+}
+
+// ---- kmer2edges on the device (node2edge.c:46-561) ----------------------------------------------------------------------
+int sdt_gpu_build_edges(sdt_ctx *c, uint64_t *n_edges, uint64_t *num_ed, uint64_t *n_bases)
+{
+	if (!c || !n_edges || !num_ed || !n_bases) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->d_slot_of || !*v.d_idx || *v.idx_slots != v.slots || *v.idx_n != gx->n_nodes) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply first");
+	const uint64_t n = gx->n_nodes;
+	if (n >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "edge building on the device: 32-bit node indices, %llu nodes", (unsigned long long)n);
+	HIPCHK(hipSetDevice(v.device));
+	if (gx->d_result) { (void)hipFree(gx->d_result); gx->d_result = nullptr; gx->result_words = 0; }
+	if (gx->d_seq) { (void)hipFree(gx->d_seq); gx->d_seq = nullptr; gx->seq_bytes = 0; }
+	if (gx->d_pw) { (void)hipFree(gx->d_pw); gx->d_pw = nullptr; gx->pw_n = 0; }
+	Scratch S;
+	const uint64_t m = n ? n : 1;
+	uint32_t *flag, *srank, *start_node;
+	uint64_t *pw;
+	unsigned int *d_asym;
+	GCHK(S.alloc(&flag, (m + 1) * 4)); GCHK(S.alloc(&srank, (m + 1) * 4)); GCHK(S.alloc(&pw, m * 8)); GCHK(S.alloc(&d_asym, 4));
+	GCHK(hipMemsetAsync(flag, 0, (m + 1) * 4, v.stream));
+	GCHK(hipMemsetAsync(d_asym, 0, 4, v.stream));
+	LAUNCH_NW(v, k_edge_starts, sdti::scan_grid(v.cu_count, m), gx->d_slot_of, n, flag, pw);
+	GCHK(hipGetLastError());
+	int rc = exclusive_scan<uint32_t>(v, flag, srank, n + 1);                  // srank[n] = number of start nodes
+	if (rc != SDT_OK) return rc;
+	uint32_t nstarts = 0;
+	GCHK(hipMemcpy(&nstarts, srank + n, 4, hipMemcpyDeviceToHost));
+	const uint64_t nports = (uint64_t)nstarts * 8;
+	PortRec *ports;
+	uint32_t *w_edge, *w_id, *e_scan, *id_scan;
+	uint64_t *w_len, *len_scan;
+	GCHK(S.alloc(&start_node, ((uint64_t)nstarts + 1) * 4)); GCHK(S.alloc(&ports, (nports + 1) * sizeof(PortRec)));
+	GCHK(S.alloc(&w_edge, (nports + 1) * 4)); GCHK(S.alloc(&w_id, (nports + 1) * 4)); GCHK(S.alloc(&w_len, (nports + 1) * 8));
+	GCHK(S.alloc(&e_scan, (nports + 1) * 4)); GCHK(S.alloc(&id_scan, (nports + 1) * 4)); GCHK(S.alloc(&len_scan, (nports + 1) * 8));
+	GCHK(hipMemsetAsync(w_edge + nports, 0, 4, v.stream)); GCHK(hipMemsetAsync(w_id + nports, 0, 4, v.stream)); GCHK(hipMemsetAsync(w_len + nports, 0, 8, v.stream));
+	LAUNCH_NW(v, k_edge_ports_ordered, sdti::scan_grid(v.cu_count, m), *v.d_idx, gx->d_slot_of, flag, srank, n, v.K, n + 1, start_node, ports, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_build_edges: %llu chains leave the graph or never end", (unsigned long long)v.h_stats->probe_fail);
+	if (nports) hipLaunchKernelGGL(k_edge_emit, dim3(sdti::scan_grid(v.cu_count, nports)), dim3(TPB), 0, v.stream, ports, start_node, flag, srank, nports, w_edge, w_id, w_len, d_asym);
+	GCHK(hipGetLastError());
+	unsigned int asym = 0;
+	GCHK(hipMemcpyAsync(&asym, d_asym, 4, hipMemcpyDeviceToHost, v.stream));
+	GCHK(hipStreamSynchronize(v.stream));
+	if (asym) return fail(SDT_ESTATE, "sdt_gpu_build_edges: a chain does not lead back to the port it was entered from (build the edges sequentially)");
+	rc = exclusive_scan<uint32_t>(v, w_edge, e_scan, nports + 1);
+	if (rc == SDT_OK) rc = exclusive_scan<uint32_t>(v, w_id, id_scan, nports + 1);
+	if (rc == SDT_OK) rc = exclusive_scan<uint64_t>(v, w_len, len_scan, nports + 1);
+	if (rc != SDT_OK) return rc;
+	uint32_t ne = 0, ids = 0;
+	uint64_t nb = 0;
+	GCHK(hipMemcpy(&ne, e_scan + nports, 4, hipMemcpyDeviceToHost));
+	GCHK(hipMemcpy(&ids, id_scan + nports, 4, hipMemcpyDeviceToHost));
+	GCHK(hipMemcpy(&nb, len_scan + nports, 8, hipMemcpyDeviceToHost));
+	const int RW = 4 + 2 * v.nw;
+	uint64_t *erec;
+	unsigned char *seq;
+	GCHK(S.alloc(&erec, ((uint64_t)ne + 1) * RW * 8)); GCHK(S.alloc(&seq, nb + 16));
+	if (nports) LAUNCH_NW(v, k_edge_stamp, sdti::scan_grid(v.cu_count, nports), *v.d_idx, gx->d_slot_of, v.K, ports, start_node, nports, w_edge, e_scan, id_scan, len_scan, pw, seq, erec, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_build_edges: %llu chains changed between the two walks", (unsigned long long)v.h_stats->probe_fail);
+	gx->d_result = (uint64_t *)S.release(erec);
+	gx->result_words = (uint64_t)ne * RW;
+	gx->d_seq = (unsigned char *)S.release(seq);
+	gx->seq_bytes = nb;
+	gx->d_pw = (uint64_t *)S.release(pw);
+	gx->pw_n = n;
+	*n_edges = ne;
+	*num_ed = ids;
+	*n_bases = nb;
+	return SDT_OK;
+}
+
+int sdt_gpu_fetch_edge_bases(sdt_ctx *c, char *dst, uint64_t nbytes)
+{
+	if (!c || (nbytes && !dst)) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (nbytes != gx->seq_bytes) return fail(SDT_EINVAL, "the edges have %llu bases, asked for %llu", (unsigned long long)gx->seq_bytes, (unsigned long long)nbytes);
+	HIPCHK(hipSetDevice(v.device));
+	int rc = SDT_OK;
+	if (nbytes) rc = sdti::d2h_big(v.copy_stream, dst, gx->d_seq, nbytes);
+	if (gx->d_seq) (void)hipFree(gx->d_seq);
+	gx->d_seq = nullptr;
+	gx->seq_bytes = 0;
+	return rc;
 }
 
 int sdt_gpu_fetch_records(sdt_ctx *c, uint64_t *dst, uint64_t nwords)

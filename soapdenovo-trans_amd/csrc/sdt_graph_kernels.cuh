@@ -671,3 +671,188 @@ __global__ __launch_bounds__(TPB) void k_port_union(Table<NW> tbl, const uint64_
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
+
+
+// ===============================================================================================================
+// kmer2edges on the device (node2edge.c:46-561): every chain of linear nodes between two nodes that are neither linear
+// nor deleted is one edge.  The reference emits it from whichever end it visits first (set, slot order; right links 0..3
+// on the stored strand, then left links 0..3 on the other), numbers the edges in that order (a chain that is not its own
+// reverse complement takes two ids) and stamps the interior nodes with the id.  With the nodes numbered in visiting order
+// all of that is data parallel: an edge belongs to the smaller of its two (node, port) ends, its id is a prefix sum.
+//   k_edge_starts          flag the nodes that start edges; initial path word of every node (second read pass, sdt_map_kernels.cuh)
+//   k_edge_ports_ordered   the port walks of k_edge_ports, one record per start node at its rank among the start nodes
+//   k_edge_emit            which ports emit their edge; weights for the three prefix sums (ids, sequence offsets, edge index)
+//   k_edge_stamp           per emitted port: walk again, stamp the interior nodes' path words, write the edge's bases and its
+//                          record: [0] length | bal_edge << 32, [1] cvg, [2] id, [3] offset of its bases, then the oriented
+//                          first and last k-mer (NW words each)
+// ===============================================================================================================
+constexpr uint64_t GP_SKIP = 1, GP_LINEAR = 2;       // = PATH_SKIP / PATH_LINEAR of sdt_map_kernels.cuh
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_edge_starts(Table<NW> tbl, const uint64_t *__restrict__ slot_of, uint64_t n, uint32_t *__restrict__ flag,
+                                                     uint64_t *__restrict__ pw)
+{
+	for (uint64_t v = blockIdx.x * (uint64_t)TPB + threadIdx.x; v < n; v += (uint64_t)gridDim.x * TPB) {
+		const uint32_t a = tbl.aux[slot_of[v]];
+		const bool lin = a & AUX_LINEAR, del = a & AUX_DELETED;
+		flag[v] = !lin && !del;
+		pw[v] = del ? GP_SKIP : (lin ? (GP_SKIP | GP_LINEAR) : 0ULL);      // skip = deleted || (linear && !inEdge), prlRead2path.c:650
+	}
+}
+
+struct PortRec { uint64_t far, meta; };              // far node index (~0: no link), length | far_port << 32 | bal_edge << 40
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_edge_ports_ordered(Table<NW> tbl, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ slot_of,
+                                                            const uint32_t *__restrict__ flag, const uint32_t *__restrict__ srank, uint64_t n, int K,
+                                                            uint64_t max_steps, uint32_t *__restrict__ start_node, PortRec *__restrict__ ports, Stats *stats)
+{
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	const int tb = 2 * (K - 1);
+	uint32_t missing = 0;
+	for (uint64_t v = blockIdx.x * (uint64_t)TPB + threadIdx.x; v < n; v += (uint64_t)gridDim.x * TPB) {
+		if (!flag[v]) continue;
+		const uint64_t r = srank[v];
+		start_node[r] = (uint32_t)v;
+		const Entry<NW> e = tbl.ent[slot_of[v]];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+		const Key<NW> me_rc = key_revcomp<NW>(me, K);
+		for (int p = 0; p < 8; p++) {
+			uint64_t far = ~0ULL, meta = 0;
+			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
+			if (live) {
+				const Key<NW> k0 = p < 4 ? me : me_rc;
+				uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+				Key<NW> prev = k0, word = key_next_masked<NW>(k0, b, mask), k1 = word;
+				uint64_t len = 1;
+				bool ok = true, sm;
+				uint64_t os;
+				for (;;) {
+					const Key<NW> bal = key_revcomp<NW>(word, K);
+					sm = !key_less<NW>(bal, word);
+					if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+					if (!(tbl.aux[os] & AUX_LINEAR)) break;
+					if (++len > max_steps) { missing++; ok = false; break; }
+					const uint64_t ov = tbl.ent[os].val;
+					b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+					prev = word;
+					word = key_next_masked<NW>(word, b, mask);
+				}
+				if (ok) {
+					uint32_t fc = 0;
+#pragma unroll
+					for (int w = 0; w < NW; w++)
+						if (w == NW - 1 - (tb >> 6)) fc = (uint32_t)(prev.w[w] >> (tb & 63)) & 3u;
+					const uint32_t far_port = sm ? 4u + fc : (fc ^ 2u);
+					const Key<NW> rc0 = key_revcomp<NW>(k0, K), rc1 = key_revcomp<NW>(k1, K);
+					const bool palin = key_eq<NW>(word, rc0) && key_eq<NW>(prev, rc1);
+					far = idx[os];
+					meta = len | ((uint64_t)far_port << 32) | ((uint64_t)(palin ? 0 : 1) << 40);
+				}
+			}
+			ports[r * 8 + p].far = far;
+			ports[r * 8 + p].meta = meta;
+		}
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+// one thread per port: does it emit its edge?  (the first of the two ends in visiting order; node2edge.c's zeroing of the far
+// link is what keeps the other end quiet.)  asym: a far port whose own walk does not come back here -- the host then builds the
+// edges the reference's sequential way.
+__global__ __launch_bounds__(TPB) void k_edge_emit(const PortRec *__restrict__ ports, const uint32_t *__restrict__ start_node, const uint32_t *__restrict__ flag,
+                                                   const uint32_t *__restrict__ srank, uint64_t nports, uint32_t *__restrict__ w_edge,
+                                                   uint32_t *__restrict__ w_id, uint64_t *__restrict__ w_len, unsigned int *asym)
+{
+	for (uint64_t rp = blockIdx.x * (uint64_t)TPB + threadIdx.x; rp < nports; rp += (uint64_t)gridDim.x * TPB) {
+		const PortRec P = ports[rp];
+		uint32_t emit = 0;
+		if (P.far != ~0ULL) {
+			const uint64_t v = start_node[rp >> 3];
+			const uint32_t p = (uint32_t)(rp & 7), fp = (uint32_t)(P.meta >> 32) & 0xFFu;
+			emit = 1;
+			if (flag[P.far]) {
+				const PortRec Q = ports[(uint64_t)srank[P.far] * 8 + fp];
+				if (Q.far != ~0ULL) {
+					if (!(Q.far == v && ((uint32_t)(Q.meta >> 32) & 0xFFu) == p)) atomicOr(asym, 1u);
+					emit = (v < P.far || (v == P.far && p <= fp)) ? 1u : 0u;
+				}
+			}
+		}
+		w_edge[rp] = emit;
+		w_id[rp] = emit ? 1u + ((uint32_t)(P.meta >> 40) & 1u) : 0u;
+		w_len[rp] = emit ? (P.meta & 0xFFFFFFFFULL) : 0ULL;
+	}
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_edge_stamp(Table<NW> tbl, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ slot_of, int K,
+                                                    const PortRec *__restrict__ ports, const uint32_t *__restrict__ start_node, uint64_t nports,
+                                                    const uint32_t *__restrict__ w_edge, const uint32_t *__restrict__ e_scan, const uint32_t *__restrict__ id_scan,
+                                                    const uint64_t *__restrict__ len_scan, uint64_t *__restrict__ pw, unsigned char *__restrict__ seq,
+                                                    uint64_t *__restrict__ erec, Stats *stats)
+{
+	Key<NW> mask;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const int bits = 2 * K - 64 * (NW - 1 - i);
+		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
+	}
+	constexpr int RW = 4 + 2 * NW;
+	uint32_t missing = 0;
+	for (uint64_t rp = blockIdx.x * (uint64_t)TPB + threadIdx.x; rp < nports; rp += (uint64_t)gridDim.x * TPB) {
+		if (!w_edge[rp]) continue;
+		const PortRec P = ports[rp];
+		const uint64_t length = P.meta & 0xFFFFFFFFULL, cnt = length + 1;
+		const uint32_t bal = (uint32_t)(P.meta >> 40) & 1u, id = 1u + id_scan[rp];
+		const uint64_t e = e_scan[rp], off = len_scan[rp];
+		const uint64_t v = start_node[rp >> 3];
+		const int p = (int)(rp & 7);
+		const Entry<NW> first = tbl.ent[slot_of[v]];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = first.key[w];
+		const Key<NW> k0 = p < 4 ? me : key_revcomp<NW>(me, K);
+		uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+		Key<NW> word = key_next_masked<NW>(k0, b, mask);
+		// coverage (merge_linearV2, node2edge.c:474-521): length 1 -- the first node's count; else the four LEFT link counters of
+		// every interior node, visited last to first: in a chain that is its own reverse complement a node occurs twice, and its
+		// second visit (the position in the lower half) reads the id it was just stamped with -- upstream behaviour, kept
+		long long symbol = 0;
+		if (length == 1) symbol = (long long)(((uint64_t)(tbl.aux[slot_of[v]] & 0xFFFFu) << 16) | (first.val >> 48));
+		const uint32_t idsum = (id & 63u) + ((id >> 6) & 63u) + ((id >> 12) & 63u) + ((id >> 18) & 63u);
+		bool ok = true;
+		for (uint64_t i = 1; i < cnt; i++) {
+			const Key<NW> balk = key_revcomp<NW>(word, K);
+			const bool sm = !key_less<NW>(balk, word);
+			uint64_t os;
+			if (!find_slot<NW>(tbl, sm ? word : balk, os)) { missing++; ok = false; break; }
+			seq[off + i - 1] = "ACTG"[word.w[NW - 1] & 3u];
+			if (i + 1 == cnt) break;                                     // the last node: not an interior node
+			const uint64_t ov = tbl.ent[os].val;
+			if (!bal && i < cnt / 2) symbol += idsum;
+			else symbol += (long long)((ov & 63u) + ((ov >> 6) & 63u) + ((ov >> 12) & 63u) + ((ov >> 18) & 63u));
+			pw[idx[os]] = GP_LINEAR | ((uint64_t)(sm ? bal + 1u : 1u - bal) << 2) | ((uint64_t)(sm ? id : id + bal) << 32);
+			b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+			word = key_next_masked<NW>(word, b, mask);
+		}
+		if (!ok) continue;
+		long long cvg = length > 1 ? symbol / (long long)(length - 1) * 10 : symbol / (long long)length * 10;
+		if (cvg > 16000) cvg = 16000;                                    // MaxEdgeCov, inc/def.h:37
+		uint64_t *R = erec + e * RW;
+		R[0] = length | ((uint64_t)bal << 32);
+		R[1] = (uint64_t)cvg;
+		R[2] = id;
+		R[3] = off;
+#pragma unroll
+		for (int w = 0; w < NW; w++) { R[4 + w] = k0.w[w]; R[4 + NW + w] = word.w[w]; }
+	}
+	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}

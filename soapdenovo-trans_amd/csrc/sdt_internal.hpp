@@ -28,6 +28,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 struct GraphExt;                   // state of the graph unit, owned by the context (sdt_gpu_graph.hip)
 void graph_ext_free(GraphExt *gx);
+// the path words sdt_gpu_build_edges left on the device (n words, one per node index), or nullptr; the caller frees them
+uint64_t *graph_take_path_words(GraphExt *gx, uint64_t n);
 
 struct GraphView {
 	int device, K, nw, cu_count;

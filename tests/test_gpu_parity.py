@@ -1119,3 +1119,92 @@ def test_labelled_junction_records_and_their_components(pkg, synth, K, L):
             nodes = [int(r[0]) for r in rec[:nj]]
             assert labs == [want[i] for i in nodes]
             assert list(zip(labs, nodes)) == sorted(zip(labs, nodes))
+
+
+def py_build_edges(keys_int, l, rf, cnt, K):
+    """kmer2edges (node2edge.c:46-561) restated sequentially over the nodes in index order: [(length, bal_edge, cvg, id, from, to,
+    bases)], num_ed, {node: path word} -- interior nodes are stamped last to first and the coverage sum reads what is there"""
+    idx = {k: i for i, k in enumerate(keys_int)}
+    mask = (1 << (2 * K)) - 1
+    lin = [(int(x) >> 24) & 1 for x in rf]
+    dele = [(int(x) >> 25) & 1 for x in rf]
+    ll = [int(x) & 0xFFFFFF for x in l]                  # l_links as the stamping leaves them
+    zeroed = [0] * len(keys_int)
+    edges, num_ed, stamp = [], 0, {}
+    for i, k in enumerate(keys_int):
+        if lin[i] or dele[i]:
+            continue
+        for p in range(8):
+            links = int(rf[i]) & 0xFFFFFF if p < 4 else int(l[i]) & 0xFFFFFF
+            if not (links >> (6 * (p & 3))) & 63 or (zeroed[i] >> p) & 1:
+                continue
+            word = k if p < 4 else _rc_int(k, K)
+            b = p if p < 4 else (p - 4) ^ 2
+            chain, nodes, sms = [word], [i], [1 if p < 4 else 0]
+            while True:
+                word = ((word << 2) | b) & mask
+                bal = _rc_int(word, K)
+                sm = 0 if word > bal else 1
+                o = idx[word if sm else bal]
+                chain.append(word); nodes.append(o); sms.append(sm)
+                if not lin[o]:
+                    break
+                b = _first_link(int(rf[o]) & 0xFFFFFF) if sm else (_first_link(int(l[o]) & 0xFFFFFF) ^ 2)
+            n = len(chain)
+            fc = (chain[-2] >> (2 * (K - 1))) & 3
+            far_port = 4 + fc if sms[-1] else fc ^ 2
+            bal_edge = 0 if all(chain[n - 1 - j] == _rc_int(chain[j], K) for j in range(n)) else 1
+            zeroed[i] |= 1 << p
+            zeroed[nodes[-1]] |= 1 << far_port
+            num_ed += 1
+            eid = num_ed
+            num_ed += bal_edge
+            length = n - 1
+            symbol = int(cnt[i]) if length == 1 else 0
+            for j in range(n - 2, 0, -1):
+                o = nodes[j]
+                v = ll[o]
+                symbol += (v & 63) + ((v >> 6) & 63) + ((v >> 12) & 63) + ((v >> 18) & 63)
+                ll[o] = (eid if sms[j] else eid + bal_edge) & 0xFFFFFFFF
+                stamp[o] = 2 | ((bal_edge + 1 if sms[j] else 1 - bal_edge) << 2) | ((eid if sms[j] else eid + bal_edge) << 32)
+            cvg = (symbol // (length - 1) * 10) if length > 1 else (symbol // length * 10)
+            edges.append((length, bal_edge, min(cvg, 16000), eid, chain[0], chain[-1], "".join("ACTG"[w & 3] for w in chain[1:])))
+    return edges, num_ed, stamp
+
+
+@pytest.mark.parametrize("K,L,p", [(21, 100, 8), (31, 120, 3), (47, 150, 16), (75, 200, 5)])
+def test_edges_built_on_the_device_equal_the_sequential_rule(pkg, synth, K, L, p):
+    """sdt_gpu_build_edges: edge records in id order (length, bal_edge, cvg with the palindrome quirk, id, end k-mers), the bases
+    of every edge and the number of ids == kmer2edges restated sequentially over the nodes in the order the host asked for;
+    hairpin reads (X + rc(X)) put self-complementary chains into the graph"""
+    tx = synth.make_transcriptome(12, seed=K + 2)
+    codes, offs = synth.sample_reads(*tx, n_reads=2500, read_len=L, seed=K + 7, err=0.004)
+    rng = np.random.default_rng(K)
+    extra = []
+    for j in range(6):
+        x = tx[0][200 * j + 17: 200 * j + 17 + L // 2]
+        hp = np.concatenate([x, (x[::-1] ^ 2)]).astype(np.uint8)
+        extra += [hp] * 5
+    codes = np.concatenate([codes] + extra)
+    offs = np.concatenate([offs, offs[-1] + np.cumsum([len(e) for e in extra]).astype(np.uint64)])
+    with pkg.PregraphGPU(K, est_distinct=1 << 15, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        skeys, _ = g.layout_sorted_keys(p, 4 if K > 63 else (2 if K > 31 else 1))
+        g.layout_apply(rng.permutation(len(skeys)).astype(np.uint64))
+        keys, l, rf, cnt = g.export_ordered()
+        ki = keys_to_int(keys)
+        want, want_ids, _ = py_build_edges(ki, l, rf, cnt, K)
+        rec, bases, num_ed = g.build_edges()
+        nw = keys.shape[1]
+        assert num_ed == want_ids and len(rec) == len(want) > 0
+        palins = 0
+        for r, w in zip(rec, want):
+            length, bal = int(r[0]) & 0xFFFFFFFF, (int(r[0]) >> 32) & 1
+            frm = keys_to_int(r[4:4 + nw].reshape(1, nw))[0]
+            to = keys_to_int(r[4 + nw:4 + 2 * nw].reshape(1, nw))[0]
+            got = (length, bal, int(r[1]), int(r[2]), frm, to, bases[int(r[3]):int(r[3]) + length].decode())
+            assert got == w
+            palins += bal == 0
+        assert palins > 0, "the hairpin reads made no self-complementary chain"
