@@ -285,8 +285,9 @@ int sdt_gpu_edge_ports(sdt_ctx *ctx, uint64_t *records, uint64_t max_records, ui
  *                   order (csrc/host/graph/cuttip.c).  Components = union-find over node indices on the device --
  *                   removeSingleTips (thin): tip + end node of every walk; removeMinorTips: non-linear nodes joined by chains
  *                   of <= cut_len linear nodes; removeMinorOut: every record's node + its eight neighbours.  Records:
- *                   walks 3 words (node | info << 56, end, label), all sorted by (label, node); junctions 10 words (node,
- *                   8 neighbours, label), the first *n_junctions sorted by (label, node), then the neighbours to cut.
+ *                   walks 3 words (node | info << 56, end, label), all sorted by (label, node); junctions 14 words (node,
+ *                   8 neighbours, their 8 occurrence counts two per word, label), the first *n_junctions sorted by
+ *                   (label, node), then the neighbours to cut.
  *                   The records stay on the device until fetch_records copies them (nwords = records x words, exactly). */
 int sdt_gpu_layout_sorted_keys(sdt_ctx *ctx, int p, int nw_variant, uint64_t *keys, uint64_t max_nodes, uint64_t *set_start, uint64_t *n);
 int sdt_gpu_layout_apply(sdt_ctx *ctx, const uint64_t *order, uint64_t n);

@@ -447,10 +447,10 @@ class PregraphGPU:
         return self._fetch(nr.value, 3)
 
     def minor_out_labelled(self, threshold: float):
-        """-> (records uint64[n, 10], n_junctions): node, 8 neighbours, label; the junction records sorted by (label, node)"""
+        """-> (records uint64[n, 14], n_junctions): node, 8 neighbours, 8 counts (two per word), label; the junction records sorted by (label, node)"""
         nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
         self._check(self.lib.sdt_gpu_minor_out_labelled(self._ctx, ctypes.c_double(threshold), ctypes.byref(nj), ctypes.byref(nr)))
-        return self._fetch(nr.value, 10), nj.value
+        return self._fetch(nr.value, 14), nj.value
 
     def build_edges(self):
         """-> (records uint64[n_edges, 4 + 2 nw], bases bytes, num_ed): see sdt_gpu_build_edges"""

@@ -176,23 +176,34 @@ static void isolate(graph_t *g, gnode_t *q)
 		}
 }
 
+/* occurrence count of the neighbour across link (side, b): from the dry run's records when they carry it (counts never change) */
+static inline int neighbour_count(graph_t *g, const gnode_t *n, int side, unsigned b)
+{
+	if (g->nb_cnt && g->nb_slot) {
+		const uint32_t s = g->nb_slot[n - g->nodes];
+		if (s && g->nb_pool[(uint64_t)(s - 1) * 8 + (uint64_t)side * 4 + b] != NO_NODE)
+			return (int)g->nb_cnt[(uint64_t)(s - 1) * 8 + (uint64_t)side * 4 + b];
+	}
+	int sm;
+	return (int)neighbour(g, n, side, b, &sm)->count;
+}
+
 static void prune_side(graph_t *g, gnode_t *n, int side, double threshold, uint64_t *off, dry_t *dry)
 {
 	int sm, best = 0;
 	for (unsigned b = 0; b < 4; b++)
 		if (link_of(n, side, b)) {
-			const int c = (int)neighbour(g, n, side, b, &sm)->count;
+			const int c = neighbour_count(g, n, side, b);
 			if (c > best) best = c;
 		}
 	if (!best) return;
 	for (unsigned b = 0; b < 4; b++) {
 		if (!link_of(n, side, b)) continue;                   /* live: an earlier cut may have removed it */
-		gnode_t *q = neighbour(g, n, side, b, &sm);
-		const int c = (int)q->count;
+		const int c = neighbour_count(g, n, side, b);
 		if (c && (double)c / best < threshold) {
 			if (dry) { dry->would_write = 1; return; }
 			(*off)++;
-			isolate(g, q);
+			isolate(g, neighbour(g, n, side, b, &sm));
 		}
 	}
 }
@@ -453,7 +464,8 @@ static int commit_minor_out_by_components(graph_t *g, const uint64_t *ex, uint64
 	return 0;
 }
 
-/* ---- the device's labelled records (sdt_gpu_minor_out_dry): 10 words = node, 8 neighbours, component label; the junction
+/* ---- the device's labelled records (sdt_gpu_minor_out_labelled): MO_RW words = node, 8 neighbours, their 8 occurrence counts
+ * (two per word), component label; the junction
  * records come sorted by (label, node), so a component is a run of records and its visits are in the reference's order ---- */
 static void mo_scatter_records(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
@@ -462,8 +474,9 @@ static void mo_scatter_records(void *vc, uint64_t lo, uint64_t hi, int tid)
 	graph_t *g = (graph_t *)a[0];
 	const uint64_t *rec = (const uint64_t *)a[1];
 	for (uint64_t r = lo; r < hi; r++) {
-		memcpy(&g->nb_pool[r * 8], &rec[r * 10 + 1], 8 * sizeof(uint64_t));
-		g->nb_slot[rec[r * 10]] = (uint32_t)(r + 1);
+		memcpy(&g->nb_pool[r * 8], &rec[r * MO_RW + 1], 8 * sizeof(uint64_t));
+		memcpy(&g->nb_cnt[r * 8], &rec[r * MO_RW + 9], 8 * sizeof(uint32_t));
+		g->nb_slot[rec[r * MO_RW]] = (uint32_t)(r + 1);
 	}
 }
 
@@ -490,7 +503,7 @@ static void mo_run_labelled(void *vc, uint64_t lo, uint64_t hi, int tid)
 	for (uint64_t k = lo; k < hi; k++) {
 		const uint64_t c = C->corder[k];
 		for (uint64_t r = C->cstart[c]; r < C->cstart[c + 1]; r++)
-			visit_minor_out(C->g, &C->g->nodes[C->rec[r * 10]], C->threshold, &off, NULL);
+			visit_minor_out(C->g, &C->g->nodes[C->rec[r * MO_RW]], C->threshold, &off, NULL);
 	}
 	tl_dirty.on = 0;
 	const int slot = __sync_fetch_and_add(&C->ntl, 1);
@@ -503,13 +516,13 @@ static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t 
 {
 	if (!nj) return;
 	uint64_t ncomp = 1;
-	for (uint64_t r = 1; r < nj; r++) ncomp += rec[r * 10 + 9] != rec[r * 10 - 1];
+	for (uint64_t r = 1; r < nj; r++) ncomp += rec[r * MO_RW + MO_RW - 1] != rec[r * MO_RW - 1];
 	if (ncomp > 0xFFFFFFF0ULL) { printf("too many components of junctions\n"); exit(1); }
 	uint64_t *cstart = (uint64_t *)malloc((ncomp + 1) * sizeof(uint64_t));
 	ncomp = 0;
 	cstart[0] = 0;
 	for (uint64_t r = 1; r < nj; r++)
-		if (rec[r * 10 + 9] != rec[r * 10 - 1]) cstart[++ncomp] = r;
+		if (rec[r * MO_RW + MO_RW - 1] != rec[r * MO_RW - 1]) cstart[++ncomp] = r;
 	cstart[++ncomp] = nj;
 	uint32_t *corder = (uint32_t *)malloc((ncomp + 1) * sizeof(uint32_t));          /* largest first */
 	uint64_t bucket[66] = {0}, biggest = 0;
@@ -564,14 +577,16 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 		if (nr > 0xFFFFFFF0ULL) { printf("too many junction records\n"); exit(1); }
 		g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
 		g->nb_pool = (uint64_t *)malloc((nr + 1) * 8 * sizeof(uint64_t));
+		g->nb_cnt = (uint32_t *)malloc((nr + 1) * 8 * sizeof(uint32_t));
 		void *sa[2] = {g, rec};
 		par_for(0, nr, 4096, mo_scatter_records, sa);
 		SUBPHASE("scatter records");
 		commit_minor_out_labelled(g, rec, nj, threshold, &off);
 		SUBPHASE("ordered commit");
-		graph_free_later(g->nb_slot, g->nb_pool, rec, NULL);
+		graph_free_later(g->nb_slot, g->nb_pool, rec, g->nb_cnt);
 		g->nb_slot = NULL;
 		g->nb_pool = NULL;
+		g->nb_cnt = NULL;
 		printf("%llu kmers off\n", (unsigned long long)off);
 		mark_linear(g);
 		SUBPHASE("free + mark linear");
@@ -1309,7 +1324,7 @@ static int emu_walks(graph_t *g, int thin, int cut_len, uint64_t **records, uint
 static int cmp_rec10(const void *a, const void *b)
 {
 	const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
-	if (x[9] != y[9]) return x[9] < y[9] ? -1 : 1;
+	if (x[MO_RW - 1] != y[MO_RW - 1]) return x[MO_RW - 1] < y[MO_RW - 1] ? -1 : 1;
 	return x[0] < y[0] ? -1 : x[0] > y[0];
 }
 
@@ -1334,19 +1349,23 @@ static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint6
 		if (c.writes[i]) nj++;
 		else if (g->nb_slot[i]) nc++;
 	}
-	uint64_t *rec = (uint64_t *)malloc((nj + nc + 1) * 10 * sizeof(uint64_t));
+	uint64_t *rec = (uint64_t *)malloc((nj + nc + 1) * MO_RW * sizeof(uint64_t));
 	uint64_t aj = 0, ac = nj;
 	for (uint64_t i = 0; i < g->n; i++) {
 		if (!g->nb_slot[i]) continue;
-		uint64_t *r = &rec[(c.writes[i] ? aj++ : ac++) * 10];
+		uint64_t *r = &rec[(c.writes[i] ? aj++ : ac++) * MO_RW];
 		r[0] = i;
 		memcpy(r + 1, &g->nb_pool[(uint64_t)(g->nb_slot[i] - 1) * 8], 8 * sizeof(uint64_t));
-		r[9] = 0;
+		for (int k = 0; k < 8; k += 2) {
+			const uint64_t c0 = r[1 + k] != NO_NODE ? g->nodes[r[1 + k] >> 1].count : 0, c1 = r[2 + k] != NO_NODE ? g->nodes[r[2 + k] >> 1].count : 0;
+			r[9 + k / 2] = c0 | (c1 << 32);
+		}
+		r[MO_RW - 1] = 0;
 		for (int k = 0; k < 8; k++)
 			if (r[1 + k] != NO_NODE) cc_union(parent, (uint32_t)i, (uint32_t)(r[1 + k] >> 1));
 	}
-	for (uint64_t r = 0; r < nj; r++) rec[r * 10 + 9] = cc_find(parent, (uint32_t)rec[r * 10]);
-	qsort(rec, nj, 10 * sizeof(uint64_t), cmp_rec10);
+	for (uint64_t r = 0; r < nj; r++) rec[r * MO_RW + MO_RW - 1] = cc_find(parent, (uint32_t)rec[r * MO_RW]);
+	qsort(rec, nj, MO_RW * sizeof(uint64_t), cmp_rec10);
 	free(parent);
 	free(g->nb_slot); free(g->nb_pool); free(c.need); free(c.writes);
 	g->nb_slot = NULL;

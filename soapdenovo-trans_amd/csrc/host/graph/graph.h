@@ -30,6 +30,8 @@ typedef struct {
 	uint8_t twin, used;
 } gpatch_t;
 
+#define MO_RW 14                       /* words per junction record of dev_minor_out */
+
 typedef struct graph_s {
 	int K, nw, p;
 	uint64_t n;
@@ -57,7 +59,8 @@ typedef struct graph_s {
 	int (*dev_walks)(struct graph_s *g, int thin, int cut_len, uint64_t **records, uint64_t *n_records);   /* 0 = ok */
 	/* kmer2edges' port walks from the device: malloc'ed records (17 words each, sdt_gpu_edge_ports) */
 	int (*dev_edge_ports)(struct graph_s *g, uint64_t **records, uint64_t *n_records);
-	/* removeMinorOut's dry run from the device: malloc'ed records of 10 words (node index, 8 neighbours, component label);
+	/* removeMinorOut's dry run from the device: malloc'ed records of MO_RW words (node index, 8 neighbours, their 8 occurrence
+	 * counts two per word, component label);
 	 * the junction records [0, n_junctions) sorted by (label, node index), then the neighbours to cut in any order */
 	int (*dev_minor_out)(struct graph_s *g, double threshold, uint64_t **records, uint64_t *n_junctions, uint64_t *n_records);
 	/* the whole of kmer2edges from the device (sdt_gpu_build_edges): malloc'ed edge records in id order -- 4 + 2 * *key_words
@@ -70,6 +73,7 @@ typedef struct graph_s {
 	void *dev_user;
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
 	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */
+	uint32_t *nb_cnt;                  /* optional, 8 entries per slot: the occurrence counts of those neighbours */
 } graph_t;
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |

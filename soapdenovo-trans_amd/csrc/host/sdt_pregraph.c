@@ -336,9 +336,9 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
 	if (sdt_gpu_minor_out_labelled(D->gpu, threshold, nj, nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_labelled: %s\n", sdt_gpu_last_error()); return 1; }
-	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * 10 * sizeof(uint64_t));
+	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * MO_RW * sizeof(uint64_t));
 	if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)*nr); return 1; }
-	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * 10) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
+	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * MO_RW) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
 	*records = rec;
 	return 0;
 }

@@ -364,14 +364,14 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	uint64_t cap = nn / 6 + 4096;
 	uint64_t *d_rec = nullptr;
 	for (int attempt = 0; attempt < 2; attempt++) {
-		GCHK(S.alloc(&d_rec, cap * 10 * 8));
+		GCHK(S.alloc(&d_rec, cap * 14 * 8));
 		GCHK(hipMemsetAsync(d_need, 0, nn + 1, v.stream));
 		GCHK(hipMemsetAsync(d_flag, 0, nn + 1, v.stream));
 		GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
-		LAUNCH_NW(v, k_minor_out_junctions, g, *v.d_idx, v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 10);
+		LAUNCH_NW(v, k_minor_out_junctions, g, *v.d_idx, v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 14);
 		GCHK(hipGetLastError());
 		GCHK(hipMemcpyAsync(&h1, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
-		LAUNCH_NW(v, k_minor_out_candidates, g, *v.d_idx, v.K, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 10);
+		LAUNCH_NW(v, k_minor_out_candidates, g, *v.d_idx, v.K, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 14);
 		GCHK(hipGetLastError());
 		GCHK(hipMemcpyAsync(&h2, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
 		const int rc = sdti::sync_stats(c);
@@ -383,9 +383,9 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	}
 	// a visit reads and writes its junction, the junction's neighbours and the neighbours of those it may cut: unite every record's
 	// node with its eight neighbours (junction records and the records of the neighbours to cut alike)
-	if (h2) hipLaunchKernelGGL(k_uf_records, dim3(sdti::scan_grid(v.cu_count, h2)), dim3(TPB), 0, v.stream, parent, d_rec, (uint64_t)h2, 10, 1, 9, 1);
+	if (h2) hipLaunchKernelGGL(k_uf_records, dim3(sdti::scan_grid(v.cu_count, h2)), dim3(TPB), 0, v.stream, parent, d_rec, (uint64_t)h2, 14, 1, 9, 1);
 	GCHK(hipGetLastError());
-	const int rc = label_sort_keep(c, v, parent, d_rec, h2, h1, 10);
+	const int rc = label_sort_keep(c, v, parent, d_rec, h2, h1, 14);
 	if (rc != SDT_OK) return rc;
 	*n_junctions = h1;
 	*n_records = h2;

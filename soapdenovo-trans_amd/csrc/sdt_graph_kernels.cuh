@@ -276,6 +276,10 @@ __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, cons
 			rec[r * rec_stride] = me;
 #pragma unroll
 			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
+			if (rec_stride >= 13) {                              // the neighbours' occurrence counts, two per word
+#pragma unroll
+				for (int q = 0; q < 8; q += 2) rec[r * rec_stride + 9 + q / 2] = (uint64_t)cnt[q] | ((uint64_t)cnt[q + 1] << 32);
+			}
 		}
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
@@ -309,6 +313,10 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
 			rec[r * rec_stride] = me;
 #pragma unroll
 			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
+			if (rec_stride >= 13) {                              // the neighbours' occurrence counts, two per word
+#pragma unroll
+				for (int q = 0; q < 8; q += 2) rec[r * rec_stride + 9 + q / 2] = (uint64_t)cnt[q] | ((uint64_t)cnt[q + 1] << 32);
+			}
 		}
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);

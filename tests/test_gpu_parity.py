@@ -1105,7 +1105,7 @@ def test_labelled_junction_records_and_their_components(pkg, synth, K, L):
         g.mark_and_hist()
         keys, l, rf, cnt = g.export_nodes()
         perm = rng.permutation(len(keys))
-        keys = keys[perm]
+        keys, cnt = keys[perm], cnt[perm]
         g.set_node_index(keys)
         for thr in (0.05, 0.3):
             plain, nj0 = g.minor_out_dry(thr)
@@ -1113,9 +1113,13 @@ def test_labelled_junction_records_and_their_components(pkg, synth, K, L):
             assert nj == nj0 > 0 and len(rec) == len(plain)
             assert sorted(tuple(int(x) for x in r) for r in plain[:nj0]) == sorted(tuple(int(x) for x in r[:9]) for r in rec[:nj])
             assert sorted(tuple(int(x) for x in r) for r in plain[nj0:]) == sorted(tuple(int(x) for x in r[:9]) for r in rec[nj:])
+            for r in rec:                                     # the counts of the neighbours ride along
+                for q in range(8):
+                    c = (int(r[9 + q // 2]) >> (32 * (q & 1))) & 0xFFFFFFFF
+                    assert c == (0 if int(r[1 + q]) == NONE else int(cnt[int(r[1 + q]) >> 1]))
             edges = [(int(r[0]), int(x) >> 1) for r in rec for x in r[1:9] if int(x) != NONE]
             want = _uf_labels(len(keys), edges)
-            labs = [int(r[9]) for r in rec[:nj]]
+            labs = [int(r[13]) for r in rec[:nj]]
             nodes = [int(r[0]) for r in rec[:nj]]
             assert labs == [want[i] for i in nodes]
             assert list(zip(labs, nodes)) == sorted(zip(labs, nodes))
