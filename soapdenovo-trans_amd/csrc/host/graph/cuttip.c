@@ -121,15 +121,27 @@ static void mark_linear_part(void *vc, uint64_t lo, uint64_t hi, int tid)
 
 static uint64_t mark_linear(graph_t *g)
 {
-	ml_ctx M;
-	memset(&M, 0, sizeof M);
-	M.g = g;
-	par_for(0, g->n, 1 << 16, mark_linear_part, &M);
 	uint64_t c = 0;
-	for (int t = 0; t < 64; t++) {
-		for (size_t k = 0; k < M.n[t]; k++) touch(g, &g->nodes[M.list[t][k]]);
-		c += M.n[t];
-		free(M.list[t]);
+	if (g->dirty) {
+		/* with the device mirror every write of a pass is on the dirty list (touch()), and a node can only have become
+		 * 1-in-1-out by being written: the list is all there is to look at.  (Marking appends to the list: stop at its old end.) */
+		const size_t n0 = g->dn;
+		for (size_t k = 0; k < n0; k++) {
+			gnode_t *n = &g->nodes[g->dlist[k]];
+			if (n->deleted || n->linear || !one_in_one_out(n)) continue;
+			n->linear = 1;
+			c++;                                           /* (already dirty: the mirror hears about it with the rest) */
+		}
+	} else {
+		ml_ctx M;
+		memset(&M, 0, sizeof M);
+		M.g = g;
+		par_for(0, g->n, 1 << 16, mark_linear_part, &M);
+		for (int t = 0; t < 64; t++) {
+			for (size_t k = 0; k < M.n[t]; k++) touch(g, &g->nodes[M.list[t][k]]);
+			c += M.n[t];
+			free(M.list[t]);
+		}
 	}
 	printf("%d thread created for cutTipPreGraph\n", g->p);
 	printf("%llu linear nodes\n", (unsigned long long)c);
@@ -487,28 +499,27 @@ typedef struct {
 	const uint32_t *corder;
 	double threshold;
 	volatile uint64_t off;
-	uint64_t **tl;
-	size_t *tln;
-	volatile int ntl;
+	uint64_t *tl[64];         /* dirty lists, one per thread */
+	size_t tln[64], tlcap[64];
 } ml_run_ctx;
 
 static void mo_run_labelled(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
-	(void)tid;
 	ml_run_ctx *C = (ml_run_ctx *)vc;
 	uint64_t off = 0;
 	tl_dirty.on = 1;
-	tl_dirty.v = NULL;
-	tl_dirty.n = tl_dirty.cap = 0;
+	tl_dirty.v = C->tl[tid];                              /* one list per thread, kept across its chunks */
+	tl_dirty.n = C->tln[tid];
+	tl_dirty.cap = C->tlcap[tid];
 	for (uint64_t k = lo; k < hi; k++) {
 		const uint64_t c = C->corder[k];
 		for (uint64_t r = C->cstart[c]; r < C->cstart[c + 1]; r++)
 			visit_minor_out(C->g, &C->g->nodes[C->rec[r * MO_RW]], C->threshold, &off, NULL);
 	}
 	tl_dirty.on = 0;
-	const int slot = __sync_fetch_and_add(&C->ntl, 1);
-	C->tl[slot] = tl_dirty.v;
-	C->tln[slot] = tl_dirty.n;
+	C->tl[tid] = tl_dirty.v;
+	C->tln[tid] = tl_dirty.n;
+	C->tlcap[tid] = tl_dirty.cap;
 	__sync_fetch_and_add(&C->off, off);
 }
 
@@ -536,11 +547,11 @@ static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t 
 		for (int b = 65; b >= 0; b--) { const uint64_t t = bucket[b]; bucket[b] = acc; acc += t; }
 	}
 	for (uint64_t c = 0; c < ncomp; c++) corder[bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++] = (uint32_t)c;
-	const uint64_t per = 16;
-	const uint64_t nchunks = (ncomp + per - 1) / per;
-	ml_run_ctx C = {g, rec, cstart, corder, threshold, 0, (uint64_t **)calloc(nchunks + 1, sizeof(uint64_t *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
-	par_for(0, ncomp, per, mo_run_labelled, &C);
-	for (int t = 0; t < C.ntl; t++) {
+	ml_run_ctx C;
+	memset(&C, 0, sizeof C);
+	C.g = g; C.rec = rec; C.cstart = cstart; C.corder = corder; C.threshold = threshold;
+	par_for(0, ncomp, 16, mo_run_labelled, &C);
+	for (int t = 0; t < 64; t++) {
 		for (size_t k = 0; k < C.tln[t]; k++) {
 			if (g->dn == g->dcap) {
 				g->dcap = g->dcap ? g->dcap * 2 : 4096;
@@ -551,7 +562,7 @@ static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t 
 		free(C.tl[t]);
 	}
 	if (getenv("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nj, (unsigned long long)ncomp, (unsigned long long)biggest);
-	free(C.tl); free(C.tln); free(cstart); free(corder);
+	free(cstart); free(corder);
 	*off += C.off;
 }
 
@@ -964,14 +975,12 @@ typedef struct {
 	uint64_t ncomp;
 	int thin, cut_len;
 	volatile uint64_t tips;
-	uint64_t **tl;
-	size_t *tln;
-	volatile int ntl;
+	uint64_t *tl[64];         /* dirty lists, one per thread */
+	size_t tln[64], tlcap[64];
 } tc_ctx;
 
 static void tc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
 {
-	(void)tid;
 	tc_ctx *T = (tc_ctx *)vc;
 	graph_t *g = T->g;
 	uint64_t tips = 0;
@@ -979,8 +988,9 @@ static void tc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
 	memset(&C, 0, sizeof C);
 	C.g = g;
 	tl_dirty.on = 1;
-	tl_dirty.v = NULL;
-	tl_dirty.n = tl_dirty.cap = 0;
+	tl_dirty.v = T->tl[tid];                              /* one list per thread, kept across its chunks */
+	tl_dirty.n = T->tln[tid];
+	tl_dirty.cap = T->tlcap[tid];
 	tl_comp = &C;
 	for (uint64_t k = lo; k < hi; k++) {
 		const uint64_t c = T->corder[k];
@@ -1015,9 +1025,9 @@ static void tc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
 	tl_comp = NULL;
 	tl_dirty.on = 0;
 	free(C.heap.v); free(C.behind.v); free(C.dyn.v); free(C.vis.v);
-	const int slot = __sync_fetch_and_add(&T->ntl, 1);
-	T->tl[slot] = tl_dirty.v;
-	T->tln[slot] = tl_dirty.n;
+	T->tl[tid] = tl_dirty.v;
+	T->tln[tid] = tl_dirty.n;
+	T->tlcap[tid] = tl_dirty.cap;
 	__sync_fetch_and_add(&T->tips, tips);
 }
 
@@ -1056,11 +1066,11 @@ static uint64_t commit_tips_by_components(graph_t *g, const uint64_t *rec, uint6
 		for (int b = 65; b >= 0; b--) { const uint64_t t = bucket[b]; bucket[b] = acc; acc += t; }
 	}
 	for (uint64_t c = 0; c < ncomp; c++) corder[bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++] = (uint32_t)c;
-	const uint64_t per = 64;
-	const uint64_t nchunks = (ncomp + per - 1) / per;
-	tc_ctx T = {g, rec, cstart, corder, ncomp, thin, cut_len, 0, (uint64_t **)calloc(nchunks + 1, sizeof(uint64_t *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
-	par_for(0, ncomp, per, tc_run, &T);
-	for (int t = 0; t < T.ntl; t++) {
+	tc_ctx T;
+	memset(&T, 0, sizeof T);
+	T.g = g; T.rec = rec; T.cstart = cstart; T.corder = corder; T.ncomp = ncomp; T.thin = thin; T.cut_len = cut_len;
+	par_for(0, ncomp, 256, tc_run, &T);
+	for (int t = 0; t < 64; t++) {
 		for (size_t k = 0; k < T.tln[t]; k++) {
 			if (g->dn == g->dcap) {
 				g->dcap = g->dcap ? g->dcap * 2 : 4096;
@@ -1075,7 +1085,7 @@ static uint64_t commit_tips_by_components(graph_t *g, const uint64_t *rec, uint6
 		for (uint64_t c = 0; c < ncomp; c++) if (cstart[c + 1] - cstart[c] > biggest) biggest = cstart[c + 1] - cstart[c];
 		fprintf(stderr, "[cuttip]     %llu walks in %llu components, largest %llu\n", (unsigned long long)nrec, (unsigned long long)ncomp, (unsigned long long)biggest);
 	}
-	free(T.tl); free(T.tln); free(cstart); free(corder);
+	free(cstart); free(corder);
 	return T.tips;
 }
 

@@ -238,7 +238,14 @@ static void *rp_thread(void *v)
 		const double t0 = getenv("SDT_TIMING") && s == 0 ? gb_now() : 0;
 		if (J->nwk == 1) replay_set1(J->keys + b, m, replay_init_size(J->nw_variant), b, J->order + b);
 		else replay_setw(J->keys + b * J->nwk, J->nwk, m, replay_init_size(J->nw_variant), b, J->order + b);
-		if (t0 > 0) fprintf(stderr, "[graph]      set 0: replay %9.1f ms (%llu nodes)\n", gb_now() - t0, (unsigned long long)m);
+		if (t0 > 0) {
+			fprintf(stderr, "[graph]      set 0: replay %9.1f ms (%llu nodes)\n", gb_now() - t0, (unsigned long long)m);
+			FILE *f = fopen("/proc/self/smaps_rollup", "r");              /* are the big tables on huge pages? */
+			char line[256];
+			while (f && fgets(line, sizeof line, f))
+				if (!strncmp(line, "AnonHugePages:", 14) || !strncmp(line, "Rss:", 4)) fprintf(stderr, "[graph]      %s", line);
+			if (f) fclose(f);
+		}
 	}
 	return NULL;
 }

@@ -679,17 +679,27 @@ int main(int argc, char **argv)
 					qi[np++] = (uint64_t)G->patch[i].edge | ((uint64_t)G->patch[i].twin << 32);
 				}
 			uint64_t nreads2 = 0, narcs = 0;
-			if (sdt_gpu_load_paths(gpu, pk, pw, G->n, qk, qi, np, G->num_ed) != SDT_OK ||
-			    sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
+			const double t_r0 = now_ms();
+			if (sdt_gpu_load_paths(gpu, pk, pw, G->n, qk, qi, np, G->num_ed) != SDT_OK) {
 				fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error());
 				return 1;
 			}
+			const double t_r1 = now_ms();
+			if (sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
+				fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error());
+				return 1;
+			}
+			const double t_r2 = now_ms();
 			free(pk); free(pw); free(qk); free(qi);
 			uint32_t *af = (uint32_t *)malloc((narcs + 1) * 4), *at = (uint32_t *)malloc((narcs + 1) * 4), *am = (uint32_t *)malloc((narcs + 1) * 4);
 			uint64_t *ao = (uint64_t *)malloc((narcs + 1) * 8);
 			if (sdt_gpu_export_arcs(gpu, af, at, am, ao, narcs, &narcs) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+			const double t_r3 = now_ms();
 			printf("%llu reads processed\n", (unsigned long long)nreads2);
 			arcs_write_arrays(prefix, af, at, am, ao, narcs);
+			if (getenv("SDT_TIMING") && !g_quiet)
+				fprintf(stderr, "[read2edge] gather %.1f ms, load paths + patch table %.1f ms, map reads %.1f ms, export %llu arcs %.1f ms, sort + write %.1f ms\n",
+				        t_r0 - g_t_last, t_r1 - t_r0, t_r2 - t_r1, (unsigned long long)narcs, t_r3 - t_r2, now_ms() - t_r3);
 			free(af); free(at); free(am); free(ao);
 		}
 		phase(host_map ? "read2edge (host)" : "read2edge (GPU)");
