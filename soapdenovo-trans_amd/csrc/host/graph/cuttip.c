@@ -119,19 +119,33 @@ static void mark_linear_part(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
+static void mark_linear_dirty(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	ml_ctx *M = (ml_ctx *)vc;
+	graph_t *g = M->g;
+	size_t c = 0;
+	for (uint64_t k = lo; k < hi; k++) {
+		if (k + 8 < hi) __builtin_prefetch(&g->nodes[g->dlist[k + 8]], 1);
+		gnode_t *n = &g->nodes[g->dlist[k]];
+		if (n->deleted || n->linear || !one_in_one_out(n)) continue;
+		n->linear = 1;
+		c++;
+	}
+	M->n[tid] += c;
+}
+
 static uint64_t mark_linear(graph_t *g)
 {
 	uint64_t c = 0;
 	if (g->dirty) {
 		/* with the device mirror every write of a pass is on the dirty list (touch()), and a node can only have become
-		 * 1-in-1-out by being written: the list is all there is to look at.  (Marking appends to the list: stop at its old end.) */
-		const size_t n0 = g->dn;
-		for (size_t k = 0; k < n0; k++) {
-			gnode_t *n = &g->nodes[g->dlist[k]];
-			if (n->deleted || n->linear || !one_in_one_out(n)) continue;
-			n->linear = 1;
-			c++;                                           /* (already dirty: the mirror hears about it with the rest) */
-		}
+		 * 1-in-1-out by being written: the list is all there is to look at (the marked nodes are on it already: the mirror
+		 * hears about them with the rest) */
+		ml_ctx M;
+		memset(&M, 0, sizeof M);
+		M.g = g;
+		par_for(0, g->dn, 1 << 12, mark_linear_dirty, &M);
+		for (int t = 0; t < 64; t++) c += M.n[t];
 	} else {
 		ml_ctx M;
 		memset(&M, 0, sizeof M);

@@ -142,6 +142,43 @@ static int cmp_arc(const void *a, const void *b)
 	return x->first > y->first ? -1 : x->first < y->first;                  /* most recent first appearance first */
 }
 
+/* (from ascending, first appearance descending): LSD radix sort on the composite key from << 64 | ~first, 11 bits per pass,
+ * skipping the digits that are the same in every key */
+static void sort_arcs(arc_t *v, uint64_t m)
+{
+	if (m < 64) { qsort(v, m, sizeof(arc_t), cmp_arc); return; }
+	arc_t *tmp = (arc_t *)malloc(m * sizeof(arc_t));
+	if (!tmp) { qsort(v, m, sizeof(arc_t), cmp_arc); return; }
+	uint64_t or_lo = 0, and_lo = ~0ULL, or_hi = 0, and_hi = ~0ULL;
+	for (uint64_t i = 0; i < m; i++) {
+		const uint64_t lo = ~v[i].first, hi = v[i].key >> 32;
+		or_lo |= lo; and_lo &= lo; or_hi |= hi; and_hi &= hi;
+	}
+	arc_t *src = v, *dst = tmp;
+	for (int pass = 0; pass < 9; pass++) {                              /* digits 0..5: ~first, 6..8: from */
+		const int in_hi = pass >= 6, shift = in_hi ? (pass - 6) * 11 : pass * 11;
+		const uint64_t varying = in_hi ? (or_hi ^ and_hi) : (or_lo ^ and_lo);
+		if (!((varying >> shift) & 0x7FF)) continue;
+		uint64_t *cnt = (uint64_t *)calloc(2049, sizeof(uint64_t));
+		for (uint64_t i = 0; i < m; i++) cnt[(((in_hi ? src[i].key >> 32 : ~src[i].first) >> shift) & 0x7FF) + 1]++;
+		for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+		for (uint64_t i = 0; i < m; i++) dst[cnt[((in_hi ? src[i].key >> 32 : ~src[i].first) >> shift) & 0x7FF]++] = src[i];
+		free(cnt);
+		arc_t *t = src; src = dst; dst = t;
+	}
+	if (src != v) memcpy(v, src, m * sizeof(arc_t));
+	free(tmp);
+}
+
+static inline size_t arc_dec(char *p, uint32_t v)
+{
+	char tmp[12];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	for (int k = 0; k < n; k++) p[k] = tmp[n - 1 - k];
+	return (size_t)n;
+}
+
 /* output_arcs (:454-505) */
 int arcs_write(struct arcs *A, const char *prefix)
 {
@@ -153,14 +190,25 @@ int arcs_write(struct arcs *A, const char *prefix)
 	uint64_t m = 0;
 	for (uint64_t i = 0; i <= A->mask; i++)
 		if (A->tab[i].key) v[m++] = A->tab[i];
-	qsort(v, m, sizeof(arc_t), cmp_arc);
+	sort_arcs(v, m);
+	const size_t cap = (size_t)1 << 20;
+	char *buf = (char *)malloc(cap + 64);
+	size_t o = 0;
 	for (uint64_t i = 0; i < m;) {
 		const uint32_t from = (uint32_t)(v[i].key >> 32);
-		fprintf(fp, "%u", from);
-		for (; i < m && (uint32_t)(v[i].key >> 32) == from; i++)
-			fprintf(fp, " %u %u", (uint32_t)v[i].key, v[i].mult);
-		fputc('\n', fp);
+		o += arc_dec(buf + o, from);
+		for (; i < m && (uint32_t)(v[i].key >> 32) == from; i++) {
+			buf[o++] = ' ';
+			o += arc_dec(buf + o, (uint32_t)v[i].key);
+			buf[o++] = ' ';
+			o += arc_dec(buf + o, v[i].mult);
+			if (o >= cap) { fwrite(buf, 1, o, fp); o = 0; }
+		}
+		buf[o++] = '\n';
+		if (o >= cap) { fwrite(buf, 1, o, fp); o = 0; }
 	}
+	fwrite(buf, 1, o, fp);
+	free(buf);
 	fclose(fp);
 	free(v);
 	return 0;
