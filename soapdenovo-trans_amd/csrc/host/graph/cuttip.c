@@ -525,10 +525,35 @@ static void mo_run_labelled(void *vc, uint64_t lo, uint64_t hi, int tid)
 	tl_dirty.v = C->tl[tid];                              /* one list per thread, kept across its chunks */
 	tl_dirty.n = C->tln[tid];
 	tl_dirty.cap = C->tlcap[tid];
+	graph_t *g = C->g;
 	for (uint64_t k = lo; k < hi; k++) {
 		const uint64_t c = C->corder[k];
-		for (uint64_t r = C->cstart[c]; r < C->cstart[c + 1]; r++)
-			visit_minor_out(C->g, &C->g->nodes[C->rec[r * MO_RW]], C->threshold, &off, NULL);
+		const uint64_t r1 = C->cstart[c + 1];
+		for (uint64_t r = C->cstart[c]; r < r1; r++) {
+			/* a visit is a chain of dependent cache misses (junction -> neighbours -> the cut neighbour's own neighbours); the
+			 * records lie in visiting order and name every neighbour, so the lines of the visits ahead are asked for now:
+			 * three visits ahead the junction and its neighbours (node, pool slot, dirty mark), one visit ahead the neighbour
+			 * tables of those neighbours */
+			if (r + 3 < r1) {
+				const uint64_t *R = C->rec + (r + 3) * MO_RW;
+				__builtin_prefetch(&g->nodes[R[0]], 1);
+				for (int q = 1; q <= 8; q++)
+					if (R[q] != NO_NODE) {
+						__builtin_prefetch(&g->nodes[R[q] >> 1], 1);
+						__builtin_prefetch(&g->nb_slot[R[q] >> 1]);
+						__builtin_prefetch(&g->dirty[R[q] >> 1], 1);
+					}
+			}
+			if (r + 1 < r1) {
+				const uint64_t *R = C->rec + (r + 1) * MO_RW;
+				for (int q = 1; q <= 8; q++)
+					if (R[q] != NO_NODE) {
+						const uint32_t sl = g->nb_slot[R[q] >> 1];
+						if (sl) __builtin_prefetch(&g->nb_pool[(uint64_t)(sl - 1) * 8]);
+					}
+			}
+			visit_minor_out(g, &g->nodes[C->rec[r * MO_RW]], C->threshold, &off, NULL);
+		}
 	}
 	tl_dirty.on = 0;
 	C->tl[tid] = tl_dirty.v;

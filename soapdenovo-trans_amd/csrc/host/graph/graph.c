@@ -90,7 +90,12 @@ static uint64_t replay_final_size(uint64_t init, uint64_t m)
 	return size;
 }
 
+#ifndef RP_AHEAD
 #define RP_AHEAD 16
+#endif
+#ifndef RP_PF
+#define RP_PF(p) __builtin_prefetch((p), 1)
+#endif
 
 /* keys[i] (i = 0..m-1, first-occurrence order) -> ids in slot order */
 static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_t base, uint64_t *out)
@@ -111,15 +116,22 @@ static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_
 			uint64_t ring[RP_AHEAD];
 			for (uint64_t j = 0; j < RP_AHEAD && j < old; j++) {
 				ring[j] = t[j].tag == was ? t[j].key % n : 0;
-				__builtin_prefetch(&t[ring[j]], 1);
+				RP_PF(&t[ring[j]]);
 			}
 			for (uint64_t j = 0; j < old; j++) {
 				const uint64_t home = ring[j % RP_AHEAD];
 				if (j + RP_AHEAD < old) {
 					const uint64_t hp = t[j + RP_AHEAD].tag == was ? t[j + RP_AHEAD].key % n : 0;
 					ring[j % RP_AHEAD] = hp;
-					__builtin_prefetch(&t[hp], 1);
+					RP_PF(&t[hp]);
 				}
+#ifdef RP_SECOND
+				{   /* the landing slot of the entry half way ahead is in cache by now: an unmoved entry sitting there will be evicted
+				     * and carried to ITS home -- ask for that line as well */
+					const uint64_t hq = ring[(j + RP_AHEAD / 2) % RP_AHEAD];
+					if (hq < old && hq > j && t[hq].tag == was) RP_PF(&t[t[hq].key % n]);
+				}
+#endif
 				if (t[j].tag != was) continue;               /* empty, or evicted earlier in this rehash */
 				rent_t carry = t[j];
 				t[j].tag = 0;
@@ -142,7 +154,7 @@ static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_
 			size = n;
 			max = (uint64_t)(n * lf);
 		}
-		if (i + RP_AHEAD < m) __builtin_prefetch(&t[keys[i + RP_AHEAD] % size], 1);    /* its home, unless the table grows first */
+		if (i + RP_AHEAD < m) RP_PF(&t[keys[i + RP_AHEAD] % size]);    /* its home, unless the table grows first */
 		uint64_t h = keys[i] % size;
 		while (t[h].tag) h = h + 1 == size ? 0 : h + 1;
 		t[h].key = keys[i];

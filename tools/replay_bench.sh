@@ -1,0 +1,22 @@
+#!/bin/bash
+# extracts the replay from graph.c and times variants of its prefetching (run on the GPU box: its host is the target)
+set -e
+cd "$(dirname "$0")/.."
+python3 - <<'PY'
+src = open('soapdenovo-trans_amd/csrc/host/graph/graph.c').read()
+a = src.index("typedef struct { uint64_t key; uint32_t id, tag; } rent_t;")
+b = src.index("static uint64_t home_words(")
+open('tools/replay_bench_inc.h', 'w').write(src[a:b])
+PY
+T=${1:-16}; M=${2:-42000000}
+run() { gcc -O2 -pthread "$@" -o /tmp/replay_bench tools/replay_bench.c -lm && echo "== $*" && /tmp/replay_bench $T $M; }
+run
+run -DRP_SECOND
+run -DRP_AHEAD=32
+run -DRP_AHEAD=32 -DRP_SECOND
+run -DRP_AHEAD=64 -DRP_SECOND
+run -DRP_AHEAD=32 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,2)'
+run -DRP_AHEAD=64 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,2)'
+run -DRP_AHEAD=64 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,0)'
+run -DRP_AHEAD=32 -DRP_SECOND -mprfchw
+rm -f tools/replay_bench_inc.h
