@@ -1235,6 +1235,8 @@ static void vx_format(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
+int graph_vertex_quiet = 0;       /* the caller prints the "vertex outputed" line itself (it writes the file ahead of its turn) */
+
 /* output_vertex (output_pregraph.c:29-81) with print_kmer of the emulated variant (kmer.c:499-516) */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix)
 {
@@ -1261,7 +1263,7 @@ uint64_t graph_write_vertex(graph_t *g, const char *prefix)
 	free(V.before); free(V.txt); free(V.len);
 	fputc('\n', fp);
 	fclose(fp);
-	printf("%llu vertex outputed\n", (unsigned long long)c);
+	if (!graph_vertex_quiet) printf("%llu vertex outputed\n", (unsigned long long)c);
 	return c;
 }
 

@@ -129,6 +129,7 @@ void graph_emulate_device(graph_t *g);
 
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);
+extern int graph_vertex_quiet;       /* non-zero: graph_write_vertex does not print its line */
 int graph_write_basic(const char *prefix, uint64_t vertices, int K, uint64_t num_ed, int max_read_len);
 
 #endif

@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 #include <sys/prctl.h>
 #include <signal.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 
@@ -58,7 +59,7 @@ static double now_ms(void)
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
-static double g_t_last;
+static double g_t_last, g_t_main;
 static int g_quiet;                 /* --gpus N: ranks > 0 */
 static void phase(const char *name)
 {
@@ -355,6 +356,17 @@ static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records,
 	return 0;
 }
 
+/* *.vertex written beside the second read pass (the device is busy, the host is not), then the node array is let go */
+typedef struct { graph_t *G; const char *prefix; uint64_t nv; } vx_job;
+static void *vertex_thread(void *v)
+{
+	vx_job *J = (vx_job *)v;
+	J->nv = graph_write_vertex(J->G, J->prefix);
+	graph_free_later(J->G->nodes, J->G->index, J->G->dirty, J->G->dlist);
+	J->G->nodes = NULL; J->G->index = NULL; J->G->dirty = NULL; J->G->dlist = NULL;
+	return NULL;
+}
+
 int main(int argc, char **argv)
 {
 	char cfgfile[4096] = "", prefix[4096] = "";
@@ -404,7 +416,7 @@ int main(int argc, char **argv)
 	else if (K > max_k) K = max_k;
 
 	time_t t_start = time(NULL);
-	g_t_last = now_ms();
+	g_t_last = g_t_main = now_ms();
 	sdt_cfg cfg;
 	if (sdt_cfg_load(cfgfile, &cfg) != 0) return 255;
 	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;                /* prlHashReads.c:361-364 */
@@ -638,6 +650,11 @@ int main(int argc, char **argv)
 			if (Dp->by_index && !getenv("SDT_HOST_EDGES")) G->dev_build_edges = dev_build_edges_hook;
 			G->dev_user = Dp;
 		}
+		uint64_t nv_early = 0;
+		int have_nv = 0;
+		pthread_t vth_keep;
+		vx_job *vj_keep = NULL;
+		memset(&vth_keep, 0, sizeof vth_keep);
 		time_t t0 = time(NULL);
 		graph_remove_minor_out(G, dd);                                     /* pregraph.c:68-71 */
 		phase(G->dev_minor_out ? "removeMinorOut (GPU dry run + host commit)" : "removeMinorOut (host)");
@@ -678,6 +695,17 @@ int main(int argc, char **argv)
 					for (int w = 0; w < nwk; w++) qk[np * nwk + w] = G->patch[i].seq.w[4 - nwk + w];
 					qi[np++] = (uint64_t)G->patch[i].edge | ((uint64_t)G->patch[i].twin << 32);
 				}
+			/* with the edges (and the path words) made on the device the host graph has one duty left, *.vertex: write it now and
+			 * let go of the node array while the device maps the reads (its line is printed in its turn) */
+			pthread_t vth;
+			vx_job VJ = {G, prefix, 0};
+			if (G->edges_on_device) {
+				graph_vertex_quiet = 1;
+				vj_keep = (vx_job *)malloc(sizeof VJ);
+				*vj_keep = VJ;
+				have_nv = pthread_create(&vth, NULL, vertex_thread, vj_keep) == 0;
+				vth_keep = vth;
+			}
 			uint64_t nreads2 = 0, narcs = 0;
 			const double t_r0 = now_ms();
 			if (sdt_gpu_load_paths(gpu, pk, pw, G->n, qk, qi, np, G->num_ed) != SDT_OK) {
@@ -704,11 +732,16 @@ int main(int argc, char **argv)
 		}
 		phase(host_map ? "read2edge (host)" : "read2edge (GPU)");
 		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
-		uint64_t nv = graph_write_vertex(G, prefix);                       /* pregraph.c:106 */
+		if (have_nv) { pthread_join(vth_keep, NULL); nv_early = vj_keep->nv; }
+		uint64_t nv = nv_early;
+		if (have_nv) printf("%llu vertex outputed\n", (unsigned long long)nv);
+		else nv = graph_write_vertex(G, prefix);                            /* pregraph.c:106 */
 		graph_write_basic(prefix, nv, K, ne, max_read_len);
 		phase("vertex + preGraphBasic");              /* G is not freed: the process ends here and the kernel is faster at it */
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
+	phase("release the device");
+	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", "total inside main", now_ms() - g_t_main);
 	sdt_cfg_free(&cfg);
 	if (gpus > 1 && rank == 0) {                                 /* the ranks that are still leaving (the handler reaps them) */
 		for (int tries = 0; tries < 30000; tries++) {

@@ -1686,6 +1686,12 @@ static int push_reads_enqueue(sdt_ctx *c, const uint32_t *packed_words, uint64_t
 	if (nreads == 0)
 		return SDT_OK;
 	HIPCHK(hipSetDevice(c->device));
+	// nothing queued: the launch cursor is the truth (calls that count device-resident reads advance it on their own, and
+	// sdt_gpu_set_read_ordinal sets both when the queue is empty)
+	if (c->staged_head == c->staged.size()) {
+		c->push_ord_base = c->ord_base;
+		c->push_ord_stride = c->ord_stride;
+	}
 	// batch geometry from the host copy of the offsets
 	uint64_t kmers = 0, maxlen = 0, bad = 0;
 	const uint64_t Kp1 = (uint64_t)c->K + 1;
@@ -2710,7 +2716,9 @@ int sdt_gpu_push_reads_sharded(sdt_ctx *c, const uint32_t *packed_words, uint64_
 	}
 	if (nreads && ((offsets[nreads] + 15) >> 4) + TAIL_PAD > nwords)
 		return fail(SDT_EINVAL, "packed_words too short");
-	// staging buffers of the single-rank path (slot 0); the call is synchronous with respect to them
+	// staging buffers of the single-rank path (slot 0); the call is synchronous with respect to them -- a batch that an earlier
+	// asynchronous push left staged there is launched first
+	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	uint32_t *dw = nullptr;
 	uint64_t *dof = nullptr;
 	if (nreads) {

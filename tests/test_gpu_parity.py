@@ -1212,3 +1212,29 @@ def test_edges_built_on_the_device_equal_the_sequential_rule(pkg, synth, K, L, p
             assert got == w
             palins += bal == 0
         assert palins > 0, "the hairpin reads made no self-complementary chain"
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_read_ordinals_continue_from_device_batches_into_pushed_ones(pkg, synth, mode):
+    """a batch counted from device memory followed by a pushed batch with no finish_count in between: the pushed reads continue
+    the ordinals of the stream (first-occurrence order == one stream through the oracle)"""
+    import torch
+    K, L, n = 31, 100, 6000
+    tx = synth.make_transcriptome(20, seed=5)
+    codes, offs = synth.sample_reads(*tx, n_reads=n, read_len=L, seed=6, err=0.004)
+    words = synth.pack_2bit(codes)
+    half = n // 2
+    w1 = np.ascontiguousarray(words[: half * L // 16 + 8])
+    o = ob.Oracle(K, nsets=4)
+    o.add_reads(codes, offs)
+    d_w = torch.from_numpy(w1.view(np.int32).copy()).cuda()
+    d_o = torch.from_numpy(offs[: half + 1].astype(np.int64)).cuda()
+    codes2 = codes[half * L:]
+    offs2 = (offs[half:] - offs[half]).astype(np.uint64)
+    with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=mode | pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.count_reads_device(d_w, w1.size, d_o, half, L)
+        g.push_reads(synth.pack_2bit(codes2), offs2)               # no finish_count in between
+        kmers, nodes = g.finish_count()
+        assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
+        _, _, _, _, first = g.export_nodes(with_first=True)
+        assert sorted(first.tolist()) == sorted(o.export_first().tolist())

@@ -33,8 +33,16 @@ static void *run(void *v)
 	J->cs = cs;
 	return NULL;
 }
+#include <sys/syscall.h>
+#include <unistd.h>
 int main(int argc, char **argv)
 {
+	if (getenv("INTERLEAVE")) {                                /* MPOL_INTERLEAVE over the first N nodes */
+		unsigned long mask[16] = {0};
+		const int nodes = atoi(getenv("INTERLEAVE"));
+		for (int i = 0; i < nodes; i++) mask[i / 64] |= 1UL << (i % 64);
+		if (syscall(SYS_set_mempolicy, 3, mask, 1024) != 0) perror("set_mempolicy");
+	}
 	const int nt = argc > 1 ? atoi(argv[1]) : 16;
 	const uint64_t m = argc > 2 ? strtoull(argv[2], 0, 10) : 42000000;
 	pthread_t th[256];

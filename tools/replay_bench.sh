@@ -11,12 +11,7 @@ PY
 T=${1:-16}; M=${2:-42000000}
 run() { gcc -O2 -pthread "$@" -o /tmp/replay_bench tools/replay_bench.c -lm && echo "== $*" && /tmp/replay_bench $T $M; }
 run
-run -DRP_SECOND
-run -DRP_AHEAD=32
-run -DRP_AHEAD=32 -DRP_SECOND
-run -DRP_AHEAD=64 -DRP_SECOND
-run -DRP_AHEAD=32 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,2)'
-run -DRP_AHEAD=64 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,2)'
-run -DRP_AHEAD=64 -DRP_SECOND '-DRP_PF(p)=__builtin_prefetch((p),0,0)'
-run -DRP_AHEAD=32 -DRP_SECOND -mprfchw
+ls /sys/devices/system/node | grep -c node; lscpu | grep -i "numa\|model name\|^CPU(s)" ; cat /sys/fs/cgroup/cpuset.cpus.effective 2>/dev/null || true
+for t in 1 4 8 16; do /tmp/replay_bench $t $M; done
+for n in 2 4 8; do echo "interleave over $n nodes"; INTERLEAVE=$n /tmp/replay_bench $T $M; done
 rm -f tools/replay_bench_inc.h
