@@ -108,6 +108,7 @@ static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_
 	uint64_t size = init, count = 0, max = (uint64_t)(size * 0.77f);
 	const double lf = (double)0.77f;
 	uint32_t gen = 1;
+	uint64_t hring[RP_AHEAD], ring_size = 0;
 	for (uint64_t i = 0; i < m; i++) {
 		if (count + 1 > max) {
 			/* encap_kmerset (newhash.c:293-409) */
@@ -154,8 +155,13 @@ static void replay_set1(const uint64_t *keys, uint64_t m, uint64_t init, uint64_
 			size = n;
 			max = (uint64_t)(n * lf);
 		}
-		if (i + RP_AHEAD < m) RP_PF(&t[keys[i + RP_AHEAD] % size]);    /* its home, unless the table grows first */
-		uint64_t h = keys[i] % size;
+		/* the homes of the keys ahead are computed once, prefetched, and kept in a ring (a growth in between refills it) */
+		if (i == 0 || count == 0 || ring_size != size) {
+			for (uint64_t j = 0; j < RP_AHEAD && i + j < m; j++) { hring[(i + j) % RP_AHEAD] = keys[i + j] % size; RP_PF(&t[hring[(i + j) % RP_AHEAD]]); }
+			ring_size = size;
+		}
+		uint64_t h = hring[i % RP_AHEAD];
+		if (i + RP_AHEAD < m) { const uint64_t hp = keys[i + RP_AHEAD] % size; hring[i % RP_AHEAD] = hp; RP_PF(&t[hp]); }
 		while (t[h].tag) h = h + 1 == size ? 0 : h + 1;
 		t[h].key = keys[i];
 		t[h].id = (uint32_t)i;
@@ -458,10 +464,26 @@ static void job_scatter_sets(build_job *J, int tid)
 
 #define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
+/* free() of a multi-gigabyte block is one munmap that holds the address-space lock for its whole length, and every page fault
+ * of every other thread waits behind it (a 32 GB node array let go beside the second read pass stalled the arcs' download for
+ * 1.5 s).  Large blocks give their pages back first, in pieces, under the shared lock (MADV_DONTNEED); the munmap that follows
+ * finds nothing left to do. */
+#include <sys/mman.h>
+#include <malloc.h>
+static void release_pages(void *p)
+{
+	if (!p) return;
+	const size_t sz = malloc_usable_size(p), piece = (size_t)256 << 20, page = 4096;
+	if (sz < ((size_t)1 << 30)) return;
+	char *a = (char *)(((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1)), *e = (char *)(((uintptr_t)p + sz) & ~(uintptr_t)(page - 1));
+	for (; a < e; a += piece)
+		madvise(a, (size_t)(e - a) < piece ? (size_t)(e - a) : piece, MADV_DONTNEED);
+}
+
 static void *free_worker(void *v)
 {
 	void **p = (void **)v;
-	for (int i = 0; i < 4; i++) free(p[i]);
+	for (int i = 0; i < 4; i++) { release_pages(p[i]); free(p[i]); }
 	free(p);
 	return NULL;
 }
