@@ -95,6 +95,11 @@ int sdt_gpu_push_reads_async(sdt_ctx *ctx, const uint32_t *packed_words, uint64_
 int sdt_gpu_push_reads_fixed_async(sdt_ctx *ctx, const uint32_t *packed_words, uint64_t nwords, uint64_t nreads, uint64_t read_len,
                                    uint64_t *ticket);
 int sdt_gpu_push_wait(sdt_ctx *ctx, uint64_t ticket);
+/* pinned host memory for the buffers of asynchronous pushes (the copy engine reads it directly; a push from pageable memory is
+ * staged by the runtime at a fraction of the link and blocks the caller): stands where the reference mallocs its two read
+ * buffers (prlHashReads.c:430-470).  NULL when no memory can be pinned.  Callable from any host thread. */
+void *sdt_gpu_host_alloc(size_t bytes);
+void sdt_gpu_host_free(void *p);
 int sdt_gpu_hint_total_kmers(sdt_ctx *ctx, uint64_t kmers);
 
 /* Read ordinals of the NEXT batch: read i of it gets ordinal base + i*stride; afterwards the base advances by

@@ -38,6 +38,8 @@ _ABI = [
     ("sdt_gpu_push_reads_fixed_async", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_push_wait", _c.c_int, [_c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_hint_total_kmers", _c.c_int, [_c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_host_alloc", _c.c_void_p, [_c.c_size_t]),
+    ("sdt_gpu_host_free", None, [_c.c_void_p]),
     ("sdt_gpu_count_reads_device", _c.c_int,
      [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),

@@ -48,6 +48,8 @@ typedef struct {
 	unsigned long long reads;
 	/* --gpus N: chunk i of the stream is counted by rank i % N; one collective push per group of N chunks */
 	int rank, nranks, keep_all, fill, have;
+	int K, hinted;
+	uint64_t total_text;               /* bytes of all input files (0: unknown) */
 	uint32_t *w;
 	uint64_t *o, nw, n, cap_w, cap_o, ord_base, ord_stride;
 } push_state;
@@ -69,6 +71,40 @@ static void phase(const char *name)
 	g_t_last = t;
 }
 
+/* bytes of every file pass 1 will read (readstream.c's selection: asm_flags 1 or 3) */
+static uint64_t input_bytes(const sdt_cfg *cfg)
+{
+	uint64_t total = 0;
+	for (int i = 0; i < cfg->nlibs; i++) {
+		const sdt_lib *l = &cfg->libs[i];
+		if (l->asm_flag != 1 && l->asm_flag != 3) continue;
+		char **lists[] = {l->f1, l->f2, l->q1, l->q2, l->p, l->f, l->q};
+		const int counts[] = {l->nf1, l->nf2, l->nq1, l->nq2, l->np, l->nf, l->nq};
+		for (int k = 0; k < 7; k++)
+			for (int j = 0; j < counts[k]; j++) {
+				struct stat sb;
+				if (stat(lists[k][j], &sb) == 0) total += (uint64_t)sb.st_size;
+			}
+	}
+	return total;
+}
+
+/* pooled batches (pinned buffers, seqio.h) are pushed asynchronously: the buffer goes back to the pool once its copy has left it,
+ * a few pushes later */
+#define PUSH_DEPTH 12
+static struct { int slot[PUSH_DEPTH]; uint64_t ticket[PUSH_DEPTH]; int head, n; } g_inflight;
+
+static int inflight_retire(sdt_ctx *gpu, int down_to)
+{
+	while (g_inflight.n > down_to) {
+		if (sdt_gpu_push_wait(gpu, g_inflight.ticket[g_inflight.head]) != SDT_OK) { fprintf(stderr, "sdt_gpu_push_wait: %s\n", sdt_gpu_last_error()); return -1; }
+		sdt_pool_release(g_inflight.slot[g_inflight.head]);
+		g_inflight.head = (g_inflight.head + 1) % PUSH_DEPTH;
+		g_inflight.n--;
+	}
+	return 0;
+}
+
 static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
 {
 	push_state *st = (push_state *)user;
@@ -76,7 +112,31 @@ static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_
 	st->reads += b->nreads;
 	if (st->reads / 1000000ULL != before)
 		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);    /* prlHashReads.c:587-588 */
+	static int parse_only = -1;                              /* SDT_PARSE_ONLY=1 (measurement): parse and pack, push nothing */
+	if (parse_only < 0) parse_only = getenv("SDT_PARSE_ONLY") != NULL;
+	if (parse_only) return 0;
+	if (st->total_text && !st->hinted && b->text_bytes && b->nreads) {
+		/* the size of the job from its first chunk: k-mers per byte of text x bytes of all files (the pools of the locality
+		 * pipeline are then the job's from the first batch on) */
+		uint64_t km = 0;
+		for (uint64_t i = 0; i < b->nreads; i++) { const uint64_t len = b->offsets[i + 1] - b->offsets[i]; if (len > (uint64_t)st->K) km += len - (uint64_t)st->K + 1; }
+		sdt_gpu_hint_total_kmers(st->gpu, (uint64_t)((double)km / (double)b->text_bytes * (double)st->total_text));
+		st->hinted = 1;
+	}
 	sdt_gpu_set_read_ordinal(st->gpu, ord_base, ord_stride);
+	if (b->pool_slot >= 0) {
+		uint64_t ticket = 0;
+		const int rc = b->fixed_len ? sdt_gpu_push_reads_fixed_async(st->gpu, b->words, b->nwords, b->nreads, b->fixed_len, &ticket)
+		                            : sdt_gpu_push_reads_async(st->gpu, b->words, b->nwords, b->offsets, b->nreads, &ticket);
+		if (rc != SDT_OK) { fprintf(stderr, "sdt_gpu_push_reads_async: %s\n", sdt_gpu_last_error()); return -1; }
+		if (inflight_retire(st->gpu, PUSH_DEPTH - 1) != 0) return -1;
+		const int at = (g_inflight.head + g_inflight.n) % PUSH_DEPTH;
+		g_inflight.slot[at] = b->pool_slot;
+		g_inflight.ticket[at] = ticket;
+		g_inflight.n++;
+		sdt_pool_take(b->pool_slot);
+		return 0;
+	}
 	if (sdt_gpu_push_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_push_reads: %s\n", sdt_gpu_last_error());
 		return -1;
@@ -486,7 +546,12 @@ int main(int argc, char **argv)
 	const size_t chunk = getenv("SDT_CHUNK_BYTES") ? (size_t)strtoull(getenv("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
 	int rc;
 	if (gpus == 1) {
+		st.K = K;
+		st.total_text = input_bytes(&cfg);
+		if (!getenv("SDT_NO_PINNED_POOL")) sdt_pool_enable(sdt_gpu_host_alloc, sdt_gpu_host_free, my_threads + PUSH_DEPTH + 8);
 		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch, &st, NULL);
+		if (rc == 0 && inflight_retire(gpu, 0) != 0) rc = -1;
+		sdt_pool_disable();
 	} else {
 		sdt_read_shard_begin(rank, gpus, st.keep_all);
 		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch_sharded, &st, NULL);

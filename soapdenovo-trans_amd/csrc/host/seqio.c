@@ -15,6 +15,7 @@ typedef struct {
 	sdt_batch out;
 	int done;
 	int owner, encode;          /* sdt_read_shard_begin */
+	int slot;                   /* pool buffer taken with the chunk number, -1 = none */
 } chunk_t;
 
 static int g_shard_rank = 0, g_shard_n = 1, g_shard_keep_all = 0;
@@ -36,10 +37,85 @@ typedef struct {
 	pthread_cond_t cv;
 } job_t;
 
+/* ---- pool of output buffers (seqio.h) ---- */
+typedef struct { uint32_t *w; uint64_t *o; size_t wcap, ocap; int state; } pslot_t;      /* state: 0 free, 1 in use, 2 taken by the consumer */
+static struct {
+	void *(*alloc)(size_t);
+	void (*release)(void *);
+	pslot_t *slot;
+	int n, on;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+} g_pool = {NULL, NULL, NULL, 0, 0, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER};
+
+void sdt_pool_enable(void *(*alloc)(size_t bytes), void (*release)(void *p), int nslots)
+{
+	sdt_pool_disable();
+	g_pool.alloc = alloc; g_pool.release = release;
+	g_pool.slot = (pslot_t *)calloc((size_t)nslots, sizeof(pslot_t));
+	g_pool.n = nslots;
+	g_pool.on = 1;
+}
+
+void sdt_pool_disable(void)
+{
+	for (int i = 0; i < g_pool.n; i++) {
+		if (g_pool.slot[i].w) g_pool.release(g_pool.slot[i].w);
+		if (g_pool.slot[i].o) g_pool.release(g_pool.slot[i].o);
+	}
+	free(g_pool.slot);
+	g_pool.slot = NULL;
+	g_pool.n = g_pool.on = 0;
+}
+
+void sdt_pool_take(int slot)
+{
+	pthread_mutex_lock(&g_pool.mu);
+	if (slot >= 0 && slot < g_pool.n) g_pool.slot[slot].state = 2;
+	pthread_mutex_unlock(&g_pool.mu);
+}
+
+void sdt_pool_release(int slot)
+{
+	pthread_mutex_lock(&g_pool.mu);
+	if (slot >= 0 && slot < g_pool.n) g_pool.slot[slot].state = 0;
+	pthread_cond_broadcast(&g_pool.cv);
+	pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* a free slot (blocks until there is one); its buffers hold `text` bytes of input: 2 bits per byte and one offset per 64 bytes
+ * (a chunk with shorter records falls back to malloc) */
+static int pool_acquire_locked(pthread_mutex_t *held, size_t text)
+{
+	(void)held;
+	for (;;) {
+		for (int i = 0; i < g_pool.n; i++)
+			if (g_pool.slot[i].state == 0) {
+				pslot_t *s = &g_pool.slot[i];
+				s->state = 1;
+				const size_t wneed = text / 16 + 64, oneed = text / 64 + 64;
+				if (s->wcap < wneed) {
+					if (s->w) g_pool.release(s->w);
+					s->w = (uint32_t *)g_pool.alloc(wneed * sizeof(uint32_t));
+					s->wcap = s->w ? wneed : 0;
+				}
+				if (s->ocap < oneed) {
+					if (s->o) g_pool.release(s->o);
+					s->o = (uint64_t *)g_pool.alloc(oneed * sizeof(uint64_t));
+					s->ocap = s->o ? oneed : 0;
+				}
+				if (!s->w || !s->o) { s->state = 0; return -1; }          /* no pinned memory: this chunk goes the malloc way */
+				return i;
+			}
+		pthread_cond_wait(&g_pool.cv, &g_pool.mu);
+	}
+}
+
 /* ---- 2-bit stream writer ---- */
 typedef struct {
 	uint32_t *w;
 	uint64_t cap, nbases;
+	int fixed;                  /* w is a pool buffer of `cap` words: it cannot grow (the chunk then moves to a malloc block) */
 } packer_t;
 
 static void pk_reserve(packer_t *p, uint64_t more_bases)
@@ -48,7 +124,14 @@ static void pk_reserve(packer_t *p, uint64_t more_bases)
 	if (need > p->cap) {
 		uint64_t ncap = p->cap ? p->cap * 2 : 1 << 16;
 		while (ncap < need) ncap *= 2;
-		p->w = (uint32_t *)realloc(p->w, ncap * sizeof(uint32_t));
+		if (p->fixed) {                                   /* (cannot happen for buffers sized by the chunk's text: kept for safety) */
+			uint32_t *nw = (uint32_t *)malloc(ncap * sizeof(uint32_t));
+			memcpy(nw, p->w, p->cap * sizeof(uint32_t));
+			p->w = nw;
+			p->fixed = 0;
+		} else {
+			p->w = (uint32_t *)realloc(p->w, ncap * sizeof(uint32_t));
+		}
 		memset(p->w + p->cap, 0, (ncap - p->cap) * sizeof(uint32_t));
 		p->cap = ncap;
 	}
@@ -171,8 +254,21 @@ static void parse_chunk(job_t *J, chunk_t *c)
 {
 	packer_t pk = {0};
 	uint64_t cap_off = 1024, n = 0;
-	uint64_t *offs = (uint64_t *)malloc(cap_off * sizeof(uint64_t));
+	uint64_t *offs;
+	int offs_pooled = 0;
+	if (c->slot >= 0 && c->encode) {
+		pslot_t *ps = &g_pool.slot[c->slot];
+		pk.w = ps->w; pk.cap = ps->wcap; pk.fixed = 1;
+		/* only the words this chunk can reach need to be zero (the packer ORs bases in) */
+		const size_t reach = (size_t)(c->end - c->beg) / 16 + 64;
+		memset(pk.w, 0, (reach < ps->wcap ? reach : ps->wcap) * sizeof(uint32_t));
+		offs = ps->o; cap_off = ps->ocap; offs_pooled = 1;
+	} else {
+		offs = (uint64_t *)malloc(cap_off * sizeof(uint64_t));
+	}
 	offs[0] = 0;
+	uint64_t first_len = 0;
+	int same_len = 1;
 	const char *p = c->beg, *end = c->end;
 	pk_reserve(&pk, 0);
 	while (p < end) {
@@ -219,10 +315,33 @@ static void parse_chunk(job_t *J, chunk_t *c)
 		}
 		if (n + 2 > cap_off) {
 			cap_off *= 2;
-			offs = (uint64_t *)realloc(offs, cap_off * sizeof(uint64_t));
+			if (offs_pooled) {                                /* records shorter than 64 bytes of text: this chunk's offsets leave the pool */
+				uint64_t *no = (uint64_t *)malloc(cap_off * sizeof(uint64_t));
+				memcpy(no, offs, (n + 1) * sizeof(uint64_t));
+				offs = no;
+				offs_pooled = 0;
+			} else {
+				offs = (uint64_t *)realloc(offs, cap_off * sizeof(uint64_t));
+			}
 		}
 		offs[n + 1] = offs[n] + (uint64_t)len;
+		if (n == 0) first_len = (uint64_t)len;
+		else if ((uint64_t)len != first_len) same_len = 0;
 		n++;
+	}
+	c->out.pool_slot = -1;
+	c->out.fixed_len = n && same_len ? first_len : 0;
+	c->out.text_bytes = (uint64_t)(c->end - c->beg);
+	if (c->slot >= 0) {
+		if (c->encode && pk.fixed && offs_pooled) {
+			c->out.pool_slot = c->slot;                       /* everything stayed in the pool buffer */
+		} else {
+			/* (a foreign chunk, or one that outgrew its buffer: copy what is pooled out, give the slot back) */
+			if (c->encode && pk.fixed) { uint32_t *nw = (uint32_t *)malloc(pk.cap * sizeof(uint32_t)); memcpy(nw, pk.w, pk.cap * sizeof(uint32_t)); pk.w = nw; pk.fixed = 0; }
+			if (c->encode && offs_pooled) { uint64_t *no = (uint64_t *)malloc((n + 2) * sizeof(uint64_t)); memcpy(no, offs, (n + 1) * sizeof(uint64_t)); offs = no; }
+			sdt_pool_release(c->slot);
+			c->slot = -1;
+		}
 	}
 	c->out.words = pk.w;
 	c->out.nwords = ((pk.nbases + 15) >> 4) + 4;          /* pk_reserve keeps >= 8 zero words of slack */
@@ -243,10 +362,16 @@ static void *worker(void *arg)
 {
 	job_t *J = (job_t *)arg;
 	for (;;) {
-		pthread_mutex_lock(&J->mu);
-		int i = J->next < J->nchunks ? J->next++ : -1;
-		pthread_mutex_unlock(&J->mu);
+		/* chunk number and pool buffer are taken together (under the pool's lock): buffers then go out in chunk order, and the
+		 * chunk the consumer is waiting for is never the one left without */
+		pthread_mutex_lock(&g_pool.mu);
+		int i = J->next < J->nchunks ? J->next : -1, slot = -1;
+		if (i >= 0 && g_pool.on && J->chunks[i].encode)
+			slot = pool_acquire_locked(&g_pool.mu, (size_t)(J->chunks[i].end - J->chunks[i].beg));
+		if (i >= 0) J->next++;
+		pthread_mutex_unlock(&g_pool.mu);
 		if (i < 0) break;
+		J->chunks[i].slot = slot;
 		parse_chunk(J, &J->chunks[i]);
 		pthread_mutex_lock(&J->mu);
 		J->chunks[i].done = 1;
@@ -333,8 +458,15 @@ int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int 
 		pthread_mutex_unlock(&J.mu);
 		if (rc == 0 && fn(user, &J.chunks[i].out) != 0) rc = -1;
 		total += J.chunks[i].out.nreads;
-		free(J.chunks[i].out.words);
-		free(J.chunks[i].out.offsets);
+		if (J.chunks[i].out.pool_slot >= 0) {                 /* the callback may have kept the buffer (sdt_pool_take) */
+			pthread_mutex_lock(&g_pool.mu);
+			const int kept = g_pool.slot[J.chunks[i].out.pool_slot].state == 2;
+			pthread_mutex_unlock(&g_pool.mu);
+			if (!kept) sdt_pool_release(J.chunks[i].out.pool_slot);
+		} else {
+			free(J.chunks[i].out.words);
+			free(J.chunks[i].out.offsets);
+		}
 	}
 	for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
 	free(th);

@@ -18,7 +18,21 @@ typedef struct {
 	uint64_t nreads;        /* every record of the chunk, also reads shorter than K+1 (the device skips them) */
 	int owner;              /* multi-process runs (sdt_read_shard): the rank that counts this chunk in pass 1 */
 	int counted_only;       /* 1: the chunk belongs to another rank and was only counted (words == offsets == NULL) */
+	int pool_slot;          /* >= 0: words / offsets live in a buffer of the pool below (sdt_pool_take to keep it past the callback) */
+	uint64_t fixed_len;     /* > 0: every read of the batch has exactly this many bases (offsets[i] = i * fixed_len) */
+	uint64_t text_bytes;    /* bytes of the input file this batch was parsed from */
 } sdt_batch;
+
+/* Optional pool of output buffers for a host that hands batches to the device ASYNCHRONOUSLY from pinned memory (the
+ * reference double-buffers its read buffers the same way, prlHashReads.c:493-620): chunks are packed straight into pool
+ * buffers -- allocated through `alloc` (pinned memory behind the C ABI), sized by the chunk length -- instead of fresh
+ * malloc blocks.  A worker takes its buffer together with its chunk number, so the chunk the consumer waits for always has
+ * one.  The consumer's callback may keep a batch's buffer after it returns (sdt_pool_take) and gives it back when the
+ * copy has left it (sdt_pool_release); otherwise the reader recycles it.  sdt_pool_disable frees everything. */
+void sdt_pool_enable(void *(*alloc)(size_t bytes), void (*release)(void *p), int nslots);
+void sdt_pool_disable(void);
+void sdt_pool_take(int slot);
+void sdt_pool_release(int slot);
 
 /* Multi-process runs (`sdt-pregraph --gpus N`): every rank walks the same chunks in the same order, chunk i (counted
  * over all files of a pass) belongs to rank i % nranks.  A rank only COUNTS the records of foreign chunks (the read

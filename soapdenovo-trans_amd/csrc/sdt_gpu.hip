@@ -1564,6 +1564,22 @@ int sdt_gpu_reset(sdt_ctx *c)
 	return SDT_OK;
 }
 
+// pinned host memory for batches that are pushed asynchronously (the DMA engine reads it directly; pageable memory goes through the
+// runtime's own staging copy at a fraction of the link).  Any host thread may call these.
+void *sdt_gpu_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+void sdt_gpu_host_free(void *p)
+{
+	if (p) (void)hipHostFree(p);
+}
+
 int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
 uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -38,6 +38,7 @@ ap.add_argument("--variant", type=int, default=0, choices=[0, 31, 63, 127], help
 ap.add_argument("--ref-p2", type=int, default=0, help="time the reference a second time with this -p (same FASTQ): kmerFreq must agree")
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 ap.add_argument("--gen-procs", type=int, default=0, help="processes that write the FASTQ (0 = one per usable CPU; fixed-width records, written in place)")
+ap.add_argument("--ingest-probe", action="store_true", help="only time --hash-only in variants (as is, parse only, other thread counts) and stop")
 ap.add_argument("--runs", type=int, default=1, help="run sdt-pregraph this many times (page cache, first-touch effects): the fastest is reported, all walls are listed")
 args = ap.parse_args()
 
@@ -206,6 +207,17 @@ try:
     extra = ["--max-k", str(variant)] + common
     res["variant"], res["d"] = variant, args.d
     os.environ["SDT_TIMING"] = "1"
+    if args.ingest_probe:
+        probe = {}
+        for name, env, p_ in (("as_is", {}, args.p), ("as_is_again", {}, args.p), ("parse_only", {"SDT_PARSE_ONLY": "1"}, args.p),
+                              ("parse_only_p8", {"SDT_PARSE_ONLY": "1"}, 8), ("parse_only_p32", {"SDT_PARSE_ONLY": "1"}, 32), ("p8", {}, 8), ("p32", {}, 32)):
+            t0 = time.time()
+            rp = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(p_), "-o", os.path.join(tmp, "probe"),
+                                 "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env))
+            probe[name] = {"wall_s": round(time.time() - t0, 2), "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if "parse + hash" in l]}
+        res["ingest_probe"] = probe
+        print(json.dumps(res, indent=1))
+        raise SystemExit(0)
     walls, r = [], None
     for _run in range(max(1, args.runs)):
         t0 = time.time()
