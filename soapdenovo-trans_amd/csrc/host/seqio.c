@@ -31,7 +31,7 @@ void sdt_read_shard_begin(int rank, int nranks, int keep_all)
 
 typedef struct {
 	chunk_t *chunks;
-	int nchunks, next;
+	int nchunks, next, turn;    /* next: chunk numbers handed out; turn: chunks whose pool buffer has been handed out */
 	int fmt, max_read_len, reverse;
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
@@ -362,13 +362,18 @@ static void *worker(void *arg)
 {
 	job_t *J = (job_t *)arg;
 	for (;;) {
-		/* chunk number and pool buffer are taken together (under the pool's lock): buffers then go out in chunk order, and the
-		 * chunk the consumer is waiting for is never the one left without */
+		/* chunk numbers are taken in order, and so are the pool buffers: the worker of chunk i waits until the buffers of all
+		 * earlier chunks have been handed out (J->turn) -- the chunk the consumer is waiting for is never the one left without */
 		pthread_mutex_lock(&g_pool.mu);
-		int i = J->next < J->nchunks ? J->next : -1, slot = -1;
-		if (i >= 0 && g_pool.on && J->chunks[i].encode)
-			slot = pool_acquire_locked(&g_pool.mu, (size_t)(J->chunks[i].end - J->chunks[i].beg));
-		if (i >= 0) J->next++;
+		const int i = J->next < J->nchunks ? J->next++ : -1;
+		int slot = -1;
+		if (i >= 0) {
+			while (J->turn != i) pthread_cond_wait(&g_pool.cv, &g_pool.mu);
+			if (g_pool.on && J->chunks[i].encode)
+				slot = pool_acquire_locked(&g_pool.mu, (size_t)(J->chunks[i].end - J->chunks[i].beg));
+			J->turn++;
+			pthread_cond_broadcast(&g_pool.cv);
+		}
 		pthread_mutex_unlock(&g_pool.mu);
 		if (i < 0) break;
 		J->chunks[i].slot = slot;

@@ -31,14 +31,17 @@ def bin_path(pkg, name):
 
 
 @pytest.mark.parametrize("name", gu.case_names())
-@pytest.mark.parametrize("threads,chunk", [(1, 1 << 30), (4, 70000)])
-def test_reader_matches_reference_ingest(pkg, tmp_path, name, threads, chunk):
+@pytest.mark.parametrize("threads,chunk,pool", [(1, 1 << 30, 0), (4, 70000, 0), (6, 3000, 8)])
+def test_reader_matches_reference_ingest(pkg, tmp_path, name, threads, chunk, pool):
     """every read the host hands to the GPU == readseqfq's coding/truncation (oracle restatement), for one big
-    chunk and for many small chunks cut at record boundaries by 4 threads"""
+    chunk, for many small chunks cut at record boundaries by 4 threads, and for hundreds of chunks packed by 6 threads into a
+    pool of 8 buffers that the consumer holds on to for three batches each (the asynchronous pushes of sdt-pregraph: chunk
+    numbers and buffers must go out in step, or a chunk is parsed twice and another never)"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
+    env = dict(os.environ, SDT_READDUMP_POOL=str(pool)) if pool else dict(os.environ)
     out = subprocess.run([bin_path(pkg, "sdt-readdump"), cfg, str(threads), str(chunk)], check=True,
-                         capture_output=True, text=True).stdout.splitlines()
+                         capture_output=True, text=True, env=env, timeout=120).stdout.splitlines()
     got = [l for l in out if not l.startswith("#")]
     codes, offs = gu.case_reads(info)
     letters = np.frombuffer(b"ACTG", dtype=np.uint8)[codes].tobytes().decode()

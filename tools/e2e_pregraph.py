@@ -213,7 +213,7 @@ try:
                               ("parse_only_p8", {"SDT_PARSE_ONLY": "1"}, 8), ("parse_only_p32", {"SDT_PARSE_ONLY": "1"}, 32), ("p8", {}, 8), ("p32", {}, 32)):
             t0 = time.time()
             rp = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(p_), "-o", os.path.join(tmp, "probe"),
-                                 "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env))
+                                 "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
             probe[name] = {"wall_s": round(time.time() - t0, 2), "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if "parse + hash" in l]}
         res["ingest_probe"] = probe
         print(json.dumps(res, indent=1))
@@ -238,7 +238,7 @@ try:
     res["ours_walls_s"] = walls
     t0 = time.time()
     r2 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
-                         os.path.join(tmp, "ours_hash"), "--hash-only"] + extra, capture_output=True, text=True)
+                         os.path.join(tmp, "ours_hash"), "--hash-only"] + extra, capture_output=True, text=True, timeout=args.timeout)
     res["ours_hash_only_wall_s"] = round(time.time() - t0, 2)
     if args.compare_host_walks:
         t0 = time.time()
