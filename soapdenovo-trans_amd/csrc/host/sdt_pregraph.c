@@ -515,7 +515,16 @@ int main(int argc, char **argv)
 			g_nchild = g_nchild + 1;
 		}
 	}
-	const int my_threads = gpus == 1 ? threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
+	/* parser threads: the job's CPUs minus the pushing thread and the runtime's helpers -- under a CPU quota (cgroup cpu.max) one
+	 * runnable thread too many throttles every thread of the process, the one that feeds the device included (200 M reads with
+	 * -p 16 on 16 CPUs: 6.3 s against 1.6 s with -p 8).  -p stays the number of sets of the layout (graph.c). */
+	int parse_threads = threads;
+	{
+		const int usable = par_threads();
+		const int cap = getenv("SDT_PARSE_THREADS") ? atoi(getenv("SDT_PARSE_THREADS")) : (usable > 4 ? usable - 3 : usable);
+		if (parse_threads > cap) parse_threads = cap > 0 ? cap : 1;
+	}
+	const int my_threads = gpus == 1 ? parse_threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
 	sdt_ctx *gpu = NULL;
 	/* SDT_PIPELINE=1 (tests): the locality pipeline also for jobs below its 2^27 k-mer threshold */
 	const uint32_t iflags = (hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS))) |

@@ -1427,6 +1427,15 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 		return fail(SDT_ENODEV, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
 	if (device < 0 || device >= ndev)
 		return fail(SDT_EINVAL, "device %d out of range (have %d)", device, ndev);
+	{   // SDT_SYNC=block|yield|spin: how host threads wait for the device (a host that parses on every core it may use wants its
+		// waiting thread off the CPU; the default is the runtime's own choice).  Must be set before the device is first used.
+		const char *sm = getenv("SDT_SYNC");
+		if (sm && *sm) {
+			const unsigned fl = !strcmp(sm, "block") ? hipDeviceScheduleBlockingSync : !strcmp(sm, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
+			(void)hipSetDeviceFlags(fl);
+			(void)hipGetLastError();
+		}
+	}
 	e = hipSetDevice(device);
 	if (e != hipSuccess)
 		return fail(SDT_ENODEV, "hipSetDevice(%d): %s", device, hipGetErrorString(e));

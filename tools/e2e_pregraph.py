@@ -210,7 +210,10 @@ try:
     if args.ingest_probe:
         probe = {}
         for name, env, p_ in (("as_is", {}, args.p), ("as_is_again", {}, args.p), ("parse_only", {"SDT_PARSE_ONLY": "1"}, args.p),
-                              ("parse_only_p8", {"SDT_PARSE_ONLY": "1"}, 8), ("parse_only_p32", {"SDT_PARSE_ONLY": "1"}, 32), ("p8", {}, 8), ("p32", {}, 32)):
+                              ("t8", {"SDT_PARSE_THREADS": "8"}, args.p), ("t10", {"SDT_PARSE_THREADS": "10"}, args.p), ("t12", {"SDT_PARSE_THREADS": "12"}, args.p),
+                              ("t14", {"SDT_PARSE_THREADS": "14"}, args.p), ("t16", {"SDT_PARSE_THREADS": "16"}, args.p),
+                              ("t12_block", {"SDT_PARSE_THREADS": "12", "SDT_SYNC": "block"}, args.p), ("t14_block", {"SDT_PARSE_THREADS": "14", "SDT_SYNC": "block"}, args.p),
+                              ("t16_block", {"SDT_PARSE_THREADS": "16", "SDT_SYNC": "block"}, args.p), ("t12_nopool", {"SDT_PARSE_THREADS": "12", "SDT_NO_PINNED_POOL": "1"}, args.p)):
             t0 = time.time()
             rp = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(p_), "-o", os.path.join(tmp, "probe"),
                                  "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
