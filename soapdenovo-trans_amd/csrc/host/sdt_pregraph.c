@@ -579,6 +579,13 @@ int main(int argc, char **argv)
 		if (sdt_gpu_allreduce_i64(gpu, v, 2) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 		kmers = (uint64_t)v[0]; nodes = (uint64_t)v[1];
 	}
+	if (getenv("SDT_TIMING") && !g_quiet) {
+		double ms[SDT_NSTAGES];
+		uint64_t cn[SDT_NCOUNTERS];
+		if (sdt_gpu_stage_times(gpu, ms, cn) == SDT_OK)
+			fprintf(stderr, "[ingest] consumer waited %.0f ms for the parsers, spent %.0f ms pushing; device stages: direct %.0f, scatter %.0f, split %.0f, count %.0f ms; %llu batches counted, %llu early flushes, %d parser threads\n",
+			        sdt_reader_wait_ms, sdt_reader_fn_ms, ms[0], ms[1], ms[2], ms[3], (unsigned long long)cn[6], (unsigned long long)cn[3], my_threads);
+	}
 	phase("parse + hash (GPU)");
 	printf("time spent on hash reads: %ds, %llu reads processed\n", (int)(time(NULL) - t_start), st.reads);
 	printf("%llu nodes allocated, %llu kmer in reads, %llu kmer processed\n", (unsigned long long)nodes,

@@ -37,6 +37,10 @@ typedef struct {
 	pthread_cond_t cv;
 } job_t;
 
+#include <time.h>
+double sdt_reader_wait_ms = 0, sdt_reader_fn_ms = 0;      /* consumer thread: waiting for the parsers / inside the callback */
+static double seq_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 /* ---- pool of output buffers (seqio.h) ---- */
 typedef struct { uint32_t *w; uint64_t *o; size_t wcap, ocap; int state; } pslot_t;      /* state: 0 free, 1 in use, 2 taken by the consumer */
 static struct {
@@ -458,10 +462,14 @@ int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int 
 	int rc = 0;
 	uint64_t total = 0;
 	for (int i = 0; i < nc; i++) {
+		const double t_a = seq_now();
 		pthread_mutex_lock(&J.mu);
 		while (!J.chunks[i].done) pthread_cond_wait(&J.cv, &J.mu);
 		pthread_mutex_unlock(&J.mu);
+		const double t_b = seq_now();
 		if (rc == 0 && fn(user, &J.chunks[i].out) != 0) rc = -1;
+		sdt_reader_wait_ms += t_b - t_a;
+		sdt_reader_fn_ms += seq_now() - t_b;
 		total += J.chunks[i].out.nreads;
 		if (J.chunks[i].out.pool_slot >= 0) {                 /* the callback may have kept the buffer (sdt_pool_take) */
 			pthread_mutex_lock(&g_pool.mu);

@@ -41,6 +41,8 @@ void sdt_pool_release(int slot);
 void sdt_read_shard_begin(int rank, int nranks, int keep_all);
 
 typedef int (*sdt_batch_fn)(void *user, const sdt_batch *b);
+/* where the consumer thread's time went, summed over all files (measurement) */
+extern double sdt_reader_wait_ms, sdt_reader_fn_ms;
 
 /* Parse one file with `threads` workers; call `fn` on the calling thread for each batch in file order.
  * fmt: 'q' FASTQ, 'a' FASTA.  Returns 0, or -1 after printing a message. */

@@ -1759,19 +1759,24 @@ static int push_reads_enqueue(sdt_ctx *c, const uint32_t *packed_words, uint64_t
 			if (rcd != SDT_OK) return rcd;
 		}
 		HIPCHK(hipEventSynchronize(c->buf_free[b]));
+		// (capacities with head room: the chunks of a file differ by a few words, and every batch that sets a new record would
+		// otherwise cost a hipFree -- a device-wide synchronisation -- and a hipMalloc: 200 M reads in 32-MiB chunks spent
+		// seconds there)
 		if (c->cap_words[b] < nwords) {
 			if (c->d_words[b]) HIPCHK(hipFree(c->d_words[b]));
 			c->d_words[b] = nullptr;
 			c->cap_words[b] = 0;
-			HIPCHK(hipMalloc((void **)&c->d_words[b], nwords * sizeof(uint32_t)));
-			c->cap_words[b] = nwords;
+			const uint64_t cap = nwords + nwords / 8 + (1u << 16);
+			HIPCHK(hipMalloc((void **)&c->d_words[b], cap * sizeof(uint32_t)));
+			c->cap_words[b] = cap;
 		}
 		if (c->cap_offs[b] < nreads + 1) {
 			if (c->d_offs[b]) HIPCHK(hipFree(c->d_offs[b]));
 			c->d_offs[b] = nullptr;
 			c->cap_offs[b] = 0;
-			HIPCHK(hipMalloc((void **)&c->d_offs[b], (nreads + 1) * sizeof(uint64_t)));
-			c->cap_offs[b] = nreads + 1;
+			const uint64_t cap = nreads + 1 + nreads / 8 + (1u << 12);
+			HIPCHK(hipMalloc((void **)&c->d_offs[b], cap * sizeof(uint64_t)));
+			c->cap_offs[b] = cap;
 		}
 		dw = c->d_words[b];
 		dof = c->d_offs[b];

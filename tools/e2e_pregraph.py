@@ -210,14 +210,13 @@ try:
     if args.ingest_probe:
         probe = {}
         for name, env, p_ in (("as_is", {}, args.p), ("as_is_again", {}, args.p), ("parse_only", {"SDT_PARSE_ONLY": "1"}, args.p),
-                              ("t8", {"SDT_PARSE_THREADS": "8"}, args.p), ("t10", {"SDT_PARSE_THREADS": "10"}, args.p), ("t12", {"SDT_PARSE_THREADS": "12"}, args.p),
-                              ("t14", {"SDT_PARSE_THREADS": "14"}, args.p), ("t16", {"SDT_PARSE_THREADS": "16"}, args.p),
-                              ("t12_block", {"SDT_PARSE_THREADS": "12", "SDT_SYNC": "block"}, args.p), ("t14_block", {"SDT_PARSE_THREADS": "14", "SDT_SYNC": "block"}, args.p),
-                              ("t16_block", {"SDT_PARSE_THREADS": "16", "SDT_SYNC": "block"}, args.p), ("t12_nopool", {"SDT_PARSE_THREADS": "12", "SDT_NO_PINNED_POOL": "1"}, args.p)):
+                              ("t8", {"SDT_PARSE_THREADS": "8"}, args.p), ("t12", {"SDT_PARSE_THREADS": "12"}, args.p),
+                              ("t12_block", {"SDT_PARSE_THREADS": "12", "SDT_SYNC": "block"}, args.p), ("t12_block2", {"SDT_PARSE_THREADS": "12", "SDT_SYNC": "block"}, args.p),
+                              ("t12_nopool", {"SDT_PARSE_THREADS": "12", "SDT_NO_PINNED_POOL": "1"}, args.p)):
             t0 = time.time()
             rp = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(p_), "-o", os.path.join(tmp, "probe"),
                                  "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
-            probe[name] = {"wall_s": round(time.time() - t0, 2), "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if "parse + hash" in l]}
+            probe[name] = {"wall_s": round(time.time() - t0, 2), "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if "parse + hash" in l or l.startswith("[ingest]")]}
         res["ingest_probe"] = probe
         print(json.dumps(res, indent=1))
         raise SystemExit(0)
@@ -292,7 +291,7 @@ try:
             res["ref_p2_kmerFreq_same"] = open(os.path.join(tmp, "ref2.kmerFreq"), "rb").read() == open(os.path.join(tmp, "ref.kmerFreq"), "rb").read()
             res["speedup_full_vs_p2"] = round(res["ref_p2_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
-    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]", "[read2edge]"))]
+    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]", "[read2edge]", "[ingest]"))]
     print(json.dumps(res, indent=1))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
