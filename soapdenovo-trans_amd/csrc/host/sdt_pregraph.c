@@ -630,6 +630,8 @@ int main(int argc, char **argv)
 		graph_t *G = NULL;
 		dev_state *Dp = (dev_state *)calloc(1, sizeof(dev_state));
 		Dp->nwk = nwk;
+		int keys_in_device = 0;                                /* --gpus N: every shard is in rank 0's device table already */
+		keys = NULL; ll = rf = cnt = NULL;
 		if (gpus > 1) {
 			/* shards -> rank 0.  Every rank learns all shard sizes; ranks > 0 export into a shared-memory segment each and
 			 * leave once rank 0 has taken their nodes (host arrays + its own device table: sdt_gpu_import_nodes) */
@@ -658,6 +660,25 @@ int main(int argc, char **argv)
 				return 0;
 			}
 			n = nodes;                                            /* all shards */
+			const int device_layout = !host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT");
+			keys_in_device = device_layout;
+			if (device_layout) {
+				/* the shards go straight into rank 0's device table (it then lays the whole graph out like a single-GPU run: below);
+				 * nothing is gathered in host arrays */
+				if (sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+				for (int r = 1; r < gpus; r++) {
+					const uint64_t m_n = (uint64_t)sizes[r];
+					snprintf(seg, sizeof seg, "/sdt_%s_n%d", boot->name, r);
+					uint8_t *m = (uint8_t *)shm_region(seg, (size_t)(m_n + 1) * per_node, 0);
+					if (!m) { fprintf(stderr, "cannot map the shard of rank %d\n", r); return 1; }
+					const uint64_t *k2 = (const uint64_t *)m, *f2 = k2 + (m_n + 1) * (size_t)nwk;
+					const uint32_t *l2 = (const uint32_t *)(f2 + m_n + 1), *r2 = l2 + m_n + 1, *c2 = r2 + m_n + 1;
+					if (sdt_gpu_import_nodes(gpu, k2, l2, r2, c2, f2, m_n) != SDT_OK) { fprintf(stderr, "sdt_gpu_import_nodes: %s\n", sdt_gpu_last_error()); return 1; }
+					munmap(m, (size_t)(m_n + 1) * per_node);
+				}
+				if (sdt_gpu_allreduce_i64(gpu, &token, 1) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }   /* the other ranks may go */
+				phase("shards into rank 0's table");
+			} else {
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
 			if (!keys || !first || !ll || !rf || !cnt) { fprintf(stderr, "out of host memory for %llu nodes\n", (unsigned long long)n); return 1; }
@@ -683,7 +704,9 @@ int main(int argc, char **argv)
 				fprintf(stderr, "sdt_gpu_import_nodes: %s\n", sdt_gpu_last_error());
 				return 1;
 			}
-		} else if (!host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT")) {
+			}
+		}
+		if ((gpus == 1 || keys_in_device) && !host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT")) {
 			/* the visiting order with the device: it sorts the nodes by (set, first occurrence) and sends the keys, the host
 			 * replays the probing of every set (graph_replay_order), the device numbers the nodes and sends them in that order */
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);
@@ -705,7 +728,7 @@ int main(int argc, char **argv)
 			graph_free_later(keys, ll, rf, cnt);
 			free(set_start);
 			phase("graph + index");
-		} else {
+		} else if (gpus == 1) {
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8); first = (uint64_t *)malloc((n + 1) * 8);
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
 			if (sdt_gpu_export_nodes(gpu, keys, ll, rf, cnt, first, n, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
