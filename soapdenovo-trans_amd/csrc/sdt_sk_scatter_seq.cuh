@@ -68,7 +68,14 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 			done = true;
 			sk_log_alloc(1, end, base);
 		}
-		// id > end: another lane of this workgroup is fetching the next block -- look again
+		else {
+			// id > end: another lane of this workgroup is fetching the next block -- wait for its exchange without writing the word
+			unsigned long long w;
+			do {
+				__builtin_amdgcn_s_sleep(1);
+				w = __hip_atomic_load(s_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			} while ((uint32_t)w > (uint32_t)(w >> 32));
+		}
 	}
 	return got;
 }
@@ -117,8 +124,14 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 #if SDT_SK_L2_LOG >= 2
 			sk_log_cursor(2, lb, chunk, pos);            // (every look-again too: slows the spinning lanes enough to hide the failure)
 #endif
+			// pos > cap: another lane of this workgroup is replacing the chunk.  Wait for its exchange with PLAIN reads of the cursor
+			// and a short sleep, not with more returning atomics: sixteen waves hammering one LDS word with ds_add_rtn_u64 while the
+			// opener's ds_wrxchg_rtn_b64 is on its way is the one condition under which a chunk was seen handed out twice (1024-lane
+			// level-2 geometry, profiles/r3/l2_1024_lane_loss.md; 0 of 240 runs once the waiting lanes stop writing the word)
+			do {
+				__builtin_amdgcn_s_sleep(1);
+			} while ((uint32_t)__hip_atomic_load(&s_cur[lb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > cap);
 		}
-		// pos > cap: another lane of this workgroup is replacing the chunk -- look again
 	}
 	return ok;
 }

@@ -157,15 +157,16 @@ def test_pool_overflow_takes_the_direct_path(pkg, synth, monkeypatch, K, L):
 
 
 def test_hot_bucket_repeated(pkg, synth):
-    """the hot-bucket input ten times through the locality pipeline: every lane of every workgroup appends to ONE
-    level-2 cursor.  (A 1024-lane geometry of the level-2 scatter lost a chunk of 16 records in half of such runs;
-    the library's own conservation check -- k-mers cut into records == k-mers counted -- must stay silent too.)"""
+    """the hot-bucket input a hundred times through the locality pipeline: every lane of every workgroup appends to ONE
+    level-2 cursor.  (A 1024-lane geometry of the level-2 scatter lost a chunk of 16 records in half of such runs while
+    the lanes that wait for a chunk to be replaced kept adding to its cursor; the library's own conservation check --
+    k-mers cut into records == k-mers counted -- must stay silent too.)"""
     K, n, L = 21, 1500, 100
     codes = np.zeros(n * L, dtype=np.uint8)
     codes[L * 1000:] = np.tile(np.array([0, 1, 2, 3, 3, 1], dtype=np.uint8), (n - 1000) * L // 6 + 1)[: (n - 1000) * L]
     offs = (np.arange(n + 1) * L).astype(np.uint64)
     words = synth.pack_2bit(codes)
-    for _ in range(10):
+    for _ in range(100):
         with pkg.PregraphGPU(K, est_distinct=1 << 16, flags=MODES[-1]) as g:
             g.push_reads(words, offs)
             assert g.finish_count() == (n * (L - K + 1), 7)
