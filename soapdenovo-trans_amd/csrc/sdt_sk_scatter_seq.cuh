@@ -55,6 +55,13 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 	uint32_t got = 0;
 	bool done = false;
 	while (!done) {
+		{   // a block that is being replaced (next id > end) is left alone until the fetching lane's exchange: see sk_reserve
+			const unsigned long long w = __hip_atomic_load(s_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if ((uint32_t)w > (uint32_t)(w >> 32)) {
+				__builtin_amdgcn_s_sleep(1);
+				continue;
+			}
+		}
 		const unsigned long long v = atomicAdd(s_blk, 1ULL);
 		const uint32_t id = (uint32_t)v, end = (uint32_t)(v >> 32);
 		if (id < end) {
@@ -68,14 +75,7 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 			done = true;
 			sk_log_alloc(1, end, base);
 		}
-		else {
-			// id > end: another lane of this workgroup is fetching the next block -- wait for its exchange without writing the word
-			unsigned long long w;
-			do {
-				__builtin_amdgcn_s_sleep(1);
-				w = __hip_atomic_load(s_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			} while ((uint32_t)w > (uint32_t)(w >> 32));
-		}
+		// id > end: another lane of this workgroup is fetching the next block -- look again (behind the peek above)
 	}
 	return got;
 }
@@ -98,6 +98,14 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 {
 	bool done = false, ok = false;                   // (flag form: see sk_alloc_chunk)
 	while (!done) {
+		// A chunk that is being replaced (records used > cap) is left alone: PLAIN read, short sleep, next iteration.  Sixteen waves
+		// hammering one LDS word with ds_add_rtn_u64 while the opener's ds_wrxchg_rtn_b64 is on its way is the one condition under
+		// which a chunk was seen handed out twice (1024-lane level-2 geometry, profiles/r3/l2_1024_lane_loss.md).  No inner wait
+		// loop: the opener may be a lane of THIS wave, and it only gets to run when the waiting lanes come round the loop.
+		if ((uint32_t)__hip_atomic_load(&s_cur[lb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > cap) {
+			__builtin_amdgcn_s_sleep(1);
+			continue;
+		}
 		const unsigned long long cur = atomicAdd(&s_cur[lb], 1ULL);
 		pos = (uint32_t)cur;
 		chunk = (uint32_t)(cur >> 32);
@@ -124,13 +132,8 @@ __device__ inline bool sk_reserve(unsigned long long *s_cur, unsigned long long 
 #if SDT_SK_L2_LOG >= 2
 			sk_log_cursor(2, lb, chunk, pos);            // (every look-again too: slows the spinning lanes enough to hide the failure)
 #endif
-			// pos > cap: another lane of this workgroup is replacing the chunk.  Wait for its exchange with PLAIN reads of the cursor
-			// and a short sleep, not with more returning atomics: sixteen waves hammering one LDS word with ds_add_rtn_u64 while the
-			// opener's ds_wrxchg_rtn_b64 is on its way is the one condition under which a chunk was seen handed out twice (1024-lane
-			// level-2 geometry, profiles/r3/l2_1024_lane_loss.md; 0 of 240 runs once the waiting lanes stop writing the word)
-			do {
-				__builtin_amdgcn_s_sleep(1);
-			} while ((uint32_t)__hip_atomic_load(&s_cur[lb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > cap);
+			// pos > cap: another lane of this workgroup is replacing the chunk -- look again (the peek at the top of the loop keeps
+			// this lane off the word until the exchange has happened)
 		}
 	}
 	return ok;
