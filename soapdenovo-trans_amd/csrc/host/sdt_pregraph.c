@@ -204,10 +204,11 @@ static void on_sigchld(int sig)
 {
 	(void)sig;
 	int st;
-	pid_t p;
-	while ((p = waitpid(-1, &st, WNOHANG)) > 0) {
-		for (int i = 0; i < g_nchild; i++)
-			if (g_child[i] == p) g_child[i] = 0;
+	/* only the ranks recorded in g_child are reaped here (another child of the process is not this handler's business) */
+	for (int k = 0; k < g_nchild; k++) {
+		const pid_t c = g_child[k];
+		if (c <= 0 || waitpid(c, &st, WNOHANG) != c) continue;
+		g_child[k] = 0;
 		if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
 			static const char msg[] = "sdt-pregraph: a rank failed; stopping the others\n";
 			if (write(2, msg, sizeof msg - 1) < 0) { }
@@ -498,7 +499,14 @@ int main(int argc, char **argv)
 		sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
 		sigaction(SIGCHLD, &sa, NULL);
 		atexit(kill_children);
+		const pid_t parent = getpid();
 		for (int r = 1; r < gpus; r++) {
+			/* SIGCHLD stays blocked from before the fork until the pid is on record: a child that dies at once is then reaped
+			 * by the handler like any other (not left as a slot that is waited for at the end and killed by a recycled pid) */
+			sigset_t blk, old;
+			sigemptyset(&blk);
+			sigaddset(&blk, SIGCHLD);
+			sigprocmask(SIG_BLOCK, &blk, &old);
 			const pid_t pid = fork();
 			if (pid < 0) { perror("fork"); return 1; }
 			if (pid == 0) {
@@ -506,13 +514,15 @@ int main(int argc, char **argv)
 				g_quiet = 1;
 				g_nchild = 0;                                         /* (a child has no children to take along) */
 				signal(SIGCHLD, SIG_DFL);
+				sigprocmask(SIG_SETMASK, &old, NULL);
 				prctl(PR_SET_PDEATHSIG, SIGKILL);
-				if (getppid() == 1) return 1;                         /* the parent is gone already */
+				if (getppid() != parent) return 1;                    /* the parent is gone already (also under a subreaper) */
 				if (!freopen("/dev/null", "w", stdout)) return 1;       /* one voice: rank 0's */
 				break;
 			}
 			g_child[g_nchild] = pid;
 			g_nchild = g_nchild + 1;
+			sigprocmask(SIG_SETMASK, &old, NULL);
 		}
 	}
 	/* parser threads: the job's CPUs minus the pushing thread and the runtime's helpers -- under a CPU quota (cgroup cpu.max) one

