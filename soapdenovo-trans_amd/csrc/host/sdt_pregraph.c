@@ -301,7 +301,16 @@ static void gather_dirty(void *vc, uint64_t lo, uint64_t hi, int tid)
 }
 
 /* the device table mirrors the host graph: node order known to the device, nodes written since the last call sent over */
+static int dev_mirror_sync_(graph_t *g);
 static int dev_mirror_sync(graph_t *g)
+{
+	const double t0 = now_ms();
+	const size_t dn = g->dn;
+	const int rc = dev_mirror_sync_(g);
+	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   mirror sync: %zu nodes written by the host sent over in %.1f ms\n", dn, now_ms() - t0);
+	return rc;
+}
+static int dev_mirror_sync_(graph_t *g)
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	const int nwk = D->nwk;
@@ -397,10 +406,13 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
+	const double t0 = now_ms();
 	if (sdt_gpu_minor_out_labelled(D->gpu, threshold, nj, nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_labelled: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t1 = now_ms();
 	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * MO_RW * sizeof(uint64_t));
 	if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)*nr); return 1; }
 	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * MO_RW) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
+	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   junction dry run + components %.1f ms, %llu + %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nj, (unsigned long long)(*nr - *nj), now_ms() - t1);
 	*records = rec;
 	return 0;
 }
@@ -409,10 +421,13 @@ static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records,
 {
 	dev_state *D = (dev_state *)g->dev_user;
 	if (dev_mirror_sync(g) != 0) return 1;
+	const double t0 = now_ms();
 	if (sdt_gpu_tip_walks_labelled(D->gpu, thin, cut_len, nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_tip_walks_labelled: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t1 = now_ms();
 	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * 3 * sizeof(uint64_t));
 	if (!rec) { fprintf(stderr, "out of memory for %llu walk records\n", (unsigned long long)*nr); return 1; }
 	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * 3) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
+	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   walks + components %.1f ms, %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nr, now_ms() - t1);
 	*records = rec;
 	return 0;
 }
@@ -857,6 +872,13 @@ int main(int argc, char **argv)
 	phase("release the device");
 	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", "total inside main", now_ms() - g_t_main);
 	sdt_cfg_free(&cfg);
+	if (gpus == 1 && !getenv("SDT_SLOW_EXIT")) {
+		/* every file is closed and the device is released: skip the runtime's and the allocator's own teardown (atexit handlers,
+		 * unloading code objects, returning gigabytes page by page) -- the kernel takes the address space back in one go */
+		fflush(stdout);
+		fflush(stderr);
+		_exit(0);
+	}
 	if (gpus > 1 && rank == 0) {                                 /* the ranks that are still leaving (the handler reaps them) */
 		for (int tries = 0; tries < 30000; tries++) {
 			int alive = 0;

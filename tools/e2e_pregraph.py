@@ -291,7 +291,7 @@ try:
             res["ref_p2_kmerFreq_same"] = open(os.path.join(tmp, "ref2.kmerFreq"), "rb").read() == open(os.path.join(tmp, "ref.kmerFreq"), "rb").read()
             res["speedup_full_vs_p2"] = round(res["ref_p2_wall_s"] / res["ours_wall_s"], 2)
     res["ours_phase_lines"] = [l for l in r.stdout.splitlines() if l.startswith("time spent")]
-    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]", "[read2edge]", "[ingest]"))]
+    res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in r.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[cuttip]", "[graph]", "[edges]", "[read2edge]", "[ingest]", "[device]"))]
     print(json.dumps(res, indent=1))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
