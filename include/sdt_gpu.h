@@ -296,6 +296,15 @@ int sdt_gpu_edge_ports(sdt_ctx *ctx, uint64_t *records, uint64_t max_records, ui
  *                   The records stay on the device until fetch_records copies them (nwords = records x words, exactly). */
 int sdt_gpu_layout_sorted_keys(sdt_ctx *ctx, int p, int nw_variant, uint64_t *keys, uint64_t max_nodes, uint64_t *set_start, uint64_t *n);
 int sdt_gpu_layout_apply(sdt_ctx *ctx, const uint64_t *order, uint64_t n);
+/*   layout_on_device: layout_sorted_keys + the replay of put_kmerset / encap_kmerset (newhash.c:293-462) + layout_apply in one call,
+ *                   nothing but set_start[0..p] crosses the link.  Between two growths a set is laid out by priority insertion
+ *                   (first come first served in first-occurrence order, built in any order); a growth -- the in-place rehash of
+ *                   :359-406, where an entry that gives way is carried on at once -- as a fixed point of insertion times, ten to
+ *                   twenty rounds of priority insertion (csrc/sdt_graph_kernels.cuh; tools/replay_fixed_point.c checks the
+ *                   formulation against the sequential emulation).  small_init != 0: the sets of the 63mer / 127mer variants
+ *                   start at 3 slots (`-a`, prlHashReads.c:404-413).  SDT_EINVAL when a limit is passed (2^32 nodes, a set's table
+ *                   of 2^32 slots, the packed table word): use the two-step form with the host's replay then. */
+int sdt_gpu_layout_on_device(sdt_ctx *ctx, int p, int nw_variant, int small_init, uint64_t *set_start, uint64_t *n);
 int sdt_gpu_export_ordered(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count, uint64_t n);
 int sdt_gpu_update_nodes_by_index(sdt_ctx *ctx, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
 int sdt_gpu_tip_walks_labelled(sdt_ctx *ctx, int thin, int cut_len, uint64_t *n_records);

@@ -68,6 +68,7 @@ _ABI = [
     ("sdt_gpu_build_host_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_layout_sorted_keys", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_layout_apply", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_layout_on_device", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_ordered", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_update_nodes_by_index", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_tip_walks_labelled", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_uint64)]),
@@ -417,6 +418,14 @@ class PregraphGPU:
         ss = np.zeros(p + 1, dtype=np.uint64)
         self._check(self.lib.sdt_gpu_layout_sorted_keys(self._ctx, p, nw_variant, _ptr(keys), n.value, _ptr(ss), ctypes.byref(n)))
         return keys[: n.value], ss
+
+    def layout_on_device(self, p: int, nw_variant: int, small_init: bool = False):
+        """sort + replay of the probing + numbering, all on the device -> set_start uint64[p + 1]"""
+        ss = np.zeros(p + 1, dtype=np.uint64)
+        n = ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_layout_on_device(self._ctx, p, nw_variant, int(small_init), _ptr(ss), ctypes.byref(n)))
+        self._nidx = n.value
+        return ss
 
     def layout_apply(self, order: np.ndarray):
         order = np.ascontiguousarray(order, dtype=np.uint64)

@@ -736,16 +736,40 @@ int main(int argc, char **argv)
 			 * replays the probing of every set (graph_replay_order), the device numbers the nodes and sends them in that order */
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);
 			uint64_t *set_start = (uint64_t *)calloc((size_t)threads + 1, sizeof(uint64_t));
-			if (sdt_gpu_layout_sorted_keys(gpu, threads, nwv, keys, n, set_start, &n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_sorted_keys: %s\n", sdt_gpu_last_error()); return 1; }
-			phase("layout: sort (GPU) + keys D2H");
-			uint64_t *order = (uint64_t *)malloc((n + 1) * 8);
-			graph_replay_order(nwv, nwk, threads, keys, set_start, order);
-			phase("layout: replay (host)");
-			if (sdt_gpu_layout_apply(gpu, order, n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_apply: %s\n", sdt_gpu_last_error()); return 1; }
-			free(order);
+			/* all of it on the device (sort, replay of the probing as rounds of priority insertion, numbering); the two-step form
+			 * with the host's replay when a limit of the device form is passed, on request (SDT_HOST_REPLAY), and -- SDT_LAYOUT_CHECK
+			 * -- beside it: both orders must then name the same key at every visiting position */
+			int on_device = 0;
+			uint64_t *check_keys = NULL;
+			if (!getenv("SDT_HOST_REPLAY")) {
+				const int rcl = sdt_gpu_layout_on_device(gpu, threads, nwv, graph_init_kmerset_size != 0, set_start, &n);
+				if (rcl == SDT_OK) on_device = 1;
+				else if (rcl != SDT_EINVAL) { fprintf(stderr, "sdt_gpu_layout_on_device: %s\n", sdt_gpu_last_error()); return 1; }
+				if (on_device) phase("layout: sort + replay + numbering (GPU)");
+			}
+			if (!on_device || getenv("SDT_LAYOUT_CHECK")) {
+				uint64_t *hk = on_device ? (uint64_t *)malloc((n + 1) * (size_t)nwk * 8) : keys;
+				uint64_t *ss = on_device ? (uint64_t *)calloc((size_t)threads + 1, sizeof(uint64_t)) : set_start;
+				if (sdt_gpu_layout_sorted_keys(gpu, threads, nwv, hk, n, ss, &n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_sorted_keys: %s\n", sdt_gpu_last_error()); return 1; }
+				phase("layout: sort (GPU) + keys D2H");
+				uint64_t *order = (uint64_t *)malloc((n + 1) * 8);
+				graph_replay_order(nwv, nwk, threads, hk, ss, order);
+				phase("layout: replay (host)");
+				if (on_device) {
+					check_keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);
+					for (uint64_t vv = 0; vv < n; vv++) memcpy(check_keys + vv * nwk, hk + order[vv] * nwk, (size_t)nwk * 8);
+					free(hk); free(ss);
+				} else if (sdt_gpu_layout_apply(gpu, order, n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_apply: %s\n", sdt_gpu_last_error()); return 1; }
+				free(order);
+			}
 			ll = (uint32_t *)malloc((n + 1) * 4); rf = (uint32_t *)malloc((n + 1) * 4); cnt = (uint32_t *)malloc((n + 1) * 4);
 			if (sdt_gpu_export_ordered(gpu, keys, ll, rf, cnt, n) != SDT_OK) { fprintf(stderr, "sdt_gpu_export_ordered: %s\n", sdt_gpu_last_error()); return 1; }
-			phase("layout: number + export (D2H)");
+			phase("layout: export in visiting order (D2H)");
+			if (check_keys) {
+				if (memcmp(check_keys, keys, n * (size_t)nwk * 8) != 0) { fprintf(stderr, "SDT_LAYOUT_CHECK: the device's visiting order differs from the host replay's\n"); return 1; }
+				fprintf(stderr, "[sdt-pregraph] SDT_LAYOUT_CHECK: device and host replay agree on all %llu visiting positions\n", (unsigned long long)n);
+				free(check_keys);
+			}
 			Dp->gpu = gpu; Dp->indexed = 1; Dp->by_index = 1;
 			graph_index_hook = dev_index_hook;
 			graph_index_hook_user = Dp;

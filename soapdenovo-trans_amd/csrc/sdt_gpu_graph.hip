@@ -68,7 +68,7 @@ static sdti::GraphExt *ext_of(const GraphView &v)
 
 // every device buffer of a call in one place: freed when the call returns, whatever the path
 struct Scratch {
-	void *p[16] = {};
+	void *p[40] = {};
 	int n = 0;
 	template <class T> hipError_t alloc(T **out, size_t bytes)
 	{
@@ -118,6 +118,242 @@ static int exclusive_scan(const GraphView &v, const T *in, T *out, uint64_t n)
 	return SDT_OK;
 }
 
+
+// ---- the whole layout on the device: sort, replay of the probing (fixed point per growth), numbering ---------------------
+#include <math.h>
+#include <vector>
+static int rp_prime(uint64_t num)                    // find_next_prime_kh's test (newhash.c:116-158): the bound is (ubyte8)sqrt((float)n)
+{
+	if (num < 4) return 1;
+	if (num % 2 == 0) return 0;
+	const uint64_t lim = (uint64_t)sqrt((float)num);
+	for (uint64_t i = 3; i < lim; i += 2)
+		if (num % i == 0) return 0;
+	return 1;
+}
+static uint64_t rp_next_prime(uint64_t n) { if (n % 2 == 0) n++; while (!rp_prime(n)) n += 2; return n; }
+static uint64_t rp_next_size(uint64_t size, double lf, uint64_t count)      // encap_kmerset's growth (newhash.c:318-330)
+{
+	uint64_t n = size;
+	do {
+		n = n < 0xFFFFFFFu ? n << 1 : n + 0xFFFFFFu;
+		n = rp_next_prime(n);
+	} while (n * lf < (double)(count + 1));
+	return n;
+}
+
+extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int small_init, uint64_t *set_start, uint64_t *n_out)
+{
+	if (!c || !n_out || !set_start) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v0 = sdti::graph_view(c);
+	HIPCHK(hipSetDevice(v0.device));
+	int rc = sdti::release_pass1(c);
+	if (rc != SDT_OK) return rc;
+	const GraphView v = sdti::graph_view(c);
+	const uint64_t n = v.h_stats->distinct;
+	*n_out = n;
+	if (!v.d_first) return fail(SDT_ESTATE, "first-occurrence ordinals were not tracked: init with SDT_FLAG_TRACK_FIRST");
+	if (p < 1 || p > 256) return fail(SDT_EINVAL, "layout on the device: 1..256 sets, asked for %d", p);
+	if (nw_variant < v.nw || nw_variant > 4) return fail(SDT_EINVAL, "a %d-word variant cannot hold %d-word keys", nw_variant, v.nw);
+	if (n >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "layout on the device: 32-bit ranks, %llu nodes", (unsigned long long)n);
+	sdti::GraphExt *gx = ext_of(v);
+	if (gx->d_sval) { (void)hipFree(gx->d_sval); gx->d_sval = nullptr; gx->n_sorted = 0; }
+	Scratch S;
+	const uint64_t m = n ? n : 1;
+	// ---- sort by (set, first occurrence), keys gathered in that order (as sdt_gpu_layout_sorted_keys)
+	uint64_t *k0, *k1, *v0s, *v1s, *d_keys, *d_ss;
+	unsigned long long *d_cur;
+	GCHK(S.alloc(&k0, m * 8)); GCHK(S.alloc(&k1, m * 8)); GCHK(S.alloc(&v0s, m * 8)); GCHK(S.alloc(&v1s, m * 8));
+	GCHK(S.alloc(&d_cur, 8)); GCHK(S.alloc(&d_ss, (size_t)(p + 1) * 8));
+	GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
+	const int g = sdti::scan_grid(v.cu_count, v.slots);
+	LAUNCH_NW(v, k_layout_keys, g, (uint32_t)p, nw_variant, k0, v0s, (unsigned long long)n, d_cur, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "layout: %llu nodes without a usable first-occurrence ordinal", (unsigned long long)v.h_stats->probe_fail);
+	unsigned end_bit = 56;
+	for (int q = p - 1; q > 0; q >>= 1) end_bit++;
+	rc = sort_pairs<uint64_t>(v, k0, k1, v0s, v1s, n, end_bit);
+	if (rc != SDT_OK) return rc;
+	hipLaunchKernelGGL(k_layout_set_starts, dim3((p + 1 + 63) / 64), dim3(64), 0, v.stream, k1, n, (uint32_t)p, d_ss);
+	GCHK(hipGetLastError());
+	GCHK(hipMemcpyAsync(set_start, d_ss, (size_t)(p + 1) * 8, hipMemcpyDeviceToHost, v.stream));
+	if (v.nw == 1) d_keys = k0; else GCHK(S.alloc(&d_keys, m * v.nw * 8));
+	LAUNCH_NW(v, k_layout_gather_keys, sdti::scan_grid(v.cu_count, m), v1s, n, d_keys);
+	GCHK(hipGetLastError());
+	GCHK(hipStreamSynchronize(v.stream));
+	(void)hipFree(S.release(k1));                             // (the sorted sort keys are not needed any more)
+	if (v.nw != 1) (void)hipFree(S.release(k0));
+	(void)hipFree(S.release(v0s));
+	// ---- every set's growth schedule (a function of its number of keys only)
+	struct Gen { uint32_t lo, hi, size; };                   // ids [lo, hi) are put into a table of `size` slots (after a growth from the previous size)
+	std::vector<std::vector<Gen>> sched(p);
+	std::vector<RpSet> sets(p);
+	const double lf = (double)0.77f;
+	uint64_t tab_total = 0, max_m = 0, max_size = 0;
+	size_t max_gens = 0;
+	for (int s = 0; s < p; s++) {
+		const uint64_t ms = set_start[s + 1] - set_start[s];
+		uint64_t size = (nw_variant != 1 && small_init) ? 3 : rp_next_prime(1024);      // init_kmerset (prlHashReads.c:402-423, newhash.c:163-166)
+		uint64_t max = (uint64_t)(size * 0.77f), lo = 0;
+		for (;;) {
+			const uint64_t hi = ms < max ? ms : max;
+			sched[s].push_back(Gen{(uint32_t)lo, (uint32_t)hi, (uint32_t)size});
+			if (hi >= ms) break;
+			size = rp_next_size(size, lf, max);                // the put of id == max finds count + 1 > max
+			if (size >= 0xFFFFFFFFULL) return fail(SDT_EINVAL, "layout on the device: a set's table passes 2^32 slots");
+			lo = hi;
+			max = (uint64_t)(size * lf);
+		}
+		sets[s].key0 = set_start[s]; sets[s].tab0 = tab_total; sets[s].m = (uint32_t)ms;
+		tab_total += size;
+		if (ms > max_m) max_m = ms;
+		if (size > max_size) max_size = size;
+		if (sched[s].size() > max_gens) max_gens = sched[s].size();
+	}
+	int idbits = 1;
+	while ((1ULL << idbits) <= max_m) idbits++;
+	int sbits = 1;
+	while ((1ULL << sbits) < max_size) sbits++;
+	if (idbits + sbits + RP_DEPTH_BITS > 64) return fail(SDT_EINVAL, "layout on the device: %d id bits + %d slot bits do not fit the table word", idbits, sbits);
+	// ---- buffers
+	unsigned long long *tab[2], *t_time[2], *d_pre;
+	uint32_t *d_home, *d_occ, *d_rank;
+	RpSet *d_sets;
+	unsigned int *d_flags;
+	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
+	GCHK(S.alloc(&t_time[0], m * 8)); GCHK(S.alloc(&t_time[1], m * 8));
+	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
+	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
+	std::vector<unsigned long long> pre(p + 1);
+	auto upload = [&](void) -> int {
+		GCHK(hipStreamSynchronize(v.stream));                  // (kernels in flight read the old copies; the host vectors change right after)
+		GCHK(hipMemcpy(d_sets, sets.data(), (size_t)p * sizeof(RpSet), hipMemcpyHostToDevice));
+		GCHK(hipMemcpy(d_pre, pre.data(), (size_t)(p + 1) * 8, hipMemcpyHostToDevice));
+		return SDT_OK;
+	};
+	auto grid = [&](unsigned long long items) { return dim3(sdti::scan_grid(v.cu_count, items ? items : 1)); };
+	unsigned int h_flags = 0;
+	int cur = 0, total_rounds = 0;
+	for (size_t gen = 0; gen < max_gens; gen++) {
+		// ---- growth into this generation's size (every set that has a generation `gen`, except the first)
+		if (gen > 0) {
+			unsigned long long old_total = 0, cnt_total = 0;
+			for (int s = 0; s < p; s++) {
+				const bool on = gen < sched[s].size();
+				sets[s].old_size = on ? sched[s][gen - 1].size : 0;
+				sets[s].size = on ? sched[s][gen].size : sets[s].size;
+				sets[s].lo = 0; sets[s].hi = on ? sched[s][gen].lo : 0;            // ids [0, lo) are in the table
+				pre[s] = cnt_total;
+				cnt_total += sets[s].hi;
+			}
+			pre[p] = cnt_total;
+			rc = upload(); if (rc != SDT_OK) return rc;
+			// homes of every entry in the new geometry
+			if (v.nw == 1) hipLaunchKernelGGL(k_rp_home<1>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
+			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_home<2>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
+			else hipLaunchKernelGGL(k_rp_home<4>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
+			GCHK(hipGetLastError());
+			GCHK(hipStreamSynchronize(v.stream));                 // (pre / sets are overwritten below)
+			for (int s = 0; s < p; s++) { pre[s] = old_total; old_total += sets[s].old_size; }
+			pre[p] = old_total;
+			rc = upload(); if (rc != SDT_OK) return rc;
+			const int nxt = cur ^ 1;
+			int tc = 0;
+			hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 0, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc], d_flags);
+			for (int round = 0;; round++) {
+				if (round > 60) return fail(SDT_ESTATE, "layout on the device: a growth did not settle in 60 rounds");
+				for (int s = 0; s < p; s++)                       // (only the regions of the sets that grow, at their new size: the early growths are tiny)
+					if (sets[s].old_size) GCHK(hipMemsetAsync(tab[nxt] + sets[s].tab0, 0, (size_t)sets[s].size * 8, v.stream));
+				GCHK(hipMemsetAsync(d_flags, 0, 4, v.stream));
+				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc ^ 1], d_flags);
+				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 2, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc ^ 1], d_flags);
+				GCHK(hipGetLastError());
+				GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
+				GCHK(hipStreamSynchronize(v.stream));
+				total_rounds++;
+				if (h_flags & 6u) return fail(SDT_ESTATE, "layout on the device: %s", (h_flags & 2u) ? "an insertion found no slot" : "an eviction chain deeper than the time field");
+				if (!(h_flags & 1u)) break;
+				tc ^= 1;
+			}
+			// the settled layout without its times is the table of this generation
+			unsigned long long new_total = 0;
+			for (int s = 0; s < p; s++) { pre[s] = new_total; new_total += gen < sched[s].size() ? sets[s].size : 0; }
+			pre[p] = new_total;
+			// (sets without this generation keep their table: copy their region over unchanged)
+			for (int s = 0; s < p; s++)
+				if (gen >= sched[s].size())
+					GCHK(hipMemcpyAsync(tab[nxt] + sets[s].tab0, tab[cur] + sets[s].tab0, (size_t)sets[s].size * 8, hipMemcpyDeviceToDevice, v.stream));
+			rc = upload(); if (rc != SDT_OK) return rc;
+			{
+				// slots of the sets that grew: pre counts only those (others have size 0 in the prefix)
+				std::vector<RpSet> grown = sets;
+				for (int s = 0; s < p; s++) if (gen >= sched[s].size()) grown[s].size = 0;
+				GCHK(hipMemcpy(d_sets, grown.data(), (size_t)p * sizeof(RpSet), hipMemcpyHostToDevice));
+				hipLaunchKernelGGL(k_rp_slots, grid(new_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 0, idbits, tab[nxt], (uint32_t *)nullptr);
+				GCHK(hipGetLastError());
+				GCHK(hipStreamSynchronize(v.stream));
+			}
+			cur = nxt;
+		}
+		// ---- the puts of this generation
+		unsigned long long put_total = 0;
+		for (int s = 0; s < p; s++) {
+			const bool on = gen < sched[s].size();
+			sets[s].lo = on ? sched[s][gen].lo : 0;
+			sets[s].hi = on ? sched[s][gen].hi : 0;
+			if (on) sets[s].size = sched[s][gen].size;
+			pre[s] = put_total;
+			put_total += sets[s].hi - sets[s].lo;
+		}
+		pre[p] = put_total;
+		rc = upload(); if (rc != SDT_OK) return rc;
+		GCHK(hipMemsetAsync(d_flags, 0, 4, v.stream));
+		if (v.nw == 1) hipLaunchKernelGGL(k_rp_home<1>, grid(put_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 0, d_home);
+		else if (v.nw == 2) hipLaunchKernelGGL(k_rp_home<2>, grid(put_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 0, d_home);
+		else hipLaunchKernelGGL(k_rp_home<4>, grid(put_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 0, d_home);
+		hipLaunchKernelGGL(k_rp_put, grid(put_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, d_home, tab[cur], d_flags);
+		GCHK(hipGetLastError());
+		GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
+		GCHK(hipStreamSynchronize(v.stream));
+		if (h_flags) return fail(SDT_ESTATE, "layout on the device: a put found no slot");
+	}
+	// ---- the visiting order: the sets one after the other, every set's slots in order
+	unsigned long long slot_total = 0;
+	for (int s = 0; s < p; s++) { sets[s].size = sched[s].back().size; pre[s] = slot_total; slot_total += sets[s].size; }
+	pre[p] = slot_total;
+	rc = upload(); if (rc != SDT_OK) return rc;
+	// (the buffers of the replay that are free now make room for the flags and their prefix sum)
+	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(t_time[0])); (void)hipFree(S.release(t_time[1]));
+	uint64_t *d_order;
+	GCHK(S.alloc(&d_occ, (slot_total + 1) * 4)); GCHK(S.alloc(&d_rank, (slot_total + 1) * 4)); GCHK(S.alloc(&d_order, m * 8));
+	hipLaunchKernelGGL(k_rp_slots, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], d_occ);
+	GCHK(hipGetLastError());
+	rc = exclusive_scan<uint32_t>(v, d_occ, d_rank, slot_total);
+	if (rc != SDT_OK) return rc;
+	hipLaunchKernelGGL(k_rp_order, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, tab[cur], d_occ, d_rank, d_order);
+	GCHK(hipGetLastError());
+	GCHK(hipStreamSynchronize(v.stream));
+	(void)hipFree(S.release(tab[cur])); (void)hipFree(S.release(d_occ)); (void)hipFree(S.release(d_rank)); (void)hipFree(S.release(d_home));
+	// ---- number the nodes (as sdt_gpu_layout_apply)
+	if (*v.d_idx) { (void)hipFree(*v.d_idx); *v.d_idx = nullptr; }
+	*v.idx_slots = *v.idx_n = 0;
+	if (gx->d_slot_of) { (void)hipFree(gx->d_slot_of); gx->d_slot_of = nullptr; gx->n_nodes = 0; }
+	uint64_t *d_idx, *d_slot_of;
+	GCHK(S.alloc(&d_idx, v.slots * 8)); GCHK(S.alloc(&d_slot_of, m * 8));
+	GCHK(hipMemsetAsync(d_idx, 0xFF, v.slots * 8, v.stream));
+	hipLaunchKernelGGL(k_layout_apply, dim3(sdti::scan_grid(v.cu_count, m)), dim3(TPB), 0, v.stream, v1s, d_order, n, d_idx, d_slot_of, v.d_stats);
+	GCHK(hipGetLastError());
+	rc = sdti::sync_stats(c);
+	if (rc != SDT_OK) return fail(SDT_ESTATE, "layout on the device: %llu positions of the order are not ranks", (unsigned long long)v.h_stats->probe_fail);
+	*v.d_idx = (uint64_t *)S.release(d_idx);
+	*v.idx_slots = v.slots;
+	*v.idx_n = n;
+	gx->d_slot_of = (uint64_t *)S.release(d_slot_of);
+	gx->n_nodes = n;
+	if (getenv("SDT_TIMING")) fprintf(stderr, "[device]   layout replay: %zu generations, %d rounds of timed insertion in all, %llu table slots\n", max_gens, total_rounds, (unsigned long long)tab_total);
+	return SDT_OK;
+}
 
 extern "C" {
 

@@ -864,3 +864,157 @@ __global__ __launch_bounds__(TPB) void k_edge_stamp(Table<NW> tbl, const uint64_
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
+
+
+// ===============================================================================================================
+// The layout replay ON THE DEVICE (put_kmerset / encap_kmerset, newhash.c:293-462; host twin: graph.c graph_replay_order).
+// Per set the reference inserts its distinct keys in first-occurrence order into a table that grows in place.
+//   * Between two growths an insertion takes the first free slot from the key's home: first come first served, i.e. the
+//     unique layout of priority = insertion rank -- PRIORITY INSERTION (a key that meets a later one takes its slot and
+//     carries it on) builds it in any order, all keys of all sets at once (k_rp_put).
+//   * A growth re-inserts the old entries in an order that depends on where earlier ones land (an entry that gives way is
+//     carried on at once, :359-406).  As a fixed point: an old entry at slot q is inserted at time (q, 0) unless slot q is
+//     taken earlier, at time t -- then at t + 1.  From (q, 0) for everybody: lay out by time (priority insertion again,
+//     k_rp_insert_timed), read the evictions off the layout (k_rp_times; all times of a round from the layout of the round
+//     before), repeat until nothing changes: times only fall, never below the true ones, the only fixed point is the
+//     sequential run (tools/replay_fixed_point.c checks exactly this against the sequential emulation).  10-20 rounds.
+// Table word: 0 = empty; puts: id + 1; during a rehash: time << idbits | id + 1 with time = q << 6 | depth.
+// ===============================================================================================================
+struct RpSet {
+	unsigned long long key0;     // rank of the set's first key in the sorted key array (= its first visiting position)
+	unsigned long long tab0;     // first slot of the set's region in the table buffers
+	unsigned int m, size, old_size, lo, hi, pad;     // keys; slots now / before the growth; puts insert ids [lo, hi)
+};
+constexpr int RP_DEPTH_BITS = 6;
+
+__device__ inline int rp_find_set(const unsigned long long *__restrict__ pre, int p, unsigned long long g)
+{
+	int lo = 0, hi = p;                                // pre[lo] <= g < pre[hi]
+	while (hi - lo > 1) {
+		const int mid = (lo + hi) >> 1;
+		if (pre[mid] <= g) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// home slot of a key in a table of `size` slots (newhash.c:423-428 and :43-55; size < 2^32)
+template <int NW> __device__ inline uint32_t rp_home(const uint64_t *k, uint32_t size)
+{
+	if (NW == 1) return (uint32_t)(k[0] % size);
+	if (NW == 2) {
+		const uint64_t two64 = ((~0ULL) % size + 1ULL) % size;          // 2^64 mod size
+		return (uint32_t)(((k[0] % size) * two64 + k[1] % size) % size);
+	}
+	uint64_t t = k[0] % size;                                        // 32 bits at a time, as modular() does
+#pragma unroll
+	for (int i = 1; i < NW; i++) {
+		t = ((t << 32) | (k[i] >> 32)) % size;
+		t = ((t << 32) | (k[i] & 0xFFFFFFFFULL)) % size;
+	}
+	return (uint32_t)t;
+}
+
+// first come first served by priority word (smaller = earlier), any order of execution (Shun & Blelloch's deterministic linear probing)
+__device__ inline bool rp_insert(unsigned long long *tab, uint32_t size, uint32_t home, unsigned long long w)
+{
+	uint32_t i = home;
+	for (uint64_t steps = 0; steps < 2ULL * size + 64; steps++) {
+		unsigned long long c = __hip_atomic_load(tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (c == 0) {
+			c = atomicCAS(tab + i, 0ULL, w);
+			if (c == 0) return true;
+		}
+		if (c > w) {
+			const unsigned long long old = atomicCAS(tab + i, c, w);
+			if (old != c) continue;                        // somebody else changed the slot: look at it again
+			w = c;                                         // the later entry gives way and is carried on
+		}
+		i = i + 1 == size ? 0u : i + 1;
+	}
+	return false;
+}
+
+// homes of ids [a, b) of every set for a table of size `mod` (pre = exclusive prefix of b - a over the sets)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_rp_home(const uint64_t *__restrict__ keys, const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre,
+                                                 int p, int rehash, uint32_t *__restrict__ home)
+{
+	const unsigned long long total = pre[p];
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		const unsigned long long id = (rehash ? 0ULL : (unsigned long long)S.lo) + (g - pre[s]);
+		home[S.key0 + id] = rp_home<NW>(keys + (S.key0 + id) * NW, S.size);
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_rp_put(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p,
+                                                const uint32_t *__restrict__ home, unsigned long long *__restrict__ tab, unsigned int *fail)
+{
+	const unsigned long long total = pre[p];
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		const unsigned long long id = (unsigned long long)S.lo + (g - pre[s]);
+		if (!rp_insert(tab + S.tab0, S.size, home[S.key0 + id], id + 1ULL)) atomicOr(fail, 1u);
+	}
+}
+
+// over the OLD slots of every set (pre = exclusive prefix of old_size): mode 0 = initial times, 1 = timed insertion into the new table,
+// 2 = next times from the new layout
+__global__ __launch_bounds__(TPB) void k_rp_rehash(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int idbits,
+                                                   const unsigned long long *__restrict__ told, unsigned long long *__restrict__ tnew,
+                                                   const uint32_t *__restrict__ home, const unsigned long long *__restrict__ t_cur,
+                                                   unsigned long long *__restrict__ t_next, unsigned int *flags)
+{
+	const unsigned long long total = pre[p], idmask = (1ULL << idbits) - 1ULL;
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		const unsigned long long q = g - pre[s];
+		const unsigned long long y = told[S.tab0 + q];               // id + 1
+		if (!y) continue;
+		const unsigned long long at = S.key0 + y - 1ULL;
+		if (mode == 0) {
+			t_next[at] = q << RP_DEPTH_BITS;
+		} else if (mode == 1) {
+			if (!rp_insert(tnew + S.tab0, S.size, home[at], (t_cur[at] << idbits) | y)) atomicOr(flags, 2u);
+		} else {
+			const unsigned long long w = tnew[S.tab0 + q], x = w & idmask, tx = w >> idbits, mine = t_cur[at], scan = q << RP_DEPTH_BITS;
+			unsigned long long nt = scan;
+			if (x == y) nt = mine;                                     // it sits on its own old slot: nobody took it (leave the time alone)
+			else if (w && tx < scan) nt = tx + 1ULL;                   // the slot was taken before the scan reached it: carried on at once
+			if ((nt & ((1ULL << RP_DEPTH_BITS) - 1ULL)) == (1ULL << RP_DEPTH_BITS) - 1ULL) atomicOr(flags, 4u);      // chain too deep for the field
+			t_next[at] = nt;
+			if (nt != mine) atomicOr(flags, 1u);
+		}
+	}
+}
+
+// over the NEW slots (pre = exclusive prefix of size): mode 0 = drop the times (word -> id + 1), 1 = flag occupied slots for the final order
+__global__ __launch_bounds__(TPB) void k_rp_slots(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int idbits,
+                                                  unsigned long long *__restrict__ tab, uint32_t *__restrict__ occ)
+{
+	const unsigned long long total = pre[p], idmask = (1ULL << idbits) - 1ULL;
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const unsigned long long at = sets[s].tab0 + (g - pre[s]);
+		if (mode == 0) tab[at] &= idmask;
+		else occ[g] = tab[at] != 0;
+	}
+}
+
+// order[v] = rank of the node at visiting position v: the sets one after the other, inside a set the table's slots in order
+__global__ __launch_bounds__(TPB) void k_rp_order(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p,
+                                                  const unsigned long long *__restrict__ tab, const uint32_t *__restrict__ occ,
+                                                  const uint32_t *__restrict__ rank, uint64_t *__restrict__ order)
+{
+	const unsigned long long total = pre[p];
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		if (!occ[g]) continue;
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		// rank[] is the exclusive scan of occ over all sets' slots: the entries before this set's region are exactly its key0
+		order[rank[g]] = S.key0 + (tab[S.tab0 + (g - pre[s])] - 1ULL);
+	}
+}

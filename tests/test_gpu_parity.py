@@ -1239,3 +1239,39 @@ def test_read_ordinals_continue_from_device_batches_into_pushed_ones(pkg, synth,
         assert (kmers, nodes) == (o.kmers_in_reads(), o.node_count())
         _, _, _, _, first = g.export_nodes(with_first=True)
         assert sorted(first.tolist()) == sorted(o.export_first().tolist())
+
+
+@pytest.mark.parametrize("K,L,variant,p,small,n_reads", [(23, 100, 1, 8, False, 6000), (31, 150, 1, 1, False, 20000), (31, 150, 2, 3, True, 8000),
+                                                         (47, 150, 2, 5, False, 6000), (75, 200, 4, 2, True, 5000), (31, 100, 4, 16, False, 30000)])
+def test_layout_replay_on_the_device_equals_the_reference_table(pkg, synth, K, L, variant, p, small, n_reads):
+    """sdt_gpu_layout_on_device: the visiting order it numbers the nodes in == the slot order of the oracle's KmerSet (pinned to
+    the reference's newhash.c by the unit vectors: growth sizes and final slots) after the set's distinct keys went in in
+    first-occurrence order -- several growths per set, sets that start at 3 slots (-a), 1- / 2- / 4-word variants"""
+    tx = synth.make_transcriptome(10, seed=K + variant)
+    codes, offs = synth.sample_reads(*tx, n_reads=n_reads, read_len=L, seed=K + 1, err=0.01, ragged=True)
+    OL = ob.lib()
+    with pkg.PregraphGPU(K, est_distinct=1 << 15, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        skeys, ss = g.layout_sorted_keys(p, variant)
+        nwk = skeys.shape[1]
+        want = []
+        for s in range(p):
+            a, b = int(ss[s]), int(ss[s + 1])
+            st = OL.sdto_set_new(3 if (small and variant != 1) else 1024, 0.77)
+            for i in range(a, b):
+                w4 = [0] * (4 - nwk) + [int(x) for x in skeys[i]]
+                OL.sdto_set_put(st, ob.Kmer.of(w4), 4, 4, variant, None)
+            slot = ob.C.c_uint64()
+            where = []
+            for i in range(a, b):
+                w4 = [0] * (4 - nwk) + [int(x) for x in skeys[i]]
+                assert OL.sdto_set_search(st, ob.Kmer.of(w4), variant, ob.C.byref(slot)) == 1
+                where.append((slot.value, i))
+            OL.sdto_set_free(st)
+            want += [i for _, i in sorted(where)]
+        ss2 = g.layout_on_device(p, variant, small)
+        assert (ss2 == ss).all()
+        k2, _, _, _ = g.export_ordered()
+        assert (k2 == skeys[np.array(want, dtype=np.int64)]).all()
