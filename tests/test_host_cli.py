@@ -540,3 +540,16 @@ def test_whole_pipeline_with_the_reference_in_between(pkg, tmp_path, name):
         a, b = dirs["ours"][0] / f"out.{ext}", dirs["theirs"][0] / f"out.{ext}"
         assert open(a, "rb").read() == open(b, "rb").read(), ext
     assert os.path.getsize(dirs["ours"][0] / "out.scafSeq") > 0
+
+
+@pytest.mark.parametrize("keys,init", [(60000, 0), (150000, 3)])
+def test_rehash_as_a_fixed_point_of_insertion_times_equals_the_sequential_rehash(tmp_path, keys, init):
+    """tools/replay_fixed_point.c: the formulation the device's layout replay is built on (an old entry is re-inserted at time
+    (slot, 0) unless its slot is taken earlier, then at the taker's time + 1; rounds of first-come-first-served layouts until
+    nothing changes) against the sequential emulation of encap_kmerset's in-place rehash, growth by growth, slot by slot"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fp"
+    subprocess.run(["gcc", "-O2", "-o", str(exe), os.path.join(root, "tools", "replay_fixed_point.c"), "-lm"], check=True)
+    args = [str(exe), str(keys)] + ([str(init), "5"] if init else [])
+    out = subprocess.run(args, check=True, capture_output=True, text=True, timeout=300).stdout
+    assert "identical" in out, out
