@@ -222,7 +222,8 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	RpSet *d_sets;
 	unsigned int *d_flags;
 	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
-	GCHK(S.alloc(&t_time[0], m * 8)); GCHK(S.alloc(&t_time[1], m * 8));
+	uint32_t *d_home_slot;
+	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));      // per OLD slot of a growth
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
 	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
 	std::vector<unsigned long long> pre(p + 1);
@@ -247,27 +248,23 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				pre[s] = cnt_total;
 				cnt_total += sets[s].hi;
 			}
-			pre[p] = cnt_total;
-			rc = upload(); if (rc != SDT_OK) return rc;
-			// homes of every entry in the new geometry
-			if (v.nw == 1) hipLaunchKernelGGL(k_rp_home<1>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
-			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_home<2>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
-			else hipLaunchKernelGGL(k_rp_home<4>, grid(cnt_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, 1, d_home);
-			GCHK(hipGetLastError());
-			GCHK(hipStreamSynchronize(v.stream));                 // (pre / sets are overwritten below)
+			(void)cnt_total;
 			for (int s = 0; s < p; s++) { pre[s] = old_total; old_total += sets[s].old_size; }
 			pre[p] = old_total;
 			rc = upload(); if (rc != SDT_OK) return rc;
 			const int nxt = cur ^ 1;
 			int tc = 0;
-			hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 0, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc], d_flags);
+			// time (q, 0) and the home in the new geometry, per old slot
+			if (v.nw == 1) hipLaunchKernelGGL(k_rp_rehash_init<1>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
+			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_rehash_init<2>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
+			else hipLaunchKernelGGL(k_rp_rehash_init<4>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
 			for (int round = 0;; round++) {
 				if (round > 60) return fail(SDT_ESTATE, "layout on the device: a growth did not settle in 60 rounds");
 				for (int s = 0; s < p; s++)                       // (only the regions of the sets that grow, at their new size: the early growths are tiny)
 					if (sets[s].old_size) GCHK(hipMemsetAsync(tab[nxt] + sets[s].tab0, 0, (size_t)sets[s].size * 8, v.stream));
 				GCHK(hipMemsetAsync(d_flags, 0, 4, v.stream));
-				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc ^ 1], d_flags);
-				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 2, idbits, tab[cur], tab[nxt], d_home, t_time[tc], t_time[tc ^ 1], d_flags);
+				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], tab[nxt], d_home_slot, t_time[tc], t_time[tc ^ 1], d_flags);
+				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 2, idbits, tab[cur], tab[nxt], d_home_slot, t_time[tc], t_time[tc ^ 1], d_flags);
 				GCHK(hipGetLastError());
 				GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
 				GCHK(hipStreamSynchronize(v.stream));
@@ -324,7 +321,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	pre[p] = slot_total;
 	rc = upload(); if (rc != SDT_OK) return rc;
 	// (the buffers of the replay that are free now make room for the flags and their prefix sum)
-	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(t_time[0])); (void)hipFree(S.release(t_time[1]));
+	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(t_time[0])); (void)hipFree(S.release(t_time[1])); (void)hipFree(S.release(d_home_slot));
 	uint64_t *d_order;
 	GCHK(S.alloc(&d_occ, (slot_total + 1) * 4)); GCHK(S.alloc(&d_rank, (slot_total + 1) * 4)); GCHK(S.alloc(&d_order, m * 8));
 	hipLaunchKernelGGL(k_rp_slots, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], d_occ);

@@ -960,11 +960,30 @@ __global__ __launch_bounds__(TPB) void k_rp_put(const RpSet *__restrict__ sets, 
 	}
 }
 
-// over the OLD slots of every set (pre = exclusive prefix of old_size): mode 0 = initial times, 1 = timed insertion into the new table,
-// 2 = next times from the new layout
+// over the OLD slots of every set (pre = exclusive prefix of old_size; g = pre[s] + q also indexes the per-slot arrays, so a round
+// reads times and homes in slot order -- the insertion itself is the only random access of a round)
+//   k_rp_rehash_init: time (q, 0) and the home in the NEW geometry of the entry at every old slot
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_rp_rehash_init(const uint64_t *__restrict__ keys, const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre,
+                                                        int p, const unsigned long long *__restrict__ told, unsigned long long *__restrict__ t_slot,
+                                                        uint32_t *__restrict__ home_slot)
+{
+	const unsigned long long total = pre[p];
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		const unsigned long long q = g - pre[s];
+		const unsigned long long y = told[S.tab0 + q];               // id + 1
+		if (!y) continue;
+		t_slot[g] = q << RP_DEPTH_BITS;
+		home_slot[g] = rp_home<NW>(keys + (S.key0 + y - 1ULL) * NW, S.size);
+	}
+}
+
+//   k_rp_rehash: mode 1 = timed insertion into the new table, mode 2 = next times from the new layout
 __global__ __launch_bounds__(TPB) void k_rp_rehash(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int idbits,
                                                    const unsigned long long *__restrict__ told, unsigned long long *__restrict__ tnew,
-                                                   const uint32_t *__restrict__ home, const unsigned long long *__restrict__ t_cur,
+                                                   const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t_cur,
                                                    unsigned long long *__restrict__ t_next, unsigned int *flags)
 {
 	const unsigned long long total = pre[p], idmask = (1ULL << idbits) - 1ULL;
@@ -974,18 +993,15 @@ __global__ __launch_bounds__(TPB) void k_rp_rehash(const RpSet *__restrict__ set
 		const unsigned long long q = g - pre[s];
 		const unsigned long long y = told[S.tab0 + q];               // id + 1
 		if (!y) continue;
-		const unsigned long long at = S.key0 + y - 1ULL;
-		if (mode == 0) {
-			t_next[at] = q << RP_DEPTH_BITS;
-		} else if (mode == 1) {
-			if (!rp_insert(tnew + S.tab0, S.size, home[at], (t_cur[at] << idbits) | y)) atomicOr(flags, 2u);
+		if (mode == 1) {
+			if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t_cur[g] << idbits) | y)) atomicOr(flags, 2u);
 		} else {
-			const unsigned long long w = tnew[S.tab0 + q], x = w & idmask, tx = w >> idbits, mine = t_cur[at], scan = q << RP_DEPTH_BITS;
+			const unsigned long long w = tnew[S.tab0 + q], x = w & idmask, tx = w >> idbits, mine = t_cur[g], scan = q << RP_DEPTH_BITS;
 			unsigned long long nt = scan;
 			if (x == y) nt = mine;                                     // it sits on its own old slot: nobody took it (leave the time alone)
 			else if (w && tx < scan) nt = tx + 1ULL;                   // the slot was taken before the scan reached it: carried on at once
 			if ((nt & ((1ULL << RP_DEPTH_BITS) - 1ULL)) == (1ULL << RP_DEPTH_BITS) - 1ULL) atomicOr(flags, 4u);      // chain too deep for the field
-			t_next[at] = nt;
+			t_next[g] = nt;
 			if (nt != mine) atomicOr(flags, 1u);
 		}
 	}
