@@ -1882,6 +1882,23 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 	if (!c)
 		return fail(SDT_EINVAL, "ctx is NULL");
 	c->expect_kmers = kmers;
+	// The node table for the job NOW -- while nothing is in it (growing it moves nothing) and BEFORE the pools of the locality pipeline
+	// take their share of what is free: pools sized for the announced job on a device whose table then doubles several times left the
+	// table's rebuilds fighting the pools for memory (200 M reads: count stage 0.3 -> 1-3 s, and every later table scan crawled).
+	// One distinct node per 28 k-mers is what deep transcriptome data gives (C3: 35); data that repeats less grows the table as before.
+	if (kmers && c->distinct_known == 0 && c->kmers_since_sync == 0 && c->kmers_total_host == 0 && !c->sk.ready && c->staged_head == c->staged.size()) {
+		HIPCHK(hipSetDevice(c->device));
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		uint64_t est = kmers / 28;
+		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
+		while (est > (1u << 20) && (double)est / MAX_LOAD * 2.0 * (double)per_slot > (double)free_b * 0.3)
+			est /= 2;                                    // (never more than ~30 % of what is free, power-of-two rounding included)
+		if ((double)est > (double)c->slots * MAX_LOAD) {
+			const int rc = grow_table(c, est);
+			if (rc != SDT_OK) return rc;
+		}
+	}
 	return SDT_OK;
 }
 

@@ -121,6 +121,7 @@ static int exclusive_scan(const GraphView &v, const T *in, T *out, uint64_t n)
 
 // ---- the whole layout on the device: sort, replay of the probing (fixed point per growth), numbering ---------------------
 #include <math.h>
+#include <time.h>
 #include <vector>
 static int rp_prime(uint64_t num)                    // find_next_prime_kh's test (newhash.c:116-158): the bound is (ubyte8)sqrt((float)n)
 {
@@ -147,8 +148,11 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	if (!c || !n_out || !set_start) return fail(SDT_EINVAL, "NULL argument");
 	const GraphView v0 = sdti::graph_view(c);
 	HIPCHK(hipSetDevice(v0.device));
+	struct timespec ts0_; clock_gettime(CLOCK_MONOTONIC, &ts0_);
+	const double t_call = ts0_.tv_sec * 1e3 + ts0_.tv_nsec * 1e-6;
 	int rc = sdti::release_pass1(c);
 	if (rc != SDT_OK) return rc;
+	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       pass 1 released at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
 	const GraphView v = sdti::graph_view(c);
 	const uint64_t n = v.h_stats->distinct;
 	*n_out = n;
@@ -171,10 +175,12 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	GCHK(hipGetLastError());
 	rc = sdti::sync_stats(c);
 	if (rc != SDT_OK) return fail(SDT_ESTATE, "layout: %llu nodes without a usable first-occurrence ordinal", (unsigned long long)v.h_stats->probe_fail);
+	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       sort keys made at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
 	unsigned end_bit = 56;
 	for (int q = p - 1; q > 0; q >>= 1) end_bit++;
 	rc = sort_pairs<uint64_t>(v, k0, k1, v0s, v1s, n, end_bit);
 	if (rc != SDT_OK) return rc;
+	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       sorted at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
 	hipLaunchKernelGGL(k_layout_set_starts, dim3((p + 1 + 63) / 64), dim3(64), 0, v.stream, k1, n, (uint32_t)p, d_ss);
 	GCHK(hipGetLastError());
 	GCHK(hipMemcpyAsync(set_start, d_ss, (size_t)(p + 1) * 8, hipMemcpyDeviceToHost, v.stream));
@@ -182,6 +188,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	LAUNCH_NW(v, k_layout_gather_keys, sdti::scan_grid(v.cu_count, m), v1s, n, d_keys);
 	GCHK(hipGetLastError());
 	GCHK(hipStreamSynchronize(v.stream));
+	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       keys gathered at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
 	(void)hipFree(S.release(k1));                             // (the sorted sort keys are not needed any more)
 	if (v.nw != 1) (void)hipFree(S.release(k0));
 	(void)hipFree(S.release(v0s));
@@ -216,6 +223,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	int sbits = 1;
 	while ((1ULL << sbits) < max_size) sbits++;
 	if (idbits + sbits + RP_DEPTH_BITS > 64) return fail(SDT_EINVAL, "layout on the device: %d id bits + %d slot bits do not fit the table word", idbits, sbits);
+	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       schedule made at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
 	// ---- buffers
 	unsigned long long *tab[2], *t_time[2], *d_pre;
 	uint32_t *d_home, *d_occ, *d_rank;
@@ -236,6 +244,11 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	auto grid = [&](unsigned long long items) { return dim3(sdti::scan_grid(v.cu_count, items ? items : 1)); };
 	unsigned int h_flags = 0;
 	int cur = 0, total_rounds = 0;
+	auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+	const bool timing = getenv("SDT_TIMING") != nullptr;
+	const double t_start = now_ms();
+	double t_rehash = 0, t_put = 0, t_strip = 0;
+	if (timing) fprintf(stderr, "[device]     layout: release + sort + gather + schedule + buffers %.1f ms\n", t_start - t_call);
 	for (size_t gen = 0; gen < max_gens; gen++) {
 		// ---- growth into this generation's size (every set that has a generation `gen`, except the first)
 		if (gen > 0) {
@@ -254,6 +267,8 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 			rc = upload(); if (rc != SDT_OK) return rc;
 			const int nxt = cur ^ 1;
 			int tc = 0;
+			const double t_g0 = now_ms();
+			const int rounds0 = total_rounds;
 			// time (q, 0) and the home in the new geometry, per old slot
 			if (v.nw == 1) hipLaunchKernelGGL(k_rp_rehash_init<1>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
 			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_rehash_init<2>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
@@ -273,6 +288,9 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				if (!(h_flags & 1u)) break;
 				tc ^= 1;
 			}
+			const double t_g1 = now_ms();
+			t_rehash += t_g1 - t_g0;
+			if (timing && old_total > (1u << 24)) fprintf(stderr, "[device]     growth %zu: %llu old slots, %d rounds, %.1f ms\n", gen, old_total, total_rounds - rounds0, t_g1 - t_g0);
 			// the settled layout without its times is the table of this generation
 			unsigned long long new_total = 0;
 			for (int s = 0; s < p; s++) { pre[s] = new_total; new_total += gen < sched[s].size() ? sets[s].size : 0; }
@@ -292,8 +310,10 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				GCHK(hipStreamSynchronize(v.stream));
 			}
 			cur = nxt;
+			t_strip += now_ms() - t_g1;
 		}
 		// ---- the puts of this generation
+		const double t_p0 = now_ms();
 		unsigned long long put_total = 0;
 		for (int s = 0; s < p; s++) {
 			const bool on = gen < sched[s].size();
@@ -314,7 +334,9 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 		GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
 		GCHK(hipStreamSynchronize(v.stream));
 		if (h_flags) return fail(SDT_ESTATE, "layout on the device: a put found no slot");
+		t_put += now_ms() - t_p0;
 	}
+	if (timing) fprintf(stderr, "[device]     layout replay so far %.1f ms: rehash rounds %.1f, strip + copies %.1f, puts %.1f ms\n", now_ms() - t_start, t_rehash, t_strip, t_put);
 	// ---- the visiting order: the sets one after the other, every set's slots in order
 	unsigned long long slot_total = 0;
 	for (int s = 0; s < p; s++) { sets[s].size = sched[s].back().size; pre[s] = slot_total; slot_total += sets[s].size; }
@@ -332,6 +354,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	GCHK(hipGetLastError());
 	GCHK(hipStreamSynchronize(v.stream));
 	(void)hipFree(S.release(tab[cur])); (void)hipFree(S.release(d_occ)); (void)hipFree(S.release(d_rank)); (void)hipFree(S.release(d_home));
+	if (timing) fprintf(stderr, "[device]     layout: order extracted at %.1f ms\n", now_ms() - t_call);
 	// ---- number the nodes (as sdt_gpu_layout_apply)
 	if (*v.d_idx) { (void)hipFree(*v.d_idx); *v.d_idx = nullptr; }
 	*v.idx_slots = *v.idx_n = 0;
@@ -348,6 +371,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	*v.idx_n = n;
 	gx->d_slot_of = (uint64_t *)S.release(d_slot_of);
 	gx->n_nodes = n;
+	if (timing) fprintf(stderr, "[device]     layout: whole call %.1f ms\n", now_ms() - t_call);
 	if (getenv("SDT_TIMING")) fprintf(stderr, "[device]   layout replay: %zu generations, %d rounds of timed insertion in all, %llu table slots\n", max_gens, total_rounds, (unsigned long long)tab_total);
 	return SDT_OK;
 }
