@@ -22,6 +22,7 @@
 #include <new>
 #include <thread>
 #include <mutex>
+#include <atomic>
 
 #include "sdt_internal.hpp"
 #include "sdt_superkmer.cuh"
@@ -32,6 +33,7 @@ using namespace sdt;
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static std::atomic<int> g_live_ctx{0};                       // contexts alive in this process (the arena is trimmed when the last one goes)
 
 int sdti::fail(int code, const char *fmt, ...)
 {
@@ -801,7 +803,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	div = (uint64_t)clamp_int(env_int("SDT_SK_POOL_DIV", (int)div), 1, 1 << 20);
 	const int mem_pct = env_int("SDT_SK_POOL_MEM_PCT", 60);
 	size_t free_b = 0, total_b = 0;
-	HIPCHK(hipMemGetInfo(&free_b, &total_b));
+	HIPCHK(sdti::mem_info(&free_b, &total_b));
 	uint64_t cap = want_kmers < (1ULL << 24) ? (1ULL << 24) : want_kmers;
 	k.cap_is_max = cap >= SK_BATCH_MAX_KMERS;
 	const uint32_t wgs = (uint32_t)c->cu_count * 6;
@@ -1141,11 +1143,15 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		uint64_t want = k.pending_kmers + nreads * per_read;
 		if (!(c->flags & SDT_FLAG_PARTITION) && want < (1ULL << 31))
 			want = 1ULL << 31;
-		// a caller that streams its reads in and has said how much is coming (sdt_gpu_hint_total_kmers): pools for the whole job
-		// (sk_alloc caps them) -- the kernels, not the link, are the limit, so the copies only have to be hidden at the START
-		// (sk_batch_limit cuts the first batch short), and fewer, larger batches merge less (quarters of the job measured 3 % slower)
-		if (c->expect_kmers > want)
-			want = c->expect_kmers;
+		// a caller that streams its reads in and has said how much is coming (sdt_gpu_hint_total_kmers): pools for 2^31 k-mers from
+		// the first batch on (13 GiB at K = 31), not grown there batch by batch.  NOT pools for the whole job any more: fewer, larger
+		// batches merge a little less (quarters of a 14 G k-mer job measured 3 % slower than one batch), but the 103 GiB of pools of
+		// that job cost 1.4 - 4.7 s to allocate whenever the box's memory had been used before (sdt_mem.hip) -- a hundred times the gain.
+		if (c->expect_kmers > want) {
+			const uint64_t lim = 1ULL << clamp_int(env_int("SDT_SK_HINT_BATCH_LOG2", 31), 24, 34);
+			const uint64_t hinted = c->expect_kmers < lim ? c->expect_kmers : lim;
+			if (hinted > want) want = hinted;
+		}
 		rc = sk_alloc(c, want, per_read);
 	}
 	if (rc != SDT_OK)
@@ -1450,6 +1456,7 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	sdt_ctx *c = new (std::nothrow) sdt_ctx();
 	if (!c)
 		return fail(SDT_ENOMEM, "out of host memory");
+	g_live_ctx.fetch_add(1);
 	c->device = device;
 	c->K = K;
 	c->nw = K <= 31 ? 1 : (K <= 63 ? 2 : 4);
@@ -1529,6 +1536,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	delete c;
+	if (g_live_ctx.fetch_sub(1) == 1) (void)sdti::mem_trim();       // the last context of the process: the arena's memory goes back to the driver
 	return SDT_OK;
 }
 
@@ -1889,7 +1897,7 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 	if (kmers && c->distinct_known == 0 && c->kmers_since_sync == 0 && c->kmers_total_host == 0 && !c->sk.ready && c->staged_head == c->staged.size()) {
 		HIPCHK(hipSetDevice(c->device));
 		size_t free_b = 0, total_b = 0;
-		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		HIPCHK(sdti::mem_info(&free_b, &total_b));
 		uint64_t est = kmers / 28;
 		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
 		while (est > (1u << 20) && (double)est / MAX_LOAD * 2.0 * (double)per_slot > (double)free_b * 0.3)
@@ -2863,7 +2871,7 @@ int sdti::release_pass1(sdt_ctx *c)
 {
 	const int rc = ::sync_stats(c);
 	if (rc != SDT_OK) return rc;
-	sk_free(c);
+	if (!getenv("SDT_KEEP_POOLS")) sk_free(c);               // (measurement switch)
 	return SDT_OK;
 }
 

@@ -229,11 +229,14 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	uint32_t *d_home, *d_occ, *d_rank;
 	RpSet *d_sets;
 	unsigned int *d_flags;
-	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
+	auto tick = [&](const char *what) { if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       %s at %.1f ms\n", what, t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); } };
+	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); tick("tab0"); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8)); tick("tab1");
 	uint32_t *d_home_slot;
-	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));      // per OLD slot of a growth
+	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); tick("time0"); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); tick("time1"); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4)); tick("home_slot");     // per OLD slot of a growth
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
+	tick("small ones");
 	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
+	tick("memset queued");
 	std::vector<unsigned long long> pre(p + 1);
 	auto upload = [&](void) -> int {
 		GCHK(hipStreamSynchronize(v.stream));                  // (kernels in flight read the old copies; the host vectors change right after)

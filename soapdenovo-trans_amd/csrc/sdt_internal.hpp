@@ -1,5 +1,6 @@
 // sdt_internal.hpp -- what the translation units of libsdt_gpu.so share besides the public ABI (include/sdt_gpu.h).
 //   sdt_gpu.hip        pass 1 (direct kernel family, locality pipeline), table scans, second read pass, multi-GPU, map stage
+//   sdt_mem.hip        device memory: the arena behind every hipMalloc / hipFree of the library
 //   sdt_gpu_graph.hip  graph phases on the device mirror: layout (visiting order), dry runs of the cutting passes with
 //                      the components of their commits, port walks of kmer2edges
 // The context itself (struct sdt_ctx) stays private to sdt_gpu.hip; the graph unit sees it through GraphView.
@@ -25,6 +26,14 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 			return sdti::fail(e_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)",    \
 			                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                             \
 	} while (0)
+
+// every device allocation of the library goes through here (sdt_mem.hip): blocks of 1 MiB and more are kept in an arena when they
+// are freed and handed out again; under SDT_TIMING the calls into the runtime that take more than 5 ms are reported
+hipError_t dmalloc(void **p, size_t bytes, const char *file, int line);
+hipError_t dfree(void *p, const char *file, int line);
+hipError_t hmalloc(void **p, size_t bytes, unsigned flags, const char *file, int line);
+hipError_t mem_info(size_t *free_b, size_t *total_b);      // hipMemGetInfo + what the arena holds
+size_t mem_trim(void);                                     // slabs of the arena that nobody uses go back to the driver
 
 struct GraphExt;                   // state of the graph unit, owned by the context (sdt_gpu_graph.hip)
 void graph_ext_free(GraphExt *gx);
@@ -71,3 +80,7 @@ int h2d_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
 int d2h_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
 
 }  // namespace sdti
+
+#define hipMalloc(p, bytes) sdti::dmalloc((void **)(p), (bytes), __FILE__, __LINE__)
+#define hipFree(p) sdti::dfree((p), __FILE__, __LINE__)
+#define hipHostMalloc(p, bytes, flags) sdti::hmalloc((void **)(p), (bytes), (flags), __FILE__, __LINE__)

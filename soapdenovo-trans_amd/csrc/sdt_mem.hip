@@ -1,0 +1,183 @@
+// sdt_mem.hip -- device memory of libsdt_gpu.so: every hipMalloc / hipFree of the library ends here (sdt_internal.hpp).
+//
+// Why an arena.  What a hipMalloc costs on the box depends on the state its memory is in: a block that was never used comes in
+// 0.3 ms, 32 GiB of it; a block that some process -- this one included -- gave back a moment ago has to be cleared by the
+// driver first, at ~33 GiB/s on a good day and behind the clearing of everything else that was freed (measured: 1-4.7 s for the
+// 48 GiB of the locality pipeline's pools, 3.3 s for the first 5 GiB the layout asked for right after those pools were
+// released; profiles/r4/README.md).  A pregraph run allocates ~250 GiB in all but never more than ~120 GiB at a time, so blocks
+// of at least 1 MiB are kept when they are freed and handed out again: the driver sees the peak, once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <map>
+#include <mutex>
+#include <vector>
+#include "sdt_internal.hpp"
+#undef hipMalloc
+#undef hipFree
+#undef hipHostMalloc
+
+namespace {
+
+bool mem_timing() { static const bool t = getenv("SDT_TIMING") != nullptr; return t; }
+double mem_now() { struct timespec a; clock_gettime(CLOCK_MONOTONIC, &a); return a.tv_sec * 1e3 + a.tv_nsec * 1e-6; }
+void mem_report(const char *what, double gib, double ms, const char *file, int line)
+{
+	if (!mem_timing() || ms <= 5.0) return;
+	const char *f = strrchr(file, '/');
+	fprintf(stderr, "[device] %s of %.2f GiB took %.1f ms (%s:%d)\n", what, gib, ms, f ? f + 1 : file, line);
+}
+
+constexpr size_t ARENA_MIN = 1u << 20;       // smaller blocks go straight to the runtime (its own sub-allocator serves them)
+constexpr size_t ARENA_GRAIN = 1u << 16;
+
+struct Range { size_t bytes; int slab; };
+struct Slab { char *base; size_t bytes; int device; size_t used; };
+
+struct Arena {
+	std::mutex mu;
+	std::vector<Slab> slabs;
+	std::map<char *, Range> free_;           // free ranges by address (never spanning two slabs)
+	std::map<void *, Range> live;            // blocks handed out
+	size_t free_bytes = 0;
+	bool off() { static const bool o = getenv("SDT_NO_ARENA") != nullptr; return o; }
+
+	void *take(size_t bytes, int device)     // best fit among the free ranges of this device
+	{
+		auto best = free_.end();
+		for (auto it = free_.begin(); it != free_.end(); ++it)
+			if (it->second.bytes >= bytes && slabs[it->second.slab].device == device && (best == free_.end() || it->second.bytes < best->second.bytes))
+				best = it;
+		if (best == free_.end()) return nullptr;
+		char *p = best->first;
+		const Range r = best->second;
+		free_.erase(best);
+		if (r.bytes > bytes) free_[p + bytes] = Range{r.bytes - bytes, r.slab};
+		free_bytes -= bytes;
+		slabs[r.slab].used += bytes;
+		live[p] = Range{bytes, r.slab};
+		return p;
+	}
+	void give(char *p, Range r)
+	{
+		slabs[r.slab].used -= r.bytes;
+		free_bytes += r.bytes;
+		auto nx = free_.lower_bound(p);
+		if (nx != free_.end() && nx->first == p + r.bytes && nx->second.slab == r.slab) {
+			r.bytes += nx->second.bytes;
+			nx = free_.erase(nx);
+		}
+		if (nx != free_.begin()) {
+			auto pv = std::prev(nx);
+			if (pv->first + pv->second.bytes == p && pv->second.slab == r.slab) {
+				pv->second.bytes += r.bytes;
+				return;
+			}
+		}
+		free_[p] = r;
+	}
+	// slabs nobody uses go back to the driver (all devices); returns the bytes released
+	size_t trim()
+	{
+		size_t out = 0;
+		int cur = 0;
+		(void)hipGetDevice(&cur);
+		for (size_t i = 0; i < slabs.size(); i++) {
+			Slab &s = slabs[i];
+			if (!s.base || s.used) continue;
+			free_.erase(s.base);                 // (a slab without live blocks is one free range)
+			free_bytes -= s.bytes;
+			(void)hipSetDevice(s.device);
+			(void)hipFree(s.base);
+			out += s.bytes;
+			s.base = nullptr; s.bytes = 0;
+		}
+		(void)hipSetDevice(cur);
+		return out;
+	}
+};
+
+Arena &arena() { static Arena *a = new Arena; return *a; }      // (never destroyed: contexts may outlive static destructors)
+
+}  // namespace
+
+hipError_t sdti::dmalloc(void **p, size_t bytes, const char *file, int line)
+{
+	Arena &A = arena();
+	if (bytes < ARENA_MIN || A.off()) {
+		const double t0 = mem_now();
+		const hipError_t e = hipMalloc(p, bytes);
+		mem_report("hipMalloc", (double)bytes / (1 << 30), mem_now() - t0, file, line);
+		return e;
+	}
+	int device = 0;
+	hipError_t e = hipGetDevice(&device);
+	if (e != hipSuccess) return e;
+	const size_t want = (bytes + ARENA_GRAIN - 1) / ARENA_GRAIN * ARENA_GRAIN;
+	std::lock_guard<std::mutex> lock(A.mu);
+	if ((*p = A.take(want, device)) != nullptr) return hipSuccess;
+	const double t0 = mem_now();
+	void *q = nullptr;
+	e = hipMalloc(&q, want);
+	if (e == hipErrorOutOfMemory && A.trim()) {
+		(void)hipGetLastError();
+		e = hipMalloc(&q, want);
+	}
+	mem_report("hipMalloc", (double)want / (1 << 30), mem_now() - t0, file, line);
+	if (e != hipSuccess) { *p = nullptr; return e; }
+	A.slabs.push_back(Slab{(char *)q, want, device, want});
+	A.live[q] = Range{want, (int)A.slabs.size() - 1};
+	*p = q;
+	return hipSuccess;
+}
+
+hipError_t sdti::dfree(void *p, const char *file, int line)
+{
+	if (!p) return hipSuccess;
+	Arena &A = arena();
+	{
+		std::lock_guard<std::mutex> lock(A.mu);
+		auto it = A.live.find(p);
+		if (it != A.live.end()) {
+			// hipFree waits for the device before it lets go of a block; the callers rely on that (kernels of another stream may
+			// still read what is freed here)
+			const hipError_t e = hipDeviceSynchronize();
+			const Range r = it->second;
+			A.live.erase(it);
+			A.give((char *)p, r);
+			return e;
+		}
+	}
+	const double t0 = mem_now();
+	const hipError_t e = hipFree(p);
+	mem_report("hipFree", 0.0, mem_now() - t0, file, line);
+	return e;
+}
+
+hipError_t sdti::hmalloc(void **p, size_t bytes, unsigned flags, const char *file, int line)
+{
+	const double t0 = mem_now();
+	const hipError_t e = hipHostMalloc(p, bytes, flags);
+	mem_report("hipHostMalloc", (double)bytes / (1 << 30), mem_now() - t0, file, line);
+	return e;
+}
+
+hipError_t sdti::mem_info(size_t *free_b, size_t *total_b)
+{
+	const hipError_t e = hipMemGetInfo(free_b, total_b);
+	if (e != hipSuccess) return e;
+	Arena &A = arena();
+	std::lock_guard<std::mutex> lock(A.mu);
+	*free_b += A.free_bytes;                     // (what the arena holds is free for the library's purposes)
+	return hipSuccess;
+}
+
+size_t sdti::mem_trim(void)
+{
+	Arena &A = arena();
+	std::lock_guard<std::mutex> lock(A.mu);
+	return A.trim();
+}

@@ -39,6 +39,7 @@ ap.add_argument("--ref-p2", type=int, default=0, help="time the reference a seco
 ap.add_argument("--compare-host-walks", action="store_true", help="run again with --host-walks and compare all files")
 ap.add_argument("--gen-procs", type=int, default=0, help="processes that write the FASTQ (0 = one per usable CPU; fixed-width records, written in place)")
 ap.add_argument("--ingest-probe", action="store_true", help="only time --hash-only in variants (as is, parse only, other thread counts) and stop")
+ap.add_argument("--env-runs", default="", help="measurement: run sdt-pregraph once per variant 'name:K=V,K=V;name2:...' (environment switches of the library / CLI), report walls and phase lines, and stop")
 ap.add_argument("--runs", type=int, default=1, help="run sdt-pregraph this many times (page cache, first-touch effects): the fastest is reported, all walls are listed")
 args = ap.parse_args()
 
@@ -218,6 +219,19 @@ try:
                                  "--hash-only"] + extra, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
             probe[name] = {"wall_s": round(time.time() - t0, 2), "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if "parse + hash" in l or l.startswith("[ingest]")]}
         res["ingest_probe"] = probe
+        print(json.dumps(res, indent=1))
+        raise SystemExit(0)
+    if args.env_runs:
+        out = {}
+        for spec in args.env_runs.split(";"):
+            name, _, kv = spec.partition(":")
+            env = dict(x.split("=", 1) for x in kv.split(",") if x)
+            t0 = time.time()
+            rp = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o", os.path.join(tmp, "probe")] + extra,
+                                capture_output=True, text=True, env=dict(os.environ, **env), timeout=args.timeout)
+            out[name] = {"env": env, "rc": rp.returncode, "wall_s": round(time.time() - t0, 2),
+                         "phases": [l.replace("[sdt-pregraph] ", "") for l in rp.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[ingest]", "[device]", "[libsdt_gpu]"))]}
+        res["env_runs"] = out
         print(json.dumps(res, indent=1))
         raise SystemExit(0)
     walls, r = [], None
