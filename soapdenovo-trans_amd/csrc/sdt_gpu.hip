@@ -703,7 +703,7 @@ static int tile_words_for(uint64_t max_read_len)
 // ------------------------------------------------------------------------------------------------
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 34), 24, 34);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
+static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 34), 24, 36);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
 static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
@@ -1143,12 +1143,12 @@ static int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 		uint64_t want = k.pending_kmers + nreads * per_read;
 		if (!(c->flags & SDT_FLAG_PARTITION) && want < (1ULL << 31))
 			want = 1ULL << 31;
-		// a caller that streams its reads in and has said how much is coming (sdt_gpu_hint_total_kmers): pools for 2^31 k-mers from
-		// the first batch on (13 GiB at K = 31), not grown there batch by batch.  NOT pools for the whole job any more: fewer, larger
+		// a caller that streams its reads in and has said how much is coming (sdt_gpu_hint_total_kmers): pools for 2^32 k-mers from
+		// the first batch on (26 GiB at K = 31), not grown there batch by batch.  NOT pools for the whole job any more: fewer, larger
 		// batches merge a little less (quarters of a 14 G k-mer job measured 3 % slower than one batch), but the 103 GiB of pools of
 		// that job cost 1.4 - 4.7 s to allocate whenever the box's memory had been used before (sdt_mem.hip) -- a hundred times the gain.
 		if (c->expect_kmers > want) {
-			const uint64_t lim = 1ULL << clamp_int(env_int("SDT_SK_HINT_BATCH_LOG2", 31), 24, 34);
+			const uint64_t lim = 1ULL << clamp_int(env_int("SDT_SK_HINT_BATCH_LOG2", 32), 24, 34);
 			const uint64_t hinted = c->expect_kmers < lim ? c->expect_kmers : lim;
 			if (hinted > want) want = hinted;
 		}

@@ -10,6 +10,12 @@
 #ifndef SDT_SK_CLAIM_BELOW
 #define SDT_SK_CLAIM_BELOW 0      // flush: keys counted at most this often send their slot claim along with the loads (0: never; 2 measured 5 % slower: profiles/r3)
 #endif
+#ifndef SDT_SK_LOAD16
+#define SDT_SK_LOAD16 1           // owned flush of 1-word keys: one 16-byte load per entry instead of two 8-byte ones
+#endif
+#ifndef SDT_SK_CLAIM2_BELOW
+#define SDT_SK_CLAIM2_BELOW 0     // the same for 2-word keys (their claim is KEY_LOCKED, published by one 16-byte store)
+#endif
 #ifndef SDT_SK_FLUSH_NUM
 #define SDT_SK_FLUSH_NUM 4        // the LDS table is flushed between rounds once it is FLUSH_NUM / 8 full
 #endif
@@ -958,7 +964,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							if (TRACK) s_ord[i] = ORD_NONE;
 							const uint64_t slot = key_hash<NW>(key) & tbl.mask;
 							merges++;
-							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, false), add, 0u, claimed, ord))
+							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, NW == 2 && SDT_SK_CLAIM2_BELOW > 0 && (add >> 48) <= SDT_SK_CLAIM2_BELOW), add, 0u, claimed, ord))
 								failed++;
 						}
 #pragma unroll
@@ -994,10 +1000,32 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							}
 						}
 						__builtin_amdgcn_sched_barrier(0);       // (hashes first, then all loads, then the merges: interleaved by the
-#pragma unroll                                                 //  scheduler the snapshots were spilled, i.e. waited for one by one)
+						if (NW == 1 && SDT_SK_LOAD16) {          //  scheduler the snapshots were spilled, i.e. waited for one by one)
+							// key and val of a 16-byte entry with ONE agent-scope load (two 8-byte ones are two requests to the memory side)
+							typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+							u32x4 raw[PER];
+#pragma unroll
+							for (int p = 0; p < PER; p++) {
+								const Entry<NW> *e = tbl.ent + (have[p] ? key_hash<NW>(mk[p]) & tbl.mask : 0);
+								asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[p]) : "v"(e) : "memory");
+							}
+							asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]) :: "memory");
+#pragma unroll
+							for (int p = 1; p < PER; p++)
+								asm volatile("" : "+v"(raw[p]) :: "memory");
+#pragma unroll
+							for (int p = 0; p < PER; p++) {
+								sn[p].k[0] = ((uint64_t)raw[p].y << 32) | raw[p].x;
+								sn[p].v = ((uint64_t)raw[p].w << 32) | raw[p].z;
+								sn[p].f = ORD_NONE;
+								sn[p].won = false;
+							}
+						} else {
+#pragma unroll
 						for (int p = 0; p < PER; p++)
 							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
 								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+						}
 						__builtin_amdgcn_sched_barrier(0);
 						flush_finish();
 					} else {

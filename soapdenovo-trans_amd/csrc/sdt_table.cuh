@@ -345,6 +345,21 @@ __device__ inline void ord_min_noret(uint64_t *p, uint64_t ord)
 	(void)__hip_atomic_fetch_min(p, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Publishing a 2-word key into a slot this lane holds (KEY_LOCKED in key[0]): ONE 16-byte store of both words.  An entry of two
+// words is 32-byte aligned, so the pair lies in one 16-byte granule of one cache line and reaches L2 as one write: a reader that
+// sees the new key[0] sees the new key[1] (it loads key[1] after key[0], in order, from the same line).  The two-step form --
+// key[1], wait for the store to be acknowledged, key[0] -- cost a new key a whole memory round trip on the flush's critical path.
+__device__ inline void store_key_pair(uint64_t *p, uint64_t k0, uint64_t k1)
+{
+	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+	u32x4 v;
+	v.x = (uint32_t)k0; v.y = (uint32_t)(k0 >> 32); v.z = (uint32_t)k1; v.w = (uint32_t)(k1 >> 32);
+	asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
+#ifndef SDT_WIDE_ENT_LOAD
+#define SDT_WIDE_ENT_LOAD 1
+#endif
 template <int NW, bool FIRST> struct EntSnap { uint64_t k[NW]; uint64_t v; uint64_t f; bool won; };      // f: the slot's first-occurrence ordinal (FIRST only)
 
 // `claim` (1-word keys): the key is probably new -- its slot claim, a compare-and-swap on the key word, travels TOGETHER with
@@ -358,6 +373,43 @@ template <int NW, bool FIRST> __device__ inline EntSnap<NW, FIRST> ent_load(cons
 	if (NW == 1 && claim) {
 		sn.k[0] = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY, (unsigned long long)key.w[0]);
 		sn.won = sn.k[0] == KEY_EMPTY;
+	} else if (NW == 2 && claim) {
+		// 2-word keys: the claim puts KEY_LOCKED there; table_merge_owned_at publishes both key words with one 16-byte store
+		sn.k[0] = atomicCAS((unsigned long long *)&e->key[0], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
+		sn.won = sn.k[0] == KEY_EMPTY;
+		sn.k[1] = ld_relaxed(&e->key[NW - 1]);
+	} else if (SDT_WIDE_ENT_LOAD) {
+		// the whole entry in 16-byte agent-scope loads: every load is a request of its own to the memory side (agent-scope loads do
+		// not stop in this XCD's L2), so key + val of a 16-byte entry as two 8-byte loads fetched its line twice (k_sk_count's
+		// flush: 137 B fetched per merge, profiles/r3; 174 instead of 186 ms per step with the one load, profiles/r4)
+		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+		if constexpr (NW == 1) {
+			u32x4 a;
+			asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(e) : "memory");
+			sn.k[0] = ((uint64_t)a.y << 32) | a.x;
+			sn.v = ((uint64_t)a.w << 32) | a.z;
+		} else if constexpr (NW == 2) {
+			u32x4 a;
+			uint64_t b;
+			asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(a), "=&v"(b) : "v"(e) : "memory");
+			sn.k[0] = ((uint64_t)a.y << 32) | a.x;
+			sn.k[1] = ((uint64_t)a.w << 32) | a.z;
+			sn.v = b;
+		} else {
+			u32x4 a, b;
+			uint64_t c;
+			asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+			             "global_load_dwordx2 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(e) : "memory");
+			sn.k[0] = ((uint64_t)a.y << 32) | a.x;
+			sn.k[1] = ((uint64_t)a.w << 32) | a.z;
+			sn.k[NW - 2] = ((uint64_t)b.y << 32) | b.x;
+			sn.k[NW - 1] = ((uint64_t)b.w << 32) | b.z;
+			sn.v = c;
+		}
+		sn.f = ORD_NONE;
+		return sn;
 	} else {
 #pragma unroll
 		for (int i = 0; i < NW; i++)
@@ -375,9 +427,10 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
 	for (uint64_t probe = 0; probe < max_probe; probe++) {
 		Entry<NW> *e = t.ent + slot;
-		if (NW == 1 && sn.won) {
+		if (NW <= 2 && sn.won) {
 			// the claim that travelled with the loads won the slot: k_clear left val = 0, aux = 0, first = none
 			claimed++;
+			if (NW == 2) store_key_pair(&e->key[0], key.w[0], key.w[NW - 1]);
 			__hip_atomic_store(&e->val, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (hi)
 				__hip_atomic_store(t.aux + slot, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -416,7 +469,9 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 			                               (unsigned long long)(NW == 1 ? key.w[0] : KEY_LOCKED));
 			if (old == KEY_EMPTY) {
 				claimed++;
-				if (NW > 1) {
+				if (NW == 2) {
+					store_key_pair(&e->key[0], key.w[0], key.w[NW - 1]);
+				} else if (NW > 1) {
 #pragma unroll
 					for (int i = 1; i < NW; i++)
 						__hip_atomic_store(&e->key[i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
