@@ -347,6 +347,7 @@ def main():
     assert int(hist.sum()) == nodes, "kmerFreq bins do not add up to the node count"
     stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
+    log("table slots:", g.table_slots())
     log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms],
         {k: v for k, v in sk_counters.items() if "ticks" not in k or v})
     ms_per_step = dt / args.steps * 1e3

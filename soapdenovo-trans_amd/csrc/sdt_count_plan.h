@@ -8,15 +8,40 @@
 //   * a larger bucket is cut into pieces of `item_chunks` chunks, not flagged;
 //   * buckets of at most `pack_chunks` chunks share an item with their neighbours (their chunks are adjacent in the list, empty
 //     buckets in between do not matter) as long as the item stays within `pack_chunks` chunks: per-item costs are paid once;
+//   * within a launch the items are handed out LARGEST FIRST (by power-of-two size class, list order within a class): a launch
+//     ends when its slowest workgroup does, and an item of 1024 chunks taken last kept 500 workgroups waiting for ~0.7 ms --
+//     45 launches per step of the 200 M-read workload, 30 ms of its 170 ms (profiles/r4);
 //   * launches are cut between buckets: a launch holds at most `limit` k-mers (`first_limit` for the first one, whose rate of
 //     new nodes sizes the others) unless a single bucket is larger, and an item never spans two launches.
 // sk_count_all (sdt_gpu.hip) calls this; tests/test_count_plan.py checks it on the CPU through sdt_sk_plan_count_items.
 #pragma once
 #include <stdint.h>
+#include <vector>
 
 namespace sdt {
 
 constexpr uint32_t SK_ITEM_WHOLE = 0x80000000u;
+
+// items [i0, i1) largest first: a counting sort by size class (position of the highest bit of the chunk count), stable within a class
+inline void sk_plan_largest_first(uint32_t *items, uint32_t i0, uint32_t i1, std::vector<uint32_t> &tmp)
+{
+	if (i1 - i0 < 2)
+		return;
+	uint32_t cnt[33] = {0};
+	auto cls = [&](uint32_t i) { const uint32_t n = (items[2 * i + 1] & ~SK_ITEM_WHOLE) - items[2 * i]; return n ? 32u - (uint32_t)__builtin_clz(n) : 0u; };
+	for (uint32_t i = i0; i < i1; i++)
+		cnt[cls(i)]++;
+	uint32_t start[33], acc = 0;
+	for (int c = 32; c >= 0; c--) { start[c] = acc; acc += cnt[c]; }
+	tmp.resize((size_t)2 * (i1 - i0));
+	for (uint32_t i = i0; i < i1; i++) {
+		const uint32_t at = start[cls(i)]++;
+		tmp[2 * at] = items[2 * i];
+		tmp[2 * at + 1] = items[2 * i + 1];
+	}
+	for (uint32_t j = 0; j < 2 * (i1 - i0); j++)
+		items[2 * i0 + j] = tmp[j];
+}
 
 // items: 2 words per item (c0, c1 | SK_ITEM_WHOLE); first_item[l] = first item of launch l (first_item[*nlaunches] = *nitems);
 // launch_kmers[l] = its k-mers.  Returns false when an output array is too small.
@@ -26,6 +51,7 @@ inline bool sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uin
 {
 	uint32_t nci = 0, nl = 0;
 	uint64_t acc = 0;
+	std::vector<uint32_t> tmp;
 	bool pack_open = false;
 	uint32_t pack_c0 = 0;
 	if (launches_cap < 1)
@@ -39,6 +65,7 @@ inline bool sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uin
 				return false;
 			launch_kmers[nl++] = acc;
 			first_item[nl] = nci;
+			sk_plan_largest_first(items, first_item[nl - 1], nci, tmp);
 			acc = 0;
 			pack_open = false;                           // (an item belongs to one launch)
 		}
@@ -70,6 +97,7 @@ inline bool sk_plan_count_items(const uint32_t *off2, const uint64_t *kpre2, uin
 		return false;
 	launch_kmers[nl++] = acc;
 	first_item[nl] = nci;
+	sk_plan_largest_first(items, first_item[nl - 1], nci, tmp);
 	*nitems = nci;
 	*nlaunches = nl;
 	return true;

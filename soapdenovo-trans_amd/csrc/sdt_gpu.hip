@@ -705,9 +705,9 @@ static int env_int(const char *name, int dflt) { const char *v = getenv(name); r
 static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 34), 24, 36);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
-static const uint64_t SK_COUNT_KMERS = 1ULL << 29;
+static const uint64_t SK_COUNT_KMERS = 1ULL << clamp_int(env_int("SDT_SK_COUNT_KMERS_LOG2", 29), 20, 36);
 static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
-static const uint32_t SK_COUNT_ITEM_CHUNKS = 1024;          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
+static const uint32_t SK_COUNT_ITEM_CHUNKS = (uint32_t)clamp_int(env_int("SDT_SK_COUNT_ITEM_CHUNKS", 1024), 64, 1 << 24);          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 static void sk_free(sdt_ctx *c)
@@ -975,20 +975,27 @@ static int sk_count_all(sdt_ctx *c)
 	launch_kmers.resize(nlaunches);
 	if (nci)
 		SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-	for (size_t l = 0; l + 1 < first_item.size() && rc == SDT_OK; l++) {
-		const uint32_t i0 = first_item[l], i1 = first_item[l + 1];
-		if (i0 == i1)
+	auto guess_of = [&](uint64_t kmers) -> uint64_t {
+		uint64_t bound = kmers;
+		if (c->kmers_known) {
+			const double rate = (double)c->distinct_known / (double)c->kmers_known;
+			const uint64_t guess = (uint64_t)((double)kmers * (2.0 * rate < 1.0 ? 2.0 * rate : 1.0)) + (1ULL << 22);
+			if (guess < bound) bound = guess;
+		}
+		return bound;
+	};
+	const size_t nl = first_item.size() - 1;
+	for (size_t l = 0; l < nl && rc == SDT_OK;) {
+		const uint32_t i0 = first_item[l];
+		if (i0 == first_item[l + 1]) {
+			l++;
 			continue;
+		}
 		if (c->kmers_known == 0 && l > 0) {
 			rc = sync_stats(c);                      // the first launch has run: its rate of new nodes bounds the rest
 			if (rc != SDT_OK) break;
 		}
-		uint64_t bound = launch_kmers[l];
-		if (c->kmers_known) {
-			const double rate = (double)c->distinct_known / (double)c->kmers_known;
-			const uint64_t guess = (uint64_t)((double)launch_kmers[l] * (2.0 * rate < 1.0 ? 2.0 * rate : 1.0)) + (1ULL << 22);
-			if (guess < bound) bound = guess;
-		}
+		uint64_t bound = guess_of(launch_kmers[l]), hard = launch_kmers[l];
 		rc = ensure_room(c, bound);
 		// the guess keeps the load factor; this keeps the table from FILLING should the guess be wrong: whatever the data,
 		// the nodes known + every k-mer launched since + this launch must fit 95 % of the slots
@@ -997,12 +1004,28 @@ static int sk_count_all(sdt_ctx *c)
 			if (rc == SDT_OK && (double)(c->distinct_known + launch_kmers[l]) > 0.95 * (double)c->slots)
 				rc = grow_table(c, c->distinct_known + launch_kmers[l]);
 		}
+		// The planned launches behind this one join it as long as neither rule would have to look at the device's counters for
+		// them: a launch boundary is a drained GPU (every workgroup waits for the slowest), and it is only needed where the host
+		// decides about the table.  (45 planned launches per step of the 200 M-read workload become about a dozen.)
+		size_t m = l;
+		while (rc == SDT_OK && c->kmers_known && m + 1 < nl) {
+			const uint64_t b2 = guess_of(launch_kmers[m + 1]);
+			if ((double)(c->distinct_known + c->kmers_since_sync + bound + b2) > (double)c->slots * MAX_LOAD)
+				break;
+			if ((double)(c->distinct_known + c->hard_since_sync + hard + launch_kmers[m + 1]) > 0.95 * (double)c->slots)
+				break;
+			bound += b2;
+			hard += launch_kmers[m + 1];
+			m++;
+		}
+		const uint32_t i1 = first_item[m + 1];
 		if (rc == SDT_OK)
 			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
 		if (rc == SDT_OK) {                              // (only what was launched counts)
 			c->kmers_since_sync += bound;
-			c->hard_since_sync += launch_kmers[l];
+			c->hard_since_sync += hard;
 		}
+		l = m + 1;
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
 	return rc;

@@ -1058,7 +1058,11 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 						if ((tid & 63) == 0) {
 							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
 							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+#ifdef SDT_SK_SPLIT_MERGE_STAT                       // (measurement build: the merges by compare-and-swap are reported as `lds_spills`)
+							if (merges) atomicAdd(&s_stat[ST_SPILLS], merges);
+#else
 							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+#endif
 						}
 					}
 					__syncthreads();

@@ -41,7 +41,16 @@ def test_every_chunk_in_exactly_one_item(kind, first_limit, limit):
     c1 = (items[:, 1] & ~np.uint32(WHOLE)).astype(np.int64)
     whole = (items[:, 1] & np.uint32(WHOLE)) != 0
     total = int(off[-1])
-    # the items tile the chunk list in order
+    # within a launch the items come largest first (by power-of-two size class, list order within a class) ...
+    for li in range(len(lk)):
+        a, b = int(first[li]), int(first[li + 1])
+        cls = np.floor(np.log2(np.maximum(c1[a:b] - c0[a:b], 1))).astype(np.int64)
+        assert (np.diff(cls) <= 0).all(), "a launch hands out its largest items first"
+        for k in np.unique(cls):
+            assert (np.diff(c0[a:b][cls == k]) > 0).all(), "list order within a size class"
+        o = a + np.argsort(c0[a:b], kind="stable")
+        c0[a:b], c1[a:b], whole[a:b] = c0[o], c1[o], whole[o]
+    # ... and, put back into list order, they tile the chunk list
     if total == 0:
         assert len(items) == 0
     else:
@@ -87,7 +96,8 @@ def test_small_neighbours_share_an_item_and_big_ones_do_not():
     got = [(int(a), int(b & 0x7FFFFFFF), bool(b & WHOLE)) for a, b in items]
     # 3 + 5 + 7 = 15 chunks share the first item; 60 more would make 75 > 64: its own item, which 2 more (62) may join;
     # the 2000-chunk bucket is cut in two pieces, not flagged; the two single chunks behind it share the last item
-    assert got == [(0, 15, True), (15, 77, True), (77, 1101, False), (1101, 2077, False), (2077, 2079, True)]
+    # (handed out largest first: 1024 and 976 chunks, then 62, 15, 2)
+    assert got == [(77, 1101, False), (1101, 2077, False), (15, 77, True), (0, 15, True), (2077, 2079, True)]
     assert len(lk) == 1 and int(lk[0]) == int(kp[-1])
 
 
