@@ -973,8 +973,7 @@ static int sk_count_all(sdt_ctx *c)
 		return fail(SDT_ESTATE, "count stage: work item table overflow");
 	first_item.resize(nlaunches + 1);
 	launch_kmers.resize(nlaunches);
-	if (nci)
-		SK_CHK(hipMemcpyAsync(k.citems, k.h_citems, (size_t)nci * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+	std::vector<uint32_t> sort_tmp;
 	auto guess_of = [&](uint64_t kmers) -> uint64_t {
 		uint64_t bound = kmers;
 		if (c->kmers_known) {
@@ -1019,6 +1018,12 @@ static int sk_count_all(sdt_ctx *c)
 			m++;
 		}
 		const uint32_t i1 = first_item[m + 1];
+		// (largest first over everything this launch hands out -- the plan did it per planned launch; the sort is stable, so the
+		// concatenation of sorted runs comes out as one)
+		if (m > l)
+			sk_plan_largest_first((uint32_t *)k.h_citems, i0, i1, sort_tmp);
+		if (rc == SDT_OK)
+			SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
 		if (rc == SDT_OK)
 			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
 		if (rc == SDT_OK) {                              // (only what was launched counts)
