@@ -150,9 +150,16 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	HIPCHK(hipSetDevice(v0.device));
 	struct timespec ts0_; clock_gettime(CLOCK_MONOTONIC, &ts0_);
 	const double t_call = ts0_.tv_sec * 1e3 + ts0_.tv_nsec * 1e-6;
+	const bool timing = getenv("SDT_TIMING") != nullptr;
+	auto tick = [&](const char *what) {              // (SDT_TIMING: where the call's time goes, on stderr)
+		if (!timing) return;
+		struct timespec t_;
+		clock_gettime(CLOCK_MONOTONIC, &t_);
+		fprintf(stderr, "[device]       %s at %.1f ms\n", what, t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call);
+	};
 	int rc = sdti::release_pass1(c);
 	if (rc != SDT_OK) return rc;
-	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       pass 1 released at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
+	tick("pass 1 released");
 	const GraphView v = sdti::graph_view(c);
 	const uint64_t n = v.h_stats->distinct;
 	*n_out = n;
@@ -175,12 +182,12 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	GCHK(hipGetLastError());
 	rc = sdti::sync_stats(c);
 	if (rc != SDT_OK) return fail(SDT_ESTATE, "layout: %llu nodes without a usable first-occurrence ordinal", (unsigned long long)v.h_stats->probe_fail);
-	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       sort keys made at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
+	tick("sort keys made");
 	unsigned end_bit = 56;
 	for (int q = p - 1; q > 0; q >>= 1) end_bit++;
 	rc = sort_pairs<uint64_t>(v, k0, k1, v0s, v1s, n, end_bit);
 	if (rc != SDT_OK) return rc;
-	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       sorted at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
+	tick("sorted");
 	hipLaunchKernelGGL(k_layout_set_starts, dim3((p + 1 + 63) / 64), dim3(64), 0, v.stream, k1, n, (uint32_t)p, d_ss);
 	GCHK(hipGetLastError());
 	GCHK(hipMemcpyAsync(set_start, d_ss, (size_t)(p + 1) * 8, hipMemcpyDeviceToHost, v.stream));
@@ -188,7 +195,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	LAUNCH_NW(v, k_layout_gather_keys, sdti::scan_grid(v.cu_count, m), v1s, n, d_keys);
 	GCHK(hipGetLastError());
 	GCHK(hipStreamSynchronize(v.stream));
-	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       keys gathered at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
+	tick("keys gathered");
 	(void)hipFree(S.release(k1));                             // (the sorted sort keys are not needed any more)
 	if (v.nw != 1) (void)hipFree(S.release(k0));
 	(void)hipFree(S.release(v0s));
@@ -223,20 +230,18 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	int sbits = 1;
 	while ((1ULL << sbits) < max_size) sbits++;
 	if (idbits + sbits + RP_DEPTH_BITS > 64) return fail(SDT_EINVAL, "layout on the device: %d id bits + %d slot bits do not fit the table word", idbits, sbits);
-	if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       schedule made at %.1f ms\n", t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); }
+	tick("schedule made");
 	// ---- buffers
 	unsigned long long *tab[2], *t_time[2], *d_pre;
 	uint32_t *d_home, *d_occ, *d_rank;
 	RpSet *d_sets;
 	unsigned int *d_flags;
-	auto tick = [&](const char *what) { if (getenv("SDT_TIMING")) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); fprintf(stderr, "[device]       %s at %.1f ms\n", what, t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call); } };
-	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); tick("tab0"); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8)); tick("tab1");
+	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
 	uint32_t *d_home_slot;
-	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); tick("time0"); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); tick("time1"); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4)); tick("home_slot");     // per OLD slot of a growth
+	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));     // per OLD slot of a growth
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
-	tick("small ones");
 	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
-	tick("memset queued");
+	tick("buffers made");
 	std::vector<unsigned long long> pre(p + 1);
 	auto upload = [&](void) -> int {
 		GCHK(hipStreamSynchronize(v.stream));                  // (kernels in flight read the old copies; the host vectors change right after)
@@ -248,7 +253,6 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	unsigned int h_flags = 0;
 	int cur = 0, total_rounds = 0;
 	auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-	const bool timing = getenv("SDT_TIMING") != nullptr;
 	const double t_start = now_ms();
 	double t_rehash = 0, t_put = 0, t_strip = 0;
 	if (timing) fprintf(stderr, "[device]     layout: release + sort + gather + schedule + buffers %.1f ms\n", t_start - t_call);
