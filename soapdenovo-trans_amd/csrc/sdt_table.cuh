@@ -379,9 +379,10 @@ template <int NW, bool FIRST> __device__ inline EntSnap<NW, FIRST> ent_load(cons
 		sn.won = sn.k[0] == KEY_EMPTY;
 		sn.k[1] = ld_relaxed(&e->key[NW - 1]);
 	} else if (SDT_WIDE_ENT_LOAD) {
-		// the whole entry in 16-byte agent-scope loads: every load is a request of its own to the memory side (agent-scope loads do
-		// not stop in this XCD's L2), so key + val of a 16-byte entry as two 8-byte loads fetched its line twice (k_sk_count's
-		// flush: 137 B fetched per merge, profiles/r3; 174 instead of 186 ms per step with the one load, profiles/r4)
+		// the whole entry in 16-byte agent-scope loads: every agent-scope load is a request of its own on the way to the memory
+		// side (it does not stop in this XCD's L2), also when two of them ask for the same line.  The BYTES fetched did not change
+		// (FETCH_SIZE of k_sk_count: 287 GB per step of the 200 M-read workload with two 8-byte loads per entry and with one 16-byte
+		// load, profiles/r3 and r4), the time did: 186 -> 174 ms per step -- the flush is bound by requests as much as by bytes
 		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 		if constexpr (NW == 1) {
 			u32x4 a;
