@@ -742,7 +742,6 @@ int main(int argc, char **argv)
 			int on_device = 0;
 			uint64_t *check_keys = NULL;
 			if (!getenv("SDT_HOST_REPLAY")) {
-				phase("(buffers for the layout)");
 				const int rcl = sdt_gpu_layout_on_device(gpu, threads, nwv, graph_init_kmerset_size != 0, set_start, &n);
 				if (rcl == SDT_OK) on_device = 1;
 				else if (rcl != SDT_EINVAL) { fprintf(stderr, "sdt_gpu_layout_on_device: %s\n", sdt_gpu_last_error()); return 1; }
