@@ -16,6 +16,7 @@
 #include <mutex>
 #include <vector>
 #include "sdt_internal.hpp"
+#include "sdt_arena.h"
 #undef hipMalloc
 #undef hipFree
 #undef hipHostMalloc
@@ -34,67 +35,18 @@ void mem_report(const char *what, double gib, double ms, const char *file, int l
 constexpr size_t ARENA_MIN = 1u << 20;       // smaller blocks go straight to the runtime (its own sub-allocator serves them)
 constexpr size_t ARENA_GRAIN = 1u << 16;
 
-struct Range { size_t bytes; int slab; };
-struct Slab { char *base; size_t bytes; int device; size_t used; };
-
-struct Arena {
+struct Arena : sdt::ArenaBook {
 	std::mutex mu;
-	std::vector<Slab> slabs;
-	std::map<char *, Range> free_;           // free ranges by address (never spanning two slabs)
-	std::map<void *, Range> live;            // blocks handed out
-	size_t free_bytes = 0;
 	bool off() { static const bool o = getenv("SDT_NO_ARENA") != nullptr; return o; }
-
-	void *take(size_t bytes, int device)     // best fit among the free ranges of this device
-	{
-		auto best = free_.end();
-		for (auto it = free_.begin(); it != free_.end(); ++it)
-			if (it->second.bytes >= bytes && slabs[it->second.slab].device == device && (best == free_.end() || it->second.bytes < best->second.bytes))
-				best = it;
-		if (best == free_.end()) return nullptr;
-		char *p = best->first;
-		const Range r = best->second;
-		free_.erase(best);
-		if (r.bytes > bytes) free_[p + bytes] = Range{r.bytes - bytes, r.slab};
-		free_bytes -= bytes;
-		slabs[r.slab].used += bytes;
-		live[p] = Range{bytes, r.slab};
-		return p;
-	}
-	void give(char *p, Range r)
-	{
-		slabs[r.slab].used -= r.bytes;
-		free_bytes += r.bytes;
-		auto nx = free_.lower_bound(p);
-		if (nx != free_.end() && nx->first == p + r.bytes && nx->second.slab == r.slab) {
-			r.bytes += nx->second.bytes;
-			nx = free_.erase(nx);
-		}
-		if (nx != free_.begin()) {
-			auto pv = std::prev(nx);
-			if (pv->first + pv->second.bytes == p && pv->second.slab == r.slab) {
-				pv->second.bytes += r.bytes;
-				return;
-			}
-		}
-		free_[p] = r;
-	}
 	// slabs nobody uses go back to the driver (all devices); returns the bytes released
-	size_t trim()
+	size_t trim_to_driver()
 	{
-		size_t out = 0;
 		int cur = 0;
 		(void)hipGetDevice(&cur);
-		for (size_t i = 0; i < slabs.size(); i++) {
-			Slab &s = slabs[i];
-			if (!s.base || s.used) continue;
-			free_.erase(s.base);                 // (a slab without live blocks is one free range)
-			free_bytes -= s.bytes;
-			(void)hipSetDevice(s.device);
-			(void)hipFree(s.base);
-			out += s.bytes;
-			s.base = nullptr; s.bytes = 0;
-		}
+		const size_t out = trim([](char *base, int device) {
+			(void)hipSetDevice(device);
+			(void)hipFree(base);
+		});
 		(void)hipSetDevice(cur);
 		return out;
 	}
@@ -122,14 +74,13 @@ hipError_t sdti::dmalloc(void **p, size_t bytes, const char *file, int line)
 	const double t0 = mem_now();
 	void *q = nullptr;
 	e = hipMalloc(&q, want);
-	if (e == hipErrorOutOfMemory && A.trim()) {
+	if (e == hipErrorOutOfMemory && A.trim_to_driver()) {
 		(void)hipGetLastError();
 		e = hipMalloc(&q, want);
 	}
 	mem_report("hipMalloc", (double)want / (1 << 30), mem_now() - t0, file, line);
 	if (e != hipSuccess) { *p = nullptr; return e; }
-	A.slabs.push_back(Slab{(char *)q, want, device, want});
-	A.live[q] = Range{want, (int)A.slabs.size() - 1};
+	A.adopt(q, want, device);
 	*p = q;
 	return hipSuccess;
 }
@@ -140,14 +91,11 @@ hipError_t sdti::dfree(void *p, const char *file, int line)
 	Arena &A = arena();
 	{
 		std::lock_guard<std::mutex> lock(A.mu);
-		auto it = A.live.find(p);
-		if (it != A.live.end()) {
+		if (A.live.count(p)) {
 			// hipFree waits for the device before it lets go of a block; the callers rely on that (kernels of another stream may
 			// still read what is freed here)
 			const hipError_t e = hipDeviceSynchronize();
-			const Range r = it->second;
-			A.live.erase(it);
-			A.give((char *)p, r);
+			(void)A.give(p);
 			return e;
 		}
 	}
@@ -179,5 +127,5 @@ size_t sdti::mem_trim(void)
 {
 	Arena &A = arena();
 	std::lock_guard<std::mutex> lock(A.mu);
-	return A.trim();
+	return A.trim_to_driver();
 }
