@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 5
+#define SDT_ABI_VERSION 6
 
 enum {
 	SDT_OK       = 0,
@@ -310,6 +310,25 @@ int sdt_gpu_update_nodes_by_index(sdt_ctx *ctx, const uint64_t *node, const uint
 int sdt_gpu_tip_walks_labelled(sdt_ctx *ctx, int thin, int cut_len, uint64_t *n_records);
 int sdt_gpu_minor_out_labelled(sdt_ctx *ctx, double threshold, uint64_t *n_junctions, uint64_t *n_records);
 int sdt_gpu_fetch_records(sdt_ctx *ctx, uint64_t *dst, uint64_t nwords);
+/*   minor_out_commit: removeMinorOut's COMMIT (cutTipPreGraph.c:591-1010: the ratio test on the live links, `deleted`, the
+ *                   neighbours' links cleared and their `linear` re-derived) on the records minor_out_labelled left on the device,
+ *                   one lane per component, the visits of a component in the reference's order; then thread_mark's re-marking
+ *                   over the nodes it wrote (:911-967).  *off = "kmers off", *linear = nodes newly marked linear, *n_written =
+ *                   nodes whose links or flags changed -- fetch_written copies them out as (index, l_links, r_links | linear << 24 |
+ *                   deleted << 25), the form update_nodes_by_index takes.  Components of more than max_component visits (*largest
+ *                   = the largest there is) are left alone: one lane is no match for a host thread on a long chain of dependent
+ *                   accesses.  fetch_skipped hands their records over (*n_skipped_records of 14 words: first their *n_skipped junction
+ *                   records in order, then the records of the neighbours they may cut); the caller commits them (they touch no node
+ *                   the device wrote) and sends what it wrote with update_nodes_by_index. */
+int sdt_gpu_minor_out_commit(sdt_ctx *ctx, double threshold, uint64_t max_component, uint64_t *largest, uint64_t *off, uint64_t *linear, uint64_t *n_written,
+                             uint64_t *n_skipped, uint64_t *n_skipped_records);
+int sdt_gpu_fetch_skipped(sdt_ctx *ctx, uint64_t *dst, uint64_t n_records);
+/*   minor_out_commit in two halves, so that the caller can commit the long components while the device walks the short ones:
+ *                   _begin finds the components, gathers the records of the long ones (fetch_skipped may be called right after it)
+ *                   and LAUNCHES the visits; _finish waits for them, re-marks and lists the written nodes (fetch_written). */
+int sdt_gpu_minor_out_commit_begin(sdt_ctx *ctx, double threshold, uint64_t max_component, uint64_t *largest, uint64_t *n_skipped, uint64_t *n_skipped_records);
+int sdt_gpu_minor_out_commit_finish(sdt_ctx *ctx, uint64_t *off, uint64_t *linear, uint64_t *n_written);
+int sdt_gpu_fetch_written(sdt_ctx *ctx, uint64_t *node, uint32_t *l_links, uint32_t *r_flags, uint64_t n);
 /* kmer2edges (node2edge.c:46-561) on the device mirror, after sdt_gpu_layout_apply: every chain of linear nodes between two
  * nodes that are neither linear nor deleted is one edge; it belongs to the first of its two (node, port) ends in visiting order
  * (ports: right links 0..3 on the stored strand, then left links 0..3 on the other), ids are handed out in that order (an edge

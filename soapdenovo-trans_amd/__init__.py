@@ -74,6 +74,11 @@ _ABI = [
     ("sdt_gpu_tip_walks_labelled", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_minor_out_labelled", _c.c_int, [_c.c_void_p, _c.c_double, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_fetch_records", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_minor_out_commit", _c.c_int, [_c.c_void_p, _c.c_double, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    ("sdt_gpu_fetch_skipped", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
+    ("sdt_gpu_minor_out_commit_begin", _c.c_int, [_c.c_void_p, _c.c_double, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    ("sdt_gpu_minor_out_commit_finish", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    ("sdt_gpu_fetch_written", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_build_edges", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_fetch_edge_bases", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64]),
     ("sdt_gpu_index_contigs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64]),
@@ -462,6 +467,25 @@ class PregraphGPU:
         nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
         self._check(self.lib.sdt_gpu_minor_out_labelled(self._ctx, ctypes.c_double(threshold), ctypes.byref(nj), ctypes.byref(nr)))
         return self._fetch(nr.value, 14), nj.value
+
+    def minor_out_commit(self, threshold: float, max_component: int = 1 << 62):
+        """removeMinorOut's commit on the device: labelled dry run + commit.  -> dict(records, n_junctions, largest, off, linear,
+        node, l_links, r_flags, skipped, skipped_neighbours): the records of the dry run, the nodes the commit wrote, the junction
+        records of the components it left to the caller and the records of the neighbours those may cut"""
+        nj, nr = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.sdt_gpu_minor_out_labelled(self._ctx, ctypes.c_double(threshold), ctypes.byref(nj), ctypes.byref(nr)))
+        big, off, lin, nw, nsk, nskr = (ctypes.c_uint64() for _ in range(6))
+        self._check(self.lib.sdt_gpu_minor_out_commit(self._ctx, ctypes.c_double(threshold), max_component, ctypes.byref(big), ctypes.byref(off),
+                                                      ctypes.byref(lin), ctypes.byref(nw), ctypes.byref(nsk), ctypes.byref(nskr)))
+        node = np.zeros(max(nw.value, 1), dtype=np.uint64)
+        l = np.zeros(max(nw.value, 1), dtype=np.uint32)
+        r = np.zeros(max(nw.value, 1), dtype=np.uint32)
+        self._check(self.lib.sdt_gpu_fetch_written(self._ctx, _ptr(node), _ptr(l), _ptr(r), nw.value))
+        sk = np.zeros((max(nskr.value, 1), 14), dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_fetch_skipped(self._ctx, _ptr(sk), nskr.value))
+        rec = self._fetch(nr.value, 14)
+        return dict(records=rec, n_junctions=nj.value, largest=big.value, off=off.value, linear=lin.value,
+                    node=node[:nw.value], l_links=l[:nw.value], r_flags=r[:nw.value], skipped=sk[:nsk.value], skipped_neighbours=sk[nsk.value:nskr.value])
 
     def build_edges(self):
         """-> (records uint64[n_edges, 4 + 2 nw], bases bytes, num_ed): see sdt_gpu_build_edges"""

@@ -605,12 +605,79 @@ static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t 
 	*off += C.off;
 }
 
+typedef struct { graph_t *g; const uint64_t *node; const uint32_t *l, *r; } aw_ctx;
+
+static void apply_written_part(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	aw_ctx *A = (aw_ctx *)vc;
+	for (uint64_t k = lo; k < hi; k++) {
+		if (k + 16 < hi) __builtin_prefetch(&A->g->nodes[A->node[k + 16]], 1);
+		gnode_t *n = &A->g->nodes[A->node[k]];
+		n->l_links = A->l[k] & 0xFFFFFFu;
+		n->r_links = A->r[k] & 0xFFFFFFu;
+		n->linear = (A->r[k] >> 24) & 1u;
+		n->deleted = (A->r[k] >> 25) & 1u;
+	}
+}
+
+void graph_apply_written(graph_t *g, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n)
+{
+	aw_ctx A = {g, node, l_links, r_flags};
+	par_for(0, n, 1 << 14, apply_written_part, &A);
+}
+
 uint64_t graph_remove_minor_out(graph_t *g, int dd)
 {
 	const double threshold = (double)dd / 100;
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
 	double t_sub = cut_now_ms();
+	if (g->dev_minor_out_commit_begin && !getenv("SDT_HOST_COMMIT")) {
+		/* dry run, components, commit and re-marking on the device mirror; the long components here, at the same time */
+		uint64_t lin = 0, *sk = NULL, nsk = 0, nskr = 0;
+		if (g->dev_minor_out_commit_begin(g, threshold, &sk, &nsk, &nskr) != 0) {
+			printf("the device commit failed. Now exit to system...\n");          /* no silent host fallback */
+			exit(1);
+		}
+		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		g->dn = 0;
+		SUBPHASE("device dry run + components");
+		if (nsk) {
+			/* the components the device leaves alone (one lane is no match for a thread on thousands of dependent visits): the
+			 * labelled commit on their records (junctions first, then the neighbours they may cut).  What this writes is on the
+			 * dirty list: the mirror hears about it before the next dry run */
+			if (nskr > 0xFFFFFFF0ULL) { printf("too many junction records\n"); exit(1); }
+			g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
+			g->nb_pool = (uint64_t *)malloc((nskr + 1) * 8 * sizeof(uint64_t));
+			g->nb_cnt = (uint32_t *)malloc((nskr + 1) * 8 * sizeof(uint32_t));
+			void *sa[2] = {g, sk};
+			par_for(0, nskr, 4096, mo_scatter_records, sa);
+			commit_minor_out_labelled(g, sk, nsk, threshold, &off);
+			graph_free_later(g->nb_slot, g->nb_pool, sk, g->nb_cnt);
+			g->nb_slot = NULL;
+			g->nb_pool = NULL;
+			g->nb_cnt = NULL;
+			ml_ctx M;
+			memset(&M, 0, sizeof M);
+			M.g = g;
+			par_for(0, g->dn, 1 << 12, mark_linear_dirty, &M);
+			for (int t = 0; t < 64; t++) lin += M.n[t];
+			SUBPHASE("long components on the host");
+		}
+		uint64_t off_dev = 0, lin_dev = 0;
+		if (g->dev_minor_out_commit_finish(g, &off_dev, &lin_dev) != 0) {
+			printf("the device commit failed. Now exit to system...\n");
+			exit(1);
+		}
+		off += off_dev;
+		lin += lin_dev;
+		SUBPHASE("device commit finished + applied");
+		printf("%llu kmers off\n", (unsigned long long)off);
+		printf("%d thread created for cutTipPreGraph\n", g->p);
+		printf("%llu linear nodes\n", (unsigned long long)lin);
+		return off;
+	}
 	if (g->dev_minor_out) {
 		/* junction dry run + neighbour look-ups + components answered by the device mirror of the graph (sdt_gpu_minor_out_dry).
 		 * Only the junctions the dry run flagged are visited: links only disappear during the pass, so on any junction the live

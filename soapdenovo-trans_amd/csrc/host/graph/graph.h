@@ -63,6 +63,15 @@ typedef struct graph_s {
 	 * counts two per word, component label);
 	 * the junction records [0, n_junctions) sorted by (label, node index), then the neighbours to cut in any order */
 	int (*dev_minor_out)(struct graph_s *g, double threshold, uint64_t **records, uint64_t *n_junctions, uint64_t *n_records);
+	/* removeMinorOut's commit on the device as well (sdt_gpu_minor_out_commit_begin / _finish), in two hooks so that the caller's
+	 * threads and the device work side by side.  _begin brings the mirror up to date, runs the dry run, starts the commit of the
+	 * short components on the device and returns -- malloc'ed, MO_RW words each -- the records of the components the device leaves
+	 * alone (too long for one lane): their *n_skipped junction records in order, then, up to *n_skipped_records, the records of the
+	 * neighbours they may cut; the caller commits those (they share no node with the others).  _finish waits for the device,
+	 * applies the nodes it wrote to nodes[] (graph_apply_written) and returns *off = its kmers off, *linear = the nodes it newly
+	 * marked linear.  0 = ok */
+	int (*dev_minor_out_commit_begin)(struct graph_s *g, double threshold, uint64_t **skipped, uint64_t *n_skipped, uint64_t *n_skipped_records);
+	int (*dev_minor_out_commit_finish)(struct graph_s *g, uint64_t *off, uint64_t *linear);
 	/* the whole of kmer2edges from the device (sdt_gpu_build_edges): malloc'ed edge records in id order -- 4 + 2 * *key_words
 	 * words each: length | bal_edge << 32, cvg, id, offset into *bases, first and last oriented k-mer (most significant word
 	 * first) -- and the edges' bases as letters.  Returns 0, or 2 when a chain does not lead back to the port it was entered
@@ -126,6 +135,8 @@ int arcs_write_arrays(const char *prefix, const uint32_t *from, const uint32_t *
 /* CPU stand-ins for the three device hooks above, made from the host's own dry runs (sdt-graphcheck with
  * SDT_GRAPHCHECK_EMULATE=1, the CPU tests): the commits that sdt-pregraph runs on the device's records run on these */
 void graph_emulate_device(graph_t *g);
+/* links and flags of n nodes as the device sends them back (l_links; r_links | linear << 24 | deleted << 25): into nodes[], all threads */
+void graph_apply_written(graph_t *g, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);
 
 /* output_pregraph.c:47-81 */
 uint64_t graph_write_vertex(graph_t *g, const char *prefix);

@@ -417,6 +417,51 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 	return 0;
 }
 
+/* removeMinorOut's commit on the device, the long components on the host's threads at the same time (graph.h) */
+static int dev_minor_out_commit_begin_hook(graph_t *g, double threshold, uint64_t **skipped, uint64_t *n_skipped, uint64_t *n_skipped_records)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	if (dev_mirror_sync(g) != 0) return 1;
+	const double t0 = now_ms();
+	uint64_t nj = 0, nr = 0, largest = 0, nsk = 0, nskr = 0;
+	if (sdt_gpu_minor_out_labelled(D->gpu, threshold, &nj, &nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_labelled: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t1 = now_ms();
+	/* one lane walks a component at about a microsecond per dependent access (~100 us per visit); a host thread takes ~150 ns */
+	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 2048;
+	if (sdt_gpu_minor_out_commit_begin(D->gpu, threshold, max_comp, &largest, &nsk, &nskr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_commit_begin: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t2 = now_ms();
+	uint64_t *sk = (uint64_t *)malloc((nskr + 1) * MO_RW * sizeof(uint64_t));
+	if (!sk) { fprintf(stderr, "out of memory for %llu records\n", (unsigned long long)nskr); return 1; }
+	if (sdt_gpu_fetch_skipped(D->gpu, sk, nskr) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_skipped: %s\n", sdt_gpu_last_error()); return 1; }
+	if (nsk) *skipped = sk; else { free(sk); *skipped = NULL; }
+	*n_skipped = nsk;
+	*n_skipped_records = nskr;
+	if (getenv("SDT_TIMING") && !g_quiet)
+		fprintf(stderr, "[device]   junction dry run + components %.1f ms (%llu visits, largest component %llu), components + long ones gathered %.1f ms, %llu records of long components fetched in %.1f ms\n",
+		        t1 - t0, (unsigned long long)nj, (unsigned long long)largest, t2 - t1, (unsigned long long)nskr, now_ms() - t2);
+	return 0;
+}
+
+static int dev_minor_out_commit_finish_hook(graph_t *g, uint64_t *off, uint64_t *linear)
+{
+	dev_state *D = (dev_state *)g->dev_user;
+	const double t0 = now_ms();
+	uint64_t nw = 0;
+	if (sdt_gpu_minor_out_commit_finish(D->gpu, off, linear, &nw) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_commit_finish: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t1 = now_ms();
+	uint64_t *node = (uint64_t *)malloc((nw + 1) * sizeof(uint64_t));
+	uint32_t *l = (uint32_t *)malloc((nw + 1) * sizeof(uint32_t)), *r = (uint32_t *)malloc((nw + 1) * sizeof(uint32_t));
+	if (!node || !l || !r) { fprintf(stderr, "out of memory for %llu written nodes\n", (unsigned long long)nw); return 1; }
+	if (sdt_gpu_fetch_written(D->gpu, node, l, r, nw) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_written: %s\n", sdt_gpu_last_error()); return 1; }
+	const double t2 = now_ms();
+	graph_apply_written(g, node, l, r, nw);
+	free(node); free(l); free(r);
+	if (getenv("SDT_TIMING") && !g_quiet)
+		fprintf(stderr, "[device]   waited %.1f ms for the device's visits + marking + list, %llu written nodes fetched in %.1f ms, applied in %.1f ms\n",
+		        t1 - t0, (unsigned long long)nw, t2 - t1, now_ms() - t2);
+	return 0;
+}
+
 static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records, uint64_t *nr)
 {
 	dev_state *D = (dev_state *)g->dev_user;
@@ -799,6 +844,7 @@ int main(int argc, char **argv)
 			G->dirty = (uint8_t *)calloc(G->n + 1, 1);
 			G->dev_walks = dev_walks_hook;
 			G->dev_minor_out = dev_minor_out_hook;
+			if (Dp->by_index) { G->dev_minor_out_commit_begin = dev_minor_out_commit_begin_hook; G->dev_minor_out_commit_finish = dev_minor_out_commit_finish_hook; }
 			G->dev_edge_ports = dev_edge_ports_hook;
 			if (Dp->by_index && !getenv("SDT_HOST_EDGES")) G->dev_build_edges = dev_build_edges_hook;
 			G->dev_user = Dp;

@@ -27,6 +27,17 @@ struct sdti::GraphExt {
 	uint64_t n_nodes = 0;
 	uint64_t *d_result = nullptr;     // records of the last labelled dry run, waiting for sdt_gpu_fetch_records
 	uint64_t result_words = 0;
+	uint64_t result_labelled = 0;     // the first so many of them are sorted by (component, node)
+	int result_stride = 0;
+	uint64_t *d_wnode = nullptr;      // nodes the last sdt_gpu_minor_out_commit wrote, waiting for sdt_gpu_fetch_written
+	uint32_t *d_wl = nullptr, *d_wr = nullptr;
+	uint64_t n_written = 0;
+	uint64_t *d_skipped = nullptr;    // records of the components that commit left to the host, waiting for sdt_gpu_fetch_skipped
+	uint64_t n_skipped = 0;
+	bool mo_pending = false;          // between sdt_gpu_minor_out_commit_begin and _finish: what the launched kernels work on
+	uint8_t *mo_dirty = nullptr;
+	unsigned long long *mo_cnt = nullptr;
+	uint32_t *mo_recidx = nullptr, *mo_cstart = nullptr;
 	unsigned char *d_seq = nullptr;   // bases of the edges of sdt_gpu_build_edges, waiting for sdt_gpu_fetch_edge_bases
 	uint64_t seq_bytes = 0;
 	uint64_t *d_pw = nullptr;         // path word of every node after sdt_gpu_build_edges (taken by sdt_gpu_load_paths)
@@ -39,6 +50,14 @@ void sdti::graph_ext_free(GraphExt *gx)
 	if (gx->d_sval) (void)hipFree(gx->d_sval);
 	if (gx->d_slot_of) (void)hipFree(gx->d_slot_of);
 	if (gx->d_result) (void)hipFree(gx->d_result);
+	if (gx->d_wnode) (void)hipFree(gx->d_wnode);
+	if (gx->d_wl) (void)hipFree(gx->d_wl);
+	if (gx->d_wr) (void)hipFree(gx->d_wr);
+	if (gx->d_skipped) (void)hipFree(gx->d_skipped);
+	if (gx->mo_dirty) (void)hipFree(gx->mo_dirty);
+	if (gx->mo_cnt) (void)hipFree(gx->mo_cnt);
+	if (gx->mo_recidx) (void)hipFree(gx->mo_recidx);
+	if (gx->mo_cstart) (void)hipFree(gx->mo_cstart);
 	if (gx->d_seq) (void)hipFree(gx->d_seq);
 	if (gx->d_pw) (void)hipFree(gx->d_pw);
 	delete gx;
@@ -556,12 +575,17 @@ static int label_sort_keep(sdt_ctx *c, const GraphView &v, uint32_t *parent, uin
 		hipLaunchKernelGGL(k_gather_records, dim3(sdti::scan_grid(v.cu_count, n_label * stride)), dim3(TPB), 0, v.stream, d_rec, p1, n_label, stride, d_out);
 		GCHK(hipGetLastError());
 	}
-	if (n > n_label)
+	if (n > n_label) {                                        // (the records behind the sorted ones keep their order; they get their label too)
+		hipLaunchKernelGGL(k_uf_label_only, dim3(sdti::scan_grid(v.cu_count, n - n_label)), dim3(TPB), 0, v.stream, parent, d_rec, n_label, n, stride, stride - 1);
+		GCHK(hipGetLastError());
 		GCHK(hipMemcpyAsync(d_out + n_label * stride, d_rec + n_label * stride, (n - n_label) * (size_t)stride * 8, hipMemcpyDeviceToDevice, v.stream));
+	}
 	GCHK(hipStreamSynchronize(v.stream));
 	(void)c;
 	gx->d_result = (uint64_t *)S.release(d_out);
 	gx->result_words = n * (uint64_t)stride;
+	gx->result_labelled = n_label;
+	gx->result_stride = stride;
 	return SDT_OK;
 }
 
@@ -654,6 +678,195 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	*n_junctions = h1;
 	*n_records = h2;
 	return SDT_OK;
+}
+
+// removeMinorOut's commit on the records sdt_gpu_minor_out_labelled left on the device (they stay there: sdt_gpu_fetch_records still
+// works afterwards).  One lane walks a component, at about a microsecond per dependent access (most are first touches of a node:
+// HBM latency); components of more than max_component visits are left alone -- their records wait for sdt_gpu_fetch_skipped, the
+// host's threads are the better place for them.  Two halves, so that the host can work on those while the device walks the rest:
+// _begin finds the components, gathers the records of the long ones and LAUNCHES the visits; _finish waits, re-marks and lists
+// the written nodes.
+static void mo_pending_free(sdti::GraphExt *gx)
+{
+	for (void **q : {(void **)&gx->mo_dirty, (void **)&gx->mo_cnt, (void **)&gx->mo_recidx, (void **)&gx->mo_cstart})
+		if (*q) { (void)hipFree(*q); *q = nullptr; }
+	gx->mo_pending = false;
+}
+
+int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_component, uint64_t *largest, uint64_t *n_skipped, uint64_t *n_skipped_records)
+{
+	if (!c || !largest || !n_skipped || !n_skipped_records) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->d_slot_of || !*v.d_idx || *v.idx_slots != v.slots || *v.idx_n != gx->n_nodes) return fail(SDT_ESTATE, "call sdt_gpu_layout_apply first");
+	if (!gx->d_result || gx->result_stride != 14) return fail(SDT_ESTATE, "call sdt_gpu_minor_out_labelled first (its records must still be on the device)");
+	const uint64_t nn = gx->n_nodes, nj = gx->result_labelled, nr = gx->result_words / 14;
+	if (nn >= 0xFFFFFFF0ULL || nr >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "commit on the device: 32-bit record and node indices");
+	HIPCHK(hipSetDevice(v.device));
+	*largest = *n_skipped = *n_skipped_records = 0;
+	if (gx->mo_pending) { (void)hipStreamSynchronize(v.stream); mo_pending_free(gx); }
+	if (gx->d_wnode) { (void)hipFree(gx->d_wnode); gx->d_wnode = nullptr; }
+	if (gx->d_wl) { (void)hipFree(gx->d_wl); gx->d_wl = nullptr; }
+	if (gx->d_wr) { (void)hipFree(gx->d_wr); gx->d_wr = nullptr; }
+	if (gx->d_skipped) { (void)hipFree(gx->d_skipped); gx->d_skipped = nullptr; }
+	gx->n_written = gx->n_skipped = 0;
+	Scratch S;
+	uint32_t *flag, *rank, *cstart, *recidx;
+	uint8_t *dirty;
+	unsigned long long *d_cnt, h_largest = 0;                    // d_cnt: off, errors, marked, written, largest
+	GCHK(S.alloc(&d_cnt, 5 * 8));
+	GCHK(hipMemsetAsync(d_cnt, 0, 5 * 8, v.stream));
+	GCHK(S.alloc(&recidx, (nn + 1) * 4)); GCHK(S.alloc(&dirty, nn + 1));
+	GCHK(hipMemsetAsync(dirty, 0, nn + 1, v.stream));
+	if (!nj) {                                                   // nothing to visit: _finish reports zeros
+		GCHK(S.alloc(&cstart, 8));
+		gx->mo_dirty = (uint8_t *)S.release(dirty); gx->mo_cnt = (unsigned long long *)S.release(d_cnt);
+		gx->mo_recidx = (uint32_t *)S.release(recidx); gx->mo_cstart = (uint32_t *)S.release(cstart);
+		gx->mo_pending = true;
+		return SDT_OK;
+	}
+	GCHK(S.alloc(&flag, (nj + 1) * 4)); GCHK(S.alloc(&rank, (nj + 1) * 4));
+	hipLaunchKernelGGL(k_mo_comp_flags, dim3(sdti::scan_grid(v.cu_count, nj + 1)), dim3(TPB), 0, v.stream, gx->d_result, nj, 14, flag);
+	GCHK(hipGetLastError());
+	int rc = exclusive_scan<uint32_t>(v, flag, rank, nj + 1);                   // rank[nj] = number of components
+	if (rc != SDT_OK) return rc;
+	uint32_t ncomp32 = 0;
+	GCHK(hipMemcpyAsync(&ncomp32, rank + nj, 4, hipMemcpyDeviceToHost, v.stream));
+	GCHK(hipStreamSynchronize(v.stream));
+	const uint64_t ncomp = ncomp32;
+	GCHK(S.alloc(&cstart, (ncomp + 1) * 4));
+	hipLaunchKernelGGL(k_mo_comp_starts, dim3(sdti::scan_grid(v.cu_count, nj)), dim3(TPB), 0, v.stream, flag, rank, nj, cstart);
+	GCHK(hipGetLastError());
+	const uint32_t nj32 = (uint32_t)nj;
+	GCHK(hipMemcpyAsync(cstart + ncomp, &nj32, 4, hipMemcpyHostToDevice, v.stream));
+	hipLaunchKernelGGL(k_mo_comp_largest, dim3(sdti::scan_grid(v.cu_count, ncomp)), dim3(TPB), 0, v.stream, cstart, ncomp, d_cnt + 4);
+	GCHK(hipGetLastError());
+	GCHK(hipMemcpyAsync(&h_largest, d_cnt + 4, 8, hipMemcpyDeviceToHost, v.stream));
+	GCHK(hipMemsetAsync(recidx, 0, (nn + 1) * 4, v.stream));
+	hipLaunchKernelGGL(k_mo_recidx, dim3(sdti::scan_grid(v.cu_count, nr)), dim3(TPB), 0, v.stream, gx->d_result, nr, 14, recidx);
+	GCHK(hipGetLastError());
+	GCHK(hipStreamSynchronize(v.stream));
+	*largest = h_largest;
+	if (h_largest > max_component) {
+		// the records of the components that are left alone: their junction records in order, then the records of the neighbours
+		// they may cut (the host's commit finds the neighbours of a cut node there instead of looking them up)
+		uint32_t *sel, *pos, *size_of, *sel2, *pos2, nsk = 0, nsk2 = 0;
+		GCHK(S.alloc(&sel, (nj + 1) * 4)); GCHK(S.alloc(&pos, (nj + 1) * 4));
+		hipLaunchKernelGGL(k_mo_skipped_sel, dim3(sdti::scan_grid(v.cu_count, nj + 1)), dim3(TPB), 0, v.stream, flag, rank, cstart, nj, max_component, sel);
+		GCHK(hipGetLastError());
+		rc = exclusive_scan<uint32_t>(v, sel, pos, nj + 1);
+		if (rc != SDT_OK) return rc;
+		GCHK(hipMemcpyAsync(&nsk, pos + nj, 4, hipMemcpyDeviceToHost, v.stream));
+		const uint64_t nc = nr - nj;
+		GCHK(S.alloc(&size_of, (nn + 1) * 4)); GCHK(S.alloc(&sel2, (nc + 1) * 4)); GCHK(S.alloc(&pos2, (nc + 1) * 4));
+		GCHK(hipMemsetAsync(size_of, 0, (nn + 1) * 4, v.stream));
+		hipLaunchKernelGGL(k_mo_label_sizes, dim3(sdti::scan_grid(v.cu_count, ncomp)), dim3(TPB), 0, v.stream, gx->d_result, 14, cstart, ncomp, size_of);
+		GCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_mo_skipped_sel2, dim3(sdti::scan_grid(v.cu_count, nc + 1)), dim3(TPB), 0, v.stream, gx->d_result, 14, nj, nr, size_of, max_component, sel2);
+		GCHK(hipGetLastError());
+		rc = exclusive_scan<uint32_t>(v, sel2, pos2, nc + 1);
+		if (rc != SDT_OK) return rc;
+		GCHK(hipMemcpyAsync(&nsk2, pos2 + nc, 4, hipMemcpyDeviceToHost, v.stream));
+		GCHK(hipStreamSynchronize(v.stream));
+		uint64_t *sk;
+		GCHK(S.alloc(&sk, ((uint64_t)nsk + nsk2 + 1) * 14 * 8));
+		hipLaunchKernelGGL(k_mo_skipped_gather, dim3(sdti::scan_grid(v.cu_count, nj * 14)), dim3(TPB), 0, v.stream, gx->d_result, 14, sel, pos, nj, sk);
+		GCHK(hipGetLastError());
+		if (nc) hipLaunchKernelGGL(k_mo_skipped_gather, dim3(sdti::scan_grid(v.cu_count, nc * 14)), dim3(TPB), 0, v.stream, gx->d_result + nj * 14, 14, sel2, pos2, nc, sk + (uint64_t)nsk * 14);
+		GCHK(hipGetLastError());
+		GCHK(hipStreamSynchronize(v.stream));                // (sdt_gpu_fetch_skipped copies on the other stream)
+		gx->d_skipped = (uint64_t *)S.release(sk);
+		gx->n_skipped = (uint64_t)nsk + nsk2;
+		*n_skipped = nsk;
+		*n_skipped_records = (uint64_t)nsk + nsk2;
+	}
+	// the visits and the re-marking: launched, not waited for
+	{
+		const uint64_t blocks = (ncomp + TPB - 1) / TPB;
+		const int g = (int)(blocks < (uint64_t)v.cu_count * 32 ? (blocks ? blocks : 1) : (uint64_t)v.cu_count * 32);
+		LAUNCH_NW(v, k_mo_commit, g, gx->d_slot_of, v.K, threshold, gx->d_result, 14, cstart, ncomp, recidx, dirty, d_cnt, max_component);
+		GCHK(hipGetLastError());
+	}
+	LAUNCH_NW(v, k_mo_mark, sdti::scan_grid(v.cu_count, nn), gx->d_slot_of, nn, dirty, d_cnt);
+	GCHK(hipGetLastError());
+	gx->mo_dirty = (uint8_t *)S.release(dirty); gx->mo_cnt = (unsigned long long *)S.release(d_cnt);
+	gx->mo_recidx = (uint32_t *)S.release(recidx); gx->mo_cstart = (uint32_t *)S.release(cstart);
+	gx->mo_pending = true;
+	return SDT_OK;
+}
+
+int sdt_gpu_minor_out_commit_finish(sdt_ctx *c, uint64_t *off, uint64_t *linear, uint64_t *n_written)
+{
+	if (!c || !off || !linear || !n_written) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (!gx->mo_pending) return fail(SDT_ESTATE, "call sdt_gpu_minor_out_commit_begin first");
+	HIPCHK(hipSetDevice(v.device));
+	*off = *linear = *n_written = 0;
+	const uint64_t nn = gx->n_nodes;
+	unsigned long long h_cnt[5] = {0, 0, 0, 0, 0};
+	GCHK(hipMemcpyAsync(h_cnt, gx->mo_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, v.stream));
+	GCHK(hipStreamSynchronize(v.stream));
+	if (h_cnt[1]) { mo_pending_free(gx); return fail(SDT_ESTATE, "sdt_gpu_minor_out_commit: %llu cuts found no record of the node they cut", h_cnt[1]); }
+	const uint64_t nw = h_cnt[3];
+	Scratch S;
+	unsigned long long *d_cur;
+	GCHK(S.alloc(&d_cur, 8));
+	GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
+	uint64_t *wn; uint32_t *wl, *wr;
+	GCHK(S.alloc(&wn, (nw + 1) * 8)); GCHK(S.alloc(&wl, (nw + 1) * 4)); GCHK(S.alloc(&wr, (nw + 1) * 4));
+	if (nw) {
+		LAUNCH_NW(v, k_mo_emit, sdti::scan_grid(v.cu_count, nn), gx->d_slot_of, nn, gx->mo_dirty, d_cur, nw, wn, wl, wr);
+		GCHK(hipGetLastError());
+	}
+	GCHK(hipStreamSynchronize(v.stream));
+	mo_pending_free(gx);
+	gx->d_wnode = (uint64_t *)S.release(wn); gx->d_wl = (uint32_t *)S.release(wl); gx->d_wr = (uint32_t *)S.release(wr);
+	gx->n_written = nw;
+	*off = h_cnt[0];
+	*linear = h_cnt[2];
+	*n_written = nw;
+	return SDT_OK;
+}
+
+int sdt_gpu_minor_out_commit(sdt_ctx *c, double threshold, uint64_t max_component, uint64_t *largest, uint64_t *off, uint64_t *linear, uint64_t *n_written,
+                             uint64_t *n_skipped, uint64_t *n_skipped_records)
+{
+	if (!off || !linear || !n_written) return fail(SDT_EINVAL, "NULL argument");
+	const int rc = sdt_gpu_minor_out_commit_begin(c, threshold, max_component, largest, n_skipped, n_skipped_records);
+	return rc != SDT_OK ? rc : sdt_gpu_minor_out_commit_finish(c, off, linear, n_written);
+}
+
+int sdt_gpu_fetch_skipped(sdt_ctx *c, uint64_t *dst, uint64_t n_records)
+{
+	if (!c || (n_records && !dst)) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (n_records != gx->n_skipped) return fail(SDT_EINVAL, "the last commit left %llu records to the host, asked for %llu", (unsigned long long)gx->n_skipped, (unsigned long long)n_records);
+	HIPCHK(hipSetDevice(v.device));
+	int rc = SDT_OK;
+	if (n_records) rc = sdti::d2h_big(v.copy_stream, dst, gx->d_skipped, n_records * 14 * 8);
+	// (no hipFree here: freeing waits for the device, and the visits of _begin may be running -- _begin / the context let go of it)
+	return rc;
+}
+
+int sdt_gpu_fetch_written(sdt_ctx *c, uint64_t *node, uint32_t *l_links, uint32_t *r_flags, uint64_t n)
+{
+	if (!c || (n && (!node || !l_links || !r_flags))) return fail(SDT_EINVAL, "NULL argument");
+	const GraphView v = sdti::graph_view(c);
+	sdti::GraphExt *gx = ext_of(v);
+	if (n != gx->n_written) return fail(SDT_EINVAL, "the last commit wrote %llu nodes, asked for %llu", (unsigned long long)gx->n_written, (unsigned long long)n);
+	HIPCHK(hipSetDevice(v.device));
+	int rc = SDT_OK;
+	if (n) rc = sdti::d2h_big(v.copy_stream, node, gx->d_wnode, n * 8);
+	if (n && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, l_links, gx->d_wl, n * 4);
+	if (n && rc == SDT_OK) rc = sdti::d2h_big(v.copy_stream, r_flags, gx->d_wr, n * 4);
+	if (gx->d_wnode) (void)hipFree(gx->d_wnode);
+	if (gx->d_wl) (void)hipFree(gx->d_wl);
+	if (gx->d_wr) (void)hipFree(gx->d_wr);
+	gx->d_wnode = nullptr; gx->d_wl = gx->d_wr = nullptr;
+	gx->n_written = 0;
+	return rc;
 }
 
 // ---- kmer2edges on the device (node2edge.c:46-561) ----------------------------------------------------------------------

@@ -564,6 +564,235 @@ __global__ __launch_bounds__(TPB) void k_update_by_index(Table<NW> tbl, const ui
 
 
 // ===============================================================================================================
+// removeMinorOut's COMMIT on the device (cutTipPreGraph.c:591-1010; csrc/host/graph/cuttip.c visit_minor_out / prune_side /
+// isolate are the host's form).  The labelled dry run left, on the device: the junction records sorted by (component, node) --
+// node, its 8 neighbours as (index << 1 | orientation), their occurrence counts -- and the records of the neighbours a visit
+// may cut.  A visit reads and writes only nodes of its own component, so components commute; inside one the visits run in
+// record order = the reference's visiting order.  One lane per component.
+// ===============================================================================================================
+__global__ __launch_bounds__(TPB) void k_mo_comp_flags(const uint64_t *__restrict__ rec, uint64_t nj, int stride, uint32_t *__restrict__ flag)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r <= nj; r += (uint64_t)gridDim.x * TPB)
+		flag[r] = r < nj && (r == 0 || rec[r * stride + stride - 1] != rec[(r - 1) * stride + stride - 1]);
+}
+
+// cstart[c] = first record of component c (rank = exclusive scan of the flags; cstart[ncomp] = nj is written by the host side);
+// largest[0] = the largest component
+__global__ __launch_bounds__(TPB) void k_mo_comp_starts(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rank, uint64_t nj,
+                                                        uint32_t *__restrict__ cstart)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r < nj; r += (uint64_t)gridDim.x * TPB)
+		if (flag[r]) cstart[rank[r]] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(TPB) void k_mo_comp_largest(const uint32_t *__restrict__ cstart, uint64_t ncomp, unsigned long long *largest)
+{
+	unsigned long long m = 0;
+	for (uint64_t c = blockIdx.x * (uint64_t)TPB + threadIdx.x; c < ncomp; c += (uint64_t)gridDim.x * TPB) {
+		const unsigned long long sz = cstart[c + 1] - cstart[c];
+		if (sz > m) m = sz;
+	}
+	if (m) atomicMax(largest, m);
+}
+
+// recidx[node] = 1 + the record that lists the node's neighbours (junction records and the records of the neighbours to cut)
+__global__ __launch_bounds__(TPB) void k_mo_recidx(const uint64_t *__restrict__ rec, uint64_t nr, int stride, uint32_t *__restrict__ recidx)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r < nr; r += (uint64_t)gridDim.x * TPB)
+		recidx[rec[r * stride]] = (uint32_t)r + 1u;
+}
+
+// a lane re-reads what it (and only it, during this kernel) wrote: real loads and stores every time, but no cache-bypassing scope --
+// they may stop in the CU's L1 and the XCD's L2, which are coherent for one lane's own accesses (volatile accesses went to the
+// memory side: 25 us per visit, 1.4 s for the 56 288 visits of the largest component of the 200 M-read job)
+template <class T> __device__ inline T mo_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+template <class T> __device__ inline void mo_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
+template <int NW> __device__ inline uint32_t mo_first_base(const Entry<NW> *e, int K)
+{
+	const int bit = 2 * (K - 1), wi = NW - 1 - bit / 64;
+	return (uint32_t)(e->key[wi] >> (bit % 64)) & 3u;
+}
+
+// isolate(q) (cuttip.c): q is deleted, every neighbour forgets its link to q and has its `linear` re-derived
+template <int NW>
+__device__ inline void mo_isolate(const Table<NW> &tbl, const uint64_t *__restrict__ slot_of, int K, const uint64_t *__restrict__ rec, int stride,
+                                  const uint32_t *__restrict__ recidx, uint8_t *__restrict__ dirty, uint64_t q, uint32_t &errors)
+{
+	const uint64_t sq = slot_of[q];
+	Entry<NW> *eq = tbl.ent + sq;
+	const uint32_t ch_last = (uint32_t)eq->key[NW - 1] & 3u, ch_first = mo_first_base<NW>(eq, K);
+	mo_st(&tbl.aux[sq], mo_ld(&tbl.aux[sq]) | AUX_DELETED);
+	dirty[q] = 1;
+	const uint32_t rq = recidx[q];
+	if (!rq) { errors++; return; }
+	const uint64_t *Q = rec + (uint64_t)(rq - 1u) * stride;
+#pragma unroll 1
+	for (int side = 0; side < 2; side++)
+#pragma unroll 1
+		for (int b = 0; b < 4; b++) {
+			// (q's own links are read again every time: a neighbour of q can be q itself)
+			const uint64_t vq = mo_ld(&eq->val);
+			if (!(((side == 0 ? vq : vq >> 24) >> (6 * b)) & 63u)) continue;
+			const uint64_t nb = Q[1 + side * 4 + b];
+			if (nb == ~0ULL) { errors++; continue; }
+			const uint64_t x = nb >> 1, sx = slot_of[x];
+			const bool sm = (nb & 1u) != 0;
+			// unlink_next(x, last base of q, sm) for q's left neighbours, unlink_prev(y, first base of q, sm) for its right ones
+			int drop;                                    // field of val to clear: 0..3 left links, 4..7 right links
+			if (side == 0) drop = sm ? 4 + (int)ch_last : (int)(ch_last ^ 2u);
+			else drop = sm ? (int)ch_first : 4 + (int)(ch_first ^ 2u);
+			uint64_t vx = mo_ld(&tbl.ent[sx].val);
+			vx &= ~(63ULL << (6 * drop));
+			mo_st(&tbl.ent[sx].val, vx);
+			const bool lin = dev_degree(vx & 0xFFFFFFu) == 1 && dev_degree((vx >> 24) & 0xFFFFFFu) == 1;
+			const uint32_t ax = mo_ld(&tbl.aux[sx]);
+			mo_st(&tbl.aux[sx], lin ? (ax | AUX_LINEAR) : (ax & ~AUX_LINEAR));
+			dirty[x] = 1;
+		}
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_mo_commit(Table<NW> tbl, const uint64_t *__restrict__ slot_of, int K, double threshold,
+                                                   const uint64_t *__restrict__ rec, int stride, const uint32_t *__restrict__ cstart, uint64_t ncomp,
+                                                   const uint32_t *__restrict__ recidx, uint8_t *__restrict__ dirty, unsigned long long *counters,
+                                                   uint64_t max_component)
+{
+	unsigned long long off = 0;
+	uint32_t errors = 0;
+	for (uint64_t c = blockIdx.x * (uint64_t)TPB + threadIdx.x; c < ncomp; c += (uint64_t)gridDim.x * TPB) {
+		const uint32_t r1 = cstart[c + 1];
+		if ((uint64_t)(r1 - cstart[c]) > max_component) continue;      // (left to the host's threads: k_mo_skipped_*)
+#pragma unroll 1
+		for (uint32_t r = cstart[c]; r < r1; r++) {
+			const uint64_t *R = rec + (uint64_t)r * stride;
+			const uint64_t sn = slot_of[R[0]];
+			const uint64_t *pv = &tbl.ent[sn].val;
+			if (mo_ld(&tbl.aux[sn]) & (AUX_LINEAR | AUX_DELETED)) continue;
+			const uint64_t v0 = mo_ld(pv);
+			const uint32_t in = dev_degree(v0 & 0xFFFFFFu), out = dev_degree((v0 >> 24) & 0xFFFFFFu);      // both sampled before any cut (:616-617)
+			if (in <= 1 && out <= 1) continue;
+#pragma unroll 1
+			for (int side = 0; side < 2; side++) {
+				if ((side == 0 ? in : out) <= 1) continue;
+				int best = 0;
+				const uint64_t vs = mo_ld(pv);
+				for (int b = 0; b < 4; b++)
+					if (((side == 0 ? vs : vs >> 24) >> (6 * b)) & 63u) {
+						const uint64_t cw = R[9 + (side * 4 + b) / 2];
+						const int cnt = (int)(uint32_t)((side * 4 + b) & 1 ? cw >> 32 : cw);
+						if (cnt > best) best = cnt;
+					}
+				if (!best) continue;
+#pragma unroll 1
+				for (int b = 0; b < 4; b++) {
+					const uint64_t vl = mo_ld(pv);                 // live: an earlier cut may have removed the link
+					if (!(((side == 0 ? vl : vl >> 24) >> (6 * b)) & 63u)) continue;
+					const uint64_t cw = R[9 + (side * 4 + b) / 2];
+					const int cnt = (int)(uint32_t)((side * 4 + b) & 1 ? cw >> 32 : cw);
+					if (cnt && (double)cnt / best < threshold) {
+						off++;
+						const uint64_t nb = R[1 + side * 4 + b];
+						if (nb == ~0ULL) { errors++; continue; }
+						mo_isolate<NW>(tbl, slot_of, K, rec, stride, recidx, dirty, nb >> 1, errors);
+					}
+				}
+			}
+		}
+	}
+	if (off) atomicAdd(&counters[0], off);
+	if (errors) atomicAdd(&counters[1], (unsigned long long)errors);
+}
+
+// the junction records of the components k_mo_commit left alone, in order: sel[r] = 1 for them (rank = exclusive scan of the start
+// flags: the component of record r is rank[r] + flag[r] - 1), then gathered to the positions an exclusive scan of sel gives
+__global__ __launch_bounds__(TPB) void k_mo_skipped_sel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rank, const uint32_t *__restrict__ cstart,
+                                                        uint64_t nj, uint64_t max_component, uint32_t *__restrict__ sel)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r <= nj; r += (uint64_t)gridDim.x * TPB) {
+		uint32_t v = 0;
+		if (r < nj) {
+			const uint32_t c = rank[r] + flag[r] - 1u;
+			v = (uint64_t)(cstart[c + 1] - cstart[c]) > max_component;
+		}
+		sel[r] = v;
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_mo_skipped_gather(const uint64_t *__restrict__ rec, int stride, const uint32_t *__restrict__ sel,
+                                                           const uint32_t *__restrict__ pos, uint64_t nj, uint64_t *__restrict__ out)
+{
+	for (uint64_t w = blockIdx.x * (uint64_t)TPB + threadIdx.x; w < nj * (uint64_t)stride; w += (uint64_t)gridDim.x * TPB) {
+		const uint64_t r = w / (uint64_t)stride;
+		if (sel[r]) out[(uint64_t)pos[r] * stride + w % (uint64_t)stride] = rec[w];
+	}
+}
+
+// size_of[label] = visits of the component with that label
+__global__ __launch_bounds__(TPB) void k_mo_label_sizes(const uint64_t *__restrict__ rec, int stride, const uint32_t *__restrict__ cstart, uint64_t ncomp,
+                                                        uint32_t *__restrict__ size_of)
+{
+	for (uint64_t c = blockIdx.x * (uint64_t)TPB + threadIdx.x; c < ncomp; c += (uint64_t)gridDim.x * TPB)
+		size_of[rec[(uint64_t)cstart[c] * stride + stride - 1]] = cstart[c + 1] - cstart[c];
+}
+
+// the neighbour records [nj, nr) that belong to components left to the host
+__global__ __launch_bounds__(TPB) void k_mo_skipped_sel2(const uint64_t *__restrict__ rec, int stride, uint64_t nj, uint64_t nr, const uint32_t *__restrict__ size_of,
+                                                         uint64_t max_component, uint32_t *__restrict__ sel)
+{
+	for (uint64_t r = blockIdx.x * (uint64_t)TPB + threadIdx.x; r <= nr - nj; r += (uint64_t)gridDim.x * TPB)
+		sel[r] = r < nr - nj && (uint64_t)size_of[rec[(nj + r) * stride + stride - 1]] > max_component;
+}
+
+// mark_linear over the nodes the commit wrote (cuttip.c: mark_linear_dirty) + their number
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_mo_mark(Table<NW> tbl, const uint64_t *__restrict__ slot_of, uint64_t nn, const uint8_t *__restrict__ dirty,
+                                                 unsigned long long *counters)
+{
+	unsigned long long marked = 0, written = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < nn; i += (uint64_t)gridDim.x * TPB) {
+		if (!dirty[i]) continue;
+		written++;
+		const uint64_t s = slot_of[i];
+		const uint32_t a = tbl.aux[s];
+		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
+		const uint64_t v = tbl.ent[s].val;
+		if (dev_degree(v & 0xFFFFFFu) == 1 && dev_degree((v >> 24) & 0xFFFFFFu) == 1) {
+			tbl.aux[s] = a | AUX_LINEAR;
+			marked++;
+		}
+	}
+	if (marked) atomicAdd(&counters[2], marked);
+	if (written) atomicAdd(&counters[3], written);
+}
+
+// the written nodes as (index, l_links, r_links | linear << 24 | deleted << 25): what sdt_gpu_update_nodes_by_index takes, the other way
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_mo_emit(Table<NW> tbl, const uint64_t *__restrict__ slot_of, uint64_t nn, const uint8_t *__restrict__ dirty,
+                                                 unsigned long long *cursor, uint64_t cap, uint64_t *__restrict__ node, uint32_t *__restrict__ l_links,
+                                                 uint32_t *__restrict__ r_flags)
+{
+	const uint64_t nn64 = (nn + 63) & ~63ULL;                // (whole waves stay in the loop: the ballot needs every lane)
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < nn64; i += (uint64_t)gridDim.x * TPB) {
+		const bool d = i < nn && dirty[i];
+		const unsigned long long m = __ballot(d);            // one atomic per wave, not per node (62 M of them on one word took 120 ms)
+		if (!m) continue;
+		const int lane = threadIdx.x & 63;
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+		base = __shfl(base, 0);
+		if (!d) continue;
+		const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
+		if (at >= cap) continue;
+		const uint64_t s = slot_of[i], v = tbl.ent[s].val;
+		const uint32_t a = tbl.aux[s];
+		node[at] = i;
+		l_links[at] = (uint32_t)(v & 0xFFFFFFu);
+		r_flags[at] = (uint32_t)((v >> 24) & 0xFFFFFFu) | ((a & AUX_LINEAR) ? 1u << 24 : 0u) | ((a & AUX_DELETED) ? 1u << 25 : 0u);
+	}
+}
+
+// ===============================================================================================================
 // Components of the ordered commits (csrc/host/graph/cuttip.c): lock-free union-find over node indices.
 // parent[] only ever changes from "root" to "child of a smaller root" (and by path halving, to an ancestor), so a stale value
 // still leads up the same tree; the per-XCD L2s are not coherent, so parent[] is read with device-scope atomic loads and
@@ -622,6 +851,13 @@ __global__ __launch_bounds__(TPB) void k_uf_label(uint32_t *parent, uint64_t *__
 		skey[r] = ((uint64_t)root << 32) | me;
 		sval[r] = (uint32_t)r;
 	}
+}
+
+// label word of records that are not sorted (the neighbours to cut behind the junction records)
+__global__ __launch_bounds__(TPB) void k_uf_label_only(uint32_t *parent, uint64_t *__restrict__ rec, uint64_t r0, uint64_t n, int stride, int label_word)
+{
+	for (uint64_t r = r0 + blockIdx.x * (uint64_t)TPB + threadIdx.x; r < n; r += (uint64_t)gridDim.x * TPB)
+		rec[r * stride + label_word] = uf_find(parent, (uint32_t)(rec[r * stride] & 0x00FFFFFFFFFFFFFFULL));
 }
 
 __global__ __launch_bounds__(TPB) void k_gather_records(const uint64_t *__restrict__ rec, const uint32_t *__restrict__ perm, uint64_t n, int stride,

@@ -1126,6 +1126,143 @@ def test_labelled_junction_records_and_their_components(pkg, synth, K, L):
             assert list(zip(labs, nodes)) == sorted(zip(labs, nodes))
 
 
+def py_minor_out_commit(rec, nj, keys_int, l, rf, K, thr):
+    """removeMinorOut's commit (cutTipPreGraph.c:591-1010; csrc/host/graph/cuttip.c: visit_minor_out / prune_side / isolate) over
+    the junction records in node order -- the reference's sweep -- plus the re-marking of the nodes it wrote:
+    (l, r, linear, deleted, kmers off, newly linear, written nodes)"""
+    ll = [int(x) & 0xFFFFFF for x in l]
+    rr = [int(x) & 0xFFFFFF for x in rf]
+    lin = [(int(x) >> 24) & 1 for x in rf]
+    dele = [(int(x) >> 25) & 1 for x in rf]
+    recof = {int(R[0]): R for R in rec}
+    deg = lambda v: sum(1 for b in range(4) if (v >> (6 * b)) & 63)
+    cnt_of = lambda R, q: (int(R[9 + q // 2]) >> (32 * (q & 1))) & 0xFFFFFFFF
+    touched, off = set(), 0
+
+    def isolate(q):
+        dele[q] = 1
+        touched.add(q)
+        Q, kq = recof[q], keys_int[q]
+        ch_last, ch_first = kq & 3, (kq >> (2 * (K - 1))) & 3
+        for side in (0, 1):
+            for b in range(4):
+                if not ((ll[q] if side == 0 else rr[q]) >> (6 * b)) & 63:
+                    continue
+                nb = int(Q[1 + side * 4 + b])
+                x, sm = nb >> 1, nb & 1
+                if side == 0:                                 # unlink_next(x, last base of q, sm)
+                    right, base = (1, ch_last) if sm else (0, ch_last ^ 2)
+                else:                                         # unlink_prev(y, first base of q, sm)
+                    right, base = (0, ch_first) if sm else (1, ch_first ^ 2)
+                if right:
+                    rr[x] &= ~(63 << (6 * base))
+                else:
+                    ll[x] &= ~(63 << (6 * base))
+                lin[x] = 1 if deg(ll[x]) == 1 and deg(rr[x]) == 1 else 0
+                touched.add(x)
+
+    for R in sorted(rec[:nj], key=lambda R: int(R[0])):
+        n = int(R[0])
+        if lin[n] or dele[n]:
+            continue
+        i, o = deg(ll[n]), deg(rr[n])
+        if i <= 1 and o <= 1:
+            continue
+        for side, d in ((0, i), (1, o)):
+            if d <= 1:
+                continue
+            links = ll[n] if side == 0 else rr[n]
+            best = max([cnt_of(R, side * 4 + b) for b in range(4) if (links >> (6 * b)) & 63] + [0])
+            if not best:
+                continue
+            for b in range(4):
+                if not ((ll[n] if side == 0 else rr[n]) >> (6 * b)) & 63:
+                    continue
+                c = cnt_of(R, side * 4 + b)
+                if c and c / best < thr:
+                    off += 1
+                    isolate(int(R[1 + side * 4 + b]) >> 1)
+    marked = 0
+    for i in touched:
+        if not dele[i] and not lin[i] and deg(ll[i]) == 1 and deg(rr[i]) == 1:
+            lin[i] = 1
+            marked += 1
+    return ll, rr, lin, dele, off, marked, touched
+
+
+@pytest.mark.parametrize("K,L,thr", [(21, 100, 0.05), (31, 150, 0.3), (31, 150, 0.05), (47, 150, 0.3), (75, 200, 0.2)])
+def test_minor_out_commit_on_the_device_equals_the_sequential_commit(pkg, synth, K, L, thr):
+    """sdt_gpu_minor_out_commit (one lane per component, the visits of a component in record order) against the sequential sweep over
+    the junctions in node order: kmers off, newly linear nodes, the set of written nodes, and every node's links and flags afterwards"""
+    tx = synth.make_transcriptome(8, seed=K + 31)
+    codes, offs = synth.sample_reads(*tx, n_reads=5000, read_len=L, seed=K + 32, err=0.01)
+    variant = 1 if K <= 31 else (2 if K <= 63 else 4)
+    with pkg.PregraphGPU(K, est_distinct=1 << 15, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        g.layout_on_device(4, variant)
+        keys, l, rf, cnt = g.export_ordered()
+        ki = keys_to_int(keys)
+        # a component limit of zero: every component is left to the caller -- nothing written, all junction records handed over in order
+        small = g.minor_out_commit(thr, max_component=0)
+        assert small["largest"] >= 1 and small["off"] == 0 and len(small["node"]) == 0
+        assert (small["skipped"] == small["records"][:small["n_junctions"]]).all()
+        assert (small["skipped_neighbours"] == small["records"][small["n_junctions"]:]).all()
+        k1, l1, r1, c1 = g.export_ordered()
+        assert (l1 == l).all() and (r1 == rf).all()
+        res = g.minor_out_commit(thr)
+        rec, nj = res["records"], res["n_junctions"]
+        assert nj > 0 and res["largest"] == small["largest"] and len(res["skipped"]) == 0
+        ll, rr, lin, dele, off, marked, touched = py_minor_out_commit(rec, nj, ki, l, rf, K, thr)
+        assert off > 0 and res["off"] == off and res["linear"] == marked
+        assert sorted(int(x) for x in res["node"]) == sorted(touched)
+        for i, a, b in zip(res["node"], res["l_links"], res["r_flags"]):
+            i = int(i)
+            assert int(a) == ll[i] and int(b) & 0xFFFFFF == rr[i] and (int(b) >> 24) & 1 == lin[i] and (int(b) >> 25) & 1 == dele[i]
+        k2, l2, r2, c2 = g.export_ordered()
+        assert (k2 == keys).all() and (c2 == cnt).all()
+        assert [int(x) & 0xFFFFFF for x in l2] == ll and [int(x) & 0xFFFFFF for x in r2] == rr
+        assert [(int(x) >> 24) & 1 for x in r2] == lin and [(int(x) >> 25) & 1 for x in r2] == dele
+
+
+@pytest.mark.parametrize("K,L,thr", [(31, 150, 0.3), (47, 150, 0.2)])
+def test_minor_out_commit_split_between_the_device_and_the_caller(pkg, synth, K, L, thr):
+    """components above the limit are left alone and their records handed over: the device's half + the sequential commit of the
+    handed-over records (they touch no node the device wrote) = the whole sequential commit"""
+    tx = synth.make_transcriptome(8, seed=K + 41)
+    codes, offs = synth.sample_reads(*tx, n_reads=5000, read_len=L, seed=K + 42, err=0.012)
+    variant = 1 if K <= 31 else 2
+    with pkg.PregraphGPU(K, est_distinct=1 << 15, flags=pkg.SDT_FLAG_TRACK_FIRST) as g:
+        g.push_reads(synth.pack_2bit(codes), offs)
+        g.finish_count()
+        g.mark_and_hist()
+        g.layout_on_device(4, variant)
+        keys, l, rf, cnt = g.export_ordered()
+        ki = keys_to_int(keys)
+        res = g.minor_out_commit(thr, max_component=2)
+        rec, nj, sk = res["records"], res["n_junctions"], res["skipped"]
+        assert res["largest"] > 2 and 0 < len(sk) < nj, "the input must have components on both sides of the limit"
+        labs = [int(R[13]) for R in rec[:nj]]
+        big = {lab for lab in set(labs) if labs.count(lab) > 2}
+        assert [tuple(int(x) for x in R) for R in sk] == [tuple(int(x) for x in R) for R in rec[:nj] if int(R[13]) in big]
+        assert [tuple(int(x) for x in R) for R in res["skipped_neighbours"]] == [tuple(int(x) for x in R) for R in rec[nj:] if int(R[13]) in big]
+        # the whole commit, sequentially
+        ll, rr, lin, dele, off, marked, touched = py_minor_out_commit(rec, nj, ki, l, rf, K, thr)
+        # the device's half ...
+        small_rec = np.array([R for R in rec[:nj] if int(R[13]) not in big] + [R for R in rec[nj:]], dtype=np.uint64).reshape(-1, 14)
+        n_small = sum(1 for R in rec[:nj] if int(R[13]) not in big)
+        l_a, r_a, lin_a, del_a, off_a, marked_a, touched_a = py_minor_out_commit(small_rec, n_small, ki, l, rf, K, thr)
+        assert res["off"] == off_a and res["linear"] == marked_a and sorted(int(x) for x in res["node"]) == sorted(touched_a)
+        # ... and the caller's on top of it give the whole
+        rf_mid = np.array([r_a[i] | (lin_a[i] << 24) | (del_a[i] << 25) for i in range(len(ki))], dtype=np.uint32)
+        big_rec = np.array([R for R in sk] + [R for R in rec[nj:]], dtype=np.uint64).reshape(-1, 14)
+        l_b, r_b, lin_b, del_b, off_b, marked_b, touched_b = py_minor_out_commit(big_rec, len(sk), ki, np.array(l_a, dtype=np.uint32), rf_mid, K, thr)
+        assert not (touched_a & touched_b)
+        assert off_a + off_b == off and marked_a + marked_b == marked
+        assert l_b == ll and r_b == rr and lin_b == lin and del_b == dele
+
+
 def py_build_edges(keys_int, l, rf, cnt, K):
     """kmer2edges (node2edge.c:46-561) restated sequentially over the nodes in index order: [(length, bal_edge, cvg, id, from, to,
     bases)], num_ed, {node: path word} -- interior nodes are stamped last to first and the coverage sum reads what is there"""
