@@ -704,6 +704,16 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 	if (nn >= 0xFFFFFFF0ULL || nr >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "commit on the device: 32-bit record and node indices");
 	HIPCHK(hipSetDevice(v.device));
 	*largest = *n_skipped = *n_skipped_records = 0;
+	const bool timing = getenv("SDT_TIMING") != nullptr;
+	struct timespec ts0_; clock_gettime(CLOCK_MONOTONIC, &ts0_);
+	const double t_call = ts0_.tv_sec * 1e3 + ts0_.tv_nsec * 1e-6;
+	auto tick = [&](const char *what) {              // (SDT_TIMING: where the call's time goes, on stderr; waits for the stream)
+		if (!timing) return;
+		(void)hipStreamSynchronize(v.stream);
+		struct timespec t_;
+		clock_gettime(CLOCK_MONOTONIC, &t_);
+		fprintf(stderr, "[device]       commit: %s at %.1f ms\n", what, t_.tv_sec * 1e3 + t_.tv_nsec * 1e-6 - t_call);
+	};
 	if (gx->mo_pending) { (void)hipStreamSynchronize(v.stream); mo_pending_free(gx); }
 	if (gx->d_wnode) { (void)hipFree(gx->d_wnode); gx->d_wnode = nullptr; }
 	if (gx->d_wl) { (void)hipFree(gx->d_wl); gx->d_wl = nullptr; }
@@ -718,6 +728,7 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 	GCHK(hipMemsetAsync(d_cnt, 0, 5 * 8, v.stream));
 	GCHK(S.alloc(&recidx, (nn + 1) * 4)); GCHK(S.alloc(&dirty, nn + 1));
 	GCHK(hipMemsetAsync(dirty, 0, nn + 1, v.stream));
+	tick("buffers");
 	if (!nj) {                                                   // nothing to visit: _finish reports zeros
 		GCHK(S.alloc(&cstart, 8));
 		gx->mo_dirty = (uint8_t *)S.release(dirty); gx->mo_cnt = (unsigned long long *)S.release(d_cnt);
@@ -725,7 +736,12 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 		gx->mo_pending = true;
 		return SDT_OK;
 	}
-	GCHK(S.alloc(&flag, (nj + 1) * 4)); GCHK(S.alloc(&rank, (nj + 1) * 4));
+	uint64_t ncomp = 0;
+	{
+	// (the temporaries of this block are let go BEFORE the visits are launched: freeing a block waits for the device, and at the
+	// end of the call that would be a wait for the visits -- the host would start on the long components a quarter of a second late)
+	Scratch T;
+	GCHK(T.alloc(&flag, (nj + 1) * 4)); GCHK(T.alloc(&rank, (nj + 1) * 4));
 	hipLaunchKernelGGL(k_mo_comp_flags, dim3(sdti::scan_grid(v.cu_count, nj + 1)), dim3(TPB), 0, v.stream, gx->d_result, nj, 14, flag);
 	GCHK(hipGetLastError());
 	int rc = exclusive_scan<uint32_t>(v, flag, rank, nj + 1);                   // rank[nj] = number of components
@@ -733,7 +749,7 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 	uint32_t ncomp32 = 0;
 	GCHK(hipMemcpyAsync(&ncomp32, rank + nj, 4, hipMemcpyDeviceToHost, v.stream));
 	GCHK(hipStreamSynchronize(v.stream));
-	const uint64_t ncomp = ncomp32;
+	ncomp = ncomp32;
 	GCHK(S.alloc(&cstart, (ncomp + 1) * 4));
 	hipLaunchKernelGGL(k_mo_comp_starts, dim3(sdti::scan_grid(v.cu_count, nj)), dim3(TPB), 0, v.stream, flag, rank, nj, cstart);
 	GCHK(hipGetLastError());
@@ -747,18 +763,19 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 	GCHK(hipGetLastError());
 	GCHK(hipStreamSynchronize(v.stream));
 	*largest = h_largest;
+	tick("components + record index");
 	if (h_largest > max_component) {
 		// the records of the components that are left alone: their junction records in order, then the records of the neighbours
 		// they may cut (the host's commit finds the neighbours of a cut node there instead of looking them up)
 		uint32_t *sel, *pos, *size_of, *sel2, *pos2, nsk = 0, nsk2 = 0;
-		GCHK(S.alloc(&sel, (nj + 1) * 4)); GCHK(S.alloc(&pos, (nj + 1) * 4));
+		GCHK(T.alloc(&sel, (nj + 1) * 4)); GCHK(T.alloc(&pos, (nj + 1) * 4));
 		hipLaunchKernelGGL(k_mo_skipped_sel, dim3(sdti::scan_grid(v.cu_count, nj + 1)), dim3(TPB), 0, v.stream, flag, rank, cstart, nj, max_component, sel);
 		GCHK(hipGetLastError());
 		rc = exclusive_scan<uint32_t>(v, sel, pos, nj + 1);
 		if (rc != SDT_OK) return rc;
 		GCHK(hipMemcpyAsync(&nsk, pos + nj, 4, hipMemcpyDeviceToHost, v.stream));
 		const uint64_t nc = nr - nj;
-		GCHK(S.alloc(&size_of, (nn + 1) * 4)); GCHK(S.alloc(&sel2, (nc + 1) * 4)); GCHK(S.alloc(&pos2, (nc + 1) * 4));
+		GCHK(T.alloc(&size_of, (nn + 1) * 4)); GCHK(T.alloc(&sel2, (nc + 1) * 4)); GCHK(T.alloc(&pos2, (nc + 1) * 4));
 		GCHK(hipMemsetAsync(size_of, 0, (nn + 1) * 4, v.stream));
 		hipLaunchKernelGGL(k_mo_label_sizes, dim3(sdti::scan_grid(v.cu_count, ncomp)), dim3(TPB), 0, v.stream, gx->d_result, 14, cstart, ncomp, size_of);
 		GCHK(hipGetLastError());
@@ -779,6 +796,8 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 		gx->n_skipped = (uint64_t)nsk + nsk2;
 		*n_skipped = nsk;
 		*n_skipped_records = (uint64_t)nsk + nsk2;
+		tick("long components gathered");
+	}
 	}
 	// the visits and the re-marking: launched, not waited for
 	{
