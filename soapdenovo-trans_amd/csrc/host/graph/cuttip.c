@@ -1486,7 +1486,7 @@ static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint6
 		for (int k = 0; k < 8; k++)
 			if (r[1 + k] != NO_NODE) cc_union(parent, (uint32_t)i, (uint32_t)(r[1 + k] >> 1));
 	}
-	for (uint64_t r = 0; r < nj; r++) rec[r * MO_RW + MO_RW - 1] = cc_find(parent, (uint32_t)rec[r * MO_RW]);
+	for (uint64_t r = 0; r < nj + nc; r++) rec[r * MO_RW + MO_RW - 1] = cc_find(parent, (uint32_t)rec[r * MO_RW]);   /* (the neighbours' records too, as the device does) */
 	qsort(rec, nj, MO_RW * sizeof(uint64_t), cmp_rec10);
 	free(parent);
 	free(g->nb_slot); free(g->nb_pool); free(c.need); free(c.writes);
@@ -1498,9 +1498,79 @@ static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint6
 	return 0;
 }
 
+/* CPU stand-in for removeMinorOut's commit on the device (sdt_gpu_minor_out_commit_begin / _finish): the dry run's records made by
+ * the host; the components of at most SDT_COMMIT_MAX_COMPONENT visits (default 2048, as in sdt-pregraph) are committed here and
+ * now -- by the labelled commit on nodes[] itself, which is what the device's commit + graph_apply_written leave behind; their
+ * dirty marks are the caller's to clear, as after a mirror sync --, the longer ones are handed to the caller: their junction records
+ * in order, then the records of the neighbours they may cut.  The CPU suite runs every golden through the caller's half this way. */
+static struct { uint64_t off, lin; } emu_commit_pending;
+
+static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **skipped, uint64_t *n_skipped, uint64_t *n_skipped_records)
+{
+	uint64_t *rec = NULL, nj = 0, nr = 0;
+	if (emu_minor_out(g, threshold, &rec, &nj, &nr) != 0) return 1;
+	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 2048;
+	uint8_t *big = (uint8_t *)calloc(g->n + 1, 1);                      /* by label (a node index) */
+	uint64_t nbig = 0;
+	for (uint64_t r0 = 0; r0 < nj;) {
+		uint64_t r1 = r0 + 1;
+		while (r1 < nj && rec[r1 * MO_RW + MO_RW - 1] == rec[r0 * MO_RW + MO_RW - 1]) r1++;
+		if (r1 - r0 > max_comp) { big[rec[r0 * MO_RW + MO_RW - 1]] = 1; nbig += r1 - r0; }
+		r0 = r1;
+	}
+	uint64_t nbig_all = nbig;
+	for (uint64_t r = nj; r < nr; r++) nbig_all += big[rec[r * MO_RW + MO_RW - 1]];
+	uint64_t *sk = (uint64_t *)malloc((nbig_all + 1) * MO_RW * sizeof(uint64_t));
+	uint64_t *sm = (uint64_t *)malloc((nr - nbig_all + 1) * MO_RW * sizeof(uint64_t));
+	uint64_t a = 0, b = 0, nsmall = 0;
+	for (uint64_t r = 0; r < nr; r++) {                                 /* both halves keep the order: junction records first */
+		const int is_big = big[rec[r * MO_RW + MO_RW - 1]];
+		memcpy((is_big ? sk + a * MO_RW : sm + b * MO_RW), rec + r * MO_RW, MO_RW * sizeof(uint64_t));
+		if (is_big) a++; else { b++; if (r < nj) nsmall++; }
+	}
+	free(rec);
+	free(big);
+	/* "the device": the short components, committed and re-marked */
+	uint64_t off = 0, lin = 0;
+	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;
+	g->dn = 0;
+	if (b) {
+		g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
+		g->nb_pool = (uint64_t *)malloc((b + 1) * 8 * sizeof(uint64_t));
+		g->nb_cnt = (uint32_t *)malloc((b + 1) * 8 * sizeof(uint32_t));
+		void *sa[2] = {g, sm};
+		par_for(0, b, 4096, mo_scatter_records, sa);
+		commit_minor_out_labelled(g, sm, nsmall, threshold, &off);
+		free(g->nb_slot); free(g->nb_pool); free(g->nb_cnt);
+		g->nb_slot = NULL; g->nb_pool = NULL; g->nb_cnt = NULL;
+		ml_ctx M;
+		memset(&M, 0, sizeof M);
+		M.g = g;
+		par_for(0, g->dn, 1 << 12, mark_linear_dirty, &M);
+		for (int t = 0; t < 64; t++) lin += M.n[t];
+	}
+	free(sm);
+	emu_commit_pending.off = off;
+	emu_commit_pending.lin = lin;
+	if (nbig) *skipped = sk; else { free(sk); *skipped = NULL; }
+	*n_skipped = nbig;
+	*n_skipped_records = nbig ? nbig_all : 0;
+	return 0;
+}
+
+static int emu_minor_out_commit_finish(graph_t *g, uint64_t *off, uint64_t *linear)
+{
+	(void)g;
+	*off = emu_commit_pending.off;
+	*linear = emu_commit_pending.lin;
+	return 0;
+}
+
 void graph_emulate_device_cuts(graph_t *g)
 {
 	if (!g->dirty) g->dirty = (uint8_t *)calloc(g->n + 1, 1);
 	g->dev_walks = emu_walks;
 	g->dev_minor_out = emu_minor_out;
+	g->dev_minor_out_commit_begin = emu_minor_out_commit_begin;
+	g->dev_minor_out_commit_finish = emu_minor_out_commit_finish;
 }

@@ -247,7 +247,7 @@ def write_node_dump(pkg, info, path):
         f.write(fo[perm].tobytes())
 
 
-@pytest.mark.parametrize("wide", [False, True, "emulate"])
+@pytest.mark.parametrize("wide", [False, True, "emulate", "emulate-split"])
 @pytest.mark.parametrize("name", gu.case_names())
 def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name, wide):
     """csrc/host/graph (layout replay from first-occurrence order + minor-out + tip cutting + output_vertex) on the
@@ -255,14 +255,18 @@ def test_host_graph_phases_match_reference_vertex(pkg, tmp_path, name, wide):
     same -p, for 31/63/127mer variants -- with the 32-bit node index and with the 64-bit one that graphs past 2^32 nodes
     take (inc/newhash.h:79-88: the reference's sets have ubyte8 sizes); "emulate": the commits that sdt-pregraph runs on
     the device's records (labelled walks, labelled junction records, port walks: commit by components) on the same
-    records made by the host's own dry runs (graph_emulate_device)"""
+    records made by the host's own dry runs (graph_emulate_device) -- removeMinorOut through the two hooks of the device's commit:
+    short components committed by the stand-in for the device, long ones handed to the caller with their neighbours' records;
+    "emulate-split": the same with a component limit of 2 visits, so that both halves have work on every golden"""
     info = gu.load_case(name)
     dump = tmp_path / "nodes.bin"
     write_node_dump(pkg, info, dump)
     cfg = materialise(info, tmp_path)
     env = dict(os.environ, SDT_GRAPHCHECK_A=str(info["a"])) if info.get("a") else dict(os.environ)     # -a of the reference's CLI
-    if wide == "emulate":
+    if wide in ("emulate", "emulate-split"):
         env["SDT_GRAPHCHECK_EMULATE"] = "1"
+        if wide == "emulate-split":
+            env["SDT_COMMIT_MAX_COMPONENT"] = "2"
     elif wide:
         env["SDT_WIDE_INDEX"] = "1"        # the 64-bit node index of graphs past 2^32 nodes (graph.c), forced on a small one
     out = subprocess.run([bin_path(pkg, "sdt-graphcheck"), str(dump), str(tmp_path / "out"), cfg], check=True,
