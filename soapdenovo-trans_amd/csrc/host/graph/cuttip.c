@@ -1503,7 +1503,7 @@ static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint6
  * now -- by the labelled commit on nodes[] itself, which is what the device's commit + graph_apply_written leave behind; their
  * dirty marks are the caller's to clear, as after a mirror sync --, the longer ones are handed to the caller: their junction records
  * in order, then the records of the neighbours they may cut.  The CPU suite runs every golden through the caller's half this way. */
-static struct { uint64_t off, lin; } emu_commit_pending;
+static struct { uint64_t off, lin, nw, *node; uint32_t *l, *r; } emu_commit_pending;
 
 static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **skipped, uint64_t *n_skipped, uint64_t *n_skipped_records)
 {
@@ -1530,10 +1530,13 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 	}
 	free(rec);
 	free(big);
-	/* "the device": the short components, committed and re-marked */
+	/* "the device": the short components, committed and re-marked -- on nodes[], whose old contents are put back afterwards: what
+	 * was written goes through the same list of (index, links, flags) and graph_apply_written as the device's writes, in _finish */
 	uint64_t off = 0, lin = 0;
 	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;
 	g->dn = 0;
+	gnode_t *before = (gnode_t *)malloc((g->n + 1) * sizeof(gnode_t));
+	memcpy(before, g->nodes, g->n * sizeof(gnode_t));
 	if (b) {
 		g->nb_slot = (uint32_t *)calloc(g->n + 1, sizeof(uint32_t));
 		g->nb_pool = (uint64_t *)malloc((b + 1) * 8 * sizeof(uint64_t));
@@ -1550,8 +1553,22 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 		for (int t = 0; t < 64; t++) lin += M.n[t];
 	}
 	free(sm);
+	const uint64_t nw = g->dn;
+	uint64_t *wn = (uint64_t *)malloc((nw + 1) * sizeof(uint64_t));
+	uint32_t *wl = (uint32_t *)malloc((nw + 1) * sizeof(uint32_t)), *wr = (uint32_t *)malloc((nw + 1) * sizeof(uint32_t));
+	for (uint64_t k = 0; k < nw; k++) {
+		const uint64_t i = g->dlist[k];
+		const gnode_t *n = &g->nodes[i];
+		wn[k] = i;
+		wl[k] = n->l_links;
+		wr[k] = n->r_links | ((uint32_t)n->linear << 24) | ((uint32_t)n->deleted << 25);
+		g->nodes[i] = before[i];                                  /* the host's array has not heard of it yet */
+	}
+	free(before);
 	emu_commit_pending.off = off;
 	emu_commit_pending.lin = lin;
+	emu_commit_pending.nw = nw;
+	emu_commit_pending.node = wn; emu_commit_pending.l = wl; emu_commit_pending.r = wr;
 	if (nbig) *skipped = sk; else { free(sk); *skipped = NULL; }
 	*n_skipped = nbig;
 	*n_skipped_records = nbig ? nbig_all : 0;
@@ -1560,7 +1577,9 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 
 static int emu_minor_out_commit_finish(graph_t *g, uint64_t *off, uint64_t *linear)
 {
-	(void)g;
+	graph_apply_written(g, emu_commit_pending.node, emu_commit_pending.l, emu_commit_pending.r, emu_commit_pending.nw);
+	free(emu_commit_pending.node); free(emu_commit_pending.l); free(emu_commit_pending.r);
+	emu_commit_pending.node = NULL; emu_commit_pending.l = emu_commit_pending.r = NULL;
 	*off = emu_commit_pending.off;
 	*linear = emu_commit_pending.lin;
 	return 0;
