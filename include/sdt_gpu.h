@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 6
+#define SDT_ABI_VERSION 7
 
 enum {
 	SDT_OK       = 0,
@@ -152,6 +152,14 @@ int sdt_gpu_allreduce_i64(sdt_ctx *ctx, int64_t *vals, int n);
 int sdt_gpu_comm_stats(sdt_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_recv, double *exchange_ms, uint64_t *exchanges);
 int sdt_gpu_shard_ranges(const sdt_ctx *ctx, uint32_t *first_bucket);
 int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K);
+
+/* the FINAL minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit of the bucket-major node table (csrc/sdt_table.cuh:
+ * BmDir) that the locality pipeline leaves -- the nodes of one bucket lie together, a look-up by key computes this first. */
+int sdt_kmer_final_bucket(const uint64_t *key_words_msw_first, int K);
+/* the node table as it stands: info[0] layout (0 flat = power-of-two open addressing over all keys, newhash.c's shape; 1
+ * bucket-major), [1] slots, [2] nodes, [3] folds of the node log so far, [4] buckets that were merged twice (LDS table or a
+ * part over-full), [5] largest number of tables of one bucket, [6] microseconds spent folding, [7] bytes of node log allocated */
+int sdt_gpu_table_info(sdt_ctx *ctx, uint64_t info[8]);
 int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks);
 /* After pass 1 the order-dependent graph phases (cutTipPreGraph.c, node2edge.c) run on ONE host over ALL nodes: rank 0
  * takes the other ranks' exported shards (sdt_gpu_export_nodes arrays; keys are disjoint by construction) into its own
@@ -182,9 +190,10 @@ int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *rang
 /* The work items and launches of the count stage as a pure host function of the level-2 chunk lists (csrc/sdt_count_plan.h; no
  * device): what the library computes between the level-2 scatter and k_sk_count, callable so that it can be tested on a CPU.
  *   off2[f], kpre2[f]   first chunk / first k-mer of final bucket f in the chunk list (f = nbuckets: the totals)
- *   items               2 words per work item: the run [c0, c1) of the list, top bit of c1 = the item holds whole buckets only
- *                       (its workgroup is the only writer of their keys: merges without atomics).  Buckets of <= 64 chunks share an
- *                       item with their neighbours, buckets of > 1024 chunks are cut into pieces.
+ *   items               4 words per work item: the run [c0, c1) of the list, top bit of c1 = the item holds whole buckets only;
+ *                       its first and its last final bucket (k_sk_count files an item's nodes in the node log bucket by bucket).
+ *                       Buckets of <= 64 chunks share an item with their neighbours -- inside one level-1 bucket and a span of 64
+ *                       final buckets --, buckets of > 1024 chunks are cut into pieces.
  *   first_item[l], launch_kmers[l]   first item and k-mers of launch l (first_item[*nlaunches] = *nitems); a launch is cut
  *                       between buckets at `limit` k-mers (`first_limit` for the first).
  * Stands where the reference hands a batch of k-mers to its threads (prlHashReads.c:312-336, sendWorkSignal). */

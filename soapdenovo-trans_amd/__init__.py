@@ -45,6 +45,8 @@ _ABI = [
     ("sdt_gpu_finish_count", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_shard_cut_ranges", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
     ("sdt_shard_plan", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_uint32, _c.c_uint32] + [_c.c_void_p] * 6),
+    ("sdt_kmer_final_bucket", _c.c_int, [_c.c_void_p, _c.c_int]),
+    ("sdt_gpu_table_info", _c.c_int, [_c.c_void_p, _c.c_void_p]),
     ("sdt_sk_plan_count_items", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_uint64, _c.c_uint64, _c.c_uint32, _c.c_void_p, _c.c_uint32,
                                            _c.c_void_p, _c.c_void_p, _c.c_uint32, _c.c_void_p, _c.c_void_p]),
     ("sdt_gpu_delow", _c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
@@ -503,6 +505,13 @@ class PregraphGPU:
     def table_slots(self) -> int:
         return self.lib.sdt_gpu_table_slots(self._ctx)
 
+    def table_info(self) -> dict:
+        """layout of the node table as it stands (sdt_gpu_table_info)"""
+        a = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.sdt_gpu_table_info(self._ctx, a.ctypes.data))
+        return {"layout": "bucket-major" if a[0] else "flat", "slots": int(a[1]), "nodes": int(a[2]), "folds": int(a[3]), "restarts": int(a[4]),
+                "max_parts": int(a[5]), "fold_ms": float(a[6]) / 1e3, "log_bytes": int(a[7])}
+
     def stream(self) -> int:
         return self.lib.sdt_gpu_stream(self._ctx) or 0
 
@@ -535,13 +544,14 @@ def new_comm_id() -> bytes:
 
 
 def count_plan(off2, kpre2, first_limit, limit, max_launches=4096):
-    """the count stage's work items and launches for chunk lists off2 / kpre2 (csrc/sdt_count_plan.h): (items [n, 2], first_item, launch_kmers)"""
+    """the count stage's work items and launches for chunk lists off2 / kpre2 (csrc/sdt_count_plan.h): (items [n, 4] = c0, c1 | whole,
+    first and last final bucket; first_item; launch_kmers)"""
     o = np.ascontiguousarray(off2, dtype=np.uint32)
     kp = np.ascontiguousarray(kpre2, dtype=np.uint64)
     nb = len(o) - 1
     assert len(kp) == nb + 1
     cap = nb + int(o[-1]) // 1024 + 2
-    items = np.zeros((cap, 2), dtype=np.uint32)
+    items = np.zeros((cap, 4), dtype=np.uint32)
     first = np.zeros(max_launches + 2, dtype=np.uint32)
     lk = np.zeros(max_launches + 2, dtype=np.uint64)
     ni, nl = ctypes.c_uint32(), ctypes.c_uint32()
@@ -585,6 +595,12 @@ def kmer_bucket(key_words_msw_first, K: int) -> int:
     """level-1 minimizer bucket (0..255) of a canonical k-mer (host copy of the device function)"""
     a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
     return load_library().sdt_kmer_bucket(a.ctypes.data, K)
+
+
+def kmer_final_bucket(key_words_msw_first, K: int) -> int:
+    """final minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit of the bucket-major node table"""
+    a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
+    return load_library().sdt_kmer_final_bucket(a.ctypes.data, K)
 
 
 def write_kmerfreq(path: str, hist) -> None:

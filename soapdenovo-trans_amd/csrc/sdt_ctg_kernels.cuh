@@ -83,7 +83,7 @@ constexpr uint64_t PL_VALID = 1ULL << 63;
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_finalize_contig_index(Table<NW> tbl, const uint32_t *__restrict__ ctg_ids, uint64_t n_ord, Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	uint32_t bad = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
@@ -102,23 +102,15 @@ __global__ __launch_bounds__(TPB) void k_finalize_contig_index(Table<NW> tbl, co
 
 template <int NW> __device__ inline bool lookup_slot(const Table<NW> &tbl, const Key<NW> &k, uint64_t &slot_out)
 {
-	uint64_t slot = key_hash<NW>(k) & tbl.mask;
-	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
-		const Entry<NW> *e = tbl.ent + slot;
-		if (e->key[0] == KEY_EMPTY) return false;
-		bool same = true;
-#pragma unroll
-		for (int w = 0; w < NW; w++) same = same && e->key[w] == k.w[w];
-		if (same) { slot_out = slot; return true; }
-	}
-	return false;
+	return table_find<NW>(tbl, k, slot_out);
 }
 
 // searchKmer on the finalized index: the node's val (0 = absent or deleted)
 template <int NW> __device__ inline uint64_t lookup_val(const Table<NW> &tbl, const Key<NW> &k)
 {
-	uint64_t slot = key_hash<NW>(k) & tbl.mask;
-	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
+	uint64_t slot, lo, n;
+	probe_begin<NW>(tbl, k, slot, lo, n);
+	for (uint64_t probe = 0; probe < n; probe++, slot = probe_next(slot, lo, n)) {
 		if constexpr (NW == 1) {
 			const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(tbl.ent + slot);     // key + val in one 16-byte load
 			if (kv.x == KEY_EMPTY) return 0;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void k_count_reads(const uint32_t *__restrict_
 
 template <int NW> __global__ __launch_bounds__(TPB) void k_clear(Table<NW> tbl)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		Entry<NW> e;
 #pragma unroll
@@ -192,7 +192,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_clear(Table<NW> tbl)
 // thread_delow (prlHashReads.c:844-887)
 template <int NW> __global__ __launch_bounds__(TPB) void k_delow(Table<NW> tbl, uint32_t d, Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	uint32_t removed = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		if (tbl.ent[s].key[0] == KEY_EMPTY)
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB) void k_mark_hist(Table<NW> tbl, unsigned long 
 	for (int i = threadIdx.x; i < 257; i += TPB)
 		s_hist[i] = 0;
 	__syncthreads();
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	uint32_t linear = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		if (tbl.ent[s].key[0] == KEY_EMPTY)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TPB) void k_export(Table<NW> tbl, uint64_t *__restr
                                                 uint32_t *__restrict__ r_flags, uint32_t *__restrict__ count,
                                                 uint64_t *__restrict__ first, unsigned long long max_nodes, Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		const Entry<NW> e = tbl.ent[s];
 		if (e.key[0] == KEY_EMPTY)
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(TPB) void k_export(Table<NW> tbl, uint64_t *__restr
 // a plain CAS on the first word and the payload is copied, not re-counted
 template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src, Table<NW> dst, Stats *stats)
 {
-	const uint64_t slots = src.mask + 1;
+	const uint64_t slots = src.slots();
 	uint32_t failed = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		const Entry<NW> e = src.ent[s];
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(TPB) void k_import(Table<NW> tbl, const uint64_t *_
 }
 
 #include "sdt_superkmer_kernels.cuh"
+#include "sdt_bm_kernels.cuh"
 #include "sdt_comm.cuh"
 #include "sdt_shard_plan.h"
 #include "sdt_count_plan.h"
@@ -430,7 +431,7 @@ struct sdt_ctx {
 		unsigned long long *kmers2 = nullptr, *kpre2 = nullptr;
 		SkItem *items = nullptr;
 		uint32_t items_cap = 0;
-		uint2 *citems = nullptr, *h_citems = nullptr;       // work items of k_sk_count: [c0, c1) in list2 (device / pinned)
+		uint4 *citems = nullptr, *h_citems = nullptr;       // work items of k_sk_count: [c0, c1) in list2 + their final buckets (device / pinned; sdt_count_plan.h)
 		uint32_t citems_cap = 0;
 		uint32_t *next_item = nullptr;                      // one counter per k_sk_count launch
 		uint32_t *h_off1 = nullptr, *h_off2 = nullptr;      // pinned
@@ -443,6 +444,47 @@ struct sdt_ctx {
 		uint64_t l2_in_total = 0;      // k-mers that entered the count stage (sum of the level-2 bucket sizes): Stats.sk_counted must match
 		bool exchanged = false;        // records left for / came from other ranks: Stats.sk_emitted is not this rank's input
 	} sk;
+	// node log + bucket-major node table (sdt_bm_kernels.cuh): what the locality pipeline's count stage appends to, and the table
+	// sync_stats folds it into.  The flat table above stays the direct kernel family's (and the place of records that found no
+	// chunk); whatever it holds when the log is folded is folded with it, and from then on the bucket-major table is THE table
+	// (table_of): scans run over its slots, look-ups compute the key's minimizer bucket.
+	struct LogSlab {
+		uint64_t *ent = nullptr;
+		uint64_t ent_cap = 0;              // entries
+		LogDesc *desc = nullptr;
+		uint64_t desc_cap = 0;
+		unsigned long long *ctl = nullptr; // device: [0] entries, [1] descriptors handed out
+		uint64_t ent_known = 0, desc_known = 0;      // as of the last look at ctl
+		uint64_t ent_since = 0, desc_since = 0;      // upper bound of what the launches since then may take
+	};
+	struct BmTable {
+		void *ent = nullptr;
+		uint32_t *aux = nullptr;
+		uint64_t *first = nullptr;
+		BmDir *dir = nullptr;
+		uint32_t *cnt = nullptr;
+		uint64_t cap = 0;                  // slots allocated
+		uint64_t nslots = 0;               // slots in use
+		uint64_t nodes = 0;
+		bool valid = false;
+	};
+	struct BmState {
+		std::vector<LogSlab> slabs;
+		int active = -1;
+		bool log_dirty = false;            // a count launch has appended since the last fold
+		BmTable tab;                       // the table (valid: it holds the nodes)
+		BmTable spare;                     // buffers of a table that was folded into another one: kept for the next fold
+		uint64_t est_distinct = 0;         // the caller's estimate (sdt_gpu_init), sizes the first fold
+		// scratch of a fold (allocated once)
+		uint32_t *dcnt = nullptr, *doff = nullptr, *dfill = nullptr;
+		unsigned long long *dents = nullptr, *dpre = nullptr;
+		uint32_t *xcnt = nullptr, *xoff = nullptr, *xfill = nullptr;
+		uint32_t *ccnt = nullptr, *cstart = nullptr, *cfill = nullptr, *order = nullptr, *next = nullptr;
+		unsigned long long *ctl = nullptr, *h_ctl = nullptr;      // BM_CTL_N counters (device / pinned)
+		unsigned long long *h_lctl = nullptr;                    // pinned: a slab's two cursors
+		uint64_t folds = 0, restarts = 0, maxparts = 0;          // statistics
+		double fold_ms = 0;
+	} bm;
 	// multi-GPU (sdt_comm.cuh): communicator + double-buffered send / receive chunk buffers of the exchange
 	Comm comm;
 	struct Shard {
@@ -524,15 +566,39 @@ static void keep_release(sdt_ctx *c)
 	c->kept.clear();
 }
 
-template <int NW> static Table<NW> table_of(const sdt_ctx *c)
+// the flat table: what the direct kernel family counts into (and grows)
+template <int NW> static Table<NW> flat_of(const sdt_ctx *c)
 {
 	Table<NW> t;
 	t.ent = (Entry<NW> *)c->d_ent;
 	t.aux = c->d_aux;
 	t.mask = c->slots - 1;
 	t.first = c->d_first;
+	t.dir = nullptr;
+	t.nslots = 0;
+	t.K = c->K;
 	return t;
 }
+
+template <int NW> static Table<NW> bm_view(const sdt_ctx *c, const sdt_ctx::BmTable &b)
+{
+	Table<NW> t;
+	t.ent = (Entry<NW> *)b.ent;
+	t.aux = b.aux;
+	t.mask = 0;
+	t.first = b.first;
+	t.dir = b.dir;
+	t.nslots = b.nslots;
+	t.K = c->K;
+	return t;
+}
+
+// THE node table as every stage after pass 1 sees it: the bucket-major one once the log has been folded, else the flat one
+template <int NW> static Table<NW> table_of(const sdt_ctx *c)
+{
+	return c->bm.tab.valid ? bm_view<NW>(c, c->bm.tab) : flat_of<NW>(c);
+}
+static uint64_t view_slots(const sdt_ctx *c) { return c->bm.tab.valid ? c->bm.tab.nslots : c->slots; }
 
 static size_t entry_bytes(int nw) { return nw == 1 ? sizeof(Entry<1>) : nw == 2 ? sizeof(Entry<2>) : sizeof(Entry<4>); }
 
@@ -579,6 +645,352 @@ static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, u
 static int sk_flush(sdt_ctx *c);
 static void sk_free(sdt_ctx *c);
 
+// ------------------------------------------------------------------------------------------------
+// node log + bucket-major table (sdt_bm_kernels.cuh)
+// ------------------------------------------------------------------------------------------------
+static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int log_entry_words(const sdt_ctx *c) { return c->nw + 1 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0); }
+
+static void log_free(sdt_ctx *c)
+{
+	for (auto &sl : c->bm.slabs) {
+		if (sl.ent) (void)hipFree(sl.ent);
+		if (sl.desc) (void)hipFree(sl.desc);
+		if (sl.ctl) (void)hipFree(sl.ctl);
+	}
+	c->bm.slabs.clear();
+	c->bm.active = -1;
+}
+
+static void bm_table_free(sdt_ctx::BmTable &t)
+{
+	if (t.ent) (void)hipFree(t.ent);
+	if (t.aux) (void)hipFree(t.aux);
+	if (t.first) (void)hipFree(t.first);
+	if (t.dir) (void)hipFree(t.dir);
+	if (t.cnt) (void)hipFree(t.cnt);
+	t = sdt_ctx::BmTable();
+}
+
+static void bm_free(sdt_ctx *c)
+{
+	sdt_ctx::BmState &b = c->bm;
+	log_free(c);
+	bm_table_free(b.tab);
+	bm_table_free(b.spare);
+	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.order, b.next, b.ctl};
+	for (void *p : dev)
+		if (p) (void)hipFree(p);
+	if (b.h_ctl) (void)hipHostFree(b.h_ctl);
+	if (b.h_lctl) (void)hipHostFree(b.h_lctl);
+	const uint64_t est = b.est_distinct;
+	b = sdt_ctx::BmState();
+	b.est_distinct = est;
+}
+
+// look at a slab's cursors (host sync)
+static int log_refresh(sdt_ctx *c, sdt_ctx::LogSlab &sl)
+{
+	if (!c->bm.h_lctl)
+		HIPCHK(hipHostMalloc((void **)&c->bm.h_lctl, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+	HIPCHK(hipMemcpyAsync(c->bm.h_lctl, sl.ctl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	{ const int rcw = c->comm.sync_watched(c->stream, "the node log's cursors"); if (rcw != SDT_OK) return rcw; }
+	sl.ent_known = c->bm.h_lctl[0] < sl.ent_cap ? c->bm.h_lctl[0] : sl.ent_cap;
+	sl.desc_known = c->bm.h_lctl[1] < sl.desc_cap ? c->bm.h_lctl[1] : sl.desc_cap;
+	sl.ent_since = sl.desc_since = 0;
+	return SDT_OK;
+}
+
+static int bm_fold(sdt_ctx *c);
+
+// Room in the log for a count launch of `kmers` k-mers in `nbuckets` buckets and `nitems` work items -- the HARD bound: an
+// entry is a distinct key of one generation of an LDS table, so a launch appends at most one per k-mer; a descriptor is a
+// non-empty bucket of a flush, and a flush before the end of an item means 3/8 of a table of keys (or 65535 k-mers) since the
+// last one.  The launch can therefore never find the log full, whatever the data.  Returns the slab to append to.
+static int log_reserve(sdt_ctx *c, uint64_t kmers, uint64_t nbuckets, uint64_t nitems, SkLog *out)
+{
+	sdt_ctx::BmState &b = c->bm;
+	const int lw = log_entry_words(c);
+	const uint64_t need_e = kmers + (nitems + kmers / 256 + 64) * SK_LOG_ALIGN;
+	const uint64_t need_d = nbuckets + nitems + kmers / 256 + 64;
+	for (int attempt = 0; attempt < 3; attempt++) {
+		if (b.active >= 0) {
+			sdt_ctx::LogSlab &sl = b.slabs[b.active];
+			if (sl.ent_known + sl.ent_since + need_e > sl.ent_cap || sl.desc_known + sl.desc_since + need_d > sl.desc_cap) {
+				const int rc = log_refresh(c, sl);
+				if (rc != SDT_OK) return rc;
+			}
+			if (sl.ent_known + need_e <= sl.ent_cap && sl.desc_known + need_d <= sl.desc_cap) {
+				sl.ent_since += need_e;
+				sl.desc_since += need_d;
+				out->ent = sl.ent; out->ent_cap = sl.ent_cap; out->desc = sl.desc; out->desc_cap = sl.desc_cap; out->ctl = sl.ctl;
+				return SDT_OK;
+			}
+			// an emptier slab further on (slabs are kept across resets)?
+			if ((size_t)b.active + 1 < b.slabs.size()) {
+				b.active++;
+				continue;
+			}
+		} else if (!b.slabs.empty()) {
+			b.active = 0;
+			continue;
+		}
+		// another slab: as large as the pools suggest, never smaller than this launch, within a share of what is free
+		uint64_t want = c->sk.cap_kmers / 8;
+		if (want < (1ULL << 26)) want = 1ULL << 26;
+		if (want > (1ULL << 31)) want = 1ULL << 31;
+		if (env_int("SDT_LOG_SLAB_LOG2", 0) > 0)          // (tests: small slabs, many of them)
+			want = 1ULL << clamp_int(env_int("SDT_LOG_SLAB_LOG2", 0), 16, 34);
+		if (want < need_e) want = need_e;
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(sdti::mem_info(&free_b, &total_b));
+		const uint64_t per_e = (uint64_t)lw * 8 + sizeof(LogDesc) / 16 + 1;
+		while (want > need_e && want * per_e > free_b / 100 * 45)
+			want = want / 2 > need_e ? want / 2 : need_e;
+		sdt_ctx::LogSlab sl;
+		sl.ent_cap = want;
+		sl.desc_cap = want / 16 + need_d;
+		hipError_t e = hipMalloc((void **)&sl.ent, sl.ent_cap * lw * 8);
+		if (e == hipSuccess) e = hipMalloc((void **)&sl.desc, sl.desc_cap * sizeof(LogDesc));
+		if (e == hipSuccess) e = hipMalloc((void **)&sl.ctl, 2 * sizeof(unsigned long long));
+		if (e != hipSuccess) {
+			if (sl.ent) (void)hipFree(sl.ent);
+			if (sl.desc) (void)hipFree(sl.desc);
+			if (sl.ctl) (void)hipFree(sl.ctl);
+			(void)hipGetLastError();
+			// no memory for another slab: fold what the log holds into the table (which frees the slabs' contents) and start over
+			if (attempt == 0 && b.log_dirty) {
+				const int rc = bm_fold(c);
+				if (rc != SDT_OK) return rc;
+				continue;
+			}
+			return fail(SDT_ENOMEM, "node log: no device memory for a slab of %llu entries x %d B", (unsigned long long)want, lw * 8);
+		}
+		HIPCHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
+		if (getenv("SDT_TIMING"))
+			fprintf(stderr, "[libsdt_gpu] node log: slab %zu of %llu entries x %d B (%.1f GiB)\n", b.slabs.size(), (unsigned long long)want, lw * 8,
+			        (double)want * lw * 8 / (1 << 30));
+		b.slabs.push_back(sl);
+		b.active = (int)b.slabs.size() - 1;
+	}
+	return fail(SDT_ESTATE, "node log: no room for a launch of %llu k-mers", (unsigned long long)kmers);
+}
+
+static int bm_scratch_alloc(sdt_ctx *c)
+{
+	sdt_ctx::BmState &b = c->bm;
+	if (b.dcnt)
+		return SDT_OK;
+	HIPCHK(hipMalloc((void **)&b.dcnt, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&b.doff, (SK_NBF + 1) * 4));
+	HIPCHK(hipMalloc((void **)&b.dfill, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&b.dents, SK_NBF * 8));
+	HIPCHK(hipMalloc((void **)&b.dpre, (SK_NBF + 1) * 8));
+	HIPCHK(hipMalloc((void **)&b.xcnt, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&b.xoff, (SK_NBF + 1) * 4));
+	HIPCHK(hipMalloc((void **)&b.xfill, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&b.ccnt, 65 * 4));
+	HIPCHK(hipMalloc((void **)&b.cstart, 65 * 4));
+	HIPCHK(hipMalloc((void **)&b.cfill, 65 * 4));
+	HIPCHK(hipMalloc((void **)&b.order, SK_NBF * 4));
+	HIPCHK(hipMalloc((void **)&b.next, 64));
+	HIPCHK(hipMalloc((void **)&b.ctl, BM_CTL_N * sizeof(unsigned long long)));
+	HIPCHK(hipHostMalloc((void **)&b.h_ctl, BM_CTL_N * sizeof(unsigned long long), hipHostMallocDefault));
+	return SDT_OK;
+}
+
+static int bm_table_alloc(sdt_ctx *c, sdt_ctx::BmTable &t, uint64_t cap)
+{
+	if (t.cap >= cap && t.ent)
+		return SDT_OK;
+	bm_table_free(t);
+	hipError_t e = hipMalloc(&t.ent, cap * entry_bytes(c->nw));
+	if (e == hipSuccess) e = hipMalloc((void **)&t.aux, cap * 4);
+	if (e == hipSuccess && (c->flags & SDT_FLAG_TRACK_FIRST)) e = hipMalloc((void **)&t.first, cap * 8);
+	if (e == hipSuccess) e = hipMalloc((void **)&t.dir, (size_t)SK_NBF * sizeof(BmDir));
+	if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, (size_t)SK_NBF * 4);
+	if (e != hipSuccess) {
+		bm_table_free(t);
+		(void)hipGetLastError();
+		return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu slots x %zu B", (unsigned long long)cap, entry_bytes(c->nw) + 4);
+	}
+	t.cap = cap;
+	return SDT_OK;
+}
+
+template <int NW, bool TRACK>
+static int bm_fold_launch(sdt_ctx *c, const LogDesc *sorted, const uint64_t *xent, bool have_old, sdt_ctx::BmTable &dst)
+{
+	sdt_ctx::BmState &b = c->bm;
+	BmIn<NW> in;
+	in.desc = sorted;
+	in.doff = b.doff;
+	in.dpre = b.dpre;
+	in.old = have_old ? bm_view<NW>(c, b.tab) : Table<NW>{nullptr, nullptr, 0, nullptr, nullptr, 0, c->K};
+	in.old_cnt = have_old ? b.tab.cnt : nullptr;
+	in.xent = xent;
+	in.xoff = b.xoff;
+	BmOut<NW> out;
+	out.ent = (Entry<NW> *)dst.ent;
+	out.aux = dst.aux;
+	out.first = dst.first;
+	out.dir = dst.dir;
+	out.cnt = dst.cnt;
+	out.ctl = b.ctl;
+	out.cap = dst.cap;
+	using G = BmGeo<NW, TRACK>;
+	HIPCHK(hipFuncSetAttribute((const void *)k_bm_finalize<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
+	const unsigned per_cu = (unsigned)((160 * 1024) / (G::SMEM + 512));
+	const unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+	hipLaunchKernelGGL((k_bm_finalize<NW, TRACK>), dim3(grid), dim3(G::T), G::SMEM, c->stream, in, out, (const uint32_t *)b.order, (uint32_t)SK_NBF, b.next, c->K, c->d_stats);
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+// Fold everything pass 1 has left so far -- the log's segments, the nodes of the flat table, the nodes of an earlier
+// bucket-major table -- into ONE bucket-major table; the log is empty and the flat table clear afterwards.  Host sync.
+static int bm_fold(sdt_ctx *c)
+{
+	sdt_ctx::BmState &b = c->bm;
+	const double t0 = comm_now();
+	int rc = bm_scratch_alloc(c);
+	if (rc != SDT_OK) return rc;
+	// what is there (host sync: the log's cursors, the flat table's node count)
+	uint64_t nlog = 0, ndesc = 0;
+	for (auto &sl : b.slabs) {
+		rc = log_refresh(c, sl);
+		if (rc != SDT_OK) return rc;
+		nlog += sl.ent_known;
+		ndesc += sl.desc_known;
+	}
+	HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+	{ const int rcw = c->comm.sync_watched(c->stream, "the fold of the node log"); if (rcw != SDT_OK) return rcw; }
+	if (c->h_stats->probe_fail)
+		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full, node log or route bucket overflow)", (unsigned long long)c->h_stats->probe_fail);
+	const uint64_t nflat = c->h_stats->distinct;
+	const bool have_old = b.tab.valid;
+	const uint64_t nold = have_old ? b.tab.nodes : 0;
+	const int g = c->cu_count * 8;
+	// descriptors by bucket
+	LogDesc *sorted = nullptr;
+	uint64_t *xent = nullptr;
+	HIPCHK(hipMemsetAsync(b.dcnt, 0, SK_NBF * 4, c->stream));
+	HIPCHK(hipMemsetAsync(b.dents, 0, SK_NBF * 8, c->stream));
+	for (auto &sl : b.slabs)
+		if (sl.desc_known)
+			hipLaunchKernelGGL(k_bm_desc_hist, dim3(g), dim3(256), 0, c->stream, (const LogDesc *)sl.desc, (const unsigned long long *)(sl.ctl + 1), sl.desc_cap, b.dcnt, b.dents);
+	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, b.dcnt, b.doff, b.dfill, (int)SK_NBF, (const unsigned long long *)b.dents, b.dpre);
+	HIPCHK(hipGetLastError());
+	int ret = SDT_OK;
+#define FOLD_CHK(expr)                                                                                 \
+	do {                                                                                               \
+		hipError_t e5_ = (expr);                                                                       \
+		if (e5_ != hipSuccess) {                                                                       \
+			ret = fail(e5_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e5_), __FILE__, __LINE__); \
+			goto done;                                                                                 \
+		}                                                                                              \
+	} while (0)
+	{
+		FOLD_CHK(hipMalloc((void **)&sorted, (ndesc ? ndesc : 1) * sizeof(LogDesc)));
+		for (auto &sl : b.slabs)
+			if (sl.desc_known)
+				hipLaunchKernelGGL(k_bm_desc_place, dim3(g), dim3(256), 0, c->stream, (const LogDesc *)sl.desc, (const unsigned long long *)(sl.ctl + 1), sl.desc_cap,
+				                   (const uint32_t *)b.doff, b.dfill, sorted);
+		FOLD_CHK(hipGetLastError());
+		// the flat table's nodes by bucket
+		if (nflat) {
+			const int gs = scan_grid(c, c->slots);
+			FOLD_CHK(hipMemsetAsync(b.xcnt, 0, SK_NBF * 4, c->stream));
+			if (c->nw == 1) hipLaunchKernelGGL(k_bm_flat_hist<1>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<1>(c), c->K, b.xcnt);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_bm_flat_hist<2>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<2>(c), c->K, b.xcnt);
+			else hipLaunchKernelGGL(k_bm_flat_hist<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, b.xcnt);
+			hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, b.xcnt, b.xoff, b.xfill, (int)SK_NBF, (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
+			FOLD_CHK(hipMalloc((void **)&xent, nflat * (c->nw + 3) * 8));
+			if (c->nw == 1) hipLaunchKernelGGL(k_bm_flat_place<1>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<1>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_bm_flat_place<2>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<2>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
+			else hipLaunchKernelGGL(k_bm_flat_place<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
+			FOLD_CHK(hipGetLastError());
+		}
+		// buckets in order of falling size
+		FOLD_CHK(hipMemsetAsync(b.ccnt, 0, 65 * 4, c->stream));
+		hipLaunchKernelGGL(k_bm_class_hist, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
+		                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, b.ccnt);
+		hipLaunchKernelGGL(k_bm_class_scan, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)b.ccnt, b.cstart, b.cfill);
+		hipLaunchKernelGGL(k_bm_class_place, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
+		                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, (const uint32_t *)b.cstart, b.cfill, b.order);
+		FOLD_CHK(hipGetLastError());
+		// the table: sized by a guess of the distinct keys (the caller's estimate when there is one; 45 % of the log's entries are
+		// distinct on deep transcriptome data), and again with the exact number of slots should the guess have been short
+		const uint64_t in_total = nlog + nold + nflat;
+		uint64_t guess = nold + nflat + (uint64_t)((double)nlog * 0.45);
+		if (b.est_distinct > guess) guess = b.est_distinct;
+		if (guess > in_total) guess = in_total;
+		uint64_t cap = (uint64_t)((double)guess * (4.0 / 3.0) * 1.10) + (uint64_t)SK_NBF * 12 + (1u << 16);
+		sdt_ctx::BmTable &dst = have_old ? b.spare : b.tab;
+		if (dst.cap > cap) cap = dst.cap;                // (buffers of an earlier fold are used as they are)
+		for (int attempt = 0; attempt < 2; attempt++) {
+			ret = bm_table_alloc(c, dst, cap);
+			if (ret != SDT_OK) goto done;
+			FOLD_CHK(hipMemsetAsync(b.ctl, 0, BM_CTL_N * sizeof(unsigned long long), c->stream));
+			FOLD_CHK(hipMemsetAsync(b.next, 0, 4, c->stream));
+			const bool track = (c->flags & SDT_FLAG_TRACK_FIRST) != 0;
+			if (c->nw == 1) ret = track ? bm_fold_launch<1, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<1, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
+			else if (c->nw == 2) ret = track ? bm_fold_launch<2, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<2, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
+			else ret = track ? bm_fold_launch<4, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<4, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
+			if (ret != SDT_OK) goto done;
+			FOLD_CHK(hipMemcpyAsync(b.h_ctl, b.ctl, BM_CTL_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+			{ const int rcw = c->comm.sync_watched(c->stream, "the merge of the node log"); if (rcw != SDT_OK) { ret = rcw; goto done; } }
+			if (b.h_ctl[BM_CTL_SLOTS] <= dst.cap)
+				break;
+			if (attempt == 1) { ret = fail(SDT_ESTATE, "bucket-major table: %llu slots needed, %llu allocated twice", (unsigned long long)b.h_ctl[BM_CTL_SLOTS], (unsigned long long)dst.cap); goto done; }
+			cap = b.h_ctl[BM_CTL_SLOTS] + (1u << 16);        // (the sizes are a function of the input: the second run asks for exactly this)
+		}
+		dst.nslots = b.h_ctl[BM_CTL_SLOTS];
+		dst.nodes = b.h_ctl[BM_CTL_NODES];
+		dst.valid = true;
+		b.restarts += b.h_ctl[BM_CTL_RESTARTS];
+		if (b.h_ctl[BM_CTL_MAXPARTS] > b.maxparts) b.maxparts = b.h_ctl[BM_CTL_MAXPARTS];
+		if (have_old) {
+			std::swap(b.tab, b.spare);
+			b.spare.valid = false;
+			b.spare.nslots = b.spare.nodes = 0;
+		}
+		// the log is empty, the flat table clear
+		for (auto &sl : b.slabs) {
+			FOLD_CHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
+			sl.ent_known = sl.desc_known = sl.ent_since = sl.desc_since = 0;
+		}
+		b.active = b.slabs.empty() ? -1 : 0;
+		b.log_dirty = false;
+		if (nflat) {
+			ret = launch_clear(c, c->d_ent, c->d_aux, c->d_first, c->slots);
+			if (ret != SDT_OK) goto done;
+			FOLD_CHK(hipMemsetAsync(&c->d_stats->distinct, 0, sizeof(unsigned long long), c->stream));
+		}
+		c->h_stats->distinct = 0;
+		c->distinct_known = 0;
+		c->kmers_since_sync = 0;
+		c->hard_since_sync = 0;
+		// (a fold invalidates slot numbers: whatever indexed the old table is gone)
+		if (c->d_idx) { (void)hipFree(c->d_idx); c->d_idx = nullptr; c->idx_slots = c->idx_n = 0; }
+		FOLD_CHK(hipStreamSynchronize(c->stream));
+		b.folds++;
+		b.fold_ms += (comm_now() - t0) * 1e3;
+		if (getenv("SDT_TIMING"))
+			fprintf(stderr, "[libsdt_gpu] node log folded: %llu entries in %llu segments + %llu flat + %llu old nodes -> %llu nodes in %llu slots (%llu restarts, %llu parts at most) in %.1f ms\n",
+			        (unsigned long long)nlog, (unsigned long long)ndesc, (unsigned long long)nflat, (unsigned long long)nold, (unsigned long long)b.tab.nodes,
+			        (unsigned long long)b.tab.nslots, (unsigned long long)b.h_ctl[BM_CTL_RESTARTS], (unsigned long long)b.h_ctl[BM_CTL_MAXPARTS], (comm_now() - t0) * 1e3);
+	}
+done:
+#undef FOLD_CHK
+	if (ret != SDT_OK)
+		(void)hipStreamSynchronize(c->stream);
+	if (sorted) (void)hipFree(sorted);
+	if (xent) (void)hipFree(xent);
+	return ret;
+}
+
 static int drain_staged(sdt_ctx *c, bool force);
 
 static int sync_stats(sdt_ctx *c)
@@ -614,6 +1026,13 @@ static int sync_stats(sdt_ctx *c)
 	c->kmers_known = c->h_stats->kmers;
 	c->kmers_since_sync = 0;
 	c->hard_since_sync = 0;
+	// the count stage has appended to the node log (or the flat table has taken nodes beside a bucket-major one): one table again
+	if (!c->sk.flushing && (c->bm.log_dirty || (c->bm.tab.valid && c->h_stats->distinct))) {
+		const int rcf = bm_fold(c);
+		if (rcf != SDT_OK)
+			return rcf;
+	}
+	c->h_stats->distinct += c->bm.tab.valid ? c->bm.tab.nodes : 0;       // (the host's copy counts the nodes of BOTH tables; distinct_known is the flat one's)
 	return SDT_OK;
 }
 
@@ -641,9 +1060,9 @@ static int grow_table(sdt_ctx *c, uint64_t need_nodes)
 	if (rc != SDT_OK)
 		return rc;
 	const int g = scan_grid(c, c->slots);
-	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d, c->d_stats); }
-	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d, c->d_stats); }
-	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d, c->d_stats); }
+	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, flat_of<1>(c), d, c->d_stats); }
+	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, flat_of<2>(c), d, c->d_stats); }
+	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, flat_of<4>(c), d, c->d_stats); }
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipFree(c->d_ent));
@@ -701,8 +1120,6 @@ static int tile_words_for(uint64_t max_read_len)
 // ------------------------------------------------------------------------------------------------
 // locality pipeline (sdt_superkmer.cuh): scatter super-k-mers -> split -> count in LDS -> merge
 // ------------------------------------------------------------------------------------------------
-static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 34), 24, 36);      // k-mers per batch at most (pools: ~6 B per k-mer at K = 31)
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << clamp_int(env_int("SDT_SK_COUNT_KMERS_LOG2", 29), 20, 36);
@@ -855,8 +1272,8 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	HIPCHK(hipHostMalloc((void **)&k.h_kpre2, (SK_NBF + 1) * 8, hipHostMallocDefault));
 	HIPCHK(hipHostMalloc((void **)&k.h_items, (size_t)k.items_cap * sizeof(SkItem), hipHostMallocDefault));
 	k.citems_cap = (uint32_t)SK_NBF + k.p2.chunks / SK_COUNT_ITEM_CHUNKS + 1;
-	HIPCHK(hipMalloc((void **)&k.citems, (size_t)k.citems_cap * sizeof(uint2)));
-	HIPCHK(hipHostMalloc((void **)&k.h_citems, (size_t)k.citems_cap * sizeof(uint2), hipHostMallocDefault));
+	HIPCHK(hipMalloc((void **)&k.citems, (size_t)k.citems_cap * sizeof(uint4)));
+	HIPCHK(hipHostMalloc((void **)&k.h_citems, (size_t)k.citems_cap * sizeof(uint4), hipHostMallocDefault));
 	HIPCHK(hipMalloc((void **)&k.next_item, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t)));
 	k.cap_kmers = cap;
 	k.ready = true;
@@ -866,24 +1283,25 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	return sk_reset_pool1(c);
 }
 
-template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch, const SkLog &lg)
 {
 	sdt_ctx::SkState &k = c->sk;
 	const size_t smem = sk_count_smem<NW, TRACK>();
 	// persistent workgroups: as many as the LDS tables let the chip hold; they take work items first come first served
-	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 256));
+	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 1024));
 	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
 	if (grid > i1 - i0) grid = i1 - i0;
 	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-	hipLaunchKernelGGL((k_sk_count<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, k.citems, i0, i1,
-	                   k.next_item + launch, c->K, table_of<NW>(c), c->d_stats);
+	hipLaunchKernelGGL((k_sk_count<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, (const uint4 *)k.citems, i0, i1,
+	                   k.next_item + launch, c->K, lg, c->d_stats);
 	HIPCHK(hipGetLastError());
+	c->bm.log_dirty = true;
 	return SDT_OK;
 }
 
-template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch, const SkLog &lg)
 {
-	return c->d_first ? sk_launch_count_t<NW, true>(c, i0, i1, launch) : sk_launch_count_t<NW, false>(c, i0, i1, launch);
+	return (c->flags & SDT_FLAG_TRACK_FIRST) ? sk_launch_count_t<NW, true>(c, i0, i1, launch, lg) : sk_launch_count_t<NW, false>(c, i0, i1, launch, lg);
 }
 
 #define SK_CHK(expr)                                                                                   \
@@ -953,83 +1371,74 @@ static int sk_count_all(sdt_ctx *c)
 	k.st_flushes++;
 	k.stream_flushes++;
 	k.l2_in_total += k.h_kpre2[SK_NBF];
-	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
-	// k-mers (every one might be a new node: ensure_room)
+	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; planned launches of at most SK_COUNT_KMERS k-mers
+	// (the items and launches are a pure function of the chunk lists: sdt_count_plan.h, tested on the CPU)
 	int rc = SDT_OK;
 	uint32_t nci = 0;
 	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
-	// A launch must find room for every node it may create.  "Every occurrence is a new node" is hopeless for a batch of
-	// 2^33 k-mers, so: a first launch of at most 2^26 k-mers under that bound, then launches bounded by twice the rate of
-	// new nodes per occurrence seen so far (later data usually brings fewer new nodes, not more; should it bring more, the load
-	// factor suffers until the next look but the table cannot fill: see the 95 % rule below).
-	// (the items and launches are a pure function of the chunk lists: sdt_count_plan.h, tested on the CPU)
 	std::vector<uint32_t> first_item(SK_MAX_COUNT_LAUNCHES + 2);   // first item of every launch
 	std::vector<uint64_t> launch_kmers(SK_MAX_COUNT_LAUNCHES + 2);
 	uint32_t nlaunches = 0;
-	static_assert(sizeof(uint2) == 2 * sizeof(uint32_t), "an item is two words");
-	if (!sk_plan_count_items(k.h_off2, (const uint64_t *)k.h_kpre2, (uint32_t)SK_NBF, c->kmers_known == 0 ? (1ULL << 26) : SK_COUNT_KMERS, SK_COUNT_KMERS,
+	static_assert(sizeof(uint4) == SK_ITEM_WORDS * sizeof(uint32_t), "an item is four words");
+	if (!sk_plan_count_items(k.h_off2, (const uint64_t *)k.h_kpre2, (uint32_t)SK_NBF, SK_COUNT_KMERS, SK_COUNT_KMERS,
 	                         SK_MAX_COUNT_LAUNCHES, SK_COUNT_PACK_CHUNKS, SK_COUNT_ITEM_CHUNKS, (uint32_t *)k.h_citems, k.citems_cap,
 	                         first_item.data(), launch_kmers.data(), (uint32_t)first_item.size(), &nci, &nlaunches))
 		return fail(SDT_ESTATE, "count stage: work item table overflow");
 	first_item.resize(nlaunches + 1);
 	launch_kmers.resize(nlaunches);
 	std::vector<uint32_t> sort_tmp;
-	auto guess_of = [&](uint64_t kmers) -> uint64_t {
-		uint64_t bound = kmers;
-		if (c->kmers_known) {
-			const double rate = (double)c->distinct_known / (double)c->kmers_known;
-			const uint64_t guess = (uint64_t)((double)kmers * (2.0 * rate < 1.0 ? 2.0 * rate : 1.0)) + (1ULL << 22);
-			if (guess < bound) bound = guess;
-		}
-		return bound;
+	const uint32_t *iw = (const uint32_t *)k.h_citems;
+	// non-empty buckets of the items [i0, i1): what bounds the descriptors of a launch (an item's buckets are its own)
+	auto buckets_of = [&](uint32_t i0, uint32_t i1) -> uint64_t {
+		uint64_t n = 0;
+		for (uint32_t i = i0; i < i1; i++)
+			n += iw[SK_ITEM_WORDS * i + 3] - iw[SK_ITEM_WORDS * i + 2] + 1;
+		return n;
 	};
+	// A launch appends to the node log and must find room for whatever it may append: one entry per k-mer at the very most
+	// (log_reserve).  Until round 4 the launches were cut where the host had to look at the node table's load; now a planned
+	// launch joins the one before it as long as the log's slab has room for both under that bound -- a launch boundary is a
+	// drained GPU (every workgroup waits for the slowest), and it is only needed where the host decides about memory.
 	const size_t nl = first_item.size() - 1;
+	static const uint64_t merge_max = 1ULL << clamp_int(env_int("SDT_SK_LAUNCH_MAX_LOG2", 33), 20, 40);
 	for (size_t l = 0; l < nl && rc == SDT_OK;) {
 		const uint32_t i0 = first_item[l];
 		if (i0 == first_item[l + 1]) {
 			l++;
 			continue;
 		}
-		if (c->kmers_known == 0 && l > 0) {
-			rc = sync_stats(c);                      // the first launch has run: its rate of new nodes bounds the rest
-			if (rc != SDT_OK) break;
-		}
-		uint64_t bound = guess_of(launch_kmers[l]), hard = launch_kmers[l];
-		rc = ensure_room(c, bound);
-		// the guess keeps the load factor; this keeps the table from FILLING should the guess be wrong: whatever the data,
-		// the nodes known + every k-mer launched since + this launch must fit 95 % of the slots
-		if (rc == SDT_OK && (double)(c->distinct_known + c->hard_since_sync + launch_kmers[l]) > 0.95 * (double)c->slots) {
-			rc = sync_stats(c);
-			if (rc == SDT_OK && (double)(c->distinct_known + launch_kmers[l]) > 0.95 * (double)c->slots)
-				rc = grow_table(c, c->distinct_known + launch_kmers[l]);
-		}
-		// The planned launches behind this one join it as long as neither rule would have to look at the device's counters for
-		// them: a launch boundary is a drained GPU (every workgroup waits for the slowest), and it is only needed where the host
-		// decides about the table.  (45 planned launches per step of the 200 M-read workload become about a dozen.)
+		// how much the active slab could take without another look at the device
+		uint64_t hard = launch_kmers[l];
 		size_t m = l;
-		while (rc == SDT_OK && c->kmers_known && m + 1 < nl) {
-			const uint64_t b2 = guess_of(launch_kmers[m + 1]);
-			if ((double)(c->distinct_known + c->kmers_since_sync + bound + b2) > (double)c->slots * MAX_LOAD)
+		uint64_t room = 0;
+		if (c->bm.active >= 0) {
+			sdt_ctx::LogSlab &sl = c->bm.slabs[c->bm.active];
+			// (the bound of the launches since the last look is far above what they took: look again before giving up on joining launches)
+			if (sl.ent_since && sl.ent_known + sl.ent_since + hard + (m + 1 < nl ? launch_kmers[m + 1] : 0) > sl.ent_cap) {
+				rc = log_refresh(c, sl);
+				if (rc != SDT_OK) break;
+			}
+			const uint64_t used = sl.ent_known + sl.ent_since;
+			room = sl.ent_cap > used ? sl.ent_cap - used : 0;
+		}
+		while (m + 1 < nl && hard + launch_kmers[m + 1] <= merge_max) {
+			const uint64_t next = hard + launch_kmers[m + 1];
+			const uint64_t ni = first_item[m + 2] - i0;
+			if (next + (ni + next / 256 + 64) * SK_LOG_ALIGN > room)
 				break;
-			if ((double)(c->distinct_known + c->hard_since_sync + hard + launch_kmers[m + 1]) > 0.95 * (double)c->slots)
-				break;
-			bound += b2;
-			hard += launch_kmers[m + 1];
+			hard = next;
 			m++;
 		}
 		const uint32_t i1 = first_item[m + 1];
+		SkLog lg;
+		rc = log_reserve(c, hard, buckets_of(i0, i1), i1 - i0, &lg);
+		if (rc != SDT_OK) break;
 		// (largest first over everything this launch hands out -- the plan did it per planned launch; the sort is stable, so the
 		// concatenation of sorted runs comes out as one)
 		if (m > l)
 			sk_plan_largest_first((uint32_t *)k.h_citems, i0, i1, sort_tmp);
-		if (rc == SDT_OK)
-			SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-		if (rc == SDT_OK)
-			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
-		if (rc == SDT_OK) {                              // (only what was launched counts)
-			c->kmers_since_sync += bound;
-			c->hard_since_sync += hard;
-		}
+		SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+		rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l, lg) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l, lg) : sk_launch_count<4>(c, i0, i1, (uint32_t)l, lg);
 		l = m + 1;
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
@@ -1087,7 +1496,7 @@ static int sk_flush(sdt_ctx *c)
 
 template <int NW> static Table<NW> sk_tbl(const sdt_ctx *c, bool allow_direct)
 {
-	Table<NW> t = table_of<NW>(c);
+	Table<NW> t = flat_of<NW>(c);
 	if (!allow_direct)
 		t.ent = nullptr;
 	return t;
@@ -1492,10 +1901,15 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (est_distinct == 0)
 		est_distinct = 1ULL << 22;
+	// The flat table is the direct kernel family's (jobs below 2^27 k-mers, SDT_FLAG_DIRECT, the contig index); the locality
+	// pipeline builds the bucket-major table out of its log (sized when the log is folded: bm_fold) and uses the flat one only
+	// for records that found no chunk.  So the estimate sizes the flat table up to 2^27 slots and the fold beyond that.
 	uint64_t slots = 1ULL << 16;
-	while ((double)slots * 0.5 < (double)est_distinct)
+	const uint64_t flat_max = (flags & (SDT_FLAG_DIRECT | SDT_FLAG_CONTIG_INDEX)) ? ~0ULL : (1ULL << 27);
+	while ((double)slots * 0.5 < (double)est_distinct && slots < flat_max)
 		slots <<= 1;
 	c->slots = slots;
+	c->bm.est_distinct = est_distinct;
 #define INIT_CHK(expr)                                                                    \
 	do {                                                                                  \
 		hipError_t e2_ = (expr);                                                          \
@@ -1559,6 +1973,7 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_hit_cursor) (void)hipFree(c->d_hit_cursor);
 	for (int i = 0; i < 5; i++) if (c->ab[i]) (void)hipFree(c->ab[i]);
 	sk_free(c);
+	bm_free(c);
 	shard_free(c);
 	c->comm.close_all();
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1577,6 +1992,15 @@ int sdt_gpu_reset(sdt_ctx *c)
 	if (rc != SDT_OK)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
+	// the node log is empty, there is no bucket-major table (their buffers stay: the next run uses them)
+	for (auto &sl : c->bm.slabs) {
+		HIPCHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
+		sl.ent_known = sl.desc_known = sl.ent_since = sl.desc_since = 0;
+	}
+	c->bm.active = c->bm.slabs.empty() ? -1 : 0;
+	c->bm.log_dirty = false;
+	c->bm.tab.valid = false;
+	c->bm.tab.nslots = c->bm.tab.nodes = 0;
 	c->sk.l2_in_total = 0;
 	c->sk.stream_flushes = 0;
 	c->sk.exchanged = false;
@@ -1627,7 +2051,7 @@ void sdt_gpu_host_free(void *p)
 }
 
 int sdt_gpu_key_words(const sdt_ctx *c) { return c ? c->nw : 0; }
-uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? c->slots : 0; }
+uint64_t sdt_gpu_table_slots(const sdt_ctx *c) { return c ? view_slots(c) : 0; }
 void *sdt_gpu_stream(const sdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int sdt_gpu_set_read_ordinal(sdt_ctx *c, uint64_t base, uint64_t stride)
 {
@@ -1717,11 +2141,11 @@ static int launch_count(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 		HIPCHK(hipEventRecord(ev->a, c->stream));
 		// offsets are absolute base indices into d_words, so a sub-range of reads is just a shifted pointer
 		if (c->nw == 1)
-			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<1>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, flat_of<1>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else if (c->nw == 2)
-			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<2>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, flat_of<2>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		else
-			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, table_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
+			hipLaunchKernelGGL(k_count_reads<4>, dim3((unsigned)grid), dim3(TPB), smem, c->stream, d_words, d_offs + r0, nr, c->K, mtw, flat_of<4>(c), c->d_stats, c->ord_base + r0 * c->ord_stride, c->ord_stride);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev->b, c->stream));
 		c->kmers_since_sync += upper;
@@ -1930,7 +2354,10 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
 		while (est > (1u << 20) && (double)est / MAX_LOAD * 2.0 * (double)per_slot > (double)free_b * 0.3)
 			est /= 2;                                    // (never more than ~30 % of what is free, power-of-two rounding included)
-		if ((double)est > (double)c->slots * MAX_LOAD) {
+		if (!(c->flags & SDT_FLAG_DIRECT)) {
+			// (the locality pipeline folds its log into a table of its own: the estimate sizes THAT, bm_fold)
+			if (c->bm.est_distinct < est) c->bm.est_distinct = est;
+		} else if ((double)est > (double)c->slots * MAX_LOAD) {
 			const int rc = grow_table(c, est);
 			if (rc != SDT_OK) return rc;
 		}
@@ -1984,7 +2411,7 @@ int sdt_gpu_delow(sdt_ctx *c, int d, uint64_t *removed)
 	HIPCHK(hipSetDevice(c->device));
 	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
-	const int g = scan_grid(c, c->slots);
+	const int g = scan_grid(c, view_slots(c));
 	if (c->nw == 1) hipLaunchKernelGGL(k_delow<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), (uint32_t)d, c->d_stats);
 	else if (c->nw == 2) hipLaunchKernelGGL(k_delow<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), (uint32_t)d, c->d_stats);
 	else hipLaunchKernelGGL(k_delow<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), (uint32_t)d, c->d_stats);
@@ -2004,7 +2431,7 @@ int sdt_gpu_mark_and_hist(sdt_ctx *c, int64_t hist[257], uint64_t *linear)
 	{ const int rcd = drain_staged(c, true); if (rcd != SDT_OK) return rcd; }
 	HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 	HIPCHK(hipMemsetAsync(c->d_hist, 0, 257 * sizeof(unsigned long long), c->stream));
-	const int g = scan_grid(c, c->slots);
+	const int g = scan_grid(c, view_slots(c));
 	if (c->nw == 1) hipLaunchKernelGGL(k_mark_hist<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_hist, c->d_stats);
 	else if (c->nw == 2) hipLaunchKernelGGL(k_mark_hist<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_hist, c->d_stats);
 	else hipLaunchKernelGGL(k_mark_hist<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_hist, c->d_stats);
@@ -2055,7 +2482,7 @@ int sdt_gpu_export_nodes(sdt_ctx *c, uint64_t *keys, uint32_t *l_links, uint32_t
 	if (first) EXP_CHK(hipMalloc((void **)&d_f, m * sizeof(uint64_t)));
 	EXP_CHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 	{
-		const int g = scan_grid(c, c->slots);
+		const int g = scan_grid(c, view_slots(c));
 		if (c->nw == 1) hipLaunchKernelGGL(k_export<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
 		else if (c->nw == 2) hipLaunchKernelGGL(k_export<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
 		else hipLaunchKernelGGL(k_export<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_keys, d_l, d_r, d_c, d_f, (unsigned long long)nodes, c->d_stats);
@@ -2087,7 +2514,7 @@ int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_wo
 	uint64_t *d_own = (!keys && !path_words && n) ? sdti::graph_take_path_words(c->gx, n) : nullptr;
 	if (n && !path_words && !d_own)
 		return fail(keys ? SDT_EINVAL : SDT_ESTATE, "no path words: pass them, or build the edges with sdt_gpu_build_edges first");
-	if (by_index && n && (!c->d_idx || c->idx_slots != c->slots || c->idx_n != n)) {
+	if (by_index && n && (!c->d_idx || c->idx_slots != view_slots(c) || c->idx_n != n)) {
 		if (d_own) (void)hipFree(d_own);
 		return fail(SDT_ESTATE, "keys == NULL needs the node index of sdt_gpu_set_node_index for the same %llu nodes", (unsigned long long)n);
 	}
@@ -2103,7 +2530,7 @@ int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_wo
 		if (rcu == SDT_OK && !d_own) rcu = sdti::h2d_big(c->copy_stream, d_i, path_words, n * sizeof(uint64_t));
 		if (rcu != SDT_OK) { if (d_k) (void)hipFree(d_k); (void)hipFree(d_i); return rcu; }
 		if (by_index) {
-			const int g = scan_grid(c, c->slots);
+			const int g = scan_grid(c, view_slots(c));
 			if (c->nw == 1) hipLaunchKernelGGL(k_set_paths_by_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), c->d_idx, d_i, n, c->d_stats);
 			else if (c->nw == 2) hipLaunchKernelGGL(k_set_paths_by_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), c->d_idx, d_i, n, c->d_stats);
 			else hipLaunchKernelGGL(k_set_paths_by_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), c->d_idx, d_i, n, c->d_stats);
@@ -2338,7 +2765,7 @@ static int launch_align(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_o
 	if (!c->index_final) {
 		int rcs = sync_stats(c);                          // counts stay readable through finish_count (host copy)
 		if (rcs != SDT_OK) return rcs;
-		const int g = scan_grid(c, c->slots);
+		const int g = scan_grid(c, view_slots(c));
 		if (c->nw == 1) hipLaunchKernelGGL(k_finalize_contig_index<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
 		else if (c->nw == 2) hipLaunchKernelGGL(k_finalize_contig_index<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
 		else hipLaunchKernelGGL(k_finalize_contig_index<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), (const uint32_t *)c->d_ctg_ids, c->ctg_ord, c->d_stats);
@@ -2615,6 +3042,35 @@ int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K)
 	return (int)sk_l1_bucket(sk_bucket_hash(best));
 }
 
+int sdt_kmer_final_bucket(const uint64_t *key_words_msw_first, int K)
+{
+	// the final minimizer bucket (0 .. 2^18 - 1) of a k-mer: where the bucket-major node table keeps it (csrc/sdt_minimizer.cuh,
+	// the function the device's look-ups call)
+	if (!key_words_msw_first || K < 13 || K > 127)
+		return -1;
+	if (K <= 31) { Key<1> k{{key_words_msw_first[0]}}; return (int)key_final_bucket<1>(k, K); }
+	if (K <= 63) { Key<2> k{{key_words_msw_first[0], key_words_msw_first[1]}}; return (int)key_final_bucket<2>(k, K); }
+	Key<4> k{{key_words_msw_first[0], key_words_msw_first[1], key_words_msw_first[2], key_words_msw_first[3]}};
+	return (int)key_final_bucket<4>(k, K);
+}
+
+int sdt_gpu_table_info(sdt_ctx *c, uint64_t info[8])
+{
+	if (!c || !info)
+		return fail(SDT_EINVAL, "NULL argument");
+	info[0] = c->bm.tab.valid ? 1 : 0;               // layout: 0 flat, 1 bucket-major
+	info[1] = view_slots(c);
+	info[2] = c->bm.tab.valid ? c->bm.tab.nodes : c->distinct_known;
+	info[3] = c->bm.folds;
+	info[4] = c->bm.restarts;
+	info[5] = c->bm.maxparts;
+	info[6] = (uint64_t)(c->bm.fold_ms * 1e3);       // microseconds spent folding the node log (host view, syncs included)
+	uint64_t logb = 0;
+	for (auto &sl : c->bm.slabs) logb += sl.ent_cap * (uint64_t)log_entry_words(c) * 8;
+	info[7] = logb;
+	return SDT_OK;
+}
+
 int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks)
 {
 	// owner under EQUAL bucket ranges (what a context uses before its first sharded call has weighed the buckets)
@@ -2680,9 +3136,9 @@ int sdt_gpu_import_nodes(sdt_ctx *c, const uint64_t *keys, const uint32_t *l_lin
 		HIPCHK(hipMemcpyAsync(d_c, count + i0, k * 4, hipMemcpyHostToDevice, c->stream));
 		if (d_f) HIPCHK(hipMemcpyAsync(d_f, first + i0, k * 8, hipMemcpyHostToDevice, c->stream));
 		const int g = scan_grid(c, k);
-		if (c->nw == 1) hipLaunchKernelGGL(k_import<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_import<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
-		else hipLaunchKernelGGL(k_import<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		if (c->nw == 1) hipLaunchKernelGGL(k_import<1>, dim3(g), dim3(TPB), 0, c->stream, flat_of<1>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_import<2>, dim3(g), dim3(TPB), 0, c->stream, flat_of<2>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
+		else hipLaunchKernelGGL(k_import<4>, dim3(g), dim3(TPB), 0, c->stream, flat_of<4>(c), d_k, d_l, d_r, d_c, d_f, k, c->d_stats);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(c->stream));
 	}
@@ -2857,6 +3313,7 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 	}
 	if (counters) {
 		HIPCHK(hipMemcpy(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost));
+		c->h_stats->distinct += c->bm.tab.valid ? c->bm.tab.nodes : 0;
 		counters[0] = c->h_stats->sk_merges;
 		counters[1] = c->h_stats->sk_spills;
 		counters[2] = c->h_stats->sk_direct;
@@ -2872,7 +3329,7 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 		counters[16] = c->h_stats->sk_distinct_recs;
 		counters[17] = c->h_stats->sk_records;
 		counters[18] = c->h_stats->sk_distinct_kmers;
-		counters[19] = 0;
+		counters[19] = c->bm.restarts;
 	}
 	return SDT_OK;
 }
@@ -2884,8 +3341,11 @@ sdti::GraphView sdti::graph_view(sdt_ctx *c)
 {
 	GraphView v;
 	v.device = c->device; v.K = c->K; v.nw = c->nw; v.cu_count = c->cu_count;
-	v.slots = c->slots;
-	v.d_ent = c->d_ent; v.d_aux = c->d_aux; v.d_first = c->d_first;
+	// (the node table in whichever layout holds it: sdt_table.cuh)
+	const bool bmv = c->bm.tab.valid;
+	v.slots = view_slots(c);
+	v.d_ent = bmv ? c->bm.tab.ent : c->d_ent; v.d_aux = bmv ? c->bm.tab.aux : c->d_aux; v.d_first = bmv ? c->bm.tab.first : c->d_first;
+	v.dir = bmv ? c->bm.tab.dir : nullptr;
 	v.d_stats = c->d_stats; v.h_stats = c->h_stats;
 	v.stream = c->stream; v.copy_stream = c->copy_stream;
 	v.d_idx = &c->d_idx; v.idx_slots = &c->idx_slots; v.idx_n = &c->idx_n;
@@ -2899,7 +3359,11 @@ int sdti::release_pass1(sdt_ctx *c)
 {
 	const int rc = ::sync_stats(c);
 	if (rc != SDT_OK) return rc;
-	if (!getenv("SDT_KEEP_POOLS")) sk_free(c);               // (measurement switch)
+	if (!getenv("SDT_KEEP_POOLS")) {                         // (measurement switch)
+		sk_free(c);
+		log_free(c);
+		bm_table_free(c->bm.spare);
+	}
 	return SDT_OK;
 }
 

@@ -12,21 +12,7 @@
 // ---------------------------------------------------------------------------------------------------------------
 template <int NW> __device__ inline bool find_slot(const Table<NW> &tbl, const Key<NW> &k, uint64_t &slot_out)
 {
-	uint64_t slot = key_hash<NW>(k) & tbl.mask;
-	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
-		const Entry<NW> *e = tbl.ent + slot;
-		if (e->key[0] == KEY_EMPTY)
-			return false;
-		bool same = true;
-#pragma unroll
-		for (int w = 0; w < NW; w++)
-			same = same && e->key[w] == k.w[w];
-		if (same) {
-			slot_out = slot;
-			return true;
-		}
-	}
-	return false;
+	return table_find<NW>(tbl, k, slot_out);         // (either layout of the node table: sdt_table.cuh)
 }
 
 template <int NW>
@@ -103,7 +89,7 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
                                                    uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
                                                    unsigned long long *cursor = nullptr, int rec_stride = 2)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
@@ -233,7 +219,7 @@ __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, cons
                                                              uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
                                                              Stats *stats, int rec_stride = 9)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
@@ -292,7 +278,7 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
                                                               uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
                                                               Stats *stats, int rec_stride = 9)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
@@ -340,7 +326,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_build_host_index(Table<NW> tbl, const uint64_t *__restrict__ idx, unsigned int *__restrict__ index,
                                                           uint64_t index_mask)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;
 		uint64_t w[4] = {0, 0, 0, 0};
@@ -367,7 +353,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_edge_ports(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, uint64_t max_steps,
                                                     uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor, Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
@@ -456,7 +442,7 @@ __global__ __launch_bounds__(TPB) void k_layout_keys(Table<NW> tbl, uint32_t p, 
 {
 	__shared__ int32_t s_crc[256];
 	crc_table_to_lds(s_crc);
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	uint32_t bad = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		const Entry<NW> e = tbl.ent[s];
@@ -875,7 +861,7 @@ __global__ __launch_bounds__(TPB) void k_gather_records(const uint64_t *__restri
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_port_union(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int max_linear, uint32_t *parent, Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {

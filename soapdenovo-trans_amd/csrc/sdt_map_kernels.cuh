@@ -41,23 +41,10 @@ __global__ __launch_bounds__(TPB) void k_set_paths(Table<NW> tbl, const uint64_t
 #pragma unroll
 		for (int w = 0; w < NW; w++)
 			k.w[w] = keys[i * NW + w];
-		uint64_t slot = key_hash<NW>(k) & tbl.mask;
-		bool ok = false;
-		for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
-			const Entry<NW> *e = tbl.ent + slot;
-			if (e->key[0] == KEY_EMPTY)
-				break;
-			bool same = true;
-#pragma unroll
-			for (int w = 0; w < NW; w++)
-				same = same && e->key[w] == k.w[w];
-			if (same) {
-				tbl.ent[slot].val = info[i];
-				ok = true;
-				break;
-			}
-		}
-		if (!ok)
+		uint64_t slot;
+		if (table_find<NW>(tbl, k, slot))
+			tbl.ent[slot].val = info[i];
+		else
 			failed++;
 	}
 	if (failed)
@@ -66,8 +53,9 @@ __global__ __launch_bounds__(TPB) void k_set_paths(Table<NW> tbl, const uint64_t
 
 template <int NW> __device__ inline bool lookup_path(const Table<NW> &tbl, const Key<NW> &k, uint64_t &info)
 {
-	uint64_t slot = key_hash<NW>(k) & tbl.mask;
-	for (uint64_t probe = 0; probe <= tbl.mask; probe++, slot = (slot + 1) & tbl.mask) {
+	uint64_t slot, lo, n;
+	probe_begin<NW>(tbl, k, slot, lo, n);
+	for (uint64_t probe = 0; probe < n; probe++, slot = probe_next(slot, lo, n)) {
 		const Entry<NW> *e = tbl.ent + slot;
 		if (NW == 1) {
 			const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(e);
@@ -266,7 +254,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_set_paths_by_index(Table<NW> tbl, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ info, uint64_t n,
                                                             Stats *stats)
 {
-	const uint64_t slots = tbl.mask + 1;
+	const uint64_t slots = tbl.slots();
 	uint32_t failed = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		if (tbl.ent[s].key[0] == KEY_EMPTY) continue;

@@ -31,19 +31,12 @@
 // and a record that finds no chunk go through table_put directly.
 #pragma once
 #include "sdt_kmer.cuh"
+#include "sdt_minimizer.cuh"
 #include "sdt_table.cuh"
 
 namespace sdt {
 
-constexpr int SK_L1BITS = 8;
-#ifndef SDT_SK_L2BITS
-#define SDT_SK_L2BITS 10
-#endif
-constexpr int SK_L2BITS = SDT_SK_L2BITS;
 constexpr int SK_POSBITS = 22 - SK_L2BITS;          // header: level-2 bucket and position share 22 bits
-constexpr int SK_NB1 = 1 << SK_L1BITS;
-constexpr int SK_NB2 = 1 << SK_L2BITS;
-constexpr int SK_NBF = SK_NB1 * SK_NB2;          // final buckets
 constexpr int SK_CAP1 = 32;                      // records per level-1 chunk
 constexpr int SK_CAP2 = 16;                      // records per level-2 chunk
 constexpr uint32_t SK_NOCHUNK = 0xFFFFFFFFu;
@@ -65,9 +58,6 @@ constexpr int SK_MAX_READ_LEN = (1 << SK_POSBITS) - 1;                          
 
 __host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 3 : (nw == 2 ? 5 : 7); }
 
-// minimizer length for a k-mer size (window w = K - m + 1 m-mers)
-__host__ __device__ inline int sk_minimizer_len(int K) { return K >= 23 ? 11 : (K >= 17 ? 9 : 7); }
-
 // longest run a record can hold: n + K - 1 bases + 2 context bases must fit the base words; a power of two
 __host__ __device__ inline int sk_max_run(int K, int nw)
 {
@@ -76,46 +66,6 @@ __host__ __device__ inline int sk_max_run(int K, int nw)
 	while (n > cap)
 		n >>= 1;
 	return n;
-}
-
-// order of the canonical m-mers (which m-mer wins is a layout detail; one 32-bit multiply: v_mul_lo_u32 is quarter rate)
-__host__ __device__ inline uint32_t sk_mmer_hash(uint32_t canon)
-{
-	uint32_t h = (canon + 0x7F4A7C15u) * 0x9E3779B1u;
-	return h ^ (h >> 15);
-}
-
-// bucket hash of a k-mer = a second mix of its smallest m-mer hash (the minimum itself is biased towards 0); the
-// buckets are its TOP bits
-__host__ __device__ inline uint32_t sk_bucket_hash(uint32_t hvmin)
-{
-	uint32_t h = (hvmin ^ 0x5BD1E995u) * 0x85EBCA77u;
-	return h ^ (h >> 13);
-}
-__host__ __device__ inline uint32_t sk_final_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS - SK_L2BITS); }
-__host__ __device__ inline uint32_t sk_l1_bucket(uint32_t bh) { return bh >> (32 - SK_L1BITS); }
-__host__ __device__ inline uint32_t sk_l2_bucket(uint32_t bh) { return (bh >> (32 - SK_L1BITS - SK_L2BITS)) & (SK_NB2 - 1); }
-
-// reverse the order of the 16 two-bit groups of a 32-bit word
-__host__ __device__ inline uint32_t sk_rev2bit32(uint32_t x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	x = __brev(x);
-#else
-	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
-	x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
-	x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
-	x = (x >> 16) | (x << 16);
-#endif
-	return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
-}
-
-// canonical m-mer (m <= 15) from its right-aligned forward value
-__host__ __device__ inline uint32_t sk_canon_mmer(uint32_t fw, int m)
-{
-	const uint32_t rc = sk_rev2bit32(fw ^ 0xAAAAAAAAu) >> (32 - 2 * m);
-	return fw < rc ? fw : rc;
 }
 
 // the m bases starting at base index p of a packed word stream (16 bases per uint32, first base in bits 31..30)

@@ -597,7 +597,7 @@ template <int NW, int SLOTS> __device__ inline uint32_t sk_lds_hash(const Key<NW
 
 // find-or-claim in the LDS table; -1: no room (full table or too many probes)
 template <int NW, int SLOTS>
-__device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
+__device__ __forceinline__ int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
 {
 	uint32_t s = sk_lds_hash<NW, SLOTS>(key);
 	int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
@@ -628,7 +628,7 @@ __device__ inline int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill,
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // (a system-scope fence here cost 20x: it invalidates L2)
 #pragma unroll
 			for (int i = 1; i < NW; i++)
-				same = same && (*(volatile unsigned long long *)&s_key[i * SLOTS + s] == key.w[i]);
+				same = same && (__hip_atomic_load(&s_key[i * SLOTS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[i]);     // (a volatile access stays a FLAT load: the address space is not inferred through it)
 		}
 		if (same)
 			return (int)s;
@@ -672,15 +672,37 @@ __device__ inline uint64_t sk_weighted_val(uint32_t w, uint32_t prev, uint32_t n
 
 constexpr uint32_t SK_CNT_MAX_SINCE = 65535;     // k-mers counted into the LDS table between two clears at most (16-bit fields)
 
+// ---- the node log: what a flush of k_sk_count's LDS table leaves behind (round 5) ---------------------------------------
+// Until round 4 a flush MERGED every LDS node into the flat node table: a random 16..48-byte read-modify-write of HBM per distinct
+// key and generation, 2.5 generations per key, 5x the compulsory traffic of the stage and a memory-side compare-and-swap per new
+// key.  Now a flush APPENDS: the nodes of a bucket become one contiguous SEGMENT of (key, val[, ordinal])
+// entries in a log -- coalesced stores, no load, no atomic on a node -- and a descriptor (where, which bucket, how many).  All
+// segments of a bucket are merged once, in LDS, by k_bm_finalize (sdt_bm_kernels.cuh), which writes the bucket's nodes as a small
+// open-addressing table of their own: the bucket-major layout of sdt_table.cuh.
+struct LogDesc {
+	uint64_t ptr;              // device address of the segment's first entry
+	uint32_t bucket;           // final bucket
+	uint32_t count;            // entries
+};
+struct SkLog {                 // the slab a launch appends to
+	uint64_t *ent;             // entries: LW = NW + 1 (+ 1 with ordinals) words each
+	uint64_t ent_cap;          // entries
+	LogDesc *desc;
+	uint64_t desc_cap;
+	unsigned long long *ctl;   // [0] entries handed out, [1] descriptors handed out
+};
+constexpr int SK_LOG_ALIGN = 8;        // a segment starts at a multiple of this many entries (whole 128-byte lines)
+constexpr int SK_CNT_MAX_BUCKETS = 64; // final buckets a work item may hold (sdt_count_plan.h packs small neighbours within this span)
+
 // (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU.  8 waves per SIMD also
 // means 78 usable SCALAR registers -- 800 per SIMD in granules of 16, 16 of every wave's reserved -- and this kernel keeps
 // about ninety uniform values: the overflow lives in lanes of vector registers.  Raising the scalar budget by hand
 // (amdgpu_waves_per_eu(4, 8) + amdgpu_num_vgpr(32) + amdgpu_num_sgpr(96)) removed every spill and cost the second workgroup
 // per CU: 172 -> 251 ms per step on the 200 M-read workload.)
 template <int NW, bool TRACK>
-__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint2 *__restrict__ items,
+__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint4 *__restrict__ items,
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
-                                                         Table<NW> tbl, Stats *stats)
+                                                         SkLog lg, Stats *stats)
 {
 	using G = SkCntGeo<NW, TRACK>;
 	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = G::SLOTS;
@@ -690,6 +712,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
 	constexpr int NWAVES = TR / 64;
 	constexpr uint32_t REP = G::REP, REP_EMPTY = 0xFFFFFFFFu;
+	constexpr int LW = NW + 1 + (TRACK ? 1 : 0);     // words of a log entry
 	extern __shared__ unsigned long long sm64[];
 	// (the tile's small arrays first: every base below 64 KB is an immediate offset of a ds instruction, not a register)
 	unsigned long long *s_h0 = sm64;                                     // TR: headers (TRACK: the smallest among a record's duplicates)
@@ -702,13 +725,14 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 	unsigned long long *s_key = (unsigned long long *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);     // NW x SLOTS, word-major
 	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
 	uint32_t *s_f = (uint32_t *)(s_ord + (TRACK ? SLOTS : 0));           // 5 x SLOTS
-	__shared__ uint32_t s_fillc[2], s_item, s_spilled;       // s_fillc: keys in the LDS table = the sum of two counters, see phase D
-	// statistics of the workgroup (claimed, failed, merges, spills, gens, k-mers, records, distinct records, their k-mers): in LDS, not
-	// in nine registers per lane that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
-	enum { ST_CLAIMED, ST_FAILED, ST_MERGES, ST_SPILLS, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
+	__shared__ uint32_t s_fillc[2], s_item, s_full;          // s_fillc: keys in the LDS table = the sum of two counters, see phase D
+	// statistics of the workgroup: in LDS, not in registers that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
+	enum { ST_FAILED, ST_MERGES, ST_RETRIES, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
 	__shared__ uint32_t s_stat[ST_N];
 	__shared__ uint32_t s_ent[3 * (G::TILE / SK_CAP2)];      // ring of list entries: the tiles t, t + 1, t + 2 (see below)
 	__shared__ unsigned long long s_wsum[NWAVES];
+	__shared__ uint32_t s_bcnt[SK_CNT_MAX_BUCKETS], s_boff[SK_CNT_MAX_BUCKETS];     // flush: nodes per bucket of the item, their offsets in the segment
+	__shared__ unsigned long long s_seg;                     // flush: first entry of the segment (~0: the log is full)
 	const int tid = threadIdx.x;
 	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
 		s_key[i] = KEY_EMPTY;
@@ -720,10 +744,14 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		s_words[tid] = 0;
 	if (tid < TAIL_PAD)
 		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
-	if (tid == 0)
+	if (tid == 0) {
 		s_fillc[0] = s_fillc[1] = 0;
+		s_full = 0;
+	}
 	if (tid < ST_N)
 		s_stat[tid] = 0;
+	if (tid < SK_CNT_MAX_BUCKETS)
+		s_bcnt[tid] = 0;
 	uint32_t *words = s_words + LDS_LEAD;
 #ifdef SDT_SK_TICKS
 	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
@@ -731,55 +759,24 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #else
 #define SK_TICK(i) do { } while (0)
 #endif
-	// The owned flush of 1-word keys works on registers: every lane takes its PER slots out of LDS, issues all node-table loads, then
-	// merges (flush_finish).  (An experiment that finished the merges a tile later -- to hide the round trip behind the next tile's
-	// phases A-C -- measured no gain, the flushes are bound by HBM traffic, and was removed: profiles/r3/count_kernel_experiments.md.)
 	constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
-	Key<NW> mk[PER];
-	uint64_t madd[PER], mord[TRACK ? PER : 1];       // (the slot of a key is hashed again when the flush is finished: two registers
-	bool have[PER];                                  //  per key less to carry across a tile)
-	EntSnap<NW, TRACK> sn[PER];
 	uint32_t ko = 0, km = 0;                         // (uniform) the two key counters as of the last barrier: the one that stands still in the coming round; the one the round adds to (bit 31: which)
 	uint32_t room_shift = NW == 1 ? 2u : 1u;          // (uniform) a round of phase D takes 1, 2 or 4 k-mers per free slot of the LDS table
-	bool stores_pending = false;                     // (uniform) plain stores of an owned flush may still be in flight
-	auto flush_finish = [&]() {
-		uint32_t claimed = 0, failed = 0, merges = 0;
-#pragma unroll
-		for (int p = 0; p < PER; p++)
-			if (have[p]) {
-				merges++;
-				if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], key_hash<NW>(mk[p]) & tbl.mask, sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
-					failed++;
-			}
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) {
-			claimed += __shfl_down(claimed, d);
-			failed += __shfl_down(failed, d);
-			merges += __shfl_down(merges, d);
-		}
-		if ((tid & 63) == 0) {
-			if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
-			if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
-			if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
-		}
-		stores_pending = true;
-	};
-	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
-	// its own), handed out first come first served
+	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and logged on
+	// its own; small neighbours share one), handed out first come first served
 	for (;;) {
-		if (tid == 0) {
+		if (tid == 0)
 			s_item = item0 + atomicAdd(next_item, 1u);
-			s_spilled = 0;
-		}
 		__syncthreads();
 		const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);     // (uniform values belong in scalar registers)
 		__syncthreads();
 		if (item >= item1)
 			break;
-		const uint2 it = items[item];
+		const uint4 it = items[item];                // c0, c1 | whole, first and last final bucket (sdt_count_plan.h)
 		const uint32_t ity = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
 		const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), c1 = ity & 0x7FFFFFFFu;
-		const bool whole = (ity >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
+		const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z);          // the item's final buckets: f0 .. f0 + nbk - 1
+		const uint32_t nbk = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w) - f0 + 1u;
 		// Chunk id -> record are two dependent memory round trips per tile, and on this kernel's 64-register budget nothing can
 		// wait in registers across the counting loop: the compiler spilled every such value (the next record, its chunk id, even
 		// one prefetch dword), i.e. waited for the load at once -- with both trips in the open phases A-C were a third of the
@@ -924,148 +921,110 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 			}
 			__syncthreads();
 			SK_TICK(1);
-			// ---- D: rounds of up to 4 k-mers per free slot: barriers are what this loop pays for (a k-mer that does find the table
-			// full takes the direct path)
+			// ---- D: rounds of up to 4 k-mers per free slot: barriers are what this loop pays for.  A lane handles the k-mers
+			// tid, tid + TPB, ... of the tile and keeps its own position: a k-mer that finds the table full stays where it is,
+			// the table is flushed, and the round is taken up again (rounds 1-4 sent such k-mers to the node table one by one)
 			const bool last_tile = cb + CPT >= c1;
 			tile_no++;
+			uint32_t myq = (uint32_t)tid;
 			for (uint32_t qb = 0;;) {
 				if (want_flush) {
 					SK_TICK(2);
-					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
-					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise.  (The ONE place where it is
-					// done -- before a tile that could overflow the fields, between rounds when the table is half full, after the
-					// item's last round: three copies of the merge code cost the hot loop its registers.)
-					const bool owned = whole && __builtin_amdgcn_readfirstlane((int)s_spilled) == 0;
-					uint32_t claimed = 0, failed = 0, merges = 0;
-					// (the stores of the previous flush were left in flight: they must have landed before this one reads)
-					if (stores_pending) {
-						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-						__syncthreads();
-						stores_pending = false;
-					}
-					if (owned && (NW > 1 || TRACK) && SDT_SK_SEQ_FLUSH) {
-						// multi-word keys, keys with ordinals: one slot at a time -- two keys, two snapshots and two addresses in flight did not fit the 64
-						// registers, and a spilled snapshot is a load that is waited for at once (see the 1-word path below)
-#pragma unroll 1
-						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-							if (s_key[i] == KEY_EMPTY)
-								continue;
+					// ---- flush: every LDS node becomes an entry of its bucket's segment in the log, the table is cleared.
+					// (the ONE place where it is done -- before a tile that could overflow the fields, between rounds when the table
+					// is half full or a k-mer found no slot, after the item's last round)
+					bool have[PER];
+					uint32_t rel[PER], rank[PER];
+#pragma unroll
+					for (int p = 0; p < PER; p++) {
+						const int i = tid + p * SK_CNT_TPB;
+						have[p] = i < SLOTS && s_key[i] != KEY_EMPTY;
+						rel[p] = 0;
+						rank[p] = 0;
+						if (nbk == 1u) {                     // one bucket: ranks by ballot, one LDS atomic per wave
+							const unsigned long long bal = __ballot(have[p]);
+							const uint32_t below = (uint32_t)__popcll(bal & ((1ULL << (tid & 63)) - 1ULL));
+							uint32_t base = 0;
+							if ((tid & 63) == 0 && bal)
+								base = atomicAdd(&s_bcnt[0], (uint32_t)__popcll(bal));
+							rank[p] = (uint32_t)__shfl((int)base, 0) + below;
+						} else if (have[p]) {                // neighbours that share the item: the key says which one it belongs to
 							Key<NW> key;
 							key.w[0] = s_key[i];
 #pragma unroll
 							for (int wv = 1; wv < NW; wv++)
 								key.w[wv] = s_key[wv * SLOTS + i];
-							const uint64_t add = sk_lds_val(&s_f[5 * i]);
-							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
-							s_key[i] = KEY_EMPTY;
-#pragma unroll
-							for (int f = 0; f < 5; f++)
-								s_f[5 * i + f] = 0;
-							if (TRACK) s_ord[i] = ORD_NONE;
-							const uint64_t slot = key_hash<NW>(key) & tbl.mask;
-							merges++;
-							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, NW == 2 && SDT_SK_CLAIM2_BELOW > 0 && (add >> 48) <= SDT_SK_CLAIM2_BELOW), add, 0u, claimed, ord))
-								failed++;
-						}
-#pragma unroll
-						for (int d = 32; d > 0; d >>= 1) {
-							claimed += __shfl_down(claimed, d);
-							failed += __shfl_down(failed, d);
-							merges += __shfl_down(merges, d);
-						}
-						if ((tid & 63) == 0) {
-							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
-							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
-							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
-						}
-						stores_pending = true;
-					} else if (owned) {
-						// this lane's PER slots: everything out of LDS, all global loads issued, then (now or a tile later) the merges
-#pragma unroll
-						for (int p = 0; p < PER; p++) {
-							const int i = tid + p * SK_CNT_TPB;
-							have[p] = i < SLOTS && s_key[i] != KEY_EMPTY;
-							if (have[p]) {
-								mk[p].w[0] = s_key[i];
-#pragma unroll
-								for (int wv = 1; wv < NW; wv++)
-									mk[p].w[wv] = s_key[wv * SLOTS + i];
-								madd[p] = sk_lds_val(&s_f[5 * i]);
-								if (TRACK) mord[p] = (uint64_t)s_ord[i];
-								s_key[i] = KEY_EMPTY;
-#pragma unroll
-								for (int f = 0; f < 5; f++)
-									s_f[5 * i + f] = 0;
-								if (TRACK) s_ord[i] = ORD_NONE;
-							}
-						}
-						__builtin_amdgcn_sched_barrier(0);       // (hashes first, then all loads, then the merges: interleaved by the
-						if (NW == 1 && SDT_SK_LOAD16) {          //  scheduler the snapshots were spilled, i.e. waited for one by one)
-							// key and val of a 16-byte entry with ONE agent-scope load (two 8-byte ones are two requests to the memory side)
-							typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-							u32x4 raw[PER];
-#pragma unroll
-							for (int p = 0; p < PER; p++) {
-								const Entry<NW> *e = tbl.ent + (have[p] ? key_hash<NW>(mk[p]) & tbl.mask : 0);
-								asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[p]) : "v"(e) : "memory");
-							}
-							asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]) :: "memory");
-#pragma unroll
-							for (int p = 1; p < PER; p++)
-								asm volatile("" : "+v"(raw[p]) :: "memory");
-#pragma unroll
-							for (int p = 0; p < PER; p++) {
-								sn[p].k[0] = ((uint64_t)raw[p].y << 32) | raw[p].x;
-								sn[p].v = ((uint64_t)raw[p].w << 32) | raw[p].z;
-								sn[p].f = ORD_NONE;
-								sn[p].won = false;
-							}
-						} else {
-#pragma unroll
-						for (int p = 0; p < PER; p++)
-							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
-								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
-						}
-						__builtin_amdgcn_sched_barrier(0);
-						flush_finish();
-					} else {
-						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-							const uint64_t k0 = s_key[i];
-							if (k0 == KEY_EMPTY)
-								continue;
-							Key<NW> key;
-							key.w[0] = k0;
-#pragma unroll
-							for (int wv = 1; wv < NW; wv++)
-								key.w[wv] = s_key[wv * SLOTS + i];
-							merges++;
-							const uint64_t add = sk_lds_val(&s_f[5 * i]);
-							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
-							if (!table_merge<NW>(tbl, key, add, 0u, claimed, ord))
-								failed++;
-							s_key[i] = KEY_EMPTY;
-#pragma unroll
-							for (int f = 0; f < 5; f++)
-								s_f[5 * i + f] = 0;
-							if (TRACK) s_ord[i] = ORD_NONE;
-						}
-#pragma unroll
-						for (int d = 32; d > 0; d >>= 1) {
-							claimed += __shfl_down(claimed, d);
-							failed += __shfl_down(failed, d);
-							merges += __shfl_down(merges, d);
-						}
-						if ((tid & 63) == 0) {
-							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
-							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
-#ifdef SDT_SK_SPLIT_MERGE_STAT                       // (measurement build: the merges by compare-and-swap are reported as `lds_spills`)
-							if (merges) atomicAdd(&s_stat[ST_SPILLS], merges);
-#else
-							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
-#endif
+							uint32_t r = key_final_bucket<NW>(key, K) - f0;
+							if (r >= nbk) r = 0;             // (cannot happen: every k-mer of the item lies in one of its buckets)
+							rel[p] = r;
+							rank[p] = atomicAdd(&s_bcnt[r], 1u);
 						}
 					}
 					__syncthreads();
+					if (tid < 64) {
+						// exclusive scan of the bucket counts by one wave; the segment and the descriptors come out of the log's cursors
+						const uint32_t cnt = (uint32_t)tid < nbk ? s_bcnt[tid] : 0u;
+						uint32_t x = cnt;
+#pragma unroll
+						for (int d = 1; d < 64; d <<= 1) {
+							const uint32_t y = __shfl_up(x, d);
+							if (tid >= d)
+								x += y;
+						}
+						const uint32_t total_ent = (uint32_t)__shfl((int)x, 63);
+						const unsigned long long nz = __ballot(cnt != 0u);
+						unsigned long long seg = 0, dseg = 0;
+						if (tid == 0 && total_ent) {
+							const uint32_t al = (total_ent + (uint32_t)SK_LOG_ALIGN - 1u) & ~((uint32_t)SK_LOG_ALIGN - 1u);
+							seg = atomicAdd(&lg.ctl[0], (unsigned long long)al);
+							dseg = atomicAdd(&lg.ctl[1], (unsigned long long)__popcll(nz));
+							if (seg + al > lg.ent_cap || dseg + (unsigned long long)__popcll(nz) > lg.desc_cap)
+								seg = ~0ULL;                 // the host keeps room for every k-mer of a launch: never expected
+							s_seg = seg;
+							s_stat[ST_MERGES] += total_ent;
+							if (seg == ~0ULL) s_stat[ST_FAILED] += total_ent;
+						}
+						seg = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(seg >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)seg, 0);
+						dseg = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(dseg >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)dseg, 0);
+						s_boff[tid] = x - cnt;
+						if (cnt && seg != ~0ULL) {
+							LogDesc d;
+							d.ptr = (uint64_t)(lg.ent + (size_t)(seg + (x - cnt)) * LW);
+							d.bucket = f0 + (uint32_t)tid;
+							d.count = cnt;
+							lg.desc[dseg + (unsigned long long)__popcll(nz & ((1ULL << tid) - 1ULL))] = d;
+						}
+						if (tid == 0)
+							s_full = 0;
+					}
+					__syncthreads();
+					const unsigned long long seg = s_seg;
+#pragma unroll
+					for (int p = 0; p < PER; p++) {
+						const int i = tid + p * SK_CNT_TPB;
+						if (have[p]) {
+							if (seg != ~0ULL) {
+								uint64_t *dst = lg.ent + (size_t)(seg + s_boff[rel[p]] + rank[p]) * LW;
+								const uint64_t val = sk_lds_val(&s_f[5 * i]);
+								if (NW == 1 && !TRACK) {
+									*reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(s_key[i], val);       // (16-byte entries, 16-byte aligned)
+								} else {
+#pragma unroll
+									for (int wv = 0; wv < NW; wv++)
+										dst[wv] = s_key[wv * SLOTS + i];
+									dst[NW] = val;
+									if (TRACK) dst[NW + 1] = (uint64_t)s_ord[i];
+								}
+							}
+							s_key[i] = KEY_EMPTY;
+#pragma unroll
+							for (int f = 0; f < 5; f++)
+								s_f[5 * i + f] = 0;
+							if (TRACK) s_ord[i] = ORD_NONE;
+						}
+					}
+					if (tid < SK_CNT_MAX_BUCKETS)
+						s_bcnt[tid] = 0;
 					if (tid == 0) {
 						s_fillc[0] = s_fillc[1] = 0;
 						if (!(last_tile && qb >= total)) s_stat[ST_GENS]++;
@@ -1088,7 +1047,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 				uint32_t *const fillc = &s_fillc[km >> 31];
 				const uint32_t maxfill = MAXFILL - ko;
 				const uint32_t qe = qb + room < total ? qb + room : total;
-				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
+				for (; myq < qe; myq += SK_CNT_TPB) {
+					const uint32_t q = myq;
 					uint32_t ci = s_idx[q >> 4];             // the record of k-mer q & ~15; q's own is at most a few records on
 					while (s_pre[ci + 1] <= q)
 						ci++;
@@ -1101,44 +1061,38 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					uint32_t prev, next;
 					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
 					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill);
-					if (s >= 0) {
-						sk_lds_update(s_f, s, prev, next, wgt);
-						if (TRACK) {
-							const uint64_t ord = (sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j);
-							if (ord < *(volatile unsigned long long *)&s_ord[s])
-								atomicMin(&s_ord[s], (unsigned long long)ord);
-						}
-					} else {
-						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
-						// (the plain stores of the last owned flush may still be in flight: this wave's own must have landed before its
-						// atomics touch the table.  Other waves' are not waited for here -- they were issued at least a barrier and a round
-						// of LDS work earlier; the next flush waits for all of them)
-						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-						const uint64_t ord = TRACK ? ((sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j)) : ORD_NONE;
-						uint32_t cl = 0;
-						atomicAdd(&s_stat[ST_SPILLS], 1u);
-						if (!table_merge<NW>(tbl, key, sk_weighted_val(wgt, prev, next), 0u, cl, ord))
-							atomicAdd(&s_stat[ST_FAILED], 1u);
-						if (cl)
-							atomicAdd(&s_stat[ST_CLAIMED], cl);
+					if (s < 0) {
+						s_full = 1;                      // no slot: this lane waits here for the flush (its later k-mers wait with it)
+						break;
+					}
+					sk_lds_update(s_f, s, prev, next, wgt);
+					if (TRACK) {
+						const uint64_t ord = (sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j);
+						if (ord < *(volatile unsigned long long *)&s_ord[s])
+							atomicMin(&s_ord[s], (unsigned long long)ord);
 					}
 				}
 				__syncthreads();
 				const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)*fillc);     // (nobody adds to it before the round after next)
+				const bool full = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&s_full) != 0;      // (cleared inside the flush it asks for, behind a barrier)
 				const uint32_t fill1 = cur + ko;
 				km = ko | (~km & 0x80000000u);               // the next round adds to the other counter
 				ko = cur;
 				// k-mers per free slot in a round follow the data: a round that used more than half of the free slots halves them (the
-				// next one might have run out: its k-mers would take the direct path and cost the item its plain merges), a full
-				// round that used less than an eighth doubles them
-				if (NW > 1) {                                // (1-word keys, K <= 31: 4 per slot has always been enough, and the bookkeeping costs 5 %)
-					if ((fill1 - fill0) * 2u > MAXFILL - fill0)
+				// next one might have run out), a full round that used less than an eighth doubles them
+				if (NW > 1 || full) {                        // (1-word keys, K <= 31: 4 per slot has always been enough, and the bookkeeping costs 5 %)
+					if (full || (fill1 - fill0) * 2u > MAXFILL - fill0)
 						room_shift = room_shift ? room_shift - 1u : 0u;
 					else if (qe - qb == room && (fill1 - fill0) * 8u < MAXFILL - fill0 && room_shift < 2u)
 						room_shift++;
 				}
-				qb = qe;
-				want_flush = (qb >= total && last_tile) || fill1 >= FLUSH_AT;     // the item is done: the table must be clear for the next one
+				if (full) {
+					if (tid == 0) s_stat[ST_RETRIES]++;
+					want_flush = true;                       // ... and the same stretch again: the lanes that were done with it have nothing left in it
+				} else {
+					qb = qe;
+					want_flush = (qb >= total && last_tile) || fill1 >= FLUSH_AT;     // the item is done: the table must be clear for the next one
+				}
 			}
 			SK_TICK(2);
 		}
@@ -1146,10 +1100,9 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #undef SK_TICK
 	__syncthreads();
 	if (tid == 0) {
-		if (s_stat[ST_CLAIMED]) atomicAdd(&stats->distinct, (unsigned long long)s_stat[ST_CLAIMED]);
 		if (s_stat[ST_FAILED]) atomicAdd(&stats->probe_fail, (unsigned long long)s_stat[ST_FAILED]);
 		if (s_stat[ST_MERGES]) atomicAdd(&stats->sk_merges, (unsigned long long)s_stat[ST_MERGES]);
-		if (s_stat[ST_SPILLS]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_SPILLS]);
+		if (s_stat[ST_RETRIES]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_RETRIES]);
 		if (s_stat[ST_GENS]) atomicAdd(&stats->sk_gens, (unsigned long long)s_stat[ST_GENS]);
 		if (s_stat[ST_KMERS]) {
 			atomicAdd(&stats->kmers, (unsigned long long)s_stat[ST_KMERS]);

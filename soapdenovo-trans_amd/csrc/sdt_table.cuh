@@ -25,6 +25,7 @@
 // so the atomics, not the plain loads, are authoritative.
 #pragma once
 #include "sdt_kmer.cuh"
+#include "sdt_minimizer.cuh"
 
 namespace sdt {
 
@@ -50,12 +51,68 @@ template <> struct alignas(16) Entry<4> {   // 48 B: three dwordx4 loads
 	uint64_t pad;
 };
 
+// Bucket-major layout (round 5; what pass 1 of the locality pipeline leaves, sdt_bm_kernels.cuh): the nodes of one minimizer
+// bucket (SK_NBF of them) lie together -- `parts` small open-addressing tables of `ssub` slots each, one behind the other from
+// slot `base` on; a key's table is chosen by the high half of its hash, its home slot by the low half, probing wraps inside the
+// table.  Entry / aux / first are the flat layout's, so every scan (delow, mark, export, layout keys ...) is the same loop over
+// [0, nslots); a look-up by key needs the key's bucket, i.e. its minimizer (key_final_bucket: w m-mer hashes).  Why: the keys
+// a workgroup of k_sk_count merges are the keys of ONE bucket, so the whole table is built by streaming -- no random
+// read-modify-write of HBM per distinct key and generation.
+struct BmDir {
+	uint64_t base;        // first slot of the bucket's tables
+	uint32_t ssub;        // slots per table (a multiple of 8)
+	uint32_t parts;       // tables (0: the bucket is empty)
+};
+
 template <int NW> struct Table {
 	Entry<NW> *ent;
 	uint32_t *aux;
-	uint64_t mask;        // slots - 1 (slots is a power of two)
+	uint64_t mask;        // flat layout: slots - 1 (slots is a power of two)
 	uint64_t *first;      // optional (SDT_FLAG_TRACK_FIRST): smallest ordinal of an occurrence of the key, ~0 = none
+	const BmDir *dir;     // bucket-major layout: SK_NBF directory entries (nullptr: flat)
+	uint64_t nslots;      // bucket-major layout: slots in use
+	int K;                // bucket-major layout: the k-mer size (look-ups compute the minimizer)
+	__host__ __device__ uint64_t slots() const { return dir ? nslots : mask + 1; }
 };
+
+// Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times; n == 0:
+// the key's bucket is empty (bucket-major) -- the key is not there.
+template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const Key<NW> &key, uint64_t &slot, uint64_t &lo, uint64_t &n)
+{
+	const uint64_t h = key_hash<NW>(key);
+	if (!t.dir) {
+		lo = 0;
+		n = t.mask + 1;
+		slot = h & t.mask;
+		return;
+	}
+	const BmDir d = t.dir[key_final_bucket<NW>(key, t.K)];
+	n = d.parts ? d.ssub : 0;
+	lo = d.base + (uint64_t)__umulhi((uint32_t)(h >> 32), d.parts) * d.ssub;
+	slot = lo + __umulhi((uint32_t)h, d.ssub);
+}
+__device__ inline uint64_t probe_next(uint64_t slot, uint64_t lo, uint64_t n) { return slot + 1 == lo + n ? lo : slot + 1; }
+
+// read-only look-up in either layout: the slot of `key`, or false
+template <int NW> __device__ inline bool table_find(const Table<NW> &t, const Key<NW> &key, uint64_t &slot_out)
+{
+	uint64_t slot, lo, n;
+	probe_begin<NW>(t, key, slot, lo, n);
+	for (uint64_t probe = 0; probe < n; probe++, slot = probe_next(slot, lo, n)) {
+		const Entry<NW> *e = t.ent + slot;
+		if (e->key[0] == KEY_EMPTY)
+			return false;
+		bool same = true;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			same = same && e->key[w] == key.w[w];
+		if (same) {
+			slot_out = slot;
+			return true;
+		}
+	}
+	return false;
+}
 
 constexpr uint64_t ORD_NONE = ~0ULL;
 

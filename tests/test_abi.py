@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/sdt_gpu.h but not exported"
     assert sorted(pkg.ABI_SYMBOLS) == syms, "python binding table and header disagree"
-    assert lib.sdt_gpu_abi_version() == 6
+    assert lib.sdt_gpu_abi_version() == 7
 
 
 def test_is_gfx950_code_object(pkg):

@@ -1,14 +1,16 @@
 """CPU: the work items and launches of the count stage (csrc/sdt_count_plan.h through sdt_sk_plan_count_items) -- the host
 computation between the level-2 scatter and k_sk_count.  An item is a run of the level-2 chunk list; the kernel's workgroups
-take items first come first served and merge WITHOUT atomics when the item is flagged as holding whole buckets only, so the
-plan must be airtight: every chunk in exactly one item, a flagged item made of complete buckets, no item across two launches.
+take items first come first served and file an item's nodes in the node log under the item's final buckets (rounds 3-4: they
+merged WITHOUT atomics when the item was flagged as holding whole buckets only), so the plan must be airtight: every chunk in
+exactly one item, a flagged item made of complete buckets, the buckets an item names exactly the buckets of its chunks -- all in one
+level-1 bucket and a span of 64 --, no item across two launches.
 Stands where the reference hands a batch to its threads (prlHashReads.c:312-336); the kernels it feeds are tested on the GPU."""
 import numpy as np
 import pytest
 
 import __graft_entry__ as ge
 
-PACK, ITEM, WHOLE = 64, 1024, 0x80000000
+PACK, ITEM, WHOLE, SPAN, L2 = 64, 1024, 0x80000000, 64, 1024
 
 
 def _lists(rng, nb, kind):
@@ -40,6 +42,7 @@ def test_every_chunk_in_exactly_one_item(kind, first_limit, limit):
     c0 = items[:, 0].astype(np.int64)
     c1 = (items[:, 1] & ~np.uint32(WHOLE)).astype(np.int64)
     whole = (items[:, 1] & np.uint32(WHOLE)) != 0
+    f0, f1 = items[:, 2].astype(np.int64), items[:, 3].astype(np.int64)
     total = int(off[-1])
     # within a launch the items come largest first (by power-of-two size class, list order within a class) ...
     for li in range(len(lk)):
@@ -49,7 +52,7 @@ def test_every_chunk_in_exactly_one_item(kind, first_limit, limit):
         for k in np.unique(cls):
             assert (np.diff(c0[a:b][cls == k]) > 0).all(), "list order within a size class"
         o = a + np.argsort(c0[a:b], kind="stable")
-        c0[a:b], c1[a:b], whole[a:b] = c0[o], c1[o], whole[o]
+        c0[a:b], c1[a:b], whole[a:b], f0[a:b], f1[a:b] = c0[o], c1[o], whole[o], f0[o], f1[o]
     # ... and, put back into list order, they tile the chunk list
     if total == 0:
         assert len(items) == 0
@@ -59,8 +62,11 @@ def test_every_chunk_in_exactly_one_item(kind, first_limit, limit):
     bucket_of = np.repeat(np.arange(nb), np.diff(off.astype(np.int64)))
     starts = set(off[:-1][np.diff(off.astype(np.int64)) > 0].tolist())
     ends = set(off[1:][np.diff(off.astype(np.int64)) > 0].tolist())
-    for a, b, w in zip(c0, c1, whole):
+    for a, b, w, fa, fb in zip(c0, c1, whole, f0, f1):
         nbk = len(np.unique(bucket_of[a:b]))
+        # the buckets the item names are the buckets of its chunks: k_sk_count files every node under first bucket + offset
+        assert fa == bucket_of[a] and fb == bucket_of[b - 1], "an item knows its first and last final bucket"
+        assert fb - fa < SPAN and fa // L2 == fb // L2, "an item stays inside one level-1 bucket and a span of 64 final buckets"
         if w:
             assert a in starts and b in ends, "a flagged item must be made of complete buckets"
             assert b - a <= ITEM
@@ -93,12 +99,26 @@ def test_small_neighbours_share_an_item_and_big_ones_do_not():
     off[1:] = np.cumsum(n)
     kp = (off.astype(np.uint64) * np.uint64(100))
     items, first, lk = pkg.count_plan(off, kp, 1 << 62, 1 << 62)
-    got = [(int(a), int(b & 0x7FFFFFFF), bool(b & WHOLE)) for a, b in items]
+    got = [(int(a), int(b & 0x7FFFFFFF), bool(b & WHOLE)) for a, b, _, _ in items]
+    assert [(int(x), int(y)) for _, _, x, y in items] == [(8, 8), (8, 8), (6, 7), (0, 5), (9, 10)]
     # 3 + 5 + 7 = 15 chunks share the first item; 60 more would make 75 > 64: its own item, which 2 more (62) may join;
     # the 2000-chunk bucket is cut in two pieces, not flagged; the two single chunks behind it share the last item
     # (handed out largest first: 1024 and 976 chunks, then 62, 15, 2)
     assert got == [(77, 1101, False), (1101, 2077, False), (15, 77, True), (0, 15, True), (2077, 2079, True)]
     assert len(lk) == 1 and int(lk[0]) == int(kp[-1])
+
+
+def test_sparse_small_buckets_do_not_share_an_item_across_a_span_or_a_level_one_bucket():
+    pkg = ge.load_package()
+    n = np.zeros(3000, dtype=np.int64)
+    n[[0, 63, 64, 1000, 1023, 1024, 1030, 2047, 2048]] = 1
+    off = np.zeros(len(n) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(n)
+    kp = (off.astype(np.uint64) * np.uint64(100))
+    items, first, lk = pkg.count_plan(off, kp, 1 << 62, 1 << 62)
+    spans = sorted((int(x), int(y)) for _, _, x, y in items)
+    # 0 and 63 share (span 64), 64 starts anew; 1000 and 1023 share, 1024 is another level-1 bucket; 1030 joins it; 2047 and 2048 part
+    assert spans == [(0, 63), (64, 64), (1000, 1023), (1024, 1030), (2047, 2047), (2048, 2048)]
 
 
 def test_bad_arguments():
