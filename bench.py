@@ -348,7 +348,7 @@ def main():
     stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
     log("table slots:", g.table_slots())
-    log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms],
+    log("stage ms per step [direct, sk scatter, sk split, sk count, sk fold]:", [round(x / args.steps, 2) for x in stage_ms],
         {k: v for k, v in sk_counters.items() if "ticks" not in k or v})
     ms_per_step = dt / args.steps * 1e3
     value = kmers_total * args.steps / dt
@@ -368,12 +368,14 @@ def main():
                 "traffic_unit": "HBM bytes per launch, a LOWER bound (FETCH_SIZE x2 for the record-streaming kernels + WRITE_SIZE PMC passes of this workload, this build; FETCH_SIZE under-reports wide coalesced reads on gfx950)",
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(B * per_launch_kmers),
-                "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records + k_sk_count (every k-mer goes through "
-                           "all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
+                "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records + k_sk_count + the fold of the node log "
+                           "(descriptor sort + k_bm_finalize; every k-mer goes through all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
                 "bytes_per_kmer": round(B, 3), "launches": int(batches * args.steps),
                 "avg_launch_ms": round(kms / (batches * args.steps), 4), "kernel_ms_per_step": round(kms / args.steps, 3),
                 "stage_ms_per_step": {"scatter": round(stage_ms[1] / args.steps, 2), "split": round(stage_ms[2] / args.steps, 2),
-                                      "count": round(stage_ms[3] / args.steps, 2), "direct": round(stage_ms[0] / args.steps, 2)},
+                                      "count": round(stage_ms[3] / args.steps, 2), "fold": round(stage_ms[4] / args.steps, 2),
+                                      "direct": round(stage_ms[0] / args.steps, 2)},
+                "node_table": g.table_info(),
                 "merges_per_kmer": round(sk_counters["merges"] / max(local_kmers, 1), 4) if pipeline else None}
         if sharded_path:
             roof["rank"] = 0
@@ -492,7 +494,7 @@ def main():
                                      "h2d_alone_GBps": round(hw.numel() * 4 / h2d_s / 1e9, 2),
                                      "frac_of_h2d_bound": round(h2d_s / med, 3),
                                      "wall_ms": round(med * 1e3, 2), "walls_ms": [round(w * 1e3, 2) for w in walls],
-                                     "stage_ms": dict(zip(("direct", "scatter", "split", "count"), pcie_stage)),
+                                     "stage_ms": dict(zip(("direct", "scatter", "split", "count", "fold"), pcie_stage)),
                                      "ragged": None if not rag_walls else {
                                          "value": nfull * rag_kmers_per_batch / min(rag_walls), "unit": "kmers/s", "reads": nfull * batch,
                                          "walls_ms": [round(w * 1e3, 2) for w in rag_walls],

@@ -410,7 +410,8 @@ int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches,
 #define SDT_STAGE_SK_SCATTER  1   /* k_sk_scatter_reads: chop + minimizers + level-1 scatter */
 #define SDT_STAGE_SK_SPLIT    2   /* chunk lists + k_sk_scatter_records (level 2) */
 #define SDT_STAGE_SK_COUNT    3   /* k_sk_count: LDS counting + merges */
-#define SDT_NSTAGES           4
+#define SDT_STAGE_SK_FOLD     4   /* the node log folded into the bucket-major table: descriptor sort + k_bm_finalize */
+#define SDT_NSTAGES           5
 #define SDT_NCOUNTERS         20   /* [16] distinct records of the count stage's tiles, [17] records (level-2), [18] k-mers of the distinct records, [19] reserved */
 int sdt_gpu_stage_times(sdt_ctx *ctx, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS]);
 /* the device table's slot hash of a canonical key (host-callable, identical to the device function) */

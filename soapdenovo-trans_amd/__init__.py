@@ -525,8 +525,8 @@ class PregraphGPU:
         return ms.value, launches.value, kmers.value
 
     def stage_times(self):
-        """(ms per stage [direct, sk scatter, sk split, sk count], pipeline counters) since the last kernel_time(reset=True)"""
-        ms = (ctypes.c_double * 4)()
+        """(ms per stage [direct, sk scatter, sk split, sk count, sk fold], pipeline counters) since the last kernel_time(reset=True)"""
+        ms = (ctypes.c_double * 5)()
         cnt = (ctypes.c_uint64 * 20)()
         self._check(self.lib.sdt_gpu_stage_times(self._ctx, ms, cnt))
         names = ("merges", "lds_spills", "pool_direct", "early_flushes", "chunks_l1", "chunks_l2", "batches", "batch_kmers", "cnt_ticks_setup",

@@ -464,6 +464,7 @@ struct sdt_ctx {
 		BmDir *dir = nullptr;
 		uint32_t *cnt = nullptr;
 		uint64_t cap = 0;                  // slots allocated
+		uint64_t dir_cap = 0;              // directory entries allocated (SK_NBF + those of the sub-buckets of giant buckets)
 		uint64_t nslots = 0;               // slots in use
 		uint64_t nodes = 0;
 		bool valid = false;
@@ -479,7 +480,7 @@ struct sdt_ctx {
 		uint32_t *dcnt = nullptr, *doff = nullptr, *dfill = nullptr;
 		unsigned long long *dents = nullptr, *dpre = nullptr;
 		uint32_t *xcnt = nullptr, *xoff = nullptr, *xfill = nullptr;
-		uint32_t *ccnt = nullptr, *cstart = nullptr, *cfill = nullptr, *order = nullptr, *next = nullptr;
+		uint32_t *ccnt = nullptr, *cstart = nullptr, *cfill = nullptr, *next = nullptr;
 		unsigned long long *ctl = nullptr, *h_ctl = nullptr;      // BM_CTL_N counters (device / pinned)
 		unsigned long long *h_lctl = nullptr;                    // pinned: a slab's two cursors
 		uint64_t folds = 0, restarts = 0, maxparts = 0;          // statistics
@@ -679,7 +680,7 @@ static void bm_free(sdt_ctx *c)
 	log_free(c);
 	bm_table_free(b.tab);
 	bm_table_free(b.spare);
-	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.order, b.next, b.ctl};
+	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.next, b.ctl};
 	for (void *p : dev)
 		if (p) (void)hipFree(p);
 	if (b.h_ctl) (void)hipHostFree(b.h_ctl);
@@ -703,6 +704,7 @@ static int log_refresh(sdt_ctx *c, sdt_ctx::LogSlab &sl)
 }
 
 static int bm_fold(sdt_ctx *c);
+static EventPair *next_event(sdt_ctx *c);
 
 // Room in the log for a count launch of `kmers` k-mers in `nbuckets` buckets and `nitems` work items -- the HARD bound: an
 // entry is a distinct key of one generation of an LDS table, so a launch appends at most one per k-mer; a descriptor is a
@@ -737,16 +739,19 @@ static int log_reserve(sdt_ctx *c, uint64_t kmers, uint64_t nbuckets, uint64_t n
 			continue;
 		}
 		// another slab: as large as the pools suggest, never smaller than this launch, within a share of what is free
-		uint64_t want = c->sk.cap_kmers / 8;
+		// (room for four launches like this one under the hard bound -- what they really take is a fraction of it, so a slab lasts
+		// a batch or more and the host looks at its cursor a few times per batch)
+		uint64_t want = c->sk.cap_kmers / 4;
+		if (want < 4 * need_e) want = 4 * need_e;
 		if (want < (1ULL << 26)) want = 1ULL << 26;
-		if (want > (1ULL << 31)) want = 1ULL << 31;
+		if (want > (1ULL << 32)) want = 1ULL << 32;
 		if (env_int("SDT_LOG_SLAB_LOG2", 0) > 0)          // (tests: small slabs, many of them)
 			want = 1ULL << clamp_int(env_int("SDT_LOG_SLAB_LOG2", 0), 16, 34);
 		if (want < need_e) want = need_e;
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(sdti::mem_info(&free_b, &total_b));
 		const uint64_t per_e = (uint64_t)lw * 8 + sizeof(LogDesc) / 16 + 1;
-		while (want > need_e && want * per_e > free_b / 100 * 45)
+		while (want > need_e && want * per_e > free_b / 100 * 30)
 			want = want / 2 > need_e ? want / 2 : need_e;
 		sdt_ctx::LogSlab sl;
 		sl.ent_cap = want;
@@ -793,34 +798,36 @@ static int bm_scratch_alloc(sdt_ctx *c)
 	HIPCHK(hipMalloc((void **)&b.ccnt, 65 * 4));
 	HIPCHK(hipMalloc((void **)&b.cstart, 65 * 4));
 	HIPCHK(hipMalloc((void **)&b.cfill, 65 * 4));
-	HIPCHK(hipMalloc((void **)&b.order, SK_NBF * 4));
 	HIPCHK(hipMalloc((void **)&b.next, 64));
 	HIPCHK(hipMalloc((void **)&b.ctl, BM_CTL_N * sizeof(unsigned long long)));
 	HIPCHK(hipHostMalloc((void **)&b.h_ctl, BM_CTL_N * sizeof(unsigned long long), hipHostMallocDefault));
 	return SDT_OK;
 }
 
-static int bm_table_alloc(sdt_ctx *c, sdt_ctx::BmTable &t, uint64_t cap)
+static int bm_table_alloc(sdt_ctx *c, sdt_ctx::BmTable &t, uint64_t cap, uint64_t dir_cap)
 {
-	if (t.cap >= cap && t.ent)
+	if (t.cap >= cap && t.dir_cap >= dir_cap && t.ent)
 		return SDT_OK;
+	if (t.cap > cap) cap = t.cap;
+	if (t.dir_cap > dir_cap) dir_cap = t.dir_cap;
 	bm_table_free(t);
 	hipError_t e = hipMalloc(&t.ent, cap * entry_bytes(c->nw));
 	if (e == hipSuccess) e = hipMalloc((void **)&t.aux, cap * 4);
 	if (e == hipSuccess && (c->flags & SDT_FLAG_TRACK_FIRST)) e = hipMalloc((void **)&t.first, cap * 8);
-	if (e == hipSuccess) e = hipMalloc((void **)&t.dir, (size_t)SK_NBF * sizeof(BmDir));
-	if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, (size_t)SK_NBF * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&t.dir, dir_cap * sizeof(BmDir));
+	if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, dir_cap * 4);
 	if (e != hipSuccess) {
 		bm_table_free(t);
 		(void)hipGetLastError();
 		return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu slots x %zu B", (unsigned long long)cap, entry_bytes(c->nw) + 4);
 	}
 	t.cap = cap;
+	t.dir_cap = dir_cap;
 	return SDT_OK;
 }
 
 template <int NW, bool TRACK>
-static int bm_fold_launch(sdt_ctx *c, const LogDesc *sorted, const uint64_t *xent, bool have_old, sdt_ctx::BmTable &dst)
+static int bm_fold_launch(sdt_ctx *c, const LogDesc *sorted, const uint64_t *xent, bool have_old, sdt_ctx::BmTable &dst, const BmUnit *units, unsigned grid, const BmKnobs &kn)
 {
 	sdt_ctx::BmState &b = c->bm;
 	BmIn<NW> in;
@@ -841,9 +848,7 @@ static int bm_fold_launch(sdt_ctx *c, const LogDesc *sorted, const uint64_t *xen
 	out.cap = dst.cap;
 	using G = BmGeo<NW, TRACK>;
 	HIPCHK(hipFuncSetAttribute((const void *)k_bm_finalize<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
-	const unsigned per_cu = (unsigned)((160 * 1024) / (G::SMEM + 512));
-	const unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
-	hipLaunchKernelGGL((k_bm_finalize<NW, TRACK>), dim3(grid), dim3(G::T), G::SMEM, c->stream, in, out, (const uint32_t *)b.order, (uint32_t)SK_NBF, b.next, c->K, c->d_stats);
+	hipLaunchKernelGGL((k_bm_finalize<NW, TRACK>), dim3(grid), dim3(G::T), G::SMEM, c->stream, in, out, units, c->K, c->d_stats, kn);
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
 }
@@ -875,6 +880,14 @@ static int bm_fold(sdt_ctx *c)
 	// descriptors by bucket
 	LogDesc *sorted = nullptr;
 	uint64_t *xent = nullptr;
+	BmUnit *units = nullptr;
+	EventPair *ev = next_event(c);                   // (the fold is part of pass 1: sdt_gpu_kernel_time / sdt_gpu_stage_times count it)
+	if (!ev)
+		return fail(SDT_EHIP, "hipEventCreate failed");
+	ev->kmers = 0;
+	ev->stage = SDT_STAGE_SK_FOLD;
+	HIPCHK(hipEventRecord(ev->a, c->stream));
+	HIPCHK(hipEventRecord(ev->b, c->stream));         // (moved behind the merge kernel below; recorded here so that a failed fold leaves a valid pair)
 	HIPCHK(hipMemsetAsync(b.dcnt, 0, SK_NBF * 4, c->stream));
 	HIPCHK(hipMemsetAsync(b.dents, 0, SK_NBF * 8, c->stream));
 	for (auto &sl : b.slabs)
@@ -912,33 +925,47 @@ static int bm_fold(sdt_ctx *c)
 			else hipLaunchKernelGGL(k_bm_flat_place<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
 			FOLD_CHK(hipGetLastError());
 		}
-		// buckets in order of falling size
-		FOLD_CHK(hipMemsetAsync(b.ccnt, 0, 65 * 4, c->stream));
-		hipLaunchKernelGGL(k_bm_class_hist, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
-		                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, b.ccnt);
-		hipLaunchKernelGGL(k_bm_class_scan, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)b.ccnt, b.cstart, b.cfill);
-		hipLaunchKernelGGL(k_bm_class_place, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
-		                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, (const uint32_t *)b.cstart, b.cfill, b.order);
-		FOLD_CHK(hipGetLastError());
 		// the table: sized by a guess of the distinct keys (the caller's estimate when there is one; 45 % of the log's entries are
 		// distinct on deep transcriptome data), and again with the exact number of slots should the guess have been short
 		const uint64_t in_total = nlog + nold + nflat;
 		uint64_t guess = nold + nflat + (uint64_t)((double)nlog * 0.45);
 		if (b.est_distinct > guess) guess = b.est_distinct;
 		if (guess > in_total) guess = in_total;
-		uint64_t cap = (uint64_t)((double)guess * (4.0 / 3.0) * 1.10) + (uint64_t)SK_NBF * 12 + (1u << 16);
+		// workgroups of the merge: two per CU (k_bm_finalize), fewer for a small input -- each takes the table's slots in chunks of BM_CHUNK
+		unsigned grid = (unsigned)c->cu_count * 2;
+		if ((uint64_t)grid > in_total / 8192 + 1) grid = (unsigned)(in_total / 8192 + 1);
+		uint64_t cap = (uint64_t)((double)guess * (4.0 / 3.0) * 1.12) + (uint64_t)SK_NBF * 12 + (uint64_t)grid * BM_CHUNK + (1u << 16);
+		// directory entries of the sub-buckets of giant buckets: a bucket of n > BM_GIANT entries takes 2^ceil(log2(n / BM_SUB_TARGET)) < 4 n / BM_SUB_TARGET
+		// (SDT_BM_GIANT / SDT_BM_SUB_TARGET / SDT_BM_LDS_CAP: test hooks -- small inputs through sub-buckets and several parts)
+		BmKnobs kn;
+		kn.giant = env_int("SDT_BM_GIANT", 0) > 0 ? (unsigned long long)env_int("SDT_BM_GIANT", 0) : BM_GIANT;
+		kn.sub_target = env_int("SDT_BM_SUB_TARGET", 0) > 0 ? (unsigned long long)env_int("SDT_BM_SUB_TARGET", 0) : BM_SUB_TARGET;
+		kn.lds_cap = (uint32_t)clamp_int(env_int("SDT_BM_LDS_CAP", 0), 0, 1 << 20);
+		if (kn.lds_cap && kn.lds_cap < 16) kn.lds_cap = 16;
+		// (a bucket past kn.giant takes 2^ceil(log2(n / sub_target)) <= 2 n / sub_target + 2 entries; at most in_total / giant buckets are that large)
+		const uint64_t ext_cap = in_total / kn.sub_target * 2 + in_total / kn.giant * 2 + 4096;
+		FOLD_CHK(hipMalloc((void **)&units, ((size_t)SK_NBF + ext_cap) * sizeof(BmUnit)));
 		sdt_ctx::BmTable &dst = have_old ? b.spare : b.tab;
-		if (dst.cap > cap) cap = dst.cap;                // (buffers of an earlier fold are used as they are)
 		for (int attempt = 0; attempt < 2; attempt++) {
-			ret = bm_table_alloc(c, dst, cap);
+			ret = bm_table_alloc(c, dst, cap, (uint64_t)SK_NBF + ext_cap);
 			if (ret != SDT_OK) goto done;
 			FOLD_CHK(hipMemsetAsync(b.ctl, 0, BM_CTL_N * sizeof(unsigned long long), c->stream));
 			FOLD_CHK(hipMemsetAsync(b.next, 0, 4, c->stream));
+			// work units (buckets, sub-buckets of giant buckets) in order of falling size, the directory entries of empty and giant buckets
+			FOLD_CHK(hipMemsetAsync(b.ccnt, 0, 65 * 4, c->stream));
+			hipLaunchKernelGGL(k_bm_class_hist, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
+			                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, b.ccnt, kn);
+			hipLaunchKernelGGL(k_bm_class_scan, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)b.ccnt, b.cstart, b.cfill, b.ctl);
+			hipLaunchKernelGGL(k_bm_class_place, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
+			                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, (const uint32_t *)b.cstart, b.cfill, units, dst.dir, dst.cnt, b.ctl,
+			                   (uint32_t)ext_cap, c->d_stats, kn);
+			FOLD_CHK(hipGetLastError());
 			const bool track = (c->flags & SDT_FLAG_TRACK_FIRST) != 0;
-			if (c->nw == 1) ret = track ? bm_fold_launch<1, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<1, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
-			else if (c->nw == 2) ret = track ? bm_fold_launch<2, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<2, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
-			else ret = track ? bm_fold_launch<4, true>(c, sorted, nflat ? xent : nullptr, have_old, dst) : bm_fold_launch<4, false>(c, sorted, nflat ? xent : nullptr, have_old, dst);
+			if (c->nw == 1) ret = track ? bm_fold_launch<1, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<1, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
+			else if (c->nw == 2) ret = track ? bm_fold_launch<2, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<2, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
+			else ret = track ? bm_fold_launch<4, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<4, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
 			if (ret != SDT_OK) goto done;
+			FOLD_CHK(hipEventRecord(ev->b, c->stream));
 			FOLD_CHK(hipMemcpyAsync(b.h_ctl, b.ctl, BM_CTL_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 			{ const int rcw = c->comm.sync_watched(c->stream, "the merge of the node log"); if (rcw != SDT_OK) { ret = rcw; goto done; } }
 			if (b.h_ctl[BM_CTL_SLOTS] <= dst.cap)
@@ -988,6 +1015,7 @@ done:
 		(void)hipStreamSynchronize(c->stream);
 	if (sorted) (void)hipFree(sorted);
 	if (xent) (void)hipFree(xent);
+	if (units) (void)hipFree(units);
 	return ret;
 }
 

@@ -62,6 +62,8 @@ struct BmDir {
 	uint64_t base;        // first slot of the bucket's tables
 	uint32_t ssub;        // slots per table (a multiple of 8)
 	uint32_t parts;       // tables (0: the bucket is empty)
+	// ssub == 0 && parts != 0: a GIANT bucket, cut into 2^parts sub-buckets by the top bits of the hash's high half; base = index of
+	// the first of their 2^parts directory entries (behind the SK_NBF bucket entries)
 };
 
 template <int NW> struct Table {
@@ -75,21 +77,56 @@ template <int NW> struct Table {
 	__host__ __device__ uint64_t slots() const { return dir ? nslots : mask + 1; }
 };
 
+// The two hashes of the bucket-major layout: `hi` picks the sub-bucket (its top bits) and the table (the bits below), `lo` the home
+// slot.  Cheap on purpose -- a fold of the key words and two 32-bit multiplies each: k_bm_finalize computes `hi` for every entry of
+// the log in every pass over a bucket, and key_hash (four 64-bit multiplies) was a third of its instructions.  Keys that collide in
+// the fold collide in both: they only share a probe sequence.
+template <int NW> __host__ __device__ inline uint32_t bm_fold(const Key<NW> &k)
+{
+	uint32_t x = 0x9747B28Cu;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		x = ((x << 7) | (x >> 25)) ^ (uint32_t)k.w[i];
+		x = ((x << 9) | (x >> 23)) ^ (uint32_t)(k.w[i] >> 32);
+	}
+	return x;
+}
+__host__ __device__ inline uint32_t bm_hash_hi(uint32_t fold)
+{
+	uint32_t h = fold * 0x85EBCA6Bu;
+	h ^= h >> 15;
+	h *= 0xC2B2AE35u;
+	return h ^ (h >> 16);
+}
+__host__ __device__ inline uint32_t bm_hash_lo(uint32_t fold)
+{
+	uint32_t h = (fold ^ 0x5BD1E995u) * 0x27D4EB2Fu;
+	h ^= h >> 13;
+	h *= 0x165667B1u;
+	return h ^ (h >> 16);
+}
+
 // Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times; n == 0:
 // the key's bucket is empty (bucket-major) -- the key is not there.
 template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const Key<NW> &key, uint64_t &slot, uint64_t &lo, uint64_t &n)
 {
-	const uint64_t h = key_hash<NW>(key);
 	if (!t.dir) {
 		lo = 0;
 		n = t.mask + 1;
-		slot = h & t.mask;
+		slot = key_hash<NW>(key) & t.mask;
 		return;
 	}
-	const BmDir d = t.dir[key_final_bucket<NW>(key, t.K)];
+	BmDir d = t.dir[key_final_bucket<NW>(key, t.K)];
+	const uint32_t f = bm_fold<NW>(key);
+	uint32_t hh = bm_hash_hi(f);
+	if (d.ssub == 0 && d.parts) {                        // a giant bucket: 2^parts sub-buckets with directory entries of their own
+		const uint32_t lg = d.parts;
+		d = t.dir[d.base + (hh >> (32u - lg))];
+		hh <<= lg;
+	}
 	n = d.parts ? d.ssub : 0;
-	lo = d.base + (uint64_t)__umulhi((uint32_t)(h >> 32), d.parts) * d.ssub;
-	slot = lo + __umulhi((uint32_t)h, d.ssub);
+	lo = d.base + (uint64_t)__umulhi(hh, d.parts) * d.ssub;
+	slot = lo + __umulhi(bm_hash_lo(f), d.ssub);
 }
 __device__ inline uint64_t probe_next(uint64_t slot, uint64_t lo, uint64_t n) { return slot + 1 == lo + n ? lo : slot + 1; }
 
