@@ -25,14 +25,20 @@
 template <int NW> struct BmX { static constexpr int W = NW + 3; };
 
 template <int NW, bool TRACK> struct BmGeo {
-	static constexpr int T = NW == 1 ? 1024 : 512;                                     // two workgroups per CU; 1-word keys: 32 waves, what a CU holds (64 registers)
-	static constexpr int WAVES_PER_SIMD = 2 * (T / 256);
+#ifndef BM_WGS_PER_CU
+#define BM_WGS_PER_CU 1
+#endif
+#ifndef BM_T1
+#define BM_T1 1024
+#endif
+	static constexpr int T = BM_WGS_PER_CU == 1 ? 1024 : (NW == 1 ? BM_T1 : 512);             // two workgroups per CU; 1-word keys: 32 waves, what a CU holds (64 registers)
+	static constexpr int WAVES_PER_SIMD = BM_WGS_PER_CU * (T / 256);
 	static constexpr int MAXD = 128;                                                   // segment descriptors held in LDS at a time
 	static constexpr int SLOT_BYTES = NW * 8 + 8 + 4 + (TRACK ? 8 : 0);
-	static constexpr int M = (70 * 1024 / SLOT_BYTES) / 64 * 64;                       // LDS merge table: 3584 / 2560 / 2560 / 1984 / 1600 / 1344 slots
-	static constexpr uint32_t CAP = (uint32_t)M * 3u / 4u;                             // keys it takes
-	static constexpr int BITW = M / 16;                                                // bitmap of a table being written: 2 M slots at most
-	static constexpr size_t SMEM = (size_t)M * SLOT_BYTES + (size_t)BITW * 4 + (size_t)MAXD * 8 + (size_t)(MAXD + 1) * 4 + 8;
+	static constexpr int M = ((BM_WGS_PER_CU == 1 ? 144 : 70) * 1024 / SLOT_BYTES) / 512 * 512;                     // LDS image of a table: 3584 / 2560 / 2560 / 1536 / 1536 / 1024 slots
+	static constexpr int STEP = M / 16;                                                // a bucket's table: a multiple of this many slots (or M / 64 for the smallest)
+	static constexpr size_t SMEM = (size_t)M * SLOT_BYTES + (size_t)MAXD * 8 + (size_t)(MAXD + 1) * 4 + 16;
+	static_assert(M % 512 == 0, "table sizes are multiples of 8 slots down to M / 64");
 };
 
 template <int NW> struct BmIn {
@@ -238,14 +244,90 @@ __device__ __forceinline__ void bm_lds_merge(unsigned long long *val_g, uint32_t
 		(void)__hip_atomic_fetch_or(hi, auxadd & (AUX_LINEAR | AUX_DELETED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// one entry into the LDS merge table: a unit takes the keys of its sub-bucket (the top lg bits of the hash's high half), pass p of
-// P those whose following bits fall into part p; no room: *abort = 1
-template <int NW, bool TRACK, int M>
-__device__ __forceinline__ void bm_insert(unsigned long long *m_key, unsigned long long *m_val, unsigned long long *m_ord, uint32_t *m_hi, uint32_t *fill, uint32_t *abort_flag,
-                                          uint32_t cap, uint32_t lg, uint32_t sub, uint32_t P, uint32_t p, const Key<NW> &key, uint64_t val, uint32_t auxadd, uint64_t ord)
+// Find-or-claim in the LDS image of a bucket's table: `msz` slots (word-major key words, stride M), linear probing from the
+// key's home -- the very layout the table has in HBM afterwards (sdt_table.cuh: bm_home), so that the image is written out as it
+// stands.  1-word keys probe a group of four slots per step (home is a multiple of four): 32 bytes of keys per LDS round trip;
+// a slot that looked empty in the snapshot is settled by the compare-and-swap, and a key never changes once it is there.
+// Nothing counts the keys here (one counter for all lanes was a same-address atomic per new key: the LDS serialises those); an
+// image that is too full shows as a probe sequence of more than BM_MAX_PROBE slots (-1), and its keys are counted when it is
+// written out.
+constexpr uint32_t BM_MAX_PROBE = 128;
+template <int NW, int M>
+__device__ __forceinline__ int bm_locate(unsigned long long *m_key, uint32_t msz, const Key<NW> &key, uint32_t hlo)
 {
+	uint32_t s = bm_home<NW>(hlo, msz);
+	const uint32_t lim = msz < BM_MAX_PROBE ? msz : BM_MAX_PROBE;
+	if constexpr (NW == 1) {
+		// (per group ONE read of the four keys and at most one compare-and-swap -- at the first slot that looks empty; a key that
+		// is in the table sits before the first empty slot of its probe sequence, nothing is ever removed.  Written slot by slot,
+		// the lanes of a wave took the four slots' branches one after the other: four times the LDS instructions.)
+		for (uint32_t probe = 0; probe < lim; probe += 4) {
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&m_key[s]), b = *reinterpret_cast<const ulonglong2 *>(&m_key[s + 2]);
+			uint64_t k0 = a.x, k1 = a.y, k2 = b.x, k3 = b.y;
+			for (;;) {
+				const uint64_t me = key.w[0];
+				// position of the key / of the first empty slot in the group (4: none)
+				const int jm = k0 == me ? 0 : (k1 == me ? 1 : (k2 == me ? 2 : (k3 == me ? 3 : 4)));
+				const int je = k0 == KEY_EMPTY ? 0 : (k1 == KEY_EMPTY ? 1 : (k2 == KEY_EMPTY ? 2 : (k3 == KEY_EMPTY ? 3 : 4)));
+				if (jm < je)
+					return (int)s + jm;
+				if (je == 4)
+					break;                               // a full group of other keys: on to the next
+				const uint64_t old = atomicCAS(&m_key[s + je], (unsigned long long)KEY_EMPTY, (unsigned long long)me);
+				if (old == KEY_EMPTY || old == me)
+					return (int)s + je;
+				// somebody else's key got there first: it is part of the picture now
+				k0 = je == 0 ? old : k0;
+				k1 = je == 1 ? old : k1;
+				k2 = je == 2 ? old : k2;
+				k3 = je == 3 ? old : k3;
+			}
+			s = s + 4 == msz ? 0u : s + 4;
+		}
+		return -1;
+	} else {
+		int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
+		for (uint32_t probe = 0; probe < lim && found == -2;) {
+			uint64_t k0 = __hip_atomic_load(&m_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (k0 == KEY_EMPTY) {
+				const uint64_t old = atomicCAS(&m_key[s], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
+				if (old == KEY_EMPTY) {
+#pragma unroll
+					for (int i = 1; i < NW; i++)
+						m_key[i * M + s] = key.w[i];
+					__hip_atomic_store(&m_key[s], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					found = (int)s;
+					continue;
+				}
+				k0 = old;
+			}
+			if (k0 == KEY_LOCKED)
+				continue;                                // the claimer is writing the low words: look again
+			bool same = k0 == key.w[0];
+			if (same) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+				for (int i = 1; i < NW; i++)
+					same = same && (__hip_atomic_load(&m_key[i * M + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[i]);
+			}
+			if (same)
+				return (int)s;
+			s = s + 1 == msz ? 0u : s + 1;
+			probe++;
+		}
+		return found == -2 ? -1 : found;
+	}
+}
+
+// one entry into the LDS image: a unit takes the keys of its sub-bucket (the top lg bits of the `hi` hash), pass p of P those whose
+// following bits fall into part p; no room: *abort = 1
+template <int NW, bool TRACK, int M>
+__device__ __forceinline__ void bm_insert(unsigned long long *m_key, unsigned long long *m_val, unsigned long long *m_ord, uint32_t *m_hi, uint32_t *abort_flag,
+                                          uint32_t msz, uint32_t lg, uint32_t sub, uint32_t P, uint32_t p, const Key<NW> &key, uint64_t val, uint32_t auxadd, uint64_t ord)
+{
+	const uint32_t f = bm_fold<NW>(key);
 	if (lg || P > 1) {
-		uint32_t hh = bm_hash_hi(bm_fold<NW>(key));
+		uint32_t hh = bm_hash_hi(f);
 		if (lg) {
 			if ((hh >> (32u - lg)) != sub)
 				return;
@@ -254,16 +336,27 @@ __device__ __forceinline__ void bm_insert(unsigned long long *m_key, unsigned lo
 		if (P > 1 && __umulhi(hh, P) != p)
 			return;
 	}
-	const int s = sk_lds_locate<NW, M>(m_key, fill, key, cap);
+#if defined(SDT_BM_EXP) && (SDT_BM_EXP == 1 || SDT_BM_EXP == 3)                  /* measurement builds: what the phases of an insert cost (profiles/r5) */
+	asm volatile("" :: "v"(f), "v"(val));
+	return;
+#endif
+	const int s = bm_locate<NW, M>(m_key, msz, key, bm_hash_lo(f));
 	if (s < 0) {
 		*abort_flag = 1;
 		return;
 	}
+#if defined(SDT_BM_EXP) && SDT_BM_EXP == 2
+	asm volatile("" :: "v"(s), "v"(val));
+	return;
+#endif
 	bm_lds_merge(&m_val[s], &m_hi[s], val, auxadd);
 	if (TRACK && ord != ORD_NONE)
 		atomicMin(&m_ord[s], (unsigned long long)ord);
 }
 
+#ifndef BM_UNROLL
+#define BM_UNROLL 2
+#endif
 constexpr unsigned long long BM_CHUNK = 65536;          // slots a workgroup takes from the table at a time (a global atomic per unit was a round trip on every unit's critical path)
 
 template <int NW> __device__ __forceinline__ void bm_store_empty(const BmOut<NW> &out, uint64_t slot, bool track)
@@ -283,21 +376,26 @@ template <int NW> __device__ __forceinline__ void bm_store_empty(const BmOut<NW>
 // know about its next unit sits at addresses the scalar unit can compute ahead of time -- no atomic, no broadcast, no dependent
 // vector load between two units.  Slots come out of a chunk of the table the workgroup owns (BM_CHUNK at a time; what is left of
 // a chunk when it is given up is filled with empties: the scans of the table must find nothing there).
+//
+// A unit's table(s) are built IN LDS in the layout they have in HBM -- `msz` slots, linear probing from bm_home -- and written out
+// as they stand, empties included: no second hash, no slot claims, no pass over the empties.  `msz` comes from a guess of the
+// unit's distinct keys (half its log entries + its nodes): a multiple of M / 16 aimed at a load of 0.7; a unit that needs more
+// than M slots gets `parts` tables of M; a guess that turns out short (the image fills past 4/5) costs the unit another attempt
+// with twice the room.
 template <int NW, bool TRACK>
 __global__ __launch_bounds__((BmGeo<NW, TRACK>::T), (BmGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_bm_finalize(BmIn<NW> in, BmOut<NW> out, const BmUnit *__restrict__ units,
                                                                                                          int K, Stats *stats, BmKnobs kn)
 {
 	using G = BmGeo<NW, TRACK>;
-	constexpr int M = G::M, T = G::T, BITW = G::BITW, MAXD = G::MAXD;
-	const uint32_t CAP = kn.lds_cap && kn.lds_cap < G::CAP ? kn.lds_cap : G::CAP;
+	constexpr int M = G::M, T = G::T, MAXD = G::MAXD;
 	constexpr int LW = NW + 1 + (TRACK ? 1 : 0), XW = BmX<NW>::W;
-	extern __shared__ unsigned long long bm_sm[];
-	unsigned long long *m_key = bm_sm;                               // NW x M, word-major (sk_lds_locate's layout)
+	const uint32_t MEFF = kn.lds_cap && kn.lds_cap < (uint32_t)M ? ((kn.lds_cap + 7u) & ~7u) : (uint32_t)M;     // (tests: a small image forces several parts)
+	extern __shared__ __attribute__((aligned(16))) unsigned long long bm_sm[];
+	unsigned long long *m_key = bm_sm;                               // NW x M, word-major (16-byte aligned: bm_locate reads two keys at a time)
 	unsigned long long *m_val = m_key + NW * M;                      // M
 	unsigned long long *m_ord = m_val + M;                           // M when TRACK
 	uint32_t *m_hi = (uint32_t *)(m_ord + (TRACK ? M : 0));          // M: the node's aux word
-	uint32_t *s_bits = m_hi + M;                                     // BITW
-	unsigned long long *s_dptr = (unsigned long long *)(s_bits + BITW + ((BITW + M) & 1));      // MAXD: the segments being read (8-byte aligned)
+	unsigned long long *s_dptr = (unsigned long long *)(m_hi + M + (M & 1));      // MAXD: the segments being read (8-byte aligned)
 	uint32_t *s_dpre = (uint32_t *)(s_dptr + MAXD);                  // MAXD + 1: prefix of their entry counts
 	__shared__ uint32_t s_fill, s_abort;
 	__shared__ unsigned long long s_base;
@@ -312,15 +410,13 @@ __global__ __launch_bounds__((BmGeo<NW, TRACK>::T), (BmGeo<NW, TRACK>::WAVES_PER
 #define BM_TICK(i) do { } while (0)
 #endif
 	unsigned long long loc_next = 0, loc_end = 0;                    // (uniform) the workgroup's chunk of the table: [loc_next, loc_end)
-	// the merge table and the bitmap start out clear (and are cleared again behind every part: see the end of the part loop)
+	// the image starts out clear (and is cleared again as it is written out)
 	for (int i = tid; i < M; i += T) {
 		m_key[i] = KEY_EMPTY;
 		m_val[i] = 0;
 		m_hi[i] = 0;
 		if (TRACK) m_ord[i] = ORD_NONE;
 	}
-	for (int i = tid; i < BITW; i += T)
-		s_bits[i] = 0;
 	if (tid == 0) {
 		s_fill = 0;
 		s_abort = 0;
@@ -370,28 +466,33 @@ __global__ __launch_bounds__((BmGeo<NW, TRACK>::T), (BmGeo<NW, TRACK>::WAVES_PER
 			nold_r = od.parts ? (od.ssub ? 1u : 1u << od.parts) : 0u;
 		}
 		const uint32_t x0 = in.xent ? in.xoff[b] : 0u, x1 = in.xent ? in.xoff[b + 1] : 0u;
-		// (what this unit takes of the bucket's input: all of it, or about a 2^lg-th)
-		const unsigned long long n_in = (nlog + nold + (x1 - x0)) >> lg;
-		// parts: one when everything fits whatever the keys are; else from a guess of the distinct keys (an entry of the log is one of
-		// ~2.5 of its key, a node of a table is the only one), doubled whenever the LDS table fills up all the same
-		uint32_t P = 1;
-		if (n_in > CAP || lg) {
-			const unsigned long long est = ((nold + (x1 - x0) + nlog * 9 / 20) >> lg) + 1;       // (an entry of the log is one of ~2.5 of its key)
-			const unsigned long long per = (unsigned long long)CAP * 90 / 100;
-			P = (uint32_t)((est + per - 1) / per);
+		// Slots.  An attempt that runs out of room costs the unit another pass over its input -- as much as ten thousand slots cost
+		// every later scan of the table -- so: a unit whose input fits one image whatever its keys are gets room for all of it (load
+		// <= 0.8 even if no two entries share a key); a larger one room for 0.65 distinct keys per log entry (0.4 is the average of deep
+		// transcriptome data) at a load of 0.8, in as many tables as that takes, each as small as that allows.
+		const unsigned long long n_unit = ((nlog + nold + (x1 - x0)) >> lg) + 1;
+		const unsigned long long est = ((nold + (x1 - x0) + nlog * 13 / 20) >> lg) + 1;
+		const uint32_t step = (uint32_t)G::STEP < MEFF ? (uint32_t)G::STEP : MEFF;
+		uint32_t P = 1, msz = MEFF;
+		if (!lg && n_unit * 5 / 4 + 1 <= MEFF) {
+			const unsigned long long want = n_unit * 5 / 4 + 1;
+			msz = (uint32_t)((want + step - 1) / step) * step;
+			if (want <= (uint32_t)M / 64 && (uint32_t)M / 64 <= MEFF) msz = (uint32_t)M / 64;
+		} else {
+			const unsigned long long want = est * 5 / 4 + 1;
+			P = (uint32_t)((want + MEFF - 1) / MEFF);
+			msz = (uint32_t)(((want + P - 1) / P + step - 1) / step) * step;
 		}
-		uint32_t margin = 0, floor_ssub = 8;
+		if (msz > MEFF) msz = MEFF;
 		BM_TICK(0);                                      // unit header
 		unsigned long long base = 0;
-		uint32_t ssub = 0, total_d = 0;
-		bool valid = false;                          // the unit's slots lie inside the table
+		uint32_t total_d = 0;
+		bool valid = false;                              // the unit's slots lie inside the table
 		for (;;) {
-			bool ok = true, lds_full = false;
-			base = 0;
-			ssub = 0;
+			bool ok = true;
 			total_d = 0;
-			valid = false;
-			bool allocated = false;
+			base = take((unsigned long long)P * msz, valid);         // (uniform: every lane keeps the chunk's cursor)
+			BM_TICK(4);                                  // slots
 			for (uint32_t p = 0; p < P; p++) {
 				// ---- the bucket's segments of the log: descriptors into LDS (MAXD at a time), then ONE loop over all their entries
 				// with two loads per lane in flight (a loop per segment paid a descriptor round trip and a ragged last sweep per
@@ -424,43 +525,55 @@ __global__ __launch_bounds__((BmGeo<NW, TRACK>::T), (BmGeo<NW, TRACK>::WAVES_PER
 					BM_TICK(1);                          // descriptors + scan
 					const uint32_t total = s_dpre[nd];
 					uint32_t seg = 0;
-					for (uint32_t e0 = 0; e0 < total; e0 += 2u * T) {
-						const uint32_t ea = e0 + (uint32_t)tid, eb = ea + (uint32_t)T;
-						Key<NW> ka, kb;
-						uint64_t va = 0, vb = 0, oa = ORD_NONE, ob = ORD_NONE;
-						const bool ha = ea < total, hb = eb < total;
-						if (ha) {
-							while (ea >= s_dpre[seg + 1]) seg++;
-							const uint64_t *x = (const uint64_t *)s_dptr[seg] + (size_t)(ea - s_dpre[seg]) * LW;
-							if (NW == 1 && !TRACK) {
-								const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(x);
-								ka.w[0] = kv.x;
-								va = kv.y;
-							} else {
+					// (BM_UNROLL entries per lane in flight: the loop is a chain of memory round trips -- address out of LDS, load, insert --
+					// and with one or two loads per wave between waits it ran at a fifth of what the memory system gives)
+					constexpr int U = BM_UNROLL;
+					typedef const __attribute__((address_space(1))) uint64_t *gptr;      // (a pointer out of LDS is generic: say that it is global memory)
+					// (software pipeline: the loads of the next U entries are in flight while these U go into the image)
+					Key<NW> kk[U], kn[U];
+					uint64_t vv[U], oo[U], vn[U], on[U];
+					bool hh[U], hn[U];
+					auto fetch = [&](uint32_t e0, Key<NW> *k, uint64_t *v, uint64_t *o, bool *h) {
 #pragma unroll
-								for (int i = 0; i < NW; i++)
-									ka.w[i] = x[i];
-								va = x[NW];
-								if (TRACK) oa = x[NW + (TRACK ? 1 : 0)];
+						for (int q = 0; q < U; q++) {
+							const uint32_t e = e0 + (uint32_t)q * T + (uint32_t)tid;
+							h[q] = e < total;
+							v[q] = 0;
+							o[q] = ORD_NONE;
+							if (h[q]) {
+								while (e >= s_dpre[seg + 1]) seg++;
+#if defined(SDT_BM_EXP) && SDT_BM_EXP == 3                  /* measurement build: every load hits the same few lines */
+								gptr x = (gptr)(s_dptr[0]) + (size_t)((e - s_dpre[seg]) & 63u) * LW;
+#else
+								gptr x = (gptr)(s_dptr[seg]) + (size_t)(e - s_dpre[seg]) * LW;
+#endif
+								if (NW == 1 && !TRACK) {
+									typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+									const u64x2 kv = *reinterpret_cast<const __attribute__((address_space(1))) u64x2 *>(x);
+									k[q].w[0] = kv.x;
+									v[q] = kv.y;
+								} else {
+#pragma unroll
+									for (int i = 0; i < NW; i++)
+										k[q].w[i] = x[i];
+									v[q] = x[NW];
+									if (TRACK) o[q] = x[NW + (TRACK ? 1 : 0)];
+								}
 							}
 						}
-						if (hb) {
-							while (eb >= s_dpre[seg + 1]) seg++;
-							const uint64_t *x = (const uint64_t *)s_dptr[seg] + (size_t)(eb - s_dpre[seg]) * LW;
-							if (NW == 1 && !TRACK) {
-								const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(x);
-								kb.w[0] = kv.x;
-								vb = kv.y;
-							} else {
+					};
+					fetch(0, kk, vv, oo, hh);
+					for (uint32_t e0 = 0; e0 < total; e0 += (uint32_t)U * T) {
+						const bool more = e0 + (uint32_t)U * T < total;
+						if (more)
+							fetch(e0 + (uint32_t)U * T, kn, vn, on, hn);
 #pragma unroll
-								for (int i = 0; i < NW; i++)
-									kb.w[i] = x[i];
-								vb = x[NW];
-								if (TRACK) ob = x[NW + (TRACK ? 1 : 0)];
-							}
+						for (int q = 0; q < U; q++)
+							if (hh[q]) bm_insert<NW, TRACK, M>(m_key, m_val, m_ord, m_hi, &s_abort, msz, lg, sub, P, p, kk[q], vv[q], 0u, oo[q]);
+#pragma unroll
+						for (int q = 0; q < U; q++) {
+							kk[q] = kn[q]; vv[q] = vn[q]; oo[q] = on[q]; hh[q] = more && hn[q];
 						}
-						if (ha) bm_insert<NW, TRACK, M>(m_key, m_val, m_ord, m_hi, &s_fill, &s_abort, CAP, lg, sub, P, p, ka, va, 0u, oa);
-						if (hb) bm_insert<NW, TRACK, M>(m_key, m_val, m_ord, m_hi, &s_fill, &s_abort, CAP, lg, sub, P, p, kb, vb, 0u, ob);
 					}
 				}
 				BM_TICK(2);                              // entries of the log
@@ -500,101 +613,73 @@ __global__ __launch_bounds__((BmGeo<NW, TRACK>::T), (BmGeo<NW, TRACK>::WAVES_PER
 							auxadd = (uint32_t)x[NW + 1];
 							ord = x[NW + 2];
 						}
-						bm_insert<NW, TRACK, M>(m_key, m_val, m_ord, m_hi, &s_fill, &s_abort, CAP, lg, sub, P, p, key, val, auxadd, ord);
+						bm_insert<NW, TRACK, M>(m_key, m_val, m_ord, m_hi, &s_abort, msz, lg, sub, P, p, key, val, auxadd, ord);
 					}
 				}
 				__syncthreads();
 				BM_TICK(3);                              // old + flat nodes, the barrier behind the inserts
-				const uint32_t d = s_fill;
-				lds_full = s_abort != 0;
-				bool part_ok = !lds_full;
-				if (part_ok && p == 0) {
-					// slots per table: load 3/4; with several parts a quarter (and more after a failed attempt) on top of what part 0 holds
-					uint64_t want = P == 1 ? ((uint64_t)d * 4 + 2) / 3 + 1 : ((uint64_t)d * (5 + margin) / 4 * 4 + 2) / 3 + 16;
-					want = (want + 7) & ~7ULL;
-					if (want < floor_ssub) want = floor_ssub;
-					if (want > (uint64_t)BITW * 32) want = (uint64_t)BITW * 32;
-					ssub = (uint32_t)want;
-					base = take((unsigned long long)P * ssub, valid);       // (uniform: every lane keeps the chunk's cursor)
-					allocated = true;
-				}
-				if (part_ok && (uint64_t)d * 16 > (uint64_t)ssub * 15) {     // (one empty slot at the very least: a look-up of an absent key must end)
-					part_ok = false;
-					floor_ssub = (uint32_t)((((uint64_t)d * 5 / 3 + 16) + 7) & ~7ULL);      // what this part needs, and a quarter
-				}
-				BM_TICK(4);                              // slots
-				if (part_ok) {
-					total_d += d;
-					if (valid) {
-						// write the table of this part: every node claims the first free slot from its home on, in the bitmap
-						const uint64_t sub0 = base + (uint64_t)p * ssub;
-						for (int i = tid; i < M; i += T) {
-							if (m_key[i] == KEY_EMPTY)
-								continue;
-							Key<NW> key;
-							key.w[0] = m_key[i];
+				const bool part_ok = s_abort == 0;
+				__syncthreads();                         // (everybody has read it before it is reset below)
+				// the image goes out as it stands (a failed part: only cleared) and is clear again for whatever comes next
+				const uint64_t sub0 = base + (uint64_t)p * msz;
+				uint32_t mine = 0;
+				for (uint32_t i = (uint32_t)tid; i < msz; i += T) {
+					const uint64_t k0 = m_key[i];
+					mine += k0 != KEY_EMPTY;
+					if (part_ok && valid) {
+						Entry<NW> e;
+						e.key[0] = k0;
 #pragma unroll
-							for (int wv = 1; wv < NW; wv++)
-								key.w[wv] = m_key[wv * M + i];
-							uint32_t pos = __umulhi(bm_hash_lo(bm_fold<NW>(key)), ssub);
-							for (;;) {
-								const uint32_t bit = 1u << (pos & 31u);
-								if (!(atomicOr(&s_bits[pos >> 5], bit) & bit))
-									break;
-								pos = pos + 1u == ssub ? 0u : pos + 1u;
-							}
-							Entry<NW> e;
-#pragma unroll
-							for (int wv = 0; wv < NW; wv++)
-								e.key[wv] = key.w[wv];
-							e.val = m_val[i];
-							if constexpr (NW != 1) e.pad = 0;
-							out.ent[sub0 + pos] = e;
-							out.aux[sub0 + pos] = m_hi[i];
-							if (TRACK) out.first[sub0 + pos] = m_ord[i];
-						}
-						__syncthreads();
-						BM_TICK(5);                      // nodes written
-						for (uint32_t pos = (uint32_t)tid; pos < ssub; pos += T)
-							if (!(s_bits[pos >> 5] & (1u << (pos & 31u))))
-								bm_store_empty<NW>(out, sub0 + pos, TRACK);
+						for (int wv = 1; wv < NW; wv++)
+							e.key[wv] = k0 == KEY_EMPTY ? KEY_EMPTY : m_key[wv * M + i];
+						e.val = m_val[i];
+						if constexpr (NW != 1) e.pad = 0;
+						out.ent[sub0 + i] = e;
+						out.aux[sub0 + i] = m_hi[i];
+						if (TRACK) out.first[sub0 + i] = m_ord[i];
+					}
+					if (k0 != KEY_EMPTY) {
+						m_key[i] = KEY_EMPTY;
+						m_val[i] = 0;
+						m_hi[i] = 0;
+						if (TRACK) m_ord[i] = ORD_NONE;
 					}
 				}
-				// the merge table and the bitmap are clear again for whatever comes next (the next part, the next attempt, the next unit)
-				__syncthreads();
-				for (int i = tid; i < M; i += T) {
-					m_key[i] = KEY_EMPTY;
-					m_val[i] = 0;
-					m_hi[i] = 0;
-					if (TRACK) m_ord[i] = ORD_NONE;
-				}
-				for (int i = tid; i < BITW; i += T)
-					s_bits[i] = 0;
-				if (tid == 0) {
-					s_fill = 0;
+#pragma unroll
+				for (int dd = 32; dd > 0; dd >>= 1)
+					mine += __shfl_down(mine, dd);
+				if ((tid & 63) == 0 && mine)
+					atomicAdd(&s_fill, mine);
+				if (tid == 0)
 					s_abort = 0;
-				}
 				__syncthreads();
-				BM_TICK(6);                              // empties, LDS cleared
-				if (!part_ok) {
+				const uint32_t d = s_fill;               // the keys of this part
+				__syncthreads();
+				if (tid == 0)
+					s_fill = 0;
+				BM_TICK(5);                              // image written + cleared
+				// (a table must keep an empty slot: a look-up of an absent key ends there.  Past 15/16 the part is done again with room.)
+				if (!part_ok || (uint64_t)d * 16 > (uint64_t)msz * 15) {
 					ok = false;
 					break;
 				}
+				total_d += d;
 			}
 			if (ok)
 				break;
-			// again, with more parts (the LDS table filled up) or more room per part (a part turned out larger than part 0 suggested).
-			// Slots handed out to the failed attempt are wiped: the scans of the table must find nothing in them.
-			if (allocated && valid) {
-				const uint64_t hi = (uint64_t)P * ssub;
+			// again with twice the room (more slots, or more parts once the image is as large as LDS allows).  The slots handed
+			// out to the failed attempt are wiped: the scans of the table must find nothing in them.
+			if (valid) {
+				const uint64_t hi = (uint64_t)P * msz;
 				for (uint64_t pos = (uint64_t)tid; pos < hi; pos += T)
 					bm_store_empty<NW>(out, base + pos, TRACK);
 			}
-			if (lds_full) P *= 2; else margin += 2;
+			if (msz < MEFF) msz = msz * 2 < MEFF ? msz * 2 : MEFF; else P *= 2;
 			restarts++;
+			BM_TICK(6);
 		}
 		if (tid == 0) {
-			out.dir[u.dirix] = valid && total_d ? BmDir{base, ssub, P} : BmDir{0, 0, 0};
+			out.dir[u.dirix] = valid ? BmDir{base, msz, P} : BmDir{0, 0, 0};
 			out.cnt[u.dirix] = total_d;
 			if (lg && total_d)
 				atomicAdd(&out.cnt[b], total_d);     // (the bucket's own entry counts all its sub-buckets: k_bm_class_place zeroed it)

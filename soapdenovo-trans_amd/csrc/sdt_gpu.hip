@@ -481,6 +481,10 @@ struct sdt_ctx {
 		unsigned long long *dents = nullptr, *dpre = nullptr;
 		uint32_t *xcnt = nullptr, *xoff = nullptr, *xfill = nullptr;
 		uint32_t *ccnt = nullptr, *cstart = nullptr, *cfill = nullptr, *next = nullptr;
+		LogDesc *sorted = nullptr;                               // the segment descriptors by bucket (kept: grows only)
+		uint64_t sorted_cap = 0;
+		BmUnit *units = nullptr;                                 // the work units of a fold (kept: grows only)
+		uint64_t units_cap = 0;
 		unsigned long long *ctl = nullptr, *h_ctl = nullptr;      // BM_CTL_N counters (device / pinned)
 		unsigned long long *h_lctl = nullptr;                    // pinned: a slab's two cursors
 		uint64_t folds = 0, restarts = 0, maxparts = 0;          // statistics
@@ -680,7 +684,7 @@ static void bm_free(sdt_ctx *c)
 	log_free(c);
 	bm_table_free(b.tab);
 	bm_table_free(b.spare);
-	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.next, b.ctl};
+	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.next, b.ctl, b.sorted, b.units};
 	for (void *p : dev)
 		if (p) (void)hipFree(p);
 	if (b.h_ctl) (void)hipHostFree(b.h_ctl);
@@ -806,23 +810,39 @@ static int bm_scratch_alloc(sdt_ctx *c)
 
 static int bm_table_alloc(sdt_ctx *c, sdt_ctx::BmTable &t, uint64_t cap, uint64_t dir_cap)
 {
-	if (t.cap >= cap && t.dir_cap >= dir_cap && t.ent)
+	// (the directory on its own: its size follows the input of a fold, which differs a little from run to run -- replacing the
+	// 30 GB of slots along with it cost 0.6 s whenever a fold needed three directory entries more than the last)
+	if (t.dir_cap < dir_cap || !t.dir) {
+		if (t.dir) (void)hipFree(t.dir);
+		if (t.cnt) (void)hipFree(t.cnt);
+		t.dir = nullptr;
+		t.cnt = nullptr;
+		t.dir_cap = 0;
+		const uint64_t want = dir_cap + dir_cap / 4;
+		hipError_t e = hipMalloc((void **)&t.dir, want * sizeof(BmDir));
+		if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, want * 4);
+		if (e != hipSuccess) {
+			bm_table_free(t);
+			(void)hipGetLastError();
+			return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu directory entries", (unsigned long long)want);
+		}
+		t.dir_cap = want;
+	}
+	if (t.cap >= cap && t.ent)
 		return SDT_OK;
-	if (t.cap > cap) cap = t.cap;
-	if (t.dir_cap > dir_cap) dir_cap = t.dir_cap;
-	bm_table_free(t);
+	if (t.ent) (void)hipFree(t.ent);
+	if (t.aux) (void)hipFree(t.aux);
+	if (t.first) (void)hipFree(t.first);
+	t.ent = nullptr; t.aux = nullptr; t.first = nullptr; t.cap = 0;
 	hipError_t e = hipMalloc(&t.ent, cap * entry_bytes(c->nw));
 	if (e == hipSuccess) e = hipMalloc((void **)&t.aux, cap * 4);
 	if (e == hipSuccess && (c->flags & SDT_FLAG_TRACK_FIRST)) e = hipMalloc((void **)&t.first, cap * 8);
-	if (e == hipSuccess) e = hipMalloc((void **)&t.dir, dir_cap * sizeof(BmDir));
-	if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, dir_cap * 4);
 	if (e != hipSuccess) {
 		bm_table_free(t);
 		(void)hipGetLastError();
 		return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu slots x %zu B", (unsigned long long)cap, entry_bytes(c->nw) + 4);
 	}
 	t.cap = cap;
-	t.dir_cap = dir_cap;
 	return SDT_OK;
 }
 
@@ -905,7 +925,14 @@ static int bm_fold(sdt_ctx *c)
 		}                                                                                              \
 	} while (0)
 	{
-		FOLD_CHK(hipMalloc((void **)&sorted, (ndesc ? ndesc : 1) * sizeof(LogDesc)));
+		if (b.sorted_cap < ndesc + 1) {
+			if (b.sorted) (void)hipFree(b.sorted);
+			b.sorted = nullptr;
+			b.sorted_cap = 0;
+			FOLD_CHK(hipMalloc((void **)&b.sorted, (ndesc + ndesc / 8 + 1024) * sizeof(LogDesc)));
+			b.sorted_cap = ndesc + ndesc / 8 + 1024;
+		}
+		sorted = b.sorted;
 		for (auto &sl : b.slabs)
 			if (sl.desc_known)
 				hipLaunchKernelGGL(k_bm_desc_place, dim3(g), dim3(256), 0, c->stream, (const LogDesc *)sl.desc, (const unsigned long long *)(sl.ctl + 1), sl.desc_cap,
@@ -925,16 +952,13 @@ static int bm_fold(sdt_ctx *c)
 			else hipLaunchKernelGGL(k_bm_flat_place<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
 			FOLD_CHK(hipGetLastError());
 		}
-		// the table: sized by a guess of the distinct keys (the caller's estimate when there is one; 45 % of the log's entries are
-		// distinct on deep transcriptome data), and again with the exact number of slots should the guess have been short
+		// the table: k_bm_finalize gives a unit 1.25 slots per entry of its input when that fits one LDS image, 0.81 beyond, in steps
+		// of M / 16 slots -- about one slot per entry over a deep data set; again with what it asked for should that have been short
 		const uint64_t in_total = nlog + nold + nflat;
-		uint64_t guess = nold + nflat + (uint64_t)((double)nlog * 0.45);
-		if (b.est_distinct > guess) guess = b.est_distinct;
-		if (guess > in_total) guess = in_total;
 		// workgroups of the merge: two per CU (k_bm_finalize), fewer for a small input -- each takes the table's slots in chunks of BM_CHUNK
-		unsigned grid = (unsigned)c->cu_count * 2;
+		unsigned grid = (unsigned)c->cu_count * BM_WGS_PER_CU;
 		if ((uint64_t)grid > in_total / 8192 + 1) grid = (unsigned)(in_total / 8192 + 1);
-		uint64_t cap = (uint64_t)((double)guess * (4.0 / 3.0) * 1.12) + (uint64_t)SK_NBF * 12 + (uint64_t)grid * BM_CHUNK + (1u << 16);
+		uint64_t cap = (uint64_t)((double)(nold + nflat + nlog) * 1.05) + (uint64_t)SK_NBF * 256 + (uint64_t)grid * BM_CHUNK + (1u << 16);
 		// directory entries of the sub-buckets of giant buckets: a bucket of n > BM_GIANT entries takes 2^ceil(log2(n / BM_SUB_TARGET)) < 4 n / BM_SUB_TARGET
 		// (SDT_BM_GIANT / SDT_BM_SUB_TARGET / SDT_BM_LDS_CAP: test hooks -- small inputs through sub-buckets and several parts)
 		BmKnobs kn;
@@ -944,8 +968,22 @@ static int bm_fold(sdt_ctx *c)
 		if (kn.lds_cap && kn.lds_cap < 16) kn.lds_cap = 16;
 		// (a bucket past kn.giant takes 2^ceil(log2(n / sub_target)) <= 2 n / sub_target + 2 entries; at most in_total / giant buckets are that large)
 		const uint64_t ext_cap = in_total / kn.sub_target * 2 + in_total / kn.giant * 2 + 4096;
-		FOLD_CHK(hipMalloc((void **)&units, ((size_t)SK_NBF + ext_cap) * sizeof(BmUnit)));
+		if (b.units_cap < (uint64_t)SK_NBF + ext_cap) {
+			if (b.units) (void)hipFree(b.units);
+			b.units = nullptr;
+			b.units_cap = 0;
+			FOLD_CHK(hipMalloc((void **)&b.units, ((size_t)SK_NBF + ext_cap + ext_cap / 8) * sizeof(BmUnit)));
+			b.units_cap = (uint64_t)SK_NBF + ext_cap + ext_cap / 8;
+		}
+		units = b.units;
 		sdt_ctx::BmTable &dst = have_old ? b.spare : b.tab;
+		// (buffers of an earlier fold are used as they are when they hold what this one can need at the very most -- 1.25 slots per
+		// entry --; what a fold takes differs a little from run to run, and asking for a few slots more than last time would
+		// replace 30 GB)
+		if (dst.ent && dst.cap < cap && dst.cap >= in_total + (uint64_t)SK_NBF * 64)
+			cap = dst.cap;
+		else if (!dst.ent || dst.cap < cap)
+			cap += cap / 16;
 		for (int attempt = 0; attempt < 2; attempt++) {
 			ret = bm_table_alloc(c, dst, cap, (uint64_t)SK_NBF + ext_cap);
 			if (ret != SDT_OK) goto done;
@@ -971,7 +1009,9 @@ static int bm_fold(sdt_ctx *c)
 			if (b.h_ctl[BM_CTL_SLOTS] <= dst.cap)
 				break;
 			if (attempt == 1) { ret = fail(SDT_ESTATE, "bucket-major table: %llu slots needed, %llu allocated twice", (unsigned long long)b.h_ctl[BM_CTL_SLOTS], (unsigned long long)dst.cap); goto done; }
-			cap = b.h_ctl[BM_CTL_SLOTS] + (1u << 16);        // (the sizes are a function of the input: the second run asks for exactly this)
+			// (the sizes are a function of the input; what is left over in the workgroups' chunks depends on the order of the units
+			// within a size class, which is not: a hundredth on top)
+			cap = b.h_ctl[BM_CTL_SLOTS] + b.h_ctl[BM_CTL_SLOTS] / 100 + (uint64_t)grid * BM_CHUNK + (1u << 16);
 		}
 		dst.nslots = b.h_ctl[BM_CTL_SLOTS];
 		dst.nodes = b.h_ctl[BM_CTL_NODES];
@@ -1013,9 +1053,7 @@ done:
 #undef FOLD_CHK
 	if (ret != SDT_OK)
 		(void)hipStreamSynchronize(c->stream);
-	if (sorted) (void)hipFree(sorted);
 	if (xent) (void)hipFree(xent);
-	if (units) (void)hipFree(units);
 	return ret;
 }
 

@@ -106,6 +106,17 @@ __host__ __device__ inline uint32_t bm_hash_lo(uint32_t fold)
 	return h ^ (h >> 16);
 }
 
+// home slot of a key in a table of `msz` slots (a multiple of 8) from its `lo` hash.  1-word keys start at a multiple of four: four
+// 16-byte entries are one 64-byte sector in HBM and one 32-byte read of key words in LDS (sdt_bm_kernels.cuh: bm_locate).
+template <int NW> __host__ __device__ inline uint32_t bm_home(uint32_t hlo, uint32_t msz)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return NW == 1 ? __umulhi(hlo, msz >> 2) << 2 : __umulhi(hlo, msz);
+#else
+	return NW == 1 ? (uint32_t)(((uint64_t)hlo * (msz >> 2)) >> 32) << 2 : (uint32_t)(((uint64_t)hlo * msz) >> 32);
+#endif
+}
+
 // Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times; n == 0:
 // the key's bucket is empty (bucket-major) -- the key is not there.
 template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const Key<NW> &key, uint64_t &slot, uint64_t &lo, uint64_t &n)
@@ -126,7 +137,7 @@ template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const K
 	}
 	n = d.parts ? d.ssub : 0;
 	lo = d.base + (uint64_t)__umulhi(hh, d.parts) * d.ssub;
-	slot = lo + __umulhi(bm_hash_lo(f), d.ssub);
+	slot = lo + bm_home<NW>(bm_hash_lo(f), d.ssub);
 }
 __device__ inline uint64_t probe_next(uint64_t slot, uint64_t lo, uint64_t n) { return slot + 1 == lo + n ? lo : slot + 1; }
 
