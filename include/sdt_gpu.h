@@ -38,8 +38,10 @@ enum {
 	SDT_ENOMEM   = -3,   /* device or host allocation failed */
 	SDT_EHIP     = -4,   /* HIP runtime error (message in sdt_gpu_last_error) */
 	SDT_EFULL    = -5,   /* node table cannot grow any further */
-	SDT_ESTATE   = -6    /* call out of order (e.g. export before finish); also: the pipeline's conservation check failed
+	SDT_ESTATE   = -6,   /* call out of order (e.g. export before finish); also: the pipeline's conservation check failed
 	                      * (k-mers cut into records != k-mers counted, sdt_gpu_finish_count) -- never a silent loss */
+	SDT_ELIMIT   = -7    /* a data-dependent limit of a device algorithm was passed (sdt_gpu_layout_on_device: rounds of a growth,
+	                      * depth of an eviction chain); nothing was changed: the caller takes the other path */
 };
 
 typedef struct sdt_ctx sdt_ctx;

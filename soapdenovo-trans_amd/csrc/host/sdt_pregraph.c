@@ -789,6 +789,7 @@ int main(int argc, char **argv)
 			if (!getenv("SDT_HOST_REPLAY")) {
 				const int rcl = sdt_gpu_layout_on_device(gpu, threads, nwv, graph_init_kmerset_size != 0, set_start, &n);
 				if (rcl == SDT_OK) on_device = 1;
+				else if (rcl == SDT_ELIMIT) { if (!g_quiet) fprintf(stderr, "[sdt-pregraph] %s: the host replays the layout\n", sdt_gpu_last_error()); }
 				else if (rcl != SDT_EINVAL) { fprintf(stderr, "sdt_gpu_layout_on_device: %s\n", sdt_gpu_last_error()); return 1; }
 				if (on_device) phase("layout: sort + replay + numbering (GPU)");
 			}

@@ -299,8 +299,10 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 			if (v.nw == 1) hipLaunchKernelGGL(k_rp_rehash_init<1>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
 			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_rehash_init<2>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
 			else hipLaunchKernelGGL(k_rp_rehash_init<4>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
+			// (SDT_RP_MAX_ROUNDS: test hook -- a cap that real data passes, so that the caller's other path is exercised)
+			static const int max_rounds = getenv("SDT_RP_MAX_ROUNDS") ? atoi(getenv("SDT_RP_MAX_ROUNDS")) : 60;
 			for (int round = 0;; round++) {
-				if (round > 60) return fail(SDT_ESTATE, "layout on the device: a growth did not settle in 60 rounds");
+				if (round > max_rounds) return fail(SDT_ELIMIT, "layout on the device: a growth did not settle in %d rounds", max_rounds);
 				for (int s = 0; s < p; s++)                       // (only the regions of the sets that grow, at their new size: the early growths are tiny)
 					if (sets[s].old_size) GCHK(hipMemsetAsync(tab[nxt] + sets[s].tab0, 0, (size_t)sets[s].size * 8, v.stream));
 				GCHK(hipMemsetAsync(d_flags, 0, 4, v.stream));
@@ -310,7 +312,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
 				GCHK(hipStreamSynchronize(v.stream));
 				total_rounds++;
-				if (h_flags & 6u) return fail(SDT_ESTATE, "layout on the device: %s", (h_flags & 2u) ? "an insertion found no slot" : "an eviction chain deeper than the time field");
+				if (h_flags & 6u) return fail(SDT_ELIMIT, "layout on the device: %s", (h_flags & 2u) ? "an insertion found no slot" : "an eviction chain deeper than the time field");
 				if (!(h_flags & 1u)) break;
 				tc ^= 1;
 			}
@@ -359,7 +361,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 		GCHK(hipGetLastError());
 		GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
 		GCHK(hipStreamSynchronize(v.stream));
-		if (h_flags) return fail(SDT_ESTATE, "layout on the device: a put found no slot");
+		if (h_flags) return fail(SDT_ELIMIT, "layout on the device: a put found no slot");
 		t_put += now_ms() - t_p0;
 	}
 	if (timing) fprintf(stderr, "[device]     layout replay so far %.1f ms: rehash rounds %.1f, strip + copies %.1f, puts %.1f ms\n", now_ms() - t_start, t_rehash, t_strip, t_put);

@@ -523,6 +523,229 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+// ---- level 2, staged (round 5) ---------------------------------------------------------------------------------------
+// k_sk_scatter_records above stores every record where its sub-bucket's open chunk has room: 24..56 bytes at a time into one
+// of 1024 open chunks per workgroup, so a 128-byte line is written by five or six stores sweeps apart, and many lines leave L2
+// before they are full (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4).  Here a record waits in LDS until its sub-bucket
+// has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56): per tile of 512 records
+//   1   every record takes a ticket of its sub-bucket (one LDS atomic; the tickets start at the records already waiting)
+//   1.5 the lane with the first new ticket of a sub-bucket does its bookkeeping ALONE: complete groups of this tile, room in the
+//       open chunk, new chunks (contiguous ids), the records that waited (read into registers), the state of the next tile --
+//       no cursor that several lanes fight over (sk_reserve's protocol is not used here at all)
+//   2   a record of a complete group goes to its slot of the group in global memory -- the S records of a group are stored in
+//       the same phase, by up to S lanes: 96 / 80 / 112 contiguous bytes that meet in L2 --, the others wait in the stage
+// and at the end of the item the waiting records are written as a last, partial group.  Chunks fill from slot 0 up, so the
+// count stage's lists (chunk id + fill) stay what they were.
+template <int NW> struct SkL2Stage {
+	static constexpr int S = NW == 1 ? 4 : 2;                        // records per group
+	static constexpr int GPC = SK_CAP2 / S;                          // groups per chunk
+	static constexpr size_t SMEM = (size_t)SK_NB2 * S * SkFmt<NW>::REC_WORDS * 8;
+};
+
+template <int NW>
+__global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool src, const uint32_t *__restrict__ list1,
+                                                                         const SkItem *__restrict__ items, SkPool dst,
+                                                                         uint32_t *__restrict__ g_cnt, unsigned long long *__restrict__ g_kmers, Stats *stats)
+{
+	constexpr int RW = SkFmt<NW>::REC_WORDS, S = SkL2Stage<NW>::S, GPC = SkL2Stage<NW>::GPC;
+	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
+	extern __shared__ unsigned long long s_stage[];  // SK_NB2 x S records
+	__shared__ uint32_t s_cnt[SK_NB2];               // tickets of the running tile (start: the records waiting in the stage)
+	__shared__ uint32_t s_open[SK_NB2];              // open chunk of the sub-bucket (SK_NOCHUNK: none)
+	__shared__ uint32_t s_pub_open[SK_NB2], s_pub_new[SK_NB2], s_pub_g[SK_NB2];     // what phase 2 of the tile needs: the open chunk and the groups used in it
+	                                                                               // before the tile (g: used | groups << 8), the first new chunk
+	__shared__ unsigned char s_fill[SK_NB2], s_used[SK_NB2];                       // records waiting; groups used in the open chunk
+	__shared__ uint32_t s_kc[SK_NB2], s_cc[SK_NB2];  // k-mers and chunks per level-2 bucket of this item
+	__shared__ unsigned long long s_blk;
+	const SkItem it = items[blockIdx.x];
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+		s_cnt[i] = 0;
+		s_open[i] = SK_NOCHUNK;
+		s_fill[i] = 0;
+		s_used[i] = 0;
+		s_kc[i] = 0;
+		s_cc[i] = 0;
+	}
+	if (tid == 0)
+		s_blk = 0;
+	__syncthreads();
+	uint32_t failed = 0;
+	// n chunk ids (contiguous): one out of the workgroup's block, more straight from the pool; SK_NOCHUNK: the pool is exhausted
+	auto alloc = [&](uint32_t n) -> uint32_t {
+		const uint32_t id = n == 1 ? sk_alloc_chunk(&s_blk, dst) : atomicAdd(dst.next, n);
+		return id < dst.chunks && id + n <= dst.chunks ? id : SK_NOCHUNK;
+	};
+	// slot of record `t` (ticket) of a sub-bucket whose open chunk had `used` groups in use before: in the open chunk while it lasts,
+	// then in the new chunks
+	auto slot_of = [&](uint32_t open, uint32_t used, uint32_t first_new, uint32_t t) -> uint64_t * {
+		const uint32_t a = (open == SK_NOCHUNK ? (uint32_t)GPC : used) + t / S;
+		if (a < (uint32_t)GPC)
+			return dst.recs + ((size_t)open * SK_CAP2 + a * S + t % S) * RW;
+		if (first_new == SK_NOCHUNK)
+			return nullptr;
+		return dst.recs + ((size_t)(first_new + (a - GPC) / GPC) * SK_CAP2 + ((a - GPC) % GPC) * S + t % S) * RW;
+	};
+	constexpr int D = SDT_SK_L2_DEPTH;
+	const uint32_t slot = (uint32_t)tid % SK_CAP1, cfirst = it.c0 + (uint32_t)tid / SK_CAP1;
+	uint32_t id_a[D], id_b[D], fill_a[D];
+	uint64_t rec_a[D][RW];
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		const uint32_t ca = cfirst + (uint32_t)d * CPT, cb = ca + (uint32_t)D * CPT;
+		id_a[d] = ca < it.c1 ? list1[ca] : SK_NOCHUNK;
+		id_b[d] = cb < it.c1 ? list1[cb] : SK_NOCHUNK;
+	}
+#pragma unroll
+	for (int d = 0; d < D; d++) {
+		fill_a[d] = 0;
+#pragma unroll
+		for (int i = 0; i < RW; i++)
+			rec_a[d][i] = 0;
+		if (id_a[d] != SK_NOCHUNK) {
+			fill_a[d] = src.meta[id_a[d]] >> 24;
+			sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
+		}
+	}
+	// (the sweeps are uniform: every lane of the workgroup runs the same number of them, barriers included)
+	const uint32_t nsweep = (it.c1 - it.c0 + CPT - 1) / CPT;
+	for (uint32_t sw = 0; sw < nsweep; sw += (uint32_t)D) {
+#pragma unroll
+		for (int d = 0; d < D; d++) {
+			const uint32_t ci = cfirst + (sw + (uint32_t)d) * CPT;
+			uint64_t rec[RW];
+#pragma unroll
+			for (int i = 0; i < RW; i++)
+				rec[i] = rec_a[d][i];
+			const uint32_t fill = ci < it.c1 ? fill_a[d] : 0u;
+			id_a[d] = id_b[d];
+			const uint32_t cn = ci + 2u * (uint32_t)D * CPT;
+			id_b[d] = cn < it.c1 ? list1[cn] : SK_NOCHUNK;
+			if (id_a[d] != SK_NOCHUNK) {
+				fill_a[d] = src.meta[id_a[d]] >> 24;
+				sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
+			}
+			const bool valid = slot < fill;
+			// ---- 1: tickets
+			uint32_t b2 = 0, t = 0, f = 0;
+			if (valid) {
+				b2 = sk_hdr_l2(rec[0]);
+				f = s_fill[b2];
+				t = atomicAdd(&s_cnt[b2], 1u);
+				atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
+			}
+			__syncthreads();
+			// ---- 1.5: the first newcomer of a sub-bucket keeps its books
+			const bool keeper = valid && t == f;
+			uint64_t old[S > 1 ? S - 1 : 1][RW];
+			uint32_t kG = 0;
+			if (keeper) {
+				const uint32_t total = s_cnt[b2], G = total / S, left = total - G * S;
+				const uint32_t open = s_open[b2], used = open == SK_NOCHUNK ? (uint32_t)GPC : s_used[b2];
+				const uint32_t room = (uint32_t)GPC - used;
+				uint32_t first_new = SK_NOCHUNK, nnew = 0;
+				if (G > room) {
+					nnew = (G - room + GPC - 1) / GPC;
+					first_new = alloc(nnew);
+					if (first_new != SK_NOCHUNK) {
+						for (uint32_t j = 0; j < nnew; j++)
+							dst.meta[first_new + j] = (it.b1 * SK_NB2 + b2) | ((uint32_t)SK_CAP2 << 24);
+						atomicAdd(&s_cc[b2], nnew);
+					}
+				}
+				s_pub_open[b2] = open;
+				s_pub_new[b2] = first_new;
+				s_pub_g[b2] = used | (G << 8);
+				kG = G;
+				if (G && f) {                        // the records that waited leave with the first group
+#pragma unroll
+					for (int j = 0; j < S - 1; j++)
+						if ((uint32_t)j < f) {
+#pragma unroll
+							for (int i = 0; i < RW; i++)
+								old[j][i] = s_stage[((size_t)b2 * S + j) * RW + i];
+						}
+				}
+				// the next tile's state
+				if (G) {
+					const uint32_t a_end = used + G;     // groups in use, counted from the open chunk's first
+					if (a_end <= (uint32_t)GPC) {
+						s_used[b2] = (unsigned char)a_end;
+					} else if (first_new != SK_NOCHUNK) {
+						s_open[b2] = first_new + (a_end - GPC - 1) / GPC;
+						s_used[b2] = (unsigned char)((a_end - GPC - 1) % GPC + 1);
+					} else {
+						s_open[b2] = SK_NOCHUNK;         // (pool exhausted: the records of this tile are counted as failed below)
+						s_used[b2] = 0;
+					}
+				}
+				s_fill[b2] = (unsigned char)left;
+				s_cnt[b2] = left;
+			}
+			__syncthreads();
+			// ---- 2: complete groups to global memory, the rest waits
+			if (valid) {
+				const uint32_t g = s_pub_g[b2], G = g >> 8, used = g & 0xFFu;
+				if (t / S < G) {
+					uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], t);
+					if (p) sk_store_record<RW>(p, rec);
+					else failed++;
+				} else {
+					const uint32_t at = t - G * S;
+#pragma unroll
+					for (int i = 0; i < RW; i++)
+						s_stage[((size_t)b2 * S + at) * RW + i] = rec[i];
+				}
+				if (keeper && kG && f) {
+#pragma unroll
+					for (int j = 0; j < S - 1; j++)
+						if ((uint32_t)j < f) {
+							uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], (uint32_t)j);
+							if (p) sk_store_record<RW>(p, old[j]);
+							else failed++;
+						}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// the records still waiting: a last, partial group; the open chunks' fills; the item's counts
+	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+		const uint32_t f = s_fill[i];
+		uint32_t open = s_open[i], used = open == SK_NOCHUNK ? (uint32_t)GPC : s_used[i];
+		if (f) {
+			if (used == (uint32_t)GPC) {
+				open = alloc(1);
+				used = 0;
+				if (open != SK_NOCHUNK)
+					s_cc[i]++;
+			}
+			if (open != SK_NOCHUNK) {
+				for (uint32_t j = 0; j < f; j++) {
+					uint64_t rec[RW];
+#pragma unroll
+					for (int w = 0; w < RW; w++)
+						rec[w] = s_stage[((size_t)i * S + j) * RW + w];
+					sk_store_record<RW>(dst.recs + ((size_t)open * SK_CAP2 + used * S + j) * RW, rec);
+				}
+			} else {
+				failed += f;
+			}
+		}
+		if (open != SK_NOCHUNK)
+			dst.meta[open] = (it.b1 * SK_NB2 + (uint32_t)i) | ((used * S + f) << 24);
+		if (s_kc[i])
+			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], (unsigned long long)s_kc[i]);     // (64 bits: a hot bucket of a 2^33-k-mer batch)
+		if (s_cc[i])
+			atomicAdd(&g_cnt[it.b1 * SK_NB2 + i], s_cc[i]);
+	}
+	__syncthreads();
+	if (tid == 0)
+		sk_retire_block(s_blk, dst);
+	if (failed)
+		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
 // ---- exchange: pack the level-1 chunks of every destination rank's buckets into one contiguous run ------------------
 struct SkGatherPlan {
 	uint32_t begin[64];          // first position in the chunk list of the piece that goes to rank p

@@ -75,12 +75,15 @@ def test_config_parser(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks"])
+@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks", "pipeline", "replay-limit"])
 @pytest.mark.parametrize("name", gu.case_names())
 def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     """sdt-pregraph end to end: all five files of the reference's pregraph, byte for byte, with the second read
     pass (prlRead2edge) on the GPU over the reads kept in HBM (default) or on the host (--host-map), and with the
-    tip-cutting dry runs on the device (default) or on the host (--host-walks, and always with --host-map)"""
+    tip-cutting dry runs on the device (default) or on the host (--host-walks, and always with --host-map).
+    `pipeline`: pass 1 through the locality pipeline, whatever the size of the job -- every device graph phase (layout, walks,
+    junction records, commits, kmer2edges, the second read pass) then looks its k-mers up in the BUCKET-MAJOR node table;
+    `replay-limit`: the device's layout replay gives up at once (SDT_ELIMIT) and the CLI takes the host's replay instead"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
@@ -93,8 +96,15 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
         cmd += ["--host-map"]
     if second_pass == "host-walks":      # default: the tip walks come from the device mirror of the graph
         cmd += ["--host-walks"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    env = dict(os.environ)
+    if second_pass == "pipeline":
+        env["SDT_PIPELINE"] = "1"
+    if second_pass == "replay-limit":
+        env["SDT_RP_MAX_ROUNDS"] = "0"
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
+    if second_pass == "replay-limit" and name == "pe150_k31_p8":      # (its sets grow: the limit is hit)
+        assert "the host replays the layout" in r.stderr
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")      # same -p => same order
     assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == gzip.open(os.path.join(info["dir"], "out.edge.txt.gz"), "rt").read()
