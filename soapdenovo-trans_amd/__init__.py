@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
 SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST, SDT_FLAG_KEEP_READS, SDT_FLAG_CONTIG_INDEX = 1, 2, 4, 8, 16
+SDT_FLAG_FLAT_MERGE, SDT_FLAG_NODE_LOG = 32, 64
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE, SDT_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)

@@ -66,8 +66,8 @@ enum { BM_CTL_SLOTS, BM_CTL_NODES, BM_CTL_RESTARTS, BM_CTL_MAXPARTS, BM_CTL_EXT,
 // merged side by side by different workgroups (one workgroup taking the whole of a giant minimizer's bucket -- 84 passes over
 // half a million entries on the 200 M-read workload -- was the whole tail of the kernel: 89 ms).  Its directory entry then says
 // {base = index of the first of 2^lg directory entries of its own, ssub = 0, parts = lg} (sdt_table.cuh: probe_begin).
-constexpr unsigned long long BM_GIANT = 16384;       // entries + nodes a bucket is merged as one unit up to
-constexpr unsigned long long BM_SUB_TARGET = 8192;   // ... and what a sub-bucket holds on average beyond
+constexpr unsigned long long BM_GIANT = 32768;       // entries + nodes a bucket is merged as one unit up to (its parts re-read its input)
+constexpr unsigned long long BM_SUB_TARGET = 12288;  // ... and what a sub-bucket holds on average beyond (every sub-bucket reads all of it)
 constexpr uint32_t BM_MAX_LG = 12;
 struct BmKnobs {                                     // (the host's copy of the three: tests shrink them so that small inputs take every path)
 	unsigned long long giant, sub_target;
@@ -286,34 +286,63 @@ __device__ __forceinline__ int bm_locate(unsigned long long *m_key, uint32_t msz
 		}
 		return -1;
 	} else {
-		int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
+		// Multi-word keys, the same four slots per step: the first key words of a group in one read; a candidate (first word equal)
+		// is settled by its other words, an empty slot by a compare-and-swap to KEY_LOCKED, the other words, and the first word last
+		// (release).  A slot that is LOCKED is somebody writing those: the group is read again.  Flag form -- the claimer's stores
+		// are INSIDE the loop body and the loop ends on `found`: an exit path may be moved behind the loop, and the lanes that wait
+		// for the claimer -- possibly a lane of their own wave -- would wait for ever (tools/lds_cursor_stress.hip).
+		int found = -2;
 		for (uint32_t probe = 0; probe < lim && found == -2;) {
-			uint64_t k0 = __hip_atomic_load(&m_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (k0 == KEY_EMPTY) {
-				const uint64_t old = atomicCAS(&m_key[s], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
-				if (old == KEY_EMPTY) {
+			asm volatile("" ::: "memory");               // (the group is READ AGAIN when a slot was being written: not a value the compiler may keep)
+			const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&m_key[s]), b = *reinterpret_cast<const ulonglong2 *>(&m_key[s + 2]);
+			uint64_t k0 = a.x, k1 = a.y, k2 = b.x, k3 = b.y;
+			const uint64_t me = key.w[0];
+			bool again = false;
+			while (found == -2 && !again) {
+				// the first slot of the group that matters: a candidate, an empty one, or one being written
+				const int j = (k0 == me || k0 >= KEY_LOCKED) ? 0 : ((k1 == me || k1 >= KEY_LOCKED) ? 1 : ((k2 == me || k2 >= KEY_LOCKED) ? 2 : ((k3 == me || k3 >= KEY_LOCKED) ? 3 : 4)));
+				if (j == 4)
+					break;                               // four other keys: on to the next group
+				const uint64_t kj = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3));
+				uint64_t seen = kj;
+				if (kj == KEY_EMPTY) {
+					seen = atomicCAS(&m_key[s + j], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_LOCKED);
+					if (seen == KEY_EMPTY) {
 #pragma unroll
-					for (int i = 1; i < NW; i++)
-						m_key[i * M + s] = key.w[i];
-					__hip_atomic_store(&m_key[s], key.w[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-					found = (int)s;
+						for (int i = 1; i < NW; i++)
+							m_key[i * M + s + j] = key.w[i];
+						__hip_atomic_store(&m_key[s + j], me, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						found = (int)s + j;
+						continue;
+					}
+				}
+				if (seen == KEY_LOCKED) {
+					again = true;                        // (its claimer is about to publish it: look at the group again)
 					continue;
 				}
-				k0 = old;
-			}
-			if (k0 == KEY_LOCKED)
-				continue;                                // the claimer is writing the low words: look again
-			bool same = k0 == key.w[0];
-			if (same) {
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				bool same = seen == me;
+				if (same) {
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-				for (int i = 1; i < NW; i++)
-					same = same && (__hip_atomic_load(&m_key[i * M + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[i]);
+					for (int i = 1; i < NW; i++)
+						same = same && (__hip_atomic_load(&m_key[i * M + s + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[i]);
+				}
+				if (same) {
+					found = (int)s + j;
+					continue;
+				}
+				// another key (its first word may even equal ours): not a candidate any more
+				const uint64_t other = 1ULL << 62;       // (nobody's first word: a key word never has its top two bits set; < KEY_LOCKED)
+				if (seen == me) {
+					k0 = j == 0 ? other : k0; k1 = j == 1 ? other : k1; k2 = j == 2 ? other : k2; k3 = j == 3 ? other : k3;
+				} else {
+					k0 = j == 0 ? seen : k0; k1 = j == 1 ? seen : k1; k2 = j == 2 ? seen : k2; k3 = j == 3 ? seen : k3;
+				}
 			}
-			if (same)
-				return (int)s;
-			s = s + 1 == msz ? 0u : s + 1;
-			probe++;
+			if (found == -2 && !again) {
+				s = s + 4 == msz ? 0u : s + 4;
+				probe += 4;
+			}
 		}
 		return found == -2 ? -1 : found;
 	}

@@ -416,6 +416,7 @@ struct sdt_ctx {
 	uint64_t kmers_total_host = 0;
 	uint64_t kmers_offered = 0;        // upper bound of the k-mers handed to pass 1 since the last reset (picks the kernel family)
 	uint32_t flags = 0;
+	bool node_log = true;              // the count stage appends to the node log (false: it merges into the flat table, rounds 2-4)
 	// locality pipeline (sdt_superkmer.cuh): chunk pools of the two scatter levels, chunk lists, pending work
 	struct SkState {
 		bool ready = false;
@@ -958,7 +959,8 @@ static int bm_fold(sdt_ctx *c)
 		// workgroups of the merge: two per CU (k_bm_finalize), fewer for a small input -- each takes the table's slots in chunks of BM_CHUNK
 		unsigned grid = (unsigned)c->cu_count * BM_WGS_PER_CU;
 		if ((uint64_t)grid > in_total / 8192 + 1) grid = (unsigned)(in_total / 8192 + 1);
-		uint64_t cap = (uint64_t)((double)(nold + nflat + nlog) * 1.05) + (uint64_t)SK_NBF * 256 + (uint64_t)grid * BM_CHUNK + (1u << 16);
+		// (wide keys: 52 bytes per slot -- three quarters of that, and the second run when it was short)
+		uint64_t cap = (uint64_t)((double)(nold + nflat + nlog) * (c->nw == 1 ? 1.05 : 0.8)) + (uint64_t)SK_NBF * 256 + (uint64_t)grid * BM_CHUNK + (1u << 16);
 		// directory entries of the sub-buckets of giant buckets: a bucket of n > BM_GIANT entries takes 2^ceil(log2(n / BM_SUB_TARGET)) < 4 n / BM_SUB_TARGET
 		// (SDT_BM_GIANT / SDT_BM_SUB_TARGET / SDT_BM_LDS_CAP: test hooks -- small inputs through sub-buckets and several parts)
 		BmKnobs kn;
@@ -1349,6 +1351,26 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	return sk_reset_pool1(c);
 }
 
+template <int NW, bool TRACK> static int sk_launch_count_flat_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+{
+	sdt_ctx::SkState &k = c->sk;
+	const size_t smem = sk_count_smem<NW, TRACK>();
+	// persistent workgroups: as many as the LDS tables let the chip hold; they take work items first come first served
+	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 256));
+	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+	if (grid > i1 - i0) grid = i1 - i0;
+	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count_flat<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	hipLaunchKernelGGL((k_sk_count_flat<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, (const uint4 *)k.citems, i0, i1,
+	                   k.next_item + launch, c->K, flat_of<NW>(c), c->d_stats);
+	HIPCHK(hipGetLastError());
+	return SDT_OK;
+}
+
+template <int NW> static int sk_launch_count_flat(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+{
+	return c->d_first ? sk_launch_count_flat_t<NW, true>(c, i0, i1, launch) : sk_launch_count_flat_t<NW, false>(c, i0, i1, launch);
+}
+
 template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch, const SkLog &lg)
 {
 	sdt_ctx::SkState &k = c->sk;
@@ -1439,9 +1461,104 @@ static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_
 	return SDT_OK;
 }
 
+// count pool 2 bucket by bucket with merges into the flat table (rounds 2-4: SDT_FLAG_FLAT_MERGE, multi-word keys)
+static int sk_count_all_flat(sdt_ctx *c)
+{
+	sdt_ctx::SkState &k = c->sk;
+	SK_CHK(hipStreamSynchronize(c->stream));
+	k.st_chunks2 = k.h_off2[SK_NBF];
+	k.st_flushes++;
+	k.stream_flushes++;
+	k.l2_in_total += k.h_kpre2[SK_NBF];
+	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; launches of at most SK_COUNT_KMERS
+	// k-mers (every one might be a new node: ensure_room)
+	int rc = SDT_OK;
+	uint32_t nci = 0;
+	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
+	// A launch must find room for every node it may create.  "Every occurrence is a new node" is hopeless for a batch of
+	// 2^33 k-mers, so: a first launch of at most 2^26 k-mers under that bound, then launches bounded by twice the rate of
+	// new nodes per occurrence seen so far (later data usually brings fewer new nodes, not more; should it bring more, the load
+	// factor suffers until the next look but the table cannot fill: see the 95 % rule below).
+	// (the items and launches are a pure function of the chunk lists: sdt_count_plan.h, tested on the CPU)
+	std::vector<uint32_t> first_item(SK_MAX_COUNT_LAUNCHES + 2);   // first item of every launch
+	std::vector<uint64_t> launch_kmers(SK_MAX_COUNT_LAUNCHES + 2);
+	uint32_t nlaunches = 0;
+	
+	if (!sk_plan_count_items(k.h_off2, (const uint64_t *)k.h_kpre2, (uint32_t)SK_NBF, c->kmers_known == 0 ? (1ULL << 26) : SK_COUNT_KMERS, SK_COUNT_KMERS,
+	                         SK_MAX_COUNT_LAUNCHES, SK_COUNT_PACK_CHUNKS, SK_COUNT_ITEM_CHUNKS, (uint32_t *)k.h_citems, k.citems_cap,
+	                         first_item.data(), launch_kmers.data(), (uint32_t)first_item.size(), &nci, &nlaunches))
+		return fail(SDT_ESTATE, "count stage: work item table overflow");
+	first_item.resize(nlaunches + 1);
+	launch_kmers.resize(nlaunches);
+	std::vector<uint32_t> sort_tmp;
+	auto guess_of = [&](uint64_t kmers) -> uint64_t {
+		uint64_t bound = kmers;
+		if (c->kmers_known) {
+			const double rate = (double)c->distinct_known / (double)c->kmers_known;
+			const uint64_t guess = (uint64_t)((double)kmers * (2.0 * rate < 1.0 ? 2.0 * rate : 1.0)) + (1ULL << 22);
+			if (guess < bound) bound = guess;
+		}
+		return bound;
+	};
+	const size_t nl = first_item.size() - 1;
+	for (size_t l = 0; l < nl && rc == SDT_OK;) {
+		const uint32_t i0 = first_item[l];
+		if (i0 == first_item[l + 1]) {
+			l++;
+			continue;
+		}
+		if (c->kmers_known == 0 && l > 0) {
+			rc = sync_stats(c);                      // the first launch has run: its rate of new nodes bounds the rest
+			if (rc != SDT_OK) break;
+		}
+		uint64_t bound = guess_of(launch_kmers[l]), hard = launch_kmers[l];
+		rc = ensure_room(c, bound);
+		// the guess keeps the load factor; this keeps the table from FILLING should the guess be wrong: whatever the data,
+		// the nodes known + every k-mer launched since + this launch must fit 95 % of the slots
+		if (rc == SDT_OK && (double)(c->distinct_known + c->hard_since_sync + launch_kmers[l]) > 0.95 * (double)c->slots) {
+			rc = sync_stats(c);
+			if (rc == SDT_OK && (double)(c->distinct_known + launch_kmers[l]) > 0.95 * (double)c->slots)
+				rc = grow_table(c, c->distinct_known + launch_kmers[l]);
+		}
+		// The planned launches behind this one join it as long as neither rule would have to look at the device's counters for
+		// them: a launch boundary is a drained GPU (every workgroup waits for the slowest), and it is only needed where the host
+		// decides about the table.  (45 planned launches per step of the 200 M-read workload become about a dozen.)
+		size_t m = l;
+		while (rc == SDT_OK && c->kmers_known && m + 1 < nl) {
+			const uint64_t b2 = guess_of(launch_kmers[m + 1]);
+			if ((double)(c->distinct_known + c->kmers_since_sync + bound + b2) > (double)c->slots * MAX_LOAD)
+				break;
+			if ((double)(c->distinct_known + c->hard_since_sync + hard + launch_kmers[m + 1]) > 0.95 * (double)c->slots)
+				break;
+			bound += b2;
+			hard += launch_kmers[m + 1];
+			m++;
+		}
+		const uint32_t i1 = first_item[m + 1];
+		// (largest first over everything this launch hands out -- the plan did it per planned launch; the sort is stable, so the
+		// concatenation of sorted runs comes out as one)
+		if (m > l)
+			sk_plan_largest_first((uint32_t *)k.h_citems, i0, i1, sort_tmp);
+		if (rc == SDT_OK)
+			SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+		if (rc == SDT_OK)
+			rc = c->nw == 1 ? sk_launch_count_flat<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count_flat<2>(c, i0, i1, (uint32_t)l) : sk_launch_count_flat<4>(c, i0, i1, (uint32_t)l);
+		if (rc == SDT_OK) {                              // (only what was launched counts)
+			c->kmers_since_sync += bound;
+			c->hard_since_sync += hard;
+		}
+		l = m + 1;
+	}
+	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
+	return rc;
+}
+
 // count pool 2 bucket by bucket (host sync first: the chunk lists of sk_split come back)
 static int sk_count_all(sdt_ctx *c)
 {
+	if (!c->node_log)
+		return sk_count_all_flat(c);
+
 	sdt_ctx::SkState &k = c->sk;
 	SK_CHK(hipStreamSynchronize(c->stream));
 	k.st_chunks2 = k.h_off2[SK_NBF];
@@ -1981,8 +2098,12 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	// The flat table is the direct kernel family's (jobs below 2^27 k-mers, SDT_FLAG_DIRECT, the contig index); the locality
 	// pipeline builds the bucket-major table out of its log (sized when the log is folded: bm_fold) and uses the flat one only
 	// for records that found no chunk.  So the estimate sizes the flat table up to 2^27 slots and the fold beyond that.
+	c->node_log = c->nw == 1;
+	if (const char *pt = getenv("SDT_PASS1_TABLE")) c->node_log = !strcmp(pt, "log") ? true : (!strcmp(pt, "flat") ? false : c->node_log);
+	if (flags & SDT_FLAG_FLAT_MERGE) c->node_log = false;
+	if (flags & SDT_FLAG_NODE_LOG) c->node_log = true;
 	uint64_t slots = 1ULL << 16;
-	const uint64_t flat_max = (flags & (SDT_FLAG_DIRECT | SDT_FLAG_CONTIG_INDEX)) ? ~0ULL : (1ULL << 27);
+	const uint64_t flat_max = ((flags & (SDT_FLAG_DIRECT | SDT_FLAG_CONTIG_INDEX)) || !c->node_log) ? ~0ULL : (1ULL << 27);
 	while ((double)slots * 0.5 < (double)est_distinct && slots < flat_max)
 		slots <<= 1;
 	c->slots = slots;
@@ -2431,7 +2552,7 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
 		while (est > (1u << 20) && (double)est / MAX_LOAD * 2.0 * (double)per_slot > (double)free_b * 0.3)
 			est /= 2;                                    // (never more than ~30 % of what is free, power-of-two rounding included)
-		if (!(c->flags & SDT_FLAG_DIRECT)) {
+		if (c->node_log && !(c->flags & SDT_FLAG_DIRECT)) {
 			// (the locality pipeline folds its log into a table of its own: the estimate sizes THAT, bm_fold)
 			if (c->bm.est_distinct < est) c->bm.est_distinct = est;
 		} else if ((double)est > (double)c->slots * MAX_LOAD) {

@@ -895,6 +895,504 @@ __device__ inline uint64_t sk_weighted_val(uint32_t w, uint32_t prev, uint32_t n
 
 constexpr uint32_t SK_CNT_MAX_SINCE = 65535;     // k-mers counted into the LDS table between two clears at most (16-bit fields)
 
+// ---- count with merges into the FLAT node table (rounds 2-4; since round 5 the path of multi-word keys and of SDT_FLAG_FLAT_MERGE) --------
+// The same phases A-D as k_sk_count below; a flush MERGES every LDS node into the flat table -- without atomics when the workgroup is the
+// only writer of the bucket's keys in the launch, by one saturating compare-and-swap otherwise --, and a k-mer that finds no LDS slot goes
+// there directly.  Kept beside the node log because the log's fold is not faster for 2- and 4-word keys (profiles/r5/README.md: C4 27.9
+// against 35.8 G k-mers/s) and needs the log's memory on top of the table's.
+// (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU.  8 waves per SIMD also
+// means 78 usable SCALAR registers -- 800 per SIMD in granules of 16, 16 of every wave's reserved -- and this kernel keeps
+// about ninety uniform values: the overflow lives in lanes of vector registers.  Raising the scalar budget by hand
+// (amdgpu_waves_per_eu(4, 8) + amdgpu_num_vgpr(32) + amdgpu_num_sgpr(96)) removed every spill and cost the second workgroup
+// per CU: 172 -> 251 ms per step on the 200 M-read workload.)
+template <int NW, bool TRACK>
+__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count_flat(SkPool pool, const uint32_t *__restrict__ list2, const uint4 *__restrict__ items,
+                                                         uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
+                                                         Table<NW> tbl, Stats *stats)
+{
+	using G = SkCntGeo<NW, TRACK>;
+	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = G::SLOTS;
+	constexpr uint32_t FLUSH_AT = G::FLUSH_AT, MAXFILL = G::MAXFILL;
+	constexpr int SK_CNT_TPB = G::TPB;
+	constexpr int TR = G::TILE;                      // records per tile: the first TR lanes bring one each
+	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
+	constexpr int NWAVES = TR / 64;
+	constexpr uint32_t REP = G::REP, REP_EMPTY = 0xFFFFFFFFu;
+	extern __shared__ unsigned long long sm64[];
+	// (the tile's small arrays first: every base below 64 KB is an immediate offset of a ds instruction, not a register)
+	unsigned long long *s_h0 = sm64;                                     // TR: headers (TRACK: the smallest among a record's duplicates)
+	uint32_t *s_w = (uint32_t *)(s_h0 + TR);                             // TR: weight of a distinct record
+	uint32_t *s_pre = s_w + TR;                                          // TR + 2   } this region is the dedupe table s_rep
+	unsigned short *s_map = (unsigned short *)(s_pre + TR + 2);          // TR       } (REP words) during phase B
+	unsigned short *s_idx = s_map + TR;                                  // IDXN: distinct record of every 16th k-mer
+	uint32_t *s_rep = s_pre;
+	uint32_t *s_words = (uint32_t *)((char *)s_pre + G::REGION);         // LDS_LEAD + TR * BW * 2 + TAIL_PAD (an even number of words)
+	unsigned long long *s_key = (unsigned long long *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);     // NW x SLOTS, word-major
+	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
+	uint32_t *s_f = (uint32_t *)(s_ord + (TRACK ? SLOTS : 0));           // 5 x SLOTS
+	__shared__ uint32_t s_fillc[2], s_item, s_spilled;       // s_fillc: keys in the LDS table = the sum of two counters, see phase D
+	// statistics of the workgroup (claimed, failed, merges, spills, gens, k-mers, records, distinct records, their k-mers): in LDS, not
+	// in nine registers per lane that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
+	enum { ST_CLAIMED, ST_FAILED, ST_MERGES, ST_SPILLS, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
+	__shared__ uint32_t s_stat[ST_N];
+	__shared__ uint32_t s_ent[3 * (G::TILE / SK_CAP2)];      // ring of list entries: the tiles t, t + 1, t + 2 (see below)
+	__shared__ unsigned long long s_wsum[NWAVES];
+	const int tid = threadIdx.x;
+	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+		s_key[i] = KEY_EMPTY;
+		if (TRACK) s_ord[i] = ORD_NONE;
+	}
+	for (int i = tid; i < 5 * SLOTS; i += SK_CNT_TPB)
+		s_f[i] = 0;
+	if (tid < LDS_LEAD)
+		s_words[tid] = 0;
+	if (tid < TAIL_PAD)
+		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
+	if (tid == 0)
+		s_fillc[0] = s_fillc[1] = 0;
+	if (tid < ST_N)
+		s_stat[tid] = 0;
+	uint32_t *words = s_words + LDS_LEAD;
+#ifdef SDT_SK_TICKS
+	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
+#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define SK_TICK(i) do { } while (0)
+#endif
+	// The owned flush of 1-word keys works on registers: every lane takes its PER slots out of LDS, issues all node-table loads, then
+	// merges (flush_finish).  (An experiment that finished the merges a tile later -- to hide the round trip behind the next tile's
+	// phases A-C -- measured no gain, the flushes are bound by HBM traffic, and was removed: profiles/r3/count_kernel_experiments.md.)
+	constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
+	Key<NW> mk[PER];
+	uint64_t madd[PER], mord[TRACK ? PER : 1];       // (the slot of a key is hashed again when the flush is finished: two registers
+	bool have[PER];                                  //  per key less to carry across a tile)
+	EntSnap<NW, TRACK> sn[PER];
+	uint32_t ko = 0, km = 0;                         // (uniform) the two key counters as of the last barrier: the one that stands still in the coming round; the one the round adds to (bit 31: which)
+	uint32_t room_shift = NW == 1 ? 2u : 1u;          // (uniform) a round of phase D takes 1, 2 or 4 k-mers per free slot of the LDS table
+	bool stores_pending = false;                     // (uniform) plain stores of an owned flush may still be in flight
+	auto flush_finish = [&]() {
+		uint32_t claimed = 0, failed = 0, merges = 0;
+#pragma unroll
+		for (int p = 0; p < PER; p++)
+			if (have[p]) {
+				merges++;
+				if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], key_hash<NW>(mk[p]) & tbl.mask, sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
+					failed++;
+			}
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) {
+			claimed += __shfl_down(claimed, d);
+			failed += __shfl_down(failed, d);
+			merges += __shfl_down(merges, d);
+		}
+		if ((tid & 63) == 0) {
+			if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+			if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+			if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+		}
+		stores_pending = true;
+	};
+	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and merged on
+	// its own), handed out first come first served
+	for (;;) {
+		if (tid == 0) {
+			s_item = item0 + atomicAdd(next_item, 1u);
+			s_spilled = 0;
+		}
+		__syncthreads();
+		const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);     // (uniform values belong in scalar registers)
+		__syncthreads();
+		if (item >= item1)
+			break;
+		const uint4 it = items[item];                // c0, c1 | whole (the bucket words are the node log's: k_sk_count)
+		const uint32_t ity = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+		const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), c1 = ity & 0x7FFFFFFFu;
+		const bool whole = (ity >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
+		// Chunk id -> record are two dependent memory round trips per tile, and on this kernel's 64-register budget nothing can
+		// wait in registers across the counting loop: the compiler spilled every such value (the next record, its chunk id, even
+		// one prefetch dword), i.e. waited for the load at once -- with both trips in the open phases A-C were a third of the
+		// kernel's time (tick counters, profiles/r3).  So the prefetches live across phases A-C only, where registers are free:
+		// at the top of tile t wave 0 asks for the list entries of tile t + 2 and every record lane for ONE dword of its record
+		// of tile t + 1 (which pulls the record's line into L2); at the end of phase C the entries go into a ring of three rows
+		// in LDS and the dword is dropped.  The real record load at the top of a tile is then an L2 hit behind a known address.
+		// A list entry carries the chunk's fill (k_sk_chunk_place): pool.meta is not read here.  (LDS-DMA -- global_load_lds_dword,
+		// no destination register at all -- was tried for both and ran 10..50x slower than no prefetch: profiles/r3.)
+		auto rec_ptr = [&](uint32_t e, uint32_t t) -> const uint64_t * {
+			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * RW;
+		};
+		auto rec_ok = [&](uint32_t e, uint32_t t) -> bool { return e != SK_NOCHUNK && t % SK_CAP2 <= (e >> SK_LIST2_FILL_SHIFT); };
+		auto ent_row = [&](uint32_t t) -> uint32_t * { return s_ent + (t % 3u) * CPT; };
+		if (tid < CPT) {
+			ent_row(0)[tid] = c0 + (uint32_t)tid < c1 ? list2[c0 + tid] : SK_NOCHUNK;
+			ent_row(1)[tid] = c0 + CPT + (uint32_t)tid < c1 ? list2[c0 + CPT + tid] : SK_NOCHUNK;
+		}
+		__syncthreads();
+		uint32_t tile_no = 0;
+		uint32_t since = 0;                          // k-mers counted into the LDS table since its last clear (uniform)
+		SK_TICK(0);
+		for (uint32_t cb = c0; cb < c1; cb += CPT) {
+			// ---- A: the first TR lanes put their record into LDS
+			// (phases A-C address everything from an opaque copy of the lane id: hoisted out of the tile loop, lane-dependent
+			// addresses would sit in -- spilled -- registers, and every reload of a spilled register waits for ALL loads in
+			// flight, the prefetches included)
+			uint32_t ot_ = (uint32_t)tid;
+			asm volatile("" : "+v"(ot_));
+			const int ot = (int)ot_;
+			uint32_t n = 0;
+			uint64_t h0 = 0;
+			uint64_t nx[RW];
+			uint32_t ring_e = SK_NOCHUNK, pf = 0;        // prefetches: in flight during phases A-C
+			const uint32_t e = ot < TR ? ent_row(tile_no)[ot / SK_CAP2] : SK_NOCHUNK;
+			const uint32_t e1 = ot < TR ? ent_row(tile_no + 1)[ot / SK_CAP2] : SK_NOCHUNK;
+			const bool ok = rec_ok(e, ot);
+			// (every lane loads, from a harmless address when it has nothing to load: behind a branch the compiler cannot count
+			// the loads in flight and waits for all of them; and the prefetches are issued BEHIND the loads this phase waits
+			// for, because vector memory returns in order)
+			sk_load_record<RW>(ok ? rec_ptr(e, ot) : pool.recs, nx);
+			const bool ring_ok = ot < CPT && cb + 2 * CPT + (uint32_t)ot < c1;
+			ring_e = (list2 + cb)[ring_ok ? 2 * CPT + ot : 0];
+			if (!ring_ok)
+				ring_e = SK_NOCHUNK;
+			if (SDT_SK_PREFETCH)
+				pf = *(const uint32_t *)(rec_ok(e1, ot) ? rec_ptr(e1, ot) : pool.recs);
+			if (ot < TR) {
+				if (ok) {
+					h0 = nx[0];
+					n = (uint32_t)sk_hdr_n(h0);
+#pragma unroll
+					for (int i = 0; i < BW; i++) {
+						words[ot * BW * 2 + 2 * i] = (uint32_t)(nx[1 + i] >> 32);
+						words[ot * BW * 2 + 2 * i + 1] = (uint32_t)nx[1 + i];
+					}
+				}
+				s_h0[ot] = h0;
+				s_w[ot] = 1;
+			}
+			for (uint32_t i = ot; i < REP; i += SK_CNT_TPB)
+				s_rep[i] = REP_EMPTY;
+			__syncthreads();                             // (also: the rounds of the last tile are over, the table is quiet)
+			// ---- B: dedupe
+			bool distinct = false;
+			if (n) {
+				distinct = true;
+				uint32_t x = (uint32_t)h0 & SK_HDR_KIND_MASK;
+#pragma unroll
+				for (int i = 0; i < BW; i++) {
+					x = __builtin_rotateleft32(x, 5) ^ (uint32_t)nx[1 + i];
+					x = __builtin_rotateleft32(x, 11) ^ (uint32_t)(nx[1 + i] >> 32);
+				}
+				uint32_t slot = (x * 0x85EBCA77u) >> (32 - 10);
+				static_assert(REP == 1024, "the dedupe slot is 10 bits of the hash");
+				for (;;) {
+					const uint32_t cur = atomicCAS(&s_rep[slot], REP_EMPTY, (uint32_t)ot);
+					if (cur == REP_EMPTY)
+						break;                           // this record represents its kind
+					// identical records: same bases, and the same low 18 header bits (bucket, n, context flags)
+					bool same = (((uint32_t)s_h0[cur] ^ (uint32_t)h0) & SK_HDR_KIND_MASK) == 0;
+#pragma unroll
+					for (int i = 0; i < BW; i++)
+						same = same && (((uint64_t)words[cur * BW * 2 + 2 * i] << 32) | words[cur * BW * 2 + 2 * i + 1]) == nx[1 + i];
+					if (same) {
+						atomicAdd(&s_w[cur], 1u);
+						if (TRACK)
+							atomicMin(&s_h0[cur], (unsigned long long)h0);
+						distinct = false;
+						break;
+					}
+					slot = (slot + 1) & (REP - 1);
+				}
+			}
+			// exclusive prefix sums over the distinct records: k-mers [15:0], records [31:16]; all k-mers of the tile [47:32], all its records [63:48]
+			const uint32_t n_mine = distinct ? n : 0u;
+			unsigned long long xs = ((unsigned long long)(n ? (n | 0x10000u) : 0u) << 32) | (distinct ? (n | 0x10000u) : 0u);
+			const unsigned long long xs_mine = xs;
+			if (ot < TR) {
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const unsigned long long y = __shfl_up(xs, d);
+					if ((ot & 63) >= d)
+						xs += y;
+				}
+				if ((ot & 63) == 63)
+					s_wsum[ot >> 6] = xs;
+			}
+			__syncthreads();
+			// ---- C: compact map of the distinct records
+			unsigned long long wbase = 0, tot = 0;
+#pragma unroll
+			for (int wv = 0; wv < NWAVES; wv++) {
+				const unsigned long long v = s_wsum[wv];
+				if (wv < (ot >> 6)) wbase += v;
+				tot += v;
+			}
+			const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tot), thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tot >> 32));
+			const uint32_t total = tlo & 0xFFFFu, ndist = tlo >> 16, tile_kmers = thi & 0xFFFFu;
+			// the 16-bit fields hold what this tile can add only if the table is young enough (uniform decision)
+			bool want_flush = since + tile_kmers > SK_CNT_MAX_SINCE;
+			since += tile_kmers;
+			if (distinct) {
+				const uint32_t ex = (uint32_t)(wbase + xs - xs_mine);
+				const uint32_t lo = ex & 0xFFFFu, ci = (ex >> 16) & 0xFFFFu, hi = lo + n_mine;
+				s_pre[ci] = lo;
+				s_map[ci] = (unsigned short)ot;
+				// coarse index: every 16th k-mer of the tile lies in exactly one record, which writes itself there
+				// (the look-up below starts from it instead of searching the whole prefix array)
+				for (uint32_t m16 = (lo + 15u) & ~15u; m16 < hi; m16 += 16u)
+					s_idx[m16 >> 4] = (unsigned short)ci;
+			}
+			if (ot < CPT)
+				ent_row(tile_no + 2)[ot] = ring_e;
+			asm volatile("" :: "v"(pf));                 // (the warm-up dword dies here)
+			if (ot == 0) {
+				s_pre[ndist] = total;
+				s_stat[ST_KMERS] += tile_kmers;
+				s_stat[ST_RECS] += thi >> 16;
+				s_stat[ST_DRECS] += ndist;
+				s_stat[ST_DKMERS] += total;
+			}
+			__syncthreads();
+			SK_TICK(1);
+			// ---- D: rounds of up to 4 k-mers per free slot: barriers are what this loop pays for (a k-mer that does find the table
+			// full takes the direct path)
+			const bool last_tile = cb + CPT >= c1;
+			tile_no++;
+			for (uint32_t qb = 0;;) {
+				if (want_flush) {
+					SK_TICK(2);
+					// merge every LDS node into the node table and clear it: plain read-modify-write when this workgroup is the
+					// only writer of the bucket's keys, one saturating CAS per distinct key otherwise.  (The ONE place where it is
+					// done -- before a tile that could overflow the fields, between rounds when the table is half full, after the
+					// item's last round: three copies of the merge code cost the hot loop its registers.)
+					const bool owned = whole && __builtin_amdgcn_readfirstlane((int)s_spilled) == 0;
+					uint32_t claimed = 0, failed = 0, merges = 0;
+					// (the stores of the previous flush were left in flight: they must have landed before this one reads)
+					if (stores_pending) {
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						__syncthreads();
+						stores_pending = false;
+					}
+					if (owned && (NW > 1 || TRACK) && SDT_SK_SEQ_FLUSH) {
+						// multi-word keys, keys with ordinals: one slot at a time -- two keys, two snapshots and two addresses in flight did not fit the 64
+						// registers, and a spilled snapshot is a load that is waited for at once (see the 1-word path below)
+#pragma unroll 1
+						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+							if (s_key[i] == KEY_EMPTY)
+								continue;
+							Key<NW> key;
+							key.w[0] = s_key[i];
+#pragma unroll
+							for (int wv = 1; wv < NW; wv++)
+								key.w[wv] = s_key[wv * SLOTS + i];
+							const uint64_t add = sk_lds_val(&s_f[5 * i]);
+							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
+							s_key[i] = KEY_EMPTY;
+#pragma unroll
+							for (int f = 0; f < 5; f++)
+								s_f[5 * i + f] = 0;
+							if (TRACK) s_ord[i] = ORD_NONE;
+							const uint64_t slot = key_hash<NW>(key) & tbl.mask;
+							merges++;
+							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, NW == 2 && SDT_SK_CLAIM2_BELOW > 0 && (add >> 48) <= SDT_SK_CLAIM2_BELOW), add, 0u, claimed, ord))
+								failed++;
+						}
+#pragma unroll
+						for (int d = 32; d > 0; d >>= 1) {
+							claimed += __shfl_down(claimed, d);
+							failed += __shfl_down(failed, d);
+							merges += __shfl_down(merges, d);
+						}
+						if ((tid & 63) == 0) {
+							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+						}
+						stores_pending = true;
+					} else if (owned) {
+						// this lane's PER slots: everything out of LDS, all global loads issued, then (now or a tile later) the merges
+#pragma unroll
+						for (int p = 0; p < PER; p++) {
+							const int i = tid + p * SK_CNT_TPB;
+							have[p] = i < SLOTS && s_key[i] != KEY_EMPTY;
+							if (have[p]) {
+								mk[p].w[0] = s_key[i];
+#pragma unroll
+								for (int wv = 1; wv < NW; wv++)
+									mk[p].w[wv] = s_key[wv * SLOTS + i];
+								madd[p] = sk_lds_val(&s_f[5 * i]);
+								if (TRACK) mord[p] = (uint64_t)s_ord[i];
+								s_key[i] = KEY_EMPTY;
+#pragma unroll
+								for (int f = 0; f < 5; f++)
+									s_f[5 * i + f] = 0;
+								if (TRACK) s_ord[i] = ORD_NONE;
+							}
+						}
+						__builtin_amdgcn_sched_barrier(0);       // (hashes first, then all loads, then the merges: interleaved by the
+						if (NW == 1 && SDT_SK_LOAD16) {          //  scheduler the snapshots were spilled, i.e. waited for one by one)
+							// key and val of a 16-byte entry with ONE agent-scope load (two 8-byte ones are two requests to the memory side)
+							typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+							u32x4 raw[PER];
+#pragma unroll
+							for (int p = 0; p < PER; p++) {
+								const Entry<NW> *e = tbl.ent + (have[p] ? key_hash<NW>(mk[p]) & tbl.mask : 0);
+								asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[p]) : "v"(e) : "memory");
+							}
+							asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]) :: "memory");
+#pragma unroll
+							for (int p = 1; p < PER; p++)
+								asm volatile("" : "+v"(raw[p]) :: "memory");
+#pragma unroll
+							for (int p = 0; p < PER; p++) {
+								sn[p].k[0] = ((uint64_t)raw[p].y << 32) | raw[p].x;
+								sn[p].v = ((uint64_t)raw[p].w << 32) | raw[p].z;
+								sn[p].f = ORD_NONE;
+								sn[p].won = false;
+							}
+						} else {
+#pragma unroll
+						for (int p = 0; p < PER; p++)
+							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
+								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+						}
+						__builtin_amdgcn_sched_barrier(0);
+						flush_finish();
+					} else {
+						for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
+							const uint64_t k0 = s_key[i];
+							if (k0 == KEY_EMPTY)
+								continue;
+							Key<NW> key;
+							key.w[0] = k0;
+#pragma unroll
+							for (int wv = 1; wv < NW; wv++)
+								key.w[wv] = s_key[wv * SLOTS + i];
+							merges++;
+							const uint64_t add = sk_lds_val(&s_f[5 * i]);
+							const uint64_t ord = TRACK ? (uint64_t)s_ord[i] : ORD_NONE;
+							if (!table_merge<NW>(tbl, key, add, 0u, claimed, ord))
+								failed++;
+							s_key[i] = KEY_EMPTY;
+#pragma unroll
+							for (int f = 0; f < 5; f++)
+								s_f[5 * i + f] = 0;
+							if (TRACK) s_ord[i] = ORD_NONE;
+						}
+#pragma unroll
+						for (int d = 32; d > 0; d >>= 1) {
+							claimed += __shfl_down(claimed, d);
+							failed += __shfl_down(failed, d);
+							merges += __shfl_down(merges, d);
+						}
+						if ((tid & 63) == 0) {
+							if (claimed) atomicAdd(&s_stat[ST_CLAIMED], claimed);
+							if (failed) atomicAdd(&s_stat[ST_FAILED], failed);
+#ifdef SDT_SK_SPLIT_MERGE_STAT                       // (measurement build: the merges by compare-and-swap are reported as `lds_spills`)
+							if (merges) atomicAdd(&s_stat[ST_SPILLS], merges);
+#else
+							if (merges) atomicAdd(&s_stat[ST_MERGES], merges);
+#endif
+						}
+					}
+					__syncthreads();
+					if (tid == 0) {
+						s_fillc[0] = s_fillc[1] = 0;
+						if (!(last_tile && qb >= total)) s_stat[ST_GENS]++;
+					}
+					__syncthreads();
+					ko = 0;
+					km &= 0x80000000u;
+					since = tile_kmers;                  // (what is left of this tile is at most the tile)
+					SK_TICK(3);
+				}
+				if (qb >= total)
+					break;
+				// The number of keys in the table decides how long a round is and when to flush, so every wave must see the SAME number:
+				// a wave that read one live counter a little late -- after a faster wave had claimed the next round's first slots --
+				// would take another branch than its workgroup and meet it at the wrong barrier (seen as hangs and lost k-mers once
+				// merges ran between the barrier and the read).  Hence two counters: round r adds to counter r & 1 only, so the
+				// other one stands still for the whole round and can be read at leisure; ko / km are the values all waves agree on.
+				const uint32_t fill0 = ko + (km & 0x7FFFFFFFu);  // < FLUSH_AT here
+				const uint32_t room = (MAXFILL - fill0) << room_shift;
+				uint32_t *const fillc = &s_fillc[km >> 31];
+				const uint32_t maxfill = MAXFILL - ko;
+				const uint32_t qe = qb + room < total ? qb + room : total;
+				for (uint32_t q = qb + tid; q < qe; q += SK_CNT_TPB) {
+					uint32_t ci = s_idx[q >> 4];             // the record of k-mer q & ~15; q's own is at most a few records on
+					while (s_pre[ci + 1] <= q)
+						ci++;
+					const int r = s_map[ci];
+					const int j = (int)(q - s_pre[ci]);
+					const uint64_t hr = s_h0[r];
+					const uint32_t wgt = s_w[r];
+					const int hp = sk_hdr_prev(hr), nr = sk_hdr_n(hr);
+					const int len = hp + nr + K - 1 + sk_hdr_next(hr);
+					uint32_t prev, next;
+					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
+					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill);
+					if (s >= 0) {
+						sk_lds_update(s_f, s, prev, next, wgt);
+						if (TRACK) {
+							const uint64_t ord = (sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j);
+							if (ord < *(volatile unsigned long long *)&s_ord[s])
+								atomicMin(&s_ord[s], (unsigned long long)ord);
+						}
+					} else {
+						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
+						// (the plain stores of the last owned flush may still be in flight: this wave's own must have landed before its
+						// atomics touch the table.  Other waves' are not waited for here -- they were issued at least a barrier and a round
+						// of LDS work earlier; the next flush waits for all of them)
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						const uint64_t ord = TRACK ? ((sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j)) : ORD_NONE;
+						uint32_t cl = 0;
+						atomicAdd(&s_stat[ST_SPILLS], 1u);
+						if (!table_merge<NW>(tbl, key, sk_weighted_val(wgt, prev, next), 0u, cl, ord))
+							atomicAdd(&s_stat[ST_FAILED], 1u);
+						if (cl)
+							atomicAdd(&s_stat[ST_CLAIMED], cl);
+					}
+				}
+				__syncthreads();
+				const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)*fillc);     // (nobody adds to it before the round after next)
+				const uint32_t fill1 = cur + ko;
+				km = ko | (~km & 0x80000000u);               // the next round adds to the other counter
+				ko = cur;
+				// k-mers per free slot in a round follow the data: a round that used more than half of the free slots halves them (the
+				// next one might have run out: its k-mers would take the direct path and cost the item its plain merges), a full
+				// round that used less than an eighth doubles them
+				if (NW > 1) {                                // (1-word keys, K <= 31: 4 per slot has always been enough, and the bookkeeping costs 5 %)
+					if ((fill1 - fill0) * 2u > MAXFILL - fill0)
+						room_shift = room_shift ? room_shift - 1u : 0u;
+					else if (qe - qb == room && (fill1 - fill0) * 8u < MAXFILL - fill0 && room_shift < 2u)
+						room_shift++;
+				}
+				qb = qe;
+				want_flush = (qb >= total && last_tile) || fill1 >= FLUSH_AT;     // the item is done: the table must be clear for the next one
+			}
+			SK_TICK(2);
+		}
+	}
+#undef SK_TICK
+	__syncthreads();
+	if (tid == 0) {
+		if (s_stat[ST_CLAIMED]) atomicAdd(&stats->distinct, (unsigned long long)s_stat[ST_CLAIMED]);
+		if (s_stat[ST_FAILED]) atomicAdd(&stats->probe_fail, (unsigned long long)s_stat[ST_FAILED]);
+		if (s_stat[ST_MERGES]) atomicAdd(&stats->sk_merges, (unsigned long long)s_stat[ST_MERGES]);
+		if (s_stat[ST_SPILLS]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_SPILLS]);
+		if (s_stat[ST_GENS]) atomicAdd(&stats->sk_gens, (unsigned long long)s_stat[ST_GENS]);
+		if (s_stat[ST_KMERS]) {
+			atomicAdd(&stats->kmers, (unsigned long long)s_stat[ST_KMERS]);
+			atomicAdd(&stats->sk_counted, (unsigned long long)s_stat[ST_KMERS]);
+		}
+		if (s_stat[ST_RECS]) atomicAdd(&stats->sk_records, (unsigned long long)s_stat[ST_RECS]);
+		if (s_stat[ST_DRECS]) atomicAdd(&stats->sk_distinct_recs, (unsigned long long)s_stat[ST_DRECS]);
+		if (s_stat[ST_DKMERS]) atomicAdd(&stats->sk_distinct_kmers, (unsigned long long)s_stat[ST_DKMERS]);
+#ifdef SDT_SK_TICKS
+		for (int i = 0; i < 4; i++)
+			atomicAdd(&stats->sk_cyc[i], cyc[i]);
+#endif
+	}
+}
+
 // ---- the node log: what a flush of k_sk_count's LDS table leaves behind (round 5) ---------------------------------------
 // Until round 4 a flush MERGED every LDS node into the flat node table: a random 16..48-byte read-modify-write of HBM per distinct
 // key and generation, 2.5 generations per key, 5x the compulsory traffic of the stage and a memory-side compare-and-swap per new

@@ -106,14 +106,15 @@ __host__ __device__ inline uint32_t bm_hash_lo(uint32_t fold)
 	return h ^ (h >> 16);
 }
 
-// home slot of a key in a table of `msz` slots (a multiple of 8) from its `lo` hash.  1-word keys start at a multiple of four: four
-// 16-byte entries are one 64-byte sector in HBM and one 32-byte read of key words in LDS (sdt_bm_kernels.cuh: bm_locate).
+// home slot of a key in a table of `msz` slots (a multiple of 8) from its `lo` hash: a multiple of four -- k_bm_finalize probes
+// the LDS image of a table four slots at a time (sdt_bm_kernels.cuh: bm_locate), and four 16-byte entries are one 64-byte sector
+// in HBM.
 template <int NW> __host__ __device__ inline uint32_t bm_home(uint32_t hlo, uint32_t msz)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return NW == 1 ? __umulhi(hlo, msz >> 2) << 2 : __umulhi(hlo, msz);
+	return __umulhi(hlo, msz >> 2) << 2;
 #else
-	return NW == 1 ? (uint32_t)(((uint64_t)hlo * (msz >> 2)) >> 32) << 2 : (uint32_t)(((uint64_t)hlo * msz) >> 32);
+	return (uint32_t)(((uint64_t)hlo * (msz >> 2)) >> 32) << 2;
 #endif
 }
 

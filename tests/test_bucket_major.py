@@ -14,7 +14,7 @@ from test_gpu_parity import node_dict_gpu, node_dict_oracle, keys_to_int
 
 pytestmark = pytest.mark.gpu
 
-PIPE = 2          # SDT_FLAG_PARTITION
+PIPE = 2 | 64     # SDT_FLAG_PARTITION | SDT_FLAG_NODE_LOG (multi-word keys take the flat merges by default)
 
 
 @pytest.fixture

@@ -35,7 +35,10 @@ def node_dict_oracle(o):
     return {k: (int(a), int(b), f(c), int(d)) for k, a, b, c, d in zip(ki, l, r, fl, cnt)}
 
 
-MODES = [1, 2]     # SDT_FLAG_DIRECT (one atomic per occurrence), SDT_FLAG_PARTITION (super-k-mer buckets counted in LDS)
+# SDT_FLAG_DIRECT (one atomic per occurrence); SDT_FLAG_PARTITION (super-k-mer buckets counted in LDS) with SDT_FLAG_FLAT_MERGE (every
+# generation of the LDS table merged into the flat table: rounds 2-4) and with SDT_FLAG_NODE_LOG (appended to the node log, folded
+# into the bucket-major table: round 5) -- every key width through both, whatever its default is
+MODES = [1, 2 | 32, 2 | 64]
 
 
 @pytest.mark.parametrize("mode", MODES)

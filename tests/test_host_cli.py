@@ -99,6 +99,7 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     env = dict(os.environ)
     if second_pass == "pipeline":
         env["SDT_PIPELINE"] = "1"
+        env["SDT_PASS1_TABLE"] = "log"               # (multi-word keys take the flat merges by default: here all widths use the node log)
     if second_pass == "replay-limit":
         env["SDT_RP_MAX_ROUNDS"] = "0"
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
