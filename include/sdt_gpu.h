@@ -61,10 +61,10 @@ typedef struct sdt_ctx sdt_ctx;
 /* map stage: the table indexes the k-mers of the contigs (sdt_gpu_index_contigs; implies TRACK_FIRST) */
 #define SDT_FLAG_CONTIG_INDEX 16u
 /* What the count stage of the locality pipeline does with a generation of its LDS table (both give identical nodes):
+ *   FLAT_MERGE  merges it into the flat table at once (rounds 2-4).  The default.
  *   NODE_LOG    appends it to the node log; sdt_gpu_finish_count folds the log into the bucket-major node table (csrc/sdt_table.cuh:
- *               BmDir) -- no memory-side atomic, half the HBM traffic of pass 1.  Default for 1-word keys (K <= 31).
- *   FLAT_MERGE  merges it into the flat table at once (rounds 2-4).  Default for 2- and 4-word keys, where the fold is slower.
- * Neither flag: the default for the key width (SDT_PASS1_TABLE=flat|log in the environment overrides it). */
+ *               BmDir) -- no memory-side atomic in pass 1 and half its HBM traffic, but the fold costs what the merges saved
+ *               (profiles/r5/README.md): opt-in, also by SDT_PASS1_TABLE=log in the environment. */
 #define SDT_FLAG_FLAT_MERGE 32u
 #define SDT_FLAG_NODE_LOG   64u
 

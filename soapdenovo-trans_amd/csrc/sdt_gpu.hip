@@ -2098,7 +2098,9 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	// The flat table is the direct kernel family's (jobs below 2^27 k-mers, SDT_FLAG_DIRECT, the contig index); the locality
 	// pipeline builds the bucket-major table out of its log (sized when the log is folded: bm_fold) and uses the flat one only
 	// for records that found no chunk.  So the estimate sizes the flat table up to 2^27 slots and the fold beyond that.
-	c->node_log = c->nw == 1;
+	// (measured on one box, profiles/r5/README.md: the node log is 1 % behind the flat merges on the headline workload, 11 % on the
+	// 400 M-read one, 5 % ahead on 50 M reads, and a quarter behind for 2-word keys: the flat merges stay the default)
+	c->node_log = false;
 	if (const char *pt = getenv("SDT_PASS1_TABLE")) c->node_log = !strcmp(pt, "log") ? true : (!strcmp(pt, "flat") ? false : c->node_log);
 	if (flags & SDT_FLAG_FLAT_MERGE) c->node_log = false;
 	if (flags & SDT_FLAG_NODE_LOG) c->node_log = true;
