@@ -67,6 +67,25 @@ struct ArenaBook {
 		free_[a] = r;
 		return true;
 	}
+	// what the arena can really give a new allocation on `device`: the slabs nobody uses (trim returns them to the backing allocator, which
+	// may then serve a block of any size) + the largest free range inside a slab that is partly in use (ranges never coalesce across
+	// slabs: their SUM says nothing about the largest block that fits)
+	size_t usable(int device) const
+	{
+		size_t whole = 0, largest = 0;
+		for (const auto &kv : free_) {
+			const ArenaSlab &s = slabs[kv.second.slab];
+			if (s.device != device) continue;
+			if (!s.used) whole += kv.second.bytes;       // (a slab without live blocks is one free range)
+			else if (kv.second.bytes > largest) largest = kv.second.bytes;
+		}
+		return whole + largest;
+	}
+	int device_of(void *p) const
+	{
+		auto it = live.find(p);
+		return it == live.end() ? -1 : slabs[it->second.slab].device;
+	}
 	// slabs nobody uses leave the book; `release(base, device)` gives each back to the backing allocator.  Returns the bytes released
 	template <class F> size_t trim(F release)
 	{

@@ -304,9 +304,9 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 #pragma unroll
 		for (int i = 0; i < NW; i++)
 			key.w[i] = e.key[i];
-		uint64_t slot = key_hash<NW>(key) & dst.mask;
+		uint64_t slot = flat_home<NW>(dst, key);
 		bool placed = false;
-		for (uint64_t probe = 0; probe <= dst.mask; probe++) {
+		for (uint64_t probe = 0; probe < dst.fslots; probe++) {
 			const uint64_t old = atomicCAS((unsigned long long *)&dst.ent[slot].key[0], (unsigned long long)KEY_EMPTY,
 			                               (unsigned long long)e.key[0]);
 			if (old == KEY_EMPTY) {
@@ -320,7 +320,7 @@ template <int NW> __global__ __launch_bounds__(TPB) void k_rehash(Table<NW> src,
 				placed = true;
 				break;
 			}
-			slot = (slot + 1) & dst.mask;
+			slot = flat_next(slot, dst.fslots);
 		}
 		if (!placed)
 			failed++;
@@ -543,6 +543,15 @@ struct sdt_ctx {
 };
 
 static const double MAX_LOAD = 0.70;
+// slots of a flat table for `nodes` nodes: a load of SDT_TABLE_LOAD percent (default 55: half way between what the probes of the merges
+// like and what the scans of the table cost), a multiple of 4096, 2^16 at least
+static uint64_t flat_slots_for(uint64_t nodes)
+{
+	static const int pct = getenv("SDT_TABLE_LOAD") && atoi(getenv("SDT_TABLE_LOAD")) >= 10 && atoi(getenv("SDT_TABLE_LOAD")) <= 69 ? atoi(getenv("SDT_TABLE_LOAD")) : 55;
+	uint64_t slots = (uint64_t)((double)nodes * 100.0 / pct) + 4095;
+	slots &= ~4095ULL;
+	return slots < (1ULL << 16) ? (1ULL << 16) : slots;
+}
 
 static void *keep_alloc(sdt_ctx *c, size_t bytes)
 {
@@ -578,7 +587,7 @@ template <int NW> static Table<NW> flat_of(const sdt_ctx *c)
 	Table<NW> t;
 	t.ent = (Entry<NW> *)c->d_ent;
 	t.aux = c->d_aux;
-	t.mask = c->slots - 1;
+	t.fslots = c->slots;
 	t.first = c->d_first;
 	t.dir = nullptr;
 	t.nslots = 0;
@@ -591,7 +600,7 @@ template <int NW> static Table<NW> bm_view(const sdt_ctx *c, const sdt_ctx::BmTa
 	Table<NW> t;
 	t.ent = (Entry<NW> *)b.ent;
 	t.aux = b.aux;
-	t.mask = 0;
+	t.fslots = 0;
 	t.first = b.first;
 	t.dir = b.dir;
 	t.nslots = b.nslots;
@@ -620,9 +629,9 @@ static int scan_grid(const sdt_ctx *c, uint64_t items)
 static int launch_clear(sdt_ctx *c, void *ent, uint32_t *aux, uint64_t *first, uint64_t slots)
 {
 	const int g = scan_grid(c, slots);
-	if (c->nw == 1) { Table<1> t{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<1>, dim3(g), dim3(TPB), 0, c->stream, t); }
-	else if (c->nw == 2) { Table<2> t{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<2>, dim3(g), dim3(TPB), 0, c->stream, t); }
-	else { Table<4> t{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_clear<4>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	if (c->nw == 1) { Table<1> t{(Entry<1> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_clear<1>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else if (c->nw == 2) { Table<2> t{(Entry<2> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_clear<2>, dim3(g), dim3(TPB), 0, c->stream, t); }
+	else { Table<4> t{(Entry<4> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_clear<4>, dim3(g), dim3(TPB), 0, c->stream, t); }
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
 }
@@ -1106,9 +1115,9 @@ static int sync_stats(sdt_ctx *c)
 
 static int grow_table(sdt_ctx *c, uint64_t need_nodes)
 {
-	uint64_t slots = c->slots;
-	while ((double)slots * MAX_LOAD < (double)need_nodes)
-		slots <<= 1;
+	// (any number of slots: what the nodes need at the load a fresh table is sized for, at least half as many again as before)
+	uint64_t slots = flat_slots_for(need_nodes);
+	if (slots < c->slots + c->slots / 2) slots = c->slots + c->slots / 2;
 	void *ent = nullptr;
 	uint32_t *aux = nullptr;
 	uint64_t *first = nullptr;
@@ -1128,9 +1137,9 @@ static int grow_table(sdt_ctx *c, uint64_t need_nodes)
 	if (rc != SDT_OK)
 		return rc;
 	const int g = scan_grid(c, c->slots);
-	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, flat_of<1>(c), d, c->d_stats); }
-	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, flat_of<2>(c), d, c->d_stats); }
-	else { Table<4> d{(Entry<4> *)ent, aux, slots - 1, first}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, flat_of<4>(c), d, c->d_stats); }
+	if (c->nw == 1) { Table<1> d{(Entry<1> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_rehash<1>, dim3(g), dim3(TPB), 0, c->stream, flat_of<1>(c), d, c->d_stats); }
+	else if (c->nw == 2) { Table<2> d{(Entry<2> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_rehash<2>, dim3(g), dim3(TPB), 0, c->stream, flat_of<2>(c), d, c->d_stats); }
+	else { Table<4> d{(Entry<4> *)ent, aux, slots, first}; hipLaunchKernelGGL(k_rehash<4>, dim3(g), dim3(TPB), 0, c->stream, flat_of<4>(c), d, c->d_stats); }
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipFree(c->d_ent));
@@ -2104,10 +2113,9 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	if (const char *pt = getenv("SDT_PASS1_TABLE")) c->node_log = !strcmp(pt, "log") ? true : (!strcmp(pt, "flat") ? false : c->node_log);
 	if (flags & SDT_FLAG_FLAT_MERGE) c->node_log = false;
 	if (flags & SDT_FLAG_NODE_LOG) c->node_log = true;
-	uint64_t slots = 1ULL << 16;
 	const uint64_t flat_max = ((flags & (SDT_FLAG_DIRECT | SDT_FLAG_CONTIG_INDEX)) || !c->node_log) ? ~0ULL : (1ULL << 27);
-	while ((double)slots * 0.5 < (double)est_distinct && slots < flat_max)
-		slots <<= 1;
+	uint64_t slots = flat_slots_for(est_distinct);
+	if (slots > flat_max) slots = flat_max;
 	c->slots = slots;
 	c->bm.est_distinct = est_distinct;
 #define INIT_CHK(expr)                                                                    \
@@ -2552,8 +2560,8 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 		HIPCHK(sdti::mem_info(&free_b, &total_b));
 		uint64_t est = kmers / 28;
 		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
-		while (est > (1u << 20) && (double)est / MAX_LOAD * 2.0 * (double)per_slot > (double)free_b * 0.3)
-			est /= 2;                                    // (never more than ~30 % of what is free, power-of-two rounding included)
+		while (est > (1u << 20) && (double)flat_slots_for(est) * (double)per_slot > (double)free_b * 0.3)
+			est /= 2;                                    // (never more than ~30 % of what is free)
 		if (c->node_log && !(c->flags & SDT_FLAG_DIRECT)) {
 			// (the locality pipeline folds its log into a table of its own: the estimate sizes THAT, bm_fold)
 			if (c->bm.est_distinct < est) c->bm.est_distinct = est;

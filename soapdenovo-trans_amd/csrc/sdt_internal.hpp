@@ -60,7 +60,7 @@ template <int NW> inline sdt::Table<NW> table_of(const GraphView &v)
 	sdt::Table<NW> t;
 	t.ent = (sdt::Entry<NW> *)v.d_ent;
 	t.aux = v.d_aux;
-	t.mask = v.dir ? 0 : v.slots - 1;
+	t.fslots = v.dir ? 0 : v.slots;
 	t.first = v.d_first;
 	t.dir = v.dir;
 	t.nslots = v.dir ? v.slots : 0;

@@ -93,8 +93,13 @@ hipError_t sdti::dfree(void *p, const char *file, int line)
 		std::lock_guard<std::mutex> lock(A.mu);
 		if (A.live.count(p)) {
 			// hipFree waits for the device before it lets go of a block; the callers rely on that (kernels of another stream may
-			// still read what is freed here)
+			// still read what is freed here).  The device that OWNS the block: a process may hold contexts on several.
+			int cur = 0;
+			(void)hipGetDevice(&cur);
+			const int dev = A.device_of(p);
+			if (dev >= 0 && dev != cur) (void)hipSetDevice(dev);
 			const hipError_t e = hipDeviceSynchronize();
+			if (dev >= 0 && dev != cur) (void)hipSetDevice(cur);
 			(void)A.give(p);
 			return e;
 		}
@@ -117,9 +122,14 @@ hipError_t sdti::mem_info(size_t *free_b, size_t *total_b)
 {
 	const hipError_t e = hipMemGetInfo(free_b, total_b);
 	if (e != hipSuccess) return e;
+	// + what the arena can give a new block on THIS device: its unused slabs and the largest range inside a used one (not the sum
+	// of all free ranges of all devices: a pool sized to 60 % of that could ask for a block no range holds, with the driver's memory
+	// pinned by small long-lived blocks carved out of the large slabs)
+	int device = 0;
+	(void)hipGetDevice(&device);
 	Arena &A = arena();
 	std::lock_guard<std::mutex> lock(A.mu);
-	*free_b += A.free_bytes;                     // (what the arena holds is free for the library's purposes)
+	*free_b += A.usable(device);
 	return hipSuccess;
 }
 

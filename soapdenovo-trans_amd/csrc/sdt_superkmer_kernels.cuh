@@ -976,7 +976,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		for (int p = 0; p < PER; p++)
 			if (have[p]) {
 				merges++;
-				if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], key_hash<NW>(mk[p]) & tbl.mask, sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
+				if (!table_merge_owned_at<NW, TRACK>(tbl, mk[p], flat_home<NW>(tbl, mk[p]), sn[p], madd[p], 0u, claimed, TRACK ? mord[TRACK ? p : 0] : ORD_NONE))
 					failed++;
 			}
 #pragma unroll
@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							for (int f = 0; f < 5; f++)
 								s_f[5 * i + f] = 0;
 							if (TRACK) s_ord[i] = ORD_NONE;
-							const uint64_t slot = key_hash<NW>(key) & tbl.mask;
+							const uint64_t slot = flat_home<NW>(tbl, key);
 							merges++;
 							if (!table_merge_owned_at<NW, TRACK>(tbl, key, slot, ent_load<NW, TRACK>(tbl, slot, key, NW == 2 && SDT_SK_CLAIM2_BELOW > 0 && (add >> 48) <= SDT_SK_CLAIM2_BELOW), add, 0u, claimed, ord))
 								failed++;
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							u32x4 raw[PER];
 #pragma unroll
 							for (int p = 0; p < PER; p++) {
-								const Entry<NW> *e = tbl.ent + (have[p] ? key_hash<NW>(mk[p]) & tbl.mask : 0);
+								const Entry<NW> *e = tbl.ent + (have[p] ? flat_home<NW>(tbl, mk[p]) : 0);
 								asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[p]) : "v"(e) : "memory");
 							}
 							asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]) :: "memory");
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 #pragma unroll
 						for (int p = 0; p < PER; p++)
 							if (have[p])       // (seen once or twice in this generation: an error k-mer, most likely new to the node table)
-								sn[p] = ent_load<NW, TRACK>(tbl, key_hash<NW>(mk[p]) & tbl.mask, mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
+								sn[p] = ent_load<NW, TRACK>(tbl, flat_home<NW>(tbl, mk[p]), mk[p], SDT_SK_CLAIM_BELOW > 0 && (madd[p] >> 48) <= SDT_SK_CLAIM_BELOW);
 						}
 						__builtin_amdgcn_sched_barrier(0);
 						flush_finish();

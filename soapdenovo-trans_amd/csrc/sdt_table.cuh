@@ -69,12 +69,13 @@ struct BmDir {
 template <int NW> struct Table {
 	Entry<NW> *ent;
 	uint32_t *aux;
-	uint64_t mask;        // flat layout: slots - 1 (slots is a power of two)
+	uint64_t fslots;      // flat layout: slots (any number since round 5: the home slot is the high word of hash x slots, not hash & mask --
+	                      // a table of 2^31 slots for the 0.68 G nodes of the headline workload was a third more to clear and scan than it needs)
 	uint64_t *first;      // optional (SDT_FLAG_TRACK_FIRST): smallest ordinal of an occurrence of the key, ~0 = none
 	const BmDir *dir;     // bucket-major layout: SK_NBF directory entries (nullptr: flat)
 	uint64_t nslots;      // bucket-major layout: slots in use
 	int K;                // bucket-major layout: the k-mer size (look-ups compute the minimizer)
-	__host__ __device__ uint64_t slots() const { return dir ? nslots : mask + 1; }
+	__host__ __device__ uint64_t slots() const { return dir ? nslots : fslots; }
 };
 
 // The two hashes of the bucket-major layout: `hi` picks the sub-bucket (its top bits) and the table (the bits below), `lo` the home
@@ -118,14 +119,18 @@ template <int NW> __host__ __device__ inline uint32_t bm_home(uint32_t hlo, uint
 #endif
 }
 
+// home slot of a key in the flat table
+template <int NW> __device__ inline uint64_t flat_home(const Table<NW> &t, const Key<NW> &key) { return __umul64hi(key_hash<NW>(key), t.fslots); }
+__device__ inline uint64_t flat_next(uint64_t slot, uint64_t fslots) { return slot + 1 == fslots ? 0 : slot + 1; }
+
 // Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times; n == 0:
 // the key's bucket is empty (bucket-major) -- the key is not there.
 template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const Key<NW> &key, uint64_t &slot, uint64_t &lo, uint64_t &n)
 {
 	if (!t.dir) {
 		lo = 0;
-		n = t.mask + 1;
-		slot = key_hash<NW>(key) & t.mask;
+		n = t.fslots;
+		slot = flat_home<NW>(t, key);
 		return;
 	}
 	BmDir d = t.dir[key_final_bucket<NW>(key, t.K)];
@@ -259,8 +264,8 @@ template <int NW>
 __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint32_t &claimed, uint64_t &slot_out,
                                     uint64_t &seen_out)
 {
-	uint64_t slot = key_hash<NW>(key) & t.mask;
-	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
+	uint64_t slot = flat_home<NW>(t, key);
+	const uint64_t max_probe = t.fslots < 4096 ? t.fslots : 4096;
 	// Multi-word keys: a lane that reads KEY_LOCKED looks again until the claimer -- possibly a lane of its own wave -- has
 	// published the low words, so the claimer's stores must stay INSIDE the loop body: its branch ends in `hit = true;
 	// continue;` and the loop condition lets it out, not a `return` (an exit path, which the compiler may move behind the
@@ -284,7 +289,7 @@ __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint
 			k0 = a.x;
 			if (k0 != KEY_EMPTY && k0 != KEY_LOCKED) {
 				if (k0 != key.w[0]) {
-					slot = (slot + 1) & t.mask;
+					slot = flat_next(slot, t.fslots);
 					probe++;
 					continue;
 				}
@@ -356,7 +361,7 @@ __device__ inline bool table_locate(const Table<NW> &t, const Key<NW> &key, uint
 			seen_out = seen;
 			return true;
 		}
-		slot = (slot + 1) & t.mask;
+		slot = flat_next(slot, t.fslots);
 		probe++;
 	}
 	return hit;
@@ -531,7 +536,7 @@ template <int NW, bool FIRST>
 __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &key, uint64_t slot, EntSnap<NW, FIRST> sn, uint64_t add, uint32_t hi,
                                             uint32_t &claimed, uint64_t ord)
 {
-	const uint64_t max_probe = t.mask < 4096 ? t.mask + 1 : 4096;
+	const uint64_t max_probe = t.fslots < 4096 ? t.fslots : 4096;
 	for (uint64_t probe = 0; probe < max_probe; probe++) {
 		Entry<NW> *e = t.ent + slot;
 		if (NW <= 2 && sn.won) {
@@ -595,7 +600,7 @@ __device__ inline bool table_merge_owned_at(const Table<NW> &t, const Key<NW> &k
 			}
 			// somebody else's key (or its KEY_LOCKED) got there first: not ours
 		}
-		slot = (slot + 1) & t.mask;
+		slot = flat_next(slot, t.fslots);
 		sn = ent_load<NW, FIRST>(t, slot, key, false);
 	}
 	return false;

@@ -39,6 +39,17 @@ static int check(const ArenaBook &A, const char **why)
 		if (used[i] != A.slabs[i].used) { *why = "a slab's used count is off"; return 1; }
 	}
 	if (free_sum != A.free_bytes) { *why = "free_bytes is off"; return 1; }
+	// what mem_info may promise: the unused slabs whole + the largest free range inside a used slab, per device
+	for (int dev = 0; dev < 2; dev++) {
+		size_t whole = 0, largest = 0;
+		for (const Piece &p : all) {
+			if (p.live || A.slabs[p.slab].device != dev) continue;
+			if (!A.slabs[p.slab].used) whole += p.n;
+			else if (p.n > largest) largest = p.n;
+		}
+		if (A.usable(dev) != whole + largest) { *why = "usable() is off"; return 1; }
+		if (A.usable(dev) > A.free_bytes) { *why = "usable() promises more than is free"; return 1; }
+	}
 	return 0;
 }
 
