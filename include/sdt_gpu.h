@@ -232,6 +232,14 @@ int sdt_gpu_mark_and_hist(sdt_ctx *ctx, int64_t hist[257], uint64_t *linear);
 int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags,
                          uint32_t *count, uint64_t *first, uint64_t max_nodes, uint64_t *n);
 
+/* --gpus N, second read pass on every rank: the final graph as that pass needs it -- every node's key and path word -- out of the
+ * table of the rank that built the edges (after sdt_gpu_load_paths), and into the table of a rank that holds its own share of the
+ * reads (sdt_gpu_keep_reads / SDT_FLAG_KEEP_READS): its shard of pass 1 makes way, the kept reads stay; patch table and edge count
+ * as in sdt_gpu_load_paths.  Then sdt_gpu_map_reads + sdt_gpu_export_arcs on every rank, and the arcs of all ranks add up
+ * (prlRead2path.c:415-430 counts arcs per thread and adds them the same way). */
+int sdt_gpu_export_paths(sdt_ctx *ctx, uint64_t *keys, uint64_t *path_words, uint64_t max_nodes, uint64_t *n);
+int sdt_gpu_import_paths(sdt_ctx *ctx, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
+                         const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed);
 /* ---- pass 2: reads -> edge paths -> arcs (prlRead2edge, prlRead2path.c:817-1335) --------------------------
  * After the host graph phases (minor-out, tip cutting, kmer2edges) every node gets one path word
  *     bit 0 skip = deleted || (linear && !inEdge) (:650) | bit 1 linear | bits 2..3 twin | bits 32..63 l_links = edge id

@@ -58,6 +58,8 @@ _ABI = [
     ("sdt_gpu_set_read_ordinal", _c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_load_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p,
                                       _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_export_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
+    ("sdt_gpu_import_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_map_reads", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_arcs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
                                        _c.POINTER(_c.c_uint64)]),

@@ -47,7 +47,7 @@ typedef struct {
 	sdt_ctx *gpu;
 	unsigned long long reads;
 	/* --gpus N: chunk i of the stream is counted by rank i % N; one collective push per group of N chunks */
-	int rank, nranks, keep_all, fill, have;
+	int rank, nranks, keep_all, keep_mine, fill, have;
 	int K, hinted;
 	uint64_t total_text;               /* bytes of all input files (0: unknown) */
 	uint32_t *w;
@@ -163,7 +163,8 @@ static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base,
 	st->reads += b->nreads;
 	if (st->reads / 1000000ULL != before)
 		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);
-	if (st->keep_all && !b->counted_only && b->nreads) {         /* rank 0: every read stays resident for the second pass */
+	if (((st->keep_all && !b->counted_only) || (st->keep_mine && b->owner == st->rank)) && b->nreads) {
+		/* the reads of the second pass stay resident: this rank's own share (every rank maps its reads), or -- rank 0 without that -- all */
 		sdt_gpu_set_read_ordinal(st->gpu, ord_base, ord_stride);
 		if (sdt_gpu_keep_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
 			fprintf(stderr, "sdt_gpu_keep_reads: %s\n", sdt_gpu_last_error());
@@ -185,7 +186,15 @@ static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base,
 }
 
 /* --gpus N: the shard of every other rank comes to rank 0 through POSIX shared memory */
-typedef struct { volatile int ready; sdt_comm_id id; char name[64]; } boot_t;
+typedef struct {
+	volatile int ready; sdt_comm_id id; char name[64];
+	/* second read pass on every rank (round 5): rank 0 publishes the graph (key -> path word, patch table) in shared memory and says
+	 * so here; every rank maps ITS reads and leaves its arcs in a segment of its own */
+	volatile int paths_state;                  /* 0 not yet, 1 published, -1 no per-rank pass (the ranks may go), 2 rank 0 has all arcs */
+	volatile unsigned long long paths_n, patch_n, num_ed;
+	volatile int arcs_state[64];               /* 1: this rank's arcs are in its segment, -1: it failed */
+	volatile unsigned long long arcs_n[64], arcs_reads[64];
+} boot_t;
 
 /* Failure propagation between the forked ranks.  RCCL collectives have no timeout: a rank that leaves early would keep its
  * peers blocked for ever, holding their GPUs.  So: every child dies with its parent (PR_SET_PDEATHSIG); rank 0 -- the parent --
@@ -227,6 +236,33 @@ static void *shm_region(const char *name, size_t bytes, int create)
 	void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
 	close(fd);
 	return p == MAP_FAILED ? NULL : p;
+}
+
+/* arcs of several ranks in one array: equal (from, to) pairs become one arc -- multiplicities add up, the first occurrence is the
+ * smallest.  Returns the number of arcs left (in the front of the arrays). */
+typedef struct { uint64_t key, ord; uint32_t mult; } arc_rec;
+static int arc_rec_cmp(const void *a, const void *b)
+{
+	const arc_rec *x = (const arc_rec *)a, *y = (const arc_rec *)b;
+	return x->key < y->key ? -1 : (x->key > y->key ? 1 : (x->ord < y->ord ? -1 : (x->ord > y->ord)));
+}
+static uint64_t arcs_combine(uint32_t *from, uint32_t *to, uint32_t *mult, uint64_t *ord, uint64_t n)
+{
+	arc_rec *v = (arc_rec *)malloc((n + 1) * sizeof(arc_rec));
+	if (!v) { fprintf(stderr, "out of host memory for %llu arcs\n", (unsigned long long)n); exit(1); }
+	for (uint64_t i = 0; i < n; i++) { v[i].key = ((uint64_t)from[i] << 32) | to[i]; v[i].ord = ord[i]; v[i].mult = mult[i]; }
+	qsort(v, n, sizeof(arc_rec), arc_rec_cmp);
+	uint64_t m = 0;
+	for (uint64_t i = 0; i < n;) {
+		uint64_t j = i, sum = 0;
+		while (j < n && v[j].key == v[i].key) sum += v[j++].mult;
+		from[m] = (uint32_t)(v[i].key >> 32); to[m] = (uint32_t)v[i].key; ord[m] = v[i].ord;      /* (sorted: the smallest ordinal first) */
+		mult[m] = sum > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sum;
+		m++;
+		i = j;
+	}
+	free(v);
+	return m;
 }
 
 /* second pass (prlRead2edge): unpack each read and thread it through the edge graph */
@@ -621,7 +657,11 @@ int main(int argc, char **argv)
 	phase("config + gpu init");
 	push_state st;
 	memset(&st, 0, sizeof st);
-	st.gpu = gpu; st.rank = rank; st.nranks = gpus; st.keep_all = gpus > 1 && rank == 0 && !hash_only && !host_map;
+	/* --gpus N: every rank keeps the reads it parsed and maps them itself once rank 0 has the graph (the default path: layout, cutting
+	 * and edges on rank 0's device); with --host-map / --host-walks the second pass is the host's, which reads the files again */
+	const int per_rank_map = gpus > 1 && !hash_only && !host_map && !host_walks && threads <= 256 && !getenv("SDT_HOST_LAYOUT") && !getenv("SDT_RANK0_MAP");
+	st.gpu = gpu; st.rank = rank; st.nranks = gpus; st.keep_all = gpus > 1 && rank == 0 && !hash_only && !host_map && !per_rank_map;
+	st.keep_mine = per_rank_map;
 	const size_t chunk = getenv("SDT_CHUNK_BYTES") ? (size_t)strtoull(getenv("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
 	int rc;
 	if (gpus == 1) {
@@ -726,6 +766,50 @@ int main(int argc, char **argv)
 				}
 				munmap(m, (size_t)(my_nodes + 1) * per_node);
 				shm_unlink(seg);
+				if (per_rank_map) {
+					/* wait for the graph (rank 0 lays it out, cuts it and builds the edges: seconds to minutes -- polled, not a collective with
+					 * its deadline; the parent's death takes this process along), map my reads, leave my arcs */
+					while (boot->paths_state == 0) usleep(2000);
+					int ok = boot->paths_state == 1;
+					if (ok) {
+						const uint64_t pn = boot->paths_n, qn = boot->patch_n;
+						snprintf(seg, sizeof seg, "/sdt_%s_paths", boot->name);
+						const size_t pbytes = (size_t)(pn + 1) * ((size_t)nwk * 8 + 8) + (size_t)(qn + 1) * ((size_t)nwk * 8 + 8);
+						uint8_t *pm = (uint8_t *)shm_region(seg, pbytes, 0);
+						uint64_t nreads2 = 0, narcs = 0;
+						if (!pm) { fprintf(stderr, "[rank %d] cannot map the path table\n", rank); ok = 0; }
+						if (ok) {
+							const uint64_t *pk = (const uint64_t *)pm, *pw = pk + (pn + 1) * (size_t)nwk, *qk = pw + pn + 1, *qi = qk + (qn + 1) * (size_t)nwk;
+							if (sdt_gpu_import_paths(gpu, pk, pw, pn, qk, qi, qn, boot->num_ed) != SDT_OK ||
+							    sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
+								fprintf(stderr, "[rank %d] second pass: %s\n", rank, sdt_gpu_last_error());
+								ok = 0;
+							}
+							munmap(pm, pbytes);
+						}
+						uint8_t *am = NULL;
+						size_t abytes = 0;
+						if (ok) {
+							snprintf(seg, sizeof seg, "/sdt_%s_a%d", boot->name, rank);
+							abytes = (size_t)(narcs + 1) * 20;
+							am = (uint8_t *)shm_region(seg, abytes, 1);
+							uint64_t *ao = (uint64_t *)am;
+							uint32_t *af = am ? (uint32_t *)(ao + narcs + 1) : NULL, *at2 = af ? af + narcs + 1 : NULL, *amu = at2 ? at2 + narcs + 1 : NULL;
+							if (!am || sdt_gpu_export_arcs(gpu, af, at2, amu, ao, narcs, &narcs) != SDT_OK) {
+								fprintf(stderr, "[rank %d] arcs: %s\n", rank, am ? sdt_gpu_last_error() : "no shared memory");
+								ok = 0;
+							}
+						}
+						boot->arcs_n[rank] = narcs;
+						boot->arcs_reads[rank] = nreads2;
+						__sync_synchronize();
+						boot->arcs_state[rank] = ok ? 1 : -1;
+						while (ok && boot->paths_state == 1) usleep(2000);     /* rank 0 is reading them */
+						if (am) { munmap(am, abytes); shm_unlink(seg); }
+					}
+					sdt_gpu_destroy(gpu);
+					return ok || boot->paths_state == -1 ? 0 : 1;
+				}
 				sdt_gpu_destroy(gpu);
 				return 0;
 			}
@@ -870,7 +954,9 @@ int main(int argc, char **argv)
 		printf("time spent on making edges: %ds\n\n", (int)(time(NULL) - t0));
 		t0 = time(NULL);
 		printf("%d thread created prlRead2path\n", threads);                /* pregraph.c:101-104 */
-		if (host_map) {
+		const int rank0_host_map = per_rank_map && !keys_in_device;       /* (the graph did not take the device path: rank 0 holds only its own reads) */
+		if (gpus > 1 && per_rank_map && rank0_host_map) { __sync_synchronize(); boot->paths_state = -1; }
+		if (host_map || rank0_host_map) {
 			arc_state as = {G, arcs_new(), 0};
 			if (sdt_stream_reads(&cfg, max_read_len, threads, chunk, 1, arc_batch, &as, NULL) != 0) return 1;
 			printf("%llu reads processed\n", as.reads);
@@ -912,6 +998,26 @@ int main(int argc, char **argv)
 				fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error());
 				return 1;
 			}
+			uint8_t *paths_m = NULL;
+			size_t paths_bytes = 0;
+			char paths_seg[128] = "";
+			if (gpus > 1 && per_rank_map) {
+				/* every rank maps its own reads: the graph as that pass needs it goes into shared memory */
+				uint64_t pn = 0;
+				if (sdt_gpu_export_paths(gpu, NULL, NULL, 0, &pn) != SDT_OK) { fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error()); return 1; }
+				snprintf(paths_seg, sizeof paths_seg, "/sdt_%s_paths", boot->name);
+				paths_bytes = (size_t)(pn + 1) * ((size_t)nwk * 8 + 8) + (size_t)(np + 1) * ((size_t)nwk * 8 + 8);
+				paths_m = (uint8_t *)shm_region(paths_seg, paths_bytes, 1);
+				if (!paths_m) { fprintf(stderr, "shared memory for the path table of %llu nodes failed\n", (unsigned long long)pn); return 1; }
+				uint64_t *sk = (uint64_t *)paths_m, *sw = sk + (pn + 1) * (size_t)nwk, *sqk = sw + pn + 1, *sqi = sqk + (np + 1) * (size_t)nwk;
+				if (sdt_gpu_export_paths(gpu, sk, sw, pn, &pn) != SDT_OK) { fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error()); return 1; }
+				memcpy(sqk, qk, np * (size_t)nwk * 8);
+				memcpy(sqi, qi, np * 8);
+				boot->paths_n = pn; boot->patch_n = np; boot->num_ed = G->num_ed;
+				__sync_synchronize();
+				boot->paths_state = 1;
+				phase("path table -> shared memory");
+			}
 			const double t_r1 = now_ms();
 			if (sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
 				fprintf(stderr, "second pass: %s\n", sdt_gpu_last_error());
@@ -922,6 +1028,38 @@ int main(int argc, char **argv)
 			uint32_t *af = (uint32_t *)malloc((narcs + 1) * 4), *at = (uint32_t *)malloc((narcs + 1) * 4), *am = (uint32_t *)malloc((narcs + 1) * 4);
 			uint64_t *ao = (uint64_t *)malloc((narcs + 1) * 8);
 			if (sdt_gpu_export_arcs(gpu, af, at, am, ao, narcs, &narcs) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+			if (gpus > 1 && per_rank_map) {
+				/* the arcs of the other ranks: same (from, to) pairs add up, the first occurrence is the earliest (prlRead2path.c:415-430
+				 * counts per thread and adds up the same way) */
+				uint64_t total = narcs;
+				for (int r = 1; r < gpus; r++) {
+					while (boot->arcs_state[r] == 0) usleep(1000);
+					if (boot->arcs_state[r] < 0) { fprintf(stderr, "rank %d failed in the second pass\n", r); return 1; }
+					total += boot->arcs_n[r];
+					nreads2 += boot->arcs_reads[r];
+				}
+				af = (uint32_t *)realloc(af, (total + 1) * 4); at = (uint32_t *)realloc(at, (total + 1) * 4); am = (uint32_t *)realloc(am, (total + 1) * 4);
+				ao = (uint64_t *)realloc(ao, (total + 1) * 8);
+				if (!af || !at || !am || !ao) { fprintf(stderr, "out of host memory for %llu arcs\n", (unsigned long long)total); return 1; }
+				uint64_t at_ = narcs;
+				for (int r = 1; r < gpus; r++) {
+					const uint64_t m_n = boot->arcs_n[r];
+					char seg2[128];
+					snprintf(seg2, sizeof seg2, "/sdt_%s_a%d", boot->name, r);
+					const size_t ab = (size_t)(m_n + 1) * 20;
+					uint8_t *m2 = (uint8_t *)shm_region(seg2, ab, 0);
+					if (!m2) { fprintf(stderr, "cannot map the arcs of rank %d\n", r); return 1; }
+					const uint64_t *o2 = (const uint64_t *)m2;
+					const uint32_t *f2 = (const uint32_t *)(o2 + m_n + 1), *t2 = f2 + m_n + 1, *u2 = t2 + m_n + 1;
+					memcpy(ao + at_, o2, m_n * 8); memcpy(af + at_, f2, m_n * 4); memcpy(at + at_, t2, m_n * 4); memcpy(am + at_, u2, m_n * 4);
+					at_ += m_n;
+					munmap(m2, ab);
+				}
+				__sync_synchronize();
+				boot->paths_state = 2;                                /* the other ranks may go */
+				if (paths_m) { munmap(paths_m, paths_bytes); shm_unlink(paths_seg); }
+				narcs = arcs_combine(af, at, am, ao, total);
+			}
 			const double t_r3 = now_ms();
 			printf("%llu reads processed\n", (unsigned long long)nreads2);
 			arcs_write_arrays(prefix, af, at, am, ao, narcs);

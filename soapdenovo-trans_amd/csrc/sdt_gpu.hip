@@ -357,6 +357,47 @@ __global__ __launch_bounds__(TPB) void k_import(Table<NW> tbl, const uint64_t *_
 	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
 
+// the final graph as the second read pass needs it -- key -> path word -- out of one rank's table and into another's (--gpus N: every rank
+// maps its own reads, prlRead2path.c:817-1335 on every rank's share of the input)
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_export_paths(Table<NW> tbl, uint64_t *__restrict__ keys, uint64_t *__restrict__ paths, unsigned long long max_nodes, Stats *stats)
+{
+	const uint64_t slots = tbl.slots();
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY)
+			continue;
+		const unsigned long long pos = atomicAdd(&stats->scratch, 1ULL);
+		if (pos >= max_nodes)
+			continue;
+#pragma unroll
+		for (int i = 0; i < NW; i++)
+			keys[pos * NW + i] = e.key[i];
+		paths[pos] = e.val;
+	}
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_import_paths(Table<NW> tbl, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ paths, uint64_t n, Stats *stats)
+{
+	uint32_t claimed = 0, failed = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		Key<NW> key;
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+			key.w[w] = keys[i * NW + w];
+		uint64_t slot, seen;
+		const uint32_t before = claimed;
+		if (!table_locate<NW>(tbl, key, claimed, slot, seen) || claimed == before) {
+			failed++;                                // no room, or the key twice
+			continue;
+		}
+		tbl.ent[slot].val = paths[i];
+	}
+	if (claimed) atomicAdd(&stats->distinct, (unsigned long long)claimed);
+	if (failed) atomicAdd(&stats->probe_fail, (unsigned long long)failed);
+}
+
 #include "sdt_superkmer_kernels.cuh"
 #include "sdt_bm_kernels.cuh"
 #include "sdt_comm.cuh"
@@ -543,11 +584,11 @@ struct sdt_ctx {
 };
 
 static const double MAX_LOAD = 0.70;
-// slots of a flat table for `nodes` nodes: a load of SDT_TABLE_LOAD percent (default 55: half way between what the probes of the merges
+// slots of a flat table for `nodes` nodes: a load of SDT_TABLE_LOAD percent (default 45: measured best on the headline workload, between what the probes of the merges
 // like and what the scans of the table cost), a multiple of 4096, 2^16 at least
 static uint64_t flat_slots_for(uint64_t nodes)
 {
-	static const int pct = getenv("SDT_TABLE_LOAD") && atoi(getenv("SDT_TABLE_LOAD")) >= 10 && atoi(getenv("SDT_TABLE_LOAD")) <= 69 ? atoi(getenv("SDT_TABLE_LOAD")) : 55;
+	static const int pct = getenv("SDT_TABLE_LOAD") && atoi(getenv("SDT_TABLE_LOAD")) >= 10 && atoi(getenv("SDT_TABLE_LOAD")) <= 69 ? atoi(getenv("SDT_TABLE_LOAD")) : 45;
 	uint64_t slots = (uint64_t)((double)nodes * 100.0 / pct) + 4095;
 	slots &= ~4095ULL;
 	return slots < (1ULL << 16) ? (1ULL << 16) : slots;
@@ -2773,6 +2814,96 @@ int sdt_gpu_load_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_wo
 		return fail(SDT_ESTATE, "sdt_gpu_load_paths: %llu nodes are not in the table", (unsigned long long)c->h_stats->probe_fail);
 	c->paths_loaded = true;
 	return SDT_OK;
+}
+
+int sdt_gpu_export_paths(sdt_ctx *c, uint64_t *keys, uint64_t *path_words, uint64_t max_nodes, uint64_t *n)
+{
+	if (!c || !n)
+		return fail(SDT_EINVAL, "NULL argument");
+	if (!c->paths_loaded)
+		return fail(SDT_ESTATE, "call sdt_gpu_load_paths first");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK) return rc;
+	const uint64_t nodes = c->h_stats->distinct;
+	*n = nodes;
+	if (!keys && !path_words)
+		return SDT_OK;
+	if (!keys || !path_words || max_nodes < nodes)
+		return fail(SDT_EINVAL, "export arrays hold %llu nodes, the table has %llu", (unsigned long long)max_nodes, (unsigned long long)nodes);
+	uint64_t *d_k = nullptr, *d_p = nullptr;
+	const uint64_t m = nodes ? nodes : 1;
+	HIPCHK(hipMalloc((void **)&d_k, m * c->nw * 8));
+	hipError_t e = hipMalloc((void **)&d_p, m * 8);
+	if (e != hipSuccess) { (void)hipFree(d_k); return fail(SDT_ENOMEM, "path export: %s", hipGetErrorString(e)); }
+	int ret = SDT_OK;
+	e = hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream);
+	const int g = scan_grid(c, view_slots(c));
+	if (c->nw == 1) hipLaunchKernelGGL(k_export_paths<1>, dim3(g), dim3(TPB), 0, c->stream, table_of<1>(c), d_k, d_p, (unsigned long long)nodes, c->d_stats);
+	else if (c->nw == 2) hipLaunchKernelGGL(k_export_paths<2>, dim3(g), dim3(TPB), 0, c->stream, table_of<2>(c), d_k, d_p, (unsigned long long)nodes, c->d_stats);
+	else hipLaunchKernelGGL(k_export_paths<4>, dim3(g), dim3(TPB), 0, c->stream, table_of<4>(c), d_k, d_p, (unsigned long long)nodes, c->d_stats);
+	if (e == hipSuccess) e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) ret = fail(SDT_EHIP, "k_export_paths: %s", hipGetErrorString(e));
+	if (ret == SDT_OK) ret = sdti::d2h_big(c->copy_stream, keys, d_k, nodes * c->nw * 8);
+	if (ret == SDT_OK) ret = sdti::d2h_big(c->copy_stream, path_words, d_p, nodes * 8);
+	(void)hipFree(d_k);
+	(void)hipFree(d_p);
+	return ret;
+}
+
+int sdt_gpu_import_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
+                         const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed)
+{
+	if (!c || (n && (!keys || !path_words)) || (npatch && (!patch_keys || !patch_info)))
+		return fail(SDT_EINVAL, "NULL argument");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sync_stats(c);
+	if (rc != SDT_OK) return rc;
+	// the table of this rank's shard makes way (the reads kept for the second pass stay): an empty flat table with room for the graph
+	c->bm.tab.valid = false;
+	c->bm.tab.nslots = c->bm.tab.nodes = 0;
+	if (c->d_idx) { (void)hipFree(c->d_idx); c->d_idx = nullptr; c->idx_slots = c->idx_n = 0; }
+	const uint64_t want = flat_slots_for(n);
+	if (want > c->slots) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (c->d_ent) (void)hipFree(c->d_ent);
+		if (c->d_aux) (void)hipFree(c->d_aux);
+		if (c->d_first) (void)hipFree(c->d_first);
+		c->d_ent = nullptr; c->d_aux = nullptr; c->d_first = nullptr;
+		rc = alloc_table(c, want, &c->d_ent, &c->d_aux, &c->d_first);
+		if (rc != SDT_OK) { c->slots = 0; return rc; }
+		c->slots = want;
+	}
+	rc = launch_clear(c, c->d_ent, c->d_aux, c->d_first, c->slots);
+	if (rc != SDT_OK) return rc;
+	HIPCHK(hipMemsetAsync(&c->d_stats->distinct, 0, sizeof(unsigned long long), c->stream));
+	c->distinct_known = 0;
+	c->kmers_since_sync = c->hard_since_sync = 0;
+	uint64_t *d_k = nullptr, *d_p = nullptr;
+	const uint64_t STEP = 1ULL << 26;                // nodes per upload: bounded staging memory
+	const uint64_t m = n < STEP ? (n ? n : 1) : STEP;
+	HIPCHK(hipMalloc((void **)&d_k, m * c->nw * 8));
+	hipError_t e = hipMalloc((void **)&d_p, m * 8);
+	if (e != hipSuccess) { (void)hipFree(d_k); return fail(SDT_ENOMEM, "path import: %s", hipGetErrorString(e)); }
+	for (uint64_t i0 = 0; i0 < n && rc == SDT_OK; i0 += STEP) {
+		const uint64_t k = n - i0 < STEP ? n - i0 : STEP;
+		rc = sdti::h2d_big(c->copy_stream, d_k, keys + i0 * c->nw, k * c->nw * 8);
+		if (rc == SDT_OK) rc = sdti::h2d_big(c->copy_stream, d_p, path_words + i0, k * 8);
+		if (rc != SDT_OK) break;
+		const int g = scan_grid(c, k);
+		if (c->nw == 1) hipLaunchKernelGGL(k_import_paths<1>, dim3(g), dim3(TPB), 0, c->stream, flat_of<1>(c), d_k, d_p, k, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_import_paths<2>, dim3(g), dim3(TPB), 0, c->stream, flat_of<2>(c), d_k, d_p, k, c->d_stats);
+		else hipLaunchKernelGGL(k_import_paths<4>, dim3(g), dim3(TPB), 0, c->stream, flat_of<4>(c), d_k, d_p, k, c->d_stats);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) rc = fail(SDT_EHIP, "k_import_paths: %s", hipGetErrorString(e));
+	}
+	(void)hipFree(d_k);
+	(void)hipFree(d_p);
+	if (rc != SDT_OK) return rc;
+	// patch table, arc map, and the check that every key went in once (sdt_gpu_load_paths with no node of its own to set)
+	return sdt_gpu_load_paths(c, nullptr, nullptr, 0, patch_keys, patch_info, npatch, num_ed);
 }
 
 int sdt_gpu_map_reads(sdt_ctx *c, uint64_t *reads_processed, uint64_t *arcs)

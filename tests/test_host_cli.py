@@ -120,19 +120,27 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("gpus,second", [(2, "ranks"), (3, "ranks"), (4, "ranks"), (2, "rank0"), (3, "host")])
 @pytest.mark.parametrize("name", ["se100_k23_p8_d1", "pe150_k31_p8", "se250_k63_p8_127mer", "dirty_ragged_k25_cut80"])
-def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus):
+def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus, second):
     """`sdt-pregraph --gpus N`: one process per rank (forked before HIP is touched; here all on the one GPU of the box over
     the shared-memory transport), the read stream cut into small chunks that alternate between the ranks, pass 1 bucket
-    sharded, shards gathered on rank 0 for the graph phases: all five files as the reference wrote them"""
+    sharded, shards gathered on rank 0 for the graph phases: all five files as the reference wrote them.
+    second = ranks: every rank keeps the reads it parsed and maps them against the graph rank 0 publishes (key -> path word), the
+    arcs of all ranks add up (round 5; prlRead2path.c:817-1335 on every rank's share); rank0: rank 0 keeps and maps all reads
+    (rounds 2-4, SDT_RANK0_MAP); host: --host-map, the host reads the files again"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
            str(tmp_path / "out"), "--max-k", str(gu.VARIANT_MAXK[info["variant"]]), "--gpus", str(gpus), "--share-device"]
     if info["d"]:
         cmd += ["-d", str(info["d"])]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SDT_CHUNK_BYTES="30000"))
+    env = dict(os.environ, SDT_CHUNK_BYTES="30000")
+    if second == "rank0":
+        env["SDT_RANK0_MAP"] = "1"
+    if second == "host":
+        cmd += ["--host-map"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")
     assert open(tmp_path / "out.vertex").read() == gu.golden_text(info, "vertex")
