@@ -40,6 +40,7 @@ ap.add_argument("--compare-host-walks", action="store_true", help="run again wit
 ap.add_argument("--gen-procs", type=int, default=0, help="processes that write the FASTQ (0 = one per usable CPU; fixed-width records, written in place)")
 ap.add_argument("--ingest-probe", action="store_true", help="only time --hash-only in variants (as is, parse only, other thread counts) and stop")
 ap.add_argument("--env-runs", default="", help="measurement: run sdt-pregraph once per variant 'name:K=V,K=V;name2:...' (environment switches of the library / CLI), report walls and phase lines, and stop")
+ap.add_argument("--also-cli-args", default="", help="run sdt-pregraph once more with these extra arguments (e.g. '--gpus 4 --share-device') and compare its five files with the first run's")
 ap.add_argument("--runs", type=int, default=1, help="run sdt-pregraph this many times (page cache, first-touch effects): the fastest is reported, all walls are listed")
 args = ap.parse_args()
 
@@ -256,6 +257,17 @@ try:
     r2 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
                          os.path.join(tmp, "ours_hash"), "--hash-only"] + extra, capture_output=True, text=True, timeout=args.timeout)
     res["ours_hash_only_wall_s"] = round(time.time() - t0, 2)
+    if args.also_cli_args:
+        t0 = time.time()
+        ra = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",
+                             os.path.join(tmp, "also")] + extra + args.also_cli_args.split(), capture_output=True, text=True, timeout=args.timeout)
+        res["also"] = {"cli_args": args.also_cli_args, "rc": ra.returncode, "wall_s": round(time.time() - t0, 2),
+                       "phase_ms": [l.replace("[sdt-pregraph] ", "") for l in ra.stderr.splitlines() if l.startswith(("[sdt-pregraph]", "[read2edge]"))],
+                       "same_as_first_run": {ext: (os.path.exists(os.path.join(tmp, "also." + ext)) and
+                                                   open(os.path.join(tmp, "ours." + ext), "rb").read() == open(os.path.join(tmp, "also." + ext), "rb").read())
+                                             for ext in ("kmerFreq", "vertex", "preGraphBasic", "preArc", "edge.gz")}}
+        if ra.returncode != 0:
+            res["also"]["stderr_tail"] = ra.stderr[-1500:]
     if args.compare_host_walks:
         t0 = time.time()
         r3 = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",

@@ -22,12 +22,18 @@ for f in glob.glob(f"{d}/pass_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-PASS1 = ("k_sk_scatter_reads", "k_sk_scatter_reads_seq", "k_sk_scatter_records", "k_sk_count", "k_sk_chunk_place", "k_sk_scan", "k_sk_seal", "k_sk_init_cursors", "k_count_reads")
-DOUBLE = ("k_sk_scatter_records", "k_sk_count")
+PASS1 = ("k_sk_scatter_reads", "k_sk_scatter_reads_seq", "k_sk_scatter_records", "k_sk_scatter_records_staged", "k_sk_count", "k_sk_count_flat", "k_sk_chunk_place",
+         "k_sk_chunk_place_few", "k_sk_scan", "k_sk_seal", "k_sk_init_cursors", "k_count_reads",
+         # round 5: the fold of the node log (SDT_FLAG_NODE_LOG)
+         "k_bm_finalize", "k_bm_desc_hist", "k_bm_desc_place", "k_bm_class_hist", "k_bm_class_scan", "k_bm_class_place", "k_bm_flat_hist", "k_bm_flat_place")
+DOUBLE = ("k_sk_scatter_records", "k_sk_scatter_records_staged", "k_sk_count", "k_sk_count_flat", "k_bm_finalize")
+OURS = PASS1 + ("k_clear", "k_mark_hist", "k_delow", "k_export", "k_rehash", "k_fixed_offsets")
 res = {"reads": reads, "read_len": L, "K": K, "steps_profiled": steps, "kmers": kmers, "kernels": {}}
 tot_f = tot_w = tot_a = 0.0
 for k, c in sorted(agg.items()):
     base = k.split("<")[0]
+    if base not in OURS:                             # (the workload generator's at::native kernels are not part of the measurement)
+        continue
     fetch = c.get("FETCH_SIZE", 0) * 1024 * (2 if base in DOUBLE else 1)
     write = c.get("WRITE_SIZE", 0) * 1024
     atom = c.get("TCC_EA0_ATOMIC_sum", 0)
