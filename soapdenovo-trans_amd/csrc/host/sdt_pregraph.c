@@ -990,6 +990,7 @@ int main(int argc, char **argv)
 				vj_keep = (vx_job *)malloc(sizeof VJ);
 				*vj_keep = VJ;
 				have_nv = pthread_create(&vth, NULL, vertex_thread, vj_keep) == 0;
+				if (!have_nv) graph_vertex_quiet = 0;                 /* (no thread: *.vertex is written in its turn below, with its line) */
 				vth_keep = vth;
 			}
 			uint64_t nreads2 = 0, narcs = 0;

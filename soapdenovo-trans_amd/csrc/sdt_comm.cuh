@@ -167,14 +167,20 @@ struct Comm {
 
 	// RCCL collectives have no timeout: a peer that has left keeps this rank's stream waiting for ever.  With a communicator over
 	// several ranks every host-side wait therefore polls, and gives up -- with the rank, the place and the exchange round in the
-	// message, never by re-executing anything -- after SDT_COMM_TIMEOUT_S seconds (default 300) without the stream completing.
+	// message, never by re-executing anything -- when the stream has not completed after a deadline: SDT_COMM_TIMEOUT_S seconds
+	// (default 1800) for a wait on the exchange stream -- a collective, which also waits for the SLOWEST peer's work before it (rank 0
+	// taking every shard into its table while the others stand in the token all-reduce) --, SDT_DRAIN_TIMEOUT_S (default 7200) for a
+	// drain of this rank's own kernels, which needs no peer at all.  The deadline is total time, not time without progress: the
+	// stream offers no heartbeat to tell the two apart; a job that legitimately waits longer raises the knob.
 	int sync_watched(hipStream_t s, const char *what)
 	{
 		if (kind != 1 || nranks == 1) {
 			HIPCHK(hipStreamSynchronize(s));
 			return SDT_OK;
 		}
-		static const double limit = getenv("SDT_COMM_TIMEOUT_S") && atof(getenv("SDT_COMM_TIMEOUT_S")) > 0 ? atof(getenv("SDT_COMM_TIMEOUT_S")) : 300.0;
+		static const double comm_limit = getenv("SDT_COMM_TIMEOUT_S") && atof(getenv("SDT_COMM_TIMEOUT_S")) > 0 ? atof(getenv("SDT_COMM_TIMEOUT_S")) : 1800.0;
+		static const double drain_limit = getenv("SDT_DRAIN_TIMEOUT_S") && atof(getenv("SDT_DRAIN_TIMEOUT_S")) > 0 ? atof(getenv("SDT_DRAIN_TIMEOUT_S")) : 7200.0;
+		const double limit = s == xstream ? comm_limit : drain_limit;
 		const double t0 = comm_now();
 		for (;;) {
 			const hipError_t e = hipStreamQuery(s);
@@ -182,8 +188,9 @@ struct Comm {
 			if (e != hipErrorNotReady)
 				return fail(SDT_EHIP, "rank %d of %d: %s: %s", rank, nranks, what, hipGetErrorString(e));
 			if (comm_now() - t0 > limit)
-				return fail(SDT_EHIP, "rank %d of %d: no progress for %.0f s in %s (exchange %llu, %llu bytes sent so far): a peer has probably left -- giving up",
-				            rank, nranks, limit, what, (unsigned long long)exchanges, (unsigned long long)bytes_sent);
+				return fail(SDT_EHIP, "rank %d of %d: %s not complete after %.0f s (exchange %llu, %llu bytes sent so far): a peer has probably left -- giving up "
+				            "(SDT_COMM_TIMEOUT_S / SDT_DRAIN_TIMEOUT_S raise the deadlines)",
+				            rank, nranks, what, limit, (unsigned long long)exchanges, (unsigned long long)bytes_sent);
 			usleep(50);
 		}
 	}

@@ -460,6 +460,7 @@ __device__ inline void ord_min_noret(uint64_t *p, uint64_t ord)
 // words is 32-byte aligned, so the pair lies in one 16-byte granule of one cache line and reaches L2 as one write: a reader that
 // sees the new key[0] sees the new key[1] (it loads key[1] after key[0], in order, from the same line).  The two-step form --
 // key[1], wait for the store to be acknowledged, key[0] -- cost a new key a whole memory round trip on the flush's critical path.
+static_assert(alignof(Entry<2>) == 32 && sizeof(Entry<2>) == 32, "a 2-word key's pair of words lies in one 16-byte granule of one 32-byte entry");
 __device__ inline void store_key_pair(uint64_t *p, uint64_t k0, uint64_t k1)
 {
 	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

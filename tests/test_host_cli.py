@@ -214,6 +214,53 @@ def test_cli_against_oracle_on_fresh_inputs(pkg, synth, tmp_path, K, p, d, L, va
 
 
 @pytest.mark.gpu
+def test_cli_against_oracle_at_size_with_long_and_short_components(pkg, synth, tmp_path):
+    """the device graph units AT SIZE against the C oracle (pinned file by file to the reference, tests/test_oracle_vs_reference.py): a
+    million reads off a few deeply covered transcripts -- removeMinorOut's commit runs on the device for the components up to the limit and
+    on the host's threads beside it for the longer ones (here the limit is lowered to 64 visits so that BOTH sides have thousands of
+    visits), the tip passes commit by components, kmer2edges and the second read pass run on the device; every file must be the oracle's
+    (cutTipPreGraph.c:43-1076, node2edge.c:46-561, prlRead2path.c:817-1335)"""
+    import oracle_binding as ob
+    K, p, L = 31, 8, 150
+    tx = synth.make_transcriptome(60, seed=77)
+    codes, offs = synth.sample_reads(*tx, n_reads=500_000, read_len=L, seed=78, err=0.004, ragged=False)
+    letters = np.frombuffer(b"ACTG", dtype=np.uint8)[codes]
+    o64 = offs.astype(np.int64)
+    n = len(o64) - 1
+    # fixed-length FASTQ written in one piece: "@r<i>\n" + read + "\n+\n" + quality + "\n"
+    with open(tmp_path / "reads.fq", "wb") as fq:
+        qual = b"I" * L
+        step = 50_000
+        for a in range(0, n, step):
+            b = min(a + step, n)
+            block = letters[o64[a]: o64[b]].reshape(b - a, L)
+            fq.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (a + i, block[i].tobytes(), qual) for i in range(b - a)))
+    cfg = tmp_path / "lib.cfg"
+    cfg.write_text(f"max_rd_len={L}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq={tmp_path}/reads.fq\n")
+    cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", str(cfg), "-K", str(K), "-p", str(p), "-o", str(tmp_path / "out"), "--max-k", "31"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SDT_TIMING="1", SDT_COMMIT_MAX_COMPONENT="64"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"\((\d+) visits, largest component (\d+)\).* (\d+) records of long components", r.stderr)
+    assert m, r.stderr[-3000:]
+    visits, largest, long_records = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert largest > 64 and long_records > 0 and visits > long_records, "components on both sides of the limit"
+    o = ob.Oracle(K, nsets=p, nw=1)
+    o.add_reads(codes, offs)
+    hist, _ = o.mark()
+    o.remove_minor_out(5)
+    o.remove_single_tips()
+    o.remove_minor_tips()
+    nvert = o.write_vertex(str(tmp_path / "o.vertex"))
+    num_ed, _, _ = o.write_edges(str(tmp_path / "o.edge"))
+    o.read2edge(codes, offs, str(tmp_path / "o.preArc"))
+    assert nvert > 0 and num_ed > 0
+    assert open(tmp_path / "out.kmerFreq").read() == ob.kmerfreq_text(hist)
+    assert open(tmp_path / "out.vertex").read() == open(tmp_path / "o.vertex").read()
+    assert gzip.open(tmp_path / "out.edge.gz", "rt").read() == open(tmp_path / "o.edge").read()
+    assert open(tmp_path / "out.preArc").read() == open(tmp_path / "o.preArc").read()
+
+
+@pytest.mark.gpu
 def test_cli_usage_and_errors(pkg, tmp_path):
     exe = bin_path(pkg, "sdt-pregraph")
     r = subprocess.run([exe, "pregraph"], capture_output=True, text=True)
