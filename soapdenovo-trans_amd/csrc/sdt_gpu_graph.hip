@@ -223,7 +223,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	std::vector<std::vector<Gen>> sched(p);
 	std::vector<RpSet> sets(p);
 	const double lf = (double)0.77f;
-	uint64_t tab_total = 0, max_m = 0, max_size = 0;
+	uint64_t tab_total = 0, max_size = 0;
 	size_t max_gens = 0;
 	for (int s = 0; s < p; s++) {
 		const uint64_t ms = set_start[s + 1] - set_start[s];
@@ -240,26 +240,32 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 		}
 		sets[s].key0 = set_start[s]; sets[s].tab0 = tab_total; sets[s].m = (uint32_t)ms;
 		tab_total += size;
-		if (ms > max_m) max_m = ms;
 		if (size > max_size) max_size = size;
 		if (sched[s].size() > max_gens) max_gens = sched[s].size();
 	}
-	int idbits = 1;
-	while ((1ULL << idbits) <= max_m) idbits++;
-	int sbits = 1;
-	while ((1ULL << sbits) < max_size) sbits++;
-	if (idbits + sbits + RP_DEPTH_BITS > 64) return fail(SDT_EINVAL, "layout on the device: %d id bits + %d slot bits do not fit the table word", idbits, sbits);
+	// table word of a growth's rounds: time << qbits | q + 1 (q = old slot, time = old slot << RP_DEPTH_BITS | depth); a dirty cluster's
+	// list entry keeps the set in 10 bits
+	int qbits = 1;
+	while ((1ULL << qbits) <= max_size) qbits++;
+	if (2 * qbits + RP_DEPTH_BITS > 64 || p >= 1024) return fail(SDT_ELIMIT, "layout on the device: twice %d slot bits do not fit the table word (or %d sets the list entry)", qbits, p);
 	tick("schedule made");
 	// ---- buffers
-	unsigned long long *tab[2], *t_time[2], *d_pre;
+	unsigned long long *tab[2], *d_time, *d_work, *d_list[2], *d_pre;
 	uint32_t *d_home, *d_occ, *d_rank;
 	RpSet *d_sets;
-	unsigned int *d_flags;
+	unsigned int *d_flags, *d_dirty;
+	RpRound *d_round;
 	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
 	uint32_t *d_home_slot;
-	GCHK(S.alloc(&t_time[0], (tab_total + 1) * 8)); GCHK(S.alloc(&t_time[1], (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));     // per OLD slot of a growth
+	// per OLD slot of a growth: time and home; per entry: the work list of a round and the two lists of dirty clusters (a cluster is
+	// listed by one of its entries, an entry sits in one cluster); one dirty bit per new slot
+	const unsigned long long list_cap = m + 1;
+	GCHK(S.alloc(&d_time, (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));
+	GCHK(S.alloc(&d_work, list_cap * 8)); GCHK(S.alloc(&d_list[0], list_cap * 8)); GCHK(S.alloc(&d_list[1], list_cap * 8));
+	GCHK(S.alloc(&d_dirty, (tab_total / 32 + 2) * 4)); GCHK(S.alloc(&d_round, sizeof(RpRound)));
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
 	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
+	GCHK(hipMemsetAsync(d_dirty, 0, (tab_total / 32 + 2) * 4, v.stream));        // (every bit a round sets is cleared by the next one)
 	tick("buffers made");
 	std::vector<unsigned long long> pre(p + 1);
 	auto upload = [&](void) -> int {
@@ -292,29 +298,41 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 			pre[p] = old_total;
 			rc = upload(); if (rc != SDT_OK) return rc;
 			const int nxt = cur ^ 1;
-			int tc = 0;
 			const double t_g0 = now_ms();
 			const int rounds0 = total_rounds;
 			// time (q, 0) and the home in the new geometry, per old slot
-			if (v.nw == 1) hipLaunchKernelGGL(k_rp_rehash_init<1>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
-			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_rehash_init<2>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
-			else hipLaunchKernelGGL(k_rp_rehash_init<4>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], t_time[tc], d_home_slot);
+			if (v.nw == 1) hipLaunchKernelGGL(k_rp_rehash_init<1>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], d_time, d_home_slot);
+			else if (v.nw == 2) hipLaunchKernelGGL(k_rp_rehash_init<2>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], d_time, d_home_slot);
+			else hipLaunchKernelGGL(k_rp_rehash_init<4>, grid(old_total), dim3(TPB), 0, v.stream, d_keys, d_sets, d_pre, p, tab[cur], d_time, d_home_slot);
+			for (int s = 0; s < p; s++)                           // (only the regions of the sets that grow, at their new size: the early growths are tiny)
+				if (sets[s].old_size) GCHK(hipMemsetAsync(tab[nxt] + sets[s].tab0, 0, (size_t)sets[s].size * 8, v.stream));
+			GCHK(hipMemsetAsync(d_round, 0, sizeof(RpRound), v.stream));
+			// round 0: everybody
+			hipLaunchKernelGGL(k_rp_ins_all, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_round);
+			hipLaunchKernelGGL(k_rp_eval_all, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_dirty,
+			                   d_list[0], list_cap, d_round);
+			GCHK(hipGetLastError());
 			// (SDT_RP_MAX_ROUNDS: test hook -- a cap that real data passes, so that the caller's other path is exercised)
 			static const int max_rounds = getenv("SDT_RP_MAX_ROUNDS") ? atoi(getenv("SDT_RP_MAX_ROUNDS")) : 60;
+			int lc = 0;
 			for (int round = 0;; round++) {
-				if (round > max_rounds) return fail(SDT_ELIMIT, "layout on the device: a growth did not settle in %d rounds", max_rounds);
-				for (int s = 0; s < p; s++)                       // (only the regions of the sets that grow, at their new size: the early growths are tiny)
-					if (sets[s].old_size) GCHK(hipMemsetAsync(tab[nxt] + sets[s].tab0, 0, (size_t)sets[s].size * 8, v.stream));
-				GCHK(hipMemsetAsync(d_flags, 0, 4, v.stream));
-				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], tab[nxt], d_home_slot, t_time[tc], t_time[tc ^ 1], d_flags);
-				hipLaunchKernelGGL(k_rp_rehash, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 2, idbits, tab[cur], tab[nxt], d_home_slot, t_time[tc], t_time[tc ^ 1], d_flags);
-				GCHK(hipGetLastError());
-				GCHK(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, v.stream));
+				RpRound h_round;
+				GCHK(hipMemcpyAsync(&h_round, d_round, sizeof(RpRound), hipMemcpyDeviceToHost, v.stream));
 				GCHK(hipStreamSynchronize(v.stream));
 				total_rounds++;
-				if (h_flags & 6u) return fail(SDT_ELIMIT, "layout on the device: %s", (h_flags & 2u) ? "an insertion found no slot" : "an eviction chain deeper than the time field");
-				if (!(h_flags & 1u)) break;
-				tc ^= 1;
+				if (h_round.flags) return fail(SDT_ELIMIT, "layout on the device: %s", (h_round.flags & 2u) ? "an insertion found no slot" :
+				                               (h_round.flags & 4u) ? "an eviction chain or a cluster past its field" : "a list of the rounds is full");
+				if (!h_round.n_next) break;
+				if (round >= max_rounds) return fail(SDT_ELIMIT, "layout on the device: a growth did not settle in %d rounds", max_rounds);
+				// the clusters that hold a changed entry: taken apart, laid out again, their old slots evaluated again
+				const unsigned long long n_list = h_round.n_next;
+				GCHK(hipMemsetAsync(d_round, 0, sizeof(RpRound), v.stream));
+				hipLaunchKernelGGL(k_rp_collect, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[nxt], d_dirty, d_list[lc], n_list, d_work, list_cap, d_round);
+				hipLaunchKernelGGL(k_rp_ins_list, grid(n_list * 4), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[nxt], d_home_slot, d_time, d_work, d_round);
+				hipLaunchKernelGGL(k_rp_eval_list, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_dirty,
+				                   d_list[lc], n_list, d_list[lc ^ 1], list_cap, d_round);
+				GCHK(hipGetLastError());
+				lc ^= 1;
 			}
 			const double t_g1 = now_ms();
 			t_rehash += t_g1 - t_g0;
@@ -333,7 +351,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				std::vector<RpSet> grown = sets;
 				for (int s = 0; s < p; s++) if (gen >= sched[s].size()) grown[s].size = 0;
 				GCHK(hipMemcpy(d_sets, grown.data(), (size_t)p * sizeof(RpSet), hipMemcpyHostToDevice));
-				hipLaunchKernelGGL(k_rp_slots, grid(new_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 0, idbits, tab[nxt], (uint32_t *)nullptr);
+				hipLaunchKernelGGL(k_rp_slots, grid(new_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 0, qbits, tab[cur], tab[nxt], (uint32_t *)nullptr);
 				GCHK(hipGetLastError());
 				GCHK(hipStreamSynchronize(v.stream));
 			}
@@ -371,10 +389,11 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	pre[p] = slot_total;
 	rc = upload(); if (rc != SDT_OK) return rc;
 	// (the buffers of the replay that are free now make room for the flags and their prefix sum)
-	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(t_time[0])); (void)hipFree(S.release(t_time[1])); (void)hipFree(S.release(d_home_slot));
+	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(d_time)); (void)hipFree(S.release(d_home_slot));
+	(void)hipFree(S.release(d_work)); (void)hipFree(S.release(d_list[0])); (void)hipFree(S.release(d_list[1]));
 	uint64_t *d_order;
 	GCHK(S.alloc(&d_occ, (slot_total + 1) * 4)); GCHK(S.alloc(&d_rank, (slot_total + 1) * 4)); GCHK(S.alloc(&d_order, m * 8));
-	hipLaunchKernelGGL(k_rp_slots, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, idbits, tab[cur], d_occ);
+	hipLaunchKernelGGL(k_rp_slots, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, qbits, (const unsigned long long *)nullptr, tab[cur], d_occ);
 	GCHK(hipGetLastError());
 	rc = exclusive_scan<uint32_t>(v, d_occ, d_rank, slot_total);
 	if (rc != SDT_OK) return rc;

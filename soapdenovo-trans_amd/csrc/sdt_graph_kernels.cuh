@@ -443,28 +443,51 @@ __global__ __launch_bounds__(TPB) void k_layout_keys(Table<NW> tbl, uint32_t p, 
 	__shared__ int32_t s_crc[256];
 	crc_table_to_lds(s_crc);
 	const uint64_t slots = tbl.slots();
+	const int lane = threadIdx.x & 63;
 	uint32_t bad = 0;
-	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
-		const Entry<NW> e = tbl.ent[s];
-		if (e.key[0] == KEY_EMPTY) continue;
-		int32_t crc = ~0;
-		// raw bytes of the variant's Kmer struct: words most significant first, each little endian; a variant wider than the
-		// device key has zero words in front
-		for (int w = 0; w < nw_variant; w++) {
-			const int kw = w - (nw_variant - NW);
-			const uint64_t word = kw >= 0 ? e.key[kw] : 0ULL;
+	// eight slots per lane and ONE reservation per wave for all of them (the output order is free: the pairs are sorted next)
+	constexpr int IT = 8;
+	for (uint64_t base = blockIdx.x * (uint64_t)TPB * IT; base < slots; base += (uint64_t)gridDim.x * TPB * IT) {
+		uint32_t occ = 0;
 #pragma unroll
-			for (int j = 0; j < 8; j++)
-				crc = s_crc[(crc ^ (int32_t)((word >> (8 * j)) & 0xFF)) & 0xFF] ^ (crc >> 8);     // >> on a negative int shifts sign bits in
+		for (int j = 0; j < IT; j++) {
+			const uint64_t s = base + (uint64_t)j * TPB + threadIdx.x;
+			if (s < slots && tbl.ent[s].key[0] != KEY_EMPTY) occ |= 1u << j;
 		}
-		crc = ~crc;
-		const uint64_t set = ((uint64_t)(int64_t)crc & 0xFFFFFFULL) % p;
-		const uint64_t first = tbl.first[s];
-		if (first >> 56) bad++;
-		const unsigned long long pos = atomicAdd(cursor, 1ULL);
-		if (pos >= max_nodes) { bad++; continue; }
-		skey[pos] = (set << 56) | (first & 0x00FFFFFFFFFFFFFFULL);
-		sval[pos] = s;
+		const uint32_t mine = __popc(occ);
+		uint32_t inc = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(inc, d);
+			if (lane >= d) inc += o;
+		}
+		const uint32_t total = __shfl(inc, 63);
+		unsigned long long pos = 0;
+		if (lane == 0 && total) pos = atomicAdd(cursor, (unsigned long long)total);
+		pos = __shfl(pos, 0) + (inc - mine);
+		for (int j = 0; j < IT; j++) {
+			if (!((occ >> j) & 1u)) continue;
+			const uint64_t s = base + (uint64_t)j * TPB + threadIdx.x;
+			const Entry<NW> e = tbl.ent[s];
+			int32_t crc = ~0;
+			// raw bytes of the variant's Kmer struct: words most significant first, each little endian; a variant wider than the
+			// device key has zero words in front
+			for (int w = 0; w < nw_variant; w++) {
+				const int kw = w - (nw_variant - NW);
+				const uint64_t word = kw >= 0 ? e.key[kw] : 0ULL;
+#pragma unroll
+				for (int b = 0; b < 8; b++)
+					crc = s_crc[(crc ^ (int32_t)((word >> (8 * b)) & 0xFF)) & 0xFF] ^ (crc >> 8);     // >> on a negative int shifts sign bits in
+			}
+			crc = ~crc;
+			const uint64_t set = ((uint64_t)(int64_t)crc & 0xFFFFFFULL) % p;
+			const uint64_t first = tbl.first[s];
+			if (first >> 56) bad++;
+			const unsigned long long at = pos++;
+			if (at >= max_nodes) { bad++; continue; }
+			skey[at] = (set << 56) | (first & 0x00FFFFFFFFFFFFFFULL);
+			sval[at] = s;
+		}
 	}
 	if (bad) atomicAdd(&stats->probe_fail, (unsigned long long)bad);
 }
@@ -1100,7 +1123,7 @@ __global__ __launch_bounds__(TPB) void k_edge_stamp(Table<NW> tbl, const uint64_
 //     k_rp_insert_timed), read the evictions off the layout (k_rp_times; all times of a round from the layout of the round
 //     before), repeat until nothing changes: times only fall, never below the true ones, the only fixed point is the
 //     sequential run (tools/replay_fixed_point.c checks exactly this against the sequential emulation).  10-20 rounds.
-// Table word: 0 = empty; puts: id + 1; during a rehash: time << idbits | id + 1 with time = q << 6 | depth.
+// Table word: 0 = empty; puts: id + 1; during a rehash: time << qbits | q + 1 with q = the entry's old slot, time = q' << 6 | depth.
 // ===============================================================================================================
 struct RpSet {
 	unsigned long long key0;     // rank of the set's first key in the sorted key array (= its first visiting position)
@@ -1202,43 +1225,154 @@ __global__ __launch_bounds__(TPB) void k_rp_rehash_init(const uint64_t *__restri
 	}
 }
 
-//   k_rp_rehash: mode 1 = timed insertion into the new table, mode 2 = next times from the new layout
-__global__ __launch_bounds__(TPB) void k_rp_rehash(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int idbits,
-                                                   const unsigned long long *__restrict__ told, unsigned long long *__restrict__ tnew,
-                                                   const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t_cur,
-                                                   unsigned long long *__restrict__ t_next, unsigned int *flags)
+//   The rounds of a growth (table word here: time << qbits | q + 1, q = the entry's OLD slot; home and time are per old slot).
+//   The set of occupied slots of a linear-probing table does not depend on the order of insertion, so the CLUSTERS of the new
+//   table (maximal runs of occupied slots) are the same in every round, and an entry whose time changed can only re-arrange the
+//   cluster it sits in.  Round 0 is full (k_rp_ins_all, k_rp_eval_all); every later round takes the clusters that hold a changed
+//   entry apart (k_rp_collect), re-inserts their entries with the new times (k_rp_ins_list) and re-evaluates the old slots that
+//   lie inside them (k_rp_eval_list: an evaluation depends on the word at the entry's old slot and on its own time only, and is
+//   idempotent) -- 0.7 of one full round in all instead of 15-20 full rounds (tools/replay_fixed_point.c, table C).
+//   List entry of a dirty cluster: set << 54 | length << 32 | first slot.
+constexpr int RP_LEN_BITS = 22;
+struct RpRound {
+	unsigned long long n_next;       // clusters in the list this round writes
+	unsigned long long n_work;       // entries taken out of the clusters of this round
+	unsigned int flags;              // 2 = an insertion found no slot, 4 = chain or cluster past its field, 8 = a list is full
+	unsigned int pad;
+};
+
+__global__ __launch_bounds__(TPB) void k_rp_ins_all(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int qbits,
+                                                    const unsigned long long *__restrict__ told, unsigned long long *tnew,
+                                                    const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t, RpRound *st)
 {
-	const unsigned long long total = pre[p], idmask = (1ULL << idbits) - 1ULL;
+	const unsigned long long total = pre[p];
 	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
 		const int s = rp_find_set(pre, p, g);
 		const RpSet S = sets[s];
 		const unsigned long long q = g - pre[s];
-		const unsigned long long y = told[S.tab0 + q];               // id + 1
-		if (!y) continue;
-		if (mode == 1) {
-			if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t_cur[g] << idbits) | y)) atomicOr(flags, 2u);
-		} else {
-			const unsigned long long w = tnew[S.tab0 + q], x = w & idmask, tx = w >> idbits, mine = t_cur[g], scan = q << RP_DEPTH_BITS;
-			unsigned long long nt = scan;
-			if (x == y) nt = mine;                                     // it sits on its own old slot: nobody took it (leave the time alone)
-			else if (w && tx < scan) nt = tx + 1ULL;                   // the slot was taken before the scan reached it: carried on at once
-			if ((nt & ((1ULL << RP_DEPTH_BITS) - 1ULL)) == (1ULL << RP_DEPTH_BITS) - 1ULL) atomicOr(flags, 4u);      // chain too deep for the field
-			t_next[g] = nt;
-			if (nt != mine) atomicOr(flags, 1u);
+		if (!told[S.tab0 + q]) continue;
+		if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t[g] << qbits) | (q + 1ULL))) atomicOr(&st->flags, 2u);
+	}
+}
+
+// next time of the entry of old slot q (g = its index over all sets) from the layout; a change marks the entry's cluster
+__device__ inline void rp_eval(const RpSet &S, int s, unsigned long long g, unsigned long long q, int qbits, const unsigned long long *tnew,
+                               const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
+                               unsigned long long *next_list, unsigned long long cap, RpRound *st)
+{
+	const unsigned long long *T = tnew + S.tab0;
+	const unsigned long long w = T[q], x = w & ((1ULL << qbits) - 1ULL), tx = w >> qbits, mine = t[g], scan = q << RP_DEPTH_BITS;
+	unsigned long long nt = scan;
+	if (x == q + 1ULL) nt = mine;                                  // it sits on its own old slot: nobody took it (leave the time alone)
+	else if (w && tx < scan) nt = tx + 1ULL;                       // the slot was taken before the scan reached it: carried on at once
+	if (nt == mine) return;
+	if ((nt & ((1ULL << RP_DEPTH_BITS) - 1ULL)) == (1ULL << RP_DEPTH_BITS) - 1ULL) atomicOr(&st->flags, 4u);      // chain too deep for the field
+	t[g] = nt;
+	uint32_t a = home_slot[g];                                     // back from the home to the first slot of the cluster
+	for (uint32_t steps = 0; steps < S.size; steps++) {
+		const uint32_t b = a ? a - 1u : S.size - 1u;
+		if (T[b] == 0) break;
+		a = b;
+	}
+	const unsigned long long bit = S.tab0 + a;
+	const unsigned int m = 1u << (bit & 31u);
+	if (!(atomicOr(dirty + (bit >> 5), m) & m)) {
+		const unsigned long long k = atomicAdd(&st->n_next, 1ULL);
+		if (k < cap) next_list[k] = ((unsigned long long)s << (32 + RP_LEN_BITS)) | a;
+		else atomicOr(&st->flags, 8u);
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_rp_eval_all(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int qbits,
+                                                     const unsigned long long *__restrict__ told, const unsigned long long *tnew,
+                                                     const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
+                                                     unsigned long long *next_list, unsigned long long cap, RpRound *st)
+{
+	const unsigned long long total = pre[p];
+	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		const unsigned long long q = g - pre[s];
+		if (!told[S.tab0 + q]) continue;
+		rp_eval(S, s, g, q, qbits, tnew, home_slot, t, dirty, next_list, cap, st);
+	}
+}
+
+// take the listed clusters apart: their entries (as indices over the old slots of all sets) go to the work list, the slots are cleared
+__global__ __launch_bounds__(TPB) void k_rp_collect(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
+                                                    unsigned long long *tnew, unsigned int *dirty, unsigned long long *list, unsigned long long n_list,
+                                                    unsigned long long *work, unsigned long long cap, RpRound *st)
+{
+	const unsigned long long qmask = (1ULL << qbits) - 1ULL;
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long e = list[k];
+		const int s = (int)(e >> (32 + RP_LEN_BITS));
+		const uint32_t a = (uint32_t)e;
+		const RpSet S = sets[s];
+		unsigned long long *T = tnew + S.tab0;
+		const unsigned long long bit = S.tab0 + a;
+		atomicAnd(dirty + (bit >> 5), ~(1u << (bit & 31u)));
+		uint32_t len = 0, i = a;
+		while (len < S.size && T[i] != 0) { len++; i = i + 1u == S.size ? 0u : i + 1u; }
+		if (len >= (1u << RP_LEN_BITS)) { atomicOr(&st->flags, 4u); continue; }
+		const unsigned long long base = atomicAdd(&st->n_work, (unsigned long long)len);
+		if (base + len > cap) { atomicOr(&st->flags, 8u); continue; }
+		i = a;
+		for (uint32_t j = 0; j < len; j++) {
+			work[base + j] = pre[s] + (T[i] & qmask) - 1ULL;
+			T[i] = 0;
+			i = i + 1u == S.size ? 0u : i + 1u;
+		}
+		list[k] = e | ((unsigned long long)len << 32);
+	}
+}
+
+__global__ __launch_bounds__(TPB) void k_rp_ins_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int qbits,
+                                                     unsigned long long *tnew, const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t,
+                                                     const unsigned long long *__restrict__ work, RpRound *st)
+{
+	const unsigned long long total = st->n_work;
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < total; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long g = work[k];
+		const int s = rp_find_set(pre, p, g);
+		const RpSet S = sets[s];
+		if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t[g] << qbits) | (g - pre[s] + 1ULL))) atomicOr(&st->flags, 2u);
+	}
+}
+
+// the old slots inside the re-arranged clusters are the only ones whose evaluation can have changed
+__global__ __launch_bounds__(TPB) void k_rp_eval_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
+                                                      const unsigned long long *__restrict__ told, const unsigned long long *tnew,
+                                                      const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
+                                                      const unsigned long long *__restrict__ list, unsigned long long n_list,
+                                                      unsigned long long *next_list, unsigned long long cap, RpRound *st)
+{
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long e = list[k];
+		const int s = (int)(e >> (32 + RP_LEN_BITS));
+		const uint32_t len = (uint32_t)(e >> 32) & ((1u << RP_LEN_BITS) - 1u);
+		const RpSet S = sets[s];
+		uint32_t i = (uint32_t)e;
+		for (uint32_t j = 0; j < len; j++) {
+			if (i < S.old_size && told[S.tab0 + i]) rp_eval(S, s, pre[s] + i, i, qbits, tnew, home_slot, t, dirty, next_list, cap, st);
+			i = i + 1u == S.size ? 0u : i + 1u;
 		}
 	}
 }
 
-// over the NEW slots (pre = exclusive prefix of size): mode 0 = drop the times (word -> id + 1), 1 = flag occupied slots for the final order
-__global__ __launch_bounds__(TPB) void k_rp_slots(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int idbits,
-                                                  unsigned long long *__restrict__ tab, uint32_t *__restrict__ occ)
+// over the NEW slots (pre = exclusive prefix of size): mode 0 = after a growth: the old slot in the word -> the entry (id + 1, from the
+// old table), 1 = flag occupied slots for the final order
+__global__ __launch_bounds__(TPB) void k_rp_slots(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int mode, int qbits,
+                                                  const unsigned long long *__restrict__ told, unsigned long long *__restrict__ tab, uint32_t *__restrict__ occ)
 {
-	const unsigned long long total = pre[p], idmask = (1ULL << idbits) - 1ULL;
+	const unsigned long long total = pre[p], qmask = (1ULL << qbits) - 1ULL;
 	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
 		const int s = rp_find_set(pre, p, g);
 		const unsigned long long at = sets[s].tab0 + (g - pre[s]);
-		if (mode == 0) tab[at] &= idmask;
-		else occ[g] = tab[at] != 0;
+		if (mode == 0) {
+			const unsigned long long w = tab[at];
+			if (w) tab[at] = told[sets[s].tab0 + (w & qmask) - 1ULL];
+		} else occ[g] = tab[at] != 0;
 	}
 }
 

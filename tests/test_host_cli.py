@@ -243,7 +243,10 @@ def test_cli_against_oracle_at_size_with_long_and_short_components(pkg, synth, t
     m = re.search(r"\((\d+) visits, largest component (\d+)\).* (\d+) records of long components", r.stderr)
     assert m, r.stderr[-3000:]
     visits, largest, long_records = int(m.group(1)), int(m.group(2)), int(m.group(3))
-    assert largest > 64 and long_records > 0 and visits > long_records, "components on both sides of the limit"
+    m2 = re.search(r"(\d+) visits in (\d+) components, largest", r.stderr)      # (the host's side: the long components)
+    assert m2, r.stderr[-3000:]
+    long_visits = int(m2.group(1))
+    assert largest > 64 and long_records > 0 and 0 < long_visits < visits, "components on both sides of the limit"
     o = ob.Oracle(K, nsets=p, nw=1)
     o.add_reads(codes, offs)
     hist, _ = o.mark()

@@ -41,6 +41,7 @@ ap.add_argument("--gen-procs", type=int, default=0, help="processes that write t
 ap.add_argument("--ingest-probe", action="store_true", help="only time --hash-only in variants (as is, parse only, other thread counts) and stop")
 ap.add_argument("--env-runs", default="", help="measurement: run sdt-pregraph once per variant 'name:K=V,K=V;name2:...' (environment switches of the library / CLI), report walls and phase lines, and stop")
 ap.add_argument("--also-cli-args", default="", help="run sdt-pregraph once more with these extra arguments (e.g. '--gpus 4 --share-device') and compare its five files with the first run's")
+ap.add_argument("--gen-only", default="", help="write the FASTQ files and lib.cfg into this directory, print the sdt-pregraph command line and stop (the directory is kept: for runs under rocprofv3, which wants the program itself after --)")
 ap.add_argument("--runs", type=int, default=1, help="run sdt-pregraph this many times (page cache, first-touch effects): the fastest is reported, all walls are listed")
 args = ap.parse_args()
 
@@ -100,7 +101,7 @@ def _gen_pe_chunk(a):
     return n
 
 
-tmp = tempfile.mkdtemp(prefix="sdt_e2e_")
+tmp = tempfile.mkdtemp(prefix="sdt_e2e_") if not args.gen_only else (os.makedirs(args.gen_only, exist_ok=True) or args.gen_only)
 try:
     tx = synth.make_transcriptome(args.T, seed=42)
     fq = os.path.join(tmp, "reads.fq")
@@ -209,6 +210,10 @@ try:
     extra = ["--max-k", str(variant)] + common
     res["variant"], res["d"] = variant, args.d
     os.environ["SDT_TIMING"] = "1"
+    if args.gen_only:
+        print(" ".join([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o", os.path.join(tmp, "ours")] + extra))
+        sys.stdout.flush()
+        os._exit(0)                                            # (keeps the directory: the finally below removes it otherwise)
     if args.ingest_probe:
         probe = {}
         for name, env, p_ in (("as_is", {}, args.p), ("as_is_again", {}, args.p), ("parse_only", {"SDT_PARSE_ONLY": "1"}, args.p),
