@@ -574,6 +574,26 @@ int main(int argc, char **argv)
 
 	time_t t_start = time(NULL);
 	g_t_last = g_t_main = now_ms();
+	if (getenv("SDT_TIMING")) {
+		/* how long the loader took to get here (process start from /proc/self/stat, in clock ticks since boot): what a caller's
+		 * wall clock holds beyond "total inside main" is this plus the kernel's teardown of the address space after _exit */
+		FILE *sf = fopen("/proc/self/stat", "r");
+		char sb[2048];
+		if (sf) {
+			const size_t got = fread(sb, 1, sizeof sb - 1, sf);
+			fclose(sf);
+			sb[got] = 0;
+			const char *q = strrchr(sb, ')');
+			unsigned long long start = 0;
+			int field = 2;
+			for (q = q ? q + 1 : sb; *q && field < 22; q++) if (*q == ' ') field++;
+			if (field == 22) start = strtoull(q, NULL, 10);
+			struct timespec bt;
+			clock_gettime(CLOCK_BOOTTIME, &bt);
+			const double since = bt.tv_sec * 1e3 + bt.tv_nsec * 1e-6 - (double)start * 1e3 / (double)sysconf(_SC_CLK_TCK);
+			fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", "before main (loader)", since);
+		}
+	}
 	sdt_cfg cfg;
 	if (sdt_cfg_load(cfgfile, &cfg) != 0) return 255;
 	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;                /* prlHashReads.c:361-364 */

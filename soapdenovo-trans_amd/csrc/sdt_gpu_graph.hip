@@ -15,6 +15,7 @@
 
 using namespace sdt;
 
+#include "sdt_append.cuh"
 #include "sdt_graph_kernels.cuh"
 
 using sdti::fail;
@@ -87,11 +88,12 @@ static sdti::GraphExt *ext_of(const GraphView &v)
 
 // every device buffer of a call in one place: freed when the call returns, whatever the path
 struct Scratch {
-	void *p[40] = {};
+	void *p[96] = {};
 	int n = 0;
 	template <class T> hipError_t alloc(T **out, size_t bytes)
 	{
 		void *q = nullptr;
+		if (n == (int)(sizeof p / sizeof p[0])) { *out = nullptr; return hipErrorOutOfMemory; }
 		const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
 		if (e == hipSuccess) p[n++] = q;
 		*out = (T *)q;
@@ -137,6 +139,50 @@ static int exclusive_scan(const GraphView &v, const T *in, T *out, uint64_t n)
 	return SDT_OK;
 }
 
+
+// ---- records appended in chunks per wave (sdt_append.cuh): storage, and packing into one dense array ---------------------
+struct ApBuf {
+	uint64_t *chunks = nullptr;
+	uint32_t *fill = nullptr, *off = nullptr;
+	unsigned long long *cursor = nullptr;
+	uint64_t cap_chunks = 0;
+	int stride = 0;
+};
+static ApOut ap_out(const ApBuf &B) { return ApOut{B.cursor, B.cap_chunks, B.fill}; }
+// room for `records` records of `stride` words (a closed chunk holds more than AP_CH - 64 records, every wave has one open chunk)
+static int ap_alloc(Scratch &S, const GraphView &v, ApBuf &B, uint64_t records, int stride)
+{
+	B.cap_chunks = records / (AP_CH - 64) + 1 + (uint64_t)v.cu_count * 8 * (TPB / 64);
+	B.stride = stride;
+	GCHK(S.alloc(&B.chunks, B.cap_chunks * AP_CH * (size_t)stride * 8));
+	GCHK(S.alloc(&B.fill, (B.cap_chunks + 1) * 4)); GCHK(S.alloc(&B.off, (B.cap_chunks + 1) * 4)); GCHK(S.alloc(&B.cursor, 8));
+	GCHK(hipMemsetAsync(B.fill, 0, (B.cap_chunks + 1) * 4, v.stream));
+	GCHK(hipMemsetAsync(B.cursor, 0, 8, v.stream));
+	return SDT_OK;
+}
+static void ap_free(Scratch &S, ApBuf &B)
+{
+	(void)hipFree(S.release(B.chunks)); (void)hipFree(S.release(B.fill)); (void)hipFree(S.release(B.off)); (void)hipFree(S.release(B.cursor));
+	B = ApBuf();
+}
+// the records of chunks [0, n_chunks) packed in chunk order into a new array (the caller's Scratch owns it); *n_split = the records
+// of the chunks before split_chunk (what an earlier kernel wrote)
+static int ap_compact(Scratch &S, const GraphView &v, const ApBuf &B, uint64_t n_chunks, uint64_t split_chunk, uint64_t **out, uint64_t *n_out, uint64_t *n_split)
+{
+	if (n_chunks > B.cap_chunks) return fail(SDT_ESTATE, "records in chunks: %llu chunks taken, room for %llu", (unsigned long long)n_chunks, (unsigned long long)B.cap_chunks);
+	const int rc = exclusive_scan<uint32_t>(v, B.fill, B.off, n_chunks + 1);          // (fill[n_chunks] is 0: off[n_chunks] = all records)
+	if (rc != SDT_OK) return rc;
+	uint32_t tot = 0, spl = 0;
+	GCHK(hipMemcpy(&tot, B.off + n_chunks, 4, hipMemcpyDeviceToHost));
+	GCHK(hipMemcpy(&spl, B.off + (split_chunk < n_chunks ? split_chunk : n_chunks), 4, hipMemcpyDeviceToHost));
+	GCHK(S.alloc(out, ((size_t)tot + 1) * (size_t)B.stride * 8));
+	if (n_chunks) hipLaunchKernelGGL(k_ap_compact, dim3(sdti::scan_grid(v.cu_count, n_chunks * AP_CH)), dim3(256), 0, v.stream, B.chunks, B.fill, B.off,
+	                                 (unsigned long long)n_chunks, B.stride, *out);
+	GCHK(hipGetLastError());
+	*n_out = tot;
+	if (n_split) *n_split = spl;
+	return SDT_OK;
+}
 
 // ---- the whole layout on the device: sort, replay of the probing (fixed point per growth), numbering ---------------------
 #include <math.h>
@@ -250,22 +296,21 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	if (2 * qbits + RP_DEPTH_BITS > 64 || p >= 1024) return fail(SDT_ELIMIT, "layout on the device: twice %d slot bits do not fit the table word (or %d sets the list entry)", qbits, p);
 	tick("schedule made");
 	// ---- buffers
-	unsigned long long *tab[2], *d_time, *d_work, *d_list[2], *d_pre;
+	unsigned long long *tab[2], *d_time, *d_saved, *d_list[2], *d_pre;
 	uint32_t *d_home, *d_occ, *d_rank;
 	RpSet *d_sets;
-	unsigned int *d_flags, *d_dirty;
+	unsigned int *d_flags;
 	RpRound *d_round;
 	GCHK(S.alloc(&tab[0], (tab_total + 1) * 8)); GCHK(S.alloc(&tab[1], (tab_total + 1) * 8));
 	uint32_t *d_home_slot;
-	// per OLD slot of a growth: time and home; per entry: the work list of a round and the two lists of dirty clusters (a cluster is
-	// listed by one of its entries, an entry sits in one cluster); one dirty bit per new slot
-	const unsigned long long list_cap = m + 1;
-	GCHK(S.alloc(&d_time, (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4));
-	GCHK(S.alloc(&d_work, list_cap * 8)); GCHK(S.alloc(&d_list[0], list_cap * 8)); GCHK(S.alloc(&d_list[1], list_cap * 8));
-	GCHK(S.alloc(&d_dirty, (tab_total / 32 + 2) * 4)); GCHK(S.alloc(&d_round, sizeof(RpRound)));
+	// per OLD slot of a growth: time and home; per new slot: the word a round took out of it; per entry: the two lists of the rounds
+	// (an entry whose time changed is listed once)
+	// (sdt_append.cuh: the lists are written in chunks of AP_CH entries per wave, the open chunk of every wave has unused slots)
+	const unsigned long long list_chunks = (m + 1) / (AP_CH - 64) + 1 + (unsigned long long)v.cu_count * 8 * (TPB / 64), list_cap = list_chunks * AP_CH;
+	GCHK(S.alloc(&d_time, (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4)); GCHK(S.alloc(&d_saved, (tab_total + 1) * 8));
+	GCHK(S.alloc(&d_list[0], list_cap * 8)); GCHK(S.alloc(&d_list[1], list_cap * 8)); GCHK(S.alloc(&d_round, sizeof(RpRound)));
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
 	GCHK(hipMemsetAsync(tab[0], 0, (tab_total + 1) * 8, v.stream));
-	GCHK(hipMemsetAsync(d_dirty, 0, (tab_total / 32 + 2) * 4, v.stream));        // (every bit a round sets is cleared by the next one)
 	tick("buffers made");
 	std::vector<unsigned long long> pre(p + 1);
 	auto upload = [&](void) -> int {
@@ -309,8 +354,8 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 			GCHK(hipMemsetAsync(d_round, 0, sizeof(RpRound), v.stream));
 			// round 0: everybody
 			hipLaunchKernelGGL(k_rp_ins_all, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_round);
-			hipLaunchKernelGGL(k_rp_eval_all, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_dirty,
-			                   d_list[0], list_cap, d_round);
+			hipLaunchKernelGGL(k_rp_eval_all, grid(old_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[cur], tab[nxt], d_home_slot, d_time,
+			                   d_list[0], list_chunks, d_round);
 			GCHK(hipGetLastError());
 			// (SDT_RP_MAX_ROUNDS: test hook -- a cap that real data passes, so that the caller's other path is exercised)
 			static const int max_rounds = getenv("SDT_RP_MAX_ROUNDS") ? atoi(getenv("SDT_RP_MAX_ROUNDS")) : 60;
@@ -321,16 +366,16 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 				GCHK(hipStreamSynchronize(v.stream));
 				total_rounds++;
 				if (h_round.flags) return fail(SDT_ELIMIT, "layout on the device: %s", (h_round.flags & 2u) ? "an insertion found no slot" :
-				                               (h_round.flags & 4u) ? "an eviction chain or a cluster past its field" : "a list of the rounds is full");
+				                               (h_round.flags & 4u) ? "an eviction chain or a stretch of slots past its field" : "the list of a round is full");
 				if (!h_round.n_next) break;
 				if (round >= max_rounds) return fail(SDT_ELIMIT, "layout on the device: a growth did not settle in %d rounds", max_rounds);
-				// the clusters that hold a changed entry: taken apart, laid out again, their old slots evaluated again
-				const unsigned long long n_list = h_round.n_next;
+				// from the home of every changed entry to the end of its cluster: taken out, laid out again, the old slots in there evaluated again
+				const unsigned long long n_list = h_round.n_next * AP_CH;
 				GCHK(hipMemsetAsync(d_round, 0, sizeof(RpRound), v.stream));
-				hipLaunchKernelGGL(k_rp_collect, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[nxt], d_dirty, d_list[lc], n_list, d_work, list_cap, d_round);
-				hipLaunchKernelGGL(k_rp_ins_list, grid(n_list * 4), dim3(TPB), 0, v.stream, d_sets, d_pre, p, qbits, tab[nxt], d_home_slot, d_time, d_work, d_round);
-				hipLaunchKernelGGL(k_rp_eval_list, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[cur], tab[nxt], d_home_slot, d_time, d_dirty,
-				                   d_list[lc], n_list, d_list[lc ^ 1], list_cap, d_round);
+				hipLaunchKernelGGL(k_rp_collect, grid(n_list), dim3(TPB), 0, v.stream, d_sets, tab[nxt], d_saved, d_list[lc], n_list, d_round);
+				hipLaunchKernelGGL(k_rp_ins_list, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[nxt], d_saved, d_home_slot, d_time, d_list[lc], n_list, d_round);
+				hipLaunchKernelGGL(k_rp_eval_list, grid(n_list), dim3(TPB), 0, v.stream, d_sets, d_pre, qbits, tab[cur], tab[nxt], d_home_slot, d_time,
+				                   d_list[lc], n_list, d_list[lc ^ 1], list_chunks, d_round);
 				GCHK(hipGetLastError());
 				lc ^= 1;
 			}
@@ -390,7 +435,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	rc = upload(); if (rc != SDT_OK) return rc;
 	// (the buffers of the replay that are free now make room for the flags and their prefix sum)
 	(void)hipFree(S.release(tab[cur ^ 1])); (void)hipFree(S.release(d_time)); (void)hipFree(S.release(d_home_slot));
-	(void)hipFree(S.release(d_work)); (void)hipFree(S.release(d_list[0])); (void)hipFree(S.release(d_list[1]));
+	(void)hipFree(S.release(d_saved)); (void)hipFree(S.release(d_list[0])); (void)hipFree(S.release(d_list[1]));
 	uint64_t *d_order;
 	GCHK(S.alloc(&d_occ, (slot_total + 1) * 4)); GCHK(S.alloc(&d_rank, (slot_total + 1) * 4)); GCHK(S.alloc(&d_order, m * 8));
 	hipLaunchKernelGGL(k_rp_slots, grid(slot_total), dim3(TPB), 0, v.stream, d_sets, d_pre, p, 1, qbits, (const unsigned long long *)nullptr, tab[cur], d_occ);
@@ -626,18 +671,27 @@ int sdt_gpu_tip_walks_labelled(sdt_ctx *c, int thin, int cut_len, uint64_t *n_re
 	const int g = sdti::scan_grid(v.cu_count, v.slots);
 	uint64_t cap = nn / 8 + 4096;
 	uint64_t *d_rec = nullptr;
+	ApBuf B;
 	for (int attempt = 0; attempt < 2; attempt++) {
-		GCHK(S.alloc(&d_rec, cap * 3 * 8));
-		GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
-		LAUNCH_NW(v, k_tip_walks, g, *v.d_idx, v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, d_rec, (unsigned long long)cap, d_cur, 3);
+		int rc = ap_alloc(S, v, B, cap, 3);
+		if (rc != SDT_OK) return rc;
+		LAUNCH_NW(v, k_tip_walks, g, *v.d_idx, v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, B.chunks, 0ULL, (unsigned long long *)nullptr, 3, ap_out(B));
 		GCHK(hipGetLastError());
-		GCHK(hipMemcpyAsync(&h, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
-		const int rc = sdti::sync_stats(c);
+		GCHK(hipMemcpyAsync(&h, B.cursor, 8, hipMemcpyDeviceToHost, v.stream));
+		rc = sdti::sync_stats(c);
 		if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: %llu walks left the graph", (unsigned long long)v.h_stats->probe_fail);
-		if (h <= cap) break;
+		if (h <= B.cap_chunks) break;
 		if (attempt) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: the number of walks changed between two runs");
-		(void)hipFree(S.release(d_rec));
-		cap = h;
+		ap_free(S, B);
+		cap = h * AP_CH;
+	}
+	{
+		uint64_t n_rec = 0;
+		const int rc = ap_compact(S, v, B, h, h, &d_rec, &n_rec, nullptr);
+		if (rc != SDT_OK) return rc;
+		GCHK(hipStreamSynchronize(v.stream));
+		ap_free(S, B);
+		h = n_rec;
 	}
 	// components: removeSingleTips -- tip and end node of every walk; removeMinorTips -- the chains a walk can cross
 	if (thin) {
@@ -672,23 +726,33 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	const int g = sdti::scan_grid(v.cu_count, v.slots);
 	uint64_t cap = nn / 6 + 4096;
 	uint64_t *d_rec = nullptr;
+	ApBuf B;
 	for (int attempt = 0; attempt < 2; attempt++) {
-		GCHK(S.alloc(&d_rec, cap * 14 * 8));
+		int rc = ap_alloc(S, v, B, cap, 14);
+		if (rc != SDT_OK) return rc;
 		GCHK(hipMemsetAsync(d_need, 0, nn + 1, v.stream));
 		GCHK(hipMemsetAsync(d_flag, 0, nn + 1, v.stream));
-		GCHK(hipMemsetAsync(d_cur, 0, 8, v.stream));
-		LAUNCH_NW(v, k_minor_out_junctions, g, *v.d_idx, v.K, threshold, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 14);
+		LAUNCH_NW(v, k_minor_out_junctions, g, *v.d_idx, v.K, threshold, d_need, d_flag, B.chunks, 0ULL, (unsigned long long *)nullptr, v.d_stats, 14, ap_out(B));
 		GCHK(hipGetLastError());
-		GCHK(hipMemcpyAsync(&h1, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
-		LAUNCH_NW(v, k_minor_out_candidates, g, *v.d_idx, v.K, d_need, d_flag, d_rec, (unsigned long long)cap, d_cur, v.d_stats, 14);
+		GCHK(hipMemcpyAsync(&h1, B.cursor, 8, hipMemcpyDeviceToHost, v.stream));
+		LAUNCH_NW(v, k_minor_out_candidates, g, *v.d_idx, v.K, d_need, d_flag, B.chunks, 0ULL, (unsigned long long *)nullptr, v.d_stats, 14, ap_out(B));
 		GCHK(hipGetLastError());
-		GCHK(hipMemcpyAsync(&h2, d_cur, 8, hipMemcpyDeviceToHost, v.stream));
-		const int rc = sdti::sync_stats(c);
+		GCHK(hipMemcpyAsync(&h2, B.cursor, 8, hipMemcpyDeviceToHost, v.stream));
+		rc = sdti::sync_stats(c);
 		if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_minor_out_labelled: %llu links point at k-mers that are not nodes", (unsigned long long)v.h_stats->probe_fail);
-		if (h2 <= cap) break;
+		if (h2 <= B.cap_chunks) break;
 		if (attempt) return fail(SDT_ESTATE, "sdt_gpu_minor_out_labelled: the number of records changed between two runs");
-		(void)hipFree(S.release(d_rec));
-		cap = h2;
+		ap_free(S, B);
+		cap = h2 * AP_CH;
+	}
+	{
+		// (h1, h2 are chunk counts so far: the junctions' chunks come first, packing keeps the chunk order)
+		uint64_t n_rec = 0, n_junc = 0;
+		const int rc = ap_compact(S, v, B, h2, h1, &d_rec, &n_rec, &n_junc);
+		if (rc != SDT_OK) return rc;
+		GCHK(hipStreamSynchronize(v.stream));
+		ap_free(S, B);
+		h1 = n_junc; h2 = n_rec;
 	}
 	// a visit reads and writes its junction, the junction's neighbours and the neighbours of those it may cut: unite every record's
 	// node with its eight neighbours (junction records and the records of the neighbours to cut alike)

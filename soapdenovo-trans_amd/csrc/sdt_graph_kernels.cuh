@@ -87,8 +87,11 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
                                                    uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
                                                    uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
-                                                   unsigned long long *cursor = nullptr, int rec_stride = 2)
+                                                   unsigned long long *cursor = nullptr, int rec_stride = 2, ApOut ap = ApOut{nullptr, 0, nullptr})
 {
+	// (ap.cursor set: the records go out in chunks per wave, sdt_append.cuh -- rec is the chunk storage then; else one dense array)
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
 	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
@@ -157,13 +160,16 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
 			end_out[me] = idx[os];
 			info_out[me] = (uint8_t)inf;
 		} else {                                             // compact: only the nodes that have a walk, in any order
-			const unsigned long long r = atomicAdd(cursor, 1ULL);
-			if (r < max_rec) {
+			unsigned long long r;
+			if (ap.cursor) r = ap_append(s_app, ap);
+			else { r = atomicAdd(cursor, 1ULL); if (r >= max_rec) r = AP_NONE; }
+			if (r != AP_NONE) {
 				rec[rec_stride * r] = me | ((uint64_t)inf << 56);
 				rec[rec_stride * r + 1] = idx[os];
 			}
 		}
 	}
+	if (ap.cursor) ap_finish(s_app, ap);
 	if (missing)
 		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
@@ -217,8 +223,10 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, double threshold,
                                                              uint8_t *__restrict__ need, uint8_t *__restrict__ flagged,
                                                              uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
-                                                             Stats *stats, int rec_stride = 9)
+                                                             Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr})
 {
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
 	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
@@ -257,8 +265,10 @@ __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, cons
 		if (!any) continue;
 		const uint64_t me = idx[s];
 		flagged[me] = 1;
-		const unsigned long long r = atomicAdd(cursor, 1ULL);
-		if (r < max_rec) {
+		unsigned long long r;
+		if (ap.cursor) r = ap_append(s_app, ap);
+		else { r = atomicAdd(cursor, 1ULL); if (r >= max_rec) r = AP_NONE; }
+		if (r != AP_NONE) {
 			rec[r * rec_stride] = me;
 #pragma unroll
 			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, cons
 			}
 		}
 	}
+	if (ap.cursor) ap_finish(s_app, ap);
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
 
@@ -276,8 +287,10 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, const uint64_t *__restrict__ idx, int K,
                                                               const uint8_t *__restrict__ need, const uint8_t *__restrict__ flagged,
                                                               uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
-                                                              Stats *stats, int rec_stride = 9)
+                                                              Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr})
 {
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
 	const uint64_t slots = tbl.slots();
 	Key<NW> mask;
 #pragma unroll
@@ -294,8 +307,10 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
 		uint64_t nb[8];
 		uint32_t cnt[8];
 		neighbours_of<NW>(tbl, idx, e, K, mask, nb, cnt, missing);
-		const unsigned long long r = atomicAdd(cursor, 1ULL);
-		if (r < max_rec) {
+		unsigned long long r;
+		if (ap.cursor) r = ap_append(s_app, ap);
+		else { r = atomicAdd(cursor, 1ULL); if (r >= max_rec) r = AP_NONE; }
+		if (r != AP_NONE) {
 			rec[r * rec_stride] = me;
 #pragma unroll
 			for (int q = 0; q < 8; q++) rec[r * rec_stride + 1 + q] = nb[q];
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, con
 			}
 		}
 	}
+	if (ap.cursor) ap_finish(s_app, ap);
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
 
@@ -1226,18 +1242,19 @@ __global__ __launch_bounds__(TPB) void k_rp_rehash_init(const uint64_t *__restri
 }
 
 //   The rounds of a growth (table word here: time << qbits | q + 1, q = the entry's OLD slot; home and time are per old slot).
-//   The set of occupied slots of a linear-probing table does not depend on the order of insertion, so the CLUSTERS of the new
-//   table (maximal runs of occupied slots) are the same in every round, and an entry whose time changed can only re-arrange the
-//   cluster it sits in.  Round 0 is full (k_rp_ins_all, k_rp_eval_all); every later round takes the clusters that hold a changed
-//   entry apart (k_rp_collect), re-inserts their entries with the new times (k_rp_ins_list) and re-evaluates the old slots that
-//   lie inside them (k_rp_eval_list: an evaluation depends on the word at the entry's old slot and on its own time only, and is
-//   idempotent) -- 0.7 of one full round in all instead of 15-20 full rounds (tools/replay_fixed_point.c, table C).
-//   List entry of a dirty cluster: set << 54 | length << 32 | first slot.
+//   The set of occupied slots of a linear-probing table does not depend on the order of insertion, and the word at slot i depends on
+//   the entries with a home at or before i only (probing goes forward): an entry of home h whose time changed can re-arrange the slots
+//   from h to the end of its cluster (the next empty slot) and nothing else.  Round 0 is full (k_rp_ins_all, k_rp_eval_all); every later
+//   round takes those stretches out of the table (k_rp_collect: walkers that meet share the work -- whoever empties a slot goes on to
+//   the next one, so every slot up to the end of the cluster is taken exactly once), re-inserts their entries with the new times
+//   (k_rp_ins_list: an entry of an earlier home passes over the untouched slots before h, all of them hold earlier entries) and
+//   re-evaluates the old slots that lie inside them (k_rp_eval_list: an evaluation depends on the word at the entry's old slot and on
+//   its own time only, and is idempotent) -- about half of one full round in all instead of 15-20 full rounds (tools/replay_fixed_point.c,
+//   table C).  List entry: set << 54 | length taken << 32 | first slot.
 constexpr int RP_LEN_BITS = 22;
 struct RpRound {
-	unsigned long long n_next;       // clusters in the list this round writes
-	unsigned long long n_work;       // entries taken out of the clusters of this round
-	unsigned int flags;              // 2 = an insertion found no slot, 4 = chain or cluster past its field, 8 = a list is full
+	unsigned long long n_next;       // CHUNKS of the list this round writes (sdt_append.cuh: unused slots are marked AP_NONE)
+	unsigned int flags;              // 2 = an insertion found no slot, 4 = chain or stretch past its field, 8 = the list is full
 	unsigned int pad;
 };
 
@@ -1255,109 +1272,109 @@ __global__ __launch_bounds__(TPB) void k_rp_ins_all(const RpSet *__restrict__ se
 	}
 }
 
-// next time of the entry of old slot q (g = its index over all sets) from the layout; a change marks the entry's cluster
+// next time of the entry of old slot q (g = its index over all sets) from the layout; a change lists the entry's home
 __device__ inline void rp_eval(const RpSet &S, int s, unsigned long long g, unsigned long long q, int qbits, const unsigned long long *tnew,
-                               const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
-                               unsigned long long *next_list, unsigned long long cap, RpRound *st)
+                               const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned long long *next_list, WaveApp *app,
+                               const ApOut &out, RpRound *st)
 {
-	const unsigned long long *T = tnew + S.tab0;
-	const unsigned long long w = T[q], x = w & ((1ULL << qbits) - 1ULL), tx = w >> qbits, mine = t[g], scan = q << RP_DEPTH_BITS;
+	const unsigned long long w = tnew[S.tab0 + q], x = w & ((1ULL << qbits) - 1ULL), tx = w >> qbits, mine = t[g], scan = q << RP_DEPTH_BITS;
 	unsigned long long nt = scan;
 	if (x == q + 1ULL) nt = mine;                                  // it sits on its own old slot: nobody took it (leave the time alone)
 	else if (w && tx < scan) nt = tx + 1ULL;                       // the slot was taken before the scan reached it: carried on at once
 	if (nt == mine) return;
 	if ((nt & ((1ULL << RP_DEPTH_BITS) - 1ULL)) == (1ULL << RP_DEPTH_BITS) - 1ULL) atomicOr(&st->flags, 4u);      // chain too deep for the field
 	t[g] = nt;
-	uint32_t a = home_slot[g];                                     // back from the home to the first slot of the cluster
-	for (uint32_t steps = 0; steps < S.size; steps++) {
-		const uint32_t b = a ? a - 1u : S.size - 1u;
-		if (T[b] == 0) break;
-		a = b;
-	}
-	const unsigned long long bit = S.tab0 + a;
-	const unsigned int m = 1u << (bit & 31u);
-	if (!(atomicOr(dirty + (bit >> 5), m) & m)) {
-		const unsigned long long k = atomicAdd(&st->n_next, 1ULL);
-		if (k < cap) next_list[k] = ((unsigned long long)s << (32 + RP_LEN_BITS)) | a;
-		else atomicOr(&st->flags, 8u);
-	}
+	const unsigned long long k = ap_append(app, out);
+	if (k != AP_NONE) next_list[k] = ((unsigned long long)s << (32 + RP_LEN_BITS)) | home_slot[g];
+	else atomicOr(&st->flags, 8u);
 }
 
 __global__ __launch_bounds__(TPB) void k_rp_eval_all(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int qbits,
                                                      const unsigned long long *__restrict__ told, const unsigned long long *tnew,
-                                                     const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
-                                                     unsigned long long *next_list, unsigned long long cap, RpRound *st)
+                                                     const uint32_t *__restrict__ home_slot, unsigned long long *t,
+                                                     unsigned long long *next_list, unsigned long long cap_chunks, RpRound *st)
 {
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
+	const ApOut out = {&st->n_next, cap_chunks, nullptr};
 	const unsigned long long total = pre[p];
 	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
 		const int s = rp_find_set(pre, p, g);
 		const RpSet S = sets[s];
 		const unsigned long long q = g - pre[s];
 		if (!told[S.tab0 + q]) continue;
-		rp_eval(S, s, g, q, qbits, tnew, home_slot, t, dirty, next_list, cap, st);
+		rp_eval(S, s, g, q, qbits, tnew, home_slot, t, next_list, s_app, out, st);
 	}
+	ap_finish_mark(s_app, out, next_list);
 }
 
-// take the listed clusters apart: their entries (as indices over the old slots of all sets) go to the work list, the slots are cleared
-__global__ __launch_bounds__(TPB) void k_rp_collect(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
-                                                    unsigned long long *tnew, unsigned int *dirty, unsigned long long *list, unsigned long long n_list,
-                                                    unsigned long long *work, unsigned long long cap, RpRound *st)
+// take the listed stretches out of the table: the words go to saved[] (same index as the slot), the slots are emptied
+__global__ __launch_bounds__(TPB) void k_rp_collect(const RpSet *__restrict__ sets, unsigned long long *tnew, unsigned long long *__restrict__ saved,
+                                                    unsigned long long *list, unsigned long long n_list, RpRound *st)
 {
-	const unsigned long long qmask = (1ULL << qbits) - 1ULL;
 	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
 		const unsigned long long e = list[k];
-		const int s = (int)(e >> (32 + RP_LEN_BITS));
-		const uint32_t a = (uint32_t)e;
-		const RpSet S = sets[s];
+		if (e == AP_NONE) continue;
+		const RpSet S = sets[(int)(e >> (32 + RP_LEN_BITS))];
 		unsigned long long *T = tnew + S.tab0;
-		const unsigned long long bit = S.tab0 + a;
-		atomicAnd(dirty + (bit >> 5), ~(1u << (bit & 31u)));
-		uint32_t len = 0, i = a;
-		while (len < S.size && T[i] != 0) { len++; i = i + 1u == S.size ? 0u : i + 1u; }
-		if (len >= (1u << RP_LEN_BITS)) { atomicOr(&st->flags, 4u); continue; }
-		const unsigned long long base = atomicAdd(&st->n_work, (unsigned long long)len);
-		if (base + len > cap) { atomicOr(&st->flags, 8u); continue; }
-		i = a;
-		for (uint32_t j = 0; j < len; j++) {
-			work[base + j] = pre[s] + (T[i] & qmask) - 1ULL;
-			T[i] = 0;
+		uint32_t len = 0, i = (uint32_t)e;
+		while (len < S.size) {
+			if (__hip_atomic_load(T + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;      // (the end, or a walker ahead of this one)
+			const unsigned long long w = atomicExch(T + i, 0ULL);
+			if (w == 0) break;
+			saved[S.tab0 + i] = w;
+			len++;
 			i = i + 1u == S.size ? 0u : i + 1u;
 		}
+		if (len >= (1u << RP_LEN_BITS)) { atomicOr(&st->flags, 4u); len = 0; }
 		list[k] = e | ((unsigned long long)len << 32);
 	}
 }
 
-__global__ __launch_bounds__(TPB) void k_rp_ins_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int p, int qbits,
-                                                     unsigned long long *tnew, const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t,
-                                                     const unsigned long long *__restrict__ work, RpRound *st)
+__global__ __launch_bounds__(TPB) void k_rp_ins_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
+                                                     unsigned long long *tnew, const unsigned long long *__restrict__ saved,
+                                                     const uint32_t *__restrict__ home_slot, const unsigned long long *__restrict__ t,
+                                                     const unsigned long long *__restrict__ list, unsigned long long n_list, RpRound *st)
 {
-	const unsigned long long total = st->n_work;
-	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < total; k += (unsigned long long)gridDim.x * TPB) {
-		const unsigned long long g = work[k];
-		const int s = rp_find_set(pre, p, g);
-		const RpSet S = sets[s];
-		if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t[g] << qbits) | (g - pre[s] + 1ULL))) atomicOr(&st->flags, 2u);
-	}
-}
-
-// the old slots inside the re-arranged clusters are the only ones whose evaluation can have changed
-__global__ __launch_bounds__(TPB) void k_rp_eval_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
-                                                      const unsigned long long *__restrict__ told, const unsigned long long *tnew,
-                                                      const uint32_t *__restrict__ home_slot, unsigned long long *t, unsigned int *dirty,
-                                                      const unsigned long long *__restrict__ list, unsigned long long n_list,
-                                                      unsigned long long *next_list, unsigned long long cap, RpRound *st)
-{
+	const unsigned long long qmask = (1ULL << qbits) - 1ULL;
 	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
 		const unsigned long long e = list[k];
+		if (e == AP_NONE) continue;
 		const int s = (int)(e >> (32 + RP_LEN_BITS));
 		const uint32_t len = (uint32_t)(e >> 32) & ((1u << RP_LEN_BITS) - 1u);
 		const RpSet S = sets[s];
 		uint32_t i = (uint32_t)e;
 		for (uint32_t j = 0; j < len; j++) {
-			if (i < S.old_size && told[S.tab0 + i]) rp_eval(S, s, pre[s] + i, i, qbits, tnew, home_slot, t, dirty, next_list, cap, st);
+			const unsigned long long q1 = saved[S.tab0 + i] & qmask, g = pre[s] + q1 - 1ULL;
+			if (!rp_insert(tnew + S.tab0, S.size, home_slot[g], (t[g] << qbits) | q1)) atomicOr(&st->flags, 2u);
 			i = i + 1u == S.size ? 0u : i + 1u;
 		}
 	}
+}
+
+// the old slots inside the re-arranged stretches are the only ones whose evaluation can have changed
+__global__ __launch_bounds__(TPB) void k_rp_eval_list(const RpSet *__restrict__ sets, const unsigned long long *__restrict__ pre, int qbits,
+                                                      const unsigned long long *__restrict__ told, const unsigned long long *tnew,
+                                                      const uint32_t *__restrict__ home_slot, unsigned long long *t,
+                                                      const unsigned long long *__restrict__ list, unsigned long long n_list,
+                                                      unsigned long long *next_list, unsigned long long cap_chunks, RpRound *st)
+{
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
+	const ApOut out = {&st->n_next, cap_chunks, nullptr};
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long e = list[k];
+		if (e == AP_NONE) continue;
+		const int s = (int)(e >> (32 + RP_LEN_BITS));
+		const uint32_t len = (uint32_t)(e >> 32) & ((1u << RP_LEN_BITS) - 1u);
+		const RpSet S = sets[s];
+		uint32_t i = (uint32_t)e;
+		for (uint32_t j = 0; j < len; j++) {
+			if (i < S.old_size && told[S.tab0 + i]) rp_eval(S, s, pre[s] + i, i, qbits, tnew, home_slot, t, next_list, s_app, out, st);
+			i = i + 1u == S.size ? 0u : i + 1u;
+		}
+	}
+	ap_finish_mark(s_app, out, next_list);
 }
 
 // over the NEW slots (pre = exclusive prefix of size): mode 0 = after a growth: the old slot in the word -> the entry (id + 1, from the

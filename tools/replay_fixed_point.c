@@ -7,9 +7,11 @@
 // round is a priority insertion (parallel, order independent): this is what sdt_gpu_layout_on_device runs (csrc/sdt_graph_kernels.cuh).
 // Third table C: the same fixed point with INCREMENTAL rounds, as the device runs it since round 5.  The set of occupied slots of a
 // linear-probing table does not depend on the order of insertion, so the clusters (maximal runs of occupied slots) of the new table
-// are the same in every round and an entry whose time changed can only re-arrange ITS cluster: after the first full round, a round
-// takes the clusters that hold a changed entry apart, re-inserts their entries with the new times, and re-evaluates only the old slots
-// that lie inside those clusters (the evaluation is idempotent: f(w, f(w, t)) = f(w, t)).  About 0.7 of one full round in all.
+// are the same in every round, and the word at slot i depends on the entries with a home at or before i only: an entry of home h
+// whose time changed can only re-arrange the slots from h to the end of its cluster.  After the first full round, a round takes those
+// stretches out (a walker stops at a slot another one emptied: that one goes on), re-inserts their entries with the new times, and
+// re-evaluates only the old slots that lie inside them (the evaluation is idempotent: f(w, f(w, t)) = f(w, t)).  About 0.5 of one
+// full round in all.
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -63,12 +65,12 @@ int main(int argc,char**argv){
       { const uint64_t D=6; memset(CW,0,n*8); uint64_t nA=0,nB=0,nW=0; int r2=0;
         #define INS(q_) do{ uint64_t w_=(ct[q_]<<32)|((q_)+1), h_=ch[q_]; for(;;){ uint64_t c_=CW[h_]; if(!c_){CW[h_]=w_;break;} if(c_>w_){CW[h_]=w_;w_=c_;} h_=h_+1==n?0:h_+1; } }while(0)
         #define EVAL(q_) do{ uint64_t w_=CW[q_], x_=w_&0xFFFFFFFFu, tx_=w_>>32, mine_=ct[q_], scan_=(uint64_t)(q_)<<D, nt_=scan_; if(x_==(q_)+1)nt_=mine_; else if(w_&&tx_<scan_)nt_=tx_+1; \
-            if(nt_!=mine_){ ct[q_]=nt_; uint64_t a_=ch[q_]; while(CW[a_?a_-1:n-1])a_=a_?a_-1:n-1; if(!dirty[a_]){dirty[a_]=1;LB[nB++]=a_;} } }while(0)
+            if(nt_!=mine_){ ct[q_]=nt_; LB[nB++]=ch[q_]; } }while(0)
         for(uint64_t q=0;q<old;q++) if(C[q]){ ct[q]=q<<D; ch[q]=keys[C[q]-1]%n; }
         for(uint64_t q=0;q<old;q++) if(C[q]){ INS(q); full_ins++; }
         for(uint64_t q=0;q<old;q++) if(C[q]) EVAL(q);
         while(nB){ r2++; memcpy(LA,LB,nB*8); nA=nB; nB=0; nW=0;
-          for(uint64_t k=0;k<nA;k++){ uint64_t i=LA[k],len=0; dirty[i]=0; while(CW[i]){ LW[nW++]=(CW[i]&0xFFFFFFFFu)-1; CW[i]=0; i=i+1==n?0:i+1; len++; } LA[k]|=len<<40; }
+          for(uint64_t k=0;k<nA;k++){ uint64_t i=LA[k],len=0; while(CW[i]){ LW[nW++]=(CW[i]&0xFFFFFFFFu)-1; CW[i]=0; i=i+1==n?0:i+1; len++; } LA[k]|=len<<40; }
           for(uint64_t k=0;k<nW;k++){ INS(LW[k]); inc_ins++; }
           for(uint64_t k=0;k<nA;k++){ uint64_t i=LA[k]&0xFFFFFFFFFFULL,len=LA[k]>>40; for(uint64_t j=0;j<len;j++){ if(i<old&&C[i]){ EVAL(i); inc_eval++; } i=i+1==n?0:i+1; } }
           if(r2>300){printf("incremental: no convergence\n");return 1;} }
