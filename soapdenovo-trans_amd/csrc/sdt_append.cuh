@@ -26,7 +26,8 @@ struct WaveApp {                       // one per wave of the workgroup, in LDS
 struct ApOut {
 	unsigned long long *cursor;        // chunks taken so far (keeps counting past cap_chunks: the caller retries with that many)
 	unsigned long long cap_chunks;
-	uint32_t *fill;                    // per chunk: slots in use (nullptr: the caller marks the holes instead)
+	uint32_t *fill;                    // per chunk: slots in use (records that are packed afterwards), or nullptr
+	unsigned long long *mark;          // ... or the list itself: its unused slots are set to AP_NONE (single words, readers skip them)
 };
 
 __device__ inline void ap_init(WaveApp *app)          // every lane, first thing in the kernel (app: TPB / 64 entries in LDS)
@@ -50,7 +51,10 @@ __device__ inline unsigned long long ap_append(WaveApp *app, const ApOut &o)
 		uint32_t used = a->used;
 		unsigned long long chunk = a->chunk;
 		if (used + n > AP_CH) {
-			if (o.fill && chunk < o.cap_chunks) o.fill[chunk] = used;
+			if (chunk < o.cap_chunks) {                    // (a chunk is closed with up to 63 slots to spare)
+				if (o.fill) o.fill[chunk] = used;
+				if (o.mark) for (uint32_t j = used; j < AP_CH; j++) o.mark[chunk * AP_CH + j] = AP_NONE;
+			}
 			chunk = atomicAdd(o.cursor, 1ULL);
 			used = 0;
 			a->chunk = chunk;
@@ -70,16 +74,42 @@ __device__ inline void ap_finish(WaveApp *app, const ApOut &o)
 }
 
 // ... or, for a list of single words: the unused slots of the wave's open chunk are marked AP_NONE
-__device__ inline void ap_finish_mark(WaveApp *app, const ApOut &o, unsigned long long *list)
+__device__ inline void ap_finish_mark(WaveApp *app, const ApOut &o)
 {
 	volatile WaveApp *a = app + (threadIdx.x >> 6);
 	const unsigned long long chunk = a->chunk;
-	if (chunk >= o.cap_chunks) return;
-	for (uint32_t j = a->used + (threadIdx.x & 63u); j < AP_CH; j += 64u) list[chunk * AP_CH + j] = AP_NONE;
+	if (chunk >= o.cap_chunks || !o.mark) return;
+	for (uint32_t j = a->used + (threadIdx.x & 63u); j < AP_CH; j += 64u) o.mark[chunk * AP_CH + j] = AP_NONE;
+}
+
+// Dense output when EVERY thread of the workgroup takes part (a scan loop whose bounds depend on the workgroup only): each thread says
+// how many slots it wants for its next few items, the workgroup makes ONE reservation.  Returns the thread's first slot.
+// scratch: 1 + blockDim.x / 64 words of LDS.
+__device__ inline unsigned long long ap_block_reserve(uint32_t mine, unsigned long long *cursor, unsigned long long *scratch)
+{
+	const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+	uint32_t inc = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(inc, d);
+		if (lane >= d) inc += o;
+	}
+	__syncthreads();                                   // (the scratch of the call before has been read)
+	if (lane == 63) scratch[1 + wave] = inc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long tot = 0;
+		for (unsigned w = 0; w < (blockDim.x >> 6); w++) tot += scratch[1 + w];
+		scratch[0] = tot ? atomicAdd(cursor, tot) : 0ULL;
+	}
+	__syncthreads();
+	unsigned long long at = scratch[0] + (inc - mine);
+	for (int w = 0; w < wave; w++) at += scratch[1 + w];
+	return at;
 }
 
 // records of `stride` words: chunk c's first fill[c] slots go to out[off[c] ...] (off = exclusive scan of fill)
-__global__ __launch_bounds__(256) void k_ap_compact(const uint64_t *__restrict__ chunks, const uint32_t *__restrict__ fill, const uint32_t *__restrict__ off,
+static __global__ __launch_bounds__(256) void k_ap_compact(const uint64_t *__restrict__ chunks, const uint32_t *__restrict__ fill, const uint32_t *__restrict__ off,
                                                     unsigned long long n_chunks, int stride, uint64_t *__restrict__ out)
 {
 	const unsigned long long total = n_chunks * AP_CH;

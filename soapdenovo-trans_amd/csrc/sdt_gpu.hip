@@ -404,6 +404,7 @@ __global__ __launch_bounds__(TPB) void k_import_paths(Table<NW> tbl, const uint6
 #include "sdt_shard_plan.h"
 #include "sdt_count_plan.h"
 static_assert(SHARD_NB1 == SK_NB1, "the exchange plan and the pipeline agree about the level-1 buckets");
+#include "sdt_append.cuh"
 #include "sdt_map_kernels.cuh"
 #include "sdt_ctg_kernels.cuh"
 
@@ -658,14 +659,7 @@ static uint64_t view_slots(const sdt_ctx *c) { return c->bm.tab.valid ? c->bm.ta
 
 static size_t entry_bytes(int nw) { return nw == 1 ? sizeof(Entry<1>) : nw == 2 ? sizeof(Entry<2>) : sizeof(Entry<4>); }
 
-static int scan_grid(const sdt_ctx *c, uint64_t items)
-{
-	uint64_t blocks = (items + TPB - 1) / TPB;
-	const uint64_t cap = (uint64_t)c->cu_count * 8;
-	if (blocks > cap) blocks = cap;
-	if (blocks < 1) blocks = 1;
-	return (int)blocks;
-}
+static int scan_grid(const sdt_ctx *c, uint64_t items) { return sdti::scan_grid(c->cu_count, items); }
 
 static int launch_clear(sdt_ctx *c, void *ent, uint32_t *aux, uint64_t *first, uint64_t slots)
 {

@@ -148,7 +148,7 @@ struct ApBuf {
 	uint64_t cap_chunks = 0;
 	int stride = 0;
 };
-static ApOut ap_out(const ApBuf &B) { return ApOut{B.cursor, B.cap_chunks, B.fill}; }
+static ApOut ap_out(const ApBuf &B) { return ApOut{B.cursor, B.cap_chunks, B.fill, nullptr}; }
 // room for `records` records of `stride` words (a closed chunk holds more than AP_CH - 64 records, every wave has one open chunk)
 static int ap_alloc(Scratch &S, const GraphView &v, ApBuf &B, uint64_t records, int stride)
 {
@@ -1264,12 +1264,13 @@ int sdt_gpu_build_host_index(sdt_ctx *c, uint32_t *index, uint64_t index_slots)
 		else hipLaunchKernelGGL(k_build_host_index<4>, dim3(g), dim3(TPB), 0, v.stream, sdti::table_of<4>(v), (*v.d_idx), d_index, index_slots - 1);
 		e = hipGetLastError();
 	}
-	if (e == hipSuccess) e = hipMemcpyAsync(index, d_index, index_slots * sizeof(unsigned int), hipMemcpyDeviceToHost, v.stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(v.stream);
+	int rc = SDT_OK;
+	if (e == hipSuccess) rc = sdti::d2h_big(v.copy_stream, index, d_index, index_slots * sizeof(unsigned int));      // (pageable destination of gigabytes: staged copies)
 	(void)hipFree(d_index);
 	if (e != hipSuccess)
 		return fail(SDT_EHIP, "sdt_gpu_build_host_index: %s", hipGetErrorString(e));
-	return SDT_OK;
+	return rc;
 }
 
 int sdt_gpu_edge_ports(sdt_ctx *c, uint64_t *records, uint64_t max_records, uint64_t *n_records)

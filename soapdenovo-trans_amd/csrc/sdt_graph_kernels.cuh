@@ -87,7 +87,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
                                                    uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
                                                    uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
-                                                   unsigned long long *cursor = nullptr, int rec_stride = 2, ApOut ap = ApOut{nullptr, 0, nullptr})
+                                                   unsigned long long *cursor = nullptr, int rec_stride = 2, ApOut ap = ApOut{nullptr, 0, nullptr, nullptr})
 {
 	// (ap.cursor set: the records go out in chunks per wave, sdt_append.cuh -- rec is the chunk storage then; else one dense array)
 	__shared__ WaveApp s_app[TPB / 64];
@@ -223,7 +223,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_minor_out_junctions(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, double threshold,
                                                              uint8_t *__restrict__ need, uint8_t *__restrict__ flagged,
                                                              uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
-                                                             Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr})
+                                                             Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr, nullptr})
 {
 	__shared__ WaveApp s_app[TPB / 64];
 	ap_init(s_app);
@@ -287,7 +287,7 @@ template <int NW>
 __global__ __launch_bounds__(TPB) void k_minor_out_candidates(Table<NW> tbl, const uint64_t *__restrict__ idx, int K,
                                                               const uint8_t *__restrict__ need, const uint8_t *__restrict__ flagged,
                                                               uint64_t *__restrict__ rec, unsigned long long max_rec, unsigned long long *cursor,
-                                                              Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr})
+                                                              Stats *stats, int rec_stride = 9, ApOut ap = ApOut{nullptr, 0, nullptr, nullptr})
 {
 	__shared__ WaveApp s_app[TPB / 64];
 	ap_init(s_app);
@@ -458,10 +458,10 @@ __global__ __launch_bounds__(TPB) void k_layout_keys(Table<NW> tbl, uint32_t p, 
 {
 	__shared__ int32_t s_crc[256];
 	crc_table_to_lds(s_crc);
+	__shared__ unsigned long long s_res[1 + TPB / 64];
 	const uint64_t slots = tbl.slots();
-	const int lane = threadIdx.x & 63;
 	uint32_t bad = 0;
-	// eight slots per lane and ONE reservation per wave for all of them (the output order is free: the pairs are sorted next)
+	// eight slots per lane and ONE reservation per workgroup for all of them (the output order is free: the pairs are sorted next)
 	constexpr int IT = 8;
 	for (uint64_t base = blockIdx.x * (uint64_t)TPB * IT; base < slots; base += (uint64_t)gridDim.x * TPB * IT) {
 		uint32_t occ = 0;
@@ -470,17 +470,7 @@ __global__ __launch_bounds__(TPB) void k_layout_keys(Table<NW> tbl, uint32_t p, 
 			const uint64_t s = base + (uint64_t)j * TPB + threadIdx.x;
 			if (s < slots && tbl.ent[s].key[0] != KEY_EMPTY) occ |= 1u << j;
 		}
-		const uint32_t mine = __popc(occ);
-		uint32_t inc = mine;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t o = __shfl_up(inc, d);
-			if (lane >= d) inc += o;
-		}
-		const uint32_t total = __shfl(inc, 63);
-		unsigned long long pos = 0;
-		if (lane == 0 && total) pos = atomicAdd(cursor, (unsigned long long)total);
-		pos = __shfl(pos, 0) + (inc - mine);
+		unsigned long long pos = ap_block_reserve(__popc(occ), cursor, s_res);
 		for (int j = 0; j < IT; j++) {
 			if (!((occ >> j) & 1u)) continue;
 			const uint64_t s = base + (uint64_t)j * TPB + threadIdx.x;
@@ -797,23 +787,28 @@ __global__ __launch_bounds__(TPB) void k_mo_emit(Table<NW> tbl, const uint64_t *
                                                  unsigned long long *cursor, uint64_t cap, uint64_t *__restrict__ node, uint32_t *__restrict__ l_links,
                                                  uint32_t *__restrict__ r_flags)
 {
-	const uint64_t nn64 = (nn + 63) & ~63ULL;                // (whole waves stay in the loop: the ballot needs every lane)
-	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < nn64; i += (uint64_t)gridDim.x * TPB) {
-		const bool d = i < nn && dirty[i];
-		const unsigned long long m = __ballot(d);            // one atomic per wave, not per node (62 M of them on one word took 120 ms)
-		if (!m) continue;
-		const int lane = threadIdx.x & 63;
-		unsigned long long base = 0;
-		if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-		base = __shfl(base, 0);
-		if (!d) continue;
-		const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
-		if (at >= cap) continue;
-		const uint64_t s = slot_of[i], v = tbl.ent[s].val;
-		const uint32_t a = tbl.aux[s];
-		node[at] = i;
-		l_links[at] = (uint32_t)(v & 0xFFFFFFu);
-		r_flags[at] = (uint32_t)((v >> 24) & 0xFFFFFFu) | ((a & AUX_LINEAR) ? 1u << 24 : 0u) | ((a & AUX_DELETED) ? 1u << 25 : 0u);
+	// eight nodes per lane, one reservation per workgroup (one per wave and iteration, 10.6 M on one word, took 126 ms of this kernel)
+	__shared__ unsigned long long s_res[1 + TPB / 64];
+	constexpr int IT = 8;
+	for (uint64_t base = blockIdx.x * (uint64_t)TPB * IT; base < nn; base += (uint64_t)gridDim.x * TPB * IT) {
+		uint32_t occ = 0;
+#pragma unroll
+		for (int j = 0; j < IT; j++) {
+			const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+			if (i < nn && dirty[i]) occ |= 1u << j;
+		}
+		unsigned long long at = ap_block_reserve(__popc(occ), cursor, s_res);
+		for (int j = 0; j < IT; j++) {
+			if (!((occ >> j) & 1u)) continue;
+			const uint64_t i = base + (uint64_t)j * TPB + threadIdx.x;
+			const unsigned long long mine = at++;
+			if (mine >= cap) continue;
+			const uint64_t s = slot_of[i], v = tbl.ent[s].val;
+			const uint32_t a = tbl.aux[s];
+			node[mine] = i;
+			l_links[mine] = (uint32_t)(v & 0xFFFFFFu);
+			r_flags[mine] = (uint32_t)((v >> 24) & 0xFFFFFFu) | ((a & AUX_LINEAR) ? 1u << 24 : 0u) | ((a & AUX_DELETED) ? 1u << 25 : 0u);
+		}
 	}
 }
 
@@ -1296,7 +1291,7 @@ __global__ __launch_bounds__(TPB) void k_rp_eval_all(const RpSet *__restrict__ s
 {
 	__shared__ WaveApp s_app[TPB / 64];
 	ap_init(s_app);
-	const ApOut out = {&st->n_next, cap_chunks, nullptr};
+	const ApOut out = {&st->n_next, cap_chunks, nullptr, next_list};
 	const unsigned long long total = pre[p];
 	for (unsigned long long g = blockIdx.x * (unsigned long long)TPB + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * TPB) {
 		const int s = rp_find_set(pre, p, g);
@@ -1305,7 +1300,7 @@ __global__ __launch_bounds__(TPB) void k_rp_eval_all(const RpSet *__restrict__ s
 		if (!told[S.tab0 + q]) continue;
 		rp_eval(S, s, g, q, qbits, tnew, home_slot, t, next_list, s_app, out, st);
 	}
-	ap_finish_mark(s_app, out, next_list);
+	ap_finish_mark(s_app, out);
 }
 
 // take the listed stretches out of the table: the words go to saved[] (same index as the slot), the slots are emptied
@@ -1361,7 +1356,7 @@ __global__ __launch_bounds__(TPB) void k_rp_eval_list(const RpSet *__restrict__ 
 {
 	__shared__ WaveApp s_app[TPB / 64];
 	ap_init(s_app);
-	const ApOut out = {&st->n_next, cap_chunks, nullptr};
+	const ApOut out = {&st->n_next, cap_chunks, nullptr, next_list};
 	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
 		const unsigned long long e = list[k];
 		if (e == AP_NONE) continue;
@@ -1374,7 +1369,7 @@ __global__ __launch_bounds__(TPB) void k_rp_eval_list(const RpSet *__restrict__ 
 			i = i + 1u == S.size ? 0u : i + 1u;
 		}
 	}
-	ap_finish_mark(s_app, out, next_list);
+	ap_finish_mark(s_app, out);
 }
 
 // over the NEW slots (pre = exclusive prefix of size): mode 0 = after a growth: the old slot in the word -> the entry (id + 1, from the

@@ -71,7 +71,10 @@ template <int NW> inline sdt::Table<NW> table_of(const GraphView &v)
 inline int scan_grid(int cu_count, uint64_t items)
 {
 	uint64_t blocks = (items + TPB - 1) / TPB;
-	const uint64_t cap = (uint64_t)cu_count * 8;
+	// (SDT_SCAN_BLOCKS: test hook -- a handful of workgroups do all the work, so that per-wave state (the chunks of sdt_append.cuh)
+	// goes through every transition on small inputs)
+	static const int forced = getenv("SDT_SCAN_BLOCKS") ? atoi(getenv("SDT_SCAN_BLOCKS")) : 0;
+	const uint64_t cap = forced > 0 ? (uint64_t)forced : (uint64_t)cu_count * 8;
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;
 	return (int)blocks;

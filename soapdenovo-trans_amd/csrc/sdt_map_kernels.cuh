@@ -234,17 +234,27 @@ __global__ __launch_bounds__(TPB) void k_export_arcs(const ArcEnt *__restrict__ 
                                                      uint32_t *__restrict__ to, uint32_t *__restrict__ mult,
                                                      uint64_t *__restrict__ first, unsigned long long max_n, unsigned long long *cursor)
 {
-	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
-		const ArcEnt e = arcs[s];
-		if (e.key == 0)
-			continue;
-		const unsigned long long pos = atomicAdd(cursor, 1ULL);
-		if (pos >= max_n)
-			continue;
-		from[pos] = (uint32_t)(e.key >> 32);
-		to[pos] = (uint32_t)e.key;
-		mult[pos] = e.mult;
-		first[pos] = e.first;
+	// eight slots per lane, one reservation per workgroup (sdt_append.cuh; max_n = 0: count only)
+	__shared__ unsigned long long s_res[1 + TPB / 64];
+	constexpr int IT = 8;
+	for (uint64_t base = blockIdx.x * (uint64_t)TPB * IT; base < slots; base += (uint64_t)gridDim.x * TPB * IT) {
+		uint32_t occ = 0;
+#pragma unroll
+		for (int j = 0; j < IT; j++) {
+			const uint64_t s = base + (uint64_t)j * TPB + threadIdx.x;
+			if (s < slots && arcs[s].key != 0) occ |= 1u << j;
+		}
+		unsigned long long pos = ap_block_reserve(__popc(occ), cursor, s_res);
+		for (int j = 0; j < IT; j++) {
+			if (!((occ >> j) & 1u)) continue;
+			const unsigned long long at = pos++;
+			if (at >= max_n) continue;
+			const ArcEnt e = arcs[base + (uint64_t)j * TPB + threadIdx.x];
+			from[at] = (uint32_t)(e.key >> 32);
+			to[at] = (uint32_t)e.key;
+			mult[at] = e.mult;
+			first[at] = e.first;
+		}
 	}
 }
 

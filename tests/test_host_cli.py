@@ -75,7 +75,7 @@ def test_config_parser(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks", "pipeline", "replay-limit"])
+@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks", "pipeline", "replay-limit", "few-workgroups"])
 @pytest.mark.parametrize("name", gu.case_names())
 def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     """sdt-pregraph end to end: all five files of the reference's pregraph, byte for byte, with the second read
@@ -83,7 +83,9 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     tip-cutting dry runs on the device (default) or on the host (--host-walks, and always with --host-map).
     `pipeline`: pass 1 through the locality pipeline, whatever the size of the job -- every device graph phase (layout, walks,
     junction records, commits, kmer2edges, the second read pass) then looks its k-mers up in the BUCKET-MAJOR node table;
-    `replay-limit`: the device's layout replay gives up at once (SDT_ELIMIT) and the CLI takes the host's replay instead"""
+    `replay-limit`: the device's layout replay gives up at once (SDT_ELIMIT) and the CLI takes the host's replay instead;
+    `few-workgroups`: every scan kernel runs in ONE workgroup (SDT_SCAN_BLOCKS), so that the per-wave chunks of csrc/sdt_append.cuh fill up,
+    are closed early and replaced on inputs of this size"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
@@ -102,6 +104,8 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
         env["SDT_PASS1_TABLE"] = "log"               # (multi-word keys take the flat merges by default: here all widths use the node log)
     if second_pass == "replay-limit":
         env["SDT_RP_MAX_ROUNDS"] = "0"
+    if second_pass == "few-workgroups":
+        env["SDT_SCAN_BLOCKS"] = "1"
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     if second_pass == "replay-limit" and name == "pe150_k31_p8":      # (its sets grow: the limit is hit)
@@ -214,7 +218,8 @@ def test_cli_against_oracle_on_fresh_inputs(pkg, synth, tmp_path, K, p, d, L, va
 
 
 @pytest.mark.gpu
-def test_cli_against_oracle_at_size_with_long_and_short_components(pkg, synth, tmp_path):
+@pytest.mark.parametrize("workgroups", [0, 3])
+def test_cli_against_oracle_at_size_with_long_and_short_components(pkg, synth, tmp_path, workgroups):
     """the device graph units AT SIZE against the C oracle (pinned file by file to the reference, tests/test_oracle_vs_reference.py): a
     million reads off a few deeply covered transcripts -- removeMinorOut's commit runs on the device for the components up to the limit and
     on the host's threads beside it for the longer ones (here the limit is lowered to 64 visits so that BOTH sides have thousands of
@@ -238,7 +243,10 @@ def test_cli_against_oracle_at_size_with_long_and_short_components(pkg, synth, t
     cfg = tmp_path / "lib.cfg"
     cfg.write_text(f"max_rd_len={L}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nq={tmp_path}/reads.fq\n")
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", str(cfg), "-K", str(K), "-p", str(p), "-o", str(tmp_path / "out"), "--max-k", "31"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SDT_TIMING="1", SDT_COMMIT_MAX_COMPONENT="64"))
+    env = dict(os.environ, SDT_TIMING="1", SDT_COMMIT_MAX_COMPONENT="64")
+    if workgroups:                                   # (three workgroups do all the scanning: thousands of appends per wave, csrc/sdt_append.cuh)
+        env["SDT_SCAN_BLOCKS"] = str(workgroups)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"\((\d+) visits, largest component (\d+)\).* (\d+) records of long components", r.stderr)
     assert m, r.stderr[-3000:]
