@@ -1209,7 +1209,7 @@ uint64_t graph_remove_single_tips(graph_t *g)
 		device_walks(g, 1, 2 * g->K, &rec, &nrec);
 		SUBPHASE("single tips: device walks");
 		tips = commit_tips_by_components(g, rec, nrec, 1, 2 * g->K);
-		free(rec);
+		graph_free_later(rec, NULL, NULL, NULL);           /* (a gigabyte of records: its pages go back beside the next pass) */
 		SUBPHASE("single tips: commit");
 	} else {
 		tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};
@@ -1233,7 +1233,7 @@ uint64_t graph_remove_minor_tips(graph_t *g)
 		device_walks(g, 0, 2 * g->K, &rec, &nrec);
 		SUBPHASE("minor tips: device walks");
 		tips = commit_tips_by_components(g, rec, nrec, 0, 2 * g->K);
-		free(rec);
+		graph_free_later(rec, NULL, NULL, NULL);
 		for (int s = 0; s < g->p; s++) printf("kmer set %d done\n", s);
 	} else {
 		tips_ctx c = {g, 0, 0, (walk_t *)malloc((g->n + 1) * sizeof(walk_t)), 0};

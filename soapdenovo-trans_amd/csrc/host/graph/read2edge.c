@@ -147,6 +147,12 @@ static int cmp_arc(const void *a, const void *b)
 static void sort_arcs(arc_t *v, uint64_t m)
 {
 	if (m < 64) { qsort(v, m, sizeof(arc_t), cmp_arc); return; }
+	{
+		/* (the device hands its arcs over in this order already) */
+		uint64_t i = 1;
+		while (i < m && cmp_arc(&v[i - 1], &v[i]) <= 0) i++;
+		if (i == m) return;
+	}
 	arc_t *tmp = (arc_t *)malloc(m * sizeof(arc_t));
 	if (!tmp) { qsort(v, m, sizeof(arc_t), cmp_arc); return; }
 	uint64_t or_lo = 0, and_lo = ~0ULL, or_hi = 0, and_hi = ~0ULL;

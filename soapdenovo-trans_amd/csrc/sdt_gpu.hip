@@ -2979,6 +2979,9 @@ int sdt_gpu_export_arcs(sdt_ctx *c, uint32_t *from, uint32_t *to, uint32_t *mult
 	ARC_CHK(hipMemcpyAsync(&h, d_cur, 8, hipMemcpyDeviceToHost, c->stream));
 	ARC_CHK(hipStreamSynchronize(c->stream));
 	if (h > max_arcs) { ret = fail(SDT_EINVAL, "arc arrays hold %llu, need %llu", (unsigned long long)max_arcs, h); goto done; }
+	// (in the order *.preArc lists them: the host's own sort finds nothing left to do)
+	ret = sdti::sort_arcs_for_output(c->stream, c->cu_count, d_f, d_t, d_m, d_o, h);
+	if (ret != SDT_OK) goto done;
 	ARC_CHK(hipMemcpy(from, d_f, h * 4, hipMemcpyDeviceToHost));
 	ARC_CHK(hipMemcpy(to, d_t, h * 4, hipMemcpyDeviceToHost));
 	ARC_CHK(hipMemcpy(mult, d_m, h * 4, hipMemcpyDeviceToHost));

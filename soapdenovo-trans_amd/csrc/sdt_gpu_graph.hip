@@ -140,6 +140,37 @@ static int exclusive_scan(const GraphView &v, const T *in, T *out, uint64_t n)
 }
 
 
+// (from ascending, first appearance descending): stable sort by ~first, then stable sort by from
+int sdti::sort_arcs_for_output(hipStream_t stream, int cu_count, uint32_t *d_from, uint32_t *d_to, uint32_t *d_mult, uint64_t *d_first, uint64_t n)
+{
+	if (n < 2) return SDT_OK;
+	if (n >= 0xFFFFFFFFULL) return fail(SDT_ELIMIT, "%llu arcs do not fit a 32-bit permutation", (unsigned long long)n);
+	Scratch S;
+	uint64_t *k0, *k1, *o2;
+	uint32_t *p0, *p1, *f0, *f1, *f2, *t2, *m2;
+	GCHK(S.alloc(&k0, n * 8)); GCHK(S.alloc(&k1, n * 8)); GCHK(S.alloc(&o2, n * 8));
+	GCHK(S.alloc(&p0, n * 4)); GCHK(S.alloc(&p1, n * 4)); GCHK(S.alloc(&f0, n * 4)); GCHK(S.alloc(&f1, n * 4));
+	GCHK(S.alloc(&f2, n * 4)); GCHK(S.alloc(&t2, n * 4)); GCHK(S.alloc(&m2, n * 4));
+	const dim3 grid(sdti::scan_grid(cu_count, n));
+	hipLaunchKernelGGL(k_arc_keys, grid, dim3(TPB), 0, stream, d_first, n, k0, p0);
+	size_t tb1 = 0, tb2 = 0;
+	GCHK(rocprim::radix_sort_pairs(nullptr, tb1, k0, k1, p0, p1, (size_t)n, 0u, 64u, stream));
+	GCHK(rocprim::radix_sort_pairs(nullptr, tb2, f0, f1, p1, p0, (size_t)n, 0u, 32u, stream));
+	void *tmp = nullptr;
+	GCHK(S.alloc(&tmp, (tb1 > tb2 ? tb1 : tb2) + 16));
+	GCHK(rocprim::radix_sort_pairs(tmp, tb1, k0, k1, p0, p1, (size_t)n, 0u, 64u, stream));
+	hipLaunchKernelGGL(k_arc_from_of, grid, dim3(TPB), 0, stream, d_from, p1, n, f0);
+	GCHK(rocprim::radix_sort_pairs(tmp, tb2, f0, f1, p1, p0, (size_t)n, 0u, 32u, stream));
+	hipLaunchKernelGGL(k_arc_gather, grid, dim3(TPB), 0, stream, p0, n, d_from, d_to, d_mult, d_first, f2, t2, m2, o2);
+	GCHK(hipGetLastError());
+	GCHK(hipMemcpyAsync(d_from, f2, n * 4, hipMemcpyDeviceToDevice, stream));
+	GCHK(hipMemcpyAsync(d_to, t2, n * 4, hipMemcpyDeviceToDevice, stream));
+	GCHK(hipMemcpyAsync(d_mult, m2, n * 4, hipMemcpyDeviceToDevice, stream));
+	GCHK(hipMemcpyAsync(d_first, o2, n * 8, hipMemcpyDeviceToDevice, stream));
+	GCHK(hipStreamSynchronize(stream));
+	return SDT_OK;
+}
+
 // ---- records appended in chunks per wave (sdt_append.cuh): storage, and packing into one dense array ---------------------
 struct ApBuf {
 	uint64_t *chunks = nullptr;
@@ -673,17 +704,30 @@ int sdt_gpu_tip_walks_labelled(sdt_ctx *c, int thin, int cut_len, uint64_t *n_re
 	uint64_t *d_rec = nullptr;
 	ApBuf B;
 	for (int attempt = 0; attempt < 2; attempt++) {
+		// the dead ends first (a list of slots), then one lane per walk
+		unsigned long long *d_list, *d_lcur, n_lchunks = 0;
+		const unsigned long long l_chunks = cap / (AP_CH - 64) + 1 + (unsigned long long)v.cu_count * 8 * (TPB / 64);
+		GCHK(S.alloc(&d_list, l_chunks * AP_CH * 8)); GCHK(S.alloc(&d_lcur, 8));
+		GCHK(hipMemsetAsync(d_lcur, 0, 8, v.stream));
 		int rc = ap_alloc(S, v, B, cap, 3);
 		if (rc != SDT_OK) return rc;
-		LAUNCH_NW(v, k_tip_walks, g, *v.d_idx, v.K, thin, cut_len, (uint64_t *)nullptr, (uint8_t *)nullptr, v.d_stats, B.chunks, 0ULL, (unsigned long long *)nullptr, 3, ap_out(B));
+		LAUNCH_NW(v, k_tip_starts, g, thin, d_list, ApOut{d_lcur, l_chunks, nullptr, d_list});
 		GCHK(hipGetLastError());
-		GCHK(hipMemcpyAsync(&h, B.cursor, 8, hipMemcpyDeviceToHost, v.stream));
-		rc = sdti::sync_stats(c);
-		if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: %llu walks left the graph", (unsigned long long)v.h_stats->probe_fail);
-		if (h <= B.cap_chunks) break;
+		GCHK(hipMemcpyAsync(&n_lchunks, d_lcur, 8, hipMemcpyDeviceToHost, v.stream));
+		GCHK(hipStreamSynchronize(v.stream));
+		if (n_lchunks <= l_chunks) {
+			const unsigned long long n_list = n_lchunks * AP_CH;
+			LAUNCH_NW(v, k_tip_walks_list, sdti::scan_grid(v.cu_count, n_list), *v.d_idx, v.K, thin, cut_len, d_list, n_list, v.d_stats, B.chunks, 3, ap_out(B));
+			GCHK(hipGetLastError());
+			GCHK(hipMemcpyAsync(&h, B.cursor, 8, hipMemcpyDeviceToHost, v.stream));
+			rc = sdti::sync_stats(c);
+			if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: %llu walks left the graph", (unsigned long long)v.h_stats->probe_fail);
+		}
+		(void)hipFree(S.release(d_list)); (void)hipFree(S.release(d_lcur));
+		if (n_lchunks <= l_chunks && h <= B.cap_chunks) break;
 		if (attempt) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: the number of walks changed between two runs");
 		ap_free(S, B);
-		cap = h * AP_CH;
+		cap = (n_lchunks > l_chunks ? n_lchunks : h) * AP_CH;          // (every walk has a start: the starts bound the records)
 	}
 	{
 		uint64_t n_rec = 0;
@@ -697,7 +741,27 @@ int sdt_gpu_tip_walks_labelled(sdt_ctx *c, int thin, int cut_len, uint64_t *n_re
 	if (thin) {
 		if (h) hipLaunchKernelGGL(k_uf_records, dim3(sdti::scan_grid(v.cu_count, h)), dim3(TPB), 0, v.stream, parent, d_rec, (uint64_t)h, 3, 1, 2, 0);
 	} else {
-		LAUNCH_NW(v, k_port_union, g, *v.d_idx, v.K, cut_len, parent, v.d_stats);
+		// every live port of every node that is neither linear nor deleted: listed, then walked one lane per port
+		unsigned long long *d_list = nullptr, *d_lcur, n_lchunks = 0;
+		GCHK(S.alloc(&d_lcur, 8));
+		unsigned long long l_chunks = nn / (AP_CH - 64) + 1 + (unsigned long long)v.cu_count * 8 * (TPB / 64);
+		for (int attempt = 0; attempt < 2; attempt++) {
+			GCHK(S.alloc(&d_list, l_chunks * AP_CH * 8));
+			GCHK(hipMemsetAsync(d_lcur, 0, 8, v.stream));
+			LAUNCH_NW(v, k_port_starts, g, d_list, ApOut{d_lcur, l_chunks, nullptr, d_list});
+			GCHK(hipGetLastError());
+			GCHK(hipMemcpyAsync(&n_lchunks, d_lcur, 8, hipMemcpyDeviceToHost, v.stream));
+			GCHK(hipStreamSynchronize(v.stream));
+			if (n_lchunks <= l_chunks) break;
+			if (attempt) return fail(SDT_ESTATE, "sdt_gpu_tip_walks_labelled: the number of ports changed between two runs");
+			(void)hipFree(S.release(d_list));
+			l_chunks = n_lchunks;
+		}
+		const unsigned long long n_list = n_lchunks * AP_CH;
+		if (n_list) LAUNCH_NW(v, k_port_union_list, sdti::scan_grid(v.cu_count, n_list), *v.d_idx, v.K, cut_len, d_list, n_list, parent, v.d_stats);
+		GCHK(hipGetLastError());
+		GCHK(hipStreamSynchronize(v.stream));
+		(void)hipFree(S.release(d_list)); (void)hipFree(S.release(d_lcur));
 	}
 	GCHK(hipGetLastError());
 	int rc = sdti::sync_stats(c);
@@ -1008,7 +1072,8 @@ int sdt_gpu_build_edges(sdt_ctx *c, uint64_t *n_edges, uint64_t *num_ed, uint64_
 	GCHK(S.alloc(&w_edge, (nports + 1) * 4)); GCHK(S.alloc(&w_id, (nports + 1) * 4)); GCHK(S.alloc(&w_len, (nports + 1) * 8));
 	GCHK(S.alloc(&e_scan, (nports + 1) * 4)); GCHK(S.alloc(&id_scan, (nports + 1) * 4)); GCHK(S.alloc(&len_scan, (nports + 1) * 8));
 	GCHK(hipMemsetAsync(w_edge + nports, 0, 4, v.stream)); GCHK(hipMemsetAsync(w_id + nports, 0, 4, v.stream)); GCHK(hipMemsetAsync(w_len + nports, 0, 8, v.stream));
-	LAUNCH_NW(v, k_edge_ports_ordered, sdti::scan_grid(v.cu_count, m), *v.d_idx, gx->d_slot_of, flag, srank, n, v.K, n + 1, start_node, ports, v.d_stats);
+	hipLaunchKernelGGL(k_edge_start_nodes, dim3(sdti::scan_grid(v.cu_count, m)), dim3(TPB), 0, v.stream, flag, srank, n, start_node);
+	if (nports) LAUNCH_NW(v, k_edge_ports_ordered, sdti::scan_grid(v.cu_count, nports), *v.d_idx, gx->d_slot_of, start_node, nports, v.K, n + 1, ports, v.d_stats);
 	GCHK(hipGetLastError());
 	rc = sdti::sync_stats(c);
 	if (rc != SDT_OK) return fail(SDT_ESTATE, "sdt_gpu_build_edges: %llu chains leave the graph or never end", (unsigned long long)v.h_stats->probe_fail);

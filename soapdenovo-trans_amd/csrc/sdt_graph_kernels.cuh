@@ -83,22 +83,81 @@ template <int NW> __device__ inline Key<NW> key_next_masked(const Key<NW> &k, ui
 // the walk of clipTipFromNode (cutTipPreGraph.c:43-281) from every node, read-only.  Output, at the HOST index of
 // the node: end = host index of the node the walk stopped at (~0 = nothing to decide), info = ch | sm << 2 |
 // thin_stop << 3 (the base by which the end node sees the chain, the strand on which it was reached).
+// the walk of one dead end (the node of entry e, aux word a): false = no walk from here (not a dead end, not `single` in the thin
+// pass, longer than cut_len, or a link that leaves the graph: `missing`); else the slot of the end node and the info bits
+// (first base of the last step | smaller << 2 | thin_stop << 3)
 template <int NW>
-__global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
-                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
-                                                   uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
-                                                   unsigned long long *cursor = nullptr, int rec_stride = 2, ApOut ap = ApOut{nullptr, 0, nullptr, nullptr})
+__device__ inline bool tip_walk_from(const Table<NW> &tbl, const Entry<NW> &e, uint32_t a, int K, int thin, int cut_len, const Key<NW> &mask,
+                                     uint32_t &missing, uint64_t &end_slot, uint32_t &inf)
 {
-	// (ap.cursor set: the records go out in chunks per wave, sdt_append.cuh -- rec is the chunk storage then; else one dense array)
-	__shared__ WaveApp s_app[TPB / 64];
-	ap_init(s_app);
-	const uint64_t slots = tbl.slots();
+	if (a & (AUX_LINEAR | AUX_DELETED)) return false;
+	const bool single = (e.val >> 48) == 1 && (a & 0xFFFFu) == 0;
+	if (thin && !single) return false;
+	const uint64_t ll = e.val & 0xFFFFFFu, rl = (e.val >> 24) & 0xFFFFFFu;
+	const uint32_t in = dev_degree(ll), out = dev_degree(rl);
+	Key<NW> at;
+#pragma unroll
+	for (int w = 0; w < NW; w++) at.w[w] = e.key[w];
+	uint32_t b;
+	if (in == 0 && out == 1) {
+		b = first_link(rl);
+	} else if (in == 1 && out == 0) {
+		at = key_revcomp<NW>(at, K);
+		b = first_link(ll) ^ 2u;
+	} else {
+		return false;
+	}
+	int steps = 1;
+	uint32_t thin_stop = 0;
+	Key<NW> step = key_next_masked<NW>(at, b, mask);
+	Key<NW> bal = key_revcomp<NW>(step, K);
+	bool sm = !key_less<NW>(bal, step);               // KmerLarger(word, bal) -> take bal, smaller = 0
+	uint64_t os;
+	if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; return false; }
+	for (;;) {
+		const uint32_t oa = tbl.aux[os];
+		if (!(oa & AUX_LINEAR)) break;
+		steps++;
+		const uint64_t ov = tbl.ent[os].val;
+		if (thin && !((ov >> 48) == 1 && (oa & 0xFFFFu) == 0)) { thin_stop = 1; break; }
+		if (steps > cut_len) return false;
+		at = step;
+		b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+		step = key_next_masked<NW>(at, b, mask);
+		bal = key_revcomp<NW>(step, K);
+		sm = !key_less<NW>(bal, step);
+		if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; return false; }
+	}
+	// first base of `at`: bits 2(K-1)..2(K-1)+1 of the NW-word value
+	const int tb = 2 * (K - 1);
+	uint32_t ch = 0;
+#pragma unroll
+	for (int w = 0; w < NW; w++)
+		if (w == NW - 1 - (tb >> 6)) ch = (uint32_t)(at.w[w] >> (tb & 63)) & 3u;
+	inf = ch | ((uint32_t)sm << 2) | (thin_stop << 3);
+	end_slot = os;
+	return true;
+}
+
+template <int NW> __device__ inline Key<NW> key_mask_of(int K)
+{
 	Key<NW> mask;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
 		const int bits = 2 * K - 64 * (NW - 1 - i);
 		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
 	}
+	return mask;
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
+                                                   uint64_t *__restrict__ end_out, uint8_t *__restrict__ info_out, Stats *stats,
+                                                   uint64_t *__restrict__ rec = nullptr, unsigned long long max_rec = 0,
+                                                   unsigned long long *cursor = nullptr, int rec_stride = 2)
+{
+	const uint64_t slots = tbl.slots();
+	const Key<NW> mask = key_mask_of<NW>(K);
 	uint32_t missing = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		const Entry<NW> e = tbl.ent[s];
@@ -108,68 +167,71 @@ __global__ __launch_bounds__(TPB) void k_tip_walks(Table<NW> tbl, const uint64_t
 			end_out[me] = ~0ULL;
 			info_out[me] = 0;
 		}
-		const uint32_t a = tbl.aux[s];
-		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
-		const bool single = (e.val >> 48) == 1 && (a & 0xFFFFu) == 0;
-		if (thin && !single) continue;
-		const uint64_t ll = e.val & 0xFFFFFFu, rl = (e.val >> 24) & 0xFFFFFFu;
-		const uint32_t in = dev_degree(ll), out = dev_degree(rl);
-		Key<NW> at;
-#pragma unroll
-		for (int w = 0; w < NW; w++) at.w[w] = e.key[w];
-		uint32_t b;
-		if (in == 0 && out == 1) {
-			b = first_link(rl);
-		} else if (in == 1 && out == 0) {
-			at = key_revcomp<NW>(at, K);
-			b = first_link(ll) ^ 2u;
-		} else {
-			continue;
-		}
-		int steps = 1;
-		uint32_t thin_stop = 0;
-		bool give_up = false;
-		Key<NW> step = key_next_masked<NW>(at, b, mask);
-		Key<NW> bal = key_revcomp<NW>(step, K);
-		bool sm = !key_less<NW>(bal, step);               // KmerLarger(word, bal) -> take bal, smaller = 0
 		uint64_t os;
-		if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; continue; }
-		for (;;) {
-			const uint32_t oa = tbl.aux[os];
-			if (!(oa & AUX_LINEAR)) break;
-			steps++;
-			const uint64_t ov = tbl.ent[os].val;
-			if (thin && !((ov >> 48) == 1 && (oa & 0xFFFFu) == 0)) { thin_stop = 1; break; }
-			if (steps > cut_len) { give_up = true; break; }
-			at = step;
-			b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
-			step = key_next_masked<NW>(at, b, mask);
-			bal = key_revcomp<NW>(step, K);
-			sm = !key_less<NW>(bal, step);
-			if (!find_slot<NW>(tbl, sm ? step : bal, os)) { missing++; give_up = true; break; }
-		}
-		if (give_up) continue;
-		// first base of `at`: bits 2(K-1)..2(K-1)+1 of the NW-word value
-		const int tb = 2 * (K - 1);
-		uint32_t ch = 0;
-#pragma unroll
-		for (int w = 0; w < NW; w++)
-			if (w == NW - 1 - (tb >> 6)) ch = (uint32_t)(at.w[w] >> (tb & 63)) & 3u;
-		const uint32_t inf = ch | ((uint32_t)sm << 2) | (thin_stop << 3);
+		uint32_t inf;
+		if (!tip_walk_from<NW>(tbl, e, tbl.aux[s], K, thin, cut_len, mask, missing, os, inf)) continue;
 		if (end_out) {
 			end_out[me] = idx[os];
 			info_out[me] = (uint8_t)inf;
 		} else {                                             // compact: only the nodes that have a walk, in any order
-			unsigned long long r;
-			if (ap.cursor) r = ap_append(s_app, ap);
-			else { r = atomicAdd(cursor, 1ULL); if (r >= max_rec) r = AP_NONE; }
-			if (r != AP_NONE) {
+			const unsigned long long r = atomicAdd(cursor, 1ULL);
+			if (r < max_rec) {
 				rec[rec_stride * r] = me | ((uint64_t)inf << 56);
 				rec[rec_stride * r + 1] = idx[os];
 			}
 		}
 	}
-	if (ap.cursor) ap_finish(s_app, ap);
+	if (missing)
+		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
+}
+
+// The same in two steps, for the labelled dry runs.  One lane in fifty of the scan has a walk, and a walk is a chain of up to 2K
+// dependent look-ups: a wave of the scan waits for its one or two walkers with all other lanes idle (430 ms for the two tip passes
+// at 678 M nodes).  k_tip_starts lists the dead ends (their slots, in chunks: sdt_append.cuh), k_tip_walks_list gives every lane of a
+// wave a walk of its own.
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_tip_starts(Table<NW> tbl, int thin, unsigned long long *__restrict__ list, ApOut ap)
+{
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
+	const uint64_t slots = tbl.slots();
+	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
+		const Entry<NW> e = tbl.ent[s];
+		if (e.key[0] == KEY_EMPTY) continue;
+		const uint32_t a = tbl.aux[s];
+		if (a & (AUX_LINEAR | AUX_DELETED)) continue;
+		if (thin && !((e.val >> 48) == 1 && (a & 0xFFFFu) == 0)) continue;
+		const uint32_t in = dev_degree(e.val & 0xFFFFFFu), out = dev_degree((e.val >> 24) & 0xFFFFFFu);
+		if (!((in == 0 && out == 1) || (in == 1 && out == 0))) continue;
+		const unsigned long long r = ap_append(s_app, ap);
+		if (r != AP_NONE) list[r] = s;
+	}
+	ap_finish_mark(s_app, ap);
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_tip_walks_list(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int thin, int cut_len,
+                                                        const unsigned long long *__restrict__ list, unsigned long long n_list, Stats *stats,
+                                                        uint64_t *__restrict__ rec, int rec_stride, ApOut ap)
+{
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
+	const Key<NW> mask = key_mask_of<NW>(K);
+	uint32_t missing = 0;
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long s = list[k];
+		if (s == AP_NONE) continue;
+		const Entry<NW> e = tbl.ent[s];
+		uint64_t os;
+		uint32_t inf;
+		if (!tip_walk_from<NW>(tbl, e, tbl.aux[s], K, thin, cut_len, mask, missing, os, inf)) continue;
+		const unsigned long long r = ap_append(s_app, ap);
+		if (r != AP_NONE) {
+			rec[rec_stride * r] = idx[s] | ((uint64_t)inf << 56);
+			rec[rec_stride * r + 1] = idx[os];
+		}
+	}
+	ap_finish(s_app, ap);
 	if (missing)
 		atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
@@ -892,46 +954,60 @@ __global__ __launch_bounds__(TPB) void k_gather_records(const uint64_t *__restri
 
 // removeMinorTips' components: every node that is neither linear nor deleted is united with the first non-linear node behind
 // each of its live ports when at most max_linear linear nodes lie in between (the chains a walk of <= cut_len steps can cross)
+// (in two steps, as the tip walks: k_port_starts lists slot << 3 | port for every live port of such a node, k_port_union_list
+// gives every lane one port to walk)
 template <int NW>
-__global__ __launch_bounds__(TPB) void k_port_union(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int max_linear, uint32_t *parent, Stats *stats)
+__global__ __launch_bounds__(TPB) void k_port_starts(Table<NW> tbl, unsigned long long *__restrict__ list, ApOut ap)
 {
+	__shared__ WaveApp s_app[TPB / 64];
+	ap_init(s_app);
 	const uint64_t slots = tbl.slots();
-	Key<NW> mask;
-#pragma unroll
-	for (int i = 0; i < NW; i++) {
-		const int bits = 2 * K - 64 * (NW - 1 - i);
-		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
-	}
-	uint32_t missing = 0;
 	for (uint64_t s = blockIdx.x * (uint64_t)TPB + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * TPB) {
 		const Entry<NW> e = tbl.ent[s];
 		if (e.key[0] == KEY_EMPTY) continue;
 		if (tbl.aux[s] & (AUX_LINEAR | AUX_DELETED)) continue;
-		const uint32_t me_idx = (uint32_t)idx[s];
-		Key<NW> me;
-#pragma unroll
-		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
-		const Key<NW> me_rc = key_revcomp<NW>(me, K);
 		for (int p = 0; p < 8; p++) {
 			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
 			if (!live) continue;
-			uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
-			Key<NW> word = key_next_masked<NW>(p < 4 ? me : me_rc, b, mask);
-			int passed = 0;
-			bool ok = true;
-			uint64_t os;
-			for (;;) {
-				const Key<NW> bal = key_revcomp<NW>(word, K);
-				const bool sm = !key_less<NW>(bal, word);
-				if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
-				if (!(tbl.aux[os] & AUX_LINEAR)) break;
-				if (++passed > max_linear) { ok = false; break; }
-				const uint64_t ov = tbl.ent[os].val;
-				b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
-				word = key_next_masked<NW>(word, b, mask);
-			}
-			if (ok) uf_union(parent, me_idx, (uint32_t)idx[os]);
+			const unsigned long long r = ap_append(s_app, ap);
+			if (r != AP_NONE) list[r] = (s << 3) | (unsigned long long)p;
 		}
+	}
+	ap_finish_mark(s_app, ap);
+}
+
+template <int NW>
+__global__ __launch_bounds__(TPB) void k_port_union_list(Table<NW> tbl, const uint64_t *__restrict__ idx, int K, int max_linear,
+                                                         const unsigned long long *__restrict__ list, unsigned long long n_list, uint32_t *parent, Stats *stats)
+{
+	const Key<NW> mask = key_mask_of<NW>(K);
+	uint32_t missing = 0;
+	for (unsigned long long k = blockIdx.x * (unsigned long long)TPB + threadIdx.x; k < n_list; k += (unsigned long long)gridDim.x * TPB) {
+		const unsigned long long le = list[k];
+		if (le == AP_NONE) continue;
+		const uint64_t s = le >> 3;
+		const int p = (int)(le & 7u);
+		const Entry<NW> e = tbl.ent[s];
+		Key<NW> me;
+#pragma unroll
+		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
+		if (p >= 4) me = key_revcomp<NW>(me, K);
+		uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+		Key<NW> word = key_next_masked<NW>(me, b, mask);
+		int passed = 0;
+		bool ok = true;
+		uint64_t os;
+		for (;;) {
+			const Key<NW> bal = key_revcomp<NW>(word, K);
+			const bool sm = !key_less<NW>(bal, word);
+			if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+			if (!(tbl.aux[os] & AUX_LINEAR)) break;
+			if (++passed > max_linear) { ok = false; break; }
+			const uint64_t ov = tbl.ent[os].val;
+			b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+			word = key_next_masked<NW>(word, b, mask);
+		}
+		if (ok) uf_union(parent, (uint32_t)idx[s], (uint32_t)idx[os]);
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
@@ -966,64 +1042,62 @@ __global__ __launch_bounds__(TPB) void k_edge_starts(Table<NW> tbl, const uint64
 
 struct PortRec { uint64_t far, meta; };              // far node index (~0: no link), length | far_port << 32 | bal_edge << 40
 
+__global__ __launch_bounds__(TPB) void k_edge_start_nodes(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ srank, uint64_t n,
+                                                           uint32_t *__restrict__ start_node)
+{
+	for (uint64_t v = blockIdx.x * (uint64_t)TPB + threadIdx.x; v < n; v += (uint64_t)gridDim.x * TPB)
+		if (flag[v]) start_node[srank[v]] = (uint32_t)v;
+}
+
+// one lane per PORT of a start node (rank r of the node among the start nodes, port p: record r * 8 + p): every lane of a wave walks
 template <int NW>
 __global__ __launch_bounds__(TPB) void k_edge_ports_ordered(Table<NW> tbl, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ slot_of,
-                                                            const uint32_t *__restrict__ flag, const uint32_t *__restrict__ srank, uint64_t n, int K,
-                                                            uint64_t max_steps, uint32_t *__restrict__ start_node, PortRec *__restrict__ ports, Stats *stats)
+                                                            const uint32_t *__restrict__ start_node, uint64_t nports, int K,
+                                                            uint64_t max_steps, PortRec *__restrict__ ports, Stats *stats)
 {
-	Key<NW> mask;
-#pragma unroll
-	for (int i = 0; i < NW; i++) {
-		const int bits = 2 * K - 64 * (NW - 1 - i);
-		mask.w[i] = bits <= 0 ? 0ULL : (bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL));
-	}
+	const Key<NW> mask = key_mask_of<NW>(K);
 	const int tb = 2 * (K - 1);
 	uint32_t missing = 0;
-	for (uint64_t v = blockIdx.x * (uint64_t)TPB + threadIdx.x; v < n; v += (uint64_t)gridDim.x * TPB) {
-		if (!flag[v]) continue;
-		const uint64_t r = srank[v];
-		start_node[r] = (uint32_t)v;
-		const Entry<NW> e = tbl.ent[slot_of[v]];
-		Key<NW> me;
+	for (uint64_t g = blockIdx.x * (uint64_t)TPB + threadIdx.x; g < nports; g += (uint64_t)gridDim.x * TPB) {
+		const int p = (int)(g & 7u);
+		const Entry<NW> e = tbl.ent[slot_of[start_node[g >> 3]]];
+		uint64_t far = ~0ULL, meta = 0;
+		const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
+		if (live) {
+			Key<NW> k0;
 #pragma unroll
-		for (int w = 0; w < NW; w++) me.w[w] = e.key[w];
-		const Key<NW> me_rc = key_revcomp<NW>(me, K);
-		for (int p = 0; p < 8; p++) {
-			uint64_t far = ~0ULL, meta = 0;
-			const bool live = p < 4 ? ((e.val >> (24 + 6 * p)) & 63u) != 0 : ((e.val >> (6 * (p - 4))) & 63u) != 0;
-			if (live) {
-				const Key<NW> k0 = p < 4 ? me : me_rc;
-				uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
-				Key<NW> prev = k0, word = key_next_masked<NW>(k0, b, mask), k1 = word;
-				uint64_t len = 1;
-				bool ok = true, sm;
-				uint64_t os;
-				for (;;) {
-					const Key<NW> bal = key_revcomp<NW>(word, K);
-					sm = !key_less<NW>(bal, word);
-					if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
-					if (!(tbl.aux[os] & AUX_LINEAR)) break;
-					if (++len > max_steps) { missing++; ok = false; break; }
-					const uint64_t ov = tbl.ent[os].val;
-					b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
-					prev = word;
-					word = key_next_masked<NW>(word, b, mask);
-				}
-				if (ok) {
-					uint32_t fc = 0;
-#pragma unroll
-					for (int w = 0; w < NW; w++)
-						if (w == NW - 1 - (tb >> 6)) fc = (uint32_t)(prev.w[w] >> (tb & 63)) & 3u;
-					const uint32_t far_port = sm ? 4u + fc : (fc ^ 2u);
-					const Key<NW> rc0 = key_revcomp<NW>(k0, K), rc1 = key_revcomp<NW>(k1, K);
-					const bool palin = key_eq<NW>(word, rc0) && key_eq<NW>(prev, rc1);
-					far = idx[os];
-					meta = len | ((uint64_t)far_port << 32) | ((uint64_t)(palin ? 0 : 1) << 40);
-				}
+			for (int w = 0; w < NW; w++) k0.w[w] = e.key[w];
+			if (p >= 4) k0 = key_revcomp<NW>(k0, K);
+			uint32_t b = p < 4 ? (uint32_t)p : ((uint32_t)(p - 4) ^ 2u);
+			Key<NW> prev = k0, word = key_next_masked<NW>(k0, b, mask), k1 = word;
+			uint64_t len = 1;
+			bool ok = true, sm;
+			uint64_t os;
+			for (;;) {
+				const Key<NW> bal = key_revcomp<NW>(word, K);
+				sm = !key_less<NW>(bal, word);
+				if (!find_slot<NW>(tbl, sm ? word : bal, os)) { missing++; ok = false; break; }
+				if (!(tbl.aux[os] & AUX_LINEAR)) break;
+				if (++len > max_steps) { missing++; ok = false; break; }
+				const uint64_t ov = tbl.ent[os].val;
+				b = sm ? first_link((ov >> 24) & 0xFFFFFFu) : (first_link(ov & 0xFFFFFFu) ^ 2u);
+				prev = word;
+				word = key_next_masked<NW>(word, b, mask);
 			}
-			ports[r * 8 + p].far = far;
-			ports[r * 8 + p].meta = meta;
+			if (ok) {
+				uint32_t fc = 0;
+#pragma unroll
+				for (int w = 0; w < NW; w++)
+					if (w == NW - 1 - (tb >> 6)) fc = (uint32_t)(prev.w[w] >> (tb & 63)) & 3u;
+				const uint32_t far_port = sm ? 4u + fc : (fc ^ 2u);
+				const Key<NW> rc0 = key_revcomp<NW>(k0, K), rc1 = key_revcomp<NW>(k1, K);
+				const bool palin = key_eq<NW>(word, rc0) && key_eq<NW>(prev, rc1);
+				far = idx[os];
+				meta = len | ((uint64_t)far_port << 32) | ((uint64_t)(palin ? 0 : 1) << 40);
+			}
 		}
+		ports[g].far = far;
+		ports[g].meta = meta;
 	}
 	if (missing) atomicAdd(&stats->probe_fail, (unsigned long long)missing);
 }
@@ -1400,5 +1474,25 @@ __global__ __launch_bounds__(TPB) void k_rp_order(const RpSet *__restrict__ sets
 		const RpSet S = sets[s];
 		// rank[] is the exclusive scan of occ over all sets' slots: the entries before this set's region are exactly its key0
 		order[rank[g]] = S.key0 + (tab[S.tab0 + (g - pre[s])] - 1ULL);
+	}
+}
+
+
+// ---- the arcs of the second read pass in the order of *.preArc (output_arcs, prlRead2path.c:454-505) --------------------------
+__global__ __launch_bounds__(TPB) void k_arc_keys(const uint64_t *__restrict__ first, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ perm)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) { key[i] = ~first[i]; perm[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(TPB) void k_arc_from_of(const uint32_t *__restrict__ from, const uint32_t *__restrict__ perm, uint64_t n, uint32_t *__restrict__ key)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) key[i] = from[perm[i]];
+}
+__global__ __launch_bounds__(TPB) void k_arc_gather(const uint32_t *__restrict__ perm, uint64_t n, const uint32_t *__restrict__ f, const uint32_t *__restrict__ t,
+                                                    const uint32_t *__restrict__ m, const uint64_t *__restrict__ o, uint32_t *__restrict__ f2,
+                                                    uint32_t *__restrict__ t2, uint32_t *__restrict__ m2, uint64_t *__restrict__ o2)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+		const uint32_t j = perm[i];
+		f2[i] = f[j]; t2[i] = t[j]; m2[i] = m[j]; o2[i] = o[j];
 	}
 }

@@ -85,6 +85,9 @@ int release_pass1(sdt_ctx *c);     // pass 1 is over: give the pools of the loca
 // large transfers between pageable host memory and the device through pinned staging buffers filled / drained by a few threads
 int h2d_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
 int d2h_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
+// n arcs (from, to, multiplicity, first appearance) in device arrays, put in the order *.preArc lists them: from ascending, most
+// recent first appearance first (sdt_gpu_graph.hip: the unit with the device-wide sorts)
+int sort_arcs_for_output(hipStream_t stream, int cu_count, uint32_t *d_from, uint32_t *d_to, uint32_t *d_mult, uint64_t *d_first, uint64_t n);
 
 }  // namespace sdti
 
