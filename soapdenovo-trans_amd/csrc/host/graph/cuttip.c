@@ -642,7 +642,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 			printf("the device commit failed. Now exit to system...\n");          /* no silent host fallback */
 			exit(1);
 		}
-		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		graph_clear_dirty(g);          /* the hook brought the mirror up to date */
 		g->dn = 0;
 		SUBPHASE("device dry run + components");
 		if (nsk) {
@@ -692,7 +692,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 			printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
 			exit(1);
 		}
-		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		graph_clear_dirty(g);          /* the hook brought the mirror up to date */
 		g->dn = 0;
 		SUBPHASE("device dry run");
 		if (nr > 0xFFFFFFF0ULL) { printf("too many junction records\n"); exit(1); }
@@ -1150,45 +1150,112 @@ static void device_walks(graph_t *g, int thin, int cut_len, uint64_t **rec, uint
 		printf("the device dry run failed. Now exit to system...\n");       /* no silent host fallback */
 		exit(1);
 	}
-	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the mirror is current as of now */
+	graph_clear_dirty(g);          /* the mirror is current as of now */
 	g->dn = 0;
+}
+
+/* the set-up of commit_tips_by_components on all threads: tens of millions of records and components (the three serial loops over
+ * them took a quarter of the commit) */
+typedef struct { const uint64_t *rec; uint64_t nrec, nblocks, per; uint64_t *count; uint64_t *cstart; uint32_t *corder; uint64_t ncomp; uint64_t *hist; } tcs_ctx;
+static void tcs_count(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	tcs_ctx *S = (tcs_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		const uint64_t r0 = b * S->per > 1 ? b * S->per : 1, r1 = (b + 1) * S->per < S->nrec ? (b + 1) * S->per : S->nrec;
+		uint64_t n = 0;
+		for (uint64_t r = r0; r < r1; r++) n += S->rec[3 * r + 2] != S->rec[3 * r - 1];
+		S->count[b] = n;
+	}
+}
+static void tcs_fill(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	tcs_ctx *S = (tcs_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		const uint64_t r0 = b * S->per > 1 ? b * S->per : 1, r1 = (b + 1) * S->per < S->nrec ? (b + 1) * S->per : S->nrec;
+		uint64_t at = S->count[b];                                 /* (exclusive prefix by now) + 1: cstart[0] = 0 is the first component */
+		for (uint64_t r = r0; r < r1; r++)
+			if (S->rec[3 * r + 2] != S->rec[3 * r - 1]) S->cstart[1 + at++] = r;
+	}
+}
+static void tcs_hist(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	tcs_ctx *S = (tcs_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		const uint64_t c0 = b * S->per, c1 = (b + 1) * S->per < S->ncomp ? (b + 1) * S->per : S->ncomp;
+		uint64_t *h = S->hist + b * 66;
+		for (uint64_t c = c0; c < c1; c++) h[64 - __builtin_clzll(S->cstart[c + 1] - S->cstart[c])]++;
+	}
+}
+static void tcs_place(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	tcs_ctx *S = (tcs_ctx *)vc;
+	for (uint64_t b = lo; b < hi; b++) {
+		const uint64_t c0 = b * S->per, c1 = (b + 1) * S->per < S->ncomp ? (b + 1) * S->per : S->ncomp;
+		uint64_t *h = S->hist + b * 66;                            /* (first position of this block's components of every size class by now) */
+		for (uint64_t c = c0; c < c1; c++) S->corder[h[64 - __builtin_clzll(S->cstart[c + 1] - S->cstart[c])]++] = (uint32_t)c;
+	}
+}
+typedef struct { graph_t *g; uint64_t **tl; size_t *tln; size_t *at; } tcd_ctx;
+static void tcd_copy(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	tcd_ctx *D = (tcd_ctx *)vc;
+	for (uint64_t t = lo; t < hi; t++)
+		if (D->tln[t]) memcpy(D->g->dlist + D->at[t], D->tl[t], D->tln[t] * sizeof(uint64_t));
 }
 
 static uint64_t commit_tips_by_components(graph_t *g, const uint64_t *rec, uint64_t nrec, int thin, int cut_len)
 {
 	if (!nrec) return 0;
 	/* components = runs of equal labels */
+	tcs_ctx S;
+	memset(&S, 0, sizeof S);
+	S.rec = rec; S.nrec = nrec;
+	S.nblocks = nrec / 65536 + 1; S.per = (nrec + S.nblocks - 1) / S.nblocks;
+	S.count = (uint64_t *)calloc(S.nblocks + 1, sizeof(uint64_t));
+	par_for(0, S.nblocks, 1, tcs_count, &S);
 	uint64_t ncomp = 1;
-	for (uint64_t r = 1; r < nrec; r++) ncomp += rec[3 * r + 2] != rec[3 * r - 1];
+	for (uint64_t b = 0; b < S.nblocks; b++) { const uint64_t t = S.count[b]; S.count[b] = ncomp - 1; ncomp += t; }
 	if (ncomp > 0xFFFFFFF0ULL) { printf("too many components of tips\n"); exit(1); }
 	uint64_t *cstart = (uint64_t *)malloc((ncomp + 1) * sizeof(uint64_t));
-	ncomp = 0;
 	cstart[0] = 0;
-	for (uint64_t r = 1; r < nrec; r++)
-		if (rec[3 * r + 2] != rec[3 * r - 1]) cstart[++ncomp] = r;
-	cstart[++ncomp] = nrec;
+	S.cstart = cstart;
+	par_for(0, S.nblocks, 1, tcs_fill, &S);
+	cstart[ncomp] = nrec;
+	free(S.count);
 	/* largest first (counting sort by the bit length of the size): the giant components must not start last */
 	uint32_t *corder = (uint32_t *)malloc((ncomp + 1) * sizeof(uint32_t));
-	uint64_t bucket[66] = {0};
-	for (uint64_t c = 0; c < ncomp; c++) bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++;
+	S.ncomp = ncomp; S.corder = corder;
+	S.nblocks = ncomp / 65536 + 1; S.per = (ncomp + S.nblocks - 1) / S.nblocks;
+	S.hist = (uint64_t *)calloc(S.nblocks * 66 + 66, sizeof(uint64_t));
+	par_for(0, S.nblocks, 1, tcs_hist, &S);
 	{
 		uint64_t acc = 0;
-		for (int b = 65; b >= 0; b--) { const uint64_t t = bucket[b]; bucket[b] = acc; acc += t; }
+		for (int bit = 65; bit >= 0; bit--)
+			for (uint64_t b = 0; b < S.nblocks; b++) { const uint64_t t = S.hist[b * 66 + bit]; S.hist[b * 66 + bit] = acc; acc += t; }
 	}
-	for (uint64_t c = 0; c < ncomp; c++) corder[bucket[64 - __builtin_clzll(cstart[c + 1] - cstart[c])]++] = (uint32_t)c;
+	par_for(0, S.nblocks, 1, tcs_place, &S);
+	free(S.hist);
 	tc_ctx T;
 	memset(&T, 0, sizeof T);
 	T.g = g; T.rec = rec; T.cstart = cstart; T.corder = corder; T.ncomp = ncomp; T.thin = thin; T.cut_len = cut_len;
 	par_for(0, ncomp, 256, tc_run, &T);
-	for (int t = 0; t < 64; t++) {
-		for (size_t k = 0; k < T.tln[t]; k++) {
-			if (g->dn == g->dcap) {
-				g->dcap = g->dcap ? g->dcap * 2 : 4096;
-				g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
-			}
-			g->dlist[g->dn++] = T.tl[t][k];
+	{
+		/* the threads' lists of written nodes behind what the list holds already */
+		size_t at[64], total = g->dn;
+		for (int t = 0; t < 64; t++) { at[t] = total; total += T.tln[t]; }
+		if (total > g->dcap) {
+			g->dcap = total + total / 4 + 4096;
+			g->dlist = (uint64_t *)realloc(g->dlist, g->dcap * sizeof(uint64_t));
 		}
-		free(T.tl[t]);
+		tcd_ctx D = {g, T.tl, T.tln, at};
+		par_for(0, 64, 1, tcd_copy, &D);
+		g->dn = total;
+		for (int t = 0; t < 64; t++) free(T.tl[t]);
 	}
 	if (getenv("SDT_TIMING")) {
 		uint64_t biggest = 0;
@@ -1533,7 +1600,7 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 	/* "the device": the short components, committed and re-marked -- on nodes[], whose old contents are put back afterwards: what
 	 * was written goes through the same list of (index, links, flags) and graph_apply_written as the device's writes, in _finish */
 	uint64_t off = 0, lin = 0;
-	for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;
+	graph_clear_dirty(g);
 	g->dn = 0;
 	gnode_t *before = (gnode_t *)malloc((g->n + 1) * sizeof(gnode_t));
 	memcpy(before, g->nodes, g->n * sizeof(gnode_t));

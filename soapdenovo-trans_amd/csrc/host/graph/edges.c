@@ -474,7 +474,7 @@ static int host_edge_records(graph_t *g, uint64_t **rec_out, uint64_t *nrec_out,
 			printf("the device dry run failed (%llu records for %llu start nodes). Now exit to system...\n", (unsigned long long)nrec, (unsigned long long)E.nstarts);
 			exit(1);
 		}
-		for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;          /* the hook brought the mirror up to date */
+		graph_clear_dirty(g);          /* the hook brought the mirror up to date */
 		g->dn = 0;
 		void *sa[3] = {&E, rec, slot_of};
 		par_for(0, nrec, 4096, scatter_ports, sa);
@@ -528,6 +528,54 @@ static int host_edge_records(graph_t *g, uint64_t **rec_out, uint64_t *nrec_out,
 	return 0;
 }
 
+/* <prefix>.edge.gz as a sequence of gzip members, each formatted and deflated by one thread over ~4 MB of records */
+typedef struct { graph_t *g; uint64_t *rec; char *bases; int kw; uint64_t nemit; char name[4200]; } ew_job;
+static void *edge_writer(void *v)
+{
+	ew_job *W = (ew_job *)v;
+	const graph_t *g = W->g;
+	uint64_t *rec = W->rec;
+	char *bases = W->bases;
+	const int kw = W->kw, RW = 4 + 2 * kw;
+	const uint64_t nemit = W->nemit;
+	const char *name = W->name;
+	const double t0 = ed_now();
+	FILE *fz = fopen(name, "wb");
+	if (!fz) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	{
+		uint64_t *cut = (uint64_t *)malloc((nemit + 2) * sizeof(uint64_t));
+		uint64_t ncut = 0;
+		size_t acc = 0;
+		const size_t chunk_bytes = getenv("SDT_GZ_CHUNK") ? (size_t)atol(getenv("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
+		cut[ncut++] = 0;
+		for (uint64_t e = 0; e < nemit; e++) {
+			acc += (size_t)(rec[e * RW] & 0xFFFFFFFFULL) + 60;
+			if (acc >= chunk_bytes) { cut[ncut++] = e + 1; acc = 0; }
+		}
+		if (cut[ncut - 1] != nemit) cut[ncut++] = nemit;
+		const uint64_t nchunks = ncut - 1;
+		gz_ctx Z = {g, rec, kw, bases, cut, (unsigned char **)calloc(nchunks + 1, sizeof(unsigned char *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
+		par_for(0, nchunks, 1, gz_chunks, &Z);
+		if (Z.failed) { printf("deflate failed on %s\n", name); exit(-1); }
+		for (uint64_t k = 0; k < nchunks; k++) { fwrite(Z.out[k], 1, Z.len[k], fz); free(Z.out[k]); }
+		if (nchunks == 0) {                                  /* no edges: still a valid (empty) gzip file */
+			gzFile fe = gzdopen(dup(fileno(fz)), "w1");
+			if (fe) gzclose(fe);
+		}
+		free(Z.out); free(Z.len); free(cut);
+	}
+	fclose(fz);
+	free(rec); free(bases);
+	if (getenv("SDT_TIMING")) fprintf(stderr, "[edges]    text + gzip write (beside the next phase) %9.1f ms\n", ed_now() - t0);
+	free(W);
+	return NULL;
+}
+
+void graph_edges_join(graph_t *g)
+{
+	if (g && g->edge_writer_on) { pthread_join(g->edge_writer, NULL); g->edge_writer_on = 0; }
+}
+
 uint64_t graph_build_edges(graph_t *g, const char *prefix)
 {
 	double t_sub = ed_now();
@@ -541,7 +589,7 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		rc = g->dev_build_edges(g, &rec, &kw, &nemit, &num_ed, &bases, &nb);
 		if (rc != 0 && rc != 2) { printf("the device edge builder failed. Now exit to system...\n"); exit(1); }
 		if (rc == 0) {
-			for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0;
+			graph_clear_dirty(g);
 			g->dn = 0;
 			g->edges_on_device = 1;
 		}
@@ -574,39 +622,19 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		else patch_put(g, &bal, id + bal_edge, (uint8_t)(1 - bal_edge));
 	}
 	EPHASE("patch table");
-	/* <prefix>.edge.gz as a sequence of gzip members, each formatted and deflated by one thread over ~4 MB of records */
-	char name[4200];
-	snprintf(name, sizeof name, "%s.edge.gz", prefix);
-	FILE *fz = fopen(name, "wb");
-	if (!fz) { printf("Cannot open %s. Now exit to system...\n", name); exit(-1); }
+	/* <prefix>.edge.gz is written by a thread of its own, beside the second read pass (the device is busy there, the host is not):
+	 * graph_edges_join waits for it */
 	{
-		uint64_t *cut = (uint64_t *)malloc((nemit + 2) * sizeof(uint64_t));
-		uint64_t ncut = 0;
-		size_t acc = 0;
-		const size_t chunk_bytes = getenv("SDT_GZ_CHUNK") ? (size_t)atol(getenv("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
-		cut[ncut++] = 0;
-		for (uint64_t e = 0; e < nemit; e++) {
-			acc += (size_t)(rec[e * RW] & 0xFFFFFFFFULL) + 60;
-			if (acc >= chunk_bytes) { cut[ncut++] = e + 1; acc = 0; }
-		}
-		if (cut[ncut - 1] != nemit) cut[ncut++] = nemit;
-		const uint64_t nchunks = ncut - 1;
-		gz_ctx Z = {g, rec, kw, bases, cut, (unsigned char **)calloc(nchunks + 1, sizeof(unsigned char *)), (size_t *)calloc(nchunks + 1, sizeof(size_t)), 0};
-		par_for(0, nchunks, 1, gz_chunks, &Z);
-		if (Z.failed) { printf("deflate failed on %s\n", name); exit(-1); }
-		for (uint64_t k = 0; k < nchunks; k++) { fwrite(Z.out[k], 1, Z.len[k], fz); free(Z.out[k]); }
-		if (nchunks == 0) {                                  /* no edges: still a valid (empty) gzip file */
-			gzFile fe = gzdopen(dup(fileno(fz)), "w1");
-			if (fe) gzclose(fe);
-		}
-		free(Z.out); free(Z.len); free(cut);
+		ew_job *W = (ew_job *)malloc(sizeof *W);
+		W->g = g; W->rec = rec; W->bases = bases; W->kw = kw; W->nemit = nemit;
+		snprintf(W->name, sizeof W->name, "%s.edge.gz", prefix);
+		if (getenv("SDT_EDGES_INLINE") || pthread_create(&g->edge_writer, NULL, edge_writer, W) != 0) edge_writer(W);
+		else g->edge_writer_on = 1;
 	}
-	fclose(fz);
-	EPHASE("text + gzip write");
+	EPHASE("text + gzip write (started)");
 	g->num_ed = num_ed;
 	printf("%llu (%llu) edges %llu extra nodes\n", (unsigned long long)num_ed, (unsigned long long)nemit, (unsigned long long)extra);
-	free(rec); free(bases);
-	return num_ed;
+	return num_ed;                                           /* (rec and bases belong to the writer now) */
 }
 
 /* ---- host stand-in for sdt_gpu_edge_ports (sdt-graphcheck, the CPU tests): the same 17-word records from dry_ports ---- */

@@ -662,6 +662,19 @@ graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t 
 	return g;
 }
 
+static void clear_dirty_part(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	graph_t *g = (graph_t *)vc;
+	for (uint64_t k = lo; k < hi; k++) g->dirty[g->dlist[k]] = 0;
+}
+
+void graph_clear_dirty(graph_t *g)
+{
+	if (g->dn < 65536) { for (size_t k = 0; k < g->dn; k++) g->dirty[g->dlist[k]] = 0; return; }
+	par_for(0, g->dn, 1 << 16, clear_dirty_part, g);
+}
+
 void graph_free(graph_t *g)
 {
 	if (!g) return;

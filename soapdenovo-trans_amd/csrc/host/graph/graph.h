@@ -13,6 +13,7 @@
 #define SDT_GRAPH_H
 #include <stdint.h>
 #include <stdio.h>
+#include <pthread.h>
 #include "kw.h"
 
 typedef struct {
@@ -83,6 +84,8 @@ typedef struct graph_s {
 	uint32_t *nb_slot;                 /* per node: 1 + index into nb_pool of its precomputed neighbours, 0 = none */
 	uint64_t *nb_pool;                 /* 8 entries per slot: (neighbour index << 1 | smaller) for LEFT 0..3, RIGHT 0..3 */
 	uint32_t *nb_cnt;                  /* optional, 8 entries per slot: the occurrence counts of those neighbours */
+	pthread_t edge_writer;             /* <prefix>.edge.gz is written in the background (graph_build_edges); graph_edges_join waits */
+	int edge_writer_on;
 } graph_t;
 
 /* keys: nw words per node, most significant first; r_flags as exported (r_links | linear<<24 | deleted<<25 |
@@ -98,6 +101,8 @@ void graph_replay_order(int nw_variant, int nw_keys, int p, const uint64_t *keys
 graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys, const uint32_t *l_links,
                             const uint32_t *r_flags, const uint32_t *count, const uint64_t *set_start);
 void graph_free(graph_t *g);
+/* dirty[dlist[k]] = 0 for the whole list, on all threads (tens of millions of scattered bytes: 90 ms on one thread); dn stays */
+void graph_clear_dirty(graph_t *g);
 /* free() of up to four large blocks on a detached thread (munmap of gigabytes is not free) */
 void graph_free_later(void *a, void *b, void *c, void *d);
 /* optional: called by graph_build once the nodes are in visiting order; returns 0 after filling g->index /
@@ -121,6 +126,8 @@ uint64_t graph_remove_minor_tips(graph_t *g);
  * <prefix>.edge.gz, numbers the edges in visiting order, stamps interior nodes with their edge id.
  * Returns num_ed. */
 uint64_t graph_build_edges(graph_t *g, const char *prefix);
+/* <prefix>.edge.gz is complete when this returns (its writer runs beside whatever the caller does next) */
+void graph_edges_join(graph_t *g);
 const gpatch_t *graph_find_patch(const graph_t *g, const kw_t *canon_kplus1);
 
 /* prlRead2edge (prlRead2path.c:817-1335): reads -> edge paths -> arcs -> <prefix>.preArc */

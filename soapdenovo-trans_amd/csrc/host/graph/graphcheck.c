@@ -55,6 +55,7 @@ int main(int argc, char **argv)
 	graph_remove_minor_tips(G);
 	phase("minor tips");
 	uint64_t ne = graph_build_edges(G, argv[2]);
+	graph_edges_join(G);
 	phase("edges");
 	if (argc > 3) {
 		sdt_cfg cfg;

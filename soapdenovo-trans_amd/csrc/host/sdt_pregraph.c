@@ -1091,6 +1091,7 @@ int main(int argc, char **argv)
 		}
 		phase(host_map ? "read2edge (host)" : "read2edge (GPU)");
 		printf("time spent on mapping reads: %ds\n\n", (int)(time(NULL) - t0));
+		graph_edges_join(G);                                                /* (*.edge.gz was written beside the second read pass) */
 		if (have_nv) { pthread_join(vth_keep, NULL); nv_early = vj_keep->nv; }
 		uint64_t nv = nv_early;
 		if (have_nv) printf("%llu vertex outputed\n", (unsigned long long)nv);
