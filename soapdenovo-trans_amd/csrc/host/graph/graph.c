@@ -629,6 +629,15 @@ static void fo_index(void *vc, uint64_t lo, uint64_t hi, int tid)
 	}
 }
 
+int graph_index_hook_early = 0;
+typedef struct { graph_t *g; int rc; } ih_job;
+static void *index_hook_thread(void *v)
+{
+	ih_job *J = (ih_job *)v;
+	J->rc = graph_index_hook(J->g, graph_index_hook_user);
+	return NULL;
+}
+
 graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys, const uint32_t *l_links,
                             const uint32_t *r_flags, const uint32_t *count, const uint64_t *set_start)
 {
@@ -639,8 +648,6 @@ graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t 
 	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
 	memcpy(g->set_start, set_start, ((size_t)p + 1) * sizeof(uint64_t));
 	fo_ctx F = {g, nw_keys, keys, l_links, r_flags, count};
-	par_for(0, n, 1 << 16, fo_unpack, &F);
-	GB_PHASE("unpack");
 	const int wide = n >= 0xFFFFFFFEULL || getenv("SDT_WIDE_INDEX") != NULL;
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
@@ -649,8 +656,17 @@ graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t 
 		if (!g->index64) { printf("out of memory for the node index (%llu entries)\n", (unsigned long long)cap); exit(1); }
 		g->index_mask = cap - 1;
 	}
-	if (graph_index_hook && graph_index_hook(g, graph_index_hook_user) == 0) {
-		GB_PHASE("index (device)");
+	/* the device builds the index from ITS copy of the node order and sends it over while the host's threads unpack the nodes
+	 * (graph_index_hook_early: the hook reads nothing of nodes[]) */
+	ih_job IH = {g, 1};
+	pthread_t ih;
+	const int early = graph_index_hook && graph_index_hook_early && pthread_create(&ih, NULL, index_hook_thread, &IH) == 0;
+	par_for(0, n, 1 << 16, fo_unpack, &F);
+	GB_PHASE("unpack");
+	if (early) pthread_join(ih, NULL);
+	else if (graph_index_hook) IH.rc = graph_index_hook(g, graph_index_hook_user);
+	if (graph_index_hook && IH.rc == 0) {
+		GB_PHASE(early ? "index (device, beside the unpacking): the rest" : "index (device)");
 		return g;
 	}
 	if (!wide) {

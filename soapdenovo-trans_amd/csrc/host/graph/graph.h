@@ -109,6 +109,9 @@ void graph_free_later(void *a, void *b, void *c, void *d);
  * g->index_mask itself (the GPU host does, from the device's copy of the nodes), non-zero to let the host build it */
 extern int (*graph_index_hook)(graph_t *g, void *user);
 extern void *graph_index_hook_user;
+/* non-zero: the hook reads nothing of nodes[] (the device has the node order already): graph_from_ordered runs it on a thread of its
+ * own beside the unpacking of the nodes */
+extern int graph_index_hook_early;
 
 /* hash_kmer (hashFunction.c:83-122) for an nw-word variant */
 uint64_t ref_hash_kmer(const kw_t *k, int nw);

@@ -923,6 +923,7 @@ int main(int argc, char **argv)
 			Dp->gpu = gpu; Dp->indexed = 1; Dp->by_index = 1;
 			graph_index_hook = dev_index_hook;
 			graph_index_hook_user = Dp;
+			graph_index_hook_early = getenv("SDT_INDEX_INLINE") == NULL;      /* (the device numbered the nodes itself) */
 			G = graph_from_ordered(K, nwv, nwk, threads, n, keys, ll, rf, cnt, set_start);
 			graph_free_later(keys, ll, rf, cnt);
 			free(set_start);

@@ -2231,6 +2231,8 @@ int sdt_gpu_reset(sdt_ctx *c)
 	if (!c)
 		return fail(SDT_EINVAL, "ctx is NULL");
 	HIPCHK(hipSetDevice(c->device));
+	if ((c->flags & SDT_FLAG_TRACK_FIRST) && !c->d_first)           // (dropped once the device had laid the graph out: sdti::drop_first)
+		HIPCHK(hipMalloc((void **)&c->d_first, c->slots * sizeof(uint64_t)));
 	int rc = launch_clear(c, c->d_ent, c->d_aux, c->d_first, c->slots);
 	if (rc != SDT_OK)
 		return rc;
@@ -2915,16 +2917,42 @@ int sdt_gpu_map_reads(sdt_ctx *c, uint64_t *reads_processed, uint64_t *arcs)
 		HIPCHK(hipMemset2DAsync(&c->d_arcs[0].first, sizeof(ArcEnt), 0xFF, sizeof(unsigned long long), c->arc_slots, c->stream));
 		HIPCHK(hipMemsetAsync(&c->d_stats->scratch, 0, sizeof(unsigned long long), c->stream));
 		uint64_t reads = 0;
+		// One lane per read and ~120 dependent look-ups per lane: a kept batch of the CLI (10^5 reads) is 1 600 waves, six per CU, and
+		// its launch lasts as long as the longest chain (0.4 ms: 1 900 launches one after the other took 770 ms at 200 M reads).  The
+		// batches are independent (arcs are atomic adds / mins): several streams keep several launches on the device at a time.
+		constexpr int NS = 6;
+		hipStream_t ms[NS];
+		hipEvent_t ready, done[NS];
+		int ns = c->kept.size() > 8 ? NS : 1;
+		if (ns > 1) {
+			if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) ns = 1;
+			for (int i = 0; i < ns && ns > 1; i++)
+				if (hipStreamCreateWithFlags(&ms[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+					return fail(SDT_EHIP, "streams for the second read pass");
+		}
+		if (ns > 1) {
+			HIPCHK(hipEventRecord(ready, c->stream));
+			for (int i = 0; i < ns; i++) HIPCHK(hipStreamWaitEvent(ms[i], ready, 0));
+		}
+		size_t bi = 0;
 		for (auto &kb : c->kept) {
 			const int g = scan_grid(c, kb.nreads);
-			if (c->nw == 1) hipLaunchKernelGGL(k_map_reads<1>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<1>(c), (const PatchEnt<1> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
-			else if (c->nw == 2) hipLaunchKernelGGL(k_map_reads<2>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<2>(c), (const PatchEnt<2> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
-			else hipLaunchKernelGGL(k_map_reads<4>, dim3(g), dim3(TPB), 0, c->stream, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<4>(c), (const PatchEnt<4> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			const hipStream_t st = ns > 1 ? ms[bi++ % (size_t)ns] : c->stream;
+			if (c->nw == 1) hipLaunchKernelGGL(k_map_reads<1>, dim3(g), dim3(TPB), 0, st, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<1>(c), (const PatchEnt<1> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			else if (c->nw == 2) hipLaunchKernelGGL(k_map_reads<2>, dim3(g), dim3(TPB), 0, st, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<2>(c), (const PatchEnt<2> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
+			else hipLaunchKernelGGL(k_map_reads<4>, dim3(g), dim3(TPB), 0, st, kb.d_words, kb.d_offs, kb.nreads, c->K, table_of<4>(c), (const PatchEnt<4> *)c->d_patch, c->patch_slots - 1, c->d_arcs, c->arc_slots - 1, kb.ord_base, kb.ord_stride, c->d_stats);
 			HIPCHK(hipGetLastError());
 			reads += kb.nreads;
 		}
+		if (ns > 1) {
+			for (int i = 0; i < ns; i++) { HIPCHK(hipEventRecord(done[i], ms[i])); HIPCHK(hipStreamWaitEvent(c->stream, done[i], 0)); }
+		}
 		HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
+		if (ns > 1) {
+			for (int i = 0; i < ns; i++) { (void)hipStreamDestroy(ms[i]); (void)hipEventDestroy(done[i]); }
+			(void)hipEventDestroy(ready);
+		}
 		if (c->h_stats->scratch)
 			return fail(SDT_ESTATE, "%llu reads hold a k-mer that is not in the node table (different reads than pass 1?)",
 			            (unsigned long long)c->h_stats->scratch);
@@ -3690,6 +3718,15 @@ sdti::GraphView sdti::graph_view(sdt_ctx *c)
 }
 
 int sdti::sync_stats(sdt_ctx *c) { return ::sync_stats(c); }
+
+// the first-occurrence ordinals have done their work (the device has the visiting order): 8 bytes per table slot go back to the arena
+int sdti::drop_first(sdt_ctx *c)
+{
+	HIPCHK(hipSetDevice(c->device));
+	if (c->d_first) { HIPCHK(hipFree(c->d_first)); c->d_first = nullptr; }
+	if (c->bm.tab.first) { HIPCHK(hipFree(c->bm.tab.first)); c->bm.tab.first = nullptr; }
+	return SDT_OK;
+}
 
 int sdti::release_pass1(sdt_ctx *c)
 {

@@ -337,7 +337,9 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	// per OLD slot of a growth: time and home; per new slot: the word a round took out of it; per entry: the two lists of the rounds
 	// (an entry whose time changed is listed once)
 	// (sdt_append.cuh: the lists are written in chunks of AP_CH entries per wave, the open chunk of every wave has unused slots)
-	const unsigned long long list_chunks = (m + 1) / (AP_CH - 64) + 1 + (unsigned long long)v.cu_count * 8 * (TPB / 64), list_cap = list_chunks * AP_CH;
+	// A round lists the entries whose time changed: a fifth of the entries of a growth in round 0 (tools/replay_fixed_point.c), i.e. an
+	// eighth of all keys when the largest set grows; room for a quarter of all keys (past that: SDT_ELIMIT, the caller replays on the host)
+	const unsigned long long list_chunks = (m / 4 + 1) / (AP_CH - 64) + 1 + (unsigned long long)v.cu_count * 8 * (TPB / 64), list_cap = list_chunks * AP_CH;
 	GCHK(S.alloc(&d_time, (tab_total + 1) * 8)); GCHK(S.alloc(&d_home_slot, (tab_total + 1) * 4)); GCHK(S.alloc(&d_saved, (tab_total + 1) * 8));
 	GCHK(S.alloc(&d_list[0], list_cap * 8)); GCHK(S.alloc(&d_list[1], list_cap * 8)); GCHK(S.alloc(&d_round, sizeof(RpRound)));
 	GCHK(S.alloc(&d_home, m * 4)); GCHK(S.alloc(&d_sets, (size_t)p * sizeof(RpSet))); GCHK(S.alloc(&d_pre, (size_t)(p + 1) * 8)); GCHK(S.alloc(&d_flags, 4));
@@ -482,6 +484,9 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	if (*v.d_idx) { (void)hipFree(*v.d_idx); *v.d_idx = nullptr; }
 	*v.idx_slots = *v.idx_n = 0;
 	if (gx->d_slot_of) { (void)hipFree(gx->d_slot_of); gx->d_slot_of = nullptr; gx->n_nodes = 0; }
+	// the replay is through (every limit it can run into lies behind): the first-occurrence ordinals have done their work, and the
+	// node index is exactly as large -- 8 bytes per table slot that it finds in the arena instead of asking the driver
+	if (!getenv("SDT_KEEP_FIRST")) { rc = sdti::drop_first(c); if (rc != SDT_OK) return rc; }
 	uint64_t *d_idx, *d_slot_of;
 	GCHK(S.alloc(&d_idx, v.slots * 8)); GCHK(S.alloc(&d_slot_of, m * 8));
 	GCHK(hipMemsetAsync(d_idx, 0xFF, v.slots * 8, v.stream));

@@ -82,6 +82,7 @@ inline int scan_grid(int cu_count, uint64_t items)
 
 int sync_stats(sdt_ctx *c);        // drain + copy the device counters to h_stats (SDT_EFULL when a probe failed)
 int release_pass1(sdt_ctx *c);     // pass 1 is over: give the pools of the locality pipeline back to the device
+int drop_first(sdt_ctx *c);        // the visiting order is on the device: the first-occurrence ordinals are not needed any more
 // large transfers between pageable host memory and the device through pinned staging buffers filled / drained by a few threads
 int h2d_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
 int d2h_big(hipStream_t copy_stream, void *dst, const void *src, size_t bytes);
