@@ -250,7 +250,8 @@ int sdt_gpu_import_paths(sdt_ctx *ctx, const uint64_t *keys, const uint64_t *pat
  * sdt_gpu_build_edges left on the device.  map_reads then replays parse1read (:617-789),
  * search1kmerPlus (:575-615) and the arc counting (:190-241,415-430) over the kept reads; export_arcs returns
  * every arc with its multiplicity and the ordinal of its first appearance ((read ordinal << 16) | item index):
- * per from-edge the reference prints arcs most-recent-first-appearance first (:427-428,472-496). */
+ * per from-edge the reference prints arcs most-recent-first-appearance first (:427-428,472-496) -- the arrays come in that order
+ * (from ascending, first appearance descending) since round 5. */
 int sdt_gpu_load_paths(sdt_ctx *ctx, const uint64_t *keys, const uint64_t *path_words, uint64_t n,
                        const uint64_t *patch_keys, const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed);
 int sdt_gpu_map_reads(sdt_ctx *ctx, uint64_t *reads_processed, uint64_t *arcs);
@@ -329,7 +330,10 @@ int sdt_gpu_layout_apply(sdt_ctx *ctx, const uint64_t *order, uint64_t n);
  *                   twenty rounds of priority insertion (csrc/sdt_graph_kernels.cuh; tools/replay_fixed_point.c checks the
  *                   formulation against the sequential emulation).  small_init != 0: the sets of the 63mer / 127mer variants
  *                   start at 3 slots (`-a`, prlHashReads.c:404-413).  SDT_EINVAL when a limit is passed (2^32 nodes, a set's table
- *                   of 2^32 slots, the packed table word): use the two-step form with the host's replay then. */
+ *                   of 2^32 slots, the packed table word): use the two-step form with the host's replay then.
+ *                   Round 5: SDT_ELIMIT for those limits and for a growth that does not settle; the rounds are incremental (only the
+ *                   stretch from a changed entry's home to the end of its cluster is laid out again); on success the first-occurrence
+ *                   ordinals are dropped (8 bytes per table slot: layout_sorted_keys / export_nodes(first) return SDT_ESTATE after). */
 int sdt_gpu_layout_on_device(sdt_ctx *ctx, int p, int nw_variant, int small_init, uint64_t *set_start, uint64_t *n);
 int sdt_gpu_export_ordered(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32_t *r_flags, uint32_t *count, uint64_t n);
 int sdt_gpu_update_nodes_by_index(sdt_ctx *ctx, const uint64_t *node, const uint32_t *l_links, const uint32_t *r_flags, uint64_t n);

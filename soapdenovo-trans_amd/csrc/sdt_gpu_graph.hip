@@ -798,7 +798,9 @@ int sdt_gpu_minor_out_labelled(sdt_ctx *c, double threshold, uint64_t *n_junctio
 	GCHK(S.alloc(&d_need, nn + 1)); GCHK(S.alloc(&d_flag, nn + 1));
 	hipLaunchKernelGGL(k_uf_init, dim3(sdti::scan_grid(v.cu_count, nn + 1)), dim3(TPB), 0, v.stream, parent, nn + 1);
 	const int g = sdti::scan_grid(v.cu_count, v.slots);
-	uint64_t cap = nn / 6 + 4096;
+	// (one node in twenty has a record in the transcriptome jobs measured; the chunks add a third: room for one in sixteen, a second
+	// attempt with what the first one counted otherwise)
+	uint64_t cap = nn / 16 + 4096;
 	uint64_t *d_rec = nullptr;
 	ApBuf B;
 	for (int attempt = 0; attempt < 2; attempt++) {
