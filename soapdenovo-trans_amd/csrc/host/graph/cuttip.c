@@ -1104,6 +1104,22 @@ static void tc_run(void *vc, uint64_t lo, uint64_t hi, int tid)
 	tl_comp = &C;
 	for (uint64_t k = lo; k < hi; k++) {
 		const uint64_t c = T->corder[k];
+		/* almost all components hold one to four walks, so the prefetch inside comp_sweep (four records ahead) never fires: the
+		 * nodes of the components eight further on are asked for here (components of a size class come in ascending order:
+		 * cstart[] and rec[] are read almost sequentially, nodes[] and dirty[] are the random accesses) */
+		if (k + 8 < hi) {
+			const uint64_t c8 = T->corder[k + 8];
+			const uint64_t *r8 = T->rec + 3 * T->cstart[c8];
+			uint64_t n8 = T->cstart[c8 + 1] - T->cstart[c8];
+			if (n8 > 4) n8 = 4;
+			for (uint64_t j = 0; j < n8; j++) {
+				const uint64_t tipn = CW_NODE(r8, j);
+				__builtin_prefetch(&g->nodes[tipn]);
+				__builtin_prefetch((const char *)&g->nodes[tipn] + 40);
+				__builtin_prefetch(&g->nodes[r8[3 * j + 1]]);
+				__builtin_prefetch(&g->dirty[tipn]);
+			}
+		}
 		C.rec = T->rec + 3 * T->cstart[c];
 		C.n = T->cstart[c + 1] - T->cstart[c];
 		C.heap.n = C.behind.n = C.dyn.n = C.vis.n = 0;

@@ -42,6 +42,7 @@ ap.add_argument("--ingest-probe", action="store_true", help="only time --hash-on
 ap.add_argument("--env-runs", default="", help="measurement: run sdt-pregraph once per variant 'name:K=V,K=V;name2:...' (environment switches of the library / CLI), report walls and phase lines, and stop")
 ap.add_argument("--also-cli-args", default="", help="run sdt-pregraph once more with these extra arguments (e.g. '--gpus 4 --share-device') and compare its five files with the first run's")
 ap.add_argument("--gen-only", default="", help="write the FASTQ files and lib.cfg into this directory, print the sdt-pregraph command line and stop (the directory is kept: for runs under rocprofv3, which wants the program itself after --)")
+ap.add_argument("--pause", type=float, default=0.0, help="seconds to wait between the runs of --runs (the driver clears the device memory a process held: a run that starts right after another one may wait for that in hipInit / hipMalloc)")
 ap.add_argument("--runs", type=int, default=1, help="run sdt-pregraph this many times (page cache, first-touch effects): the fastest is reported, all walls are listed")
 args = ap.parse_args()
 
@@ -242,6 +243,8 @@ try:
         raise SystemExit(0)
     walls, r = [], None
     for _run in range(max(1, args.runs)):
+        if _run and args.pause > 0:
+            time.sleep(args.pause)
         t0 = time.time()
         try:
             rk = subprocess.run([ours, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(args.K), "-p", str(args.p), "-o",

@@ -39,8 +39,9 @@ E
   SDT_PASS1_TABLE=log run C5_400M_k31_d1_sigma2.5_nodelog --reads 400000000 --sigma 2.5 --d 1 --cpu-sample 0 --extras 0
   # wall clock: BASELINE's layout (paired-end files) at 200 M reads, ours only, three runs; 20 M reads against the reference on the same
   # box, and the same 20 M reads once more with --gpus 4 (four ranks on the one GPU: shared-memory transport)
-  timeout 600 python tools/e2e_pregraph.py --reads 200000000 --p 16 --T 20000 --layout pe --skip-ref --timeout 200 --runs 3 > $O/e2e_pregraph_200M_k31_p16_pe_ours_only.json 2> $O/e2e_200M.err
+  timeout 700 python tools/e2e_pregraph.py --reads 200000000 --p 16 --T 20000 --layout pe --skip-ref --timeout 200 --runs 4 --pause 20 > $O/e2e_pregraph_200M_k31_p16_pe_ours_only.json 2> $O/e2e_200M.err
   timeout 1200 python tools/e2e_pregraph.py --reads 20000000 --p 16 --T 20000 --layout pe --timeout 600 --runs 2 --also-cli-args "--gpus 4 --share-device" > $O/e2e_pregraph_20M_k31_p16_pe.json 2> $O/e2e_20M.err
+  timeout 500 bash tools/e2e_profile.sh 200000000 pe $O/e2e_prof > $O/e2e_prof.log 2>&1; tail -12 $O/e2e_prof.log | cut -c1-130
   python3 - $O <<'E'
 import json, sys
 o = sys.argv[1]
