@@ -1582,7 +1582,7 @@ static int emu_minor_out(graph_t *g, double threshold, uint64_t **records, uint6
 }
 
 /* CPU stand-in for removeMinorOut's commit on the device (sdt_gpu_minor_out_commit_begin / _finish): the dry run's records made by
- * the host; the components of at most SDT_COMMIT_MAX_COMPONENT visits (default 2048, as in sdt-pregraph) are committed here and
+ * the host; the components of at most SDT_COMMIT_MAX_COMPONENT visits (default 3072, as in sdt-pregraph) are committed here and
  * now -- by the labelled commit on nodes[] itself, which is what the device's commit + graph_apply_written leave behind; their
  * dirty marks are the caller's to clear, as after a mirror sync --, the longer ones are handed to the caller: their junction records
  * in order, then the records of the neighbours they may cut.  The CPU suite runs every golden through the caller's half this way. */
@@ -1592,7 +1592,7 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 {
 	uint64_t *rec = NULL, nj = 0, nr = 0;
 	if (emu_minor_out(g, threshold, &rec, &nj, &nr) != 0) return 1;
-	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 2048;
+	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
 	uint8_t *big = (uint8_t *)calloc(g->n + 1, 1);                      /* by label (a node index) */
 	uint64_t nbig = 0;
 	for (uint64_t r0 = 0; r0 < nj;) {

@@ -463,7 +463,9 @@ static int dev_minor_out_commit_begin_hook(graph_t *g, double threshold, uint64_
 	if (sdt_gpu_minor_out_labelled(D->gpu, threshold, &nj, &nr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_labelled: %s\n", sdt_gpu_last_error()); return 1; }
 	const double t1 = now_ms();
 	/* one lane walks a component at about a microsecond per dependent access (~100 us per visit); a host thread takes ~150 ns */
-	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 2048;
+	/* (the device's lanes and the host's threads work side by side: at 200 M reads 1536 / 2048 / 2560 / 3072 / 4096 visits per component gave
+	 * 983 / 895 / 829 / 813 / 1020 ms for the whole pass -- past 3072 the host waits for the longest lane, profiles/r5/README.md) */
+	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
 	if (sdt_gpu_minor_out_commit_begin(D->gpu, threshold, max_comp, &largest, &nsk, &nskr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_commit_begin: %s\n", sdt_gpu_last_error()); return 1; }
 	const double t2 = now_ms();
 	uint64_t *sk = (uint64_t *)malloc((nskr + 1) * MO_RW * sizeof(uint64_t));
