@@ -27,6 +27,7 @@ ap.add_argument("--K", type=int, default=31)
 ap.add_argument("--p", type=int, default=8)
 ap.add_argument("--T", type=int, default=2000)
 ap.add_argument("--skip-ref", action="store_true")
+ap.add_argument("--sigma", type=float, default=2.0, help="log-normal sigma of the expression weights (2.5: the skew of SURVEY's C5)")
 ap.add_argument("--timeout", type=int, default=300)
 ap.add_argument("--no-max-rd-len", action="store_true", help="drop max_rd_len from the config (reference default: reads cut to 100)")
 ap.add_argument("--cutoff", type=int, default=0, help="rd_len_cutoff for the library")
@@ -81,7 +82,7 @@ def _fixed_records(letters, first_id, suffix=b""):
 
 def _gen_se_chunk(a):
     path, done, n, seed0, read_len, T = a
-    tx_ = synth.make_transcriptome(T, seed=42)
+    tx_ = synth.make_transcriptome(T, seed=42, sigma=args.sigma)
     codes, _ = synth.sample_reads(*tx_, n_reads=n, read_len=read_len, seed=seed0 + done, err=0.002)
     blob, W = _fixed_records(synth.BASES[codes].reshape(n, read_len), done)
     fd = os.open(path, os.O_WRONLY)
@@ -92,7 +93,7 @@ def _gen_se_chunk(a):
 
 def _gen_pe_chunk(a):
     p1, p2, done, n, seed0, read_len, T = a
-    tx_ = synth.make_transcriptome(T, seed=42)
+    tx_ = synth.make_transcriptome(T, seed=42, sigma=args.sigma)
     (c1, _), (c2, _) = synth.sample_pairs(*tx_, n_pairs=n, read_len=read_len, seed=seed0 + done, err=0.002, avg_ins=300)
     for path, c, suf in ((p1, c1, b"/1"), (p2, c2, b"/2")):
         blob, W = _fixed_records(synth.BASES[c].reshape(n, read_len), done, suf)
@@ -104,7 +105,7 @@ def _gen_pe_chunk(a):
 
 tmp = tempfile.mkdtemp(prefix="sdt_e2e_") if not args.gen_only else (os.makedirs(args.gen_only, exist_ok=True) or args.gen_only)
 try:
-    tx = synth.make_transcriptome(args.T, seed=42)
+    tx = synth.make_transcriptome(args.T, seed=42, sigma=args.sigma)
     fq = os.path.join(tmp, "reads.fq")
     t0 = time.time()
 
