@@ -49,8 +49,87 @@ __global__ void k_gather(const uint4 *a, size_t mask, unsigned long long per_lan
 	if (s == 12345) *sink = s;
 }
 
-int main(void)
+// `box_probe sweep`: the scattered writes alone, on buffers allocated one after the other in ONE process (16 GiB each, some freed in
+// between, some kept), and on footprints of 1 / 4 / 16 GiB of one buffer: does the rate go with the allocation?
+static int sweep(void)
 {
+	hipEvent_t e0, e1;
+	CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+	const size_t big = (size_t)16 << 30;
+	const unsigned long long groups = 40000000ULL;
+	uint4 *keep[6] = {};
+	printf("{\"scatter_sweep_GBps\": [");
+	for (int rep = 0; rep < 6; rep++) {
+		uint4 *a;
+		CHK(hipMalloc(&a, big));
+		CHK(hipMemset(a, rep, big));
+		CHK(hipDeviceSynchronize());
+		float best = 0, ms;
+		double r[3];
+		for (int t = 0; t < 3; t++) {
+			CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_scatter, dim3(2048), dim3(256), 0, 0, a, (uint32_t *)nullptr, groups); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+			CHK(hipEventElapsedTime(&ms, e0, e1));
+			r[t] = (double)groups * 208 / (ms * 1e6);
+			if (r[t] > best) best = (float)r[t];
+		}
+		printf("%s[%.0f, %.0f, %.0f]", rep ? ", " : "", r[0], r[1], r[2]);
+		if (rep & 1) keep[rep] = a; else CHK(hipFree(a));           // (every second buffer stays: the next one gets other pages)
+	}
+	printf("]}\n");
+	for (int i = 0; i < 6; i++) if (keep[i]) CHK(hipFree(keep[i]));
+	return 0;
+}
+
+// `box_probe vmm <granule MiB> <shuffle 0|1>`: the same scattered writes into 16 GiB of virtual addresses backed by physical granules
+// of the given size (hipMemCreate), mapped in the order they were created or in a shuffled order
+static int vmm(size_t gran_mib, int shuffle)
+{
+	hipEvent_t e0, e1;
+	CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+	const size_t big = (size_t)16 << 30;
+	hipMemAllocationProp prop = {};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = 0;
+	size_t min_gran = 0;
+	CHK(hipMemGetAllocationGranularity(&min_gran, &prop, hipMemAllocationGranularityMinimum));
+	size_t gran = gran_mib << 20;
+	if (gran < min_gran) gran = min_gran;
+	gran = (gran + min_gran - 1) / min_gran * min_gran;
+	const size_t n = big / gran;
+	hipMemGenericAllocationHandle_t *h = (hipMemGenericAllocationHandle_t *)malloc(n * sizeof *h);
+	size_t *order = (size_t *)malloc(n * sizeof(size_t));
+	for (size_t i = 0; i < n; i++) { CHK(hipMemCreate(&h[i], gran, &prop, 0)); order[i] = i; }
+	if (shuffle) { uint64_t x = 88172645463325252ULL; for (size_t i = n - 1; i > 0; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; const size_t j = x % (i + 1); const size_t t = order[i]; order[i] = order[j]; order[j] = t; } }
+	void *va = nullptr;
+	CHK(hipMemAddressReserve(&va, big, 0, nullptr, 0));
+	for (size_t i = 0; i < n; i++) CHK(hipMemMap((char *)va + i * gran, gran, 0, h[order[i]], 0));
+	hipMemAccessDesc acc = {};
+	acc.location.type = hipMemLocationTypeDevice;
+	acc.location.id = 0;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	CHK(hipMemSetAccess(va, big, &acc, 1));
+	CHK(hipMemset(va, 3, big));
+	CHK(hipDeviceSynchronize());
+	const unsigned long long groups = 40000000ULL;
+	double r[3];
+	float ms;
+	for (int t = 0; t < 3; t++) {
+		CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_scatter, dim3(2048), dim3(256), 0, 0, (uint4 *)va, (uint32_t *)nullptr, groups); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		CHK(hipEventElapsedTime(&ms, e0, e1));
+		r[t] = (double)groups * 208 / (ms * 1e6);
+	}
+	printf("{\"vmm_granule_MiB\": %zu, \"granules\": %zu, \"shuffled\": %d, \"scatter_GBps\": [%.0f, %.0f, %.0f]}\n", gran >> 20, n, shuffle, r[0], r[1], r[2]);
+	CHK(hipMemUnmap(va, big));
+	for (size_t i = 0; i < n; i++) CHK(hipMemRelease(h[i]));
+	CHK(hipMemAddressFree(va, big));
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc > 1 && argv[1][0] == 's') return sweep();
+	if (argc > 3 && argv[1][0] == 'v') return vmm((size_t)atoi(argv[2]), atoi(argv[3]));
 	unsigned long long *ctr, *sink;
 	CHK(hipMalloc(&ctr, 8)); CHK(hipMalloc(&sink, 8));
 	CHK(hipMemset(ctr, 0, 8));
