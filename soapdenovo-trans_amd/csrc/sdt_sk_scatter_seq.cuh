@@ -146,6 +146,18 @@ template <int RW> __device__ inline void sk_store_record(uint64_t *dst, const ui
 	for (int i = 0; i < RW; i++)
 		dst[i] = rec[i];
 }
+// a record into a slot of a LEVEL-2 chunk: the whole slot is written (a 32-byte slot of a 24-byte record: the fourth word as zero, in
+// one 16-byte store with the third -- every byte of the group's 128-byte line gets written, no block is left half done)
+template <int NW> __device__ inline void sk_store_record2(uint64_t *dst, const uint64_t (&rec)[SkFmt<NW>::REC_WORDS])
+{
+	if constexpr (SkFmt<NW>::REC2_STRIDE == 4 && SkFmt<NW>::REC_WORDS == 3) {
+		ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst);
+		d[0] = make_ulonglong2(rec[0], rec[1]);
+		d[1] = make_ulonglong2(rec[2], 0ULL);
+	} else {
+		sk_store_record<SkFmt<NW>::REC_WORDS>(dst, rec);
+	}
+}
 template <int RW> __device__ inline void sk_load_record(const uint64_t *src, uint64_t (&rec)[RW])
 {
 #pragma unroll

@@ -52,11 +52,22 @@ template <int NW> struct SkFmt {
 	static constexpr int BW = NW == 1 ? 2 : (NW == 2 ? 4 : 6);     // base words: 64 / 128 / 192 bases
 	static constexpr int REC_WORDS = 1 + BW;                       // 24 / 40 / 56 bytes
 	static constexpr int CAP_BASES = 32 * BW;
+	// The slots of a LEVEL-2 chunk.  The memory side works in aligned 64-byte blocks (tools/box_probe.hip `pieces`: scattered writes of
+	// 96 bytes run at 1.43 TB/s, of 128 aligned bytes at 5.2), and the groups of four 24-byte records the level-2 scatter writes are 96
+	// bytes.  SDT_SK_REC2_PAD=1 gives the records 32-byte slots (the fourth word written as zero: a group is one aligned 128-byte line)
+	// -- measured: the level-2 scatter got SLOWER, 64.7 / 66.7 -> 69.4 / 68.6 ms per step (a third more bytes; the kernel is not bound by
+	// the write rate but by its own phases: two barriers and a serial book-keeping section per tile of 512 records at 8 waves per CU).
+	// Kept as a build knob, off.
+#ifndef SDT_SK_REC2_PAD
+#define SDT_SK_REC2_PAD 0
+#endif
+	static constexpr int REC2_STRIDE = (NW == 1 && SDT_SK_REC2_PAD) ? 4 : REC_WORDS;
 };
 constexpr uint64_t SK_MAX_READ_ORDINAL = 1ULL << 34;             // reads of one run the header can number
 constexpr int SK_MAX_READ_LEN = (1 << SK_POSBITS) - 1;                            // positions the header can hold
 
 __host__ __device__ inline int sk_rec_words(int nw) { return nw == 1 ? 3 : (nw == 2 ? 5 : 7); }
+__host__ __device__ inline int sk_rec2_stride(int nw) { return nw == 1 ? SkFmt<1>::REC2_STRIDE : (nw == 2 ? SkFmt<2>::REC2_STRIDE : SkFmt<4>::REC2_STRIDE); }
 
 // longest run a record can hold: n + K - 1 bases + 2 context bases must fit the base words; a power of two
 __host__ __device__ inline int sk_max_run(int K, int nw)

@@ -55,6 +55,14 @@ template <int NW, bool TRACK> struct SkCntGeo {
 #ifndef SDT_SK_L2_TPB
 #define SDT_SK_L2_TPB 512
 #endif
+// the staged form (k_sk_scatter_records_staged, round 5) has no cursor that lanes fight over -- the 1024-lane geometry that lost a chunk
+// in the kernel above (profiles/r3/l2_1024_lane_loss.md) is safe there, and twice the records in flight per CU are worth 6 ms per step
+// (65.2 / 65.8 -> 59.8 / 59.0 ms on the same box): the kernel is bound by its own phases (two barriers and a serial book-keeping
+// section per tile), not by bytes
+#ifndef SDT_SK_L2S_TPB
+#define SDT_SK_L2S_TPB 1024
+#endif
+constexpr int SK_L2S_TPB = SDT_SK_L2S_TPB;
 constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one large workgroup per CU (see sk_split)
 #ifndef SDT_SK_L2_DEPTH
 #define SDT_SK_L2_DEPTH 2
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 			atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
 			uint32_t dchunk, pos;
 			if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, s_cc, dchunk, pos)) {
-				sk_store_record<RW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * RW, rec);
+				sk_store_record2<NW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * SkFmt<NW>::REC2_STRIDE, rec);
 #ifdef SDT_SK_L2_LOG
 				if (g_l2_log) {
 					const unsigned long long at = atomicAdd(g_l2_log, 1ULL);
@@ -543,12 +551,12 @@ template <int NW> struct SkL2Stage {
 };
 
 template <int NW>
-__global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool src, const uint32_t *__restrict__ list1,
+__global__ __launch_bounds__(SK_L2S_TPB) void k_sk_scatter_records_staged(SkPool src, const uint32_t *__restrict__ list1,
                                                                          const SkItem *__restrict__ items, SkPool dst,
                                                                          uint32_t *__restrict__ g_cnt, unsigned long long *__restrict__ g_kmers, Stats *stats)
 {
-	constexpr int RW = SkFmt<NW>::REC_WORDS, S = SkL2Stage<NW>::S, GPC = SkL2Stage<NW>::GPC;
-	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
+	constexpr int RW = SkFmt<NW>::REC_WORDS, RW2 = SkFmt<NW>::REC2_STRIDE, S = SkL2Stage<NW>::S, GPC = SkL2Stage<NW>::GPC;
+	constexpr int CPT = SK_L2S_TPB / SK_CAP1;         // chunks per sweep
 	extern __shared__ unsigned long long s_stage[];  // SK_NB2 x S records
 	__shared__ uint32_t s_cnt[SK_NB2];               // tickets of the running tile (start: the records waiting in the stage)
 	__shared__ uint32_t s_open[SK_NB2];              // open chunk of the sub-bucket (SK_NOCHUNK: none)
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 	__shared__ unsigned long long s_blk;
 	const SkItem it = items[blockIdx.x];
 	const int tid = threadIdx.x;
-	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+	for (int i = tid; i < SK_NB2; i += SK_L2S_TPB) {
 		s_cnt[i] = 0;
 		s_open[i] = SK_NOCHUNK;
 		s_fill[i] = 0;
@@ -581,10 +589,10 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 	auto slot_of = [&](uint32_t open, uint32_t used, uint32_t first_new, uint32_t t) -> uint64_t * {
 		const uint32_t a = (open == SK_NOCHUNK ? (uint32_t)GPC : used) + t / S;
 		if (a < (uint32_t)GPC)
-			return dst.recs + ((size_t)open * SK_CAP2 + a * S + t % S) * RW;
+			return dst.recs + ((size_t)open * SK_CAP2 + a * S + t % S) * RW2;
 		if (first_new == SK_NOCHUNK)
 			return nullptr;
-		return dst.recs + ((size_t)(first_new + (a - GPC) / GPC) * SK_CAP2 + ((a - GPC) % GPC) * S + t % S) * RW;
+		return dst.recs + ((size_t)(first_new + (a - GPC) / GPC) * SK_CAP2 + ((a - GPC) % GPC) * S + t % S) * RW2;
 	};
 	constexpr int D = SDT_SK_L2_DEPTH;
 	const uint32_t slot = (uint32_t)tid % SK_CAP1, cfirst = it.c0 + (uint32_t)tid / SK_CAP1;
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 				const uint32_t g = s_pub_g[b2], G = g >> 8, used = g & 0xFFu;
 				if (t / S < G) {
 					uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], t);
-					if (p) sk_store_record<RW>(p, rec);
+					if (p) sk_store_record2<NW>(p, rec);
 					else failed++;
 				} else {
 					const uint32_t at = t - G * S;
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 					for (int j = 0; j < S - 1; j++)
 						if ((uint32_t)j < f) {
 							uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], (uint32_t)j);
-							if (p) sk_store_record<RW>(p, old[j]);
+							if (p) sk_store_record2<NW>(p, old[j]);
 							else failed++;
 						}
 				}
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 	}
 	__syncthreads();
 	// the records still waiting: a last, partial group; the open chunks' fills; the item's counts
-	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
+	for (int i = tid; i < SK_NB2; i += SK_L2S_TPB) {
 		const uint32_t f = s_fill[i];
 		uint32_t open = s_open[i], used = open == SK_NOCHUNK ? (uint32_t)GPC : s_used[i];
 		if (f) {
@@ -726,7 +734,7 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records_staged(SkPool 
 #pragma unroll
 					for (int w = 0; w < RW; w++)
 						rec[w] = s_stage[((size_t)i * S + j) * RW + w];
-					sk_store_record<RW>(dst.recs + ((size_t)open * SK_CAP2 + used * S + j) * RW, rec);
+					sk_store_record2<NW>(dst.recs + ((size_t)open * SK_CAP2 + used * S + j) * RW2, rec);
 				}
 			} else {
 				failed += f;
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		// A list entry carries the chunk's fill (k_sk_chunk_place): pool.meta is not read here.  (LDS-DMA -- global_load_lds_dword,
 		// no destination register at all -- was tried for both and ran 10..50x slower than no prefetch: profiles/r3.)
 		auto rec_ptr = [&](uint32_t e, uint32_t t) -> const uint64_t * {
-			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * RW;
+			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * SkFmt<NW>::REC2_STRIDE;
 		};
 		auto rec_ok = [&](uint32_t e, uint32_t t) -> bool { return e != SK_NOCHUNK && t % SK_CAP2 <= (e >> SK_LIST2_FILL_SHIFT); };
 		auto ent_row = [&](uint32_t t) -> uint32_t * { return s_ent + (t % 3u) * CPT; };
@@ -1508,7 +1516,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		// A list entry carries the chunk's fill (k_sk_chunk_place): pool.meta is not read here.  (LDS-DMA -- global_load_lds_dword,
 		// no destination register at all -- was tried for both and ran 10..50x slower than no prefetch: profiles/r3.)
 		auto rec_ptr = [&](uint32_t e, uint32_t t) -> const uint64_t * {
-			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * RW;
+			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * SkFmt<NW>::REC2_STRIDE;
 		};
 		auto rec_ok = [&](uint32_t e, uint32_t t) -> bool { return e != SK_NOCHUNK && t % SK_CAP2 <= (e >> SK_LIST2_FILL_SHIFT); };
 		auto ent_row = [&](uint32_t t) -> uint32_t * { return s_ent + (t % 3u) * CPT; };

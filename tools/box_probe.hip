@@ -126,8 +126,48 @@ static int vmm(size_t gran_mib, int shuffle)
 	return 0;
 }
 
+// `box_probe pieces`: the scattered writes with pieces of 96 ... 1536 bytes (L lanes x 16 bytes each, to 2^18 destinations over 16 GiB)
+template <int L>
+__global__ void k_scatter_l(uint4 *dst, unsigned long long groups)
+{
+	const unsigned long long t = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x / L;
+	if (t / L >= stride) return;
+	for (unsigned long long g = t / L; g < groups; g += stride) {
+		const uint32_t b = (uint32_t)(mix(g) & 0x3FFFFu);
+		const uint32_t at = (uint32_t)(mix(g * 0x9E3779B97F4A7C15ULL + b) % (4096u / L));
+		dst[(size_t)b * 4096 + (size_t)at * L + (t % L)] = make_uint4((uint32_t)g, b, at, 0);
+	}
+}
+template <int L> static int pieces_one(uint4 *a, hipEvent_t e0, hipEvent_t e1)
+{
+	const unsigned long long bytes = 8ULL << 30, groups = bytes / (16ULL * L);
+	float ms, best = 1e9f;
+	for (int t = 0; t < 3; t++) {
+		CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_scatter_l<L>, dim3(2048), dim3(256), 0, 0, a, groups); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		CHK(hipEventElapsedTime(&ms, e0, e1));
+		if (ms < best) best = ms;
+	}
+	printf("%s\"%d\": %.0f", L == 1 ? "" : ", ", L * 16, (double)groups * 16 * L / (best * 1e6));
+	return 0;
+}
+static int pieces(void)
+{
+	hipEvent_t e0, e1;
+	CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+	uint4 *a;
+	CHK(hipMalloc(&a, (size_t)16 << 30));
+	CHK(hipMemset(a, 1, (size_t)16 << 30));
+	CHK(hipDeviceSynchronize());
+	printf("{\"scatter_GBps_by_piece_bytes\": {");
+	if (pieces_one<1>(a, e0, e1) || pieces_one<2>(a, e0, e1) || pieces_one<3>(a, e0, e1) || pieces_one<4>(a, e0, e1) || pieces_one<6>(a, e0, e1) || pieces_one<8>(a, e0, e1) || pieces_one<12>(a, e0, e1) || pieces_one<16>(a, e0, e1) || pieces_one<24>(a, e0, e1) || pieces_one<32>(a, e0, e1) || pieces_one<64>(a, e0, e1) || pieces_one<96>(a, e0, e1)) return 1;
+	printf("}}\n");
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
+	if (argc > 1 && argv[1][0] == 'p') return pieces();
 	if (argc > 1 && argv[1][0] == 's') return sweep();
 	if (argc > 3 && argv[1][0] == 'v') return vmm((size_t)atoi(argv[2]), atoi(argv[3]));
 	unsigned long long *ctr, *sink;
