@@ -80,10 +80,18 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=False):
-    """Rank 0, N=1 only.  Time the reference binary (oracle/_ref, kind 'reference') on the first
-    `sample_reads` reads of the same workload, from process start until <prefix>.kmerFreq is complete
-    (= parse + chop + hash + mark, the part of pregraph this repo replaces); fall back to the oracle port."""
+def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=False, e2e=True, gpu_hist=None, ours_exe=None):
+    """Rank 0, N=1 only.  Returns (cpu_baseline, e2e).
+
+    cpu_baseline: the reference binary (oracle/_ref, kind 'reference') on the first `sample_reads` reads of the same workload,
+    timed from process start until <prefix>.kmerFreq is complete (= parse + chop + hash + mark, the part of pregraph the bench's
+    step replaces); the GPU's 257 bins for the SAME reads are compared with the file the reference wrote
+    (`kmerfreq_identical`).  Falls back to the oracle port when the binary is not there.
+
+    e2e (BASELINE.json north_star: ">= 10x the reference CPU pregraph wall-clock ... with bit-identical *.kmerFreq"; the reference's
+    phases: pregraph.c:61-110): the same reference run is left to finish (all five files), `sdt-pregraph` runs on the same
+    config, and the five files are compared byte for byte (edge.gz after gunzip: the gzip header carries no data)."""
+    import gzip
     import oracle_binding as ob
 
     n = min(sample_reads, n_reads_total)
@@ -97,7 +105,8 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=Fals
 
     kmers = n * (L - K + 1)
     cores = usable_cpus()
-    exe = ob.ref_binary(31 if K <= 31 else 127)
+    variant = 31 if K <= 31 else 127
+    exe = ob.ref_binary(variant)
     if exe and os.access(exe, os.X_OK):
         from soapdenovo_trans_amd import synth
         tmp = tempfile.mkdtemp(prefix="sdt_cpu_")
@@ -112,48 +121,110 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=Fals
             if os.path.getsize(fq) % 32768 == 0:       # reference hangs on exact multiples (survey q9)
                 with open(fq, "ab") as fo:
                     fo.write(b"\n")
-            synth.write_config(os.path.join(tmp, "lib.cfg"), L, fastq=[fq])
-            def run_ref(p_threads):
+            cfg = os.path.join(tmp, "lib.cfg")
+            synth.write_config(cfg, L, fastq=[fq])
+
+            def run_ref(p_threads, to_the_end):
                 """one run of the reference: (seconds from process start until *.kmerFreq is complete, the reference's own
-                'time spent on hash reads' in whole seconds or None)"""
-                out = os.path.join(tmp, f"out_p{p_threads}")
+                'time spent on hash reads' in whole seconds or None, seconds until the process ended or None, its stdout,
+                the bytes of its *.kmerFreq)"""
+                out = os.path.join(tmp, f"ref_p{p_threads}")
                 log_path = out + ".stdout"
                 t0 = time.time()
+                t1 = t2 = None
                 with open(log_path, "wb") as lo:
-                    proc = subprocess.Popen([exe, "pregraph", "-s", os.path.join(tmp, "lib.cfg"), "-K", str(K), "-p",
+                    proc = subprocess.Popen([exe, "pregraph", "-s", cfg, "-K", str(K), "-p",
                                              str(p_threads), "-o", out], stdout=lo, stderr=subprocess.DEVNULL)
                     kf = out + ".kmerFreq"
-                    t1 = None
                     while proc.poll() is None and time.time() - t0 < 1200:
-                        if os.path.exists(kf) and os.path.getsize(kf) > 0:
+                        if t1 is None and os.path.exists(kf) and os.path.getsize(kf) > 0:
                             with open(kf, "rb") as fi:
                                 if fi.read().count(b"\n") >= 255:
                                     t1 = time.time()
-                                    break
+                                    if not to_the_end:
+                                        break
                         time.sleep(0.02)
                     if proc.poll() is None:
-                        proc.kill()           # exact child we started; the later phases are out of scope here
+                        proc.kill()           # exact child we started (the later phases are not wanted, or it hangs)
+                    elif proc.returncode == 0:
+                        t2 = time.time()
+                        if t1 is None:
+                            t1 = t2
                     proc.wait()
                 hash_s = None
-                for line in open(log_path, errors="replace"):
+                text = open(log_path, errors="replace").read()
+                for line in text.splitlines():
                     if line.startswith("time spent on hash reads:"):       # prlHashReads.c:623 (whole seconds)
                         hash_s = int(line.split(":")[1].split("s")[0])
-                return (None if t1 is None else t1 - t0), hash_s
+                kfb = open(kf, "rb").read() if t1 is not None else None
+                return (None if t1 is None else t1 - t0), hash_s, (None if t2 is None else t2 - t0), text, kfb
 
             p_threads = min(cores, 64)
-            wall, hash_s = run_ref(p_threads)
+            want_e2e = bool(e2e and ours_exe and os.access(ours_exe, os.X_OK))
+            wall, hash_s, ref_total, ref_stdout, ref_kf = run_ref(p_threads, want_e2e)
             if wall is not None:
                 res = {"value": kmers / wall, "unit": "kmers/s", "cores": p_threads, "kind": "reference",
                        "sample": f"first {n} reads ({kmers} k-mers, 1/{max(n_reads_total // max(n, 1), 1)} of the workload) as FASTQ; reference "
                                  f"SOAPdenovo-Trans pregraph -K {K} -p {p_threads}, process start until "
                                  f"*.kmerFreq written ({wall:.2f} s)",
                        "hash_reads_s": hash_s,
-                       "hash_reads_kmers_per_s": None if not hash_s else kmers / hash_s}
+                       "hash_reads_kmers_per_s": None if not hash_s else kmers / hash_s,
+                       "kmerfreq_identical": None}
+                if gpu_hist is not None:
+                    # the bench's own kernels on the very reads the reference just counted: bins 1..255 as freqStat prints them
+                    # (prlHashReads.c:994-1023)
+                    try:
+                        h = gpu_hist(n)
+                        res["kmerfreq_identical"] = bool(b"".join(b"%d\n" % int(v) for v in h[1:256]) == ref_kf)
+                    except Exception as ex:
+                        log("kmerFreq comparison failed:", repr(ex))
                 if also_p8 and p_threads != 8:
-                    w8, h8 = run_ref(8)
+                    w8, h8, _, _, _ = run_ref(8, False)
                     res["p8"] = {"value": None if w8 is None else kmers / w8, "cores": 8, "wall_s": w8, "hash_reads_s": h8,
                                  "hash_reads_kmers_per_s": None if not h8 else kmers / h8}
-                return res
+                e2e_res = None
+                if want_e2e and ref_total is not None:
+                    e2e_res = {"reads": n, "read_len": L, "K": K, "kmers": kmers, "threads": p_threads,
+                               "ref_wall_s": round(ref_total, 2),
+                               "ref_cmd": f"SOAPdenovo-Trans-{variant}mer pregraph -s lib.cfg -K {K} -p {p_threads} -o ref",
+                               "ref_phase_lines": [l for l in ref_stdout.splitlines() if l.startswith("time spent")]}
+                    ours_out = os.path.join(tmp, "ours")
+                    walls, rk = [], None
+                    for _ in range(2):
+                        t0 = time.time()
+                        rk = subprocess.run([ours_exe, "pregraph", "-s", cfg, "-K", str(K), "-p", str(p_threads), "-o", ours_out,
+                                             "--max-k", str(variant)], capture_output=True, text=True, timeout=600,
+                                            env=dict(os.environ, SDT_TIMING="1"))
+                        walls.append(round(time.time() - t0, 3))
+                        if rk.returncode != 0:
+                            break
+                    e2e_res["ours_cmd"] = f"sdt-pregraph pregraph -s lib.cfg -K {K} -p {p_threads} -o ours --max-k {variant}"
+                    e2e_res["ours_rc"] = rk.returncode
+                    e2e_res["ours_walls_s"] = walls
+                    if rk.returncode == 0:
+                        e2e_res["ours_wall_s"] = max(walls)          # the slower of two runs: nothing is warmed up for the first
+                        e2e_res["speedup"] = round(ref_total / max(walls), 2)
+                        same = {}
+                        for ext in ("kmerFreq", "vertex", "preGraphBasic", "preArc"):
+                            a, b = ours_out + "." + ext, os.path.join(tmp, f"ref_p{p_threads}.{ext}")
+                            same[ext] = os.path.exists(a) and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()
+                        try:
+                            same["edge"] = (gzip.open(ours_out + ".edge.gz").read() ==
+                                            gzip.open(os.path.join(tmp, f"ref_p{p_threads}.edge.gz")).read())
+                        except OSError:
+                            same["edge"] = False
+                        e2e_res["identical"] = same
+                        e2e_res["file_bytes"] = {ext: os.path.getsize(ours_out + "." + ext) for ext in
+                                                 ("kmerFreq", "vertex", "preGraphBasic", "preArc", "edge.gz") if os.path.exists(ours_out + "." + ext)}
+                        e2e_res["ours_phase_lines"] = [l for l in rk.stdout.splitlines() if l.startswith("time spent")]
+                        e2e_res["ours_phase_ms"] = [l.replace("[sdt-pregraph] ", "") for l in rk.stderr.splitlines()
+                                                    if l.startswith("[sdt-pregraph]")]
+                    else:
+                        e2e_res["stderr_tail"] = rk.stderr[-1500:]
+                    e2e_res["note"] = ("whole pregraph stage, process start to exit, same FASTQ and config on the same box: the reference on "
+                                       f"{p_threads} host threads against sdt-pregraph on one MI355X + the same host threads; five output files "
+                                       "compared byte for byte (edge.gz by content)")
+                return res, e2e_res
             log("reference binary did not produce kmerFreq; falling back to the oracle port")
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -164,10 +235,16 @@ def cpu_baseline(words_dev, n_reads_total, L, K, sample_reads, log, also_p8=Fals
     offs = (np.arange(n + 1, dtype=np.uint64) * L)
     t0 = time.time()
     o.add_reads(codes, offs)
-    o.mark()
+    ohist, _ = o.mark()
     dt = time.time() - t0
-    return {"value": kmers / dt, "unit": "kmers/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} reads ({kmers} k-mers), oracle/sdt_oracle.c single thread ({dt:.2f} s)"}
+    res = {"value": kmers / dt, "unit": "kmers/s", "cores": 1, "kind": "port",
+           "sample": f"first {n} reads ({kmers} k-mers), oracle/sdt_oracle.c single thread ({dt:.2f} s)", "kmerfreq_identical": None}
+    if gpu_hist is not None:
+        try:
+            res["kmerfreq_identical"] = bool((np.asarray(gpu_hist(n), dtype=np.int64) == np.asarray(ohist, dtype=np.int64)).all())
+        except Exception as ex:
+            log("kmerFreq comparison failed:", repr(ex))
+    return res, None
 
 
 def main():
@@ -184,6 +261,8 @@ def main():
     ap.add_argument("--d", type=int, default=0, help="-d: also run the low-coverage filter (k_delow) in every step")
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed on the CPU baseline (0 = skip); the default keeps the reference at ~25 s of wall clock on 16 cores")
     ap.add_argument("--cpu-p8", action="store_true", help="cpu_baseline: also time the reference with its default -p 8")
+    ap.add_argument("--e2e", type=int, default=1, help="N=1: let the reference finish its whole pregraph on the CPU sample, run sdt-pregraph on "
+                                                       "the same config and compare the five files (0 = skip: the reference is stopped at *.kmerFreq)")
     ap.add_argument("--est-distinct", type=int, default=0)
     ap.add_argument("--pipeline", choices=["auto", "direct", "superkmer"], default="auto",
                     help="pass-1 kernel family: 'direct' = one device atomic per occurrence (k_count_reads); 'superkmer' = "
@@ -348,7 +427,7 @@ def main():
     stage_ms, sk_counters = g.stage_times()
     kms, launches, _ = g.kernel_time(reset=True)
     log("table slots:", g.table_slots())
-    log("stage ms per step [direct, sk scatter, sk split, sk count, sk fold]:", [round(x / args.steps, 2) for x in stage_ms],
+    log("stage ms per step [direct, sk scatter, sk split, sk count]:", [round(x / args.steps, 2) for x in stage_ms[:4]],
         {k: v for k, v in sk_counters.items() if "ticks" not in k or v})
     ms_per_step = dt / args.steps * 1e3
     value = kmers_total * args.steps / dt
@@ -368,12 +447,12 @@ def main():
                 "traffic_unit": "HBM bytes per launch, a LOWER bound (FETCH_SIZE x2 for the record-streaming kernels + WRITE_SIZE PMC passes of this workload, this build; FETCH_SIZE under-reports wide coalesced reads on gfx950)",
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(B * per_launch_kmers),
-                "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records + k_sk_count + the fold of the node log "
-                           "(descriptor sort + k_bm_finalize; every k-mer goes through all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
+                "kernel": ("pass 1 = k_sk_scatter_reads_seq (or k_sk_scatter_reads) + chunk lists + k_sk_scatter_records_staged + k_sk_count_flat "
+                           "(every k-mer goes through all of them; a 'launch' = one batch through the pipeline)") if pipeline else "k_count_reads",
                 "bytes_per_kmer": round(B, 3), "launches": int(batches * args.steps),
                 "avg_launch_ms": round(kms / (batches * args.steps), 4), "kernel_ms_per_step": round(kms / args.steps, 3),
                 "stage_ms_per_step": {"scatter": round(stage_ms[1] / args.steps, 2), "split": round(stage_ms[2] / args.steps, 2),
-                                      "count": round(stage_ms[3] / args.steps, 2), "fold": round(stage_ms[4] / args.steps, 2),
+                                      "count": round(stage_ms[3] / args.steps, 2),
                                       "direct": round(stage_ms[0] / args.steps, 2)},
                 "node_table": g.table_info(),
                 "merges_per_kmer": round(sk_counters["merges"] / max(local_kmers, 1), 4) if pipeline else None}
@@ -494,7 +573,7 @@ def main():
                                      "h2d_alone_GBps": round(hw.numel() * 4 / h2d_s / 1e9, 2),
                                      "frac_of_h2d_bound": round(h2d_s / med, 3),
                                      "wall_ms": round(med * 1e3, 2), "walls_ms": [round(w * 1e3, 2) for w in walls],
-                                     "stage_ms": dict(zip(("direct", "scatter", "split", "count", "fold"), pcie_stage)),
+                                     "stage_ms": dict(zip(("direct", "scatter", "split", "count"), pcie_stage)),
                                      "ragged": None if not rag_walls else {
                                          "value": nfull * rag_kmers_per_batch / sorted(rag_walls)[len(rag_walls) // 2], "unit": "kmers/s", "reads": nfull * batch,
                                          "walls_ms": [round(w * 1e3, 2) for w in rag_walls],
@@ -507,12 +586,22 @@ def main():
             log("pcie extra failed:", repr(e))
     if rank == 0 and world == 1 and not sharded_path and args.cpu_sample > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log, also_p8=args.cpu_p8)
+            def gpu_hist(m):
+                """257 bins of the first m reads of the workload, by the kernels the step above ran"""
+                with pkg.PregraphGPU(K, est_distinct=max(m * 4, 1 << 20), device=dev.index or 0, flags=base_flags) as gh:
+                    gh.count_reads_device(words, (m * L + 15) // 16 + 4, offsets, m, L)
+                    gh.finish_count()
+                    return gh.mark_and_hist()[0]
+            out["cpu_baseline"], out["e2e"] = cpu_baseline(words, n_local, L, K, args.cpu_sample, log, also_p8=args.cpu_p8,
+                                                           e2e=bool(args.e2e), gpu_hist=gpu_hist,
+                                                           ours_exe=os.path.join(pkg.CSRC_DIR, "sdt-pregraph"))
         except Exception as e:     # the baseline is reported, never required
             log("cpu baseline failed:", repr(e))
             out["cpu_baseline"] = None
+            out["e2e"] = None
     else:
         out["cpu_baseline"] = None
+        out["e2e"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if g is not None:

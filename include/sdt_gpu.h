@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SDT_ABI_VERSION 7
+#define SDT_ABI_VERSION 8
 
 enum {
 	SDT_OK       = 0,
@@ -60,13 +60,8 @@ typedef struct sdt_ctx sdt_ctx;
 #define SDT_FLAG_KEEP_READS 8u
 /* map stage: the table indexes the k-mers of the contigs (sdt_gpu_index_contigs; implies TRACK_FIRST) */
 #define SDT_FLAG_CONTIG_INDEX 16u
-/* What the count stage of the locality pipeline does with a generation of its LDS table (both give identical nodes):
- *   FLAT_MERGE  merges it into the flat table at once (rounds 2-4).  The default.
- *   NODE_LOG    appends it to the node log; sdt_gpu_finish_count folds the log into the bucket-major node table (csrc/sdt_table.cuh:
- *               BmDir) -- no memory-side atomic in pass 1 and half its HBM traffic, but the fold costs what the merges saved
- *               (profiles/r5/README.md): opt-in, also by SDT_PASS1_TABLE=log in the environment. */
-#define SDT_FLAG_FLAT_MERGE 32u
-#define SDT_FLAG_NODE_LOG   64u
+/* (bits 32 and 64 were SDT_FLAG_FLAT_MERGE / SDT_FLAG_NODE_LOG until ABI 7: the count stage of the locality pipeline merges every
+ * generation of its LDS table into the node table, the only form since ABI 8; the bits are ignored) */
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 
@@ -162,12 +157,11 @@ int sdt_gpu_comm_stats(sdt_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_recv,
 int sdt_gpu_shard_ranges(const sdt_ctx *ctx, uint32_t *first_bucket);
 int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K);
 
-/* the FINAL minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit of the bucket-major node table (csrc/sdt_table.cuh:
- * BmDir) that the locality pipeline leaves -- the nodes of one bucket lie together, a look-up by key computes this first. */
+/* the FINAL minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit the count stage of the locality pipeline works on (one
+ * workgroup counts all occurrences of a bucket's keys in LDS) */
 int sdt_kmer_final_bucket(const uint64_t *key_words_msw_first, int K);
-/* the node table as it stands: info[0] layout (0 flat = power-of-two open addressing over all keys, newhash.c's shape; 1
- * bucket-major), [1] slots, [2] nodes, [3] folds of the node log so far, [4] buckets that were merged twice (LDS table or a
- * part over-full), [5] largest number of tables of one bucket, [6] microseconds spent folding, [7] bytes of node log allocated */
+/* the node table as it stands: info[1] slots, [2] nodes as of the last look at the device's counters; the other words are 0
+ * (they described the node log of ABI 7) */
 int sdt_gpu_table_info(sdt_ctx *ctx, uint64_t info[8]);
 int sdt_kmer_owner(const uint64_t *key_words_msw_first, int K, int nranks);
 /* After pass 1 the order-dependent graph phases (cutTipPreGraph.c, node2edge.c) run on ONE host over ALL nodes: rank 0
@@ -240,6 +234,11 @@ int sdt_gpu_export_nodes(sdt_ctx *ctx, uint64_t *keys, uint32_t *l_links, uint32
 int sdt_gpu_export_paths(sdt_ctx *ctx, uint64_t *keys, uint64_t *path_words, uint64_t max_nodes, uint64_t *n);
 int sdt_gpu_import_paths(sdt_ctx *ctx, const uint64_t *keys, const uint64_t *path_words, uint64_t n, const uint64_t *patch_keys,
                          const uint64_t *patch_info, uint64_t npatch, uint64_t num_ed);
+/* A rank whose shard has been handed over (sdt_gpu_export_nodes) and that now waits for the graph: its node table, the
+ * first-occurrence ordinals and the pools of the locality pipeline go back to the device; the reads kept for the second pass stay.
+ * The context then holds no nodes until sdt_gpu_import_paths gives it the graph.  (The reference frees its sets only at the very
+ * end, pregraph.c:107-108: one process, one address space.  Here the waiting ranks may share a device with rank 0's graph phases.) */
+int sdt_gpu_release_table(sdt_ctx *ctx);
 /* ---- pass 2: reads -> edge paths -> arcs (prlRead2edge, prlRead2path.c:817-1335) --------------------------
  * After the host graph phases (minor-out, tip cutting, kmer2edges) every node gets one path word
  *     bit 0 skip = deleted || (linear && !inEdge) (:650) | bit 1 linear | bits 2..3 twin | bits 32..63 l_links = edge id
@@ -431,7 +430,7 @@ int sdt_gpu_kernel_time(sdt_ctx *ctx, int reset, double *ms, uint64_t *launches,
 #define SDT_STAGE_SK_SCATTER  1   /* k_sk_scatter_reads: chop + minimizers + level-1 scatter */
 #define SDT_STAGE_SK_SPLIT    2   /* chunk lists + k_sk_scatter_records (level 2) */
 #define SDT_STAGE_SK_COUNT    3   /* k_sk_count: LDS counting + merges */
-#define SDT_STAGE_SK_FOLD     4   /* the node log folded into the bucket-major table: descriptor sort + k_bm_finalize */
+#define SDT_STAGE_SK_FOLD     4   /* (ABI 7: the fold of the node log; always 0 now) */
 #define SDT_NSTAGES           5
 #define SDT_NCOUNTERS         20   /* [16] distinct records of the count stage's tiles, [17] records (level-2), [18] k-mers of the distinct records, [19] reserved */
 int sdt_gpu_stage_times(sdt_ctx *ctx, double ms[SDT_NSTAGES], uint64_t counters[SDT_NCOUNTERS]);

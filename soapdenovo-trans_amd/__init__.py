@@ -23,7 +23,6 @@ LIB_PATH = os.path.join(CSRC_DIR, "libsdt_gpu.so")
 REPO_ROOT = os.path.dirname(PKG_DIR)
 
 SDT_FLAG_DIRECT, SDT_FLAG_PARTITION, SDT_FLAG_TRACK_FIRST, SDT_FLAG_KEEP_READS, SDT_FLAG_CONTIG_INDEX = 1, 2, 4, 8, 16
-SDT_FLAG_FLAT_MERGE, SDT_FLAG_NODE_LOG = 32, 64
 SDT_OK, SDT_EINVAL, SDT_ENODEV, SDT_ENOMEM, SDT_EHIP, SDT_EFULL, SDT_ESTATE, SDT_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/sdt_gpu.h declares: (name, restype, argtypes)
@@ -60,6 +59,7 @@ _ABI = [
                                       _c.c_uint64, _c.c_uint64]),
     ("sdt_gpu_export_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_import_paths", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_uint64]),
+    ("sdt_gpu_release_table", _c.c_int, [_c.c_void_p]),
     ("sdt_gpu_map_reads", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     ("sdt_gpu_export_arcs", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64,
                                        _c.POINTER(_c.c_uint64)]),
@@ -512,8 +512,7 @@ class PregraphGPU:
         """layout of the node table as it stands (sdt_gpu_table_info)"""
         a = np.zeros(8, dtype=np.uint64)
         self._check(self.lib.sdt_gpu_table_info(self._ctx, a.ctypes.data))
-        return {"layout": "bucket-major" if a[0] else "flat", "slots": int(a[1]), "nodes": int(a[2]), "folds": int(a[3]), "restarts": int(a[4]),
-                "max_parts": int(a[5]), "fold_ms": float(a[6]) / 1e3, "log_bytes": int(a[7])}
+        return {"layout": "flat", "slots": int(a[1]), "nodes": int(a[2])}
 
     def stream(self) -> int:
         return self.lib.sdt_gpu_stream(self._ctx) or 0
@@ -601,7 +600,7 @@ def kmer_bucket(key_words_msw_first, K: int) -> int:
 
 
 def kmer_final_bucket(key_words_msw_first, K: int) -> int:
-    """final minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit of the bucket-major node table"""
+    """final minimizer bucket (0 .. 2^18 - 1) of a canonical k-mer: the unit of the locality pipeline's count stage"""
     a = np.ascontiguousarray(key_words_msw_first, dtype=np.uint64)
     return load_library().sdt_kmer_final_bucket(a.ctypes.data, K)
 

@@ -48,10 +48,16 @@ typedef struct {
 	unsigned long long reads;
 	/* --gpus N: chunk i of the stream is counted by rank i % N; one collective push per group of N chunks */
 	int rank, nranks, keep_all, keep_mine, fill, have;
+	unsigned long long kept_reads;     /* reads handed to sdt_gpu_keep_reads (a rank that owns no chunk of the input keeps none) */
 	int K, hinted;
 	uint64_t total_text;               /* bytes of all input files (0: unknown) */
 	uint32_t *w;
 	uint64_t *o, nw, n, cap_w, cap_o, ord_base, ord_stride;
+	/* --gpus N without a rank that keeps every read: nobody scans foreign chunks (seqio.h: sdt_read_shard_skip_foreign).  The record
+	 * counts of a group's chunks are gathered when the group is complete, and only then does a rank know the ordinals of its own */
+	int defer;
+	struct { int sid, stride, parity; uint64_t n; } grp[64];
+	sdt_stream_ordinals ords;
 } push_state;
 
 /* millisecond phase timer on stderr (the reference's own lines on stdout have 1 s resolution) */
@@ -144,10 +150,36 @@ static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_
 	return 0;
 }
 
+static void count_reads_line(push_state *st, uint64_t n)
+{
+	const unsigned long long before = st->reads / 1000000ULL;
+	st->reads += n;
+	if (st->reads / 1000000ULL != before)
+		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);    /* prlHashReads.c:587-588 */
+}
+
 static int flush_group(push_state *st)
 {
 	static const uint32_t none[4] = {0, 0, 0, 0};
 	static const uint64_t zero[1] = {0};
+	if (st->defer) {
+		/* who parsed what: one all-gather (a sum over vectors with one non-zero entry each) per group of nranks chunks, then every rank
+		 * does the arithmetic of readstream.c for the group's chunks in order */
+		int64_t cnt[64];
+		memset(cnt, 0, sizeof cnt);
+		if (st->have) cnt[st->rank] = (int64_t)st->grp[st->rank].n;
+		if (sdt_gpu_allreduce_i64(st->gpu, cnt, st->nranks) != SDT_OK) { fprintf(stderr, "[rank %d] record counts of a group: %s\n", st->rank, sdt_gpu_last_error()); return -1; }
+		for (int i = 0; i < st->fill; i++) {
+			const uint64_t base = sdt_stream_ordinals_next(&st->ords, st->grp[i].sid, st->grp[i].stride, st->grp[i].parity, (uint64_t)cnt[i]);
+			if (i == st->rank) { st->ord_base = base; st->ord_stride = (uint64_t)st->grp[i].stride; }
+			count_reads_line(st, (uint64_t)cnt[i]);
+		}
+		if (st->have && st->keep_mine && st->n) {
+			sdt_gpu_set_read_ordinal(st->gpu, st->ord_base, st->ord_stride);
+			if (sdt_gpu_keep_reads(st->gpu, st->w, st->nw, st->o, st->n) != SDT_OK) { fprintf(stderr, "sdt_gpu_keep_reads: %s\n", sdt_gpu_last_error()); return -1; }
+			st->kept_reads += st->n;
+		}
+	}
 	if (st->have) sdt_gpu_set_read_ordinal(st->gpu, st->ord_base, st->ord_stride);
 	const int rc = sdt_gpu_push_reads_sharded(st->gpu, st->have ? st->w : none, st->have ? st->nw : 4, st->have ? st->o : zero, st->have ? st->n : 0);
 	if (rc != SDT_OK) fprintf(stderr, "[rank %d] sdt_gpu_push_reads_sharded: %s\n", st->rank, sdt_gpu_last_error());
@@ -159,17 +191,20 @@ static int flush_group(push_state *st)
 static int push_batch_sharded(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
 {
 	push_state *st = (push_state *)user;
-	unsigned long long before = st->reads / 1000000ULL;
-	st->reads += b->nreads;
-	if (st->reads / 1000000ULL != before)
-		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);
-	if (((st->keep_all && !b->counted_only) || (st->keep_mine && b->owner == st->rank)) && b->nreads) {
+	if (st->defer) {
+		if (b->owner < 0 || b->owner >= 64 || b->owner != st->fill) { fprintf(stderr, "[rank %d] chunk %llu out of turn\n", st->rank, (unsigned long long)b->chunk_index); return -1; }
+		st->grp[b->owner].sid = b->stream_id; st->grp[b->owner].stride = (int)ord_stride; st->grp[b->owner].parity = b->stream_parity;
+		st->grp[b->owner].n = b->count_unknown ? 0 : b->nreads;
+	} else
+		count_reads_line(st, b->nreads);
+	if (!st->defer && ((st->keep_all && !b->counted_only) || (st->keep_mine && b->owner == st->rank)) && b->nreads) {
 		/* the reads of the second pass stay resident: this rank's own share (every rank maps its reads), or -- rank 0 without that -- all */
 		sdt_gpu_set_read_ordinal(st->gpu, ord_base, ord_stride);
 		if (sdt_gpu_keep_reads(st->gpu, b->words, b->nwords, b->offsets, b->nreads) != SDT_OK) {
 			fprintf(stderr, "sdt_gpu_keep_reads: %s\n", sdt_gpu_last_error());
 			return -1;
 		}
+		st->kept_reads += b->nreads;
 	}
 	if (b->owner == st->rank && b->nreads) {                      /* mine: it waits for the end of its group */
 		if (b->nwords > st->cap_w) { st->cap_w = b->nwords * 5 / 4; st->w = (uint32_t *)realloc(st->w, st->cap_w * 4); }
@@ -202,11 +237,30 @@ typedef struct {
  * leaves (any `return`, atexit) it takes the children that are still alive with it. */
 static volatile pid_t g_child[64];
 static volatile int g_nchild;
+static char g_shm_name[64];                 /* rank 0: the job's name in /dev/shm ("" = no segments of ours) */
+static int g_shm_ranks;
+
+/* every segment the job may have made, whoever made it (a rank killed while polling never unlinks its own): rank 0 calls this
+ * on every way out -- unlinking a name that is not there costs a failed system call */
+static void unlink_segments(void)
+{
+	char seg[128];
+	if (!g_shm_name[0]) return;
+	snprintf(seg, sizeof seg, "/sdt_%s_paths", g_shm_name);
+	shm_unlink(seg);
+	for (int r = 1; r < g_shm_ranks; r++) {
+		snprintf(seg, sizeof seg, "/sdt_%s_a%d", g_shm_name, r);
+		shm_unlink(seg);
+		snprintf(seg, sizeof seg, "/sdt_%s_n%d", g_shm_name, r);
+		shm_unlink(seg);
+	}
+}
 
 static void kill_children(void)
 {
 	for (int i = 0; i < g_nchild; i++)
 		if (g_child[i] > 0) { kill(g_child[i], SIGKILL); (void)waitpid(g_child[i], NULL, 0); g_child[i] = 0; }
+	unlink_segments();
 }
 
 static void on_sigchld(int sig)
@@ -223,6 +277,7 @@ static void on_sigchld(int sig)
 			if (write(2, msg, sizeof msg - 1) < 0) { }
 			for (int i = 0; i < g_nchild; i++)
 				if (g_child[i] > 0) kill(g_child[i], SIGKILL);
+			unlink_segments();
 			_exit(1);
 		}
 	}
@@ -576,6 +631,7 @@ int main(int argc, char **argv)
 
 	time_t t_start = time(NULL);
 	g_t_last = g_t_main = now_ms();
+	if (getenv("SDT_LAYOUT_CHECK")) setenv("SDT_KEEP_FIRST", "1", 0);      /* the check sorts by the first-occurrence ordinals once more */
 	if (getenv("SDT_TIMING")) {
 		/* how long the loader took to get here (process start from /proc/self/stat, in clock ticks since boot): what a caller's
 		 * wall clock holds beyond "total inside main" is this plus the kernel's teardown of the address space after _exit */
@@ -610,6 +666,8 @@ int main(int argc, char **argv)
 		if (boot == MAP_FAILED) { perror("mmap"); return 1; }
 		memset(boot, 0, sizeof *boot);
 		snprintf(boot->name, sizeof boot->name, "pg%d", (int)getpid());
+		snprintf(g_shm_name, sizeof g_shm_name, "%s", boot->name);
+		g_shm_ranks = gpus;
 		fflush(stdout);
 		struct sigaction sa;
 		memset(&sa, 0, sizeof sa);
@@ -631,6 +689,7 @@ int main(int argc, char **argv)
 				rank = r;
 				g_quiet = 1;
 				g_nchild = 0;                                         /* (a child has no children to take along) */
+				g_shm_name[0] = 0;                                    /* (nor the job's segments to clear away) */
 				signal(SIGCHLD, SIG_DFL);
 				sigprocmask(SIG_SETMASK, &old, NULL);
 				prctl(PR_SET_PDEATHSIG, SIGKILL);
@@ -686,6 +745,7 @@ int main(int argc, char **argv)
 	st.keep_mine = per_rank_map;
 	const size_t chunk = getenv("SDT_CHUNK_BYTES") ? (size_t)strtoull(getenv("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
 	int rc;
+	uint64_t text_parsed = 0, text_seen = 0;
 	if (gpus == 1) {
 		st.K = K;
 		st.total_text = input_bytes(&cfg);
@@ -695,8 +755,12 @@ int main(int argc, char **argv)
 		sdt_pool_disable();
 	} else {
 		sdt_read_shard_begin(rank, gpus, st.keep_all);
+		st.defer = !st.keep_all;
+		sdt_read_shard_skip_foreign(st.defer);
+		sdt_stream_ordinals_init(&st.ords);
 		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch_sharded, &st, NULL);
 		if (rc == 0 && st.fill) rc = flush_group(&st);
+		text_parsed = sdt_reader_bytes_parsed; text_seen = sdt_reader_bytes_seen;
 		sdt_read_shard_begin(0, 1, 0);
 	}
 	if (rc != 0) { sdt_gpu_destroy(gpu); return 1; }
@@ -718,6 +782,9 @@ int main(int argc, char **argv)
 			fprintf(stderr, "[ingest] consumer waited %.0f ms for the parsers, spent %.0f ms pushing; device stages: direct %.0f, scatter %.0f, split %.0f, count %.0f ms; %llu batches counted, %llu early flushes, %d parser threads\n",
 			        sdt_reader_wait_ms, sdt_reader_fn_ms, ms[0], ms[1], ms[2], ms[3], (unsigned long long)cn[6], (unsigned long long)cn[3], my_threads);
 	}
+	if (getenv("SDT_TIMING") && !g_quiet && gpus > 1)
+		fprintf(stderr, "[ingest] rank 0 of %d parsed %.1f of %.1f MB of text (%.3f of the input; the other chunks are their owners')\n", gpus,
+		        text_parsed / 1e6, text_seen / 1e6, text_seen ? (double)text_parsed / (double)text_seen : 0.0);
 	phase("parse + hash (GPU)");
 	printf("time spent on hash reads: %ds, %llu reads processed\n", (int)(time(NULL) - t_start), st.reads);
 	printf("%llu nodes allocated, %llu kmer in reads, %llu kmer processed\n", (unsigned long long)nodes,
@@ -788,6 +855,9 @@ int main(int argc, char **argv)
 				}
 				munmap(m, (size_t)(my_nodes + 1) * per_node);
 				shm_unlink(seg);
+				/* the shard is with rank 0: its table, the ordinals and the pools of the locality pipeline go back to the device now, not
+				 * when the graph arrives (under --share-device they would sit beside rank 0's graph buffers until then) */
+				if (sdt_gpu_release_table(gpu) != SDT_OK) { fprintf(stderr, "[rank %d] %s\n", rank, sdt_gpu_last_error()); return 1; }
 				if (per_rank_map) {
 					/* wait for the graph (rank 0 lays it out, cuts it and builds the edges: seconds to minutes -- polled, not a collective with
 					 * its deadline; the parent's death takes this process along), map my reads, leave my arcs */
@@ -799,8 +869,12 @@ int main(int argc, char **argv)
 						const size_t pbytes = (size_t)(pn + 1) * ((size_t)nwk * 8 + 8) + (size_t)(qn + 1) * ((size_t)nwk * 8 + 8);
 						uint8_t *pm = (uint8_t *)shm_region(seg, pbytes, 0);
 						uint64_t nreads2 = 0, narcs = 0;
+						/* a rank that owned no chunk of the input (fewer chunks than ranks) kept no reads: it has nothing to map and leaves an
+						 * empty arc list (sdt_gpu_map_reads would refuse: "the reads were not kept") */
+						const int have_reads = st.kept_reads > 0;
 						if (!pm) { fprintf(stderr, "[rank %d] cannot map the path table\n", rank); ok = 0; }
-						if (ok) {
+						if (ok && !have_reads) munmap(pm, pbytes);
+						if (ok && have_reads) {
 							const uint64_t *pk = (const uint64_t *)pm, *pw = pk + (pn + 1) * (size_t)nwk, *qk = pw + pn + 1, *qi = qk + (qn + 1) * (size_t)nwk;
 							if (sdt_gpu_import_paths(gpu, pk, pw, pn, qk, qi, qn, boot->num_ed) != SDT_OK ||
 							    sdt_gpu_map_reads(gpu, &nreads2, &narcs) != SDT_OK) {
@@ -817,7 +891,7 @@ int main(int argc, char **argv)
 							am = (uint8_t *)shm_region(seg, abytes, 1);
 							uint64_t *ao = (uint64_t *)am;
 							uint32_t *af = am ? (uint32_t *)(ao + narcs + 1) : NULL, *at2 = af ? af + narcs + 1 : NULL, *amu = at2 ? at2 + narcs + 1 : NULL;
-							if (!am || sdt_gpu_export_arcs(gpu, af, at2, amu, ao, narcs, &narcs) != SDT_OK) {
+							if (!am || (have_reads && sdt_gpu_export_arcs(gpu, af, at2, amu, ao, narcs, &narcs) != SDT_OK)) {
 								fprintf(stderr, "[rank %d] arcs: %s\n", rank, am ? sdt_gpu_last_error() : "no shared memory");
 								ok = 0;
 							}

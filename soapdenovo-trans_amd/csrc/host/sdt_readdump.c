@@ -6,6 +6,7 @@
 #include <string.h>
 #include "libcfg.h"
 #include "seqio.h"
+#include "readstream.h"
 
 /* SDT_READDUMP_POOL=<n>: the reader packs into a pool of n buffers (seqio.h) and this consumer keeps every batch's buffer
  * for three more batches before it gives it back -- the way sdt-pregraph's asynchronous pushes hold theirs */
@@ -34,9 +35,68 @@ static int dump(void *user, const sdt_batch *b)
 	return 0;
 }
 
+/* --ordinals <nranks>: the multi-process reader without a GPU.  The pass is walked once as one rank (the ordinals sdt_stream_reads
+ * hands out are the truth), then once per rank of an N-rank job with foreign chunks skipped (seqio.h: sdt_read_shard_skip_foreign):
+ * every chunk must be parsed by exactly its owner, nobody may read a byte of a foreign chunk, and the ordinals worked out from the
+ * owners' record counts (readstream.h: sdt_stream_ordinals, what sdt-pregraph does after its all-gather per group) must be the truth. */
+typedef struct { uint64_t ord, n; int sid, stride, parity, owner, unknown; } chunk_rec;
+typedef struct { chunk_rec *v; size_t n, cap; } chunk_log;
+
+static int log_chunk(void *user, const sdt_batch *b, uint64_t ord_base, uint64_t ord_stride)
+{
+	chunk_log *L = (chunk_log *)user;
+	if (L->n == L->cap) { L->cap = L->cap ? 2 * L->cap : 256; L->v = (chunk_rec *)realloc(L->v, L->cap * sizeof(chunk_rec)); }
+	if (b->chunk_index != L->n) { fprintf(stderr, "chunk %zu reported as %llu\n", L->n, (unsigned long long)b->chunk_index); return -1; }
+	chunk_rec r = {ord_base, b->nreads, b->stream_id, (int)ord_stride, b->stream_parity, b->owner, b->count_unknown};
+	L->v[L->n++] = r;
+	return 0;
+}
+
+static int check_ordinals(const sdt_cfg *cfg, int max_read_len, int threads, size_t chunk, int nranks)
+{
+	chunk_log truth = {NULL, 0, 0};
+	sdt_read_shard_begin(0, 1, 0);
+	if (sdt_stream_reads(cfg, max_read_len, threads, chunk, 0, log_chunk, &truth, NULL) != 0) return 1;
+	chunk_log *per = (chunk_log *)calloc((size_t)nranks, sizeof(chunk_log));
+	uint64_t parsed = 0, seen = 0;
+	for (int r = 0; r < nranks; r++) {
+		sdt_read_shard_begin(r, nranks, 0);
+		sdt_read_shard_skip_foreign(1);
+		if (sdt_stream_reads(cfg, max_read_len, threads, chunk, 0, log_chunk, &per[r], NULL) != 0) return 1;
+		if (per[r].n != truth.n) { fprintf(stderr, "rank %d saw %zu chunks, one rank sees %zu\n", r, per[r].n, truth.n); return 1; }
+		parsed += sdt_reader_bytes_parsed;
+		seen = sdt_reader_bytes_seen;
+	}
+	sdt_read_shard_begin(0, 1, 0);
+	if (parsed != seen) { fprintf(stderr, "the ranks parsed %llu bytes in all, the input has %llu\n", (unsigned long long)parsed, (unsigned long long)seen); return 1; }
+	sdt_stream_ordinals so;
+	sdt_stream_ordinals_init(&so);
+	for (size_t c = 0; c < truth.n; c++) {
+		const int owner = (int)(c % (size_t)nranks);
+		for (int r = 0; r < nranks; r++) {
+			const chunk_rec *x = &per[r].v[c];
+			if (x->owner != owner || x->unknown != (r != owner) || (r != owner && x->n != 0)) { fprintf(stderr, "chunk %zu on rank %d: owner %d unknown %d n %llu\n", c, r, x->owner, x->unknown, (unsigned long long)x->n); return 1; }
+			if (x->sid != truth.v[c].sid || x->stride != truth.v[c].stride || x->parity != truth.v[c].parity) { fprintf(stderr, "chunk %zu on rank %d: another stream\n", c, r); return 1; }
+		}
+		const chunk_rec *o = &per[owner].v[c];
+		if (o->n != truth.v[c].n) { fprintf(stderr, "chunk %zu: its owner counts %llu records, one rank %llu\n", c, (unsigned long long)o->n, (unsigned long long)truth.v[c].n); return 1; }
+		const uint64_t base = sdt_stream_ordinals_next(&so, o->sid, o->stride, o->parity, o->n);
+		if (base != truth.v[c].ord) { fprintf(stderr, "chunk %zu: ordinal %llu worked out, %llu is the truth\n", c, (unsigned long long)base, (unsigned long long)truth.v[c].ord); return 1; }
+	}
+	printf("ordinals OK: %zu chunks, %d ranks, %llu bytes each parsed once\n", truth.n, nranks, (unsigned long long)seen);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
-	if (argc < 2) { fprintf(stderr, "usage: sdt-readdump <cfg> [threads] [chunk_bytes]\n"); return 2; }
+	if (argc >= 4 && strcmp(argv[1], "--ordinals") == 0) {
+		sdt_cfg cfg;
+		if (sdt_cfg_load(argv[3], &cfg) != 0) return 1;
+		const int rc = check_ordinals(&cfg, cfg.max_rd_len ? cfg.max_rd_len : 100, argc > 4 ? atoi(argv[4]) : 4, argc > 5 ? (size_t)atol(argv[5]) : 30000, atoi(argv[2]));
+		sdt_cfg_free(&cfg);
+		return rc;
+	}
+	if (argc < 2) { fprintf(stderr, "usage: sdt-readdump <cfg> [threads] [chunk_bytes]  |  sdt-readdump --ordinals <nranks> <cfg> [threads] [chunk_bytes]\n"); return 2; }
 	int threads = argc > 2 ? atoi(argv[2]) : 4;
 	size_t chunk = argc > 3 ? (size_t)atol(argv[3]) : (32u << 20);
 	sdt_cfg cfg;

@@ -15,11 +15,13 @@ typedef struct {
 	sdt_batch out;
 	int done;
 	int owner, encode;          /* sdt_read_shard_begin */
+	uint64_t index;             /* number of the chunk in the pass */
 	int slot;                   /* pool buffer taken with the chunk number, -1 = none */
 } chunk_t;
 
-static int g_shard_rank = 0, g_shard_n = 1, g_shard_keep_all = 0;
+static int g_shard_rank = 0, g_shard_n = 1, g_shard_keep_all = 0, g_shard_skip = 0;
 static uint64_t g_shard_chunk = 0;
+uint64_t sdt_reader_bytes_parsed = 0, sdt_reader_bytes_seen = 0;
 
 void sdt_read_shard_begin(int rank, int nranks, int keep_all)
 {
@@ -27,7 +29,11 @@ void sdt_read_shard_begin(int rank, int nranks, int keep_all)
 	g_shard_n = nranks > 0 ? nranks : 1;
 	g_shard_keep_all = keep_all;
 	g_shard_chunk = 0;
+	g_shard_skip = 0;
+	sdt_reader_bytes_parsed = sdt_reader_bytes_seen = 0;
 }
+
+void sdt_read_shard_skip_foreign(int on) { g_shard_skip = on; }
 
 typedef struct {
 	chunk_t *chunks;
@@ -256,6 +262,16 @@ static inline const char *line_end(const char *p, const char *end)
 
 static void parse_chunk(job_t *J, chunk_t *c)
 {
+	if (!c->encode && g_shard_skip) {                      /* a foreign chunk nobody here needs to count: not a byte of it is read */
+		memset(&c->out, 0, sizeof c->out);
+		c->out.pool_slot = -1;
+		c->out.owner = c->owner;
+		c->out.counted_only = 1;
+		c->out.count_unknown = 1;
+		c->out.text_bytes = (uint64_t)(c->end - c->beg);
+		c->out.chunk_index = c->index;
+		return;
+	}
 	packer_t pk = {0};
 	uint64_t cap_off = 1024, n = 0;
 	uint64_t *offs;
@@ -353,6 +369,9 @@ static void parse_chunk(job_t *J, chunk_t *c)
 	c->out.nreads = n;
 	c->out.owner = c->owner;
 	c->out.counted_only = !c->encode;
+	c->out.chunk_index = c->index;
+	c->out.count_unknown = 0;
+	c->out.stream_id = c->out.stream_parity = 0;
 	if (!c->encode) {                                      /* a foreign chunk: only the number of records matters */
 		free(pk.w);
 		free(offs);
@@ -447,6 +466,9 @@ int sdt_read_file(const char *path, int fmt, int max_read_len, int reverse, int 
 			J.chunks[nc].end = cut;
 			J.chunks[nc].owner = (int)(g_shard_chunk % (uint64_t)g_shard_n);
 			J.chunks[nc].encode = g_shard_keep_all || J.chunks[nc].owner == g_shard_rank;
+			J.chunks[nc].index = g_shard_chunk;
+			sdt_reader_bytes_seen += (uint64_t)(cut - prev);
+			if (J.chunks[nc].encode || !g_shard_skip) sdt_reader_bytes_parsed += (uint64_t)(cut - prev);
 			g_shard_chunk++;
 			nc++;
 			prev = cut;

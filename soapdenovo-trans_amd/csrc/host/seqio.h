@@ -21,6 +21,11 @@ typedef struct {
 	int pool_slot;          /* >= 0: words / offsets live in a buffer of the pool below (sdt_pool_take to keep it past the callback) */
 	uint64_t fixed_len;     /* > 0: every read of the batch has exactly this many bases (offsets[i] = i * fixed_len) */
 	uint64_t text_bytes;    /* bytes of the input file this batch was parsed from */
+	/* multi-process runs: where the chunk stands in the pass (readstream.c fills the stream fields) */
+	uint64_t chunk_index;   /* number of the chunk over all files of the pass (owner = chunk_index % nranks) */
+	int count_unknown;      /* 1: a foreign chunk that was not even scanned (sdt_read_shard_skip_foreign): nreads is 0, the owner knows */
+	int stream_id;          /* number of the file within the pass */
+	int stream_parity;      /* paired files: 0 = the reads of this file take the even ordinals of the pair, 1 = the odd ones */
 } sdt_batch;
 
 /* Optional pool of output buffers for a host that hands batches to the device ASYNCHRONOUSLY from pinned memory (the
@@ -37,8 +42,16 @@ void sdt_pool_release(int slot);
 /* Multi-process runs (`sdt-pregraph --gpus N`): every rank walks the same chunks in the same order, chunk i (counted
  * over all files of a pass) belongs to rank i % nranks.  A rank only COUNTS the records of foreign chunks (the read
  * ordinals of everything after them depend on it) unless keep_all is set (rank 0 keeps every read for the second
- * pass).  sdt_read_shard_begin resets the chunk counter: call it before each pass over the reads. */
+ * pass).  sdt_read_shard_begin resets the chunk counter: call it before each pass over the reads.
+ * sdt_read_shard_skip_foreign(1): a rank does not look at foreign chunks at all -- it touches the text around the chunk
+ * boundaries (the cut points are found the same way on every rank) and its own chunks, nothing else; such a batch comes with
+ * count_unknown = 1, and the caller gets the record counts from the owners (sdt_pregraph.c: one all-gather per group of nranks
+ * chunks) and works the ordinals out itself (readstream.h: sdt_stream_ordinals).  The reference has ONE reader for all threads
+ * (prlHashReads.c:432-620); N ranks that each scan the whole input would be N readers of 64 GB of text. */
 void sdt_read_shard_begin(int rank, int nranks, int keep_all);
+void sdt_read_shard_skip_foreign(int on);
+/* bytes of text this process parsed / was shown (own chunks / all chunks), summed over all files since the last shard_begin */
+extern uint64_t sdt_reader_bytes_parsed, sdt_reader_bytes_seen;
 
 typedef int (*sdt_batch_fn)(void *user, const sdt_batch *b);
 /* where the consumer thread's time went, summed over all files (measurement) */

@@ -4,13 +4,12 @@
 // and how many k-mers they hold (kpre2[f + 1] - kpre2[f]).  k_sk_count's workgroups take work items first come first served;
 // an item is a run [c0, c1) of the list:
 //   * a bucket of at most `item_chunks` chunks is one item, flagged WHOLE (top bit of c1): no other item of the launch holds
-//     keys of its buckets (rounds 3-4 merged such items into the node table without atomics; since round 5 every item
-//     appends to the node log and the flag is informational);
+//     keys of its buckets: the workgroup that takes it merges into the node table WITHOUT atomics (plain read-modify-write, a
+//     compare-and-swap only for the claim of a new key's slot);
 //   * a larger bucket is cut into pieces of `item_chunks` chunks, not flagged;
 //   * buckets of at most `pack_chunks` chunks share an item with their neighbours (their chunks are adjacent in the list, empty
 //     buckets in between do not matter) as long as the item stays within `pack_chunks` chunks, within ONE level-1 bucket and
-//     within a span of SK_PLAN_MAX_SPAN final buckets (k_sk_count sorts an item's nodes by bucket when it logs them: 64
-//     counters): per-item costs are paid once;
+//     within a span of SK_PLAN_MAX_SPAN final buckets per-item costs are paid once;
 //   * an item is FOUR words: c0, c1 | WHOLE, first final bucket, last final bucket;
 //   * within a launch the items are handed out LARGEST FIRST (by power-of-two size class, list order within a class): a launch
 //     ends when its slowest workgroup does, and an item of 1024 chunks taken last kept 500 workgroups waiting for ~0.7 ms --
@@ -25,7 +24,7 @@
 namespace sdt {
 
 constexpr uint32_t SK_ITEM_WHOLE = 0x80000000u;
-constexpr uint32_t SK_PLAN_MAX_SPAN = 64;        // final buckets an item may span (= SK_CNT_MAX_BUCKETS of k_sk_count)
+constexpr uint32_t SK_PLAN_MAX_SPAN = 64;        // final buckets an item may span 
 constexpr uint32_t SK_PLAN_L2_BUCKETS = 1024;    // final buckets per level-1 bucket (= SK_NB2)
 constexpr int SK_ITEM_WORDS = 4;
 

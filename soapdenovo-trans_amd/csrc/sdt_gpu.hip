@@ -399,7 +399,6 @@ __global__ __launch_bounds__(TPB) void k_import_paths(Table<NW> tbl, const uint6
 }
 
 #include "sdt_superkmer_kernels.cuh"
-#include "sdt_bm_kernels.cuh"
 #include "sdt_comm.cuh"
 #include "sdt_shard_plan.h"
 #include "sdt_count_plan.h"
@@ -458,7 +457,6 @@ struct sdt_ctx {
 	uint64_t kmers_total_host = 0;
 	uint64_t kmers_offered = 0;        // upper bound of the k-mers handed to pass 1 since the last reset (picks the kernel family)
 	uint32_t flags = 0;
-	bool node_log = true;              // the count stage appends to the node log (false: it merges into the flat table, rounds 2-4)
 	// locality pipeline (sdt_superkmer.cuh): chunk pools of the two scatter levels, chunk lists, pending work
 	struct SkState {
 		bool ready = false;
@@ -487,52 +485,6 @@ struct sdt_ctx {
 		uint64_t l2_in_total = 0;      // k-mers that entered the count stage (sum of the level-2 bucket sizes): Stats.sk_counted must match
 		bool exchanged = false;        // records left for / came from other ranks: Stats.sk_emitted is not this rank's input
 	} sk;
-	// node log + bucket-major node table (sdt_bm_kernels.cuh): what the locality pipeline's count stage appends to, and the table
-	// sync_stats folds it into.  The flat table above stays the direct kernel family's (and the place of records that found no
-	// chunk); whatever it holds when the log is folded is folded with it, and from then on the bucket-major table is THE table
-	// (table_of): scans run over its slots, look-ups compute the key's minimizer bucket.
-	struct LogSlab {
-		uint64_t *ent = nullptr;
-		uint64_t ent_cap = 0;              // entries
-		LogDesc *desc = nullptr;
-		uint64_t desc_cap = 0;
-		unsigned long long *ctl = nullptr; // device: [0] entries, [1] descriptors handed out
-		uint64_t ent_known = 0, desc_known = 0;      // as of the last look at ctl
-		uint64_t ent_since = 0, desc_since = 0;      // upper bound of what the launches since then may take
-	};
-	struct BmTable {
-		void *ent = nullptr;
-		uint32_t *aux = nullptr;
-		uint64_t *first = nullptr;
-		BmDir *dir = nullptr;
-		uint32_t *cnt = nullptr;
-		uint64_t cap = 0;                  // slots allocated
-		uint64_t dir_cap = 0;              // directory entries allocated (SK_NBF + those of the sub-buckets of giant buckets)
-		uint64_t nslots = 0;               // slots in use
-		uint64_t nodes = 0;
-		bool valid = false;
-	};
-	struct BmState {
-		std::vector<LogSlab> slabs;
-		int active = -1;
-		bool log_dirty = false;            // a count launch has appended since the last fold
-		BmTable tab;                       // the table (valid: it holds the nodes)
-		BmTable spare;                     // buffers of a table that was folded into another one: kept for the next fold
-		uint64_t est_distinct = 0;         // the caller's estimate (sdt_gpu_init), sizes the first fold
-		// scratch of a fold (allocated once)
-		uint32_t *dcnt = nullptr, *doff = nullptr, *dfill = nullptr;
-		unsigned long long *dents = nullptr, *dpre = nullptr;
-		uint32_t *xcnt = nullptr, *xoff = nullptr, *xfill = nullptr;
-		uint32_t *ccnt = nullptr, *cstart = nullptr, *cfill = nullptr, *next = nullptr;
-		LogDesc *sorted = nullptr;                               // the segment descriptors by bucket (kept: grows only)
-		uint64_t sorted_cap = 0;
-		BmUnit *units = nullptr;                                 // the work units of a fold (kept: grows only)
-		uint64_t units_cap = 0;
-		unsigned long long *ctl = nullptr, *h_ctl = nullptr;      // BM_CTL_N counters (device / pinned)
-		unsigned long long *h_lctl = nullptr;                    // pinned: a slab's two cursors
-		uint64_t folds = 0, restarts = 0, maxparts = 0;          // statistics
-		double fold_ms = 0;
-	} bm;
 	// multi-GPU (sdt_comm.cuh): communicator + double-buffered send / receive chunk buffers of the exchange
 	Comm comm;
 	struct Shard {
@@ -631,31 +583,12 @@ template <int NW> static Table<NW> flat_of(const sdt_ctx *c)
 	t.aux = c->d_aux;
 	t.fslots = c->slots;
 	t.first = c->d_first;
-	t.dir = nullptr;
-	t.nslots = 0;
-	t.K = c->K;
 	return t;
 }
 
-template <int NW> static Table<NW> bm_view(const sdt_ctx *c, const sdt_ctx::BmTable &b)
-{
-	Table<NW> t;
-	t.ent = (Entry<NW> *)b.ent;
-	t.aux = b.aux;
-	t.fslots = 0;
-	t.first = b.first;
-	t.dir = b.dir;
-	t.nslots = b.nslots;
-	t.K = c->K;
-	return t;
-}
-
-// THE node table as every stage after pass 1 sees it: the bucket-major one once the log has been folded, else the flat one
-template <int NW> static Table<NW> table_of(const sdt_ctx *c)
-{
-	return c->bm.tab.valid ? bm_view<NW>(c, c->bm.tab) : flat_of<NW>(c);
-}
-static uint64_t view_slots(const sdt_ctx *c) { return c->bm.tab.valid ? c->bm.tab.nslots : c->slots; }
+// the node table as every stage after pass 1 sees it
+template <int NW> static Table<NW> table_of(const sdt_ctx *c) { return flat_of<NW>(c); }
+static uint64_t view_slots(const sdt_ctx *c) { return c->slots; }
 
 static size_t entry_bytes(int nw) { return nw == 1 ? sizeof(Entry<1>) : nw == 2 ? sizeof(Entry<2>) : sizeof(Entry<4>); }
 
@@ -695,414 +628,9 @@ static int alloc_table(sdt_ctx *c, uint64_t slots, void **ent, uint32_t **aux, u
 static int sk_flush(sdt_ctx *c);
 static void sk_free(sdt_ctx *c);
 
-// ------------------------------------------------------------------------------------------------
-// node log + bucket-major table (sdt_bm_kernels.cuh)
-// ------------------------------------------------------------------------------------------------
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-static int log_entry_words(const sdt_ctx *c) { return c->nw + 1 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 1 : 0); }
-
-static void log_free(sdt_ctx *c)
-{
-	for (auto &sl : c->bm.slabs) {
-		if (sl.ent) (void)hipFree(sl.ent);
-		if (sl.desc) (void)hipFree(sl.desc);
-		if (sl.ctl) (void)hipFree(sl.ctl);
-	}
-	c->bm.slabs.clear();
-	c->bm.active = -1;
-}
-
-static void bm_table_free(sdt_ctx::BmTable &t)
-{
-	if (t.ent) (void)hipFree(t.ent);
-	if (t.aux) (void)hipFree(t.aux);
-	if (t.first) (void)hipFree(t.first);
-	if (t.dir) (void)hipFree(t.dir);
-	if (t.cnt) (void)hipFree(t.cnt);
-	t = sdt_ctx::BmTable();
-}
-
-static void bm_free(sdt_ctx *c)
-{
-	sdt_ctx::BmState &b = c->bm;
-	log_free(c);
-	bm_table_free(b.tab);
-	bm_table_free(b.spare);
-	void *dev[] = {b.dcnt, b.doff, b.dfill, b.dents, b.dpre, b.xcnt, b.xoff, b.xfill, b.ccnt, b.cstart, b.cfill, b.next, b.ctl, b.sorted, b.units};
-	for (void *p : dev)
-		if (p) (void)hipFree(p);
-	if (b.h_ctl) (void)hipHostFree(b.h_ctl);
-	if (b.h_lctl) (void)hipHostFree(b.h_lctl);
-	const uint64_t est = b.est_distinct;
-	b = sdt_ctx::BmState();
-	b.est_distinct = est;
-}
-
-// look at a slab's cursors (host sync)
-static int log_refresh(sdt_ctx *c, sdt_ctx::LogSlab &sl)
-{
-	if (!c->bm.h_lctl)
-		HIPCHK(hipHostMalloc((void **)&c->bm.h_lctl, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-	HIPCHK(hipMemcpyAsync(c->bm.h_lctl, sl.ctl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-	{ const int rcw = c->comm.sync_watched(c->stream, "the node log's cursors"); if (rcw != SDT_OK) return rcw; }
-	sl.ent_known = c->bm.h_lctl[0] < sl.ent_cap ? c->bm.h_lctl[0] : sl.ent_cap;
-	sl.desc_known = c->bm.h_lctl[1] < sl.desc_cap ? c->bm.h_lctl[1] : sl.desc_cap;
-	sl.ent_since = sl.desc_since = 0;
-	return SDT_OK;
-}
-
-static int bm_fold(sdt_ctx *c);
 static EventPair *next_event(sdt_ctx *c);
-
-// Room in the log for a count launch of `kmers` k-mers in `nbuckets` buckets and `nitems` work items -- the HARD bound: an
-// entry is a distinct key of one generation of an LDS table, so a launch appends at most one per k-mer; a descriptor is a
-// non-empty bucket of a flush, and a flush before the end of an item means 3/8 of a table of keys (or 65535 k-mers) since the
-// last one.  The launch can therefore never find the log full, whatever the data.  Returns the slab to append to.
-static int log_reserve(sdt_ctx *c, uint64_t kmers, uint64_t nbuckets, uint64_t nitems, SkLog *out)
-{
-	sdt_ctx::BmState &b = c->bm;
-	const int lw = log_entry_words(c);
-	const uint64_t need_e = kmers + (nitems + kmers / 256 + 64) * SK_LOG_ALIGN;
-	const uint64_t need_d = nbuckets + nitems + kmers / 256 + 64;
-	for (int attempt = 0; attempt < 3; attempt++) {
-		if (b.active >= 0) {
-			sdt_ctx::LogSlab &sl = b.slabs[b.active];
-			if (sl.ent_known + sl.ent_since + need_e > sl.ent_cap || sl.desc_known + sl.desc_since + need_d > sl.desc_cap) {
-				const int rc = log_refresh(c, sl);
-				if (rc != SDT_OK) return rc;
-			}
-			if (sl.ent_known + need_e <= sl.ent_cap && sl.desc_known + need_d <= sl.desc_cap) {
-				sl.ent_since += need_e;
-				sl.desc_since += need_d;
-				out->ent = sl.ent; out->ent_cap = sl.ent_cap; out->desc = sl.desc; out->desc_cap = sl.desc_cap; out->ctl = sl.ctl;
-				return SDT_OK;
-			}
-			// an emptier slab further on (slabs are kept across resets)?
-			if ((size_t)b.active + 1 < b.slabs.size()) {
-				b.active++;
-				continue;
-			}
-		} else if (!b.slabs.empty()) {
-			b.active = 0;
-			continue;
-		}
-		// another slab: as large as the pools suggest, never smaller than this launch, within a share of what is free
-		// (room for four launches like this one under the hard bound -- what they really take is a fraction of it, so a slab lasts
-		// a batch or more and the host looks at its cursor a few times per batch)
-		uint64_t want = c->sk.cap_kmers / 4;
-		if (want < 4 * need_e) want = 4 * need_e;
-		if (want < (1ULL << 26)) want = 1ULL << 26;
-		if (want > (1ULL << 32)) want = 1ULL << 32;
-		if (env_int("SDT_LOG_SLAB_LOG2", 0) > 0)          // (tests: small slabs, many of them)
-			want = 1ULL << clamp_int(env_int("SDT_LOG_SLAB_LOG2", 0), 16, 34);
-		if (want < need_e) want = need_e;
-		size_t free_b = 0, total_b = 0;
-		HIPCHK(sdti::mem_info(&free_b, &total_b));
-		const uint64_t per_e = (uint64_t)lw * 8 + sizeof(LogDesc) / 16 + 1;
-		while (want > need_e && want * per_e > free_b / 100 * 30)
-			want = want / 2 > need_e ? want / 2 : need_e;
-		sdt_ctx::LogSlab sl;
-		sl.ent_cap = want;
-		sl.desc_cap = want / 16 + need_d;
-		hipError_t e = hipMalloc((void **)&sl.ent, sl.ent_cap * lw * 8);
-		if (e == hipSuccess) e = hipMalloc((void **)&sl.desc, sl.desc_cap * sizeof(LogDesc));
-		if (e == hipSuccess) e = hipMalloc((void **)&sl.ctl, 2 * sizeof(unsigned long long));
-		if (e != hipSuccess) {
-			if (sl.ent) (void)hipFree(sl.ent);
-			if (sl.desc) (void)hipFree(sl.desc);
-			if (sl.ctl) (void)hipFree(sl.ctl);
-			(void)hipGetLastError();
-			// no memory for another slab: fold what the log holds into the table (which frees the slabs' contents) and start over
-			if (attempt == 0 && b.log_dirty) {
-				const int rc = bm_fold(c);
-				if (rc != SDT_OK) return rc;
-				continue;
-			}
-			return fail(SDT_ENOMEM, "node log: no device memory for a slab of %llu entries x %d B", (unsigned long long)want, lw * 8);
-		}
-		HIPCHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
-		if (getenv("SDT_TIMING"))
-			fprintf(stderr, "[libsdt_gpu] node log: slab %zu of %llu entries x %d B (%.1f GiB)\n", b.slabs.size(), (unsigned long long)want, lw * 8,
-			        (double)want * lw * 8 / (1 << 30));
-		b.slabs.push_back(sl);
-		b.active = (int)b.slabs.size() - 1;
-	}
-	return fail(SDT_ESTATE, "node log: no room for a launch of %llu k-mers", (unsigned long long)kmers);
-}
-
-static int bm_scratch_alloc(sdt_ctx *c)
-{
-	sdt_ctx::BmState &b = c->bm;
-	if (b.dcnt)
-		return SDT_OK;
-	HIPCHK(hipMalloc((void **)&b.dcnt, SK_NBF * 4));
-	HIPCHK(hipMalloc((void **)&b.doff, (SK_NBF + 1) * 4));
-	HIPCHK(hipMalloc((void **)&b.dfill, SK_NBF * 4));
-	HIPCHK(hipMalloc((void **)&b.dents, SK_NBF * 8));
-	HIPCHK(hipMalloc((void **)&b.dpre, (SK_NBF + 1) * 8));
-	HIPCHK(hipMalloc((void **)&b.xcnt, SK_NBF * 4));
-	HIPCHK(hipMalloc((void **)&b.xoff, (SK_NBF + 1) * 4));
-	HIPCHK(hipMalloc((void **)&b.xfill, SK_NBF * 4));
-	HIPCHK(hipMalloc((void **)&b.ccnt, 65 * 4));
-	HIPCHK(hipMalloc((void **)&b.cstart, 65 * 4));
-	HIPCHK(hipMalloc((void **)&b.cfill, 65 * 4));
-	HIPCHK(hipMalloc((void **)&b.next, 64));
-	HIPCHK(hipMalloc((void **)&b.ctl, BM_CTL_N * sizeof(unsigned long long)));
-	HIPCHK(hipHostMalloc((void **)&b.h_ctl, BM_CTL_N * sizeof(unsigned long long), hipHostMallocDefault));
-	return SDT_OK;
-}
-
-static int bm_table_alloc(sdt_ctx *c, sdt_ctx::BmTable &t, uint64_t cap, uint64_t dir_cap)
-{
-	// (the directory on its own: its size follows the input of a fold, which differs a little from run to run -- replacing the
-	// 30 GB of slots along with it cost 0.6 s whenever a fold needed three directory entries more than the last)
-	if (t.dir_cap < dir_cap || !t.dir) {
-		if (t.dir) (void)hipFree(t.dir);
-		if (t.cnt) (void)hipFree(t.cnt);
-		t.dir = nullptr;
-		t.cnt = nullptr;
-		t.dir_cap = 0;
-		const uint64_t want = dir_cap + dir_cap / 4;
-		hipError_t e = hipMalloc((void **)&t.dir, want * sizeof(BmDir));
-		if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, want * 4);
-		if (e != hipSuccess) {
-			bm_table_free(t);
-			(void)hipGetLastError();
-			return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu directory entries", (unsigned long long)want);
-		}
-		t.dir_cap = want;
-	}
-	if (t.cap >= cap && t.ent)
-		return SDT_OK;
-	if (t.ent) (void)hipFree(t.ent);
-	if (t.aux) (void)hipFree(t.aux);
-	if (t.first) (void)hipFree(t.first);
-	t.ent = nullptr; t.aux = nullptr; t.first = nullptr; t.cap = 0;
-	hipError_t e = hipMalloc(&t.ent, cap * entry_bytes(c->nw));
-	if (e == hipSuccess) e = hipMalloc((void **)&t.aux, cap * 4);
-	if (e == hipSuccess && (c->flags & SDT_FLAG_TRACK_FIRST)) e = hipMalloc((void **)&t.first, cap * 8);
-	if (e != hipSuccess) {
-		bm_table_free(t);
-		(void)hipGetLastError();
-		return fail(SDT_ENOMEM, "bucket-major node table: no device memory for %llu slots x %zu B", (unsigned long long)cap, entry_bytes(c->nw) + 4);
-	}
-	t.cap = cap;
-	return SDT_OK;
-}
-
-template <int NW, bool TRACK>
-static int bm_fold_launch(sdt_ctx *c, const LogDesc *sorted, const uint64_t *xent, bool have_old, sdt_ctx::BmTable &dst, const BmUnit *units, unsigned grid, const BmKnobs &kn)
-{
-	sdt_ctx::BmState &b = c->bm;
-	BmIn<NW> in;
-	in.desc = sorted;
-	in.doff = b.doff;
-	in.dpre = b.dpre;
-	in.old = have_old ? bm_view<NW>(c, b.tab) : Table<NW>{nullptr, nullptr, 0, nullptr, nullptr, 0, c->K};
-	in.old_cnt = have_old ? b.tab.cnt : nullptr;
-	in.xent = xent;
-	in.xoff = b.xoff;
-	BmOut<NW> out;
-	out.ent = (Entry<NW> *)dst.ent;
-	out.aux = dst.aux;
-	out.first = dst.first;
-	out.dir = dst.dir;
-	out.cnt = dst.cnt;
-	out.ctl = b.ctl;
-	out.cap = dst.cap;
-	using G = BmGeo<NW, TRACK>;
-	HIPCHK(hipFuncSetAttribute((const void *)k_bm_finalize<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
-	hipLaunchKernelGGL((k_bm_finalize<NW, TRACK>), dim3(grid), dim3(G::T), G::SMEM, c->stream, in, out, units, c->K, c->d_stats, kn);
-	HIPCHK(hipGetLastError());
-	return SDT_OK;
-}
-
-// Fold everything pass 1 has left so far -- the log's segments, the nodes of the flat table, the nodes of an earlier
-// bucket-major table -- into ONE bucket-major table; the log is empty and the flat table clear afterwards.  Host sync.
-static int bm_fold(sdt_ctx *c)
-{
-	sdt_ctx::BmState &b = c->bm;
-	const double t0 = comm_now();
-	int rc = bm_scratch_alloc(c);
-	if (rc != SDT_OK) return rc;
-	// what is there (host sync: the log's cursors, the flat table's node count)
-	uint64_t nlog = 0, ndesc = 0;
-	for (auto &sl : b.slabs) {
-		rc = log_refresh(c, sl);
-		if (rc != SDT_OK) return rc;
-		nlog += sl.ent_known;
-		ndesc += sl.desc_known;
-	}
-	HIPCHK(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-	{ const int rcw = c->comm.sync_watched(c->stream, "the fold of the node log"); if (rcw != SDT_OK) return rcw; }
-	if (c->h_stats->probe_fail)
-		return fail(SDT_EFULL, "%llu inserts found no slot (table over-full, node log or route bucket overflow)", (unsigned long long)c->h_stats->probe_fail);
-	const uint64_t nflat = c->h_stats->distinct;
-	const bool have_old = b.tab.valid;
-	const uint64_t nold = have_old ? b.tab.nodes : 0;
-	const int g = c->cu_count * 8;
-	// descriptors by bucket
-	LogDesc *sorted = nullptr;
-	uint64_t *xent = nullptr;
-	BmUnit *units = nullptr;
-	EventPair *ev = next_event(c);                   // (the fold is part of pass 1: sdt_gpu_kernel_time / sdt_gpu_stage_times count it)
-	if (!ev)
-		return fail(SDT_EHIP, "hipEventCreate failed");
-	ev->kmers = 0;
-	ev->stage = SDT_STAGE_SK_FOLD;
-	HIPCHK(hipEventRecord(ev->a, c->stream));
-	HIPCHK(hipEventRecord(ev->b, c->stream));         // (moved behind the merge kernel below; recorded here so that a failed fold leaves a valid pair)
-	HIPCHK(hipMemsetAsync(b.dcnt, 0, SK_NBF * 4, c->stream));
-	HIPCHK(hipMemsetAsync(b.dents, 0, SK_NBF * 8, c->stream));
-	for (auto &sl : b.slabs)
-		if (sl.desc_known)
-			hipLaunchKernelGGL(k_bm_desc_hist, dim3(g), dim3(256), 0, c->stream, (const LogDesc *)sl.desc, (const unsigned long long *)(sl.ctl + 1), sl.desc_cap, b.dcnt, b.dents);
-	hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, b.dcnt, b.doff, b.dfill, (int)SK_NBF, (const unsigned long long *)b.dents, b.dpre);
-	HIPCHK(hipGetLastError());
-	int ret = SDT_OK;
-#define FOLD_CHK(expr)                                                                                 \
-	do {                                                                                               \
-		hipError_t e5_ = (expr);                                                                       \
-		if (e5_ != hipSuccess) {                                                                       \
-			ret = fail(e5_ == hipErrorOutOfMemory ? SDT_ENOMEM : SDT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e5_), __FILE__, __LINE__); \
-			goto done;                                                                                 \
-		}                                                                                              \
-	} while (0)
-	{
-		if (b.sorted_cap < ndesc + 1) {
-			if (b.sorted) (void)hipFree(b.sorted);
-			b.sorted = nullptr;
-			b.sorted_cap = 0;
-			FOLD_CHK(hipMalloc((void **)&b.sorted, (ndesc + ndesc / 8 + 1024) * sizeof(LogDesc)));
-			b.sorted_cap = ndesc + ndesc / 8 + 1024;
-		}
-		sorted = b.sorted;
-		for (auto &sl : b.slabs)
-			if (sl.desc_known)
-				hipLaunchKernelGGL(k_bm_desc_place, dim3(g), dim3(256), 0, c->stream, (const LogDesc *)sl.desc, (const unsigned long long *)(sl.ctl + 1), sl.desc_cap,
-				                   (const uint32_t *)b.doff, b.dfill, sorted);
-		FOLD_CHK(hipGetLastError());
-		// the flat table's nodes by bucket
-		if (nflat) {
-			const int gs = scan_grid(c, c->slots);
-			FOLD_CHK(hipMemsetAsync(b.xcnt, 0, SK_NBF * 4, c->stream));
-			if (c->nw == 1) hipLaunchKernelGGL(k_bm_flat_hist<1>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<1>(c), c->K, b.xcnt);
-			else if (c->nw == 2) hipLaunchKernelGGL(k_bm_flat_hist<2>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<2>(c), c->K, b.xcnt);
-			else hipLaunchKernelGGL(k_bm_flat_hist<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, b.xcnt);
-			hipLaunchKernelGGL(k_sk_scan, dim3(1), dim3(1024), 0, c->stream, b.xcnt, b.xoff, b.xfill, (int)SK_NBF, (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
-			FOLD_CHK(hipMalloc((void **)&xent, nflat * (c->nw + 3) * 8));
-			if (c->nw == 1) hipLaunchKernelGGL(k_bm_flat_place<1>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<1>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
-			else if (c->nw == 2) hipLaunchKernelGGL(k_bm_flat_place<2>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<2>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
-			else hipLaunchKernelGGL(k_bm_flat_place<4>, dim3(gs), dim3(TPB), 0, c->stream, flat_of<4>(c), c->K, (const uint32_t *)b.xoff, b.xfill, xent);
-			FOLD_CHK(hipGetLastError());
-		}
-		// the table: k_bm_finalize gives a unit 1.25 slots per entry of its input when that fits one LDS image, 0.81 beyond, in steps
-		// of M / 16 slots -- about one slot per entry over a deep data set; again with what it asked for should that have been short
-		const uint64_t in_total = nlog + nold + nflat;
-		// workgroups of the merge: two per CU (k_bm_finalize), fewer for a small input -- each takes the table's slots in chunks of BM_CHUNK
-		unsigned grid = (unsigned)c->cu_count * BM_WGS_PER_CU;
-		if ((uint64_t)grid > in_total / 8192 + 1) grid = (unsigned)(in_total / 8192 + 1);
-		// (wide keys: 52 bytes per slot -- three quarters of that, and the second run when it was short)
-		uint64_t cap = (uint64_t)((double)(nold + nflat + nlog) * (c->nw == 1 ? 1.05 : 0.8)) + (uint64_t)SK_NBF * 256 + (uint64_t)grid * BM_CHUNK + (1u << 16);
-		// directory entries of the sub-buckets of giant buckets: a bucket of n > BM_GIANT entries takes 2^ceil(log2(n / BM_SUB_TARGET)) < 4 n / BM_SUB_TARGET
-		// (SDT_BM_GIANT / SDT_BM_SUB_TARGET / SDT_BM_LDS_CAP: test hooks -- small inputs through sub-buckets and several parts)
-		BmKnobs kn;
-		kn.giant = env_int("SDT_BM_GIANT", 0) > 0 ? (unsigned long long)env_int("SDT_BM_GIANT", 0) : BM_GIANT;
-		kn.sub_target = env_int("SDT_BM_SUB_TARGET", 0) > 0 ? (unsigned long long)env_int("SDT_BM_SUB_TARGET", 0) : BM_SUB_TARGET;
-		kn.lds_cap = (uint32_t)clamp_int(env_int("SDT_BM_LDS_CAP", 0), 0, 1 << 20);
-		if (kn.lds_cap && kn.lds_cap < 16) kn.lds_cap = 16;
-		// (a bucket past kn.giant takes 2^ceil(log2(n / sub_target)) <= 2 n / sub_target + 2 entries; at most in_total / giant buckets are that large)
-		const uint64_t ext_cap = in_total / kn.sub_target * 2 + in_total / kn.giant * 2 + 4096;
-		if (b.units_cap < (uint64_t)SK_NBF + ext_cap) {
-			if (b.units) (void)hipFree(b.units);
-			b.units = nullptr;
-			b.units_cap = 0;
-			FOLD_CHK(hipMalloc((void **)&b.units, ((size_t)SK_NBF + ext_cap + ext_cap / 8) * sizeof(BmUnit)));
-			b.units_cap = (uint64_t)SK_NBF + ext_cap + ext_cap / 8;
-		}
-		units = b.units;
-		sdt_ctx::BmTable &dst = have_old ? b.spare : b.tab;
-		// (buffers of an earlier fold are used as they are when they hold what this one can need at the very most -- 1.25 slots per
-		// entry --; what a fold takes differs a little from run to run, and asking for a few slots more than last time would
-		// replace 30 GB)
-		if (dst.ent && dst.cap < cap && dst.cap >= in_total + (uint64_t)SK_NBF * 64)
-			cap = dst.cap;
-		else if (!dst.ent || dst.cap < cap)
-			cap += cap / 16;
-		for (int attempt = 0; attempt < 2; attempt++) {
-			ret = bm_table_alloc(c, dst, cap, (uint64_t)SK_NBF + ext_cap);
-			if (ret != SDT_OK) goto done;
-			FOLD_CHK(hipMemsetAsync(b.ctl, 0, BM_CTL_N * sizeof(unsigned long long), c->stream));
-			FOLD_CHK(hipMemsetAsync(b.next, 0, 4, c->stream));
-			// work units (buckets, sub-buckets of giant buckets) in order of falling size, the directory entries of empty and giant buckets
-			FOLD_CHK(hipMemsetAsync(b.ccnt, 0, 65 * 4, c->stream));
-			hipLaunchKernelGGL(k_bm_class_hist, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
-			                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, b.ccnt, kn);
-			hipLaunchKernelGGL(k_bm_class_scan, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)b.ccnt, b.cstart, b.cfill, b.ctl);
-			hipLaunchKernelGGL(k_bm_class_place, dim3(g), dim3(256), 0, c->stream, (const unsigned long long *)b.dpre, have_old ? (const uint32_t *)b.tab.cnt : (const uint32_t *)nullptr,
-			                   nflat ? (const uint32_t *)b.xoff : (const uint32_t *)nullptr, (uint32_t)SK_NBF, (const uint32_t *)b.cstart, b.cfill, units, dst.dir, dst.cnt, b.ctl,
-			                   (uint32_t)ext_cap, c->d_stats, kn);
-			FOLD_CHK(hipGetLastError());
-			const bool track = (c->flags & SDT_FLAG_TRACK_FIRST) != 0;
-			if (c->nw == 1) ret = track ? bm_fold_launch<1, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<1, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
-			else if (c->nw == 2) ret = track ? bm_fold_launch<2, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<2, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
-			else ret = track ? bm_fold_launch<4, true>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn) : bm_fold_launch<4, false>(c, sorted, nflat ? xent : nullptr, have_old, dst, units, grid, kn);
-			if (ret != SDT_OK) goto done;
-			FOLD_CHK(hipEventRecord(ev->b, c->stream));
-			FOLD_CHK(hipMemcpyAsync(b.h_ctl, b.ctl, BM_CTL_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-			{ const int rcw = c->comm.sync_watched(c->stream, "the merge of the node log"); if (rcw != SDT_OK) { ret = rcw; goto done; } }
-			if (b.h_ctl[BM_CTL_SLOTS] <= dst.cap)
-				break;
-			if (attempt == 1) { ret = fail(SDT_ESTATE, "bucket-major table: %llu slots needed, %llu allocated twice", (unsigned long long)b.h_ctl[BM_CTL_SLOTS], (unsigned long long)dst.cap); goto done; }
-			// (the sizes are a function of the input; what is left over in the workgroups' chunks depends on the order of the units
-			// within a size class, which is not: a hundredth on top)
-			cap = b.h_ctl[BM_CTL_SLOTS] + b.h_ctl[BM_CTL_SLOTS] / 100 + (uint64_t)grid * BM_CHUNK + (1u << 16);
-		}
-		dst.nslots = b.h_ctl[BM_CTL_SLOTS];
-		dst.nodes = b.h_ctl[BM_CTL_NODES];
-		dst.valid = true;
-		b.restarts += b.h_ctl[BM_CTL_RESTARTS];
-		if (b.h_ctl[BM_CTL_MAXPARTS] > b.maxparts) b.maxparts = b.h_ctl[BM_CTL_MAXPARTS];
-		if (have_old) {
-			std::swap(b.tab, b.spare);
-			b.spare.valid = false;
-			b.spare.nslots = b.spare.nodes = 0;
-		}
-		// the log is empty, the flat table clear
-		for (auto &sl : b.slabs) {
-			FOLD_CHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
-			sl.ent_known = sl.desc_known = sl.ent_since = sl.desc_since = 0;
-		}
-		b.active = b.slabs.empty() ? -1 : 0;
-		b.log_dirty = false;
-		if (nflat) {
-			ret = launch_clear(c, c->d_ent, c->d_aux, c->d_first, c->slots);
-			if (ret != SDT_OK) goto done;
-			FOLD_CHK(hipMemsetAsync(&c->d_stats->distinct, 0, sizeof(unsigned long long), c->stream));
-		}
-		c->h_stats->distinct = 0;
-		c->distinct_known = 0;
-		c->kmers_since_sync = 0;
-		c->hard_since_sync = 0;
-		// (a fold invalidates slot numbers: whatever indexed the old table is gone)
-		if (c->d_idx) { (void)hipFree(c->d_idx); c->d_idx = nullptr; c->idx_slots = c->idx_n = 0; }
-		FOLD_CHK(hipStreamSynchronize(c->stream));
-		b.folds++;
-		b.fold_ms += (comm_now() - t0) * 1e3;
-		if (getenv("SDT_TIMING"))
-			fprintf(stderr, "[libsdt_gpu] node log folded: %llu entries in %llu segments + %llu flat + %llu old nodes -> %llu nodes in %llu slots (%llu restarts, %llu parts at most) in %.1f ms\n",
-			        (unsigned long long)nlog, (unsigned long long)ndesc, (unsigned long long)nflat, (unsigned long long)nold, (unsigned long long)b.tab.nodes,
-			        (unsigned long long)b.tab.nslots, (unsigned long long)b.h_ctl[BM_CTL_RESTARTS], (unsigned long long)b.h_ctl[BM_CTL_MAXPARTS], (comm_now() - t0) * 1e3);
-	}
-done:
-#undef FOLD_CHK
-	if (ret != SDT_OK)
-		(void)hipStreamSynchronize(c->stream);
-	if (xent) (void)hipFree(xent);
-	return ret;
-}
-
 static int drain_staged(sdt_ctx *c, bool force);
 
 static int sync_stats(sdt_ctx *c)
@@ -1138,13 +666,6 @@ static int sync_stats(sdt_ctx *c)
 	c->kmers_known = c->h_stats->kmers;
 	c->kmers_since_sync = 0;
 	c->hard_since_sync = 0;
-	// the count stage has appended to the node log (or the flat table has taken nodes beside a bucket-major one): one table again
-	if (!c->sk.flushing && (c->bm.log_dirty || (c->bm.tab.valid && c->h_stats->distinct))) {
-		const int rcf = bm_fold(c);
-		if (rcf != SDT_OK)
-			return rcf;
-	}
-	c->h_stats->distinct += c->bm.tab.valid ? c->bm.tab.nodes : 0;       // (the host's copy counts the nodes of BOTH tables; distinct_known is the flat one's)
 	return SDT_OK;
 }
 
@@ -1395,7 +916,7 @@ static int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	return sk_reset_pool1(c);
 }
 
-template <int NW, bool TRACK> static int sk_launch_count_flat_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
 {
 	sdt_ctx::SkState &k = c->sk;
 	const size_t smem = sk_count_smem<NW, TRACK>();
@@ -1403,37 +924,16 @@ template <int NW, bool TRACK> static int sk_launch_count_flat_t(sdt_ctx *c, uint
 	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 256));
 	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
 	if (grid > i1 - i0) grid = i1 - i0;
-	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count_flat<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-	hipLaunchKernelGGL((k_sk_count_flat<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, (const uint4 *)k.citems, i0, i1,
+	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	hipLaunchKernelGGL((k_sk_count<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, (const uint4 *)k.citems, i0, i1,
 	                   k.next_item + launch, c->K, flat_of<NW>(c), c->d_stats);
 	HIPCHK(hipGetLastError());
 	return SDT_OK;
 }
 
-template <int NW> static int sk_launch_count_flat(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
+template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch)
 {
-	return c->d_first ? sk_launch_count_flat_t<NW, true>(c, i0, i1, launch) : sk_launch_count_flat_t<NW, false>(c, i0, i1, launch);
-}
-
-template <int NW, bool TRACK> static int sk_launch_count_t(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch, const SkLog &lg)
-{
-	sdt_ctx::SkState &k = c->sk;
-	const size_t smem = sk_count_smem<NW, TRACK>();
-	// persistent workgroups: as many as the LDS tables let the chip hold; they take work items first come first served
-	const unsigned per_cu = (unsigned)((160 * 1024) / (smem + 1024));
-	unsigned grid = (unsigned)c->cu_count * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
-	if (grid > i1 - i0) grid = i1 - i0;
-	HIPCHK(hipFuncSetAttribute((const void *)k_sk_count<NW, TRACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-	hipLaunchKernelGGL((k_sk_count<NW, TRACK>), dim3(grid), dim3(SkCntGeo<NW, TRACK>::TPB), smem, c->stream, k.p2, k.list2, (const uint4 *)k.citems, i0, i1,
-	                   k.next_item + launch, c->K, lg, c->d_stats);
-	HIPCHK(hipGetLastError());
-	c->bm.log_dirty = true;
-	return SDT_OK;
-}
-
-template <int NW> static int sk_launch_count(sdt_ctx *c, uint32_t i0, uint32_t i1, uint32_t launch, const SkLog &lg)
-{
-	return (c->flags & SDT_FLAG_TRACK_FIRST) ? sk_launch_count_t<NW, true>(c, i0, i1, launch, lg) : sk_launch_count_t<NW, false>(c, i0, i1, launch, lg);
+	return c->d_first ? sk_launch_count_t<NW, true>(c, i0, i1, launch) : sk_launch_count_t<NW, false>(c, i0, i1, launch);
 }
 
 #define SK_CHK(expr)                                                                                   \
@@ -1505,8 +1005,8 @@ static int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_
 	return SDT_OK;
 }
 
-// count pool 2 bucket by bucket with merges into the flat table (rounds 2-4: SDT_FLAG_FLAT_MERGE, multi-word keys)
-static int sk_count_all_flat(sdt_ctx *c)
+// count pool 2 bucket by bucket (host sync first: the chunk lists of sk_split come back)
+static int sk_count_all(sdt_ctx *c)
 {
 	sdt_ctx::SkState &k = c->sk;
 	SK_CHK(hipStreamSynchronize(c->stream));
@@ -1586,97 +1086,11 @@ static int sk_count_all_flat(sdt_ctx *c)
 		if (rc == SDT_OK)
 			SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
 		if (rc == SDT_OK)
-			rc = c->nw == 1 ? sk_launch_count_flat<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count_flat<2>(c, i0, i1, (uint32_t)l) : sk_launch_count_flat<4>(c, i0, i1, (uint32_t)l);
+			rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l) : sk_launch_count<4>(c, i0, i1, (uint32_t)l);
 		if (rc == SDT_OK) {                              // (only what was launched counts)
 			c->kmers_since_sync += bound;
 			c->hard_since_sync += hard;
 		}
-		l = m + 1;
-	}
-	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
-	return rc;
-}
-
-// count pool 2 bucket by bucket (host sync first: the chunk lists of sk_split come back)
-static int sk_count_all(sdt_ctx *c)
-{
-	if (!c->node_log)
-		return sk_count_all_flat(c);
-
-	sdt_ctx::SkState &k = c->sk;
-	SK_CHK(hipStreamSynchronize(c->stream));
-	k.st_chunks2 = k.h_off2[SK_NBF];
-	k.st_flushes++;
-	k.stream_flushes++;
-	k.l2_in_total += k.h_kpre2[SK_NBF];
-	// work items = pieces of buckets of at most SK_COUNT_ITEM_CHUNKS chunks; planned launches of at most SK_COUNT_KMERS k-mers
-	// (the items and launches are a pure function of the chunk lists: sdt_count_plan.h, tested on the CPU)
-	int rc = SDT_OK;
-	uint32_t nci = 0;
-	SK_CHK(hipMemsetAsync(k.next_item, 0, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t), c->stream));
-	std::vector<uint32_t> first_item(SK_MAX_COUNT_LAUNCHES + 2);   // first item of every launch
-	std::vector<uint64_t> launch_kmers(SK_MAX_COUNT_LAUNCHES + 2);
-	uint32_t nlaunches = 0;
-	static_assert(sizeof(uint4) == SK_ITEM_WORDS * sizeof(uint32_t), "an item is four words");
-	if (!sk_plan_count_items(k.h_off2, (const uint64_t *)k.h_kpre2, (uint32_t)SK_NBF, SK_COUNT_KMERS, SK_COUNT_KMERS,
-	                         SK_MAX_COUNT_LAUNCHES, SK_COUNT_PACK_CHUNKS, SK_COUNT_ITEM_CHUNKS, (uint32_t *)k.h_citems, k.citems_cap,
-	                         first_item.data(), launch_kmers.data(), (uint32_t)first_item.size(), &nci, &nlaunches))
-		return fail(SDT_ESTATE, "count stage: work item table overflow");
-	first_item.resize(nlaunches + 1);
-	launch_kmers.resize(nlaunches);
-	std::vector<uint32_t> sort_tmp;
-	const uint32_t *iw = (const uint32_t *)k.h_citems;
-	// non-empty buckets of the items [i0, i1): what bounds the descriptors of a launch (an item's buckets are its own)
-	auto buckets_of = [&](uint32_t i0, uint32_t i1) -> uint64_t {
-		uint64_t n = 0;
-		for (uint32_t i = i0; i < i1; i++)
-			n += iw[SK_ITEM_WORDS * i + 3] - iw[SK_ITEM_WORDS * i + 2] + 1;
-		return n;
-	};
-	// A launch appends to the node log and must find room for whatever it may append: one entry per k-mer at the very most
-	// (log_reserve).  Until round 4 the launches were cut where the host had to look at the node table's load; now a planned
-	// launch joins the one before it as long as the log's slab has room for both under that bound -- a launch boundary is a
-	// drained GPU (every workgroup waits for the slowest), and it is only needed where the host decides about memory.
-	const size_t nl = first_item.size() - 1;
-	static const uint64_t merge_max = 1ULL << clamp_int(env_int("SDT_SK_LAUNCH_MAX_LOG2", 33), 20, 40);
-	for (size_t l = 0; l < nl && rc == SDT_OK;) {
-		const uint32_t i0 = first_item[l];
-		if (i0 == first_item[l + 1]) {
-			l++;
-			continue;
-		}
-		// how much the active slab could take without another look at the device
-		uint64_t hard = launch_kmers[l];
-		size_t m = l;
-		uint64_t room = 0;
-		if (c->bm.active >= 0) {
-			sdt_ctx::LogSlab &sl = c->bm.slabs[c->bm.active];
-			// (the bound of the launches since the last look is far above what they took: look again before giving up on joining launches)
-			if (sl.ent_since && sl.ent_known + sl.ent_since + hard + (m + 1 < nl ? launch_kmers[m + 1] : 0) > sl.ent_cap) {
-				rc = log_refresh(c, sl);
-				if (rc != SDT_OK) break;
-			}
-			const uint64_t used = sl.ent_known + sl.ent_since;
-			room = sl.ent_cap > used ? sl.ent_cap - used : 0;
-		}
-		while (m + 1 < nl && hard + launch_kmers[m + 1] <= merge_max) {
-			const uint64_t next = hard + launch_kmers[m + 1];
-			const uint64_t ni = first_item[m + 2] - i0;
-			if (next + (ni + next / 256 + 64) * SK_LOG_ALIGN > room)
-				break;
-			hard = next;
-			m++;
-		}
-		const uint32_t i1 = first_item[m + 1];
-		SkLog lg;
-		rc = log_reserve(c, hard, buckets_of(i0, i1), i1 - i0, &lg);
-		if (rc != SDT_OK) break;
-		// (largest first over everything this launch hands out -- the plan did it per planned launch; the sort is stable, so the
-		// concatenation of sorted runs comes out as one)
-		if (m > l)
-			sk_plan_largest_first((uint32_t *)k.h_citems, i0, i1, sort_tmp);
-		SK_CHK(hipMemcpyAsync(k.citems + i0, k.h_citems + i0, (size_t)(i1 - i0) * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
-		rc = c->nw == 1 ? sk_launch_count<1>(c, i0, i1, (uint32_t)l, lg) : c->nw == 2 ? sk_launch_count<2>(c, i0, i1, (uint32_t)l, lg) : sk_launch_count<4>(c, i0, i1, (uint32_t)l, lg);
 		l = m + 1;
 	}
 	// (the pinned item list must outlive its copy: the next flush rewrites it only after this stream has drained)
@@ -2139,20 +1553,10 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 	c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (est_distinct == 0)
 		est_distinct = 1ULL << 22;
-	// The flat table is the direct kernel family's (jobs below 2^27 k-mers, SDT_FLAG_DIRECT, the contig index); the locality
-	// pipeline builds the bucket-major table out of its log (sized when the log is folded: bm_fold) and uses the flat one only
-	// for records that found no chunk.  So the estimate sizes the flat table up to 2^27 slots and the fold beyond that.
-	// (measured on one box, profiles/r5/README.md: the node log is 1 % behind the flat merges on the headline workload, 11 % on the
-	// 400 M-read one, 5 % ahead on 50 M reads, and a quarter behind for 2-word keys: the flat merges stay the default)
-	c->node_log = false;
-	if (const char *pt = getenv("SDT_PASS1_TABLE")) c->node_log = !strcmp(pt, "log") ? true : (!strcmp(pt, "flat") ? false : c->node_log);
-	if (flags & SDT_FLAG_FLAT_MERGE) c->node_log = false;
-	if (flags & SDT_FLAG_NODE_LOG) c->node_log = true;
-	const uint64_t flat_max = ((flags & (SDT_FLAG_DIRECT | SDT_FLAG_CONTIG_INDEX)) || !c->node_log) ? ~0ULL : (1ULL << 27);
-	uint64_t slots = flat_slots_for(est_distinct);
-	if (slots > flat_max) slots = flat_max;
-	c->slots = slots;
-	c->bm.est_distinct = est_distinct;
+	// one node table for both kernel families (the direct one counts into it with one atomic per occurrence, the locality pipeline
+	// merges its LDS tables into it), sized by the caller's estimate and grown by k_rehash.  (Round 5 also built a node LOG folded
+	// into a bucket-major table; it ran at the speed of these merges and was removed in round 6: DESIGN.md section 3.)
+	c->slots = flat_slots_for(est_distinct);
 #define INIT_CHK(expr)                                                                    \
 	do {                                                                                  \
 		hipError_t e2_ = (expr);                                                          \
@@ -2216,7 +1620,6 @@ int sdt_gpu_destroy(sdt_ctx *c)
 	if (c->d_hit_cursor) (void)hipFree(c->d_hit_cursor);
 	for (int i = 0; i < 5; i++) if (c->ab[i]) (void)hipFree(c->ab[i]);
 	sk_free(c);
-	bm_free(c);
 	shard_free(c);
 	c->comm.close_all();
 	if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -2237,15 +1640,6 @@ int sdt_gpu_reset(sdt_ctx *c)
 	if (rc != SDT_OK)
 		return rc;
 	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), c->stream));
-	// the node log is empty, there is no bucket-major table (their buffers stay: the next run uses them)
-	for (auto &sl : c->bm.slabs) {
-		HIPCHK(hipMemsetAsync(sl.ctl, 0, 2 * sizeof(unsigned long long), c->stream));
-		sl.ent_known = sl.desc_known = sl.ent_since = sl.desc_since = 0;
-	}
-	c->bm.active = c->bm.slabs.empty() ? -1 : 0;
-	c->bm.log_dirty = false;
-	c->bm.tab.valid = false;
-	c->bm.tab.nslots = c->bm.tab.nodes = 0;
 	c->sk.l2_in_total = 0;
 	c->sk.stream_flushes = 0;
 	c->sk.exchanged = false;
@@ -2599,10 +1993,7 @@ int sdt_gpu_hint_total_kmers(sdt_ctx *c, uint64_t kmers)
 		const uint64_t per_slot = entry_bytes(c->nw) + 4 + ((c->flags & SDT_FLAG_TRACK_FIRST) ? 8 : 0);
 		while (est > (1u << 20) && (double)flat_slots_for(est) * (double)per_slot > (double)free_b * 0.3)
 			est /= 2;                                    // (never more than ~30 % of what is free)
-		if (c->node_log && !(c->flags & SDT_FLAG_DIRECT)) {
-			// (the locality pipeline folds its log into a table of its own: the estimate sizes THAT, bm_fold)
-			if (c->bm.est_distinct < est) c->bm.est_distinct = est;
-		} else if ((double)est > (double)c->slots * MAX_LOAD) {
+		if ((double)est > (double)c->slots * MAX_LOAD) {
 			const int rc = grow_table(c, est);
 			if (rc != SDT_OK) return rc;
 		}
@@ -2841,6 +2232,14 @@ int sdt_gpu_export_paths(sdt_ctx *c, uint64_t *keys, uint64_t *path_words, uint6
 	if (e == hipSuccess) e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e != hipSuccess) ret = fail(SDT_EHIP, "k_export_paths: %s", hipGetErrorString(e));
+	if (ret == SDT_OK) {
+		// every non-empty slot took a place: a table whose counters disagree with its slots would publish an incomplete graph
+		unsigned long long placed = 0;
+		e = hipMemcpy(&placed, &c->d_stats->scratch, sizeof placed, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) ret = fail(SDT_EHIP, "k_export_paths: %s", hipGetErrorString(e));
+		else if (placed != nodes)
+			ret = fail(SDT_ESTATE, "path export: the table holds %llu nodes, its counters say %llu", placed, (unsigned long long)nodes);
+	}
 	if (ret == SDT_OK) ret = sdti::d2h_big(c->copy_stream, keys, d_k, nodes * c->nw * 8);
 	if (ret == SDT_OK) ret = sdti::d2h_big(c->copy_stream, path_words, d_p, nodes * 8);
 	(void)hipFree(d_k);
@@ -2857,8 +2256,6 @@ int sdt_gpu_import_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_
 	int rc = sync_stats(c);
 	if (rc != SDT_OK) return rc;
 	// the table of this rank's shard makes way (the reads kept for the second pass stay): an empty flat table with room for the graph
-	c->bm.tab.valid = false;
-	c->bm.tab.nslots = c->bm.tab.nodes = 0;
 	if (c->d_idx) { (void)hipFree(c->d_idx); c->d_idx = nullptr; c->idx_slots = c->idx_n = 0; }
 	const uint64_t want = flat_slots_for(n);
 	if (want > c->slots) {
@@ -2899,7 +2296,31 @@ int sdt_gpu_import_paths(sdt_ctx *c, const uint64_t *keys, const uint64_t *path_
 	(void)hipFree(d_p);
 	if (rc != SDT_OK) return rc;
 	// patch table, arc map, and the check that every key went in once (sdt_gpu_load_paths with no node of its own to set)
-	return sdt_gpu_load_paths(c, nullptr, nullptr, 0, patch_keys, patch_info, npatch, num_ed);
+	rc = sdt_gpu_load_paths(c, nullptr, nullptr, 0, patch_keys, patch_info, npatch, num_ed);
+	if (rc == SDT_OK && c->h_stats->distinct != n)
+		return fail(SDT_ESTATE, "path import: %llu keys came, the table holds %llu nodes (a key twice?)", (unsigned long long)n,
+		            (unsigned long long)c->h_stats->distinct);
+	return rc;
+}
+
+int sdt_gpu_release_table(sdt_ctx *c)
+{
+	if (!c)
+		return fail(SDT_EINVAL, "ctx is NULL");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = sdti::release_pass1(c);                 // drains pass 1; the pools go back
+	if (rc != SDT_OK) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (c->d_ent) (void)hipFree(c->d_ent);
+	if (c->d_aux) (void)hipFree(c->d_aux);
+	if (c->d_first) (void)hipFree(c->d_first);
+	if (c->d_idx) { (void)hipFree(c->d_idx); c->d_idx = nullptr; c->idx_slots = c->idx_n = 0; }
+	c->d_ent = nullptr; c->d_aux = nullptr; c->d_first = nullptr;
+	c->slots = 0;
+	HIPCHK(hipMemsetAsync(&c->d_stats->distinct, 0, sizeof(unsigned long long), c->stream));
+	c->distinct_known = 0;
+	c->kmers_since_sync = c->hard_since_sync = 0;
+	return SDT_OK;
 }
 
 int sdt_gpu_map_reads(sdt_ctx *c, uint64_t *reads_processed, uint64_t *arcs)
@@ -3408,7 +2829,7 @@ int sdt_kmer_bucket(const uint64_t *key_words_msw_first, int K)
 
 int sdt_kmer_final_bucket(const uint64_t *key_words_msw_first, int K)
 {
-	// the final minimizer bucket (0 .. 2^18 - 1) of a k-mer: where the bucket-major node table keeps it (csrc/sdt_minimizer.cuh,
+	// the final minimizer bucket (0 .. 2^18 - 1) of a k-mer: the unit of the count stage (csrc/sdt_minimizer.cuh,
 	// the function the device's look-ups call)
 	if (!key_words_msw_first || K < 13 || K > 127)
 		return -1;
@@ -3422,16 +2843,9 @@ int sdt_gpu_table_info(sdt_ctx *c, uint64_t info[8])
 {
 	if (!c || !info)
 		return fail(SDT_EINVAL, "NULL argument");
-	info[0] = c->bm.tab.valid ? 1 : 0;               // layout: 0 flat, 1 bucket-major
+	for (int i = 0; i < 8; i++) info[i] = 0;
 	info[1] = view_slots(c);
-	info[2] = c->bm.tab.valid ? c->bm.tab.nodes : c->distinct_known;
-	info[3] = c->bm.folds;
-	info[4] = c->bm.restarts;
-	info[5] = c->bm.maxparts;
-	info[6] = (uint64_t)(c->bm.fold_ms * 1e3);       // microseconds spent folding the node log (host view, syncs included)
-	uint64_t logb = 0;
-	for (auto &sl : c->bm.slabs) logb += sl.ent_cap * (uint64_t)log_entry_words(c) * 8;
-	info[7] = logb;
+	info[2] = c->distinct_known;
 	return SDT_OK;
 }
 
@@ -3677,7 +3091,6 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 	}
 	if (counters) {
 		HIPCHK(hipMemcpy(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost));
-		c->h_stats->distinct += c->bm.tab.valid ? c->bm.tab.nodes : 0;
 		counters[0] = c->h_stats->sk_merges;
 		counters[1] = c->h_stats->sk_spills;
 		counters[2] = c->h_stats->sk_direct;
@@ -3693,7 +3106,7 @@ int sdt_gpu_stage_times(sdt_ctx *c, double ms[SDT_NSTAGES], uint64_t counters[SD
 		counters[16] = c->h_stats->sk_distinct_recs;
 		counters[17] = c->h_stats->sk_records;
 		counters[18] = c->h_stats->sk_distinct_kmers;
-		counters[19] = c->bm.restarts;
+		counters[19] = 0;
 	}
 	return SDT_OK;
 }
@@ -3705,11 +3118,8 @@ sdti::GraphView sdti::graph_view(sdt_ctx *c)
 {
 	GraphView v;
 	v.device = c->device; v.K = c->K; v.nw = c->nw; v.cu_count = c->cu_count;
-	// (the node table in whichever layout holds it: sdt_table.cuh)
-	const bool bmv = c->bm.tab.valid;
 	v.slots = view_slots(c);
-	v.d_ent = bmv ? c->bm.tab.ent : c->d_ent; v.d_aux = bmv ? c->bm.tab.aux : c->d_aux; v.d_first = bmv ? c->bm.tab.first : c->d_first;
-	v.dir = bmv ? c->bm.tab.dir : nullptr;
+	v.d_ent = c->d_ent; v.d_aux = c->d_aux; v.d_first = c->d_first;
 	v.d_stats = c->d_stats; v.h_stats = c->h_stats;
 	v.stream = c->stream; v.copy_stream = c->copy_stream;
 	v.d_idx = &c->d_idx; v.idx_slots = &c->idx_slots; v.idx_n = &c->idx_n;
@@ -3724,7 +3134,6 @@ int sdti::drop_first(sdt_ctx *c)
 {
 	HIPCHK(hipSetDevice(c->device));
 	if (c->d_first) { HIPCHK(hipFree(c->d_first)); c->d_first = nullptr; }
-	if (c->bm.tab.first) { HIPCHK(hipFree(c->bm.tab.first)); c->bm.tab.first = nullptr; }
 	return SDT_OK;
 }
 
@@ -3734,8 +3143,6 @@ int sdti::release_pass1(sdt_ctx *c)
 	if (rc != SDT_OK) return rc;
 	if (!getenv("SDT_KEEP_POOLS")) {                         // (measurement switch)
 		sk_free(c);
-		log_free(c);
-		bm_table_free(c->bm.spare);
 	}
 	return SDT_OK;
 }

@@ -43,7 +43,6 @@ uint64_t *graph_take_path_words(GraphExt *gx, uint64_t n);
 struct GraphView {
 	int device, K, nw, cu_count;
 	uint64_t slots;
-	const sdt::BmDir *dir;         // bucket-major layout (nullptr: flat, slots is a power of two)
 	void *d_ent;
 	uint32_t *d_aux;
 	uint64_t *d_first;
@@ -60,11 +59,8 @@ template <int NW> inline sdt::Table<NW> table_of(const GraphView &v)
 	sdt::Table<NW> t;
 	t.ent = (sdt::Entry<NW> *)v.d_ent;
 	t.aux = v.d_aux;
-	t.fslots = v.dir ? 0 : v.slots;
+	t.fslots = v.slots;
 	t.first = v.d_first;
-	t.dir = v.dir;
-	t.nslots = v.dir ? v.slots : 0;
-	t.K = v.K;
 	return t;
 }
 

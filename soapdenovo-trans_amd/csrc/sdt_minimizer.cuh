@@ -1,5 +1,5 @@
-// sdt_minimizer.cuh -- the minimizer bucket of a k-mer (shared by the locality pipeline, which files k-mers by it, and by the
-// bucket-major node table, whose look-ups find a key's bucket with it).
+// sdt_minimizer.cuh -- the minimizer bucket of a k-mer: what the locality pipeline files k-mers by and what decides the rank that
+// owns a k-mer (sdt_kmer_owner).
 //
 // A k-mer's bucket is a function of its canonical minimizer: the smallest hash among the canonical m-mers it contains
 // (m = 7..11, w = K - m + 1 of them).  A k-mer and its reverse complement contain the same canonical m-mers, so every

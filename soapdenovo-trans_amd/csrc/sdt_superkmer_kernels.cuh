@@ -40,7 +40,13 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TILE = 512;                                       // records per tile
 	// LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal).  1-word keys: 2048 slots = 75 KB with the tile, two
 	// workgroups per CU; with ordinals half the table keeps it at two
+#ifdef SDT_SK_TEST_SLOTS
+	// test build (libsdt_gpu_smalllds.so, tests/test_spills.py): an LDS table this small overflows in nearly every round, so that the
+	// spill path -- memory-side atomics on a table the same workgroup also writes with plain stores -- runs all the time
+	static constexpr int SLOTS = SDT_SK_TEST_SLOTS;
+#else
 	static constexpr int SLOTS = NW == 1 ? (TRACK ? SDT_SK_SLOTS_TRACK : 2048) : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);
+#endif
 	// (any size: 1-word keys with ordinals take 1536 slots, 36 B each -- the most that leaves two workgroups per CU)
 	static constexpr int FLUSH_AT = SLOTS * SDT_SK_FLUSH_NUM / 8;                            // flush + clear between rounds past this load ...
 	static constexpr int MAXFILL = SLOTS - 8;                             // ... a round counts 4 k-mers per slot left below this one
@@ -828,11 +834,11 @@ template <int NW, int SLOTS> __device__ inline uint32_t sk_lds_hash(const Key<NW
 
 // find-or-claim in the LDS table; -1: no room (full table or too many probes)
 template <int NW, int SLOTS>
-__device__ __forceinline__ int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill)
+__device__ __forceinline__ int sk_lds_locate(unsigned long long *s_key, uint32_t *s_fill, const Key<NW> &key, uint32_t maxfill, int max_probe = 96)
 {
 	uint32_t s = sk_lds_hash<NW, SLOTS>(key);
 	int found = -2;                                  // (flag form for the claimer of a multi-word key: see table_locate)
-	for (int probe = 0; probe < 96 && found == -2;) {
+	for (int probe = 0; probe < max_probe && found == -2;) {
 		uint64_t k0 = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (k0 == KEY_EMPTY) {
 			if (__hip_atomic_load(s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= maxfill)
@@ -903,18 +909,17 @@ __device__ inline uint64_t sk_weighted_val(uint32_t w, uint32_t prev, uint32_t n
 
 constexpr uint32_t SK_CNT_MAX_SINCE = 65535;     // k-mers counted into the LDS table between two clears at most (16-bit fields)
 
-// ---- count with merges into the FLAT node table (rounds 2-4; since round 5 the path of multi-word keys and of SDT_FLAG_FLAT_MERGE) --------
-// The same phases A-D as k_sk_count below; a flush MERGES every LDS node into the flat table -- without atomics when the workgroup is the
-// only writer of the bucket's keys in the launch, by one saturating compare-and-swap otherwise --, and a k-mer that finds no LDS slot goes
-// there directly.  Kept beside the node log because the log's fold is not faster for 2- and 4-word keys (profiles/r5/README.md: C4 27.9
-// against 35.8 G k-mers/s) and needs the log's memory on top of the table's.
+// A flush MERGES every LDS node into the node table -- without atomics when the workgroup is the only writer of the bucket's keys in
+// the launch, by one saturating compare-and-swap otherwise --, and a k-mer that finds no LDS slot goes there directly.  (Round 5 carried
+// a second form of this kernel that appended the LDS nodes to a node log, folded into a bucket-major table afterwards; the fold cost
+// what these merges cost -- profiles/r5/README.md -- and it was removed in round 6.  This kernel was k_sk_count_flat in rounds 2-5.)
 // (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU.  8 waves per SIMD also
 // means 78 usable SCALAR registers -- 800 per SIMD in granules of 16, 16 of every wave's reserved -- and this kernel keeps
 // about ninety uniform values: the overflow lives in lanes of vector registers.  Raising the scalar budget by hand
 // (amdgpu_waves_per_eu(4, 8) + amdgpu_num_vgpr(32) + amdgpu_num_sgpr(96)) removed every spill and cost the second workgroup
 // per CU: 172 -> 251 ms per step on the 200 M-read workload.)
 template <int NW, bool TRACK>
-__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count_flat(SkPool pool, const uint32_t *__restrict__ list2, const uint4 *__restrict__ items,
+__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint4 *__restrict__ items,
                                                          uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
                                                          Table<NW> tbl, Stats *stats)
 {
@@ -1012,7 +1017,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		__syncthreads();
 		if (item >= item1)
 			break;
-		const uint4 it = items[item];                // c0, c1 | whole (the bucket words are the node log's: k_sk_count)
+		const uint4 it = items[item];                // c0, c1 | whole (the bucket words: sdt_count_plan.h)
 		const uint32_t ity = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
 		const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), c1 = ity & 0x7FFFFFFFu;
 		const bool whole = (ity >> 31) != 0;        // the item is a whole bucket: nobody else touches its keys in this launch
@@ -1320,7 +1325,14 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 				// merges ran between the barrier and the read).  Hence two counters: round r adds to counter r & 1 only, so the
 				// other one stands still for the whole round and can be read at leisure; ko / km are the values all waves agree on.
 				const uint32_t fill0 = ko + (km & 0x7FFFFFFFu);  // < FLUSH_AT here
-				const uint32_t room = (MAXFILL - fill0) << room_shift;
+				// The round behind an owned flush -- its plain stores may still be on their way -- must not send a k-mer to the node table
+				// with a memory-side atomic: nothing orders another wave's plain store before that atomic on the same node.  So this one
+				// round (the table is empty: fill0 = 0) takes no more k-mers than three quarters of the slots and probes without a bound:
+				// every k-mer finds or claims a slot, whatever the keys are.  At the barrier that ends it every wave has waited for its own
+				// stores; any spill of a later round is behind all of them.
+				const bool guard = stores_pending;               // (uniform)
+				const uint32_t room = guard ? (uint32_t)(SLOTS * 3 / 4) : (MAXFILL - fill0) << room_shift;
+				const int max_probe = guard ? SLOTS : 96;
 				uint32_t *const fillc = &s_fillc[km >> 31];
 				const uint32_t maxfill = MAXFILL - ko;
 				const uint32_t qe = qb + room < total ? qb + room : total;
@@ -1336,7 +1348,7 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					const int len = hp + nr + K - 1 + sk_hdr_next(hr);
 					uint32_t prev, next;
 					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill);
+					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill, max_probe);
 					if (s >= 0) {
 						sk_lds_update(s_f, s, prev, next, wgt);
 						if (TRACK) {
@@ -1346,10 +1358,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 						}
 					} else {
 						s_spilled = 1;                   // this item's keys have met memory-side atomics: its merges must be atomics too
-						// (the plain stores of the last owned flush may still be in flight: this wave's own must have landed before its
-						// atomics touch the table.  Other waves' are not waited for here -- they were issued at least a barrier and a round
-						// of LDS work earlier; the next flush waits for all of them)
-						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						// (never in the round behind an owned flush, see `guard`: every plain store of that flush has landed -- its wave
+						// waited for it before the barrier that ended that round)
 						const uint64_t ord = TRACK ? ((sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j)) : ORD_NONE;
 						uint32_t cl = 0;
 						atomicAdd(&s_stat[ST_SPILLS], 1u);
@@ -1359,7 +1369,11 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 							atomicAdd(&s_stat[ST_CLAIMED], cl);
 					}
 				}
-				__syncthreads();
+				if (guard) {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores of the flush have landed ...
+					stores_pending = false;
+				}
+				__syncthreads();                             // ... and behind this barrier everybody's have
 				const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)*fillc);     // (nobody adds to it before the round after next)
 				const uint32_t fill1 = cur + ko;
 				km = ko | (~km & 0x80000000u);               // the next round adds to the other counter
@@ -1386,452 +1400,6 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 		if (s_stat[ST_FAILED]) atomicAdd(&stats->probe_fail, (unsigned long long)s_stat[ST_FAILED]);
 		if (s_stat[ST_MERGES]) atomicAdd(&stats->sk_merges, (unsigned long long)s_stat[ST_MERGES]);
 		if (s_stat[ST_SPILLS]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_SPILLS]);
-		if (s_stat[ST_GENS]) atomicAdd(&stats->sk_gens, (unsigned long long)s_stat[ST_GENS]);
-		if (s_stat[ST_KMERS]) {
-			atomicAdd(&stats->kmers, (unsigned long long)s_stat[ST_KMERS]);
-			atomicAdd(&stats->sk_counted, (unsigned long long)s_stat[ST_KMERS]);
-		}
-		if (s_stat[ST_RECS]) atomicAdd(&stats->sk_records, (unsigned long long)s_stat[ST_RECS]);
-		if (s_stat[ST_DRECS]) atomicAdd(&stats->sk_distinct_recs, (unsigned long long)s_stat[ST_DRECS]);
-		if (s_stat[ST_DKMERS]) atomicAdd(&stats->sk_distinct_kmers, (unsigned long long)s_stat[ST_DKMERS]);
-#ifdef SDT_SK_TICKS
-		for (int i = 0; i < 4; i++)
-			atomicAdd(&stats->sk_cyc[i], cyc[i]);
-#endif
-	}
-}
-
-// ---- the node log: what a flush of k_sk_count's LDS table leaves behind (round 5) ---------------------------------------
-// Until round 4 a flush MERGED every LDS node into the flat node table: a random 16..48-byte read-modify-write of HBM per distinct
-// key and generation, 2.5 generations per key, 5x the compulsory traffic of the stage and a memory-side compare-and-swap per new
-// key.  Now a flush APPENDS: the nodes of a bucket become one contiguous SEGMENT of (key, val[, ordinal])
-// entries in a log -- coalesced stores, no load, no atomic on a node -- and a descriptor (where, which bucket, how many).  All
-// segments of a bucket are merged once, in LDS, by k_bm_finalize (sdt_bm_kernels.cuh), which writes the bucket's nodes as a small
-// open-addressing table of their own: the bucket-major layout of sdt_table.cuh.
-struct LogDesc {
-	uint64_t ptr;              // device address of the segment's first entry
-	uint32_t bucket;           // final bucket
-	uint32_t count;            // entries
-};
-struct SkLog {                 // the slab a launch appends to
-	uint64_t *ent;             // entries: LW = NW + 1 (+ 1 with ordinals) words each
-	uint64_t ent_cap;          // entries
-	LogDesc *desc;
-	uint64_t desc_cap;
-	unsigned long long *ctl;   // [0] entries handed out, [1] descriptors handed out
-};
-constexpr int SK_LOG_ALIGN = 8;        // a segment starts at a multiple of this many entries (whole 128-byte lines)
-constexpr int SK_CNT_MAX_BUCKETS = 64; // final buckets a work item may hold (sdt_count_plan.h packs small neighbours within this span)
-
-// (1-word keys without ordinals: 64 registers per lane, so that two workgroups of 16 waves share a CU.  8 waves per SIMD also
-// means 78 usable SCALAR registers -- 800 per SIMD in granules of 16, 16 of every wave's reserved -- and this kernel keeps
-// about ninety uniform values: the overflow lives in lanes of vector registers.  Raising the scalar budget by hand
-// (amdgpu_waves_per_eu(4, 8) + amdgpu_num_vgpr(32) + amdgpu_num_sgpr(96)) removed every spill and cost the second workgroup
-// per CU: 172 -> 251 ms per step on the 200 M-read workload.)
-template <int NW, bool TRACK>
-__global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::WAVES_PER_SIMD)) void k_sk_count(SkPool pool, const uint32_t *__restrict__ list2, const uint4 *__restrict__ items,
-                                                         uint32_t item0, uint32_t item1, uint32_t *__restrict__ next_item, int K,
-                                                         SkLog lg, Stats *stats)
-{
-	using G = SkCntGeo<NW, TRACK>;
-	constexpr int BW = SkFmt<NW>::BW, RW = SkFmt<NW>::REC_WORDS, SLOTS = G::SLOTS;
-	constexpr uint32_t FLUSH_AT = G::FLUSH_AT, MAXFILL = G::MAXFILL;
-	constexpr int SK_CNT_TPB = G::TPB;
-	constexpr int TR = G::TILE;                      // records per tile: the first TR lanes bring one each
-	constexpr int CPT = TR / SK_CAP2;                // chunks per tile
-	constexpr int NWAVES = TR / 64;
-	constexpr uint32_t REP = G::REP, REP_EMPTY = 0xFFFFFFFFu;
-	constexpr int LW = NW + 1 + (TRACK ? 1 : 0);     // words of a log entry
-	extern __shared__ unsigned long long sm64[];
-	// (the tile's small arrays first: every base below 64 KB is an immediate offset of a ds instruction, not a register)
-	unsigned long long *s_h0 = sm64;                                     // TR: headers (TRACK: the smallest among a record's duplicates)
-	uint32_t *s_w = (uint32_t *)(s_h0 + TR);                             // TR: weight of a distinct record
-	uint32_t *s_pre = s_w + TR;                                          // TR + 2   } this region is the dedupe table s_rep
-	unsigned short *s_map = (unsigned short *)(s_pre + TR + 2);          // TR       } (REP words) during phase B
-	unsigned short *s_idx = s_map + TR;                                  // IDXN: distinct record of every 16th k-mer
-	uint32_t *s_rep = s_pre;
-	uint32_t *s_words = (uint32_t *)((char *)s_pre + G::REGION);         // LDS_LEAD + TR * BW * 2 + TAIL_PAD (an even number of words)
-	unsigned long long *s_key = (unsigned long long *)(s_words + LDS_LEAD + TR * BW * 2 + TAIL_PAD);     // NW x SLOTS, word-major
-	unsigned long long *s_ord = s_key + NW * SLOTS;                      // SLOTS when TRACK
-	uint32_t *s_f = (uint32_t *)(s_ord + (TRACK ? SLOTS : 0));           // 5 x SLOTS
-	__shared__ uint32_t s_fillc[2], s_item, s_full;          // s_fillc: keys in the LDS table = the sum of two counters, see phase D
-	// statistics of the workgroup: in LDS, not in registers that live across every phase (the kernel has 64 registers: two workgroups of 16 waves per CU)
-	enum { ST_FAILED, ST_MERGES, ST_RETRIES, ST_GENS, ST_KMERS, ST_RECS, ST_DRECS, ST_DKMERS, ST_N };
-	__shared__ uint32_t s_stat[ST_N];
-	__shared__ uint32_t s_ent[3 * (G::TILE / SK_CAP2)];      // ring of list entries: the tiles t, t + 1, t + 2 (see below)
-	__shared__ unsigned long long s_wsum[NWAVES];
-	__shared__ uint32_t s_bcnt[SK_CNT_MAX_BUCKETS], s_boff[SK_CNT_MAX_BUCKETS];     // flush: nodes per bucket of the item, their offsets in the segment
-	__shared__ unsigned long long s_seg;                     // flush: first entry of the segment (~0: the log is full)
-	const int tid = threadIdx.x;
-	for (int i = tid; i < SLOTS; i += SK_CNT_TPB) {
-		s_key[i] = KEY_EMPTY;
-		if (TRACK) s_ord[i] = ORD_NONE;
-	}
-	for (int i = tid; i < 5 * SLOTS; i += SK_CNT_TPB)
-		s_f[i] = 0;
-	if (tid < LDS_LEAD)
-		s_words[tid] = 0;
-	if (tid < TAIL_PAD)
-		s_words[LDS_LEAD + TR * BW * 2 + tid] = 0;
-	if (tid == 0) {
-		s_fillc[0] = s_fillc[1] = 0;
-		s_full = 0;
-	}
-	if (tid < ST_N)
-		s_stat[tid] = 0;
-	if (tid < SK_CNT_MAX_BUCKETS)
-		s_bcnt[tid] = 0;
-	uint32_t *words = s_words + LDS_LEAD;
-#ifdef SDT_SK_TICKS
-	unsigned long long cyc[4] = {0, 0, 0, 0}, t0 = wall_clock64(), t1;
-#define SK_TICK(i) do { t1 = wall_clock64(); cyc[i] += t1 - t0; t0 = t1; } while (0)
-#else
-#define SK_TICK(i) do { } while (0)
-#endif
-	constexpr int PER = (SLOTS + SK_CNT_TPB - 1) / SK_CNT_TPB;
-	uint32_t ko = 0, km = 0;                         // (uniform) the two key counters as of the last barrier: the one that stands still in the coming round; the one the round adds to (bit 31: which)
-	uint32_t room_shift = NW == 1 ? 2u : 1u;          // (uniform) a round of phase D takes 1, 2 or 4 k-mers per free slot of the LDS table
-	// work items = runs of chunks of one bucket (a giant bucket is several items: every piece is counted and logged on
-	// its own; small neighbours share one), handed out first come first served
-	for (;;) {
-		if (tid == 0)
-			s_item = item0 + atomicAdd(next_item, 1u);
-		__syncthreads();
-		const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);     // (uniform values belong in scalar registers)
-		__syncthreads();
-		if (item >= item1)
-			break;
-		const uint4 it = items[item];                // c0, c1 | whole, first and last final bucket (sdt_count_plan.h)
-		const uint32_t ity = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
-		const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), c1 = ity & 0x7FFFFFFFu;
-		const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z);          // the item's final buckets: f0 .. f0 + nbk - 1
-		const uint32_t nbk = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w) - f0 + 1u;
-		// Chunk id -> record are two dependent memory round trips per tile, and on this kernel's 64-register budget nothing can
-		// wait in registers across the counting loop: the compiler spilled every such value (the next record, its chunk id, even
-		// one prefetch dword), i.e. waited for the load at once -- with both trips in the open phases A-C were a third of the
-		// kernel's time (tick counters, profiles/r3).  So the prefetches live across phases A-C only, where registers are free:
-		// at the top of tile t wave 0 asks for the list entries of tile t + 2 and every record lane for ONE dword of its record
-		// of tile t + 1 (which pulls the record's line into L2); at the end of phase C the entries go into a ring of three rows
-		// in LDS and the dword is dropped.  The real record load at the top of a tile is then an L2 hit behind a known address.
-		// A list entry carries the chunk's fill (k_sk_chunk_place): pool.meta is not read here.  (LDS-DMA -- global_load_lds_dword,
-		// no destination register at all -- was tried for both and ran 10..50x slower than no prefetch: profiles/r3.)
-		auto rec_ptr = [&](uint32_t e, uint32_t t) -> const uint64_t * {
-			return pool.recs + ((size_t)(e & ((1u << SK_LIST2_FILL_SHIFT) - 1u)) * SK_CAP2 + t % SK_CAP2) * SkFmt<NW>::REC2_STRIDE;
-		};
-		auto rec_ok = [&](uint32_t e, uint32_t t) -> bool { return e != SK_NOCHUNK && t % SK_CAP2 <= (e >> SK_LIST2_FILL_SHIFT); };
-		auto ent_row = [&](uint32_t t) -> uint32_t * { return s_ent + (t % 3u) * CPT; };
-		if (tid < CPT) {
-			ent_row(0)[tid] = c0 + (uint32_t)tid < c1 ? list2[c0 + tid] : SK_NOCHUNK;
-			ent_row(1)[tid] = c0 + CPT + (uint32_t)tid < c1 ? list2[c0 + CPT + tid] : SK_NOCHUNK;
-		}
-		__syncthreads();
-		uint32_t tile_no = 0;
-		uint32_t since = 0;                          // k-mers counted into the LDS table since its last clear (uniform)
-		SK_TICK(0);
-		for (uint32_t cb = c0; cb < c1; cb += CPT) {
-			// ---- A: the first TR lanes put their record into LDS
-			// (phases A-C address everything from an opaque copy of the lane id: hoisted out of the tile loop, lane-dependent
-			// addresses would sit in -- spilled -- registers, and every reload of a spilled register waits for ALL loads in
-			// flight, the prefetches included)
-			uint32_t ot_ = (uint32_t)tid;
-			asm volatile("" : "+v"(ot_));
-			const int ot = (int)ot_;
-			uint32_t n = 0;
-			uint64_t h0 = 0;
-			uint64_t nx[RW];
-			uint32_t ring_e = SK_NOCHUNK, pf = 0;        // prefetches: in flight during phases A-C
-			const uint32_t e = ot < TR ? ent_row(tile_no)[ot / SK_CAP2] : SK_NOCHUNK;
-			const uint32_t e1 = ot < TR ? ent_row(tile_no + 1)[ot / SK_CAP2] : SK_NOCHUNK;
-			const bool ok = rec_ok(e, ot);
-			// (every lane loads, from a harmless address when it has nothing to load: behind a branch the compiler cannot count
-			// the loads in flight and waits for all of them; and the prefetches are issued BEHIND the loads this phase waits
-			// for, because vector memory returns in order)
-			sk_load_record<RW>(ok ? rec_ptr(e, ot) : pool.recs, nx);
-			const bool ring_ok = ot < CPT && cb + 2 * CPT + (uint32_t)ot < c1;
-			ring_e = (list2 + cb)[ring_ok ? 2 * CPT + ot : 0];
-			if (!ring_ok)
-				ring_e = SK_NOCHUNK;
-			if (SDT_SK_PREFETCH)
-				pf = *(const uint32_t *)(rec_ok(e1, ot) ? rec_ptr(e1, ot) : pool.recs);
-			if (ot < TR) {
-				if (ok) {
-					h0 = nx[0];
-					n = (uint32_t)sk_hdr_n(h0);
-#pragma unroll
-					for (int i = 0; i < BW; i++) {
-						words[ot * BW * 2 + 2 * i] = (uint32_t)(nx[1 + i] >> 32);
-						words[ot * BW * 2 + 2 * i + 1] = (uint32_t)nx[1 + i];
-					}
-				}
-				s_h0[ot] = h0;
-				s_w[ot] = 1;
-			}
-			for (uint32_t i = ot; i < REP; i += SK_CNT_TPB)
-				s_rep[i] = REP_EMPTY;
-			__syncthreads();                             // (also: the rounds of the last tile are over, the table is quiet)
-			// ---- B: dedupe
-			bool distinct = false;
-			if (n) {
-				distinct = true;
-				uint32_t x = (uint32_t)h0 & SK_HDR_KIND_MASK;
-#pragma unroll
-				for (int i = 0; i < BW; i++) {
-					x = __builtin_rotateleft32(x, 5) ^ (uint32_t)nx[1 + i];
-					x = __builtin_rotateleft32(x, 11) ^ (uint32_t)(nx[1 + i] >> 32);
-				}
-				uint32_t slot = (x * 0x85EBCA77u) >> (32 - 10);
-				static_assert(REP == 1024, "the dedupe slot is 10 bits of the hash");
-				for (;;) {
-					const uint32_t cur = atomicCAS(&s_rep[slot], REP_EMPTY, (uint32_t)ot);
-					if (cur == REP_EMPTY)
-						break;                           // this record represents its kind
-					// identical records: same bases, and the same low 18 header bits (bucket, n, context flags)
-					bool same = (((uint32_t)s_h0[cur] ^ (uint32_t)h0) & SK_HDR_KIND_MASK) == 0;
-#pragma unroll
-					for (int i = 0; i < BW; i++)
-						same = same && (((uint64_t)words[cur * BW * 2 + 2 * i] << 32) | words[cur * BW * 2 + 2 * i + 1]) == nx[1 + i];
-					if (same) {
-						atomicAdd(&s_w[cur], 1u);
-						if (TRACK)
-							atomicMin(&s_h0[cur], (unsigned long long)h0);
-						distinct = false;
-						break;
-					}
-					slot = (slot + 1) & (REP - 1);
-				}
-			}
-			// exclusive prefix sums over the distinct records: k-mers [15:0], records [31:16]; all k-mers of the tile [47:32], all its records [63:48]
-			const uint32_t n_mine = distinct ? n : 0u;
-			unsigned long long xs = ((unsigned long long)(n ? (n | 0x10000u) : 0u) << 32) | (distinct ? (n | 0x10000u) : 0u);
-			const unsigned long long xs_mine = xs;
-			if (ot < TR) {
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const unsigned long long y = __shfl_up(xs, d);
-					if ((ot & 63) >= d)
-						xs += y;
-				}
-				if ((ot & 63) == 63)
-					s_wsum[ot >> 6] = xs;
-			}
-			__syncthreads();
-			// ---- C: compact map of the distinct records
-			unsigned long long wbase = 0, tot = 0;
-#pragma unroll
-			for (int wv = 0; wv < NWAVES; wv++) {
-				const unsigned long long v = s_wsum[wv];
-				if (wv < (ot >> 6)) wbase += v;
-				tot += v;
-			}
-			const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tot), thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tot >> 32));
-			const uint32_t total = tlo & 0xFFFFu, ndist = tlo >> 16, tile_kmers = thi & 0xFFFFu;
-			// the 16-bit fields hold what this tile can add only if the table is young enough (uniform decision)
-			bool want_flush = since + tile_kmers > SK_CNT_MAX_SINCE;
-			since += tile_kmers;
-			if (distinct) {
-				const uint32_t ex = (uint32_t)(wbase + xs - xs_mine);
-				const uint32_t lo = ex & 0xFFFFu, ci = (ex >> 16) & 0xFFFFu, hi = lo + n_mine;
-				s_pre[ci] = lo;
-				s_map[ci] = (unsigned short)ot;
-				// coarse index: every 16th k-mer of the tile lies in exactly one record, which writes itself there
-				// (the look-up below starts from it instead of searching the whole prefix array)
-				for (uint32_t m16 = (lo + 15u) & ~15u; m16 < hi; m16 += 16u)
-					s_idx[m16 >> 4] = (unsigned short)ci;
-			}
-			if (ot < CPT)
-				ent_row(tile_no + 2)[ot] = ring_e;
-			asm volatile("" :: "v"(pf));                 // (the warm-up dword dies here)
-			if (ot == 0) {
-				s_pre[ndist] = total;
-				s_stat[ST_KMERS] += tile_kmers;
-				s_stat[ST_RECS] += thi >> 16;
-				s_stat[ST_DRECS] += ndist;
-				s_stat[ST_DKMERS] += total;
-			}
-			__syncthreads();
-			SK_TICK(1);
-			// ---- D: rounds of up to 4 k-mers per free slot: barriers are what this loop pays for.  A lane handles the k-mers
-			// tid, tid + TPB, ... of the tile and keeps its own position: a k-mer that finds the table full stays where it is,
-			// the table is flushed, and the round is taken up again (rounds 1-4 sent such k-mers to the node table one by one)
-			const bool last_tile = cb + CPT >= c1;
-			tile_no++;
-			uint32_t myq = (uint32_t)tid;
-			for (uint32_t qb = 0;;) {
-				if (want_flush) {
-					SK_TICK(2);
-					// ---- flush: every LDS node becomes an entry of its bucket's segment in the log, the table is cleared.
-					// (the ONE place where it is done -- before a tile that could overflow the fields, between rounds when the table
-					// is half full or a k-mer found no slot, after the item's last round)
-					bool have[PER];
-					uint32_t rel[PER], rank[PER];
-#pragma unroll
-					for (int p = 0; p < PER; p++) {
-						const int i = tid + p * SK_CNT_TPB;
-						have[p] = i < SLOTS && s_key[i] != KEY_EMPTY;
-						rel[p] = 0;
-						rank[p] = 0;
-						if (nbk == 1u) {                     // one bucket: ranks by ballot, one LDS atomic per wave
-							const unsigned long long bal = __ballot(have[p]);
-							const uint32_t below = (uint32_t)__popcll(bal & ((1ULL << (tid & 63)) - 1ULL));
-							uint32_t base = 0;
-							if ((tid & 63) == 0 && bal)
-								base = atomicAdd(&s_bcnt[0], (uint32_t)__popcll(bal));
-							rank[p] = (uint32_t)__shfl((int)base, 0) + below;
-						} else if (have[p]) {                // neighbours that share the item: the key says which one it belongs to
-							Key<NW> key;
-							key.w[0] = s_key[i];
-#pragma unroll
-							for (int wv = 1; wv < NW; wv++)
-								key.w[wv] = s_key[wv * SLOTS + i];
-							uint32_t r = key_final_bucket<NW>(key, K) - f0;
-							if (r >= nbk) r = 0;             // (cannot happen: every k-mer of the item lies in one of its buckets)
-							rel[p] = r;
-							rank[p] = atomicAdd(&s_bcnt[r], 1u);
-						}
-					}
-					__syncthreads();
-					if (tid < 64) {
-						// exclusive scan of the bucket counts by one wave; the segment and the descriptors come out of the log's cursors
-						const uint32_t cnt = (uint32_t)tid < nbk ? s_bcnt[tid] : 0u;
-						uint32_t x = cnt;
-#pragma unroll
-						for (int d = 1; d < 64; d <<= 1) {
-							const uint32_t y = __shfl_up(x, d);
-							if (tid >= d)
-								x += y;
-						}
-						const uint32_t total_ent = (uint32_t)__shfl((int)x, 63);
-						const unsigned long long nz = __ballot(cnt != 0u);
-						unsigned long long seg = 0, dseg = 0;
-						if (tid == 0 && total_ent) {
-							const uint32_t al = (total_ent + (uint32_t)SK_LOG_ALIGN - 1u) & ~((uint32_t)SK_LOG_ALIGN - 1u);
-							seg = atomicAdd(&lg.ctl[0], (unsigned long long)al);
-							dseg = atomicAdd(&lg.ctl[1], (unsigned long long)__popcll(nz));
-							if (seg + al > lg.ent_cap || dseg + (unsigned long long)__popcll(nz) > lg.desc_cap)
-								seg = ~0ULL;                 // the host keeps room for every k-mer of a launch: never expected
-							s_seg = seg;
-							s_stat[ST_MERGES] += total_ent;
-							if (seg == ~0ULL) s_stat[ST_FAILED] += total_ent;
-						}
-						seg = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(seg >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)seg, 0);
-						dseg = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(dseg >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)dseg, 0);
-						s_boff[tid] = x - cnt;
-						if (cnt && seg != ~0ULL) {
-							LogDesc d;
-							d.ptr = (uint64_t)(lg.ent + (size_t)(seg + (x - cnt)) * LW);
-							d.bucket = f0 + (uint32_t)tid;
-							d.count = cnt;
-							lg.desc[dseg + (unsigned long long)__popcll(nz & ((1ULL << tid) - 1ULL))] = d;
-						}
-						if (tid == 0)
-							s_full = 0;
-					}
-					__syncthreads();
-					const unsigned long long seg = s_seg;
-#pragma unroll
-					for (int p = 0; p < PER; p++) {
-						const int i = tid + p * SK_CNT_TPB;
-						if (have[p]) {
-							if (seg != ~0ULL) {
-								uint64_t *dst = lg.ent + (size_t)(seg + s_boff[rel[p]] + rank[p]) * LW;
-								const uint64_t val = sk_lds_val(&s_f[5 * i]);
-								if (NW == 1 && !TRACK) {
-									*reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(s_key[i], val);       // (16-byte entries, 16-byte aligned)
-								} else {
-#pragma unroll
-									for (int wv = 0; wv < NW; wv++)
-										dst[wv] = s_key[wv * SLOTS + i];
-									dst[NW] = val;
-									if (TRACK) dst[NW + 1] = (uint64_t)s_ord[i];
-								}
-							}
-							s_key[i] = KEY_EMPTY;
-#pragma unroll
-							for (int f = 0; f < 5; f++)
-								s_f[5 * i + f] = 0;
-							if (TRACK) s_ord[i] = ORD_NONE;
-						}
-					}
-					if (tid < SK_CNT_MAX_BUCKETS)
-						s_bcnt[tid] = 0;
-					if (tid == 0) {
-						s_fillc[0] = s_fillc[1] = 0;
-						if (!(last_tile && qb >= total)) s_stat[ST_GENS]++;
-					}
-					__syncthreads();
-					ko = 0;
-					km &= 0x80000000u;
-					since = tile_kmers;                  // (what is left of this tile is at most the tile)
-					SK_TICK(3);
-				}
-				if (qb >= total)
-					break;
-				// The number of keys in the table decides how long a round is and when to flush, so every wave must see the SAME number:
-				// a wave that read one live counter a little late -- after a faster wave had claimed the next round's first slots --
-				// would take another branch than its workgroup and meet it at the wrong barrier (seen as hangs and lost k-mers once
-				// merges ran between the barrier and the read).  Hence two counters: round r adds to counter r & 1 only, so the
-				// other one stands still for the whole round and can be read at leisure; ko / km are the values all waves agree on.
-				const uint32_t fill0 = ko + (km & 0x7FFFFFFFu);  // < FLUSH_AT here
-				const uint32_t room = (MAXFILL - fill0) << room_shift;
-				uint32_t *const fillc = &s_fillc[km >> 31];
-				const uint32_t maxfill = MAXFILL - ko;
-				const uint32_t qe = qb + room < total ? qb + room : total;
-				for (; myq < qe; myq += SK_CNT_TPB) {
-					const uint32_t q = myq;
-					uint32_t ci = s_idx[q >> 4];             // the record of k-mer q & ~15; q's own is at most a few records on
-					while (s_pre[ci + 1] <= q)
-						ci++;
-					const int r = s_map[ci];
-					const int j = (int)(q - s_pre[ci]);
-					const uint64_t hr = s_h0[r];
-					const uint32_t wgt = s_w[r];
-					const int hp = sk_hdr_prev(hr), nr = sk_hdr_n(hr);
-					const int len = hp + nr + K - 1 + sk_hdr_next(hr);
-					uint32_t prev, next;
-					const Key<NW> key = chop_record<NW>(words, r * BW * 32, len, hp + j, K, prev, next);
-					const int s = sk_lds_locate<NW, SLOTS>(s_key, fillc, key, maxfill);
-					if (s < 0) {
-						s_full = 1;                      // no slot: this lane waits here for the flush (its later k-mers wait with it)
-						break;
-					}
-					sk_lds_update(s_f, s, prev, next, wgt);
-					if (TRACK) {
-						const uint64_t ord = (sk_hdr_read(hr) << 16) | (uint64_t)(sk_hdr_pos(hr) + (uint32_t)j);
-						if (ord < *(volatile unsigned long long *)&s_ord[s])
-							atomicMin(&s_ord[s], (unsigned long long)ord);
-					}
-				}
-				__syncthreads();
-				const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)*fillc);     // (nobody adds to it before the round after next)
-				const bool full = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&s_full) != 0;      // (cleared inside the flush it asks for, behind a barrier)
-				const uint32_t fill1 = cur + ko;
-				km = ko | (~km & 0x80000000u);               // the next round adds to the other counter
-				ko = cur;
-				// k-mers per free slot in a round follow the data: a round that used more than half of the free slots halves them (the
-				// next one might have run out), a full round that used less than an eighth doubles them
-				if (NW > 1 || full) {                        // (1-word keys, K <= 31: 4 per slot has always been enough, and the bookkeeping costs 5 %)
-					if (full || (fill1 - fill0) * 2u > MAXFILL - fill0)
-						room_shift = room_shift ? room_shift - 1u : 0u;
-					else if (qe - qb == room && (fill1 - fill0) * 8u < MAXFILL - fill0 && room_shift < 2u)
-						room_shift++;
-				}
-				if (full) {
-					if (tid == 0) s_stat[ST_RETRIES]++;
-					want_flush = true;                       // ... and the same stretch again: the lanes that were done with it have nothing left in it
-				} else {
-					qb = qe;
-					want_flush = (qb >= total && last_tile) || fill1 >= FLUSH_AT;     // the item is done: the table must be clear for the next one
-				}
-			}
-			SK_TICK(2);
-		}
-	}
-#undef SK_TICK
-	__syncthreads();
-	if (tid == 0) {
-		if (s_stat[ST_FAILED]) atomicAdd(&stats->probe_fail, (unsigned long long)s_stat[ST_FAILED]);
-		if (s_stat[ST_MERGES]) atomicAdd(&stats->sk_merges, (unsigned long long)s_stat[ST_MERGES]);
-		if (s_stat[ST_RETRIES]) atomicAdd(&stats->sk_spills, (unsigned long long)s_stat[ST_RETRIES]);
 		if (s_stat[ST_GENS]) atomicAdd(&stats->sk_gens, (unsigned long long)s_stat[ST_GENS]);
 		if (s_stat[ST_KMERS]) {
 			atomicAdd(&stats->kmers, (unsigned long long)s_stat[ST_KMERS]);

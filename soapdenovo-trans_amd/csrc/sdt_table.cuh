@@ -51,103 +51,29 @@ template <> struct alignas(16) Entry<4> {   // 48 B: three dwordx4 loads
 	uint64_t pad;
 };
 
-// Bucket-major layout (round 5; what pass 1 of the locality pipeline leaves, sdt_bm_kernels.cuh): the nodes of one minimizer
-// bucket (SK_NBF of them) lie together -- `parts` small open-addressing tables of `ssub` slots each, one behind the other from
-// slot `base` on; a key's table is chosen by the high half of its hash, its home slot by the low half, probing wraps inside the
-// table.  Entry / aux / first are the flat layout's, so every scan (delow, mark, export, layout keys ...) is the same loop over
-// [0, nslots); a look-up by key needs the key's bucket, i.e. its minimizer (key_final_bucket: w m-mer hashes).  Why: the keys
-// a workgroup of k_sk_count merges are the keys of ONE bucket, so the whole table is built by streaming -- no random
-// read-modify-write of HBM per distinct key and generation.
-struct BmDir {
-	uint64_t base;        // first slot of the bucket's tables
-	uint32_t ssub;        // slots per table (a multiple of 8)
-	uint32_t parts;       // tables (0: the bucket is empty)
-	// ssub == 0 && parts != 0: a GIANT bucket, cut into 2^parts sub-buckets by the top bits of the hash's high half; base = index of
-	// the first of their 2^parts directory entries (behind the SK_NBF bucket entries)
-};
-
 template <int NW> struct Table {
 	Entry<NW> *ent;
 	uint32_t *aux;
 	uint64_t fslots;      // flat layout: slots (any number since round 5: the home slot is the high word of hash x slots, not hash & mask --
 	                      // a table of 2^31 slots for the 0.68 G nodes of the headline workload was a third more to clear and scan than it needs)
 	uint64_t *first;      // optional (SDT_FLAG_TRACK_FIRST): smallest ordinal of an occurrence of the key, ~0 = none
-	const BmDir *dir;     // bucket-major layout: SK_NBF directory entries (nullptr: flat)
-	uint64_t nslots;      // bucket-major layout: slots in use
-	int K;                // bucket-major layout: the k-mer size (look-ups compute the minimizer)
-	__host__ __device__ uint64_t slots() const { return dir ? nslots : fslots; }
+	__host__ __device__ uint64_t slots() const { return fslots; }
 };
-
-// The two hashes of the bucket-major layout: `hi` picks the sub-bucket (its top bits) and the table (the bits below), `lo` the home
-// slot.  Cheap on purpose -- a fold of the key words and two 32-bit multiplies each: k_bm_finalize computes `hi` for every entry of
-// the log in every pass over a bucket, and key_hash (four 64-bit multiplies) was a third of its instructions.  Keys that collide in
-// the fold collide in both: they only share a probe sequence.
-template <int NW> __host__ __device__ inline uint32_t bm_fold(const Key<NW> &k)
-{
-	uint32_t x = 0x9747B28Cu;
-#pragma unroll
-	for (int i = 0; i < NW; i++) {
-		x = ((x << 7) | (x >> 25)) ^ (uint32_t)k.w[i];
-		x = ((x << 9) | (x >> 23)) ^ (uint32_t)(k.w[i] >> 32);
-	}
-	return x;
-}
-__host__ __device__ inline uint32_t bm_hash_hi(uint32_t fold)
-{
-	uint32_t h = fold * 0x85EBCA6Bu;
-	h ^= h >> 15;
-	h *= 0xC2B2AE35u;
-	return h ^ (h >> 16);
-}
-__host__ __device__ inline uint32_t bm_hash_lo(uint32_t fold)
-{
-	uint32_t h = (fold ^ 0x5BD1E995u) * 0x27D4EB2Fu;
-	h ^= h >> 13;
-	h *= 0x165667B1u;
-	return h ^ (h >> 16);
-}
-
-// home slot of a key in a table of `msz` slots (a multiple of 8) from its `lo` hash: a multiple of four -- k_bm_finalize probes
-// the LDS image of a table four slots at a time (sdt_bm_kernels.cuh: bm_locate), and four 16-byte entries are one 64-byte sector
-// in HBM.
-template <int NW> __host__ __device__ inline uint32_t bm_home(uint32_t hlo, uint32_t msz)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	return __umulhi(hlo, msz >> 2) << 2;
-#else
-	return (uint32_t)(((uint64_t)hlo * (msz >> 2)) >> 32) << 2;
-#endif
-}
 
 // home slot of a key in the flat table
 template <int NW> __device__ inline uint64_t flat_home(const Table<NW> &t, const Key<NW> &key) { return __umul64hi(key_hash<NW>(key), t.fslots); }
 __device__ inline uint64_t flat_next(uint64_t slot, uint64_t fslots) { return slot + 1 == fslots ? 0 : slot + 1; }
 
-// Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times; n == 0:
-// the key's bucket is empty (bucket-major) -- the key is not there.
+// Where the probe sequence of `key` starts and the range it wraps in: slot = home, then probe_next() up to `n` times
 template <int NW> __device__ inline void probe_begin(const Table<NW> &t, const Key<NW> &key, uint64_t &slot, uint64_t &lo, uint64_t &n)
 {
-	if (!t.dir) {
-		lo = 0;
-		n = t.fslots;
-		slot = flat_home<NW>(t, key);
-		return;
-	}
-	BmDir d = t.dir[key_final_bucket<NW>(key, t.K)];
-	const uint32_t f = bm_fold<NW>(key);
-	uint32_t hh = bm_hash_hi(f);
-	if (d.ssub == 0 && d.parts) {                        // a giant bucket: 2^parts sub-buckets with directory entries of their own
-		const uint32_t lg = d.parts;
-		d = t.dir[d.base + (hh >> (32u - lg))];
-		hh <<= lg;
-	}
-	n = d.parts ? d.ssub : 0;
-	lo = d.base + (uint64_t)__umulhi(hh, d.parts) * d.ssub;
-	slot = lo + bm_home<NW>(bm_hash_lo(f), d.ssub);
+	lo = 0;
+	n = t.fslots;
+	slot = flat_home<NW>(t, key);
 }
 __device__ inline uint64_t probe_next(uint64_t slot, uint64_t lo, uint64_t n) { return slot + 1 == lo + n ? lo : slot + 1; }
 
-// read-only look-up in either layout: the slot of `key`, or false
+// read-only look-up: the slot of `key`, or false
 template <int NW> __device__ inline bool table_find(const Table<NW> &t, const Key<NW> &key, uint64_t &slot_out)
 {
 	uint64_t slot, lo, n;

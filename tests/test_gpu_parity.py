@@ -35,10 +35,9 @@ def node_dict_oracle(o):
     return {k: (int(a), int(b), f(c), int(d)) for k, a, b, c, d in zip(ki, l, r, fl, cnt)}
 
 
-# SDT_FLAG_DIRECT (one atomic per occurrence); SDT_FLAG_PARTITION (super-k-mer buckets counted in LDS) with SDT_FLAG_FLAT_MERGE (every
-# generation of the LDS table merged into the flat table: rounds 2-4) and with SDT_FLAG_NODE_LOG (appended to the node log, folded
-# into the bucket-major table: round 5) -- every key width through both, whatever its default is
-MODES = [1, 2 | 32, 2 | 64]
+# the two pass-1 kernel families: SDT_FLAG_DIRECT (one atomic per occurrence) and SDT_FLAG_PARTITION (the locality pipeline: super-k-mer
+# buckets counted in LDS, every generation of the LDS table merged into the node table)
+MODES = [1, 2]
 
 
 @pytest.mark.parametrize("mode", MODES)

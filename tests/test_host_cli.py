@@ -53,6 +53,41 @@ def test_reader_matches_reference_ingest(pkg, tmp_path, name, threads, chunk, po
         assert got == want
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("name", ["pe150_k31_p8", "se100_k23_p8_d1", "dirty_ragged_k25_cut80"])
+def test_multi_rank_reader_parses_every_chunk_once_and_agrees_on_ordinals(pkg, tmp_path, name, nranks):
+    """`sdt-pregraph --gpus N` without a GPU: the pass as one rank walks it (the ordinals of sdt_stream_reads are the truth) against the
+    pass as each of N ranks walks it with foreign chunks SKIPPED (seqio.h: sdt_read_shard_skip_foreign): every chunk parsed by exactly its
+    owner, the bytes parsed by all ranks together == the bytes of the input (round 5: every rank line-scanned every chunk, N scans of the
+    text), and the ordinals worked out from the owners' record counts (readstream.h: sdt_stream_ordinals_next -- what sdt-pregraph does
+    after the all-gather that ends a group of N chunks) equal the truth for every chunk, paired files and several libraries included.
+    Reference: ONE reader hands reads to all threads, prlHashReads.c:432-620."""
+    info = gu.load_case(name)
+    cfg = materialise(info, tmp_path)
+    for chunk in (3000, 30000, 1 << 30):
+        r = subprocess.run([bin_path(pkg, "sdt-readdump"), "--ordinals", str(nranks), cfg, "4", str(chunk)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.startswith("ordinals OK"), r.stdout
+
+
+def test_multi_rank_reader_ordinals_with_empty_files_and_several_libraries(pkg, tmp_path):
+    """the ordinal arithmetic across files: a pair whose second file is empty, a pair whose first file is empty, single files between
+    them, two libraries (a file without a record yields no chunk: the arithmetic never sees it)"""
+    def fq(path, n, tag):
+        path.write_text("".join(f"@{tag}{i}\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" for i in range(n)))
+    names = {}
+    for tag, n in (("a1", 57), ("a2", 0), ("b1", 0), ("b2", 31), ("c1", 40), ("c2", 44), ("s1", 23), ("s2", 0), ("s3", 9)):
+        names[tag] = tmp_path / f"{tag}.fq"
+        fq(names[tag], n, tag)
+    cfg = tmp_path / "lib.cfg"
+    cfg.write_text(f"max_rd_len=50\n[LIB]\navg_ins=200\nasm_flags=3\nq1={names['a1']}\nq2={names['a2']}\nq1={names['b1']}\nq2={names['b2']}\n"
+                   f"q1={names['c1']}\nq2={names['c2']}\nq={names['s1']}\nq={names['s2']}\n[LIB]\navg_ins=500\nasm_flags=1\nq={names['s3']}\nq1={names['c2']}\nq2={names['c1']}\n")
+    for nranks in (2, 3, 5):
+        for chunk in (200, 700, 1 << 20):
+            r = subprocess.run([bin_path(pkg, "sdt-readdump"), "--ordinals", str(nranks), str(cfg), "3", str(chunk)], capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0 and r.stdout.startswith("ordinals OK"), r.stdout + r.stderr
+
+
 def test_config_parser(pkg, tmp_path):
     f = tmp_path / "a.fa"
     f.write_text(">x\nACGTNN..acgt\n>y\nTTTT\nGGGG\n")
@@ -101,7 +136,6 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     env = dict(os.environ)
     if second_pass == "pipeline":
         env["SDT_PIPELINE"] = "1"
-        env["SDT_PASS1_TABLE"] = "log"               # (multi-word keys take the flat merges by default: here all widths use the node log)
     if second_pass == "replay-limit":
         env["SDT_RP_MAX_ROUNDS"] = "0"
     if second_pass == "few-workgroups":
@@ -124,7 +158,7 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpus,second", [(2, "ranks"), (3, "ranks"), (4, "ranks"), (2, "rank0"), (3, "host")])
+@pytest.mark.parametrize("gpus,second", [(2, "ranks"), (3, "ranks"), (4, "ranks"), (8, "ranks"), (3, "one-chunk"), (2, "rank0"), (3, "host")])
 @pytest.mark.parametrize("name", ["se100_k23_p8_d1", "pe150_k31_p8", "se250_k63_p8_127mer", "dirty_ragged_k25_cut80"])
 def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus, second):
     """`sdt-pregraph --gpus N`: one process per rank (forked before HIP is touched; here all on the one GPU of the box over
@@ -132,7 +166,8 @@ def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus, second
     sharded, shards gathered on rank 0 for the graph phases: all five files as the reference wrote them.
     second = ranks: every rank keeps the reads it parsed and maps them against the graph rank 0 publishes (key -> path word), the
     arcs of all ranks add up (round 5; prlRead2path.c:817-1335 on every rank's share); rank0: rank 0 keeps and maps all reads
-    (rounds 2-4, SDT_RANK0_MAP); host: --host-map, the host reads the files again"""
+    (rounds 2-4, SDT_RANK0_MAP); host: --host-map, the host reads the files again; one-chunk: the default chunk size (32 MiB), so that
+    the whole input is ONE chunk and ranks 1 and 2 own none of it -- they keep no reads and leave empty arc lists"""
     info = gu.load_case(name)
     cfg = materialise(info, tmp_path)
     cmd = [bin_path(pkg, "sdt-pregraph"), "pregraph", "-s", cfg, "-K", str(info["K"]), "-p", str(info["p"]), "-o",
@@ -140,6 +175,8 @@ def test_cli_multi_process_all_files_identical(pkg, tmp_path, name, gpus, second
     if info["d"]:
         cmd += ["-d", str(info["d"])]
     env = dict(os.environ, SDT_CHUNK_BYTES="30000")
+    if second == "one-chunk":
+        del env["SDT_CHUNK_BYTES"]
     if second == "rank0":
         env["SDT_RANK0_MAP"] = "1"
     if second == "host":

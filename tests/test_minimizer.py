@@ -1,5 +1,5 @@
 """CPU: the minimizer bucket of a k-mer (csrc/sdt_minimizer.cuh through sdt_kmer_final_bucket) -- the function the look-ups of the
-bucket-major node table call on the device -- against a plain Python restatement: canonical m-mers of the k-mer, the smallest hash,
+multi-GPU owner function call on the device -- against a plain Python restatement: canonical m-mers of the k-mer, the smallest hash,
 its second mix, the top 18 bits.  The level-1 scatter files a k-mer under the same value (tests/test_sharded.py pins that half on
 the GPU through sdt_kmer_bucket = the top 8 bits).  No reference counterpart: which bucket a k-mer lies in is a layout detail of
 this implementation (the reference's is hash_kmer % thrd_num, hashFunction.c:108-122)."""
