@@ -8,7 +8,8 @@ then the linear-mark + kmerFreq scan.  Inputs (packed 2-bit reads) are resident 
 region.  value = k-mer occurrences of the WHOLE job / wall time of the step (max over ranks).
 
 Workload: BASELINE.json metric "200M x 150bp, K=31" (configs[2]) when --reads is not given, as STRONG
-scaling: the same 200 M reads are split over the N ranks.  --reads/--read-len/--K/--T select other configs
+scaling: the same 200 M reads -- the very reads of the 1-rank run, rank r takes slice r -- are split over the N ranks
+(kmerfreq_sha1 is the same at every N).  --reads/--read-len/--K/--T select other configs
 (configs[1] = --reads 50000000).
 
 One JSON line on rank 0.  roofline.achieved uses SURVEY.md 8(d)'s algorithmic bytes per k-mer occurrence,
@@ -271,9 +272,11 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="N=1: also time the TRACK_FIRST configuration and the PCIe-inclusive "
                                                           "rate through sdt_gpu_push_reads (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank")
-    ap.add_argument("--slice-of-whole", action="store_true",
-                    help="validation: every rank generates the WHOLE single-rank workload and keeps its slice, so that N ranks "
-                         "count exactly the reads one rank would (default: rank r draws its own reads with seed 42 + 1000 r)")
+    ap.add_argument("--own-reads", action="store_true",
+                    help="N > 1: rank r draws its own reads (seed 42 + 1000 r) instead of taking its slice of the single-rank workload.  "
+                         "The default -- every rank generates the WHOLE workload (2 s on the device) and keeps its slice -- makes the N-rank job "
+                         "count exactly the reads the 1-rank job counts: the same kmerfreq_sha1 at every N, strong scaling of ONE input")
+    ap.add_argument("--slice-of-whole", action="store_true", help="(the default since round 6; accepted for old command lines)")
     args = ap.parse_args()
 
     import torch
@@ -314,7 +317,7 @@ def main():
     n_local = n_total // world + (1 if rank < n_total % world else 0)
     kmers_total = n_total * (L - K + 1)
     t0 = time.time()
-    if args.slice_of_whole and mode == "bucket":
+    if mode == "bucket" and not args.own_reads:
         wf, _, _ = synth.torch_workload(n_total, L, args.T, dev, err=args.err, sigma=args.sigma, seed=42)
         lo = (rank * n_total // world) // 16 * 16        # slices start on a word boundary (16 reads x L bases)
         hi = ((rank + 1) * n_total // world) // 16 * 16 if rank + 1 < world else n_total

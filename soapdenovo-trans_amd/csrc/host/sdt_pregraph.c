@@ -755,7 +755,8 @@ int main(int argc, char **argv)
 		sdt_pool_disable();
 	} else {
 		sdt_read_shard_begin(rank, gpus, st.keep_all);
-		st.defer = !st.keep_all;
+		/* (the same on every rank: only rank 0 has keep_all set, but whether ANY rank keeps everything is a property of the run) */
+		st.defer = hash_only || host_map || per_rank_map;
 		sdt_read_shard_skip_foreign(st.defer);
 		sdt_stream_ordinals_init(&st.ords);
 		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch_sharded, &st, NULL);

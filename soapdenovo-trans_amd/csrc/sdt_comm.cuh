@@ -40,9 +40,9 @@ struct RcclApi {
 };
 constexpr int NCCL_UINT8 = 1, NCCL_INT64 = 4, NCCL_SUM = 0;
 
-static RcclApi g_rccl;
+inline RcclApi g_rccl;               // (one instance for all translation units of the library)
 
-static int rccl_load()
+inline int rccl_load()
 {
 	if (g_rccl.lib)
 		return SDT_OK;
@@ -87,7 +87,7 @@ constexpr size_t SHM_HEADER_BYTES = 4096;
 constexpr size_t SHM_CTRL_BYTES = 64 * 1024;         // per rank: control messages (allgather / allreduce payloads)
 constexpr double SHM_TIMEOUT_S = 300.0;
 
-static double comm_now()
+inline double comm_now()
 {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(TPB) void k_map_reads(const uint32_t *__restrict__ 
 		atomicAdd(&stats->scratch, (unsigned long long)missing);
 }
 
-__global__ __launch_bounds__(TPB) void k_export_arcs(const ArcEnt *__restrict__ arcs, uint64_t slots, uint32_t *__restrict__ from,
+static __global__ __launch_bounds__(TPB) void k_export_arcs(const ArcEnt *__restrict__ arcs, uint64_t slots, uint32_t *__restrict__ from,
                                                      uint32_t *__restrict__ to, uint32_t *__restrict__ mult,
                                                      uint64_t *__restrict__ first, unsigned long long max_n, unsigned long long *cursor)
 {

@@ -9,7 +9,10 @@
 
 namespace sdt {
 
-constexpr int SK_L1BITS = 8;
+#ifndef SDT_SK_L1BITS
+#define SDT_SK_L1BITS 8
+#endif
+constexpr int SK_L1BITS = SDT_SK_L1BITS;
 #ifndef SDT_SK_L2BITS
 #define SDT_SK_L2BITS 10
 #endif

@@ -12,30 +12,53 @@
 
 namespace sdt {
 
-constexpr int SHARD_NB1 = 256;                   // level-1 buckets (SK_NB1; static_assert in sdt_gpu.hip)
+#ifndef SDT_SK_L1BITS
+#define SDT_SK_L1BITS 8
+#endif
+constexpr int SHARD_NB1 = 1 << SDT_SK_L1BITS;                   // level-1 buckets (SK_NB1; static_assert in sdt_gpu.hip)
 constexpr int SHARD_MAX_RANKS = 64;
 
 inline uint32_t shard_mat(const uint32_t *mat, int r, uint32_t b) { return mat[(size_t)r * (SHARD_NB1 + 1) + b]; }
 
-// Ownership: contiguous ranges of the 256 buckets with equal weight, weight = chunks of the bucket summed over the ranks (+1:
-// an empty sample still gives every bucket a weight); every rank owns at least one bucket.  ranges[0..n].
+// Ownership: contiguous ranges of the level-1 buckets, weight = chunks of the bucket summed over the ranks (+1: an empty sample still
+// gives every bucket a weight); every rank owns at least one bucket.  ranges[0..n].
+// The cut MINIMISES THE HEAVIEST RANGE (round 6): the job ends when the slowest rank does, and with N = 8 a rank owns ~32 buckets of
+// very unequal weight (expression skew: one minimizer of a highly expressed transcript can be several per cent of all records).
+// Rounds 2-5 cut greedily at the first bucket past r / n of the total, which lets one range overshoot by a whole bucket.  Here: the
+// smallest capacity C for which a greedy fill needs at most n ranges (bisection over C -- the classic linear partition), then that
+// fill.  Pure function of the matrix: every rank computes the same ranges.
 inline void shard_cut_ranges(const uint32_t *mat, int n, uint32_t *ranges)
 {
-	uint64_t wsum[SHARD_NB1 + 1];
-	wsum[0] = 0;
+	uint64_t w[SHARD_NB1], total = 0, wmax = 0;
 	for (uint32_t b = 0; b < (uint32_t)SHARD_NB1; b++) {
 		uint64_t wgt = 1;
 		for (int r = 0; r < n; r++)
 			wgt += shard_mat(mat, r, b + 1) - shard_mat(mat, r, b);
-		wsum[b + 1] = wsum[b] + wgt;
+		w[b] = wgt;
+		total += wgt;
+		if (wgt > wmax) wmax = wgt;
+	}
+	auto parts = [&](uint64_t cap) {
+		int k = 1;
+		uint64_t sum = 0;
+		for (uint32_t b = 0; b < (uint32_t)SHARD_NB1; b++) {
+			if (sum + w[b] > cap) { k++; sum = 0; }
+			sum += w[b];
+		}
+		return k;
+	};
+	uint64_t lo = wmax, hi = total;
+	while (lo < hi) {
+		const uint64_t mid = lo + (hi - lo) / 2;
+		if (parts(mid) <= n) hi = mid; else lo = mid + 1;
 	}
 	ranges[0] = 0;
-	for (int r = 1; r < n; r++) {
-		const uint64_t want_w = wsum[SHARD_NB1] * (uint64_t)r / (uint64_t)n;
-		uint32_t b = ranges[r - 1] + 1;
-		while (b < (uint32_t)SHARD_NB1 - (uint32_t)(n - r) && wsum[b] < want_w)
-			b++;
-		ranges[r] = b;
+	uint32_t b = 0;
+	for (int r = 0; r < n; r++) {
+		const uint32_t start = b, limit = (uint32_t)SHARD_NB1 - (uint32_t)(n - r - 1);      // (the ranks behind this one get a bucket each at least)
+		uint64_t sum = 0;
+		while (b < limit && (b == start || sum + w[b] <= lo)) sum += w[b++];
+		ranges[r + 1] = b;
 	}
 	ranges[n] = SHARD_NB1;
 }

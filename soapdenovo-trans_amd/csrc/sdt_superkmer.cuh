@@ -110,6 +110,8 @@ static_assert(SK_L2BITS >= 10 && SK_L2BITS <= 12, "the record header holds a 10.
 constexpr uint32_t SK_HDR_KIND_MASK = (1u << (8 + SK_L2BITS)) - 1u;     // bucket, n, context flags: what identical records share besides their bases
 
 // device state of the pipeline (all device pointers)
+struct SkItem { uint32_t b1, c0, c1, pad; };      // level 2: one work item = a run [c0, c1) of the chunk list of ONE level-1 bucket
+constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 struct SkPool {
 	uint64_t *recs;            // chunks * cap * REC_WORDS words
 	uint32_t *meta;            // per chunk: bucket (24 bits) | records in use << 24

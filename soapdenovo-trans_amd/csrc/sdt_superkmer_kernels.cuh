@@ -1,5 +1,5 @@
 // sdt_superkmer_kernels.cuh -- kernels of the super-k-mer pipeline (design notes: sdt_superkmer.cuh).
-// Included by sdt_gpu.hip after stage_tile / TileView / tile_find_read / chop_record are defined.
+// Included by sdt_pipeline.hip and sdt_sharded.hip behind sdt_tile.cuh (stage_tile / TileView / tile_find_read) and sdt_kmer.cuh (chop_record).
 #pragma once
 
 // k_sk_count geometry: 1024 lanes, tiles of 512 records; two workgroups per CU wherever the LDS table allows it (their fill /
@@ -75,7 +75,6 @@ constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one la
 #endif
 constexpr int SK_LIST2_FILL_SHIFT = 28;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
 constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
-constexpr int SK_TILE_READS = 32;                // reads per tile of k_sk_scatter_reads (half of k_count_reads': LDS for 6 workgroups per CU)
 
 #include "sdt_sk_scatter_seq.cuh"      // chunk reservation helpers + the one-lane-per-read level-1 scatter (own header: its
                                         // many instantiations are compiled in translation units of their own)
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(TPB) void k_sk_scatter_reads(const uint32_t *__rest
 }
 
 // every workgroup's open chunks: write the number of records they hold; retire the rest of its block of chunk ids
-__global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__restrict__ cursors, uint32_t n, const unsigned long long *__restrict__ blk,
+static __global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__restrict__ cursors, uint32_t n, const unsigned long long *__restrict__ blk,
                                                  uint32_t nblk, SkPool pool, uint32_t cap)
 {
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(256) void k_sk_seal(const unsigned long long *__res
 		sk_retire_block(blk[i], pool);
 }
 
-__global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cursors, uint32_t n, uint32_t cap, unsigned long long *blk, uint32_t nblk)
+static __global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cursors, uint32_t n, uint32_t cap, unsigned long long *blk, uint32_t nblk)
 {
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
 		cursors[i] = ((unsigned long long)SK_NOCHUNK << 32) | cap;           // "one past the end": the first record opens a chunk
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(256) void k_sk_init_cursors(unsigned long long *cur
 
 // ---- chunk lists per bucket (counting sort of chunk ids by bucket) ---------------------------------------------
 // exclusive scans over nb buckets by ONE workgroup of 1024: off[0..nb] of cnt, and (kmers != NULL) kpre[0..nb] of kmers
-__global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
+static __global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
                                                   int nb, const unsigned long long *__restrict__ kmers, unsigned long long *__restrict__ kpre)
 {
 	__shared__ unsigned long long s_a[1024], s_b[1024];
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_sk_scan(const uint32_t *__restrict__ c
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
+static __global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
                                                         uint32_t *__restrict__ list)
 {
 	const uint32_t used = *pool.next, n = used < pool.chunks ? used : pool.chunks;
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(256) void k_sk_chunk_place(SkPool pool, const uint3
 
 // the same for few buckets (level 1: 256): a workgroup counts its stretch of chunk ids per bucket in LDS and reserves a
 // run per bucket with ONE global atomic (25 M atomics on 256 addresses were 5.6 ms per call)
-__global__ __launch_bounds__(256) void k_sk_chunk_place_few(SkPool pool, const uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
+static __global__ __launch_bounds__(256) void k_sk_chunk_place_few(SkPool pool, const uint32_t *__restrict__ off, uint32_t *__restrict__ fillcur,
                                                             uint32_t *__restrict__ list, int nb)
 {
 	__shared__ uint32_t s_cnt[1024], s_base[1024];
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(256) void k_sk_chunk_place_few(SkPool pool, const u
 }
 
 // ---- level 2: one item = a run of chunks of ONE level-1 bucket, split into its 1024 sub-buckets ---------------
-struct SkItem { uint32_t b1, c0, c1, pad; };
 
 #ifdef SDT_SK_L2_LOG
 // debug build (tools/l2_lost_chunk.py): every slot the level-2 scatter hands out goes into a side buffer
@@ -550,14 +548,20 @@ __global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, co
 //       the same phase, by up to S lanes: 96 / 80 / 112 contiguous bytes that meet in L2 --, the others wait in the stage
 // and at the end of the item the waiting records are written as a last, partial group.  Chunks fill from slot 0 up, so the
 // count stage's lists (chunk id + fill) stay what they were.
+#ifndef SDT_SK_L2S_S1
+#define SDT_SK_L2S_S1 4           // 1-word keys: records per group of the staged level-2 scatter (4 x 24 B = 96 contiguous bytes per store phase)
+#endif
+#ifndef SDT_SK_L2S_WGS
+#define SDT_SK_L2S_WGS 1          // workgroups per CU the staged level-2 scatter is compiled for (2: 64 registers per lane)
+#endif
 template <int NW> struct SkL2Stage {
-	static constexpr int S = NW == 1 ? 4 : 2;                        // records per group
+	static constexpr int S = NW == 1 ? SDT_SK_L2S_S1 : 2;            // records per group
 	static constexpr int GPC = SK_CAP2 / S;                          // groups per chunk
 	static constexpr size_t SMEM = (size_t)SK_NB2 * S * SkFmt<NW>::REC_WORDS * 8;
 };
 
 template <int NW>
-__global__ __launch_bounds__(SK_L2S_TPB) void k_sk_scatter_records_staged(SkPool src, const uint32_t *__restrict__ list1,
+__global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_records_staged(SkPool src, const uint32_t *__restrict__ list1,
                                                                          const SkItem *__restrict__ items, SkPool dst,
                                                                          uint32_t *__restrict__ g_cnt, unsigned long long *__restrict__ g_kmers, Stats *stats)
 {
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(256) void k_sk_gather(SkPool pool, const uint32_t *
 	}
 }
 
-__global__ __launch_bounds__(256) void k_sk_iota(uint32_t *p, uint32_t n)
+static __global__ __launch_bounds__(256) void k_sk_iota(uint32_t *p, uint32_t n)
 {
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
 		p[i] = i;

@@ -6,7 +6,7 @@ first 3 000 reads of the very same device buffers bit for bit.
   C2: 50 M x 150 bp, K = 31 (1-word keys)      C4: 50 M x 250 bp, K = 63 (2-word keys, the 127mer build's layout)
   C3: 200 M x 150 bp, K = 31 -- the workload of the headline metric (as far as one GPU goes: the 8-GPU exchange is hardware)
   C5: 400 M x 150 bp, K = 31, expression skew sigma = 2.5, -d 1        K95: 30 M x 250 bp, K = 95 (4-word keys, the strip scatter)
-and the multi-rank PRODUCT path (sdt_gpu_count_reads_sharded behind bench.py --gpus N) at C2 size with 2 and 4 ranks sharing
+and the multi-rank PRODUCT path (sdt_gpu_count_reads_sharded behind bench.py --gpus N) at C2 size with 2, 4 and 8 ranks sharing
 the box's one GPU over the shared-memory transport, sub-rounds forced: every reported number and the checksum of all 257
 kmerFreq bins must be the single rank's."""
 import numpy as np
@@ -62,7 +62,7 @@ def test_baseline_config_at_full_size(pkg, synth, name, n, L, K, est, sigma):
     assert seen[pkg.SDT_FLAG_DIRECT] == seen[pkg.SDT_FLAG_PARTITION], f"{name}: the two kernel families disagree"
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_product_path_multi_rank_at_c2_size(pkg, ranks):
     """bench.py --gpus N (C-level bucket sharding: chop -> level-1 chunks to the owners of their buckets -> split + count) with N
     processes on cuda:0 (SDT_BENCH_SHARE_DEVICE=1: shared-memory transport instead of RCCL, which refuses two ranks per
@@ -72,7 +72,7 @@ def test_product_path_multi_rank_at_c2_size(pkg, ranks):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--reads", "50000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--extras", "0", "--slice-of-whole"]
+    common = ["--reads", "50000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--extras", "0"]      # (N ranks take slices of the 1-rank workload: bench.py's default)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
@@ -87,7 +87,8 @@ def test_product_path_multi_rank_at_c2_size(pkg, ranks):
     for k in ("kmers", "distinct_nodes", "linear_nodes", "kmerfreq_sha1"):
         assert a["config"][k] == b["config"][k], k
     assert sum(b["per_rank_kmers_counted"]) == a["config"]["kmers"] and len(b["per_rank_kmers_counted"]) == ranks
-    assert b["skew_max_over_mean"] < 1.6                 # ranges are cut by weight; a giant minimizer cannot be split
+    print(f"skew_max_over_mean at {ranks} ranks: {b['skew_max_over_mean']}  per rank: {b['per_rank_kmers_counted']}")
+    assert b["skew_max_over_mean"] < (1.6 if ranks <= 4 else 1.35)     # ranges are cut by weight; a giant minimizer cannot be split
 
 
 @pytest.mark.parametrize("K,L,track", [(31, 150, False), (31, 150, True), (63, 250, False)])

@@ -154,3 +154,52 @@ def test_plan_rejects_bad_arguments():
         pkg.shard_plan(mat, 2, 0, np.array([0, 128, 256], dtype=np.uint32), 10, 5)        # sub-round past the last
     r = pkg.shard_cut_ranges(mat, 2)
     assert r.tolist() == [0, 128, 256]                   # empty sample: equal ranges
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8, 16])
+def test_cut_ranges_minimise_the_heaviest_range(nranks):
+    """sdt_shard_cut_ranges against a dynamic programme over all contiguous partitions of the 256 buckets: the heaviest range is the
+    smallest any partition allows (the job ends with its slowest rank), every rank owns a bucket, the ranges tile 0..256 -- for flat,
+    log-normal (expression skew) and one-giant-bucket weights.  Round 5's greedy cut (first bucket past r / n of the total) is also
+    restated here: it must never beat the library's cut.  Reference: prlHashReads.c:79-88 (`hash_kmer % thrd_num`: the reference
+    balances by hashing single k-mers; here the unit of ownership is a minimizer bucket)."""
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    rng = np.random.default_rng(nranks)
+    for trial in range(12):
+        kind = trial % 4
+        if kind == 0:
+            w = np.ones(256, dtype=np.int64) * 7
+        elif kind == 1:
+            w = np.maximum(1, rng.lognormal(3.0, 2.0, 256)).astype(np.int64)
+        elif kind == 2:
+            w = rng.integers(1, 50, 256).astype(np.int64)
+            w[rng.integers(0, 256)] = int(w.sum() // 3)           # one giant minimizer: a third of everything
+        else:
+            w = rng.integers(0, 3, 256).astype(np.int64)         # many empty buckets
+        # the matrix of ONE source rank holding all the chunks (the others hold none): offsets = prefix sums
+        mat = np.zeros((nranks, 257), dtype=np.uint32)
+        mat[0, 1:] = np.cumsum(w)
+        r = pkg.shard_cut_ranges(mat, nranks).astype(np.int64)
+        assert r[0] == 0 and r[nranks] == 256 and (np.diff(r) >= 1).all()
+        ww = w + 1                                               # (the library gives every bucket a weight of 1 on top)
+        pre = np.concatenate([[0], np.cumsum(ww)])
+        got = max(pre[r[i + 1]] - pre[r[i]] for i in range(nranks))
+        # optimum by dynamic programming: best[k][j] = smallest possible heaviest range when the first j buckets go to k ranks
+        best = np.full((nranks + 1, 257), np.iinfo(np.int64).max, dtype=np.int64)
+        best[0, 0] = 0
+        for k in range(1, nranks + 1):
+            for j in range(k, 257):
+                i = np.arange(k - 1, j)
+                best[k, j] = np.minimum.reduce(np.maximum(best[k - 1, i], pre[j] - pre[i]))
+        assert got == best[nranks, 256], (trial, got, best[nranks, 256])
+        # round 5's greedy cut
+        g = [0]
+        for q in range(1, nranks):
+            want = pre[256] * q // nranks
+            b = g[-1] + 1
+            while b < 256 - (nranks - q) and pre[b] < want:
+                b += 1
+            g.append(b)
+        g.append(256)
+        assert got <= max(pre[g[i + 1]] - pre[g[i]] for i in range(nranks))
