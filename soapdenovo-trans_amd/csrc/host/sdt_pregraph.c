@@ -711,7 +711,13 @@ int main(int argc, char **argv)
 		const int cap = getenv("SDT_PARSE_THREADS") ? atoi(getenv("SDT_PARSE_THREADS")) : (usable > 4 ? usable - 3 : usable);
 		if (parse_threads > cap) parse_threads = cap > 0 ? cap : 1;
 	}
-	const int my_threads = gpus == 1 ? parse_threads : (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2);
+	/* --gpus N: every rank parses its own chunks and nothing else (seqio.h: sdt_read_shard_skip_foreign), so the parser threads are
+	 * shared out evenly -- two at least; when one rank keeps every read (SDT_RANK0_MAP, the way of rounds 2-4) rank 0 parses all of the
+	 * text and gets most of the threads, the others only count records */
+	const int rank0_keeps_all = gpus > 1 && !hash_only && !host_map && !(!host_walks && threads <= 256 && !getenv("SDT_HOST_LAYOUT") && !getenv("SDT_RANK0_MAP"));
+	const int my_threads = gpus == 1 ? parse_threads
+	                     : rank0_keeps_all ? (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2)
+	                     : (parse_threads / gpus > 2 ? parse_threads / gpus : 2);
 	sdt_ctx *gpu = NULL;
 	/* SDT_PIPELINE=1 (tests): the locality pipeline also for jobs below its 2^27 k-mer threshold */
 	const uint32_t iflags = (hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS))) |
@@ -825,6 +831,18 @@ int main(int argc, char **argv)
 		uint64_t n = 0;
 		const int nwk = sdt_gpu_key_words(gpu), nwv = max_k <= 31 ? 1 : (max_k <= 63 ? 2 : 4);
 		if (sdt_gpu_export_nodes(gpu, NULL, NULL, NULL, NULL, NULL, 0, &n) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
+		/* Past 2^32 - 16 nodes (the reference's sets are 64-bit: inc/newhash.h:79-88 `ubyte8 size, count, max`) the device's graph phases
+		 * are out -- their walk records, component labels, layout ranks and edge records carry 32-bit node indices -- and the documented
+		 * fallback takes over: the nodes go to the host in one export, the host replays the layout, builds its 64-bit index
+		 * (graph_t.index64) and runs cutting and kmer2edges on its threads; pass 1 and the second read pass stay on the device (they
+		 * address the table by key).  SDT_NODE_LIMIT moves the threshold so that the tests can take this path on a golden case. */
+		const uint64_t node_limit = getenv("SDT_NODE_LIMIT") ? strtoull(getenv("SDT_NODE_LIMIT"), NULL, 10) : 0xFFFFFFF0ULL;
+		if ((gpus > 1 ? nodes : n) >= node_limit) {
+			if (!g_quiet) fprintf(stderr, "[sdt-pregraph] %llu nodes: past the 32-bit node indices of the device's graph phases; layout, cutting and edges run on the host\n",
+			                      (unsigned long long)(gpus > 1 ? nodes : n));
+			host_walks = 1;
+			setenv("SDT_WIDE_INDEX", "1", 1);
+		}
 		uint64_t *keys, *first = NULL;
 		uint32_t *ll, *rf, *cnt;
 		graph_t *G = NULL;
@@ -911,7 +929,7 @@ int main(int argc, char **argv)
 				return 0;
 			}
 			n = nodes;                                            /* all shards */
-			const int device_layout = !host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT");
+			const int device_layout = !host_map && !host_walks && threads <= 256 && n < node_limit && !getenv("SDT_HOST_LAYOUT");
 			keys_in_device = device_layout;
 			if (device_layout) {
 				/* the shards go straight into rank 0's device table (it then lays the whole graph out like a single-GPU run: below);
@@ -957,7 +975,7 @@ int main(int argc, char **argv)
 			}
 			}
 		}
-		if ((gpus == 1 || keys_in_device) && !host_map && !host_walks && threads <= 256 && n < 0xFFFFFFF0ULL && !getenv("SDT_HOST_LAYOUT")) {
+		if ((gpus == 1 || keys_in_device) && !host_map && !host_walks && threads <= 256 && n < node_limit && !getenv("SDT_HOST_LAYOUT")) {
 			/* the visiting order with the device: it sorts the nodes by (set, first occurrence) and sends the keys, the host
 			 * replays the probing of every set (graph_replay_order), the device numbers the nodes and sends them in that order */
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);

@@ -34,10 +34,16 @@
 #ifndef SDT_SK_SLOTS_NW2
 #define SDT_SK_SLOTS_NW2 1280
 #endif
+#ifndef SDT_SK_TILE
+#define SDT_SK_TILE 512           // records per tile of the count stage (512: the first half of the workgroup's lanes bring one each; 1024: every lane)
+#endif
+#ifndef SDT_SK_SLOTS_NW1
+#define SDT_SK_SLOTS_NW1 2048
+#endif
 template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TPB = SDT_SK_CNT_TPB;
 	static constexpr int WAVES_PER_SIMD = (NW == 1 || (NW == 2 && SDT_SK_NW2_TWO)) ? 2 * (TPB / 256) : TPB / 256;      // two workgroups per CU where the table allows
-	static constexpr int TILE = 512;                                       // records per tile
+	static constexpr int TILE = SDT_SK_TILE;                               // records per tile
 	// LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal).  1-word keys: 2048 slots = 75 KB with the tile, two
 	// workgroups per CU; with ordinals half the table keeps it at two
 #ifdef SDT_SK_TEST_SLOTS
@@ -45,7 +51,7 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	// spill path -- memory-side atomics on a table the same workgroup also writes with plain stores -- runs all the time
 	static constexpr int SLOTS = SDT_SK_TEST_SLOTS;
 #else
-	static constexpr int SLOTS = NW == 1 ? (TRACK ? SDT_SK_SLOTS_TRACK : 2048) : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);
+	static constexpr int SLOTS = NW == 1 ? (TRACK ? SDT_SK_SLOTS_TRACK : SDT_SK_SLOTS_NW1) : (NW == 2 ? SDT_SK_SLOTS_NW2 : 2048);
 #endif
 	// (any size: 1-word keys with ordinals take 1536 slots, 36 B each -- the most that leaves two workgroups per CU)
 	static constexpr int FLUSH_AT = SLOTS * SDT_SK_FLUSH_NUM / 8;                            // flush + clear between rounds past this load ...
@@ -1098,8 +1104,8 @@ __global__ __launch_bounds__((SkCntGeo<NW, TRACK>::TPB), (SkCntGeo<NW, TRACK>::W
 					x = __builtin_rotateleft32(x, 5) ^ (uint32_t)nx[1 + i];
 					x = __builtin_rotateleft32(x, 11) ^ (uint32_t)(nx[1 + i] >> 32);
 				}
-				uint32_t slot = (x * 0x85EBCA77u) >> (32 - 10);
-				static_assert(REP == 1024, "the dedupe slot is 10 bits of the hash");
+				static_assert((REP & (REP - 1)) == 0, "the dedupe slot is the top bits of the hash");
+				uint32_t slot = (x * 0x85EBCA77u) >> (32 - __builtin_ctz(REP));
 				for (;;) {
 					const uint32_t cur = atomicCAS(&s_rep[slot], REP_EMPTY, (uint32_t)ot);
 					if (cur == REP_EMPTY)

@@ -110,14 +110,17 @@ def test_config_parser(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks", "pipeline", "replay-limit", "few-workgroups"])
+@pytest.mark.parametrize("second_pass", ["gpu", "host", "host-walks", "pipeline", "replay-limit", "few-workgroups", "node-limit"])
 @pytest.mark.parametrize("name", gu.case_names())
 def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     """sdt-pregraph end to end: all five files of the reference's pregraph, byte for byte, with the second read
     pass (prlRead2edge) on the GPU over the reads kept in HBM (default) or on the host (--host-map), and with the
     tip-cutting dry runs on the device (default) or on the host (--host-walks, and always with --host-map).
-    `pipeline`: pass 1 through the locality pipeline, whatever the size of the job -- every device graph phase (layout, walks,
-    junction records, commits, kmer2edges, the second read pass) then looks its k-mers up in the BUCKET-MAJOR node table;
+    `pipeline`: pass 1 through the locality pipeline, whatever the size of the job;
+    `node-limit`: the job is treated as one of more than 2^32 - 16 nodes (SDT_NODE_LIMIT=1000 moves the threshold under the golden case's
+    node count): the CLI must say so and take the documented fallback -- one export, layout replay, 64-bit node index, cutting and
+    kmer2edges on the host; pass 1 and the second read pass on the device -- and still write the five files (inc/newhash.h:79-88: the
+    reference's sets count in 64 bits);
     `replay-limit`: the device's layout replay gives up at once (SDT_ELIMIT) and the CLI takes the host's replay instead;
     `few-workgroups`: every scan kernel runs in ONE workgroup (SDT_SCAN_BLOCKS), so that the per-wave chunks of csrc/sdt_append.cuh fill up,
     are closed early and replaced on inputs of this size"""
@@ -136,12 +139,16 @@ def test_cli_kmerfreq_bit_identical(pkg, tmp_path, name, second_pass):
     env = dict(os.environ)
     if second_pass == "pipeline":
         env["SDT_PIPELINE"] = "1"
+    if second_pass == "node-limit":
+        env["SDT_NODE_LIMIT"] = "1000"
     if second_pass == "replay-limit":
         env["SDT_RP_MAX_ROUNDS"] = "0"
     if second_pass == "few-workgroups":
         env["SDT_SCAN_BLOCKS"] = "1"
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
+    if second_pass == "node-limit":
+        assert "past the 32-bit node indices" in r.stderr and info["nodes_allocated"] >= 1000
     if second_pass == "replay-limit" and name == "pe150_k31_p8":      # (its sets grow: the limit is hit)
         assert "the host replays the layout" in r.stderr
     assert open(tmp_path / "out.kmerFreq").read() == gu.golden_text(info, "kmerFreq")

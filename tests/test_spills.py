@@ -32,6 +32,7 @@ import oracle_binding as ob
 from test_gpu_parity import node_dict_gpu, node_dict_oracle
 
 K, L, track, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+pkg.load_library()
 assert pkg.LIB_PATH.endswith("libsdt_gpu_smalllds.so"), pkg.LIB_PATH
 # a few transcripts at deep coverage (the same keys come back generation after generation: merges into nodes that plain stores wrote a
 # moment ago) + a hot repeat (one bucket, a handful of keys, thousands of occurrences) + noise (new keys all the time: the table overflows)
