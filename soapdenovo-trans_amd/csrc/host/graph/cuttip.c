@@ -10,6 +10,7 @@
  *   Mark1in1outNode (:1193-1229)  after each pass: not-deleted, not-yet-linear nodes with 1 in / 1 out -> linear
  * All of them mutate neighbours while sweeping, so the sweep order (graph.h) is part of the result.
  */
+#include "../../sdt_knobs.h"
 #include "graph.h"
 #include "par.h"
 #include "big.h"
@@ -31,7 +32,7 @@
  * and the expensive part (the walks of the ~95 % of visits that change nothing) is parallel. */
 #include <time.h>
 static double cut_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-#define SUBPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = cut_now_ms(); fprintf(stderr, "[cuttip]   %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
+#define SUBPHASE(name) do { if (sdt_env("SDT_TIMING")) { double t_ = cut_now_ms(); fprintf(stderr, "[cuttip]   %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 #define NO_NODE (~(uint64_t)0)
 typedef struct { int would_write; uint64_t end; } dry_t;
 
@@ -484,7 +485,7 @@ static int commit_minor_out_by_components(graph_t *g, const uint64_t *ex, uint64
 		}
 		free(C.tl[t]);
 	}
-	if (getenv("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nexec, (unsigned long long)C.ncomp, (unsigned long long)biggest);
+	if (sdt_env("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nexec, (unsigned long long)C.ncomp, (unsigned long long)biggest);
 	free(C.tl); free(C.tln); free(C.order); free(C.cstart);
 	*off += C.off;
 	return 0;
@@ -602,7 +603,7 @@ static void commit_minor_out_labelled(graph_t *g, const uint64_t *rec, uint64_t 
 		}
 		free(C.tl[t]);
 	}
-	if (getenv("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nj, (unsigned long long)ncomp, (unsigned long long)biggest);
+	if (sdt_env("SDT_TIMING")) fprintf(stderr, "[cuttip]     %llu visits in %llu components, largest %llu\n", (unsigned long long)nj, (unsigned long long)ncomp, (unsigned long long)biggest);
 	free(cstart); free(corder);
 	*off += C.off;
 }
@@ -635,7 +636,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	uint64_t off = 0;
 	printf("Start to remove kmer of out frequency kmers < %f\n", threshold);
 	double t_sub = cut_now_ms();
-	if (g->dev_minor_out_commit_begin && !getenv("SDT_HOST_COMMIT")) {
+	if (g->dev_minor_out_commit_begin && !sdt_test_env("SDT_HOST_COMMIT")) {
 		/* dry run, components, commit and re-marking on the device mirror; the long components here, at the same time */
 		uint64_t lin = 0, *sk = NULL, nsk = 0, nskr = 0;
 		if (g->dev_minor_out_commit_begin(g, threshold, &sk, &nsk, &nskr) != 0) {
@@ -745,7 +746,7 @@ uint64_t graph_remove_minor_out(graph_t *g, int dd)
 	for (uint64_t i = 0; i < g->n; i++) if (c.writes[i]) ex[nexec++] = i;
 	/* every visit and every node it may cut has its neighbour table (no pool overflow)? then by components */
 	const int complete = c.cursor <= c.cap;
-	const int sequential = !complete || getenv("SDT_SEQUENTIAL_COMMIT") || commit_minor_out_by_components(g, ex, nexec, threshold, &off);
+	const int sequential = !complete || sdt_test_env("SDT_SEQUENTIAL_COMMIT") || commit_minor_out_by_components(g, ex, nexec, threshold, &off);
 	for (uint64_t cur = 0; sequential && cur < nexec; cur++) {
 		/* stage 1 (far): slot number; stage 2: the 8 neighbour entries; stage 3: the neighbour nodes and their
 		 * slot numbers; stage 4 (near): the neighbours' own neighbour entries */
@@ -1273,7 +1274,7 @@ static uint64_t commit_tips_by_components(graph_t *g, const uint64_t *rec, uint6
 		g->dn = total;
 		for (int t = 0; t < 64; t++) free(T.tl[t]);
 	}
-	if (getenv("SDT_TIMING")) {
+	if (sdt_env("SDT_TIMING")) {
 		uint64_t biggest = 0;
 		for (uint64_t c = 0; c < ncomp; c++) if (cstart[c + 1] - cstart[c] > biggest) biggest = cstart[c + 1] - cstart[c];
 		fprintf(stderr, "[cuttip]     %llu walks in %llu components, largest %llu\n", (unsigned long long)nrec, (unsigned long long)ncomp, (unsigned long long)biggest);
@@ -1592,7 +1593,7 @@ static int emu_minor_out_commit_begin(graph_t *g, double threshold, uint64_t **s
 {
 	uint64_t *rec = NULL, nj = 0, nr = 0;
 	if (emu_minor_out(g, threshold, &rec, &nj, &nr) != 0) return 1;
-	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
+	const uint64_t max_comp = sdt_test_env("SDT_COMMIT_MAX_COMPONENT") ? strtoull(sdt_test_env("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
 	uint8_t *big = (uint8_t *)calloc(g->n + 1, 1);                      /* by label (a node index) */
 	uint64_t nbig = 0;
 	for (uint64_t r0 = 0; r0 < nj;) {

@@ -11,6 +11,7 @@
  * link back; interior nodes get inEdge = 1, l_links = edge id (+bal_edge when walked against their stored
  * strand) and twin; length-1 edges register their canonical (K+1)-mer in the patch table instead.
  */
+#include "../../sdt_knobs.h"
 #include "graph.h"
 #include <stdlib.h>
 #include <string.h>
@@ -448,7 +449,7 @@ static void gz_chunks(void *vc, uint64_t lo, uint64_t hi, int tid)
 
 #include <time.h>
 static double ed_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-#define EPHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = ed_now(); fprintf(stderr, "[edges]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
+#define EPHASE(name) do { if (sdt_env("SDT_TIMING")) { double t_ = ed_now(); fprintf(stderr, "[edges]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
 /* the host's own records: port walks (dry run or the device's), ordered ids, parallel stamping.  Returns 0, or 2 when a chain
  * is not symmetric (nothing has been modified then) */
@@ -546,7 +547,7 @@ static void *edge_writer(void *v)
 		uint64_t *cut = (uint64_t *)malloc((nemit + 2) * sizeof(uint64_t));
 		uint64_t ncut = 0;
 		size_t acc = 0;
-		const size_t chunk_bytes = getenv("SDT_GZ_CHUNK") ? (size_t)atol(getenv("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
+		const size_t chunk_bytes = sdt_test_env("SDT_GZ_CHUNK") ? (size_t)atol(sdt_test_env("SDT_GZ_CHUNK")) : (4u << 20);   /* the env var is for the tests */
 		cut[ncut++] = 0;
 		for (uint64_t e = 0; e < nemit; e++) {
 			acc += (size_t)(rec[e * RW] & 0xFFFFFFFFULL) + 60;
@@ -566,7 +567,7 @@ static void *edge_writer(void *v)
 	}
 	fclose(fz);
 	free(rec); free(bases);
-	if (getenv("SDT_TIMING")) fprintf(stderr, "[edges]    text + gzip write (beside the next phase) %9.1f ms\n", ed_now() - t0);
+	if (sdt_env("SDT_TIMING")) fprintf(stderr, "[edges]    text + gzip write (beside the next phase) %9.1f ms\n", ed_now() - t0);
 	free(W);
 	return NULL;
 }
@@ -628,7 +629,7 @@ uint64_t graph_build_edges(graph_t *g, const char *prefix)
 		ew_job *W = (ew_job *)malloc(sizeof *W);
 		W->g = g; W->rec = rec; W->bases = bases; W->kw = kw; W->nemit = nemit;
 		snprintf(W->name, sizeof W->name, "%s.edge.gz", prefix);
-		if (getenv("SDT_EDGES_INLINE") || pthread_create(&g->edge_writer, NULL, edge_writer, W) != 0) edge_writer(W);
+		if (sdt_tuning_env("SDT_EDGES_INLINE") || pthread_create(&g->edge_writer, NULL, edge_writer, W) != 0) edge_writer(W);
 		else g->edge_writer_on = 1;
 	}
 	EPHASE("text + gzip write (started)");

@@ -1,4 +1,5 @@
 /* graph.c -- see graph.h: layout replay, flat node array, lookup index, hash_kmer. */
+#include "../../sdt_knobs.h"
 #include "graph.h"
 #include <pthread.h>
 #include <math.h>
@@ -42,6 +43,7 @@ uint64_t ref_hash_kmer(const kw_t *k, int nw)
  * growth doubles below 2^28-1 else adds 0xFFFFFF, until n * lf >= count + 1 (:318-330); the rehash is IN PLACE:
  * old entries are visited by slot, each is re-probed in the new geometry and an occupant that has not moved
  * yet is carried onward (:359-406). */
+int graph_force_wide_index = 0;
 int graph_init_kmerset_size = 0;      /* -a (initKmerSetSize, pregraph.c:160-162); only the 2- and 4-word variants look at it */
 
 static int prime_kh(uint64_t num)
@@ -253,7 +255,7 @@ static void *rp_thread(void *v)
 		const int s = __sync_fetch_and_add(&J->next_set, 1);
 		if (s >= J->p) break;
 		const uint64_t b = J->set_start[s], m = J->set_start[s + 1] - b;
-		const double t0 = getenv("SDT_TIMING") && s == 0 ? gb_now() : 0;
+		const double t0 = sdt_env("SDT_TIMING") && s == 0 ? gb_now() : 0;
 		if (J->nwk == 1) replay_set1(J->keys + b, m, replay_init_size(J->nw_variant), b, J->order + b);
 		else replay_setw(J->keys + b * J->nwk, J->nwk, m, replay_init_size(J->nw_variant), b, J->order + b);
 		if (t0 > 0) {
@@ -462,7 +464,7 @@ static void job_scatter_sets(build_job *J, int tid)
 	}
 }
 
-#define GB_PHASE(name) do { if (getenv("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
+#define GB_PHASE(name) do { if (sdt_env("SDT_TIMING")) { double t_ = gb_now(); fprintf(stderr, "[graph]    %-26s %9.1f ms\n", name, t_ - t_sub); t_sub = t_; } } while (0)
 
 /* free() of a multi-gigabyte block is one munmap that holds the address-space lock for its whole length, and every page fault
  * of every other thread waits behind it (a 32 GB node array let go beside the second read pass stalled the arcs' download for
@@ -577,7 +579,7 @@ graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, cons
 	/* index */
 	/* node ids past 32 bits: 64-bit index entries, built here (the device-built index is the 32-bit one; the hook still
 	 * brings the device mirror of the graph up, then declines) */
-	const int wide = n >= 0xFFFFFFFEULL || getenv("SDT_WIDE_INDEX") != NULL;
+	const int wide = n >= 0xFFFFFFFEULL || graph_force_wide_index || sdt_test_env("SDT_WIDE_INDEX") != NULL;
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
 	if (wide) {
@@ -648,7 +650,7 @@ graph_t *graph_from_ordered(int K, int nw_variant, int nw_keys, int p, uint64_t 
 	g->set_start = (uint64_t *)calloc((size_t)p + 1, sizeof(uint64_t));
 	memcpy(g->set_start, set_start, ((size_t)p + 1) * sizeof(uint64_t));
 	fo_ctx F = {g, nw_keys, keys, l_links, r_flags, count};
-	const int wide = n >= 0xFFFFFFFEULL || getenv("SDT_WIDE_INDEX") != NULL;
+	const int wide = n >= 0xFFFFFFFEULL || graph_force_wide_index || sdt_test_env("SDT_WIDE_INDEX") != NULL;
 	uint64_t cap = 1024;
 	while (cap < 2 * n + 2) cap <<= 1;
 	if (wide) {

@@ -92,6 +92,7 @@ typedef struct graph_s {
  * single<<27).  Returns NULL after printing a message on failure. */
 /* -a n (initKmerSetSize): non-zero changes the initial set size of the 63mer / 127mer variants (prlHashReads.c:404-413) */
 extern int graph_init_kmerset_size;
+extern int graph_force_wide_index;       /* the host's node index with 64-bit entries whatever the node count (the CLI past its node limit) */
 graph_t *graph_build(int K, int nw_variant, int nw_keys, int p, uint64_t n, const uint64_t *keys,
                      const uint32_t *l_links, const uint32_t *r_flags, const uint32_t *count, const uint64_t *first);
 /* the same in two steps when the nodes come grouped by set and ordered by first occurrence (sdt_gpu_layout_sorted_keys): the

@@ -4,6 +4,7 @@
  * usage: sdt-graphcheck <dump> <out prefix> [<lib.cfg>]   (with a config: also the second read pass -> .preArc) */
 #include <stdio.h>
 #include <stdlib.h>
+#include "../../sdt_knobs.h"
 #include "graph.h"
 #include <time.h>
 #include "../readstream.h"
@@ -44,10 +45,10 @@ int main(int argc, char **argv)
 	RD(keys, 8, n * nwk); RD(ll, 4, n); RD(rf, 4, n); RD(cnt, 4, n); RD(first, 8, n);
 	fclose(fi);
 	t_last = now_ms();
-	if (getenv("SDT_GRAPHCHECK_A")) graph_init_kmerset_size = atoi(getenv("SDT_GRAPHCHECK_A"));      /* -a of the CLI */
+	if (sdt_test_env("SDT_GRAPHCHECK_A")) graph_init_kmerset_size = atoi(sdt_test_env("SDT_GRAPHCHECK_A"));      /* -a of the CLI */
 	graph_t *G = graph_build(K, nwv, nwk, p, n, keys, ll, rf, cnt, first);
 	phase("build");
-	if (getenv("SDT_GRAPHCHECK_EMULATE")) graph_emulate_device(G);       /* the device-path commits on host-made records */
+	if (sdt_test_env("SDT_GRAPHCHECK_EMULATE")) graph_emulate_device(G);       /* the device-path commits on host-made records */
 	graph_remove_minor_out(G, dd);
 	phase("minor-out");
 	if (!d) graph_remove_single_tips(G);

@@ -19,6 +19,7 @@
 #include <string.h>
 #include <time.h>
 #include <zlib.h>
+#include "../sdt_knobs.h"
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
@@ -28,7 +29,7 @@ static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 static double g_t_last;
 static void phase(const char *name)
 {
-	if (!getenv("SDT_TIMING")) return;
+	if (!sdt_env("SDT_TIMING")) return;
 	const double t = now_ms();
 	fprintf(stderr, "[sdt-map] %-32s %9.1f ms\n", name, t - g_t_last);
 	g_t_last = t;
@@ -681,7 +682,7 @@ int main(int argc, char **argv)
 		}
 		for (int b = 0; b < nt * 2; b++) { free(F.ro[b].p); free(F.c2[b].p); free(F.ri[b].p); }
 		free(F.ro); free(F.c2); free(F.ri); free(F.mapped); free(F.overflowed);
-		if (getenv("SDT_TIMING")) fprintf(stderr, "[sdt-map]   format %.1f ms, pwrite %.1f ms\n", t_fmt, t_wr);
+		if (sdt_env("SDT_TIMING")) fprintf(stderr, "[sdt-map]   format %.1f ms, pwrite %.1f ms\n", t_fmt, t_wr);
 	}
 	phase("text files (parallel format)");
 	long long read_counter = 0;

@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <sys/wait.h>
 
+#include "../sdt_knobs.h"
 #include "../../../include/sdt_gpu.h"
 #include "libcfg.h"
 #include "seqio.h"
@@ -119,7 +120,7 @@ static int push_batch(void *user, const sdt_batch *b, uint64_t ord_base, uint64_
 	if (st->reads / 1000000ULL != before)
 		printf("--- %lluth reads\n", st->reads / 1000000ULL * 1000000ULL);    /* prlHashReads.c:587-588 */
 	static int parse_only = -1;                              /* SDT_PARSE_ONLY=1 (measurement): parse and pack, push nothing */
-	if (parse_only < 0) parse_only = getenv("SDT_PARSE_ONLY") != NULL;
+	if (parse_only < 0) parse_only = sdt_tuning_env("SDT_PARSE_ONLY") != NULL;
 	if (parse_only) return 0;
 	if (st->total_text && !st->hinted && b->text_bytes && b->nreads) {
 		/* the size of the job from its first chunk: k-mers per byte of text x bytes of all files (the pools of the locality
@@ -398,7 +399,7 @@ static int dev_mirror_sync(graph_t *g)
 	const double t0 = now_ms();
 	const size_t dn = g->dn;
 	const int rc = dev_mirror_sync_(g);
-	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   mirror sync: %zu nodes written by the host sent over in %.1f ms\n", dn, now_ms() - t0);
+	if (sdt_env("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   mirror sync: %zu nodes written by the host sent over in %.1f ms\n", dn, now_ms() - t0);
 	return rc;
 }
 static int dev_mirror_sync_(graph_t *g)
@@ -451,7 +452,7 @@ static int dev_index_hook(graph_t *g, void *user)
 		fprintf(stderr, "sdt_gpu_build_host_index: %s\n", sdt_gpu_last_error());
 		exit(1);
 	}
-	if (getenv("SDT_TIMING")) fprintf(stderr, "[graph]      node order to the device %.1f ms, index built + copied back %.1f ms\n", t1 - t0, now_ms() - t1);
+	if (sdt_env("SDT_TIMING")) fprintf(stderr, "[graph]      node order to the device %.1f ms, index built + copied back %.1f ms\n", t1 - t0, now_ms() - t1);
 	return 0;
 }
 
@@ -503,7 +504,7 @@ static int dev_minor_out_hook(graph_t *g, double threshold, uint64_t **records, 
 	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * MO_RW * sizeof(uint64_t));
 	if (!rec) { fprintf(stderr, "out of memory for %llu junction records\n", (unsigned long long)*nr); return 1; }
 	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * MO_RW) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
-	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   junction dry run + components %.1f ms, %llu + %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nj, (unsigned long long)(*nr - *nj), now_ms() - t1);
+	if (sdt_env("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   junction dry run + components %.1f ms, %llu + %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nj, (unsigned long long)(*nr - *nj), now_ms() - t1);
 	*records = rec;
 	return 0;
 }
@@ -520,7 +521,7 @@ static int dev_minor_out_commit_begin_hook(graph_t *g, double threshold, uint64_
 	/* one lane walks a component at about a microsecond per dependent access (~100 us per visit); a host thread takes ~150 ns */
 	/* (the device's lanes and the host's threads work side by side: at 200 M reads 1536 / 2048 / 2560 / 3072 / 4096 visits per component gave
 	 * 983 / 895 / 829 / 813 / 1020 ms for the whole pass -- past 3072 the host waits for the longest lane, profiles/r5/README.md) */
-	const uint64_t max_comp = getenv("SDT_COMMIT_MAX_COMPONENT") ? strtoull(getenv("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
+	const uint64_t max_comp = sdt_test_env("SDT_COMMIT_MAX_COMPONENT") ? strtoull(sdt_test_env("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
 	if (sdt_gpu_minor_out_commit_begin(D->gpu, threshold, max_comp, &largest, &nsk, &nskr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_commit_begin: %s\n", sdt_gpu_last_error()); return 1; }
 	const double t2 = now_ms();
 	uint64_t *sk = (uint64_t *)malloc((nskr + 1) * MO_RW * sizeof(uint64_t));
@@ -529,7 +530,7 @@ static int dev_minor_out_commit_begin_hook(graph_t *g, double threshold, uint64_
 	if (nsk) *skipped = sk; else { free(sk); *skipped = NULL; }
 	*n_skipped = nsk;
 	*n_skipped_records = nskr;
-	if (getenv("SDT_TIMING") && !g_quiet)
+	if (sdt_env("SDT_TIMING") && !g_quiet)
 		fprintf(stderr, "[device]   junction dry run + components %.1f ms (%llu visits, largest component %llu), components + long ones gathered %.1f ms, %llu records of long components fetched in %.1f ms\n",
 		        t1 - t0, (unsigned long long)nj, (unsigned long long)largest, t2 - t1, (unsigned long long)nskr, now_ms() - t2);
 	return 0;
@@ -549,7 +550,7 @@ static int dev_minor_out_commit_finish_hook(graph_t *g, uint64_t *off, uint64_t 
 	const double t2 = now_ms();
 	graph_apply_written(g, node, l, r, nw);
 	free(node); free(l); free(r);
-	if (getenv("SDT_TIMING") && !g_quiet)
+	if (sdt_env("SDT_TIMING") && !g_quiet)
 		fprintf(stderr, "[device]   waited %.1f ms for the device's visits + marking + list, %llu written nodes fetched in %.1f ms, applied in %.1f ms\n",
 		        t1 - t0, (unsigned long long)nw, t2 - t1, now_ms() - t2);
 	return 0;
@@ -565,7 +566,7 @@ static int dev_walks_hook(graph_t *g, int thin, int cut_len, uint64_t **records,
 	uint64_t *rec = (uint64_t *)malloc((*nr + 1) * 3 * sizeof(uint64_t));
 	if (!rec) { fprintf(stderr, "out of memory for %llu walk records\n", (unsigned long long)*nr); return 1; }
 	if (sdt_gpu_fetch_records(D->gpu, rec, *nr * 3) != SDT_OK) { fprintf(stderr, "sdt_gpu_fetch_records: %s\n", sdt_gpu_last_error()); free(rec); return 1; }
-	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   walks + components %.1f ms, %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nr, now_ms() - t1);
+	if (sdt_env("SDT_TIMING") && !g_quiet) fprintf(stderr, "[device]   walks + components %.1f ms, %llu records fetched in %.1f ms\n", t1 - t0, (unsigned long long)*nr, now_ms() - t1);
 	*records = rec;
 	return 0;
 }
@@ -631,8 +632,8 @@ int main(int argc, char **argv)
 
 	time_t t_start = time(NULL);
 	g_t_last = g_t_main = now_ms();
-	if (getenv("SDT_LAYOUT_CHECK")) setenv("SDT_KEEP_FIRST", "1", 0);      /* the check sorts by the first-occurrence ordinals once more */
-	if (getenv("SDT_TIMING")) {
+	if (sdt_test_env("SDT_LAYOUT_CHECK")) setenv("SDT_KEEP_FIRST", "1", 0);      /* the check sorts by the first-occurrence ordinals once more */
+	if (sdt_env("SDT_TIMING")) {
 		/* how long the loader took to get here (process start from /proc/self/stat, in clock ticks since boot): what a caller's
 		 * wall clock holds beyond "total inside main" is this plus the kernel's teardown of the address space after _exit */
 		FILE *sf = fopen("/proc/self/stat", "r");
@@ -708,20 +709,20 @@ int main(int argc, char **argv)
 	int parse_threads = threads;
 	{
 		const int usable = par_threads();
-		const int cap = getenv("SDT_PARSE_THREADS") ? atoi(getenv("SDT_PARSE_THREADS")) : (usable > 4 ? usable - 3 : usable);
+		const int cap = sdt_env("SDT_PARSE_THREADS") ? atoi(sdt_env("SDT_PARSE_THREADS")) : (usable > 4 ? usable - 3 : usable);
 		if (parse_threads > cap) parse_threads = cap > 0 ? cap : 1;
 	}
 	/* --gpus N: every rank parses its own chunks and nothing else (seqio.h: sdt_read_shard_skip_foreign), so the parser threads are
 	 * shared out evenly -- two at least; when one rank keeps every read (SDT_RANK0_MAP, the way of rounds 2-4) rank 0 parses all of the
 	 * text and gets most of the threads, the others only count records */
-	const int rank0_keeps_all = gpus > 1 && !hash_only && !host_map && !(!host_walks && threads <= 256 && !getenv("SDT_HOST_LAYOUT") && !getenv("SDT_RANK0_MAP"));
+	const int rank0_keeps_all = gpus > 1 && !hash_only && !host_map && !(!host_walks && threads <= 256 && !sdt_test_env("SDT_HOST_LAYOUT") && !sdt_test_env("SDT_RANK0_MAP"));
 	const int my_threads = gpus == 1 ? parse_threads
 	                     : rank0_keeps_all ? (rank == 0 ? (threads - (gpus - 1) > threads / 2 ? threads - (gpus - 1) : (threads + 1) / 2) : 2)
 	                     : (parse_threads / gpus > 2 ? parse_threads / gpus : 2);
 	sdt_ctx *gpu = NULL;
 	/* SDT_PIPELINE=1 (tests): the locality pipeline also for jobs below its 2^27 k-mer threshold */
 	const uint32_t iflags = (hash_only ? 0 : (SDT_FLAG_TRACK_FIRST | ((host_map || gpus > 1) ? 0 : SDT_FLAG_KEEP_READS))) |
-	                        (getenv("SDT_PIPELINE") ? SDT_FLAG_PARTITION : 0);
+	                        (sdt_test_env("SDT_PIPELINE") ? SDT_FLAG_PARTITION : 0);
 	if (sdt_gpu_init(&gpu, share_device ? device : device + rank, K, est / (unsigned long long)gpus, iflags) != SDT_OK) {
 		fprintf(stderr, "sdt_gpu_init: %s\n", sdt_gpu_last_error());
 		return 1;
@@ -746,16 +747,16 @@ int main(int argc, char **argv)
 	memset(&st, 0, sizeof st);
 	/* --gpus N: every rank keeps the reads it parsed and maps them itself once rank 0 has the graph (the default path: layout, cutting
 	 * and edges on rank 0's device); with --host-map / --host-walks the second pass is the host's, which reads the files again */
-	const int per_rank_map = gpus > 1 && !hash_only && !host_map && !host_walks && threads <= 256 && !getenv("SDT_HOST_LAYOUT") && !getenv("SDT_RANK0_MAP");
+	const int per_rank_map = gpus > 1 && !hash_only && !host_map && !host_walks && threads <= 256 && !sdt_test_env("SDT_HOST_LAYOUT") && !sdt_test_env("SDT_RANK0_MAP");
 	st.gpu = gpu; st.rank = rank; st.nranks = gpus; st.keep_all = gpus > 1 && rank == 0 && !hash_only && !host_map && !per_rank_map;
 	st.keep_mine = per_rank_map;
-	const size_t chunk = getenv("SDT_CHUNK_BYTES") ? (size_t)strtoull(getenv("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
+	const size_t chunk = sdt_test_env("SDT_CHUNK_BYTES") ? (size_t)strtoull(sdt_test_env("SDT_CHUNK_BYTES"), NULL, 10) : (size_t)(32u << 20);   /* (tests: many small chunks) */
 	int rc;
 	uint64_t text_parsed = 0, text_seen = 0;
 	if (gpus == 1) {
 		st.K = K;
 		st.total_text = input_bytes(&cfg);
-		if (!getenv("SDT_NO_PINNED_POOL")) sdt_pool_enable(sdt_gpu_host_alloc, sdt_gpu_host_free, my_threads + PUSH_DEPTH + 8);
+		if (!sdt_tuning_env("SDT_NO_PINNED_POOL")) sdt_pool_enable(sdt_gpu_host_alloc, sdt_gpu_host_free, my_threads + PUSH_DEPTH + 8);
 		rc = sdt_stream_reads(&cfg, max_read_len, my_threads, chunk, 1, push_batch, &st, NULL);
 		if (rc == 0 && inflight_retire(gpu, 0) != 0) rc = -1;
 		sdt_pool_disable();
@@ -782,14 +783,14 @@ int main(int argc, char **argv)
 		if (sdt_gpu_allreduce_i64(gpu, v, 2) != SDT_OK) { fprintf(stderr, "%s\n", sdt_gpu_last_error()); return 1; }
 		kmers = (uint64_t)v[0]; nodes = (uint64_t)v[1];
 	}
-	if (getenv("SDT_TIMING") && !g_quiet) {
+	if (sdt_env("SDT_TIMING") && !g_quiet) {
 		double ms[SDT_NSTAGES];
 		uint64_t cn[SDT_NCOUNTERS];
 		if (sdt_gpu_stage_times(gpu, ms, cn) == SDT_OK)
 			fprintf(stderr, "[ingest] consumer waited %.0f ms for the parsers, spent %.0f ms pushing; device stages: direct %.0f, scatter %.0f, split %.0f, count %.0f ms; %llu batches counted, %llu early flushes, %d parser threads\n",
 			        sdt_reader_wait_ms, sdt_reader_fn_ms, ms[0], ms[1], ms[2], ms[3], (unsigned long long)cn[6], (unsigned long long)cn[3], my_threads);
 	}
-	if (getenv("SDT_TIMING") && !g_quiet && gpus > 1)
+	if (sdt_env("SDT_TIMING") && !g_quiet && gpus > 1)
 		fprintf(stderr, "[ingest] rank 0 of %d parsed %.1f of %.1f MB of text (%.3f of the input; the other chunks are their owners')\n", gpus,
 		        text_parsed / 1e6, text_seen / 1e6, text_seen ? (double)text_parsed / (double)text_seen : 0.0);
 	phase("parse + hash (GPU)");
@@ -836,12 +837,12 @@ int main(int argc, char **argv)
 		 * fallback takes over: the nodes go to the host in one export, the host replays the layout, builds its 64-bit index
 		 * (graph_t.index64) and runs cutting and kmer2edges on its threads; pass 1 and the second read pass stay on the device (they
 		 * address the table by key).  SDT_NODE_LIMIT moves the threshold so that the tests can take this path on a golden case. */
-		const uint64_t node_limit = getenv("SDT_NODE_LIMIT") ? strtoull(getenv("SDT_NODE_LIMIT"), NULL, 10) : 0xFFFFFFF0ULL;
+		const uint64_t node_limit = sdt_test_env("SDT_NODE_LIMIT") ? strtoull(sdt_test_env("SDT_NODE_LIMIT"), NULL, 10) : 0xFFFFFFF0ULL;
 		if ((gpus > 1 ? nodes : n) >= node_limit) {
 			if (!g_quiet) fprintf(stderr, "[sdt-pregraph] %llu nodes: past the 32-bit node indices of the device's graph phases; layout, cutting and edges run on the host\n",
 			                      (unsigned long long)(gpus > 1 ? nodes : n));
 			host_walks = 1;
-			setenv("SDT_WIDE_INDEX", "1", 1);
+			graph_force_wide_index = 1;
 		}
 		uint64_t *keys, *first = NULL;
 		uint32_t *ll, *rf, *cnt;
@@ -929,7 +930,7 @@ int main(int argc, char **argv)
 				return 0;
 			}
 			n = nodes;                                            /* all shards */
-			const int device_layout = !host_map && !host_walks && threads <= 256 && n < node_limit && !getenv("SDT_HOST_LAYOUT");
+			const int device_layout = !host_map && !host_walks && threads <= 256 && n < node_limit && !sdt_test_env("SDT_HOST_LAYOUT");
 			keys_in_device = device_layout;
 			if (device_layout) {
 				/* the shards go straight into rank 0's device table (it then lays the whole graph out like a single-GPU run: below);
@@ -975,7 +976,7 @@ int main(int argc, char **argv)
 			}
 			}
 		}
-		if ((gpus == 1 || keys_in_device) && !host_map && !host_walks && threads <= 256 && n < node_limit && !getenv("SDT_HOST_LAYOUT")) {
+		if ((gpus == 1 || keys_in_device) && !host_map && !host_walks && threads <= 256 && n < node_limit && !sdt_test_env("SDT_HOST_LAYOUT")) {
 			/* the visiting order with the device: it sorts the nodes by (set, first occurrence) and sends the keys, the host
 			 * replays the probing of every set (graph_replay_order), the device numbers the nodes and sends them in that order */
 			keys = (uint64_t *)malloc((n + 1) * (size_t)nwk * 8);
@@ -985,14 +986,14 @@ int main(int argc, char **argv)
 			 * -- beside it: both orders must then name the same key at every visiting position */
 			int on_device = 0;
 			uint64_t *check_keys = NULL;
-			if (!getenv("SDT_HOST_REPLAY")) {
+			if (!sdt_test_env("SDT_HOST_REPLAY")) {
 				const int rcl = sdt_gpu_layout_on_device(gpu, threads, nwv, graph_init_kmerset_size != 0, set_start, &n);
 				if (rcl == SDT_OK) on_device = 1;
 				else if (rcl == SDT_ELIMIT) { if (!g_quiet) fprintf(stderr, "[sdt-pregraph] %s: the host replays the layout\n", sdt_gpu_last_error()); }
 				else if (rcl != SDT_EINVAL) { fprintf(stderr, "sdt_gpu_layout_on_device: %s\n", sdt_gpu_last_error()); return 1; }
 				if (on_device) phase("layout: sort + replay + numbering (GPU)");
 			}
-			if (!on_device || getenv("SDT_LAYOUT_CHECK")) {
+			if (!on_device || sdt_test_env("SDT_LAYOUT_CHECK")) {
 				uint64_t *hk = on_device ? (uint64_t *)malloc((n + 1) * (size_t)nwk * 8) : keys;
 				uint64_t *ss = on_device ? (uint64_t *)calloc((size_t)threads + 1, sizeof(uint64_t)) : set_start;
 				if (sdt_gpu_layout_sorted_keys(gpu, threads, nwv, hk, n, ss, &n) != SDT_OK) { fprintf(stderr, "sdt_gpu_layout_sorted_keys: %s\n", sdt_gpu_last_error()); return 1; }
@@ -1018,7 +1019,7 @@ int main(int argc, char **argv)
 			Dp->gpu = gpu; Dp->indexed = 1; Dp->by_index = 1;
 			graph_index_hook = dev_index_hook;
 			graph_index_hook_user = Dp;
-			graph_index_hook_early = getenv("SDT_INDEX_INLINE") == NULL;      /* (the device numbered the nodes itself) */
+			graph_index_hook_early = sdt_tuning_env("SDT_INDEX_INLINE") == NULL;      /* (the device numbered the nodes itself) */
 			G = graph_from_ordered(K, nwv, nwk, threads, n, keys, ll, rf, cnt, set_start);
 			graph_free_later(keys, ll, rf, cnt);
 			free(set_start);
@@ -1047,7 +1048,7 @@ int main(int argc, char **argv)
 			G->dev_minor_out = dev_minor_out_hook;
 			if (Dp->by_index) { G->dev_minor_out_commit_begin = dev_minor_out_commit_begin_hook; G->dev_minor_out_commit_finish = dev_minor_out_commit_finish_hook; }
 			G->dev_edge_ports = dev_edge_ports_hook;
-			if (Dp->by_index && !getenv("SDT_HOST_EDGES")) G->dev_build_edges = dev_build_edges_hook;
+			if (Dp->by_index && !sdt_test_env("SDT_HOST_EDGES")) G->dev_build_edges = dev_build_edges_hook;
 			G->dev_user = Dp;
 		}
 		uint64_t nv_early = 0;
@@ -1180,7 +1181,7 @@ int main(int argc, char **argv)
 			const double t_r3 = now_ms();
 			printf("%llu reads processed\n", (unsigned long long)nreads2);
 			arcs_write_arrays(prefix, af, at, am, ao, narcs);
-			if (getenv("SDT_TIMING") && !g_quiet)
+			if (sdt_env("SDT_TIMING") && !g_quiet)
 				fprintf(stderr, "[read2edge] gather %.1f ms, load paths + patch table %.1f ms, map reads %.1f ms, export %llu arcs %.1f ms, sort + write %.1f ms\n",
 				        t_r0 - g_t_last, t_r1 - t_r0, t_r2 - t_r1, (unsigned long long)narcs, t_r3 - t_r2, now_ms() - t_r3);
 			free(af); free(at); free(am); free(ao);
@@ -1197,9 +1198,9 @@ int main(int argc, char **argv)
 	}
 	if (gpu) sdt_gpu_destroy(gpu);
 	phase("release the device");
-	if (getenv("SDT_TIMING") && !g_quiet) fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", "total inside main", now_ms() - g_t_main);
+	if (sdt_env("SDT_TIMING") && !g_quiet) fprintf(stderr, "[sdt-pregraph] %-28s %9.1f ms\n", "total inside main", now_ms() - g_t_main);
 	sdt_cfg_free(&cfg);
-	if (gpus == 1 && !getenv("SDT_SLOW_EXIT")) {
+	if (gpus == 1 && !sdt_env("SDT_SLOW_EXIT")) {
 		/* every file is closed and the device is released: skip the runtime's and the allocator's own teardown (atexit handlers,
 		 * unloading code objects, returning gigabytes page by page) -- the kernel takes the address space back in one go */
 		fflush(stdout);

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include "../sdt_knobs.h"
 #include "libcfg.h"
 #include "seqio.h"
 #include "readstream.h"
@@ -101,7 +102,7 @@ int main(int argc, char **argv)
 	size_t chunk = argc > 3 ? (size_t)atol(argv[3]) : (32u << 20);
 	sdt_cfg cfg;
 	if (sdt_cfg_load(argv[1], &cfg) != 0) return 1;
-	if (getenv("SDT_READDUMP_POOL")) sdt_pool_enable(malloc, free, atoi(getenv("SDT_READDUMP_POOL")));
+	if (sdt_test_env("SDT_READDUMP_POOL")) sdt_pool_enable(malloc, free, atoi(sdt_test_env("SDT_READDUMP_POOL")));
 	int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;
 	printf("#libs %d max_rd_len %d\n", cfg.nlibs, max_read_len);
 	for (int i = 0; i < cfg.nlibs; i++) {

@@ -1,5 +1,6 @@
 /* seqio.c -- see seqio.h */
 #define _GNU_SOURCE
+#include "../sdt_knobs.h"
 #include "seqio.h"
 #include <fcntl.h>
 #include <pthread.h>
@@ -218,7 +219,7 @@ static int have_avx2_bmi2(void)
 	static int cached = -1;                              /* parser threads race to fill it: relaxed atomics, same value */
 	int c = __atomic_load_n(&cached, __ATOMIC_RELAXED);
 	if (c < 0) {
-		c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SDT_NO_SIMD");
+		c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !sdt_test_env("SDT_NO_SIMD");
 		__atomic_store_n(&cached, c, __ATOMIC_RELAXED);
 	}
 	return c;

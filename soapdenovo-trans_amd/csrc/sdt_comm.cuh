@@ -178,8 +178,8 @@ struct Comm {
 			HIPCHK(hipStreamSynchronize(s));
 			return SDT_OK;
 		}
-		static const double comm_limit = getenv("SDT_COMM_TIMEOUT_S") && atof(getenv("SDT_COMM_TIMEOUT_S")) > 0 ? atof(getenv("SDT_COMM_TIMEOUT_S")) : 1800.0;
-		static const double drain_limit = getenv("SDT_DRAIN_TIMEOUT_S") && atof(getenv("SDT_DRAIN_TIMEOUT_S")) > 0 ? atof(getenv("SDT_DRAIN_TIMEOUT_S")) : 7200.0;
+		static const double comm_limit = sdt_env("SDT_COMM_TIMEOUT_S") && atof(sdt_env("SDT_COMM_TIMEOUT_S")) > 0 ? atof(sdt_env("SDT_COMM_TIMEOUT_S")) : 1800.0;
+		static const double drain_limit = sdt_env("SDT_DRAIN_TIMEOUT_S") && atof(sdt_env("SDT_DRAIN_TIMEOUT_S")) > 0 ? atof(sdt_env("SDT_DRAIN_TIMEOUT_S")) : 7200.0;
 		const double limit = s == xstream ? comm_limit : drain_limit;
 		const double t0 = comm_now();
 		for (;;) {
@@ -314,7 +314,7 @@ struct Comm {
 		rank = r; nranks = n;
 		if (with_device)
 			HIPCHK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
-		const char *mb = getenv("SDT_SHM_OUTBOX_MB");
+		const char *mb = sdt_test_env("SDT_SHM_OUTBOX_MB");
 		outbox_bytes = (size_t)(mb ? atoll(mb) : 256) << 20;
 		shm_bytes = SHM_HEADER_BYTES + (size_t)n * SHM_CTRL_BYTES + (size_t)n * outbox_bytes;
 		snprintf(shm_name, sizeof shm_name, "/sdt_%s", name);

@@ -34,7 +34,7 @@ int sdti::fail(int code, const char *fmt, ...)
 // like and what the scans of the table cost), a multiple of 4096, 2^16 at least
 uint64_t flat_slots_for(uint64_t nodes)
 {
-	static const int pct = getenv("SDT_TABLE_LOAD") && atoi(getenv("SDT_TABLE_LOAD")) >= 10 && atoi(getenv("SDT_TABLE_LOAD")) <= 69 ? atoi(getenv("SDT_TABLE_LOAD")) : 45;
+	static const int pct = sdt_tuning_env("SDT_TABLE_LOAD") && atoi(sdt_tuning_env("SDT_TABLE_LOAD")) >= 10 && atoi(sdt_tuning_env("SDT_TABLE_LOAD")) <= 69 ? atoi(sdt_tuning_env("SDT_TABLE_LOAD")) : 45;
 	uint64_t slots = (uint64_t)((double)nodes * 100.0 / pct) + 4095;
 	slots &= ~4095ULL;
 	return slots < (1ULL << 16) ? (1ULL << 16) : slots;
@@ -249,7 +249,7 @@ int sdt_gpu_init(sdt_ctx **out, int device, int K, uint64_t est_distinct, uint32
 		return fail(SDT_EINVAL, "device %d out of range (have %d)", device, ndev);
 	{   // SDT_SYNC=block|yield|spin: how host threads wait for the device (a host that parses on every core it may use wants its
 		// waiting thread off the CPU; the default is the runtime's own choice).  Must be set before the device is first used.
-		const char *sm = getenv("SDT_SYNC");
+		const char *sm = sdt_tuning_env("SDT_SYNC");
 		if (sm && *sm) {
 			const unsigned fl = !strcmp(sm, "block") ? hipDeviceScheduleBlockingSync : !strcmp(sm, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
 			(void)hipSetDeviceFlags(fl);
@@ -1018,7 +1018,7 @@ int sdti::release_pass1(sdt_ctx *c)
 {
 	const int rc = ::sync_stats(c);
 	if (rc != SDT_OK) return rc;
-	if (!getenv("SDT_KEEP_POOLS")) {                         // (measurement switch)
+	if (!sdt_tuning_env("SDT_KEEP_POOLS")) {                         // (measurement switch)
 		sk_free(c);
 	}
 	return SDT_OK;

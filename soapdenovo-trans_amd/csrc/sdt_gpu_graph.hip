@@ -251,7 +251,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	HIPCHK(hipSetDevice(v0.device));
 	struct timespec ts0_; clock_gettime(CLOCK_MONOTONIC, &ts0_);
 	const double t_call = ts0_.tv_sec * 1e3 + ts0_.tv_nsec * 1e-6;
-	const bool timing = getenv("SDT_TIMING") != nullptr;
+	const bool timing = sdt_env("SDT_TIMING") != nullptr;
 	auto tick = [&](const char *what) {              // (SDT_TIMING: where the call's time goes, on stderr)
 		if (!timing) return;
 		struct timespec t_;
@@ -396,7 +396,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 			                   d_list[0], list_chunks, d_round);
 			GCHK(hipGetLastError());
 			// (SDT_RP_MAX_ROUNDS: test hook -- a cap that real data passes, so that the caller's other path is exercised)
-			static const int max_rounds = getenv("SDT_RP_MAX_ROUNDS") ? atoi(getenv("SDT_RP_MAX_ROUNDS")) : 60;
+			static const int max_rounds = sdt_test_env("SDT_RP_MAX_ROUNDS") ? atoi(sdt_test_env("SDT_RP_MAX_ROUNDS")) : 60;
 			int lc = 0;
 			for (int round = 0;; round++) {
 				RpRound h_round;
@@ -491,7 +491,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	if (gx->d_slot_of) { (void)hipFree(gx->d_slot_of); gx->d_slot_of = nullptr; gx->n_nodes = 0; }
 	// the replay is through (every limit it can run into lies behind): the first-occurrence ordinals have done their work, and the
 	// node index is exactly as large -- 8 bytes per table slot that it finds in the arena instead of asking the driver
-	if (!getenv("SDT_KEEP_FIRST")) { rc = sdti::drop_first(c); if (rc != SDT_OK) return rc; }
+	if (!sdt_test_env("SDT_KEEP_FIRST")) { rc = sdti::drop_first(c); if (rc != SDT_OK) return rc; }
 	uint64_t *d_idx, *d_slot_of;
 	GCHK(S.alloc(&d_idx, v.slots * 8)); GCHK(S.alloc(&d_slot_of, m * 8));
 	GCHK(hipMemsetAsync(d_idx, 0xFF, v.slots * 8, v.stream));
@@ -505,7 +505,7 @@ extern "C" int sdt_gpu_layout_on_device(sdt_ctx *c, int p, int nw_variant, int s
 	gx->d_slot_of = (uint64_t *)S.release(d_slot_of);
 	gx->n_nodes = n;
 	if (timing) fprintf(stderr, "[device]     layout: whole call %.1f ms\n", now_ms() - t_call);
-	if (getenv("SDT_TIMING")) fprintf(stderr, "[device]   layout replay: %zu generations, %d rounds of timed insertion in all, %llu table slots\n", max_gens, total_rounds, (unsigned long long)tab_total);
+	if (sdt_env("SDT_TIMING")) fprintf(stderr, "[device]   layout replay: %zu generations, %d rounds of timed insertion in all, %llu table slots\n", max_gens, total_rounds, (unsigned long long)tab_total);
 	return SDT_OK;
 }
 
@@ -865,7 +865,7 @@ int sdt_gpu_minor_out_commit_begin(sdt_ctx *c, double threshold, uint64_t max_co
 	if (nn >= 0xFFFFFFF0ULL || nr >= 0xFFFFFFF0ULL) return fail(SDT_EINVAL, "commit on the device: 32-bit record and node indices");
 	HIPCHK(hipSetDevice(v.device));
 	*largest = *n_skipped = *n_skipped_records = 0;
-	const bool timing = getenv("SDT_TIMING") != nullptr;
+	const bool timing = sdt_env("SDT_TIMING") != nullptr;
 	struct timespec ts0_; clock_gettime(CLOCK_MONOTONIC, &ts0_);
 	const double t_call = ts0_.tv_sec * 1e3 + ts0_.tv_nsec * 1e-6;
 	auto tick = [&](const char *what) {              // (SDT_TIMING: where the call's time goes, on stderr; waits for the stream)

@@ -5,6 +5,7 @@
 //                      the components of their commits, port walks of kmer2edges
 // The context itself (struct sdt_ctx) stays private to sdt_gpu.hip; the graph unit sees it through GraphView.
 #pragma once
+#include "sdt_knobs.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -69,7 +70,7 @@ inline int scan_grid(int cu_count, uint64_t items)
 	uint64_t blocks = (items + TPB - 1) / TPB;
 	// (SDT_SCAN_BLOCKS: test hook -- a handful of workgroups do all the work, so that per-wave state (the chunks of sdt_append.cuh)
 	// goes through every transition on small inputs)
-	static const int forced = getenv("SDT_SCAN_BLOCKS") ? atoi(getenv("SDT_SCAN_BLOCKS")) : 0;
+	static const int forced = sdt_test_env("SDT_SCAN_BLOCKS") ? atoi(sdt_test_env("SDT_SCAN_BLOCKS")) : 0;
 	const uint64_t cap = forced > 0 ? (uint64_t)forced : (uint64_t)cu_count * 8;
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;

@@ -23,7 +23,7 @@
 
 namespace {
 
-bool mem_timing() { static const bool t = getenv("SDT_TIMING") != nullptr; return t; }
+bool mem_timing() { static const bool t = sdt_env("SDT_TIMING") != nullptr; return t; }
 double mem_now() { struct timespec a; clock_gettime(CLOCK_MONOTONIC, &a); return a.tv_sec * 1e3 + a.tv_nsec * 1e-6; }
 void mem_report(const char *what, double gib, double ms, const char *file, int line)
 {
@@ -37,7 +37,7 @@ constexpr size_t ARENA_GRAIN = 1u << 16;
 
 struct Arena : sdt::ArenaBook {
 	std::mutex mu;
-	bool off() { static const bool o = getenv("SDT_NO_ARENA") != nullptr; return o; }
+	bool off() { static const bool o = sdt_env("SDT_NO_ARENA") != nullptr; return o; }
 	// slabs nobody uses go back to the driver (all devices); returns the bytes released
 	size_t trim_to_driver()
 	{

@@ -99,8 +99,8 @@ int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	if (run > (double)per_read) run = (double)per_read;
 	uint64_t div = (uint64_t)run;
 	if (div < 2) div = 2;
-	div = (uint64_t)clamp_int(env_int("SDT_SK_POOL_DIV", (int)div), 1, 1 << 20);
-	const int mem_pct = env_int("SDT_SK_POOL_MEM_PCT", 70);
+	div = (uint64_t)clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_POOL_DIV"), (int)div), 1, 1 << 20);
+	const int mem_pct = sdt_knob_int(sdt_tuning_env("SDT_SK_POOL_MEM_PCT"), 70);
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(sdti::mem_info(&free_b, &total_b));
 	uint64_t cap = want_kmers < (1ULL << 24) ? (1ULL << 24) : want_kmers;
@@ -110,7 +110,7 @@ int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 		const uint64_t recs = cap / div;
 		// (SDT_SK_POOL_CHUNKS1: test hook -- a level-1 pool of that many chunks, so that small inputs overflow it: tests/test_gpu_parity.py,
 		// tests/test_sharded.py)
-		const uint64_t chunks1 = env_int("SDT_SK_POOL_CHUNKS1", 0) > 0 ? (uint64_t)env_int("SDT_SK_POOL_CHUNKS1", 0) : recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
+		const uint64_t chunks1 = sdt_knob_int(sdt_test_env("SDT_SK_POOL_CHUNKS1"), 0) > 0 ? (uint64_t)sdt_knob_int(sdt_test_env("SDT_SK_POOL_CHUNKS1"), 0) : recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
 		const uint64_t items = chunks1 / SK_ITEM_CHUNKS + SK_NB1 + 1;
 		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw2 * 8 + (chunks1 + chunks2) * 8;
@@ -159,7 +159,7 @@ int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 	HIPCHK(hipMalloc((void **)&k.next_item, SK_MAX_COUNT_LAUNCHES * sizeof(uint32_t)));
 	k.cap_kmers = cap;
 	k.ready = true;
-	if (getenv("SDT_TIMING"))
+	if (sdt_env("SDT_TIMING"))
 		fprintf(stderr, "[libsdt_gpu] super-k-mer pools for %llu k-mers per batch: %.1f GiB in %.0f ms\n", (unsigned long long)cap,
 		        ((double)k.p1.chunks * SK_CAP1 * rw + (double)k.p2.chunks * SK_CAP2 * rw2) * 8 / (1 << 30), (comm_now() - t_alloc0) * 1e3);
 	return sk_reset_pool1(c);
@@ -213,29 +213,13 @@ int sk_split(sdt_ctx *c, const SkPool &src, const uint32_t *list, uint32_t nitem
 	SK_CHK(hipMemsetAsync(k.cnt2, 0, SK_NBF * 4, c->stream));
 	if (nitems) {
 		SK_CHK(hipMemcpyAsync(k.items, k.h_items, (size_t)nitems * sizeof(SkItem), hipMemcpyHostToDevice, c->stream));
-		// ONE workgroup (512 lanes) per CU -- the unused dynamic LDS is there to keep a second one away.  Every workgroup has
-		// 1024 chunks open and a record is 24..56 bytes of a 128-byte line: with 8 x 256 lanes per CU the lines being
-		// filled (2 M of them, 270 MB) did not live in L2 until they were full and reached HBM as partial writes
-		// (22.3 ms per 6 G k-mers); 256 K open lines do (17.8 ms).  SDT_SK_L2_PAD_KB: A/B switch.  (1024 lanes per
-		// workgroup were 1 ms faster still and lost a chunk of records in half of the runs of the hot-bucket test --
-		// 512 and 256 never did in the same stress; sync_stats' conservation check is the net under this.)
-		static const bool l2_old = getenv("SDT_SK_L2_OLD") != NULL;      // A/B switch: the round-2 kernel (a store per record into one of 1024 open chunks)
-		if (!l2_old) {
-			// staged (round 5): records wait in LDS for a group of 4 (2), groups are stored whole; one workgroup per CU by its LDS alone
-			const size_t sm = c->nw == 1 ? SkL2Stage<1>::SMEM : (c->nw == 2 ? SkL2Stage<2>::SMEM : SkL2Stage<4>::SMEM);
-			const void *fn = c->nw == 1 ? (const void *)k_sk_scatter_records_staged<1> : (c->nw == 2 ? (const void *)k_sk_scatter_records_staged<2> : (const void *)k_sk_scatter_records_staged<4>);
-			SK_CHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-			if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records_staged<1>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-			else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records_staged<2>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-			else hipLaunchKernelGGL(k_sk_scatter_records_staged<4>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		} else {
-		static const size_t l2pad = (size_t)(getenv("SDT_SK_L2_PAD_KB") ? atoi(getenv("SDT_SK_L2_PAD_KB")) : SK_L2_LDS_PAD_KB) * 1024;
-		const void *l2fn = c->nw == 1 ? (const void *)k_sk_scatter_records<1> : (c->nw == 2 ? (const void *)k_sk_scatter_records<2> : (const void *)k_sk_scatter_records<4>);
-		SK_CHK(hipFuncSetAttribute(l2fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2pad));
-		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records<1>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records<2>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		else hipLaunchKernelGGL(k_sk_scatter_records<4>, dim3(nitems), dim3(SK_L2_TPB), l2pad, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
-		}
+		// staged (round 5): records wait in LDS for a group of 4 (2), groups are stored whole; one workgroup of 1024 lanes per CU by its LDS alone
+		const size_t sm = c->nw == 1 ? SkL2Stage<1>::SMEM : (c->nw == 2 ? SkL2Stage<2>::SMEM : SkL2Stage<4>::SMEM);
+		const void *fn = c->nw == 1 ? (const void *)k_sk_scatter_records_staged<1> : (c->nw == 2 ? (const void *)k_sk_scatter_records_staged<2> : (const void *)k_sk_scatter_records_staged<4>);
+		SK_CHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+		if (c->nw == 1) hipLaunchKernelGGL(k_sk_scatter_records_staged<1>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else if (c->nw == 2) hipLaunchKernelGGL(k_sk_scatter_records_staged<2>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
+		else hipLaunchKernelGGL(k_sk_scatter_records_staged<4>, dim3(nitems), dim3(SK_L2S_TPB), sm, c->stream, src, list, k.items, k.p2, k.cnt2, k.kmers2, c->d_stats);
 		SK_CHK(hipGetLastError());
 	}
 	if (after_l2)
@@ -423,7 +407,7 @@ int sk_scatter_launch(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_off
 	} while (0)
 	// one lane per read where the window length has an instantiation and the run list can hold a read
 	const int w = c->K - m + 1;
-	static const bool no_seq = getenv("SDT_SK_STRIPS") != NULL;          // A/B switch (tools/)
+	static const bool no_seq = sdt_tuning_env("SDT_SK_STRIPS") != NULL;          // A/B switch (tools/)
 	// (instantiated: every odd window of 1-word keys with K >= 17 and of 2-word keys, i.e. every odd K from 17 to 63)
 	const bool seq1 = c->nw == 1 && (w & 1) && w >= 9 && w <= 21 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS;
 	const bool seq2 = c->nw == 2 && (w & 1) && w >= 23 && w <= 53 && per_read <= (uint64_t)SK_SEQ_MAX_KMERS;
@@ -480,7 +464,7 @@ int sk_scatter(sdt_ctx *c, const uint32_t *d_words, const uint64_t *d_offs, uint
 		// batches merge a little less (quarters of a 14 G k-mer job measured 3 % slower than one batch), but the 103 GiB of pools of
 		// that job cost 1.4 - 4.7 s to allocate whenever the box's memory had been used before (sdt_mem.hip) -- a hundred times the gain.
 		if (c->expect_kmers > want) {
-			const uint64_t lim = 1ULL << clamp_int(env_int("SDT_SK_HINT_BATCH_LOG2", 32), 24, 34);
+			const uint64_t lim = 1ULL << clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_HINT_BATCH_LOG2"), 32), 24, 34);
 			const uint64_t hinted = c->expect_kmers < lim ? c->expect_kmers : lim;
 			if (hinted > want) want = hinted;
 		}

@@ -6,11 +6,11 @@
 // k-mers per batch at most (pools: ~6 B per k-mer at K = 31).  2^35 since round 6: the 24 G k-mers of the headline workload are ONE batch
 // (144 GB of pools beside 36 GB of table on a 288 GB device; sk_alloc halves the batch wherever that does not fit) -- 276.9 -> 264.4 ms per
 // step against two batches of 2^34 (profiles/r6): one set of launches, host looks and kernel tails instead of two
-static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(env_int("SDT_SK_BATCH_LOG2", 35), 24, 36);
+static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_BATCH_LOG2"), 35), 24, 36);
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
-static const uint64_t SK_COUNT_KMERS = 1ULL << clamp_int(env_int("SDT_SK_COUNT_KMERS_LOG2", 29), 20, 36);
+static const uint64_t SK_COUNT_KMERS = 1ULL << clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_COUNT_KMERS_LOG2"), 29), 20, 36);
 static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
-static const uint32_t SK_COUNT_ITEM_CHUNKS = (uint32_t)clamp_int(env_int("SDT_SK_COUNT_ITEM_CHUNKS", 1024), 64, 1 << 24);          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
+static const uint32_t SK_COUNT_ITEM_CHUNKS = (uint32_t)clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_COUNT_ITEM_CHUNKS"), 1024), 64, 1 << 24);          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 

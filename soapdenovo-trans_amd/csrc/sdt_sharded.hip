@@ -36,8 +36,8 @@ int shard_alloc(sdt_ctx *c)
 	const size_t cw = (size_t)SK_CAP1 * sk_rec_words(c->nw) * 8;
 	h.send_chunks = k.p1.chunks;
 	h.recv_chunks = k.p1.chunks + k.p1.chunks / 4;   // a rank receives ~ what it sends; head room for unequal buckets
-	if (getenv("SDT_SHARD_RECV_CHUNKS"))             // (tests: force sub-rounds)
-		h.recv_chunks = (uint32_t)strtoul(getenv("SDT_SHARD_RECV_CHUNKS"), nullptr, 10);
+	if (sdt_test_env("SDT_SHARD_RECV_CHUNKS"))             // (tests: force sub-rounds)
+		h.recv_chunks = (uint32_t)strtoul(sdt_test_env("SDT_SHARD_RECV_CHUNKS"), nullptr, 10);
 	for (int i = 0; i < 2; i++) {
 		HIPCHK(hipMalloc((void **)&h.send[i], (size_t)h.send_chunks * cw));
 		HIPCHK(hipMalloc((void **)&h.recv[i], (size_t)h.recv_chunks * cw));
@@ -371,8 +371,8 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 	const uint64_t per_read = maxlen - c->K + 1;
 	uint64_t want = maxreads * per_read;
 	if (want > (1ULL << 31)) want = 1ULL << 31;       // rounds of at most 2 G k-mers per rank: the exchange overlaps the next round
-	if (getenv("SDT_SHARD_ROUND_KMERS"))             // (tests: many small rounds)
-		want = strtoull(getenv("SDT_SHARD_ROUND_KMERS"), nullptr, 10);
+	if (sdt_test_env("SDT_SHARD_ROUND_KMERS"))             // (tests: many small rounds)
+		want = strtoull(sdt_test_env("SDT_SHARD_ROUND_KMERS"), nullptr, 10);
 	if (!k.ready || k.cap_kmers < want) {
 		if (k.ready && !k.cap_is_max) { HIPCHK(hipStreamSynchronize(c->stream)); sk_free(c); }
 		rc = sk_alloc(c, want, per_read);
@@ -407,7 +407,7 @@ int sdt_gpu_count_reads_sharded(sdt_ctx *c, const void *d_packed_words, uint64_t
 	if (rc != SDT_OK) return rc;
 	uint64_t cap = caps[0];
 	for (int r = 1; r < cm.nranks; r++) if (caps[r] < cap) cap = caps[r];
-	if (getenv("SDT_SHARD_ROUND_KMERS") && cap > want) cap = want;
+	if (sdt_test_env("SDT_SHARD_ROUND_KMERS") && cap > want) cap = want;
 	uint64_t per_round = cap / per_read / SK_TILE_READS * SK_TILE_READS;
 	if (per_round < (uint64_t)SK_TILE_READS) per_round = SK_TILE_READS;
 	const uint64_t rounds = (maxreads + per_round - 1) / per_round;

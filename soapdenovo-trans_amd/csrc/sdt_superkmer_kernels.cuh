@@ -34,16 +34,15 @@
 #ifndef SDT_SK_SLOTS_NW2
 #define SDT_SK_SLOTS_NW2 1280
 #endif
-#ifndef SDT_SK_TILE
-#define SDT_SK_TILE 512           // records per tile of the count stage (512: the first half of the workgroup's lanes bring one each; 1024: every lane)
-#endif
 #ifndef SDT_SK_SLOTS_NW1
 #define SDT_SK_SLOTS_NW1 2048
 #endif
 template <int NW, bool TRACK> struct SkCntGeo {
 	static constexpr int TPB = SDT_SK_CNT_TPB;
 	static constexpr int WAVES_PER_SIMD = (NW == 1 || (NW == 2 && SDT_SK_NW2_TWO)) ? 2 * (TPB / 256) : TPB / 256;      // two workgroups per CU where the table allows
-	static constexpr int TILE = SDT_SK_TILE;                               // records per tile
+	// records per tile: the first half of the workgroup's lanes bring one each.  (1024 -- every lane brings one, a table of 1280 or 1024 slots
+	// to keep two workgroups per CU -- was built in round 6: count 144.9 -> 182.3 / 211.3 ms at C3, the smaller table flushes far more often)
+	static constexpr int TILE = 512;
 	// LDS table entries: 8 B per key word + 20 B of counters (+ 8 B ordinal).  1-word keys: 2048 slots = 75 KB with the tile, two
 	// workgroups per CU; with ordinals half the table keeps it at two
 #ifdef SDT_SK_TEST_SLOTS
@@ -64,9 +63,6 @@ template <int NW, bool TRACK> struct SkCntGeo {
 	static_assert(((LDS_LEAD + TAIL_PAD) & 1) == 0, "the LDS table behind the tile's words is 8-byte aligned");
 	static_assert(REGION >= (size_t)REP * 4, "the dedupe table aliases prefix + map + index");
 };
-#ifndef SDT_SK_L2_TPB
-#define SDT_SK_L2_TPB 512
-#endif
 // the staged form (k_sk_scatter_records_staged, round 5) has no cursor that lanes fight over -- the 1024-lane geometry that lost a chunk
 // in the kernel above (profiles/r3/l2_1024_lane_loss.md) is safe there, and twice the records in flight per CU are worth 6 ms per step
 // (65.2 / 65.8 -> 59.8 / 59.0 ms on the same box): the kernel is bound by its own phases (two barriers and a serial book-keeping
@@ -75,12 +71,10 @@ template <int NW, bool TRACK> struct SkCntGeo {
 #define SDT_SK_L2S_TPB 1024
 #endif
 constexpr int SK_L2S_TPB = SDT_SK_L2S_TPB;
-constexpr int SK_L2_TPB = SDT_SK_L2_TPB;         // k_sk_scatter_records: one large workgroup per CU (see sk_split)
 #ifndef SDT_SK_L2_DEPTH
 #define SDT_SK_L2_DEPTH 2
 #endif
 constexpr int SK_LIST2_FILL_SHIFT = 28;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
-constexpr int SK_L2_LDS_PAD_KB = 72;             // + 16 KB of cursors and counters: more than half of a CU's 160 KB
 
 #include "sdt_sk_scatter_seq.cuh"      // chunk reservation helpers + the one-lane-per-read level-1 scatter (own header: its
                                         // many instantiations are compiled in translation units of their own)
@@ -445,106 +439,10 @@ __device__ unsigned long long *g_l2_log = nullptr;
 __device__ unsigned long long g_l2_log_cap = 0;
 #endif
 
-template <int NW>
-__global__ __launch_bounds__(SK_L2_TPB) void k_sk_scatter_records(SkPool src, const uint32_t *__restrict__ list1,
-                                                                  const SkItem *__restrict__ items, SkPool dst,
-                                                                  uint32_t *__restrict__ g_cnt, unsigned long long *__restrict__ g_kmers, Stats *stats)
-{
-	constexpr int RW = SkFmt<NW>::REC_WORDS;
-	constexpr int CPT = SK_L2_TPB / SK_CAP1;         // chunks per sweep
-	__shared__ unsigned long long s_cur[SK_NB2];
-	__shared__ uint32_t s_kc[SK_NB2], s_cc[SK_NB2];  // k-mers and chunks per level-2 bucket of this item
-	__shared__ unsigned long long s_blk;
-	const SkItem it = items[blockIdx.x];
-	const int tid = threadIdx.x;
-	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
-		s_cur[i] = ((unsigned long long)SK_NOCHUNK << 32) | (unsigned)SK_CAP2;
-		s_kc[i] = 0;
-		s_cc[i] = 0;
-	}
-	if (tid == 0)
-		s_blk = 0;
-	__syncthreads();
-	uint32_t failed = 0;
-	// chunk id -> fill + record -> LDS cursor -> store is three memory latencies in a row, and one workgroup per CU has
-	// only 8 waves to hide them: a lane keeps the records of its next D sweeps in registers and the chunk ids of the D
-	// after those (a slot past a chunk's fill is loaded and dropped)
-	constexpr int D = SDT_SK_L2_DEPTH;
-	const uint32_t slot = (uint32_t)tid % SK_CAP1, cfirst = it.c0 + (uint32_t)tid / SK_CAP1;
-	uint32_t id_a[D], id_b[D], fill_a[D];
-	uint64_t rec_a[D][RW];
-#pragma unroll
-	for (int d = 0; d < D; d++) {
-		const uint32_t ca = cfirst + (uint32_t)d * CPT, cb = ca + (uint32_t)D * CPT;
-		id_a[d] = ca < it.c1 ? list1[ca] : SK_NOCHUNK;
-		id_b[d] = cb < it.c1 ? list1[cb] : SK_NOCHUNK;
-	}
-#pragma unroll
-	for (int d = 0; d < D; d++) {
-		fill_a[d] = 0;
-#pragma unroll
-		for (int i = 0; i < RW; i++)
-			rec_a[d][i] = 0;
-		if (id_a[d] != SK_NOCHUNK) {
-			fill_a[d] = src.meta[id_a[d]] >> 24;
-			sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
-		}
-	}
-	for (uint32_t cg = cfirst; cg < it.c1; cg += (uint32_t)D * CPT) {
-#pragma unroll
-		for (int d = 0; d < D; d++) {
-			const uint32_t ci = cg + (uint32_t)d * CPT;
-			uint64_t rec[RW];
-#pragma unroll
-			for (int i = 0; i < RW; i++)
-				rec[i] = rec_a[d][i];
-			const uint32_t fill = ci < it.c1 ? fill_a[d] : 0u;
-			id_a[d] = id_b[d];
-			const uint32_t cn = ci + 2u * (uint32_t)D * CPT;
-			id_b[d] = cn < it.c1 ? list1[cn] : SK_NOCHUNK;
-			if (id_a[d] != SK_NOCHUNK) {
-				fill_a[d] = src.meta[id_a[d]] >> 24;
-				sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
-			}
-			if (slot >= fill)
-				continue;
-			const uint32_t b2 = sk_hdr_l2(rec[0]);
-			atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
-			uint32_t dchunk, pos;
-			if (sk_reserve(s_cur, &s_blk, b2, it.b1 * SK_NB2 + b2, SK_CAP2, dst, s_cc, dchunk, pos)) {
-				sk_store_record2<NW>(dst.recs + ((size_t)dchunk * SK_CAP2 + pos) * SkFmt<NW>::REC2_STRIDE, rec);
-#ifdef SDT_SK_L2_LOG
-				if (g_l2_log) {
-					const unsigned long long at = atomicAdd(g_l2_log, 1ULL);
-					if (at + 1 < g_l2_log_cap)
-						g_l2_log[1 + at] = ((unsigned long long)dchunk << 32) | ((unsigned long long)pos << 16) | (unsigned long long)tid;
-				}
-#endif
-			} else
-				failed++;                            // the pool is sized for the worst case: never expected
-		}
-	}
-	__syncthreads();
-	for (int i = tid; i < SK_NB2; i += SK_L2_TPB) {
-		const unsigned long long cur = s_cur[i];
-		const uint32_t chunk = (uint32_t)(cur >> 32), pos = (uint32_t)cur;
-		if (chunk != SK_NOCHUNK)
-			dst.meta[chunk] = (it.b1 * SK_NB2 + (uint32_t)i) | ((pos < (uint32_t)SK_CAP2 ? pos : (uint32_t)SK_CAP2) << 24);
-		if (s_kc[i])
-			atomicAdd(&g_kmers[it.b1 * SK_NB2 + i], (unsigned long long)s_kc[i]);     // (64 bits: a hot bucket of a 2^33-k-mer batch)
-		if (s_cc[i])
-			atomicAdd(&g_cnt[it.b1 * SK_NB2 + i], s_cc[i]);
-	}
-	if (tid == 0)
-		sk_retire_block(s_blk, dst);
-	if (failed)
-		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
-}
-
-// ---- level 2, staged (round 5) ---------------------------------------------------------------------------------------
-// k_sk_scatter_records above stores every record where its sub-bucket's open chunk has room: 24..56 bytes at a time into one
-// of 1024 open chunks per workgroup, so a 128-byte line is written by five or six stores sweeps apart, and many lines leave L2
-// before they are full (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4).  Here a record waits in LDS until its sub-bucket
+// ---- level 2, staged (round 5; the only level-2 scatter since round 6) ---------------------------------------------------
+// Rounds 2-4 stored every record where its sub-bucket's open chunk had room: 24..56 bytes at a time into one of 1024 open chunks
+// per workgroup, so a 128-byte line was written by five or six stores sweeps apart, and many lines left L2 before they were full
+// (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4; that kernel, k_sk_scatter_records, is gone).  Here a record waits in LDS until its sub-bucket
 // has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56): per tile of 512 records
 //   1   every record takes a ticket of its sub-bucket (one LDS atomic; the tickets start at the records already waiting)
 //   1.5 the lane with the first new ticket of a sub-bucket does its bookkeeping ALONE: complete groups of this tile, room in the

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# test hooks of the library and its hosts (chunk sizes, pool sizes, forced paths: csrc/sdt_knobs.h) are honoured only under
+# SDT_TEST_HOOKS=1; every child process of the suite inherits it
+os.environ["SDT_TEST_HOOKS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

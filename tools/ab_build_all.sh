@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../soapdenovo-trans_amd/csrc"
 mkdir -p ../../gpurun_ab /tmp/ab_$1
 NAME=$1; FLAGS=$2
 for f in sdt_gpu sdt_gpu_graph sdt_mem sdt_scatter_seq_a sdt_scatter_seq_b sdt_scatter_seq_c sdt_scatter_seq_d; do
-  hipcc $FLAGS -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -c -o /tmp/ab_$NAME/$f.o $f.hip &
+  hipcc -DSDT_TUNING $FLAGS -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -c -o /tmp/ab_$NAME/$f.o $f.hip &
 done
 wait
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -o ../../gpurun_ab/libsdt_gpu_$NAME.so /tmp/ab_$NAME/*.o
