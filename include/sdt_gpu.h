@@ -194,7 +194,7 @@ int sdt_shard_plan(const uint32_t *mat, int nranks, int me, const uint32_t *rang
  * device): what the library computes between the level-2 scatter and k_sk_count, callable so that it can be tested on a CPU.
  *   off2[f], kpre2[f]   first chunk / first k-mer of final bucket f in the chunk list (f = nbuckets: the totals)
  *   items               4 words per work item: the run [c0, c1) of the list, top bit of c1 = the item holds whole buckets only;
- *                       its first and its last final bucket (k_sk_count files an item's nodes in the node log bucket by bucket).
+ *                       its first and its last final bucket.
  *                       Buckets of <= 64 chunks share an item with their neighbours -- inside one level-1 bucket and a span of 64
  *                       final buckets --, buckets of > 1024 chunks are cut into pieces.
  *   first_item[l], launch_kmers[l]   first item and k-mers of launch l (first_item[*nlaunches] = *nitems); a launch is cut

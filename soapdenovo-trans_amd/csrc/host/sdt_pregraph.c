@@ -284,6 +284,16 @@ static void on_sigchld(int sig)
 	}
 }
 
+/* first touch of a fresh segment, on all threads: the pages of a new shared-memory object are made (and cleared) by the kernel at the
+ * first write, one fault per page on the writing thread -- the device-to-host copy of a 2 GB path table into a fresh segment ran at
+ * 3 GB/s (685 ms at 20 M reads with four ranks, profiles/r6) when its four staging threads took those faults one by one */
+static void touch_pages(void *vc, uint64_t lo, uint64_t hi, int tid)
+{
+	(void)tid;
+	volatile char *b = (volatile char *)vc;
+	for (uint64_t pg = lo; pg < hi; pg++) b[pg << 12] = 0;
+}
+
 static void *shm_region(const char *name, size_t bytes, int create)
 {
 	int fd = create ? shm_open(name, O_CREAT | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
@@ -291,7 +301,9 @@ static void *shm_region(const char *name, size_t bytes, int create)
 	if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return NULL; }
 	void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
 	close(fd);
-	return p == MAP_FAILED ? NULL : p;
+	if (p == MAP_FAILED) return NULL;
+	if (create && bytes >= ((size_t)64 << 20)) par_for(0, (bytes + 4095) >> 12, 4096, touch_pages, p);
+	return p;
 }
 
 /* arcs of several ranks in one array: equal (from, to) pairs become one arc -- multiplicities add up, the first occurrence is the
@@ -521,7 +533,14 @@ static int dev_minor_out_commit_begin_hook(graph_t *g, double threshold, uint64_
 	/* one lane walks a component at about a microsecond per dependent access (~100 us per visit); a host thread takes ~150 ns */
 	/* (the device's lanes and the host's threads work side by side: at 200 M reads 1536 / 2048 / 2560 / 3072 / 4096 visits per component gave
 	 * 983 / 895 / 829 / 813 / 1020 ms for the whole pass -- past 3072 the host waits for the longest lane, profiles/r5/README.md) */
-	const uint64_t max_comp = sdt_test_env("SDT_COMMIT_MAX_COMPONENT") ? strtoull(sdt_test_env("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : 3072;
+	/* Round 6: the limit follows the size of the job.  The device's part lasts as long as its longest lane -- limit x ~50 us, whatever the
+	 * job --, the host's part grows with the visits of the components past the limit: 3072 is where they meet at 16.5 M visits (200 M
+	 * reads); at 1.8 M visits (8 M reads) the host was done with its six long components after 7 ms and then waited 154 ms for the lanes of
+	 * 3072 visits (profiles/r6/e2e_8M_se_ours_only.json).  visits / 5000, within 256 .. 3072. */
+	uint64_t by_size = nj / 5000;
+	if (by_size < 256) by_size = 256;
+	if (by_size > 3072) by_size = 3072;
+	const uint64_t max_comp = sdt_test_env("SDT_COMMIT_MAX_COMPONENT") ? strtoull(sdt_test_env("SDT_COMMIT_MAX_COMPONENT"), NULL, 10) : by_size;
 	if (sdt_gpu_minor_out_commit_begin(D->gpu, threshold, max_comp, &largest, &nsk, &nskr) != SDT_OK) { fprintf(stderr, "sdt_gpu_minor_out_commit_begin: %s\n", sdt_gpu_last_error()); return 1; }
 	const double t2 = now_ms();
 	uint64_t *sk = (uint64_t *)malloc((nskr + 1) * MO_RW * sizeof(uint64_t));

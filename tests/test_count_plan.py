@@ -1,7 +1,7 @@
 """CPU: the work items and launches of the count stage (csrc/sdt_count_plan.h through sdt_sk_plan_count_items) -- the host
 computation between the level-2 scatter and k_sk_count.  An item is a run of the level-2 chunk list; the kernel's workgroups
-take items first come first served and file an item's nodes in the node log under the item's final buckets (rounds 3-4: they
-merged WITHOUT atomics when the item was flagged as holding whole buckets only), so the plan must be airtight: every chunk in
+take items first come first served and merge an item's nodes into the node table WITHOUT atomics when the item is flagged as holding
+whole buckets only, so the plan must be airtight: every chunk in
 exactly one item, a flagged item made of complete buckets, the buckets an item names exactly the buckets of its chunks -- all in one
 level-1 bucket and a span of 64 --, no item across two launches.
 Stands where the reference hands a batch to its threads (prlHashReads.c:312-336); the kernels it feeds are tested on the GPU."""
