@@ -112,7 +112,7 @@ int sk_alloc(sdt_ctx *c, uint64_t want_kmers, uint64_t per_read)
 		// tests/test_sharded.py)
 		const uint64_t chunks1 = sdt_knob_int(sdt_test_env("SDT_SK_POOL_CHUNKS1"), 0) > 0 ? (uint64_t)sdt_knob_int(sdt_test_env("SDT_SK_POOL_CHUNKS1"), 0) : recs / SK_CAP1 + (uint64_t)wgs * SK_NB1 + 1024;
 		const uint64_t items = chunks1 / SK_ITEM_CHUNKS + SK_NB1 + 1;
-		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * SK_NB2 + 1024;
+		const uint64_t chunks2 = chunks1 * (SK_CAP1 / SK_CAP2) + items * (SK_NB2 + SK_BLK2) + 1024;      // (+ what an item leaves of its last block of ids)
 		const uint64_t bytes = chunks1 * SK_CAP1 * rw * 8 + chunks2 * SK_CAP2 * rw2 * 8 + (chunks1 + chunks2) * 8;
 		// (a sharded context adds two send and two receive buffers of pool-1 size: shard_alloc)
 		const uint64_t all = c->comm.nranks > 1 ? bytes + chunks1 * SK_CAP1 * rw * 8 * 9 / 2 : bytes;

@@ -14,6 +14,13 @@ using namespace sdt;
 // atomic per SK_BLK chunks.  (One atomicAdd per chunk on the single pool counter was measured to cap BOTH scatter
 // kernels: same-address device atomics run at well under 1 G/s on MI355X.)
 constexpr uint32_t SK_BLK = 128;
+// The level-2 scatter takes larger blocks: a workgroup that runs out of ids stands still for the round trip of the fetching lane's global
+// atomic (the lanes that need a chunk spin, everybody else waits at the round's barrier), 0.7 M times per step of the 200 M-read workload
+// with blocks of 128.  What an item leaves of its last block is retired (sk_retire_block) and counted in the pool's size (sk_alloc).
+#ifndef SDT_SK_BLK2
+#define SDT_SK_BLK2 1024
+#endif
+constexpr uint32_t SK_BLK2 = SDT_SK_BLK2;
 constexpr uint32_t SK_DEAD = 0xFFFFFFFFu;        // meta of a chunk id that was handed to a workgroup but never used
 
 #ifdef SDT_SK_L2_LOG
@@ -46,7 +53,7 @@ __device__ inline void sk_log_alloc(uint32_t, uint32_t, uint32_t) {}
 __device__ inline void sk_log_cursor(uint32_t, uint32_t, uint32_t, uint32_t) {}
 #endif
 
-__device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool)
+__device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPool &pool, uint32_t blk = SK_BLK)
 {
 	// Flag form on purpose: a lane that finds the block exhausted (id > end) spins until the lane that took id == end has
 	// fetched the next block -- possibly a lane of ITS OWN wave.  With `for (;;) { ... return ...; }` the compiler is free
@@ -69,8 +76,8 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 			done = true;
 			sk_log_alloc(0, end, id);
 		} else if (id == end) {
-			const uint32_t base = atomicAdd(pool.next, SK_BLK);
-			atomicExch(s_blk, ((unsigned long long)(base + SK_BLK) << 32) | (unsigned long long)(base + 1u));
+			const uint32_t base = atomicAdd(pool.next, blk);
+			atomicExch(s_blk, ((unsigned long long)(base + blk) << 32) | (unsigned long long)(base + 1u));
 			got = base;
 			done = true;
 			sk_log_alloc(1, end, base);

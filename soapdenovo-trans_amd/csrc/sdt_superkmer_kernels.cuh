@@ -71,9 +71,6 @@ template <int NW, bool TRACK> struct SkCntGeo {
 #define SDT_SK_L2S_TPB 1024
 #endif
 constexpr int SK_L2S_TPB = SDT_SK_L2S_TPB;
-#ifndef SDT_SK_L2_DEPTH
-#define SDT_SK_L2_DEPTH 2
-#endif
 constexpr int SK_LIST2_FILL_SHIFT = 28;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
 
 #include "sdt_sk_scatter_seq.cuh"      // chunk reservation helpers + the one-lane-per-read level-1 scatter (own header: its
@@ -442,14 +439,15 @@ __device__ unsigned long long g_l2_log_cap = 0;
 // ---- level 2, staged (round 5; the only level-2 scatter since round 6) ---------------------------------------------------
 // Rounds 2-4 stored every record where its sub-bucket's open chunk had room: 24..56 bytes at a time into one of 1024 open chunks
 // per workgroup, so a 128-byte line was written by five or six stores sweeps apart, and many lines left L2 before they were full
-// (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4; that kernel, k_sk_scatter_records, is gone).  Here a record waits in LDS until its sub-bucket
-// has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56): per tile of 512 records
+// (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4; that kernel, k_sk_scatter_records, is gone).  Here a record waits in LDS until its
+// sub-bucket has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56).  Per ROUND every lane brings D records (D = 1; the loop is written for any D):
 //   1   every record takes a ticket of its sub-bucket (one LDS atomic; the tickets start at the records already waiting)
-//   1.5 the lane with the first new ticket of a sub-bucket does its bookkeeping ALONE: complete groups of this tile, room in the
-//       open chunk, new chunks (contiguous ids), the records that waited (read into registers), the state of the next tile --
-//       no cursor that several lanes fight over (sk_reserve's protocol is not used here at all)
-//   2   a record of a complete group goes to its slot of the group in global memory -- the S records of a group are stored in
-//       the same phase, by up to S lanes: 96 / 80 / 112 contiguous bytes that meet in L2 --, the others wait in the stage
+//   1.5 LANE i KEEPS THE BOOKS OF SUB-BUCKET i (round 6; round 5: the lane that drew the sub-bucket's first new ticket -- about 40 of a
+//       wave's 64 lanes, in every wave, once per 1024 records): complete groups of this round, room in the open chunk, new chunks
+//       (contiguous ids), the records that waited (they leave with the first group: stored here), the state of the next round -- no
+//       cursor that several lanes fight over (sk_reserve's protocol is not used here at all)
+//   2   a record of a complete group goes to its slot of the group in global memory -- the S records of a group are stored within one
+//       round, by up to S lanes: 96 / 80 / 112 contiguous bytes that meet in L2 --, the others wait in the stage
 // and at the end of the item the waiting records are written as a last, partial group.  Chunks fill from slot 0 up, so the
 // count stage's lists (chunk id + fill) stay what they were.
 #ifndef SDT_SK_L2S_S1
@@ -458,9 +456,14 @@ __device__ unsigned long long g_l2_log_cap = 0;
 #ifndef SDT_SK_L2S_WGS
 #define SDT_SK_L2S_WGS 1          // workgroups per CU the staged level-2 scatter is compiled for (2: 64 registers per lane)
 #endif
+#ifndef SDT_SK_L2S_RPL
+#define SDT_SK_L2S_RPL 1          // records per lane and round (2 and 4 were SLOWER: split 54.6 -> 69.2 / 97.6 ms at C3, profiles/r6 -- more records per
+                                  // round mean more sub-buckets that need several new chunks at once, and those ids come from ONE global counter)
+#endif
 template <int NW> struct SkL2Stage {
 	static constexpr int S = NW == 1 ? SDT_SK_L2S_S1 : 2;            // records per group
 	static constexpr int GPC = SK_CAP2 / S;                          // groups per chunk
+	static constexpr int RPL = NW <= 2 ? SDT_SK_L2S_RPL : 1;         // records per lane and round
 	static constexpr size_t SMEM = (size_t)SK_NB2 * S * SkFmt<NW>::REC_WORDS * 8;
 };
 
@@ -471,11 +474,12 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 {
 	constexpr int RW = SkFmt<NW>::REC_WORDS, RW2 = SkFmt<NW>::REC2_STRIDE, S = SkL2Stage<NW>::S, GPC = SkL2Stage<NW>::GPC;
 	constexpr int CPT = SK_L2S_TPB / SK_CAP1;         // chunks per sweep
+	constexpr int D = SkL2Stage<NW>::RPL;            // sweeps (records per lane) per round
 	extern __shared__ unsigned long long s_stage[];  // SK_NB2 x S records
-	__shared__ uint32_t s_cnt[SK_NB2];               // tickets of the running tile (start: the records waiting in the stage)
+	__shared__ uint32_t s_cnt[SK_NB2];               // tickets of the running round (start: the records waiting in the stage)
 	__shared__ uint32_t s_open[SK_NB2];              // open chunk of the sub-bucket (SK_NOCHUNK: none)
-	__shared__ uint32_t s_pub_open[SK_NB2], s_pub_new[SK_NB2], s_pub_g[SK_NB2];     // what phase 2 of the tile needs: the open chunk and the groups used in it
-	                                                                               // before the tile (g: used | groups << 8), the first new chunk
+	__shared__ uint32_t s_pub_open[SK_NB2], s_pub_new[SK_NB2], s_pub_g[SK_NB2];     // what phase 2 of the round needs: the open chunk and the groups used in it
+	                                                                               // before the round (g: used | groups << 8), the first new chunk
 	__shared__ unsigned char s_fill[SK_NB2], s_used[SK_NB2];                       // records waiting; groups used in the open chunk
 	__shared__ uint32_t s_kc[SK_NB2], s_cc[SK_NB2];  // k-mers and chunks per level-2 bucket of this item
 	__shared__ unsigned long long s_blk;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 	uint32_t failed = 0;
 	// n chunk ids (contiguous): one out of the workgroup's block, more straight from the pool; SK_NOCHUNK: the pool is exhausted
 	auto alloc = [&](uint32_t n) -> uint32_t {
-		const uint32_t id = n == 1 ? sk_alloc_chunk(&s_blk, dst) : atomicAdd(dst.next, n);
+		const uint32_t id = n == 1 ? sk_alloc_chunk(&s_blk, dst, SK_BLK2) : atomicAdd(dst.next, n);
 		return id < dst.chunks && id + n <= dst.chunks ? id : SK_NOCHUNK;
 	};
 	// slot of record `t` (ticket) of a sub-bucket whose open chunk had `used` groups in use before: in the open chunk while it lasts,
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 			return nullptr;
 		return dst.recs + ((size_t)(first_new + (a - GPC) / GPC) * SK_CAP2 + ((a - GPC) % GPC) * S + t % S) * RW2;
 	};
-	constexpr int D = SDT_SK_L2_DEPTH;
+	// records and chunk ids are loaded a round ahead / two rounds ahead (registers: this kernel runs one workgroup per CU)
 	const uint32_t slot = (uint32_t)tid % SK_CAP1, cfirst = it.c0 + (uint32_t)tid / SK_CAP1;
 	uint32_t id_a[D], id_b[D], fill_a[D];
 	uint64_t rec_a[D][RW];
@@ -529,16 +533,18 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 			sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
 		}
 	}
-	// (the sweeps are uniform: every lane of the workgroup runs the same number of them, barriers included)
+	// (the rounds are uniform: every lane of the workgroup runs the same number of them, barriers included)
 	const uint32_t nsweep = (it.c1 - it.c0 + CPT - 1) / CPT;
 	for (uint32_t sw = 0; sw < nsweep; sw += (uint32_t)D) {
+		uint64_t rec[D][RW];
+		uint32_t b2[D], t[D];
+		bool valid[D];
 #pragma unroll
 		for (int d = 0; d < D; d++) {
 			const uint32_t ci = cfirst + (sw + (uint32_t)d) * CPT;
-			uint64_t rec[RW];
 #pragma unroll
 			for (int i = 0; i < RW; i++)
-				rec[i] = rec_a[d][i];
+				rec[d][i] = rec_a[d][i];
 			const uint32_t fill = ci < it.c1 ? fill_a[d] : 0u;
 			id_a[d] = id_b[d];
 			const uint32_t cn = ci + 2u * (uint32_t)D * CPT;
@@ -547,86 +553,81 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 				fill_a[d] = src.meta[id_a[d]] >> 24;
 				sk_load_record<RW>(src.recs + ((size_t)id_a[d] * SK_CAP1 + slot) * RW, rec_a[d]);
 			}
-			const bool valid = slot < fill;
+			valid[d] = slot < fill;
 			// ---- 1: tickets
-			uint32_t b2 = 0, t = 0, f = 0;
-			if (valid) {
-				b2 = sk_hdr_l2(rec[0]);
-				f = s_fill[b2];
-				t = atomicAdd(&s_cnt[b2], 1u);
-				atomicAdd(&s_kc[b2], (uint32_t)sk_hdr_n(rec[0]));
+			b2[d] = 0;
+			t[d] = 0;
+			if (valid[d]) {
+				b2[d] = sk_hdr_l2(rec[d][0]);
+				t[d] = atomicAdd(&s_cnt[b2[d]], 1u);
+				atomicAdd(&s_kc[b2[d]], (uint32_t)sk_hdr_n(rec[d][0]));
 			}
-			__syncthreads();
-			// ---- 1.5: the first newcomer of a sub-bucket keeps its books
-			const bool keeper = valid && t == f;
-			uint64_t old[S > 1 ? S - 1 : 1][RW];
-			uint32_t kG = 0;
-			if (keeper) {
-				const uint32_t total = s_cnt[b2], G = total / S, left = total - G * S;
-				const uint32_t open = s_open[b2], used = open == SK_NOCHUNK ? (uint32_t)GPC : s_used[b2];
-				const uint32_t room = (uint32_t)GPC - used;
-				uint32_t first_new = SK_NOCHUNK, nnew = 0;
-				if (G > room) {
-					nnew = (G - room + GPC - 1) / GPC;
-					first_new = alloc(nnew);
-					if (first_new != SK_NOCHUNK) {
-						for (uint32_t j = 0; j < nnew; j++)
-							dst.meta[first_new + j] = (it.b1 * SK_NB2 + b2) | ((uint32_t)SK_CAP2 << 24);
-						atomicAdd(&s_cc[b2], nnew);
-					}
+		}
+		__syncthreads();
+		// ---- 1.5: lane i keeps the books of sub-bucket i
+		for (int i = tid; i < SK_NB2; i += SK_L2S_TPB) {
+			const uint32_t f = s_fill[i], total = s_cnt[i];
+			if (total == f)
+				continue;                                // nobody came
+			const uint32_t G = total / S, left = total - G * S;
+			const uint32_t open = s_open[i], used = open == SK_NOCHUNK ? (uint32_t)GPC : s_used[i];
+			const uint32_t room = (uint32_t)GPC - used;
+			uint32_t first_new = SK_NOCHUNK;
+			if (G > room) {
+				const uint32_t nnew = (G - room + GPC - 1) / GPC;
+				first_new = alloc(nnew);
+				if (first_new != SK_NOCHUNK) {
+					for (uint32_t j = 0; j < nnew; j++)
+						dst.meta[first_new + j] = (it.b1 * SK_NB2 + (uint32_t)i) | ((uint32_t)SK_CAP2 << 24);
+					s_cc[i] += nnew;
 				}
-				s_pub_open[b2] = open;
-				s_pub_new[b2] = first_new;
-				s_pub_g[b2] = used | (G << 8);
-				kG = G;
-				if (G && f) {                        // the records that waited leave with the first group
-#pragma unroll
-					for (int j = 0; j < S - 1; j++)
-						if ((uint32_t)j < f) {
-#pragma unroll
-							for (int i = 0; i < RW; i++)
-								old[j][i] = s_stage[((size_t)b2 * S + j) * RW + i];
-						}
-				}
-				// the next tile's state
-				if (G) {
-					const uint32_t a_end = used + G;     // groups in use, counted from the open chunk's first
-					if (a_end <= (uint32_t)GPC) {
-						s_used[b2] = (unsigned char)a_end;
-					} else if (first_new != SK_NOCHUNK) {
-						s_open[b2] = first_new + (a_end - GPC - 1) / GPC;
-						s_used[b2] = (unsigned char)((a_end - GPC - 1) % GPC + 1);
-					} else {
-						s_open[b2] = SK_NOCHUNK;         // (pool exhausted: the records of this tile are counted as failed below)
-						s_used[b2] = 0;
-					}
-				}
-				s_fill[b2] = (unsigned char)left;
-				s_cnt[b2] = left;
 			}
-			__syncthreads();
-			// ---- 2: complete groups to global memory, the rest waits
-			if (valid) {
-				const uint32_t g = s_pub_g[b2], G = g >> 8, used = g & 0xFFu;
-				if (t / S < G) {
-					uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], t);
-					if (p) sk_store_record2<NW>(p, rec);
+			s_pub_open[i] = open;
+			s_pub_new[i] = first_new;
+			s_pub_g[i] = used | (G << 8);
+			if (G && f) {                                // the records that waited leave with the first group
+				for (uint32_t j = 0; j < f; j++) {
+					uint64_t old[RW];
+#pragma unroll
+					for (int w = 0; w < RW; w++)
+						old[w] = s_stage[((size_t)i * S + j) * RW + w];
+					uint64_t *p = slot_of(open, used, first_new, j);
+					if (p) sk_store_record2<NW>(p, old);
 					else failed++;
+				}
+			}
+			// the next round's state
+			if (G) {
+				const uint32_t a_end = used + G;         // groups in use, counted from the open chunk's first
+				if (a_end <= (uint32_t)GPC) {
+					s_used[i] = (unsigned char)a_end;
+				} else if (first_new != SK_NOCHUNK) {
+					s_open[i] = first_new + (a_end - GPC - 1) / GPC;
+					s_used[i] = (unsigned char)((a_end - GPC - 1) % GPC + 1);
 				} else {
-					const uint32_t at = t - G * S;
-#pragma unroll
-					for (int i = 0; i < RW; i++)
-						s_stage[((size_t)b2 * S + at) * RW + i] = rec[i];
+					s_open[i] = SK_NOCHUNK;              // (pool exhausted: the records of this round are counted as failed below)
+					s_used[i] = 0;
 				}
-				if (keeper && kG && f) {
+			}
+			s_fill[i] = (unsigned char)left;
+			s_cnt[i] = left;
+		}
+		__syncthreads();
+		// ---- 2: complete groups to global memory, the rest waits
 #pragma unroll
-					for (int j = 0; j < S - 1; j++)
-						if ((uint32_t)j < f) {
-							uint64_t *p = slot_of(s_pub_open[b2], used, s_pub_new[b2], (uint32_t)j);
-							if (p) sk_store_record2<NW>(p, old[j]);
-							else failed++;
-						}
-				}
+		for (int d = 0; d < D; d++) {
+			if (!valid[d])
+				continue;
+			const uint32_t g = s_pub_g[b2[d]], G = g >> 8, used = g & 0xFFu;
+			if (t[d] / S < G) {
+				uint64_t *p = slot_of(s_pub_open[b2[d]], used, s_pub_new[b2[d]], t[d]);
+				if (p) sk_store_record2<NW>(p, rec[d]);
+				else failed++;
+			} else {
+				const uint32_t at = t[d] - G * S;
+#pragma unroll
+				for (int i = 0; i < RW; i++)
+					s_stage[((size_t)b2[d] * S + at) * RW + i] = rec[d][i];
 			}
 		}
 	}
@@ -662,8 +663,12 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 			atomicAdd(&g_cnt[it.b1 * SK_NB2 + i], s_cc[i]);
 	}
 	__syncthreads();
-	if (tid == 0)
-		sk_retire_block(s_blk, dst);
+	{   // what is left of the workgroup's block of ids must not look like chunks of an earlier batch (sk_retire_block, on all lanes)
+		const unsigned long long blk = s_blk;
+		const uint32_t next = (uint32_t)blk, end = (uint32_t)(blk >> 32);
+		for (uint32_t id = next + (uint32_t)tid; id < end && id < dst.chunks; id += SK_L2S_TPB)
+			dst.meta[id] = SK_DEAD;
+	}
 	if (failed)
 		atomicAdd(&stats->probe_fail, (unsigned long long)failed);
 }
