@@ -10,7 +10,9 @@ static const uint64_t SK_BATCH_MAX_KMERS = 1ULL << clamp_int(sdt_knob_int(sdt_tu
 static const uint32_t SK_ITEM_CHUNKS = 4096;                // level-1 chunks per level-2 work item (4 MiB of records)
 static const uint64_t SK_COUNT_KMERS = 1ULL << clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_COUNT_KMERS_LOG2"), 29), 20, 36);
 static const uint32_t SK_COUNT_PACK_CHUNKS = 64;            // level-2 chunks up to which neighbouring small buckets share a work item (1 K records = two tiles)
-static const uint32_t SK_COUNT_ITEM_CHUNKS = (uint32_t)clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_COUNT_ITEM_CHUNKS"), 1024), 64, 1 << 24);          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
+// (2048 since round 6 -- one batch per step holds twice the chunks per bucket: with 1024 more buckets were cut into pieces, whose merges are
+// compare-and-swaps; count 148.1 -> 145.5 ms at C3, 512: 152.9: profiles/r6/ab_job12*)
+static const uint32_t SK_COUNT_ITEM_CHUNKS = (uint32_t)clamp_int(sdt_knob_int(sdt_tuning_env("SDT_SK_COUNT_ITEM_CHUNKS"), 2048), 64, 1 << 24);          // level-2 chunks per k_sk_count work item (16 K records); a bucket within it is counted by ONE workgroup (owned merges)
 static const uint32_t SK_MAX_COUNT_LAUNCHES = 4096;          // k-mers per k_sk_count launch (growth bound, see ensure_room)
 
 

@@ -87,6 +87,43 @@ __device__ inline uint32_t sk_alloc_chunk(unsigned long long *s_blk, const SkPoo
 	return got;
 }
 
+// n CONTIGUOUS chunk ids out of the workgroup's block (the level-2 scatter: a sub-bucket that takes many records in one round needs
+// several chunks at once).  The lane whose request crosses the end of the block retires what is left of it, fetches a fresh block
+// with room for its n ids and a whole block behind them, and takes its ids from the front.  Why not the pool's counter directly (rounds
+// 2-5 did that for n > 1): a returning atomic on ONE global address costs ~15 ns per wave-instruction chip-wide; with the keeper lanes
+// of round 6 spread over all sixteen waves of a workgroup, skewed data (every round a few sub-buckets need a run of chunks) put several
+// such instructions per workgroup and round on that one counter: split 48 -> 78 ms at sigma = 2.5 (profiles/r6/ab_job9*).
+// Flag form as above; the same protocol: a cursor past the end means "being replaced", look again.
+__device__ inline uint32_t sk_alloc_chunks(unsigned long long *s_blk, const SkPool &pool, uint32_t n, uint32_t blk)
+{
+	uint32_t got = SK_NOCHUNK;
+	bool done = false;
+	while (!done) {
+		{
+			const unsigned long long w = __hip_atomic_load(s_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if ((uint32_t)w > (uint32_t)(w >> 32)) {
+				__builtin_amdgcn_s_sleep(1);
+				continue;
+			}
+		}
+		const unsigned long long v = atomicAdd(s_blk, (unsigned long long)n);
+		const uint32_t id = (uint32_t)v, end = (uint32_t)(v >> 32);
+		if (id <= end && id + n <= end) {
+			got = id;
+			done = true;
+		} else if (id <= end) {
+			for (uint32_t x = id; x < end && x < pool.chunks; x++)     // (the rest of the old block: fewer than n ids)
+				pool.meta[x] = SK_DEAD;
+			const uint32_t base = atomicAdd(pool.next, n + blk);
+			atomicExch(s_blk, ((unsigned long long)(base + n + blk) << 32) | (unsigned long long)(base + n));
+			got = base;
+			done = true;
+		}
+		// id > end: another lane of this workgroup is fetching the next block -- look again (behind the peek above)
+	}
+	return got;
+}
+
 // the ids of a block that were never handed out must not look like chunks of an earlier batch
 __device__ inline void sk_retire_block(unsigned long long blk, const SkPool &pool)
 {

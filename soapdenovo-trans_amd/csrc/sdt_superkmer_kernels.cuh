@@ -440,7 +440,8 @@ __device__ unsigned long long g_l2_log_cap = 0;
 // Rounds 2-4 stored every record where its sub-bucket's open chunk had room: 24..56 bytes at a time into one of 1024 open chunks
 // per workgroup, so a 128-byte line was written by five or six stores sweeps apart, and many lines left L2 before they were full
 // (WRITE_SIZE 94.6 GB for 56 GB of records, profiles/r4; that kernel, k_sk_scatter_records, is gone).  Here a record waits in LDS until its
-// sub-bucket has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56).  Per ROUND every lane brings D records (D = 1; the loop is written for any D):
+// sub-bucket has a GROUP of S records (4 of 24 bytes, 2 of 40 / 56).  Per ROUND every lane brings D records (round 5: one; round 6: two -- what a
+// round costs, two barriers and the book-keeping, is paid once for 2048 records):
 //   1   every record takes a ticket of its sub-bucket (one LDS atomic; the tickets start at the records already waiting)
 //   1.5 LANE i KEEPS THE BOOKS OF SUB-BUCKET i (round 6; round 5: the lane that drew the sub-bucket's first new ticket -- about 40 of a
 //       wave's 64 lanes, in every wave, once per 1024 records): complete groups of this round, room in the open chunk, new chunks
@@ -457,13 +458,14 @@ __device__ unsigned long long g_l2_log_cap = 0;
 #define SDT_SK_L2S_WGS 1          // workgroups per CU the staged level-2 scatter is compiled for (2: 64 registers per lane)
 #endif
 #ifndef SDT_SK_L2S_RPL
-#define SDT_SK_L2S_RPL 1          // records per lane and round (2 and 4 were SLOWER: split 54.6 -> 69.2 / 97.6 ms at C3, profiles/r6 -- more records per
-                                  // round mean more sub-buckets that need several new chunks at once, and those ids come from ONE global counter)
+#define SDT_SK_L2S_RPL 2          // records per lane and round (1-word keys; 2-word keys: at most 2; 4-word keys: 1 -- a record is 56 bytes of registers).
+                                  // C3: split 50.8 (1) -> 44.8 ms (2); before the runs of chunk ids came out of the workgroup's block (sk_alloc_chunks)
+                                  // 2 and 4 were SLOWER (69 / 98 ms against 54.6): more records per round = more sub-buckets that need a run of chunks
 #endif
 template <int NW> struct SkL2Stage {
 	static constexpr int S = NW == 1 ? SDT_SK_L2S_S1 : 2;            // records per group
 	static constexpr int GPC = SK_CAP2 / S;                          // groups per chunk
-	static constexpr int RPL = NW <= 2 ? SDT_SK_L2S_RPL : 1;         // records per lane and round
+	static constexpr int RPL = NW == 1 ? SDT_SK_L2S_RPL : (NW == 2 ? (SDT_SK_L2S_RPL < 2 ? SDT_SK_L2S_RPL : 2) : 1);      // records per lane and round
 	static constexpr size_t SMEM = (size_t)SK_NB2 * S * SkFmt<NW>::REC_WORDS * 8;
 };
 
@@ -497,9 +499,9 @@ __global__ __launch_bounds__(SK_L2S_TPB, SDT_SK_L2S_WGS) void k_sk_scatter_recor
 		s_blk = 0;
 	__syncthreads();
 	uint32_t failed = 0;
-	// n chunk ids (contiguous): one out of the workgroup's block, more straight from the pool; SK_NOCHUNK: the pool is exhausted
+	// n chunk ids (contiguous) out of the workgroup's block of ids; SK_NOCHUNK: the pool is exhausted
 	auto alloc = [&](uint32_t n) -> uint32_t {
-		const uint32_t id = n == 1 ? sk_alloc_chunk(&s_blk, dst, SK_BLK2) : atomicAdd(dst.next, n);
+		const uint32_t id = sk_alloc_chunks(&s_blk, dst, n, SK_BLK2);
 		return id < dst.chunks && id + n <= dst.chunks ? id : SK_NOCHUNK;
 	};
 	// slot of record `t` (ticket) of a sub-bucket whose open chunk had `used` groups in use before: in the open chunk while it lasts,

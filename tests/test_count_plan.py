@@ -10,7 +10,7 @@ import pytest
 
 import __graft_entry__ as ge
 
-PACK, ITEM, WHOLE, SPAN, L2 = 64, 1024, 0x80000000, 64, 1024
+PACK, ITEM, WHOLE, SPAN, L2 = 64, 2048, 0x80000000, 64, 1024        # (ITEM: SK_COUNT_ITEM_CHUNKS of csrc/sdt_pipeline.hpp, 2048 since round 6)
 
 
 def _lists(rng, nb, kind):
@@ -94,7 +94,7 @@ def test_every_chunk_in_exactly_one_item(kind, first_limit, limit):
 
 def test_small_neighbours_share_an_item_and_big_ones_do_not():
     pkg = ge.load_package()
-    n = np.array([3, 0, 5, 0, 0, 7, 60, 2, 2000, 1, 1], dtype=np.int64)
+    n = np.array([3, 0, 5, 0, 0, 7, 60, 2, 4000, 1, 1], dtype=np.int64)
     off = np.zeros(len(n) + 1, dtype=np.uint32)
     off[1:] = np.cumsum(n)
     kp = (off.astype(np.uint64) * np.uint64(100))
@@ -102,9 +102,9 @@ def test_small_neighbours_share_an_item_and_big_ones_do_not():
     got = [(int(a), int(b & 0x7FFFFFFF), bool(b & WHOLE)) for a, b, _, _ in items]
     assert [(int(x), int(y)) for _, _, x, y in items] == [(8, 8), (8, 8), (6, 7), (0, 5), (9, 10)]
     # 3 + 5 + 7 = 15 chunks share the first item; 60 more would make 75 > 64: its own item, which 2 more (62) may join;
-    # the 2000-chunk bucket is cut in two pieces, not flagged; the two single chunks behind it share the last item
-    # (handed out largest first: 1024 and 976 chunks, then 62, 15, 2)
-    assert got == [(77, 1101, False), (1101, 2077, False), (15, 77, True), (0, 15, True), (2077, 2079, True)]
+    # the 4000-chunk bucket is cut in two pieces, not flagged; the two single chunks behind it share the last item
+    # (handed out largest first: 2048 and 1952 chunks, then 62, 15, 2)
+    assert got == [(77, 2125, False), (2125, 4077, False), (15, 77, True), (0, 15, True), (4077, 4079, True)]
     assert len(lk) == 1 and int(lk[0]) == int(kp[-1])
 
 

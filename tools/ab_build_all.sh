@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../soapdenovo-trans_amd/csrc"
 mkdir -p ../../gpurun_ab /tmp/ab_$1
 NAME=$1; FLAGS=$2
-for f in sdt_gpu sdt_gpu_graph sdt_mem sdt_scatter_seq_a sdt_scatter_seq_b sdt_scatter_seq_c sdt_scatter_seq_d; do
+for f in sdt_gpu sdt_pipeline sdt_sharded sdt_pass2 sdt_mapstage sdt_gpu_graph sdt_mem sdt_scatter_seq_a sdt_scatter_seq_b sdt_scatter_seq_c sdt_scatter_seq_d; do
   hipcc -DSDT_TUNING $FLAGS -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -c -o /tmp/ab_$NAME/$f.o $f.hip &
 done
 wait
