@@ -38,7 +38,11 @@ namespace sdt {
 
 constexpr int SK_POSBITS = 22 - SK_L2BITS;          // header: level-2 bucket and position share 22 bits
 constexpr int SK_CAP1 = 32;                      // records per level-1 chunk
-constexpr int SK_CAP2 = 16;                      // records per level-2 chunk
+#ifndef SDT_SK_CAP2
+#define SDT_SK_CAP2 16
+#endif
+constexpr int SK_CAP2 = SDT_SK_CAP2;             // records per level-2 chunk (16 or 32: the fill of a chunk rides in the top bits of its list entry)
+static_assert(SK_CAP2 == 16 || SK_CAP2 == 32, "a level-2 chunk holds 16 or 32 records");
 constexpr uint32_t SK_NOCHUNK = 0xFFFFFFFFu;
 constexpr int SK_MAX_RUN = 64;                   // k-mers per record (6-bit field holds n - 1)
 

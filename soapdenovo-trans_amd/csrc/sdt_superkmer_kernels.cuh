@@ -71,7 +71,7 @@ template <int NW, bool TRACK> struct SkCntGeo {
 #define SDT_SK_L2S_TPB 1024
 #endif
 constexpr int SK_L2S_TPB = SDT_SK_L2S_TPB;
-constexpr int SK_LIST2_FILL_SHIFT = 28;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
+constexpr int SK_LIST2_FILL_SHIFT = SK_CAP2 == 16 ? 28 : 27;           // list2 entry = chunk id (28 bits) | (records in use - 1) << 28 (SK_CAP2 = 16: four bits)
 
 #include "sdt_sk_scatter_seq.cuh"      // chunk reservation helpers + the one-lane-per-read level-1 scatter (own header: its
                                         // many instantiations are compiled in translation units of their own)
