@@ -70,6 +70,21 @@ def test_multi_rank_reader_parses_every_chunk_once_and_agrees_on_ordinals(pkg, t
         assert r.stdout.startswith("ordinals OK"), r.stdout
 
 
+def test_multi_rank_reader_clean_under_sanitizers(pkg, tmp_path):
+    """the reader with foreign chunks skipped and the ordinal arithmetic (seqio.c, readstream.c) under AddressSanitizer + UBSan (CPU build: the
+    GPU pool has no ASan): paired files, 3 and 8 ranks, chunks of a few records"""
+    info = gu.load_case("pe150_k31_p8")
+    cfg = materialise(info, tmp_path)
+    host = os.path.join(pkg.CSRC_DIR, "host")
+    exe = str(tmp_path / "readdump-asan")
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-Wall", "-Wextra", "-pthread", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", exe] +
+                   [os.path.join(host, f) for f in ("sdt_readdump.c", "libcfg.c", "seqio.c", "readstream.c")], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    for nranks in (3, 8):
+        r = subprocess.run([exe, "--ordinals", str(nranks), cfg, "4", "3000"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0 and r.stdout.startswith("ordinals OK"), r.stdout + r.stderr[-2000:]
+
+
 def test_multi_rank_reader_ordinals_with_empty_files_and_several_libraries(pkg, tmp_path):
     """the ordinal arithmetic across files: a pair whose second file is empty, a pair whose first file is empty, single files between
     them, two libraries (a file without a record yields no chunk: the arithmetic never sees it)"""
